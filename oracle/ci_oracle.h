@@ -1,0 +1,160 @@
+/*
+ * ci_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C float64 restatement of the Gibbs hot path behind
+ * causalimpact.fit_causalimpact():
+ *   /root/reference/causalimpact/causalimpact_lib.py:345-395  (_run_gibbs_sampler)
+ *   /root/reference/causalimpact/causalimpact_lib.py:398-500  (priors)
+ *   /root/reference/causalimpact/causalimpact_lib.py:609-632  (predictive draws)
+ * The arithmetic the reference delegates to lives in the un-vendored, un-pinned
+ * third-party dependency `tensorflow-probability` (pyproject.toml:22):
+ *   tfp.experimental.sts_gibbs.gibbs_sampler.{fit_with_gibbs_sampling,
+ *   _resample_latents,_resample_scale,one_step_predictive},
+ *   tfp.experimental.sts_gibbs.spike_and_slab.SpikeSlabSampler,
+ *   tfd.LinearGaussianStateSpaceModel.posterior_sample (Durbin-Koopman),
+ *   tfp.sts.{LocalLevel,LocalLinearTrend,Seasonal(constrained)}.
+ * This file restates their published algorithms (Durbin & Koopman 2002;
+ * Scott & Varian 2013 eq. 8; TFP source as recalled -- see DESIGN.md "Oracle").
+ *
+ * PARITY STATUS: TFP cannot be imported here, and the reference holds no golden
+ * vectors for the sampler, so per-draw parity with TFP's RNG streams is
+ * UNPINNED.  What pins this oracle:
+ *   (1) TFP-independent exact maths (dense Gaussian posterior / log-lik,
+ *       exhaustive 2^P spike-slab enumeration, inverse-gamma KS tests):
+ *       tests/test_oracle_math.py;
+ *   (2) the reference's own statistical tolerance tests
+ *       (causalimpact_lib_test.py:242-271,319-338,361-379,504-535,655-773):
+ *       tests/test_reference_stat_pins.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product path never does.
+ *
+ * Randomness is a *specified* counter-based stream (Philox4x32-10) shared with
+ * the HIP kernels so that kernel and oracle consume identical random numbers:
+ *   key     = (seed0, seed1)
+ *   counter = (call_index, site | (sub << 8), iteration, chain)
+ * One Philox call yields 4 uniforms / 4 Box-Muller normals (components 0..3);
+ * element `idx` of a site lives in call idx>>2, component idx&3.
+ */
+#ifndef CI_ORACLE_H_
+#define CI_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CI_MAX_D 40        /* max state dimension handled by the oracle */
+#define CI_MAX_BLOCKS 8    /* max seasonal blocks */
+
+/* RNG sites (shared with the HIP kernels: csrc/ci_rng.h). */
+enum {
+  CI_SITE_PERM = 1,        /* uniforms for the feature-visit permutation */
+  CI_SITE_FLIP = 2,        /* uniforms for the inclusion flips */
+  CI_SITE_OBSVAR = 3,      /* gamma attempts: sigma^2_obs (spike-slab branch) */
+  CI_SITE_WEIGHTS = 4,     /* normals for the weights draw */
+  CI_SITE_PRIOR_INIT = 5,  /* normals: DK prior initial state */
+  CI_SITE_PRIOR_LEVEL = 6, /* normals: DK level disturbances */
+  CI_SITE_PRIOR_SLOPE = 7, /* normals: DK slope disturbances */
+  CI_SITE_PRIOR_OBS = 8,   /* normals: DK observation noise */
+  CI_SITE_PRIOR_SEAS = 9,  /* normals: DK seasonal drift (sub = block) */
+  CI_SITE_LEVEL_SCALE = 10,
+  CI_SITE_SLOPE_SCALE = 11,
+  CI_SITE_DRIFT_SCALE = 12, /* sub = block */
+  CI_SITE_OBS_SCALE = 13,   /* gamma attempts: sigma_obs (no-regression branch) */
+  CI_SITE_PRED = 14         /* normals: posterior-predictive noise */
+};
+
+typedef struct {
+  /* sizes */
+  int32_t T;            /* time steps fed to the sampler (pre + after-pre) */
+  int32_t P;            /* design columns incl. intercept; 0 = no regression */
+  int32_t has_slope;    /* 0 = LocalLevel, 1 = LocalLinearTrend */
+  int32_t num_blocks;   /* seasonal blocks K */
+  int32_t num_seasons[CI_MAX_BLOCKS];
+  int32_t num_warmup;   /* W */
+  int32_t num_results;  /* S */
+  uint32_t seed[2];
+  int32_t chain;        /* global chain id (RNG counter word 3) */
+  int32_t reserved;
+  /* data (caller owned) */
+  const double* y;               /* [T]; ignored where mask != 0 */
+  const uint8_t* mask;           /* [T]; 1 = missing */
+  const double* X;               /* [T*P] row-major, intercept last */
+  const uint8_t* season_change;  /* [K*T]; 1 if t -> t+1 changes season in block k */
+  /* priors (causalimpact_lib.py:424-489) */
+  double level_conc, level_scale, level_ub;     /* IG on sigma^2_level, clip on sigma */
+  double slope_conc, slope_scale, slope_ub;     /* IG on sigma^2_slope (LLT only) */
+  double obs_conc, obs_scale, obs_ub;           /* IG on sigma^2_obs */
+  double drift_conc, drift_scale, drift_ub;     /* IG on sigma^2_drift (all blocks) */
+  double nonzero_prob;                          /* pi = min(1, 3/P) */
+  double init_level_loc, init_level_scale;      /* N(y[0], sd) */
+  double init_slope_scale;                      /* N(0, .) (LLT only) */
+  double init_seasonal_scale;                   /* N(0, sd) per effect */
+  /* initial Gibbs state (causalimpact_lib.py:566-581) */
+  double obs_scale0, level_scale0, slope_scale0, drift_scale0[CI_MAX_BLOCKS];
+} ci_oracle_problem;
+
+typedef struct {
+  /* all caller-allocated; any pointer may be NULL to skip that output */
+  double* obs_scale;     /* [S] */
+  double* level_scale;   /* [S] */
+  double* slope_scale;   /* [S] */
+  double* drift_scales;  /* [S*K] */
+  double* weights;       /* [S*P] */
+  double* level;         /* [S*T] */
+  double* slope;         /* [S*T] */
+  double* seasonal;      /* [S*T*K]  0-th latent of each block */
+  double* pred_mean;     /* [T]      mean over draws of the noise-free predictor */
+  double* trajectories;  /* [S*T]    posterior-predictive draws */
+  int32_t* nonzeros;     /* [S*P]    inclusion indicators (diagnostic) */
+} ci_oracle_outputs;
+
+/* Full Gibbs fit for one chain.  Returns 0 on success. */
+int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out);
+
+/* ---- building blocks exposed for the unit tests ---- */
+void ci_oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double ci_oracle_uniform(const uint32_t seed[2], uint32_t chain, uint32_t iter,
+                         uint32_t site, uint32_t sub, uint32_t idx);
+double ci_oracle_normal(const uint32_t seed[2], uint32_t chain, uint32_t iter,
+                        uint32_t site, uint32_t sub, uint32_t idx);
+/* Gamma(alpha, 1) by Marsaglia-Tsang with indexed attempts. */
+double ci_oracle_gamma(double alpha, const uint32_t seed[2], uint32_t chain,
+                       uint32_t iter, uint32_t site, uint32_t sub);
+
+/* State-space description used by the filter/smoother helpers. */
+typedef struct {
+  int32_t T, d, has_slope, num_blocks;
+  int32_t num_seasons[CI_MAX_BLOCKS];
+  const uint8_t* mask;
+  const uint8_t* season_change;
+  double obs_scale, level_scale, slope_scale, drift_scale[CI_MAX_BLOCKS];
+  double init_level_loc, init_level_scale, init_slope_scale, init_seasonal_scale;
+} ci_oracle_ssm;
+
+int ci_oracle_state_dim(int has_slope, int num_blocks, const int32_t* num_seasons);
+
+/* Kalman filter log-likelihood of data[T] (masked steps skipped). */
+double ci_oracle_kalman_loglik(const ci_oracle_ssm* m, const double* data);
+
+/* Smoothed state means E[x_t | data]; out is [T*d]. */
+void ci_oracle_smoothed_mean(const ci_oracle_ssm* m, const double* data, double* out);
+
+/* One Durbin-Koopman posterior draw of the latents given data[T];
+ * normals come from the spec'd stream (seed, chain, iter). out is [T*d]. */
+void ci_oracle_dk_draw(const ci_oracle_ssm* m, const double* data,
+                       const uint32_t seed[2], uint32_t chain, uint32_t iter,
+                       double* out);
+
+/* Collapsed spike-and-slab log posterior of an inclusion pattern
+ * (Scott & Varian 2013 eq. 8 as TFP states it). */
+double ci_oracle_spike_slab_logp(int P, const double* xtx, const double* prior_prec,
+                                 const double* xty, double yty, const uint8_t* nonzeros,
+                                 double nonzero_prob, double post_conc, double prior_scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* CI_ORACLE_H_ */

@@ -1,0 +1,13 @@
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "tfp-causalimpact_amd")
+if PKG not in sys.path:
+  sys.path.insert(0, PKG)
+
+
+def pytest_configure(config):
+  config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

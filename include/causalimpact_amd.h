@@ -1,0 +1,132 @@
+/*
+ * causalimpact_amd.h -- C-ABI of the MI355X-native CausalImpact hot path.
+ *
+ * The reference (google/tfp-causalimpact) has no FFI: its hot path is the
+ * Python call
+ *     _train_causalimpact_sts(...)            causalimpact/causalimpact_lib.py:503-606
+ *       -> _run_gibbs_sampler(...)            causalimpact/causalimpact_lib.py:345-395
+ *            gibbs_sampler.fit_with_gibbs_sampling(...)          :365-388
+ *            _get_posterior_means_and_trajectories(...)          :609-632
+ * into TensorFlow-Probability.  This header is the boundary a maintainer would
+ * bind instead (ctypes stub: INTEGRATION.md).  Plain pointers and sizes only;
+ * the caller owns every host buffer; the library keeps no caller pointers after
+ * a call returns.  All entry points return 0 on success, non-zero on error;
+ * ci_last_error() then describes the failure (thread-local string).
+ *
+ * Shapes use the reference's names:  T = time steps handed to the sampler
+ * (pre-period + everything after it, causalimpact_lib.py:548-562), P = design
+ * columns incl. the trailing intercept (data.py:135), K = seasonal blocks,
+ * W/S = warm-up / retained Gibbs iterations, C = chains, B = independent series.
+ */
+#ifndef CAUSALIMPACT_AMD_H_
+#define CAUSALIMPACT_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CI_ABI_VERSION 1
+#define CI_MAX_BLOCKS 8
+
+/* Per-series priors and initial Gibbs state.  One per series because every
+ * constant scales with that series' outcome_sd.
+ * Replaces the prior objects built in _build_default_gibbs_model
+ * (causalimpact_lib.py:424-489) and the initial GibbsSamplerState
+ * (causalimpact_lib.py:566-581, :370-383). */
+typedef struct ci_series_params {
+  double level_conc, level_scale, level_ub;   /* IG(sigma^2_level); clip on sigma   :424-432 */
+  double slope_conc, slope_scale, slope_ub;   /* IG(sigma^2_slope) (LocalLinearTrend only) */
+  double obs_conc, obs_scale, obs_ub;         /* IG(sigma^2_obs); upper bound        :434-443 */
+  double drift_conc, drift_scale, drift_ub;   /* IG(sigma^2_drift), all blocks       :472-474 */
+  double nonzero_prob;                        /* min(1, 3/P)                         :449-450 */
+  double init_level_loc, init_level_scale;    /* N(y[0], sd)                         :467-469 */
+  double init_slope_scale;                    /* N(0, .)  (LocalLinearTrend only) */
+  double init_seasonal_scale;                 /* N(0, sd)                            :489     */
+  double obs_scale0, level_scale0, slope_scale0;  /* initial state                   :566-572 */
+  double drift_scale0[CI_MAX_BLOCKS];             /*                                 :573-574 */
+} ci_series_params;
+
+/* The sampler's static configuration == the non-tensor arguments of
+ * _run_gibbs_sampler (causalimpact_lib.py:346-353) plus the batch extensions
+ * BASELINE.json asks for (chains, series). */
+typedef struct ci_problem {
+  int32_t abi_version;          /* CI_ABI_VERSION */
+  int32_t T, P;
+  int32_t has_slope;            /* 0 LocalLevel (reference default), 1 LocalLinearTrend */
+  int32_t num_blocks;           /* K seasonal blocks */
+  int32_t num_seasons[CI_MAX_BLOCKS];
+  int32_t num_warmup;           /* W   InferenceOptions.num_warmup_steps :215-220 */
+  int32_t num_results;          /* S   InferenceOptions.num_results */
+  int32_t num_chains;           /* C chains run by THIS call (per series) */
+  int32_t chain_offset;         /* global id of this call's first chain: results do not
+                                   depend on how chains are split over devices */
+  int32_t num_series;           /* B */
+  uint32_t seed[2];             /* sanitized seed pair (int s -> (0,s)) :535-543 */
+  int32_t device;               /* HIP device ordinal */
+  int32_t reserved;
+} ci_problem;
+
+/* Caller-allocated result buffers (float32, chain-major so per-device shards
+ * are contiguous).  == GibbsSamplerState stack + (means, trajectories) returned
+ * at causalimpact_lib.py:395.  Any pointer may be NULL to skip that output. */
+typedef struct ci_outputs {
+  float* observation_noise_scale;  /* [B,C,S]   */
+  float* level_scale;              /* [B,C,S]   */
+  float* slope_scale;              /* [B,C,S]   */
+  float* seasonal_drift_scales;    /* [B,C,S,K] */
+  float* weights;                  /* [B,C,S,P] */
+  float* level;                    /* [B,C,S,T] */
+  float* slope;                    /* [B,C,S,T] */
+  float* seasonal_levels;          /* [B,C,S,T,K]  0-th latent of each block (:312-317) */
+  float* posterior_means;          /* [B,C,T]   per-chain mean of the noise-free predictor (:627) */
+  float* posterior_trajectories;   /* [B,C,S,T] (:629-631) */
+} ci_outputs;
+
+typedef struct ci_session ci_session;  /* device-resident fit: inputs + outputs live in HBM */
+
+const char* ci_last_error(void);
+int ci_abi_version(void);
+int ci_device_count(int* count);
+
+/* One-shot: upload, run all W+S Gibbs iterations for B*C chains, download.
+ *   y     [B,T]    float32 outcome (standardised); value ignored where mask != 0
+ *   mask  [B,T]    uint8, 1 = missing (NaN pre-period steps + the whole after-pre period)
+ *   X     [B,T,P]  float32 row-major design, intercept last; NULL when P == 0
+ *   season_change [K,T] uint8, 1 where step t is the last step of a season of block k
+ *   params[B]
+ * Replaces _run_gibbs_sampler (causalimpact_lib.py:345-395). */
+int ci_fit_gibbs(const ci_problem* problem, const float* y, const uint8_t* mask, const float* X,
+                 const uint8_t* season_change, const ci_series_params* params,
+                 ci_outputs* outputs);
+
+/* Device-resident variant (what bench.py times: inputs already in HBM). */
+int ci_session_create(const ci_problem* problem, const float* y, const uint8_t* mask,
+                      const float* X, const uint8_t* season_change,
+                      const ci_series_params* params, ci_session** session);
+/* Runs the fit on the session's stream and waits for it.  kernel_ms (optional)
+ * receives the Gibbs kernel's duration measured with HIP events on that stream. */
+int ci_session_run(ci_session* session, float* kernel_ms);
+int ci_session_fetch(ci_session* session, ci_outputs* outputs);
+/* Bytes the kernel must move per run (algorithmic bytes, DESIGN.md "Roofline"). */
+int ci_session_algorithmic_bytes(const ci_session* session, double* bytes);
+int ci_session_destroy(ci_session* session);
+
+/* ---- component entry points used by the parity tests (tests/test_gpu_*.py) ---- */
+/* normals/uniforms/gammas of the specified Philox stream, computed on device. */
+int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t iter, uint32_t site,
+                uint32_t sub, int32_t n, float* uniforms, float* normals, double alpha,
+                double* gamma_draw);
+/* One Durbin-Koopman draw of the latent path given residuals and scales
+ * (LinearGaussianStateSpaceModel.posterior_sample as reached from
+ * gibbs_sampler._resample_latents).  out_latents is [T, d] float32. */
+int ci_test_dk_draw(const ci_problem* problem, const ci_series_params* params,
+                    const float* resid, const uint8_t* mask, const uint8_t* season_change,
+                    double obs_scale, double level_scale, double slope_scale,
+                    const double* drift_scales, uint32_t iter, float* out_latents);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* CAUSALIMPACT_AMD_H_ */

@@ -1,0 +1,81 @@
+"""GPU parity of the kernel building blocks against the float64 CPU oracle.
+
+Everything goes through the C-ABI (include/causalimpact_amd.h).  Tolerances are
+float32-vs-float64 tolerances on identical specified random numbers, stated per test.
+"""
+import numpy as np
+import pytest
+
+from causalimpact import _native
+from oracle import ci_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_loaded_and_device_present():
+  assert _native.device_count() >= 1
+
+
+@pytest.mark.parametrize("site,sub", [(2, 0), (6, 0), (9, 3), (14, 0)])
+def test_rng_stream_matches_oracle(site, sub):
+  seed, chain, it, n = (123, 456), 5, 17, 256
+  u, z1, z4, g = _native.test_rng(seed, chain, it, site, sub, n, alpha=40.5)
+  uo = np.array([orc.uniform(seed, chain, it, site, sub, i) for i in range(n)])
+  zo = np.array([orc.normal(seed, chain, it, site, sub, i) for i in range(n)])
+  np.testing.assert_allclose(u, uo, atol=1e-7)           # float32 rounding of a float64 uniform
+  np.testing.assert_allclose(z1, zo, atol=3e-5)          # f32 Box-Muller vs f64 Box-Muller
+  np.testing.assert_array_equal(z1, z4)                  # 1-wide and 4-wide paths are one stream
+  np.testing.assert_allclose(g, orc.gamma(40.5, seed, chain, it, site, sub), rtol=1e-12)
+
+
+@pytest.mark.parametrize("alpha", [0.3, 1.0, 16.0, 366.0, 5012.5])
+def test_gamma_draws_match_oracle(alpha):
+  seed = (9, 8)
+  for it in range(6):
+    _, _, _, g = _native.test_rng(seed, 2, it, 3, 0, 4, alpha=alpha)
+    np.testing.assert_allclose(g, orc.gamma(alpha, seed, 2, it, 3, 0), rtol=1e-11)
+
+
+def _dk_case(T, has_slope, seed=(7, 11)):
+  rng = np.random.default_rng(T + has_slope)
+  resid = (rng.normal(size=T).cumsum() * 0.05 + rng.normal(size=T) * 0.4).astype(np.float32)
+  mask = np.zeros(T, bool)
+  mask[[1, 3, 7]] = True
+  mask[int(0.7 * T):] = True
+  spec = orc.default_spec(resid.astype(np.float64), mask, None, has_slope=bool(has_slope),
+                          outcome_sd=1.0)
+  return resid, mask, spec, seed
+
+
+@pytest.mark.parametrize("has_slope", [0, 1])
+@pytest.mark.parametrize("T", [37, 100, 300, 1000, 2000, 4000])
+def test_dk_draw_matches_oracle(T, has_slope):
+  resid, mask, spec, seed = _dk_case(T, has_slope)
+  obs, lvl, slp = 0.45, 0.03, 0.004 if has_slope else 0.0
+  pb = _native.make_problem(T=T, P=0, has_slope=has_slope, num_warmup=0, num_results=1,
+                            seed=seed, chain_offset=3)
+  params = _native.make_params([spec])
+  got = _native.test_dk_draw(pb, params, resid, mask, obs, lvl, slp, it=5)
+  ssm = orc.make_ssm(spec, mask, obs_scale=obs, level_scale=lvl, slope_scale=slp)
+  want = orc.dk_draw(ssm, np.where(mask, 0.0, resid.astype(np.float64)), seed, chain=3, it=5)
+  # float32 scans over <= 4096 steps vs float64 sequential recursions: 2e-3 absolute on the
+  # O(1) fitted part plus 3e-4 relative, because a local-linear-trend forecast hundreds of
+  # masked steps ahead reaches |level| ~ 1e2 (slope noise integrates twice).
+  err = np.abs(got - want)
+  assert np.isfinite(got).all()
+  tol = 2e-3 + 3e-4 * np.abs(want)
+  assert (err <= tol).all(), (err / tol).max()
+
+
+def test_dk_draw_observed_everywhere_and_strong_signal():
+  # no missing data, large signal-to-noise: exercises the update branch at every step
+  T = 513
+  rng = np.random.default_rng(5)
+  resid = rng.normal(size=T).cumsum().astype(np.float32)
+  mask = np.zeros(T, bool)
+  spec = orc.default_spec(resid.astype(np.float64), mask, None, has_slope=True, outcome_sd=1.0)
+  pb = _native.make_problem(T=T, P=0, has_slope=1, num_warmup=0, num_results=1, seed=(1, 2))
+  got = _native.test_dk_draw(pb, _native.make_params([spec]), resid, mask, 0.1, 1.0, 0.2, it=0)
+  ssm = orc.make_ssm(spec, mask, obs_scale=0.1, level_scale=1.0, slope_scale=0.2)
+  want = orc.dk_draw(ssm, resid.astype(np.float64), (1, 2), chain=0, it=0)
+  assert np.abs(got - want).max() < 5e-3 * max(1.0, np.abs(want).max())

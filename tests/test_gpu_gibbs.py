@@ -1,0 +1,105 @@
+"""GPU parity of the full Gibbs fit (through the C-ABI) against the float64 CPU oracle.
+
+Two kinds of checks:
+  * per-draw: with the specified Philox stream the kernel and the oracle consume the same
+    random numbers, so the first iterations agree to float32 accuracy (tolerance 5e-3 on
+    O(1) quantities; discrete inclusion decisions must be identical);
+  * posterior summaries over long runs agree within Monte-Carlo error.
+"""
+import numpy as np
+import pytest
+
+from causalimpact import _native
+from causalimpact import _synthetic as syn
+from oracle import ci_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit_both(T, p, has_slope, W, S, C=1, seed=(5, 9), data_seed=0, chain_offset=0):
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, data_seed)
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope))
+  P = spec["P"]
+  pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_warmup=W, num_results=S,
+                            num_chains=C, chain_offset=chain_offset, seed=seed)
+  got = _native.fit_gibbs(pb, y[None], mask[None], None if X is None else X[None], None,
+                          _native.make_params([spec]))
+  want = [orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=seed,
+                        chain=chain_offset + c) for c in range(C)]
+  return got, want, spec
+
+
+@pytest.mark.parametrize("T,p,has_slope", [
+    (100, 1, 0),    # reference default model, P=2 => every feature always included
+    (100, 0, 0),    # no covariates: sigma_obs from the conjugate draw
+    (300, 4, 1),    # P=5 => pi=0.6, inclusion flips, local linear trend
+    (1000, 10, 1),  # BASELINE cfg2 shape
+    (700, 10, 0),   # L=4 with padding, local level
+])
+def test_first_iterations_match_oracle_per_draw(T, p, has_slope):
+  S = 4
+  got, want, spec = _fit_both(T, p, has_slope, W=0, S=S)
+  w = want[0]
+  P = spec["P"]
+  for name, key in [("observation_noise_scale", "obs_scale"), ("level_scale", "level_scale")]:
+    np.testing.assert_allclose(got[name][0, 0], w[key], rtol=5e-3, err_msg=name)
+  if has_slope:
+    np.testing.assert_allclose(got["slope_scale"][0, 0], w["slope_scale"], rtol=5e-3)
+    np.testing.assert_allclose(got["slope"][0, 0], w["slope"], atol=5e-3)
+  if P:
+    np.testing.assert_array_equal(got["weights"][0, 0] != 0, w["weights"] != 0)
+    np.testing.assert_allclose(got["weights"][0, 0], w["weights"], atol=5e-3)
+  np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=5e-3)
+  np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
+  np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=5e-3)
+
+
+def test_chain_ids_do_not_depend_on_launch_split():
+  # chains 0..3 in one call == chains {0,1} and {2,3} in two calls (multi-GPU sharding rule)
+  T, p = 200, 3
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 3)
+  spec = orc.default_spec(y, mask, X)
+  params = _native.make_params([spec])
+  def run(C, off):
+    pb = _native.make_problem(T=T, P=spec["P"], has_slope=0, num_warmup=3, num_results=5,
+                              num_chains=C, chain_offset=off, seed=(1, 1))
+    return _native.fit_gibbs(pb, y[None], mask[None], X[None], None, params)
+  whole, lo, hi = run(4, 0), run(2, 0), run(2, 2)
+  for k in ("level", "weights", "observation_noise_scale", "posterior_trajectories"):
+    np.testing.assert_array_equal(whole[k][0, :2], lo[k][0])
+    np.testing.assert_array_equal(whole[k][0, 2:], hi[k][0])
+  assert not np.array_equal(whole["level"][0, 0], whole["level"][0, 1])
+
+
+def test_posterior_summaries_match_oracle_long_run():
+  T, p, W, S, C = 200, 4, 150, 600, 4
+  got, want, spec = _fit_both(T, p, 1, W, S, C=C, seed=(21, 4), data_seed=2)
+  def pooled(key):
+    return np.concatenate([w[key] for w in want], axis=0)
+  for name, key in [("observation_noise_scale", "obs_scale"), ("level_scale", "level_scale"),
+                    ("slope_scale", "slope_scale")]:
+    g, o = got[name][0].ravel(), pooled(key)
+    # north_star: posterior mean within 1 %; 3 % here covers MC error of 2400 correlated draws
+    assert abs(g.mean() / o.mean() - 1) < 0.03, (name, g.mean(), o.mean())
+  gw = got["weights"][0].reshape(-1, spec["P"])
+  ow = pooled("weights")
+  np.testing.assert_allclose(gw.mean(0), ow.mean(0), atol=0.02)
+  np.testing.assert_allclose((gw != 0).mean(0), (ow != 0).mean(0), atol=0.06)
+  gm = got["posterior_means"][0].mean(0)
+  om = np.mean([w["pred_mean"] for w in want], axis=0)
+  np.testing.assert_allclose(gm, om, atol=0.03)
+  gt = got["posterior_trajectories"][0].reshape(-1, T)
+  ot = pooled("trajectories")
+  post = slice(int(0.7 * T), T)
+  np.testing.assert_allclose(np.quantile(gt[:, post].mean(1), [0.025, 0.975]),
+                             np.quantile(ot[:, post].mean(1), [0.025, 0.975]), atol=0.03)
+
+
+def test_invariants_pinned_by_reference_tests():
+  # causalimpact_lib_test.py:335-338: no NaNs, sigma_obs <= 1.2, sigma_level <= 1 (sd = 1)
+  got, _, spec = _fit_both(91, 2, 0, W=100, S=10, seed=(1, 1))
+  assert np.isfinite(got["level"]).all() and np.isfinite(got["weights"]).all()
+  assert (got["observation_noise_scale"] <= 1.2 * spec["outcome_sd"] + 1e-6).all()
+  assert (got["level_scale"] <= spec["outcome_sd"] + 1e-6).all()
+  # :376-379  P <= 3 => no exactly-zero weights
+  assert (got["weights"] == 0).sum() == 0

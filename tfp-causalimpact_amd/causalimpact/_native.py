@@ -1,0 +1,246 @@
+"""ctypes binding of the C-ABI in include/causalimpact_amd.h.
+
+This is the only place the host package touches native code.  There is no CPU
+fallback: if lib/libcausalimpact_amd.so is missing or no MI355X is visible the
+calls raise (the reference's hot path, causalimpact_lib.py:345-395, is replaced
+by these entry points and by nothing else).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+ABI_VERSION = 1
+MAX_BLOCKS = 8
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libcausalimpact_amd.so")
+
+_PARAM_FIELDS = (
+    "level_conc", "level_scale", "level_ub", "slope_conc", "slope_scale", "slope_ub",
+    "obs_conc", "obs_scale", "obs_ub", "drift_conc", "drift_scale", "drift_ub",
+    "nonzero_prob", "init_level_loc", "init_level_scale", "init_slope_scale",
+    "init_seasonal_scale", "obs_scale0", "level_scale0", "slope_scale0")
+
+
+class SeriesParams(C.Structure):
+  _fields_ = [(f, C.c_double) for f in _PARAM_FIELDS] + [("drift_scale0", C.c_double * MAX_BLOCKS)]
+
+
+class Problem(C.Structure):
+  _fields_ = [
+      ("abi_version", C.c_int32), ("T", C.c_int32), ("P", C.c_int32), ("has_slope", C.c_int32),
+      ("num_blocks", C.c_int32), ("num_seasons", C.c_int32 * MAX_BLOCKS),
+      ("num_warmup", C.c_int32), ("num_results", C.c_int32), ("num_chains", C.c_int32),
+      ("chain_offset", C.c_int32), ("num_series", C.c_int32), ("seed", C.c_uint32 * 2),
+      ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+_OUT_FIELDS = ("observation_noise_scale", "level_scale", "slope_scale", "seasonal_drift_scales",
+               "weights", "level", "slope", "seasonal_levels", "posterior_means",
+               "posterior_trajectories")
+
+
+class Outputs(C.Structure):
+  _fields_ = [(f, C.c_void_p) for f in _OUT_FIELDS]
+
+
+class NativeError(RuntimeError):
+  pass
+
+
+_lib = None
+
+
+def load():
+  """Loads the HIP library; raises NativeError when it has not been built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise NativeError(
+        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(there is no CPU fallback for the Gibbs hot path)")
+  L = C.CDLL(LIB_PATH)
+  L.ci_last_error.restype = C.c_char_p
+  L.ci_abi_version.restype = C.c_int
+  L.ci_device_count.argtypes = [C.POINTER(C.c_int)]
+  L.ci_fit_gibbs.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.POINTER(SeriesParams), C.POINTER(Outputs)]
+  L.ci_session_create.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.POINTER(SeriesParams), C.POINTER(C.c_void_p)]
+  L.ci_session_run.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+  L.ci_session_fetch.argtypes = [C.c_void_p, C.POINTER(Outputs)]
+  L.ci_session_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+  L.ci_session_destroy.argtypes = [C.c_void_p]
+  L.ci_test_rng.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
+                            C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+  L.ci_test_dk_draw.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                C.c_uint32, C.c_void_p]
+  if L.ci_abi_version() != ABI_VERSION:
+    raise NativeError(f"ABI mismatch: library {L.ci_abi_version()}, binding {ABI_VERSION}")
+  _lib = L
+  return L
+
+
+def exported_symbols() -> Sequence[str]:
+  """Every entry point include/causalimpact_amd.h declares."""
+  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_fit_gibbs",
+          "ci_session_create", "ci_session_run", "ci_session_fetch",
+          "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_test_rng",
+          "ci_test_dk_draw")
+
+
+def _check(rc: int):
+  if rc != 0:
+    raise NativeError(load().ci_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+  n = C.c_int(0)
+  _check(load().ci_device_count(C.byref(n)))
+  return n.value
+
+
+def seed_pair(seed):
+  """int s -> (0, s); pairs pass through (causalimpact_lib.py:535-539)."""
+  if isinstance(seed, (int, np.integer)):
+    return (0, int(seed) & 0xFFFFFFFF)
+  a, b = seed
+  return (int(a) & 0xFFFFFFFF, int(b) & 0xFFFFFFFF)
+
+
+def make_params(specs: Sequence[Dict]) -> "C.Array":
+  arr = (SeriesParams * len(specs))()
+  for i, sp in enumerate(specs):
+    for f in _PARAM_FIELDS:
+      setattr(arr[i], f, float(sp[f]))
+    for k, v in enumerate(sp.get("drift_scale0", ())):
+      arr[i].drift_scale0[k] = float(v)
+  return arr
+
+
+def make_problem(*, T, P, has_slope, num_seasons=(), num_warmup, num_results, num_chains=1,
+                 chain_offset=0, num_series=1, seed=(0, 0), device=0) -> Problem:
+  pb = Problem()
+  pb.abi_version = ABI_VERSION
+  pb.T, pb.P, pb.has_slope = int(T), int(P), int(bool(has_slope))
+  pb.num_blocks = len(num_seasons)
+  for k, n in enumerate(num_seasons):
+    pb.num_seasons[k] = int(n)
+  pb.num_warmup, pb.num_results = int(num_warmup), int(num_results)
+  pb.num_chains, pb.chain_offset, pb.num_series = int(num_chains), int(chain_offset), int(num_series)
+  s = seed_pair(seed)
+  pb.seed[0], pb.seed[1] = s
+  pb.device = int(device)
+  return pb
+
+
+def _stage_inputs(pb: Problem, y, mask, X, season_change):
+  B, T, P, K = pb.num_series, pb.T, pb.P, pb.num_blocks
+  mask8 = np.ascontiguousarray(np.asarray(mask, dtype=bool).reshape(B, T).astype(np.uint8))
+  y32 = np.asarray(y, dtype=np.float32).reshape(B, T)
+  y32 = np.ascontiguousarray(np.where(mask8 != 0, np.float32(0), y32))
+  X32 = None
+  if P > 0:
+    X32 = np.ascontiguousarray(np.asarray(X, dtype=np.float32).reshape(B, T, P))
+  sc = None
+  if K > 0:
+    sc = np.ascontiguousarray(np.asarray(season_change, dtype=np.uint8).reshape(K, T))
+  return y32, mask8, X32, sc
+
+
+def _alloc_outputs(pb: Problem, want: Optional[Sequence[str]] = None):
+  B, C_, S, T, P, K = pb.num_series, pb.num_chains, pb.num_results, pb.T, pb.P, pb.num_blocks
+  shapes = dict(
+      observation_noise_scale=(B, C_, S), level_scale=(B, C_, S), slope_scale=(B, C_, S),
+      seasonal_drift_scales=(B, C_, S, K), weights=(B, C_, S, P), level=(B, C_, S, T),
+      slope=(B, C_, S, T), seasonal_levels=(B, C_, S, T, K), posterior_means=(B, C_, T),
+      posterior_trajectories=(B, C_, S, T))
+  out, arrs = Outputs(), {}
+  for name, shp in shapes.items():
+    if want is not None and name not in want:
+      continue
+    a = np.zeros(shp, dtype=np.float32)
+    arrs[name] = a
+    setattr(out, name, a.ctypes.data if a.size else None)
+  return out, arrs
+
+
+def _ptr(a):
+  return None if a is None else a.ctypes.data
+
+
+def fit_gibbs(pb: Problem, y, mask, X, season_change, params, want=None) -> Dict[str, np.ndarray]:
+  """One-shot upload -> W+S Gibbs iterations for B*C chains -> download."""
+  L = load()
+  y32, mask8, X32, sc = _stage_inputs(pb, y, mask, X, season_change)
+  out, arrs = _alloc_outputs(pb, want)
+  _check(L.ci_fit_gibbs(C.byref(pb), _ptr(y32), _ptr(mask8), _ptr(X32), _ptr(sc), params,
+                        C.byref(out)))
+  return arrs
+
+
+class Session:
+  """Device-resident fit (inputs and outputs live in HBM between run() calls)."""
+
+  def __init__(self, pb: Problem, y, mask, X, season_change, params):
+    self._lib = load()
+    self.pb = pb
+    y32, mask8, X32, sc = _stage_inputs(pb, y, mask, X, season_change)
+    self._h = C.c_void_p()
+    _check(self._lib.ci_session_create(C.byref(pb), _ptr(y32), _ptr(mask8), _ptr(X32), _ptr(sc),
+                                       params, C.byref(self._h)))
+
+  def run(self) -> float:
+    """Runs all W+S iterations; returns the Gibbs kernel's duration in ms (HIP events)."""
+    ms = C.c_float(0)
+    _check(self._lib.ci_session_run(self._h, C.byref(ms)))
+    return float(ms.value)
+
+  def fetch(self, want=None) -> Dict[str, np.ndarray]:
+    out, arrs = _alloc_outputs(self.pb, want)
+    _check(self._lib.ci_session_fetch(self._h, C.byref(out)))
+    return arrs
+
+  def algorithmic_bytes(self) -> float:
+    b = C.c_double(0)
+    _check(self._lib.ci_session_algorithmic_bytes(self._h, C.byref(b)))
+    return float(b.value)
+
+  def close(self):
+    if self._h:
+      self._lib.ci_session_destroy(self._h)
+      self._h = C.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
+def test_rng(seed, chain, it, site, sub, n, alpha, device=0):
+  L = load()
+  s = (C.c_uint32 * 2)(*seed_pair(seed))
+  u = np.zeros(n, np.float32)
+  z = np.zeros(2 * n, np.float32)
+  g = np.zeros(1, np.float64)
+  _check(L.ci_test_rng(device, s, chain, it, site, sub, n, u.ctypes.data, z.ctypes.data,
+                       float(alpha), g.ctypes.data))
+  return u, z[:n], z[n:], float(g[0])
+
+
+def test_dk_draw(pb: Problem, params, resid, mask, obs_scale, level_scale, slope_scale=0.0, it=0):
+  L = load()
+  T, D = pb.T, 2 if pb.has_slope else 1
+  r32 = np.ascontiguousarray(np.asarray(resid, np.float32))
+  m8 = np.ascontiguousarray(np.asarray(mask, bool).astype(np.uint8))
+  out = np.zeros((T, D), np.float32)
+  _check(L.ci_test_dk_draw(C.byref(pb), params, r32.ctypes.data, m8.ctypes.data, None,
+                           float(obs_scale), float(level_scale), float(slope_scale), None, int(it),
+                           out.ctypes.data))
+  return out

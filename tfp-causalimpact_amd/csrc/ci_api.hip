@@ -1,0 +1,400 @@
+// ci_api.hip -- C-ABI (include/causalimpact_amd.h) over the HIP kernels in ci_kernels.h.
+// Plain HIP runtime: no torch, no TensorFlow.  One ci_session == one device-resident fit.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/causalimpact_amd.h"
+#include "ci_kernels.h"
+
+// One object file per (D, L) instantiation (ci_inst.hip).
+#define CI_DECL(D, L)                                                                          \
+  extern "C" void* ci_gibbs_fn_d##D##_l##L(void);                                              \
+  extern "C" void ci_launch_dk_d##D##_l##L(int, const float*, const uint8_t*, float, float,    \
+                                           float, float, float, float, uint32_t, uint32_t,     \
+                                           uint32_t, uint32_t, float*);
+CI_DECL(1, 1) CI_DECL(1, 2) CI_DECL(1, 4) CI_DECL(1, 8) CI_DECL(1, 16)
+CI_DECL(2, 1) CI_DECL(2, 2) CI_DECL(2, 4) CI_DECL(2, 8) CI_DECL(2, 16)
+#undef CI_DECL
+
+namespace ci {
+// ------------------------------------------------------------------------------------
+// setup: X~'X~ (observed rows) and the weights-prior precision (all rows), float64.
+// causalimpact_lib.py:451-453; SpikeSlabSampler.__init__ (design rows at missing steps = 0).
+// One workgroup per series; thread (i, j) streams over T (coalesced over the
+// feature-major copy).
+// ------------------------------------------------------------------------------------
+static __global__ void setup_regression_kernel(int T, int P, const float* Xt, const uint8_t* mask,
+                                        double* xtx, double* omega) {
+  const int series = blockIdx.x;
+  const float* X = Xt + (size_t)series * P * T;
+  const uint8_t* m = mask + (size_t)series * T;
+  for (int e = threadIdx.x; e < P * P; e += blockDim.x) {
+    const int i = e / P, j = e % P;
+    double so = 0.0, sa = 0.0;
+    for (int t = 0; t < T; ++t) {
+      const double v = (double)X[(size_t)i * T + t] * (double)X[(size_t)j * T + t];
+      sa += v;
+      if (!m[t]) so += v;
+    }
+    xtx[(size_t)series * P * P + e] = so;
+    omega[(size_t)series * P * P + e] = 0.01 * (i == j ? sa : 0.5 * sa) / (double)T;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// component test kernels
+// ------------------------------------------------------------------------------------
+static __global__ void test_rng_kernel(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter,
+                                uint32_t site, uint32_t sub, int n, float* uni, float* nor,
+                                double alpha, double* gam) {
+  Rng g{k0, k1, chain};
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += blockDim.x) {
+    uni[i] = (float)uniform_d(g, iter, site, sub, (uint32_t)i);
+    float z[1];
+    fill_normals<1>(g, iter, site, sub, (uint32_t)i, z);
+    nor[i] = z[0];
+  }
+  if (tid < 64) {
+    const double v = gamma_wave(alpha, g, iter, site, sub, tid);
+    if (tid == 0) gam[0] = v;
+    // also exercise the 4-wide path: normals via fill_normals<4> must agree with <1>
+    float z4[4];
+    fill_normals<4>(g, iter, site, sub, (uint32_t)(tid * 4), z4);
+    for (int q = 0; q < 4; ++q)
+      if (tid * 4 + q < n) nor[n + tid * 4 + q] = z4[q];
+  }
+}
+
+
+}  // namespace ci
+
+namespace {
+using KernelFn = void (*)(ci::KArgs);
+KernelFn pick_kernel(int D, int L) {
+#define CI_CASE(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs_fn_d##DD##_l##LL();
+  CI_CASE(1, 1) CI_CASE(1, 2) CI_CASE(1, 4) CI_CASE(1, 8) CI_CASE(1, 16)
+  CI_CASE(2, 1) CI_CASE(2, 2) CI_CASE(2, 4) CI_CASE(2, 8) CI_CASE(2, 16)
+#undef CI_CASE
+  return nullptr;
+}
+}  // namespace
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <class T> struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+};
+
+
+
+int steps_per_thread(int T) {
+  for (int L = 1; L <= 16; L *= 2)
+    if (ci::NT * L >= T) return L;
+  return 0;
+}
+
+}  // namespace
+
+struct ci_session {
+  ci_problem pb;
+  int L = 0, x_in_lds = 0;
+  size_t lds_bytes = 0;
+  KernelFn fn = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DevBuf<float> y, Xt, o_obs, o_lscale, o_sscale, o_w, o_level, o_slope, o_pm, o_traj;
+  DevBuf<uint8_t> mask;
+  DevBuf<double> xtx, omega;
+  DevBuf<ci::DevSeriesParams> sp;
+};
+
+extern "C" {
+
+const char* ci_last_error(void) { return g_err.c_str(); }
+
+int ci_abi_version(void) { return CI_ABI_VERSION; }
+
+int ci_device_count(int* count) {
+  if (!count) return fail("count is NULL");
+  HIP_TRY(hipGetDeviceCount(count));
+  return 0;
+}
+
+static int validate(const ci_problem* pb) {
+  if (!pb) return fail("problem is NULL");
+  if (pb->abi_version != CI_ABI_VERSION)
+    return fail("ABI mismatch: caller %d, library %d", pb->abi_version, CI_ABI_VERSION);
+  if (pb->T < 3) return fail("T must be >= 3, got %d", pb->T);
+  if (pb->P < 0 || pb->P > ci::MAXP) return fail("P must be in [0, %d], got %d", ci::MAXP, pb->P);
+  if (pb->num_blocks != 0)
+    return fail("seasonal blocks are not implemented on the device path yet (num_blocks=%d)",
+                pb->num_blocks);
+  if (pb->num_warmup < 0 || pb->num_results < 1) return fail("need num_warmup >= 0, num_results >= 1");
+  if (pb->num_chains < 1 || pb->num_series < 1) return fail("need num_chains >= 1, num_series >= 1");
+  if (steps_per_thread(pb->T) == 0)
+    return fail("T=%d exceeds the register-resident path (max %d)", pb->T, ci::NT * 16);
+  return 0;
+}
+
+int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask, const float* X,
+                      const uint8_t* season_change, const ci_series_params* params,
+                      ci_session** out) {
+  (void)season_change;
+  if (validate(pb)) return 1;
+  if (!y || !mask || !params || !out) return fail("NULL argument");
+  if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
+  HIP_TRY(hipSetDevice(pb->device));
+  ci_session* s = new ci_session();
+  s->pb = *pb;
+  const int T = pb->T, P = pb->P, B = pb->num_series, C = pb->num_chains, S = pb->num_results;
+  const int D = pb->has_slope ? 2 : 1;
+  s->L = steps_per_thread(T);
+  // X lives in LDS when the whole layout fits in 160 KiB (leave room for a second block).
+  const ci::LdsLayout with_x = ci::make_layout(P, D, ci::NT * s->L, 1);
+  s->x_in_lds = (P > 0 && with_x.total <= 150 * 1024) ? 1 : 0;
+  s->lds_bytes = ci::make_layout(P, D, ci::NT * s->L, s->x_in_lds).total;
+  s->fn = pick_kernel(D, s->L);
+  if (!s->fn) { delete s; return fail("no kernel for L=%d", s->L); }
+  HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)s->lds_bytes));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&s->ev0));
+  HIP_TRY(hipEventCreate(&s->ev1));
+
+  const size_t BT = (size_t)B * T, BCS = (size_t)B * C * S;
+  HIP_TRY(s->y.alloc(BT));
+  HIP_TRY(s->mask.alloc(BT));
+  HIP_TRY(s->Xt.alloc((size_t)B * P * T));
+  HIP_TRY(s->xtx.alloc((size_t)B * P * P));
+  HIP_TRY(s->omega.alloc((size_t)B * P * P));
+  HIP_TRY(s->sp.alloc(B));
+  HIP_TRY(s->o_obs.alloc(BCS));
+  HIP_TRY(s->o_lscale.alloc(BCS));
+  HIP_TRY(s->o_sscale.alloc(BCS));
+  HIP_TRY(s->o_w.alloc(BCS * P));
+  HIP_TRY(s->o_level.alloc(BCS * T));
+  HIP_TRY(s->o_slope.alloc(pb->has_slope ? BCS * T : 0));
+  HIP_TRY(s->o_pm.alloc((size_t)B * C * T));
+  HIP_TRY(s->o_traj.alloc(BCS * T));
+
+  // host-side staging: zero masked outcomes, transpose X to feature-major, count observations
+  std::vector<float> yh(BT);
+  std::vector<ci::DevSeriesParams> sph(B);
+  for (int b = 0; b < B; ++b) {
+    double nobs = 0;
+    for (int t = 0; t < T; ++t) {
+      const size_t i = (size_t)b * T + t;
+      const bool m = mask[i] != 0;
+      yh[i] = m ? 0.f : y[i];
+      if (!m) {
+        nobs += 1;
+        if (!std::isfinite(y[i])) { ci_session_destroy(s); return fail("y[%d,%d] is not finite but unmasked", b, t); }
+      }
+    }
+    const ci_series_params& q = params[b];
+    ci::DevSeriesParams& d = sph[b];
+    d.level_conc = q.level_conc; d.level_scale = q.level_scale; d.level_ub = q.level_ub;
+    d.slope_conc = q.slope_conc; d.slope_scale = q.slope_scale; d.slope_ub = q.slope_ub;
+    d.obs_conc = q.obs_conc; d.obs_scale = q.obs_scale; d.obs_ub = q.obs_ub;
+    d.nonzero_prob = q.nonzero_prob;
+    d.init_level_loc = q.init_level_loc; d.init_level_scale = q.init_level_scale;
+    d.init_slope_scale = q.init_slope_scale;
+    d.obs_scale0 = q.obs_scale0; d.level_scale0 = q.level_scale0; d.slope_scale0 = q.slope_scale0;
+    d.n_obs = nobs;
+  }
+  HIP_TRY(hipMemcpy(s->y.p, yh.data(), BT * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->mask.p, mask, BT, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->sp.p, sph.data(), B * sizeof(ci::DevSeriesParams), hipMemcpyHostToDevice));
+  if (P > 0) {
+    std::vector<float> xt((size_t)B * P * T);
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < T; ++t)
+        for (int j = 0; j < P; ++j)
+          xt[((size_t)b * P + j) * T + t] = X[((size_t)b * T + t) * P + j];
+    HIP_TRY(hipMemcpy(s->Xt.p, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  *out = s;
+  return 0;
+}
+
+int ci_session_run(ci_session* s, float* kernel_ms) {
+  if (!s) return fail("session is NULL");
+  const ci_problem& pb = s->pb;
+  HIP_TRY(hipSetDevice(pb.device));
+  ci::KArgs a;
+  a.T = pb.T; a.P = pb.P; a.W = pb.num_warmup; a.S = pb.num_results; a.C = pb.num_chains;
+  a.B = pb.num_series; a.chain_offset = pb.chain_offset;
+  a.seed0 = pb.seed[0]; a.seed1 = pb.seed[1];
+  a.x_in_lds = s->x_in_lds;
+  a.y = s->y.p; a.mask = s->mask.p; a.Xt = s->Xt.p; a.xtx = s->xtx.p; a.omega = s->omega.p;
+  a.sp = s->sp.p;
+  a.out_obs = s->o_obs.p; a.out_level_scale = s->o_lscale.p; a.out_slope_scale = s->o_sscale.p;
+  a.out_weights = s->o_w.p; a.out_level = s->o_level.p; a.out_slope = s->o_slope.p;
+  a.out_pred_mean = s->o_pm.p; a.out_traj = s->o_traj.p;
+  if (pb.P > 0) {
+    hipLaunchKernelGGL(ci::setup_regression_kernel, dim3(pb.num_series), dim3(256), 0, s->stream,
+                       pb.T, pb.P, s->Xt.p, s->mask.p, s->xtx.p, s->omega.p);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(s->ev0, s->stream));
+  hipLaunchKernelGGL(s->fn, dim3(pb.num_series * pb.num_chains), dim3(ci::NT), s->lds_bytes,
+                     s->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s->ev0, s->ev1));
+  return 0;
+}
+
+int ci_session_fetch(ci_session* s, ci_outputs* o) {
+  if (!s || !o) return fail("NULL argument");
+  HIP_TRY(hipSetDevice(s->pb.device));
+  auto get = [&](float* dst, const DevBuf<float>& src) -> hipError_t {
+    if (!dst || src.n == 0) return hipSuccess;
+    return hipMemcpy(dst, src.p, src.n * sizeof(float), hipMemcpyDeviceToHost);
+  };
+  HIP_TRY(get(o->observation_noise_scale, s->o_obs));
+  HIP_TRY(get(o->level_scale, s->o_lscale));
+  HIP_TRY(get(o->slope_scale, s->o_sscale));
+  HIP_TRY(get(o->weights, s->o_w));
+  HIP_TRY(get(o->level, s->o_level));
+  HIP_TRY(get(o->posterior_means, s->o_pm));
+  HIP_TRY(get(o->posterior_trajectories, s->o_traj));
+  if (o->slope) {
+    if (s->pb.has_slope) HIP_TRY(get(o->slope, s->o_slope));
+    else memset(o->slope, 0, s->o_level.n * sizeof(float));
+  }
+  return 0;
+}
+
+int ci_session_algorithmic_bytes(const ci_session* s, double* bytes) {
+  if (!s || !bytes) return fail("NULL argument");
+  const ci_problem& pb = s->pb;
+  const double T = pb.T, P = pb.P, S = pb.num_results;
+  const double chains = (double)pb.num_series * pb.num_chains;
+  const double d_out = 1.0 + (pb.has_slope ? 1.0 : 0.0);
+  // per retained draw 4 T (d_out + 1) + 4 (P + 2 + slope); inputs once
+  // per chain: 4 T (P + 1) + T.
+  const double per_draw = 4.0 * T * (d_out + 1.0) + 4.0 * (P + 2.0 + (pb.has_slope ? 1.0 : 0.0));
+  const double per_chain = 4.0 * T * (P + 1.0) + T;
+  *bytes = chains * (S * per_draw + per_chain);
+  return 0;
+}
+
+int ci_session_destroy(ci_session* s) {
+  if (!s) return 0;
+  (void)hipSetDevice(s->pb.device);
+  s->y.release(); s->Xt.release(); s->o_obs.release(); s->o_lscale.release(); s->o_sscale.release();
+  s->o_w.release(); s->o_level.release(); s->o_slope.release(); s->o_pm.release();
+  s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->sp.release();
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return 0;
+}
+
+int ci_fit_gibbs(const ci_problem* pb, const float* y, const uint8_t* mask, const float* X,
+                 const uint8_t* season_change, const ci_series_params* params, ci_outputs* outputs) {
+  if (!outputs) return fail("outputs is NULL");
+  ci_session* s = nullptr;
+  if (ci_session_create(pb, y, mask, X, season_change, params, &s)) return 1;
+  int rc = ci_session_run(s, nullptr);
+  if (!rc) rc = ci_session_fetch(s, outputs);
+  ci_session_destroy(s);
+  return rc;
+}
+
+int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t iter, uint32_t site,
+                uint32_t sub, int32_t n, float* uniforms, float* normals, double alpha,
+                double* gamma_draw) {
+  if (n < 1 || n > 256) return fail("n must be in [1, 256]");
+  HIP_TRY(hipSetDevice(device));
+  DevBuf<float> du, dn;
+  DevBuf<double> dg;
+  HIP_TRY(du.alloc(n));
+  HIP_TRY(dn.alloc(2 * (size_t)n));
+  HIP_TRY(dg.alloc(1));
+  hipLaunchKernelGGL(ci::test_rng_kernel, dim3(1), dim3(256), 0, 0, seed[0], seed[1], chain, iter,
+                     site, sub, n, du.p, dn.p, alpha, dg.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(uniforms, du.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(normals, dn.p, 2 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(gamma_draw, dg.p, sizeof(double), hipMemcpyDeviceToHost));
+  du.release(); dn.release(); dg.release();
+  return 0;
+}
+
+int ci_test_dk_draw(const ci_problem* pb, const ci_series_params* params, const float* resid,
+                    const uint8_t* mask, const uint8_t* season_change, double obs_scale,
+                    double level_scale, double slope_scale, const double* drift_scales,
+                    uint32_t iter, float* out_latents) {
+  (void)season_change; (void)drift_scales;
+  if (validate(pb)) return 1;
+  HIP_TRY(hipSetDevice(pb->device));
+  const int T = pb->T, D = pb->has_slope ? 2 : 1, L = steps_per_thread(T);
+  DevBuf<float> dres, dout;
+  DevBuf<uint8_t> dmask;
+  HIP_TRY(dres.alloc(T));
+  HIP_TRY(dmask.alloc(T));
+  HIP_TRY(dout.alloc((size_t)T * D));
+  HIP_TRY(hipMemcpy(dres.p, resid, T * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dmask.p, mask, T, hipMemcpyHostToDevice));
+  const uint32_t chain = (uint32_t)pb->chain_offset;
+const ci_series_params* q = params;
+#define CI_DK_CASE(DD, LL)                                                                     \
+  if (D == DD && L == LL)                                                                      \
+    ci_launch_dk_d##DD##_l##LL(T, dres.p, dmask.p, (float)(obs_scale * obs_scale),             \
+                               (float)level_scale, (float)slope_scale,                        \
+                               (float)q->init_level_loc,                                       \
+                               (float)(q->init_level_scale * q->init_level_scale),             \
+                               (float)(q->init_slope_scale * q->init_slope_scale), pb->seed[0], \
+                               pb->seed[1], chain, iter, dout.p);
+  CI_DK_CASE(1, 1) CI_DK_CASE(1, 2) CI_DK_CASE(1, 4) CI_DK_CASE(1, 8) CI_DK_CASE(1, 16)
+  CI_DK_CASE(2, 1) CI_DK_CASE(2, 2) CI_DK_CASE(2, 4) CI_DK_CASE(2, 8) CI_DK_CASE(2, 16)
+#undef CI_DK_CASE
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_latents, dout.p, (size_t)T * D * sizeof(float), hipMemcpyDeviceToHost));
+  dres.release(); dmask.release(); dout.release();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// ci_inst.hip -- one (D, L) instantiation of the Gibbs kernel per object file so the
+// instantiations build in parallel (make -j).  Compile with -DCI_D=<1|2> -DCI_L=<1|2|4|8|16>.
+#include <hip/hip_runtime.h>
+
+#include "ci_kernels.h"
+
+#ifndef CI_D
+#error "define CI_D"
+#endif
+#ifndef CI_L
+#error "define CI_L"
+#endif
+
+#define CI_CAT_(a, b, c, d) a##b##c##d
+#define CI_CAT(a, b, c, d) CI_CAT_(a, b, c, d)
+
+extern "C" {
+
+// Returns the device-function handle of gibbs_kernel<CI_D, CI_L>.
+void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(void) {
+  return (void*)(&ci::gibbs_kernel<CI_D, CI_L>);
+}
+
+// Launches the one-draw Durbin-Koopman test kernel on the default stream.
+void CI_CAT(ci_launch_dk_d, CI_D, _l, CI_L)(int T, const float* resid, const uint8_t* mask, float H,
+                                           float sig0, float sig1, float a1, float p10, float p11,
+                                           uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter,
+                                           float* out) {
+  ci::DkModel<CI_D> md;
+  md.H = H;
+  md.sig.v[0] = sig0;
+  md.a1 = ci::Vec<CI_D>{};
+  md.a1.v[0] = a1;
+  md.p1.v[0] = p10;
+#if CI_D == 2
+  md.sig.v[1] = sig1;
+  md.p1.v[1] = p11;
+#else
+  (void)sig1; (void)p11;
+#endif
+  hipLaunchKernelGGL((ci::test_dk_kernel<CI_D, CI_L>), dim3(1), dim3(ci::NT), 0, 0, T, resid, mask,
+                     md, k0, k1, chain, iter, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,926 @@
+// ci_kernels.h -- the Gibbs hot path as ONE persistent workgroup per (series, chain).
+//
+// What the reference does per Gibbs iteration, as
+// three sequential length-T loops plus a length-P sweep of dynamic-shape Choleskys,
+// all dispatched op by op through TensorFlow:
+//   (a) spike-and-slab draw of (sigma^2_obs, weights)   spike_and_slab.SpikeSlabSampler
+//   (b) residual y - X w
+//   (c) Durbin-Koopman draw of the latent path          LGSSM.posterior_sample
+//   (d) conjugate inverse-gamma scale draws             gibbs_sampler._resample_scale
+// (reference call site causalimpact/causalimpact_lib.py:365-388).
+//
+// MI355X design (DESIGN.md "Kernel"):
+//   * 256 threads (4 wavefronts) own one chain for all W+S iterations: no launches, no
+//     host round trips, state in VGPRs / LDS, outputs streamed once to HBM.
+//   * time is parallel: thread i owns the L consecutive steps [i*L, (i+1)*L).  The prior
+//     simulation, the Kalman filter (Sarkka associative elements) and the backward
+//     smoother are block-wide scans: in-wave Kogge-Stone over wavefront shuffles, one LDS
+//     hand-off between the 4 waves, local sequential fix-up over the L owned steps.
+//   * the P x P regression algebra is wave-cooperative in float64 in LDS: a sweep operator
+//     makes each inclusion-flip proposal O(1) reads and each accepted flip one rank-1
+//     update, instead of a fresh Cholesky per proposal.
+//   * randomness is the specified Philox stream (ci_rng.h), so results do not depend on
+//     how chains are spread over devices.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ci_linalg.h"
+#include "ci_rng.h"
+
+namespace ci {
+
+constexpr int NT = 256;   // threads per workgroup
+constexpr int NW = 4;     // wavefronts per workgroup
+constexpr int MAXP = 48;  // design columns supported by the LDS-resident regression block
+
+struct DevSeriesParams {
+  double level_conc, level_scale, level_ub;
+  double slope_conc, slope_scale, slope_ub;
+  double obs_conc, obs_scale, obs_ub;
+  double nonzero_prob;
+  double init_level_loc, init_level_scale, init_slope_scale;
+  double obs_scale0, level_scale0, slope_scale0;
+  double n_obs;
+};
+
+struct KArgs {
+  int T, P, W, S, C, B, chain_offset;
+  uint32_t seed0, seed1;
+  int x_in_lds;
+  const float* y;          // [B,T]   0 where masked
+  const uint8_t* mask;     // [B,T]
+  const float* Xt;         // [B,P,T] feature-major
+  const double* xtx;       // [B,P,P] X~'X~ over observed rows
+  const double* omega;     // [B,P,P] 0.01 (XtX/2 + diag(XtX)/2) / T over ALL rows
+  const DevSeriesParams* sp;  // [B]
+  float* out_obs;          // [B,C,S]
+  float* out_level_scale;  // [B,C,S]
+  float* out_slope_scale;  // [B,C,S]
+  float* out_weights;      // [B,C,S,P]
+  float* out_level;        // [B,C,S,T]
+  float* out_slope;        // [B,C,S,T]
+  float* out_pred_mean;    // [B,C,T]
+  float* out_traj;         // [B,C,S,T]
+};
+
+// ------------------------------------------------------------------------------------
+// wave / block primitives
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class E> struct Arr { float f[sizeof(E) / 4]; };
+
+template <class E> __device__ __forceinline__ E shfl_up_e(const E& e, int off) {
+  Arr<E> a = __builtin_bit_cast(Arr<E>, e);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(E) / 4); ++i) a.f[i] = __shfl_up(a.f[i], off, 64);
+  return __builtin_bit_cast(E, a);
+}
+template <class E> __device__ __forceinline__ E shfl_down_e(const E& e, int off) {
+  Arr<E> a = __builtin_bit_cast(Arr<E>, e);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(E) / 4); ++i) a.f[i] = __shfl_down(a.f[i], off, 64);
+  return __builtin_bit_cast(E, a);
+}
+template <class E> __device__ __forceinline__ void lds_store_e(float* p, const E& e) {
+  const Arr<E> a = __builtin_bit_cast(Arr<E>, e);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(E) / 4); ++i) p[i] = a.f[i];
+}
+template <class E> __device__ __forceinline__ E lds_load_e(const float* p) {
+  Arr<E> a;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(E) / 4); ++i) a.f[i] = p[i];
+  return __builtin_bit_cast(E, a);
+}
+
+// Exclusive block scan over thread order (thread 0 first).  op(earlier, later).
+// Contains exactly one __syncthreads(); `slots` needs NW * sizeof(E)/4 floats and must not
+// be rewritten before another barrier has been passed.
+template <class E, class Op>
+__device__ __forceinline__ E block_scan_excl_fwd(const E& tot, Op op, const E& ident, float* slots,
+                                                 int lane, int wave) {
+  constexpr int N = sizeof(E) / 4;
+  E incl = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const E o = shfl_up_e(incl, off);
+    if (lane >= off) incl = op(o, incl);
+  }
+  if (lane == 63) lds_store_e(slots + wave * N, incl);
+  __syncthreads();
+  E wp = ident;
+  for (int ww = 0; ww < wave; ++ww) wp = op(wp, lds_load_e<E>(slots + ww * N));
+  E ex = shfl_up_e(incl, 1);
+  if (lane == 0) ex = ident;
+  return op(wp, ex);
+}
+
+// Exclusive suffix scan: result for thread i = e_{i+1} o e_{i+2} o ... o e_last, with
+// op(outer, inner) (outer is applied after inner; the last thread's element acts first).
+template <class E, class Op>
+__device__ __forceinline__ E block_scan_excl_bwd(const E& tot, Op op, const E& ident, float* slots,
+                                                 int lane, int wave) {
+  constexpr int N = sizeof(E) / 4;
+  E incl = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const E o = shfl_down_e(incl, off);
+    if (lane + off < 64) incl = op(incl, o);
+  }
+  if (lane == 0) lds_store_e(slots + wave * N, incl);
+  __syncthreads();
+  E ws = ident;
+  for (int ww = wave + 1; ww < NW; ++ww) ws = op(ws, lds_load_e<E>(slots + ww * N));
+  E ex = shfl_down_e(incl, 1);
+  if (lane == 63) ex = ident;
+  return op(ex, ws);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------
+// Durbin-Koopman simulation smoother for the trend block, time-parallel.
+// (LinearGaussianStateSpaceModel.posterior_sample reached from
+//  gibbs_sampler._resample_latents; oracle: ci_oracle_dk_draw.)
+// ------------------------------------------------------------------------------------
+template <int D> struct DkModel {
+  float H;        // observation-noise variance
+  Vec<D> sig;     // state disturbance scales (level, slope)
+  Vec<D> a1;      // prior mean of x_0
+  Vec<D> p1;      // prior variances of x_0 (diagonal)
+};
+
+// slots: 3 regions of NW * 16 floats.  Contains 3 __syncthreads().
+template <int D, int L>
+__device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
+                                        uint32_t maskbits, const Rng& rng, uint32_t iter, int tid,
+                                        int lane, int wave, float* slots, Vec<D> (&xout)[L]) {
+  const uint32_t t0 = (uint32_t)tid * L;
+  Vec<D> q;
+#pragma unroll
+  for (int i = 0; i < D; ++i) q.v[i] = md.sig.v[i] * md.sig.v[i];
+
+  // ---- (1) simulate x+ from the prior with zero initial mean: a scan of x <- T x + n_t
+  float zl[L], zs[L], zo[L];
+  fill_normals<L>(rng, iter, SITE_PRIOR_LEVEL, 0, t0, zl);
+  if constexpr (D == 2) fill_normals<L>(rng, iter, SITE_PRIOR_SLOPE, 0, t0, zs);
+  fill_normals<L>(rng, iter, SITE_PRIOR_OBS, 0, t0, zo);
+  // The initial draw x+_0 = chol(P_1) z is NOT propagated through the simulated path (it
+  // would grow like t * slope+_0 and cancel against the smoother in float32).  By linearity
+  // it is folded into the filter's prior mean instead:
+  //   x~ = x+_noise + E[x | y - y+_noise ; prior mean a_1 + x+_0]
+  // which is the same draw as the oracle's x+ + E[x | y - y+ ; prior mean a_1].
+  PElem<D> ptot = pelem_identity<D>();
+  Vec<D> a1e = md.a1;
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float zi[1];
+      fill_normals<1>(rng, iter, SITE_PRIOR_INIT, 0, (uint32_t)i, zi);
+      a1e.v[i] = fmaf(__fsqrt_rn(md.p1.v[i]), zi[0], md.a1.v[i]);
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    PElem<D> e;
+    e.k = 1.f;
+    e.s.v[0] = md.sig.v[0] * zl[l];
+    if constexpr (D == 2) e.s.v[1] = md.sig.v[1] * zs[l];
+    ptot = pelem_combine(ptot, e);
+  }
+  const PElem<D> ppre = block_scan_excl_fwd(
+      ptot, [](const PElem<D>& a, const PElem<D>& b) { return pelem_combine(a, b); },
+      pelem_identity<D>(), slots, lane, wave);
+  Vec<D> xp[L];
+  float ytil[L];
+  {
+    Vec<D> x = ppre.s;
+    const float so = __fsqrt_rn(md.H);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      xp[l] = x;
+      ytil[l] = resid[l] - (x.v[0] + so * zo[l]);
+      x = trans_apply(x);
+      x.v[0] = fmaf(md.sig.v[0], zl[l], x.v[0]);
+      if constexpr (D == 2) x.v[1] = fmaf(md.sig.v[1], zs[l], x.v[1]);
+    }
+  }
+
+  // ---- (2) Kalman filter as an associative scan over (A, b, C, eta, J)
+  const Mat<D> Tm = trans_mat<D>();
+  FElem<D> ftot = felem_identity<D>();
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const bool obs = ((maskbits >> l) & 1u) == 0u;
+    FElem<D> e;
+    if (tid == 0 && l == 0) {
+      // prior element: A = 0, (b, C) = moments of x_0 after its own update
+      e.A = mzero<D>();
+      e.eta = vzero<D>();
+      e.J = mzero<D>();
+      e.b = a1e;
+      e.C = mzero<D>();
+#pragma unroll
+      for (int i = 0; i < D; ++i) e.C.m[i][i] = md.p1.v[i];
+      if (obs) {
+        const float F = md.p1.v[0] + md.H;
+        const float k0 = md.p1.v[0] / F;
+        e.b.v[0] = fmaf(k0, ytil[l] - a1e.v[0], a1e.v[0]);
+        e.C.m[0][0] = md.p1.v[0] * md.H / F;
+      }
+    } else if (obs) {
+      // S = Z Q Z' + H ; K = Q Z'/S ; A = (I - K Z) T ; b = K y ; C = (I - K Z) Q
+      // eta = T' Z' y / S ; J = T' Z' Z T / S          (Z = e_0')
+      const float Sv = q.v[0] + md.H;
+      const float rS = 1.0f / Sv;
+      const float hk = md.H * rS;
+      e.A = Tm;
+#pragma unroll
+      for (int j = 0; j < D; ++j) e.A.m[0][j] = hk * Tm.m[0][j];
+      e.b = vzero<D>();
+      e.b.v[0] = q.v[0] * rS * ytil[l];
+      e.C = mzero<D>();
+      e.C.m[0][0] = hk * q.v[0];
+      if constexpr (D == 2) e.C.m[1][1] = q.v[1];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        e.eta.v[i] = Tm.m[0][i] * ytil[l] * rS;
+#pragma unroll
+        for (int j = 0; j < D; ++j) e.J.m[i][j] = Tm.m[0][i] * Tm.m[0][j] * rS;
+      }
+    } else {
+      e.A = Tm;
+      e.b = vzero<D>();
+      e.C = mzero<D>();
+#pragma unroll
+      for (int i = 0; i < D; ++i) e.C.m[i][i] = q.v[i];
+      e.eta = vzero<D>();
+      e.J = mzero<D>();
+    }
+    ftot = (l == 0) ? e : felem_combine(ftot, e);
+  }
+  const FElem<D> fpre = block_scan_excl_fwd(
+      ftot, [](const FElem<D>& a, const FElem<D>& b) { return felem_combine(a, b); },
+      felem_identity<D>(), slots + NW * 16, lane, wave);
+
+  // local sequential Kalman pass over the owned steps (predicted-form quantities kept)
+  Vec<D> ap[L];
+  Mat<D> Pp[L];
+  Vec<D> kf[L];
+  float vf[L];
+  {
+    Vec<D> mf = fpre.b;
+    Mat<D> Pf = fpre.C;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const bool obs = ((maskbits >> l) & 1u) == 0u;
+      Vec<D> a;
+      Mat<D> P;
+      if (tid == 0 && l == 0) {
+        a = a1e;
+        P = mzero<D>();
+#pragma unroll
+        for (int i = 0; i < D; ++i) P.m[i][i] = md.p1.v[i];
+      } else {
+        a = trans_apply(mf);
+        P = trans_cov(Pf, q);
+      }
+      ap[l] = a;
+      Pp[l] = P;
+      if (obs) {
+        const float v = ytil[l] - a.v[0];
+        const float rF = 1.0f / (P.m[0][0] + md.H);
+        vf[l] = v * rF;
+#pragma unroll
+        for (int i = 0; i < D; ++i) kf[l].v[i] = P.m[i][0] * rF;
+#pragma unroll
+        for (int i = 0; i < D; ++i) mf.v[i] = fmaf(kf[l].v[i], v, a.v[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int j = 0; j < D; ++j) Pf.m[i][j] = P.m[i][j] - kf[l].v[i] * P.m[0][j];
+        symmetrize(Pf);
+      } else {
+        vf[l] = 0.f;
+        kf[l] = vzero<D>();
+        mf = a;
+        Pf = P;
+      }
+    }
+  }
+
+  // ---- (3) backward recursion r_{t-1} = (I - K_t Z)' T' r_t + Z' v_t / F_t as a suffix scan
+  auto step_map = [&](int l) {
+    AElem<D> e;
+    // (I - kf Z)' : identity with row 0 reduced by kf'
+    Mat<D> ikzt = meye<D>();
+#pragma unroll
+    for (int j = 0; j < D; ++j) ikzt.m[0][j] -= kf[l].v[j];
+    // T' = transpose of trans_mat
+    Mat<D> Tt = meye<D>();
+    if constexpr (D == 2) Tt.m[1][0] = 1.f;
+    e.M = mm(ikzt, Tt);
+    e.c = vzero<D>();
+    e.c.v[0] = vf[l];
+    return e;
+  };
+  AElem<D> atot = step_map(L - 1);
+#pragma unroll
+  for (int l = L - 2; l >= 0; --l) atot = aelem_compose(step_map(l), atot);
+  const AElem<D> asuf = block_scan_excl_bwd(
+      atot, [](const AElem<D>& o, const AElem<D>& i) { return aelem_compose(o, i); },
+      aelem_identity<D>(), slots + 2 * NW * 16, lane, wave);
+  {
+    Vec<D> r = asuf.c;  // the map of everything after this chunk applied to r = 0
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+      const AElem<D> e = step_map(l);
+      r = vadd(mv(e.M, r), e.c);
+      const Vec<D> sm = vadd(ap[l], mv(Pp[l], r));
+      xout[l] = vadd(sm, xp[l]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// spike-and-slab regression block (wave 0 only, float64 in LDS)
+// ------------------------------------------------------------------------------------
+struct RegLds {
+  double* xtx;     // [P*P]
+  double* omega;   // [P*P]
+  double* aug[2];  // [(P+1)^2] swept augmented matrix [[M, b],[b', y'y]], double buffered
+  double* pri[2];  // [P*P]     swept prior precision
+  double* chol;    // [P*P]
+  double* bvec;    // [P+4]     reduced X~'targets, y'y, ss_level, ss_slope
+  double* zv;      // [P]
+  double* uperm;   // [P]
+  int* nz;         // [P]
+  int* perm;       // [P]
+  int* idx;        // [P]
+  float* w;        // [P]
+};
+
+// One symmetric sweep (or its inverse) of both matrices on pivot k: src -> dst.
+__device__ __forceinline__ void sweep_pair(const double* sa, double* da, int n, const double* sp,
+                                           double* dp, int np, int k, bool reverse, int lane) {
+  const double sgn = reverse ? -1.0 : 1.0;
+  {
+    const double rd = 1.0 / sa[k * n + k];
+    for (int i = lane >> 4; i < n; i += 4)
+      for (int j = lane & 15; j < n; j += 16) {
+        const double aik = sa[i * n + k], akj = sa[k * n + j];
+        double nv;
+        if (i == k) nv = (j == k) ? -rd : sgn * akj * rd;
+        else if (j == k) nv = sgn * aik * rd;
+        else nv = sa[i * n + j] - aik * akj * rd;
+        da[i * n + j] = nv;
+      }
+  }
+  {
+    const double rd = 1.0 / sp[k * np + k];
+    for (int i = lane >> 4; i < np; i += 4)
+      for (int j = lane & 15; j < np; j += 16) {
+        const double aik = sp[i * np + k], akj = sp[k * np + j];
+        double nv;
+        if (i == k) nv = (j == k) ? -rd : sgn * akj * rd;
+        else if (j == k) nv = sgn * aik * rd;
+        else nv = sp[i * np + j] - aik * akj * rd;
+        dp[i * np + j] = nv;
+      }
+  }
+  wave_sync();
+}
+
+// Draws (sigma^2_obs, weights) for iteration `iter`.  Executed by all 64 lanes of wave 0
+// with uniform control flow.  Returns the new observation-noise scale.
+// spike_and_slab.SpikeSlabSampler.sample_noise_variance_and_weights with
+// experimental_use_weight_adjustment=True (causalimpact_lib.py:387-388).
+__device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
+                                                  const DevSeriesParams& sp, double prev_obs_scale,
+                                                  const Rng& rng, uint32_t iter, int lane) {
+  const int n = P + 1;
+  const double prev_var = prev_obs_scale * prev_obs_scale;
+  const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
+  const bool all_in = sp.nonzero_prob >= 1.0;
+  int cur = 0;
+  for (int i = lane >> 4; i < n; i += 4)
+    for (int j = lane & 15; j < n; j += 16) {
+      double v;
+      if (i < P && j < P) v = R.omega[i * P + j] * prev_var + R.xtx[i * P + j];
+      else if (i == P && j == P) v = R.bvec[P];
+      else v = R.bvec[i < j ? i : j];
+      R.aug[0][i * n + j] = v;
+      if (i < P && j < P) R.pri[0][i * P + j] = R.omega[i * P + j] * prev_var;
+    }
+  if (lane < P) {
+    R.nz[lane] = all_in ? 1 : (R.w[lane] != 0.f ? 1 : 0);
+    if (!all_in) R.uperm[lane] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)lane);
+  }
+  wave_sync();
+  // sweep in the currently included features
+  for (int j = 0; j < P; ++j) {
+    if (R.nz[j]) {
+      sweep_pair(R.aug[cur], R.aug[cur ^ 1], n, R.pri[cur], R.pri[cur ^ 1], P, j, false, lane);
+      cur ^= 1;
+    }
+  }
+  if (!all_in) {
+    // visiting order = stable argsort of P uniforms
+    if (lane < P) {
+      const double uj = R.uperm[lane];
+      int rank = 0;
+      for (int k = 0; k < P; ++k) {
+        const double uk = R.uperm[k];
+        rank += (uk < uj || (uk == uj && k < lane)) ? 1 : 0;
+      }
+      R.perm[rank] = lane;
+    }
+    wave_sync();
+    const double logit_pi = log(sp.nonzero_prob) - log1p(-sp.nonzero_prob);
+    for (int s = 0; s < P; ++s) {
+      const int j = R.perm[s];
+      const bool in = R.nz[j] != 0;
+      const double* A = R.aug[cur];
+      const double ajj = A[j * n + j], ajb = A[j * n + P], corner = A[P * n + P];
+      const double pjj = R.pri[cur][j * P + j];
+      const double beta_old = sp.obs_scale + 0.5 * corner;
+      double delta;
+      if (!in) {
+        const double beta_new = sp.obs_scale + 0.5 * (corner - ajb * ajb / ajj);
+        delta = 0.5 * log(pjj) - 0.5 * log(ajj) + logit_pi -
+                (a_post - 1.0) * (log(beta_new) - log(beta_old));
+      } else {
+        const double V = -ajj, Vp = -pjj;
+        const double beta_new = sp.obs_scale + 0.5 * (corner + ajb * ajb / V);
+        delta = 0.5 * log(Vp) - 0.5 * log(V) - logit_pi -
+                (a_post - 1.0) * (log(beta_new) - log(beta_old));
+      }
+      const double u = uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)s);
+      const bool flip = u < 1.0 / (1.0 + exp(-delta));
+      if (flip) {
+        sweep_pair(R.aug[cur], R.aug[cur ^ 1], n, R.pri[cur], R.pri[cur ^ 1], P, j, in, lane);
+        cur ^= 1;
+        if (lane == 0) R.nz[j] = in ? 0 : 1;
+        wave_sync();
+      }
+    }
+  }
+  const double* A = R.aug[cur];
+  const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
+  const double g = gamma_wave(a_post, rng, iter, SITE_OBSVAR, 0, lane);
+  double var = beta_post / g;
+  if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
+  const double new_scale = sqrt(var);
+
+  // active set in increasing feature order
+  const int mynz = (lane < P) ? R.nz[lane] : 0;
+  const unsigned long long bal = __ballot(mynz != 0);
+  const int na = __popcll(bal);
+  if (mynz) R.idx[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
+  if (lane < P) R.w[lane] = 0.f;
+  wave_sync();
+  // Cholesky of M_S = Omega_S * prev_var + XtX_S  (right-looking, in LDS)
+  for (int i = lane >> 4; i < na; i += 4)
+    for (int j = lane & 15; j < na; j += 16) {
+      const int fi = R.idx[i], fj = R.idx[j];
+      R.chol[i * na + j] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
+    }
+  if (lane < na) R.zv[lane] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[lane]);
+  wave_sync();
+  for (int k = 0; k < na; ++k) {
+    const double dkk = sqrt(R.chol[k * na + k]);
+    wave_sync();
+    for (int i = k + lane; i < na; i += 64) R.chol[i * na + k] = (i == k) ? dkk : R.chol[i * na + k] / dkk;
+    wave_sync();
+    for (int i = k + 1 + (lane >> 4); i < na; i += 4)
+      for (int j = k + 1 + (lane & 15); j <= i; j += 16)
+        R.chol[i * na + j] -= R.chol[i * na + k] * R.chol[j * na + k];
+    wave_sync();
+  }
+  // solve L' u = z (column-oriented back substitution); u overwrites zv
+  for (int i = na - 1; i >= 0; --i) {
+    const double ui = R.zv[i] / R.chol[i * na + i];
+    wave_sync();
+    if (lane == 0) R.zv[i] = ui;
+    for (int k = lane; k < i; k += 64) R.zv[k] -= R.chol[i * na + k] * ui;
+    wave_sync();
+  }
+  if (lane < na) {
+    const int f = R.idx[lane];
+    R.w[f] = (float)(A[f * n + P] + new_scale * R.zv[lane]);
+  }
+  wave_sync();
+  return new_scale;
+}
+
+// gibbs_sampler._resample_scale: sqrt(IG(conc + n/2, scale + ss/2)) clipped at the bound.
+__device__ __forceinline__ double scale_draw(double conc, double scale, double ub, double n,
+                                             double ss, const Rng& rng, uint32_t iter,
+                                             uint32_t site, int lane) {
+  const double g = gamma_wave(conc + 0.5 * n, rng, iter, site, 0, lane);
+  const double s = sqrt((scale + 0.5 * ss) / g);
+  return s < ub ? s : ub;
+}
+
+// ------------------------------------------------------------------------------------
+// the persistent Gibbs kernel
+// ------------------------------------------------------------------------------------
+enum Scal { SC_OBS_DK = 0, SC_OBS_EMIT = 1, SC_LEVEL = 2, SC_SLOPE = 3 };
+
+// Everything the serial (wave 0) section needs, resident in LDS for the whole fit.
+struct SerialCtx {
+  DevSeriesParams sp;
+  double obs_scale, level_scale, slope_scale;   // chain state (scalars)
+  RegLds R;
+  float* scal;
+  const float* red;
+  float* out_obs;
+  float* out_level_scale;
+  float* out_slope_scale;
+  float* out_weights;
+  size_t chain_lin;
+  Rng rng;
+  int P, T, D, W, S, n_iter;
+};
+
+struct LdsLayout {
+  size_t off_ctx, off_xtx, off_omega, off_aug0, off_aug1, off_pri0, off_pri1, off_chol, off_bvec,
+      off_zv, off_uperm, off_nz, off_perm, off_idx, off_w, off_scal, off_red, off_slots, off_xlast,
+      off_tg, off_x, total;
+};
+
+__host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_in_lds) {
+  LdsLayout l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
+  const int Pp = P > 0 ? P : 1;
+  l.off_ctx = take(sizeof(SerialCtx));
+  l.off_xtx = take(sizeof(double) * Pp * Pp);
+  l.off_omega = take(sizeof(double) * Pp * Pp);
+  l.off_aug0 = take(sizeof(double) * (Pp + 1) * (Pp + 1));
+  l.off_aug1 = take(sizeof(double) * (Pp + 1) * (Pp + 1));
+  l.off_pri0 = take(sizeof(double) * Pp * Pp);
+  l.off_pri1 = take(sizeof(double) * Pp * Pp);
+  l.off_chol = take(sizeof(double) * Pp * Pp);
+  l.off_bvec = take(sizeof(double) * (Pp + 4));
+  l.off_zv = take(sizeof(double) * Pp);
+  l.off_uperm = take(sizeof(double) * Pp);
+  l.off_nz = take(sizeof(int) * Pp);
+  l.off_perm = take(sizeof(int) * Pp);
+  l.off_idx = take(sizeof(int) * Pp);
+  l.off_w = take(sizeof(float) * Pp);
+  l.off_scal = take(sizeof(float) * 16);
+  l.off_red = take(sizeof(float) * NW * (Pp + 4));
+  l.off_slots = take(sizeof(float) * 3 * NW * 16);
+  l.off_xlast = take(sizeof(float) * NT * D);
+  l.off_tg = take(sizeof(float) * 16);
+  l.off_x = take(x_in_lds ? sizeof(float) * (size_t)Pp * tpad : 16);
+  l.total = o;
+  return l;
+}
+
+// Serial section of iteration `it` (wave 0, all 64 lanes, uniform control flow):
+//   * reduce the per-wave partial sums,
+//   * draw the scales of iteration it-1 from the path drawn in it-1 and emit its scalars,
+//   * draw (sigma^2_obs, weights) of iteration it.
+static __device__ __noinline__ void serial_section(SerialCtx* cx, int it, int lane) {
+  const int P = cx->P, T = cx->T;
+  const RegLds& R = cx->R;
+  for (int j = lane; j < P + 3; j += 64) {
+    double s = 0.0;
+    for (int w = 0; w < NW; ++w) s += (double)cx->red[w * (P + 4) + j];
+    R.bvec[j] = s;
+  }
+  wave_sync();
+  double obs_scale = cx->obs_scale, level_scale = cx->level_scale, slope_scale = cx->slope_scale;
+  double emit_obs = obs_scale;
+  if (it > 0) {
+    const uint32_t pit = (uint32_t)(it - 1);
+    level_scale = scale_draw(cx->sp.level_conc, cx->sp.level_scale, cx->sp.level_ub,
+                             (double)(T - 1), R.bvec[P + 1], cx->rng, pit, SITE_LEVEL_SCALE, lane);
+    if (cx->D == 2)
+      slope_scale = scale_draw(cx->sp.slope_conc, cx->sp.slope_scale, cx->sp.slope_ub,
+                               (double)(T - 1), R.bvec[P + 2], cx->rng, pit, SITE_SLOPE_SCALE, lane);
+    if (P == 0)
+      obs_scale = scale_draw(cx->sp.obs_conc, cx->sp.obs_scale, cx->sp.obs_ub, cx->sp.n_obs,
+                             R.bvec[P], cx->rng, pit, SITE_OBS_SCALE, lane);
+    emit_obs = obs_scale;
+    const int s = it - 1 - cx->W;
+    if (s >= 0) {
+      const size_t o = cx->chain_lin * cx->S + s;
+      if (lane == 0) {
+        if (cx->out_obs) cx->out_obs[o] = (float)obs_scale;
+        if (cx->out_level_scale) cx->out_level_scale[o] = (float)level_scale;
+        if (cx->out_slope_scale) cx->out_slope_scale[o] = (float)(cx->D == 2 ? slope_scale : 0.0);
+      }
+      if (cx->out_weights && lane < P) cx->out_weights[o * P + lane] = R.w[lane];
+    }
+  }
+  if (P > 0 && it < cx->n_iter)
+    obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, cx->rng, (uint32_t)it, lane);
+  if (lane == 0) {
+    cx->obs_scale = obs_scale;
+    cx->level_scale = level_scale;
+    cx->slope_scale = slope_scale;
+    cx->scal[SC_OBS_DK] = (float)obs_scale;
+    cx->scal[SC_OBS_EMIT] = (float)emit_obs;
+    cx->scal[SC_LEVEL] = (float)level_scale;
+    cx->scal[SC_SLOPE] = (float)slope_scale;
+  }
+  wave_sync();
+}
+
+template <int D, int L>
+__global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int series = blockIdx.x / a.C, chain = blockIdx.x % a.C;
+  const int T = a.T, P = a.P;
+  constexpr int TPAD = NT * L;
+  const LdsLayout lay = make_layout(P, D, TPAD, a.x_in_lds);
+  SerialCtx* cx = (SerialCtx*)(smem + lay.off_ctx);
+  float* scal = (float*)(smem + lay.off_scal);
+  float* red = (float*)(smem + lay.off_red);
+  float* slots = (float*)(smem + lay.off_slots);
+  float* xlast = (float*)(smem + lay.off_xlast);
+  float* wls = (float*)(smem + lay.off_w);
+  const float* Xs = (const float*)(smem + lay.off_x);
+  const size_t chain_lin = (size_t)series * a.C + chain;
+
+  Rng rng;
+  rng.k0 = a.seed0;
+  rng.k1 = a.seed1;
+  rng.chain = (uint32_t)(a.chain_offset + chain);
+
+  // ---- stage the constants of this series
+  const float* yg = a.y + (size_t)series * T;
+  const uint8_t* mg = a.mask + (size_t)series * T;
+  const float* Xg = a.Xt + (size_t)series * P * T;
+  const int t0 = tid * L;
+  if (tid == 0) {
+    cx->sp = a.sp[series];
+    cx->obs_scale = cx->sp.obs_scale0;           // causalimpact_lib.py:566-572
+    cx->level_scale = cx->sp.level_scale0;
+    cx->slope_scale = cx->sp.slope_scale0;
+    RegLds R;
+    R.xtx = (double*)(smem + lay.off_xtx);
+    R.omega = (double*)(smem + lay.off_omega);
+    R.aug[0] = (double*)(smem + lay.off_aug0);
+    R.aug[1] = (double*)(smem + lay.off_aug1);
+    R.pri[0] = (double*)(smem + lay.off_pri0);
+    R.pri[1] = (double*)(smem + lay.off_pri1);
+    R.chol = (double*)(smem + lay.off_chol);
+    R.bvec = (double*)(smem + lay.off_bvec);
+    R.zv = (double*)(smem + lay.off_zv);
+    R.uperm = (double*)(smem + lay.off_uperm);
+    R.nz = (int*)(smem + lay.off_nz);
+    R.perm = (int*)(smem + lay.off_perm);
+    R.idx = (int*)(smem + lay.off_idx);
+    R.w = wls;
+    cx->R = R;
+    cx->scal = scal;
+    cx->red = red;
+    cx->out_obs = a.out_obs;
+    cx->out_level_scale = a.out_level_scale;
+    cx->out_slope_scale = a.out_slope_scale;
+    cx->out_weights = a.out_weights;
+    cx->chain_lin = chain_lin;
+    cx->rng = rng;
+    cx->P = P; cx->T = T; cx->D = D; cx->W = a.W; cx->S = a.S; cx->n_iter = a.W + a.S;
+    scal[8] = (float)cx->sp.init_level_loc;
+    scal[9] = (float)(cx->sp.init_level_scale * cx->sp.init_level_scale);
+    scal[10] = (float)(cx->sp.init_slope_scale * cx->sp.init_slope_scale);
+  }
+  float yv[L];
+  uint32_t maskbits = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    const bool in = t < T;
+    yv[l] = in ? yg[t] : 0.f;
+    const bool m = in ? (mg[t] != 0) : true;
+    if (m) { maskbits |= (1u << l); yv[l] = 0.f; }
+  }
+  {
+    double* lx = (double*)(smem + lay.off_xtx);
+    double* lo = (double*)(smem + lay.off_omega);
+    for (int e = tid; e < P * P; e += NT) {
+      lx[e] = a.xtx[(size_t)series * P * P + e];
+      lo[e] = a.omega[(size_t)series * P * P + e];
+    }
+    if (a.x_in_lds) {
+      float* xw_ = (float*)(smem + lay.off_x);
+      for (int j = 0; j < P; ++j)
+        for (int t = tid; t < TPAD; t += NT) xw_[j * TPAD + t] = (t < T) ? Xg[(size_t)j * T + t] : 0.f;
+    }
+    if (tid < P) wls[tid] = 0.f;                   // weights = 0            :575-578
+  }
+  __syncthreads();
+  const float init_loc = scal[8], init_var = scal[9], init_svar = scal[10];
+
+  // chain state
+  float lev[L], slp[L], xw[L], pm_acc[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { lev[l] = 0.f; slp[l] = 0.f; xw[l] = 0.f; pm_acc[l] = 0.f; }  // :580-581
+
+  float* o_level = a.out_level ? a.out_level + chain_lin * a.S * T : nullptr;
+  float* o_slope = a.out_slope ? a.out_slope + chain_lin * a.S * T : nullptr;
+  float* o_traj = a.out_traj ? a.out_traj + chain_lin * a.S * T : nullptr;
+
+  const int n_iter = a.W + a.S;
+  for (int it = 0; it <= n_iter; ++it) {
+    // ---- partial sums over the owned steps (targets use the CURRENT level)
+    {
+      float tg[L];
+      float yty = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const bool obs = ((maskbits >> l) & 1u) == 0u;
+        tg[l] = obs ? (yv[l] - lev[l]) : 0.f;
+        yty = fmaf(tg[l], tg[l], yty);
+      }
+      for (int j = 0; j < P; ++j) {
+        float pj = 0.f;
+        if (a.x_in_lds) {
+#pragma unroll
+          for (int l = 0; l < L; ++l) pj = fmaf(Xs[j * TPAD + t0 + l], tg[l], pj);
+        } else {
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+            if (t0 + l < T) pj = fmaf(Xg[(size_t)j * T + t0 + l], tg[l], pj);
+        }
+        const float s = wave_sum(pj);
+        if (lane == 0) red[wave * (P + 4) + j] = s;
+      }
+      // level / slope increments ending at the owned steps need the previous thread's last state
+      xlast[tid * D] = lev[L - 1];
+      if constexpr (D == 2) xlast[tid * D + 1] = slp[L - 1];
+      __syncthreads();
+      float ssl = 0.f, sss = 0.f;
+      float pl = (tid > 0) ? xlast[(tid - 1) * D] : 0.f;
+      float ps = 0.f;
+      if constexpr (D == 2) ps = (tid > 0) ? xlast[(tid - 1) * D + 1] : 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const int t = t0 + l;
+        if (t >= 1 && t < T) {
+          float dl = lev[l] - pl;
+          if constexpr (D == 2) {
+            dl -= ps;
+            const float ds = slp[l] - ps;
+            sss = fmaf(ds, ds, sss);
+          }
+          ssl = fmaf(dl, dl, ssl);
+        }
+        pl = lev[l];
+        if constexpr (D == 2) ps = slp[l];
+      }
+      const float s0 = wave_sum(yty), s1 = wave_sum(ssl), s2 = wave_sum(sss);
+      if (lane == 0) {
+        red[wave * (P + 4) + P] = s0;
+        red[wave * (P + 4) + P + 1] = s1;
+        red[wave * (P + 4) + P + 2] = s2;
+      }
+    }
+    __syncthreads();
+
+    // ---- serial section: scale draws for iteration it-1, regression draw for iteration it
+    if (wave == 0) serial_section(cx, it, lane);
+    __syncthreads();
+
+    // ---- emit iteration it-1: level / slope / posterior-predictive trajectory
+    if (it > a.W) {
+      const int s = it - 1 - a.W;
+      const float so = scal[SC_OBS_EMIT];
+      float zp[L];
+      fill_normals<L>(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)t0, zp);
+      float tr[L];
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const float loc = lev[l] + xw[l];
+        pm_acc[l] += loc;
+        tr[l] = fmaf(so, zp[l], loc);
+      }
+      const size_t row = (size_t)s * T;
+      bool vec_done = false;
+      if constexpr (L % 4 == 0) {
+        if ((T & 3) == 0) {
+          vec_done = true;
+#pragma unroll
+          for (int q = 0; q < L / 4; ++q) {
+            const int t = t0 + 4 * q;
+            if (t < T) {
+              if (o_level) *(float4*)(o_level + row + t) = make_float4(lev[4 * q], lev[4 * q + 1], lev[4 * q + 2], lev[4 * q + 3]);
+              if (o_slope) *(float4*)(o_slope + row + t) = make_float4(slp[4 * q], slp[4 * q + 1], slp[4 * q + 2], slp[4 * q + 3]);
+              if (o_traj) *(float4*)(o_traj + row + t) = make_float4(tr[4 * q], tr[4 * q + 1], tr[4 * q + 2], tr[4 * q + 3]);
+            }
+          }
+        }
+      }
+      if (!vec_done) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const int t = t0 + l;
+          if (t < T) {
+            if (o_level) o_level[row + t] = lev[l];
+            if (o_slope) o_slope[row + t] = slp[l];
+            if (o_traj) o_traj[row + t] = tr[l];
+          }
+        }
+      }
+    }
+    if (it == n_iter) break;
+
+    // ---- residual and the latent-path draw of iteration it
+    float resid[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) xw[l] = 0.f;
+    for (int j = 0; j < P; ++j) {
+      const float wj = wls[j];
+      if (a.x_in_lds) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) xw[l] = fmaf(Xs[j * TPAD + t0 + l], wj, xw[l]);
+      } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+          if (t0 + l < T) xw[l] = fmaf(Xg[(size_t)j * T + t0 + l], wj, xw[l]);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) resid[l] = yv[l] - xw[l];
+    DkModel<D> md;
+    {
+      const float so = scal[SC_OBS_DK];
+      md.H = so * so;
+      md.sig.v[0] = scal[SC_LEVEL];
+      md.a1 = vzero<D>();
+      md.a1.v[0] = init_loc;
+      md.p1.v[0] = init_var;
+      if constexpr (D == 2) {
+        md.sig.v[1] = scal[SC_SLOPE];
+        md.p1.v[1] = init_svar;
+      }
+    }
+    Vec<D> x[L];
+    dk_draw<D, L>(md, resid, maskbits, rng, (uint32_t)it, tid, lane, wave, slots, x);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      lev[l] = x[l].v[0];
+      if constexpr (D == 2) slp[l] = x[l].v[1];
+    }
+  }
+
+  if (a.out_pred_mean) {
+    const float inv = 1.0f / (float)(a.S > 0 ? a.S : 1);
+    float* pm = a.out_pred_mean + chain_lin * T;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int t = t0 + l;
+      if (t < T) pm[t] = pm_acc[l] * inv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// component test kernel: one Durbin-Koopman draw
+// ------------------------------------------------------------------------------------
+template <int D, int L>
+__global__ __launch_bounds__(NT) void test_dk_kernel(int T, const float* resid_g,
+                                                     const uint8_t* mask_g, DkModel<D> md,
+                                                     uint32_t k0, uint32_t k1, uint32_t chain,
+                                                     uint32_t iter, float* out) {
+  __shared__ float slots[3 * NW * 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t0 = tid * L;
+  float resid[L];
+  uint32_t maskbits = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    resid[l] = (t < T) ? resid_g[t] : 0.f;
+    if (t >= T || mask_g[t]) maskbits |= 1u << l;
+  }
+  Rng g{k0, k1, chain};
+  Vec<D> x[L];
+  dk_draw<D, L>(md, resid, maskbits, g, iter, tid, lane, wave, slots, x);
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    if (t < T)
+#pragma unroll
+      for (int i = 0; i < D; ++i) out[(size_t)t * D + i] = x[l].v[i];
+  }
+}
+
+}  // namespace ci

@@ -1,0 +1,260 @@
+// ci_linalg.h -- register-resident d x d algebra (d = 1, 2) and the two associative
+// operators the time-parallel Kalman recursions are built from.
+//
+// The reference runs LinearGaussianStateSpaceModel.forward_filter /
+// posterior_marginals as three sequential length-T loops inside every Gibbs
+// iteration.  Here each recursion is an associative scan:
+//   * filtering  : elements (A, b, C, eta, J), Sarkka & Garcia-Fernandez (2021),
+//                  "Temporal parallelization of Bayesian smoothers", eqs. (10)-(12);
+//   * smoothing  : affine maps r_{t-1} = M_t r_t + c_t of the Durbin-Koopman /
+//                  de Jong backward recursion.
+// Everything is fully unrolled so the arrays live in VGPRs (no scratch).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ci {
+
+template <int D> struct Vec { float v[D]; };
+template <int D> struct Mat { float m[D][D]; };
+
+template <int D> __device__ __forceinline__ Vec<D> vzero() {
+  Vec<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i) r.v[i] = 0.f;
+  return r;
+}
+template <int D> __device__ __forceinline__ Mat<D> mzero() {
+  Mat<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) r.m[i][j] = 0.f;
+  return r;
+}
+template <int D> __device__ __forceinline__ Mat<D> meye() {
+  Mat<D> r = mzero<D>();
+#pragma unroll
+  for (int i = 0; i < D; ++i) r.m[i][i] = 1.f;
+  return r;
+}
+template <int D> __device__ __forceinline__ Mat<D> mm(const Mat<D>& a, const Mat<D>& b) {
+  Mat<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fmaf(a.m[i][k], b.m[k][j], s);
+      r.m[i][j] = s;
+    }
+  return r;
+}
+// a * b'
+template <int D> __device__ __forceinline__ Mat<D> mmt(const Mat<D>& a, const Mat<D>& b) {
+  Mat<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fmaf(a.m[i][k], b.m[j][k], s);
+      r.m[i][j] = s;
+    }
+  return r;
+}
+// a' * b
+template <int D> __device__ __forceinline__ Mat<D> mtm(const Mat<D>& a, const Mat<D>& b) {
+  Mat<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fmaf(a.m[k][i], b.m[k][j], s);
+      r.m[i][j] = s;
+    }
+  return r;
+}
+template <int D> __device__ __forceinline__ Vec<D> mv(const Mat<D>& a, const Vec<D>& x) {
+  Vec<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s = fmaf(a.m[i][k], x.v[k], s);
+    r.v[i] = s;
+  }
+  return r;
+}
+// a' * x
+template <int D> __device__ __forceinline__ Vec<D> mtv(const Mat<D>& a, const Vec<D>& x) {
+  Vec<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s = fmaf(a.m[k][i], x.v[k], s);
+    r.v[i] = s;
+  }
+  return r;
+}
+template <int D> __device__ __forceinline__ Mat<D> madd(const Mat<D>& a, const Mat<D>& b) {
+  Mat<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) r.m[i][j] = a.m[i][j] + b.m[i][j];
+  return r;
+}
+template <int D> __device__ __forceinline__ Vec<D> vadd(const Vec<D>& a, const Vec<D>& b) {
+  Vec<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+template <int D> __device__ __forceinline__ Vec<D> vsub(const Vec<D>& a, const Vec<D>& b) {
+  Vec<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i) r.v[i] = a.v[i] - b.v[i];
+  return r;
+}
+template <int D> __device__ __forceinline__ void symmetrize(Mat<D>& a) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i + 1; j < D; ++j) {
+      const float s = 0.5f * (a.m[i][j] + a.m[j][i]);
+      a.m[i][j] = s;
+      a.m[j][i] = s;
+    }
+}
+__device__ __forceinline__ Mat<1> minv(const Mat<1>& a) {
+  Mat<1> r;
+  r.m[0][0] = 1.0f / a.m[0][0];
+  return r;
+}
+__device__ __forceinline__ Mat<2> minv(const Mat<2>& a) {
+  const float det = a.m[0][0] * a.m[1][1] - a.m[0][1] * a.m[1][0];
+  const float rd = 1.0f / det;
+  Mat<2> r;
+  r.m[0][0] = a.m[1][1] * rd;
+  r.m[0][1] = -a.m[0][1] * rd;
+  r.m[1][0] = -a.m[1][0] * rd;
+  r.m[1][1] = a.m[0][0] * rd;
+  return r;
+}
+
+// ---- transition of the trend block: LocalLevel (D=1) T=[1]; LocalLinearTrend (D=2)
+// T=[[1,1],[0,1]]  (tfp.sts.LocalLevel / LocalLinearTrend state-space models).
+template <int D> __device__ __forceinline__ Mat<D> trans_mat() {
+  Mat<D> t = meye<D>();
+  if constexpr (D == 2) t.m[0][1] = 1.f;
+  return t;
+}
+template <int D> __device__ __forceinline__ Vec<D> trans_apply(const Vec<D>& x) {
+  Vec<D> r = x;
+  if constexpr (D == 2) r.v[0] = x.v[0] + x.v[1];
+  return r;
+}
+// T P T' + Q, Q = diag(q)
+template <int D>
+__device__ __forceinline__ Mat<D> trans_cov(const Mat<D>& p, const Vec<D>& q) {
+  Mat<D> r;
+  if constexpr (D == 1) {
+    r.m[0][0] = p.m[0][0] + q.v[0];
+  } else {
+    const float s01 = p.m[0][1] + p.m[1][1];
+    r.m[0][0] = p.m[0][0] + p.m[0][1] + p.m[1][0] + p.m[1][1] + q.v[0];
+    r.m[0][1] = 0.5f * (s01 + p.m[1][0] + p.m[1][1]);
+    r.m[1][0] = r.m[0][1];
+    r.m[1][1] = p.m[1][1] + q.v[1];
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------
+// Filtering element: p(x_k | y_{i:k}, x_{i-1}) = N(A x_{i-1} + b, C),
+//                    p(y_{i:k} | x_{i-1})     ~ N_I(eta, J)   (information form).
+// ---------------------------------------------------------------------------------
+template <int D> struct FElem {
+  Mat<D> A;
+  Vec<D> b;
+  Mat<D> C;
+  Vec<D> eta;
+  Mat<D> J;
+};
+
+template <int D> __device__ __forceinline__ FElem<D> felem_identity() {
+  FElem<D> e;
+  e.A = meye<D>();
+  e.b = vzero<D>();
+  e.C = mzero<D>();
+  e.eta = vzero<D>();
+  e.J = mzero<D>();
+  return e;
+}
+
+// e1 covers the earlier steps, e2 the later ones.
+template <int D>
+__device__ __forceinline__ FElem<D> felem_combine(const FElem<D>& e1, const FElem<D>& e2) {
+  FElem<D> r;
+  const Mat<D> M = madd(meye<D>(), mm(e1.C, e2.J));   // I + C1 J2
+  const Mat<D> Mi = minv(M);
+  const Mat<D> G = mm(Mi, e1.A);                       // (I + C1 J2)^-1 A1
+  const Mat<D> A2Mi = mm(e2.A, Mi);
+  r.A = mm(e2.A, G);
+  r.b = vadd(mv(A2Mi, vadd(e1.b, mv(e1.C, e2.eta))), e2.b);
+  r.C = madd(mmt(mm(A2Mi, e1.C), e2.A), e2.C);
+  // (I + J2 C1)^-1 = Mi'  because C1 and J2 are symmetric  =>  A1' (I + J2 C1)^-1 = G'
+  r.eta = vadd(mtv(G, vsub(e2.eta, mv(e2.J, e1.b))), e1.eta);
+  r.J = madd(mtm(G, mm(e2.J, e1.A)), e1.J);
+  symmetrize(r.C);
+  symmetrize(r.J);
+  return r;
+}
+
+// Affine map r_out = M r_in + c (backward smoothing recursion).
+template <int D> struct AElem {
+  Mat<D> M;
+  Vec<D> c;
+};
+template <int D> __device__ __forceinline__ AElem<D> aelem_identity() {
+  AElem<D> e;
+  e.M = meye<D>();
+  e.c = vzero<D>();
+  return e;
+}
+// outer after inner: (outer o inner)(r) = outer.M (inner.M r + inner.c) + outer.c
+template <int D>
+__device__ __forceinline__ AElem<D> aelem_compose(const AElem<D>& outer, const AElem<D>& inner) {
+  AElem<D> r;
+  r.M = mm(outer.M, inner.M);
+  r.c = vadd(mv(outer.M, inner.c), outer.c);
+  return r;
+}
+
+// Prior-simulation element: x_out = T^k x_in + s  (constant transition T).
+template <int D> struct PElem {
+  float k;
+  Vec<D> s;
+};
+template <int D> __device__ __forceinline__ PElem<D> pelem_identity() {
+  PElem<D> e;
+  e.k = 0.f;
+  e.s = vzero<D>();
+  return e;
+}
+template <int D>
+__device__ __forceinline__ PElem<D> pelem_combine(const PElem<D>& e1, const PElem<D>& e2) {
+  PElem<D> r;
+  r.k = e1.k + e2.k;
+  r.s = e1.s;
+  if constexpr (D == 2) r.s.v[0] = fmaf(e2.k, e1.s.v[1], e1.s.v[0]);  // T^k2 s1
+  r.s = vadd(r.s, e2.s);
+  return r;
+}
+
+}  // namespace ci

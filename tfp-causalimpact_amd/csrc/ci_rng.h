@@ -1,0 +1,144 @@
+// ci_rng.h -- the specified counter-based random stream, device side (gfx950).
+//
+// Same stream as oracle/ci_oracle.c:  Philox4x32-10,
+//   key = (seed0, seed1), counter = (call, site | sub << 8, iteration, chain).
+// One call = 4 uniforms or 4 Box-Muller normals (components 0..3); element idx of a
+// site lives in call idx >> 2, component idx & 3.  Replaces the stateless seeds TFP
+// threads through gibbs_sampler (tfp.random.split_seed; reference call sites
+// causalimpact_lib.py:364, :543).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ci {
+
+enum Site : uint32_t {
+  SITE_PERM = 1, SITE_FLIP = 2, SITE_OBSVAR = 3, SITE_WEIGHTS = 4, SITE_PRIOR_INIT = 5,
+  SITE_PRIOR_LEVEL = 6, SITE_PRIOR_SLOPE = 7, SITE_PRIOR_OBS = 8, SITE_PRIOR_SEAS = 9,
+  SITE_LEVEL_SCALE = 10, SITE_SLOPE_SCALE = 11, SITE_DRIFT_SCALE = 12, SITE_OBS_SCALE = 13,
+  SITE_PRED = 14
+};
+
+struct U4 { uint32_t x, y, z, w; };
+
+struct Rng {
+  uint32_t k0, k1, chain;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ U4 site_call(const Rng& g, uint32_t iter, uint32_t site, uint32_t sub,
+                                        uint32_t call) {
+  return philox4x32_10(call, site | (sub << 8), iter, g.chain, g.k0, g.k1);
+}
+
+__device__ __forceinline__ float u01f(uint32_t r) { return ((float)r + 0.5f) * 2.3283064365386963e-10f; }
+__device__ __forceinline__ double u01d(uint32_t r) { return ((double)r + 0.5) * (1.0 / 4294967296.0); }
+
+// Box-Muller on one (ra, rb) pair; the angle is taken in revolutions so it maps onto
+// v_sin_f32 / v_cos_f32 directly.
+__device__ __forceinline__ void box_muller_f(uint32_t ra, uint32_t rb, float& z0, float& z1) {
+  const float u1 = fminf(u01f(ra), 1.0f);
+  const float rev = (float)rb * 2.3283064365386963e-10f;
+  const float rad = __fsqrt_rn(-2.0f * __logf(u1));
+  z0 = rad * __builtin_amdgcn_cosf(rev);
+  z1 = rad * __builtin_amdgcn_sinf(rev);
+}
+
+__device__ __forceinline__ void box_muller_d(uint32_t ra, uint32_t rb, double& z0, double& z1) {
+  const double u1 = u01d(ra);
+  const double rev = (double)rb * (1.0 / 4294967296.0);
+  const double rad = sqrt(-2.0 * log(u1));
+  const double ang = 6.283185307179586476925286766559 * rev;
+  z0 = rad * cos(ang);
+  z1 = rad * sin(ang);
+}
+
+__device__ __forceinline__ void normals4(const U4& r, float z[4]) {
+  box_muller_f(r.x, r.y, z[0], z[1]);
+  box_muller_f(r.z, r.w, z[2], z[3]);
+}
+
+// Normals for the L consecutive elements [t0, t0 + L) of a site (t0 a multiple of L,
+// L in {1, 2, 4, 8, 16}).
+template <int L>
+__device__ __forceinline__ void fill_normals(const Rng& g, uint32_t iter, uint32_t site,
+                                             uint32_t sub, uint32_t t0, float (&z)[L]) {
+  if constexpr (L % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < L / 4; ++q) {
+      const U4 r = site_call(g, iter, site, sub, (t0 >> 2) + q);
+      float zz[4];
+      normals4(r, zz);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z[4 * q + i] = zz[i];
+    }
+  } else if constexpr (L == 2) {
+    const U4 r = site_call(g, iter, site, sub, t0 >> 2);
+    const bool hi = (t0 & 2u) != 0u;
+    box_muller_f(hi ? r.z : r.x, hi ? r.w : r.y, z[0], z[1]);
+  } else {
+    static_assert(L == 1, "L must be 1, 2 or a multiple of 4");
+    const U4 r = site_call(g, iter, site, sub, t0 >> 2);
+    const bool hi = (t0 & 2u) != 0u;
+    float a, b;
+    box_muller_f(hi ? r.z : r.x, hi ? r.w : r.y, a, b);
+    z[0] = (t0 & 1u) ? b : a;
+  }
+}
+
+__device__ __forceinline__ double normal_d(const Rng& g, uint32_t iter, uint32_t site,
+                                           uint32_t sub, uint32_t idx) {
+  const U4 r = site_call(g, iter, site, sub, idx >> 2);
+  const bool hi = (idx & 2u) != 0u;
+  double a, b;
+  box_muller_d(hi ? r.z : r.x, hi ? r.w : r.y, a, b);
+  return (idx & 1u) ? b : a;
+}
+
+__device__ __forceinline__ double uniform_d(const Rng& g, uint32_t iter, uint32_t site,
+                                            uint32_t sub, uint32_t idx) {
+  const U4 r = site_call(g, iter, site, sub, idx >> 2);
+  const uint32_t c = idx & 3u;
+  return u01d(c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w);
+}
+
+// Gamma(alpha, 1), Marsaglia-Tsang.  The 64 lanes of the calling wavefront evaluate
+// attempts 0..63 at once; the first accepted attempt (lowest index) wins, which is
+// exactly the sequential oracle's answer.  Must be called by a full, converged wave.
+__device__ __forceinline__ double gamma_wave(double alpha, const Rng& g, uint32_t iter,
+                                             uint32_t site, uint32_t sub, int lane) {
+  const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
+  const double d = a - 1.0 / 3.0;
+  const double c = 1.0 / sqrt(9.0 * d);
+  const U4 r = site_call(g, iter, site, sub, (uint32_t)lane);
+  double x, unused;
+  box_muller_d(r.x, r.y, x, unused);
+  const double t = 1.0 + c * x;
+  const double v = t * t * t;
+  bool ok = false;
+  double gval = d;
+  if (v > 0.0) {
+    const double u = u01d(r.z);
+    ok = log(u) < 0.5 * x * x + d - d * v + d * log(v);
+    gval = d * v;
+    if (alpha < 1.0) gval *= pow(u01d(r.w), 1.0 / alpha);
+  }
+  const unsigned long long m = __ballot(ok);
+  if (m == 0ull) return d;
+  const int first = __ffsll((long long)m) - 1;
+  return __shfl(gval, first, 64);
+}
+
+}  // namespace ci

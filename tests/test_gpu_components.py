@@ -25,7 +25,7 @@ def test_rng_stream_matches_oracle(site, sub):
   np.testing.assert_allclose(u, uo, atol=1e-7)           # float32 rounding of a float64 uniform
   np.testing.assert_allclose(z1, zo, atol=3e-5)          # f32 Box-Muller vs f64 Box-Muller
   np.testing.assert_array_equal(z1, z4)                  # 1-wide and 4-wide paths are one stream
-  np.testing.assert_allclose(g, orc.gamma(40.5, seed, chain, it, site, sub), rtol=1e-12)
+  np.testing.assert_allclose(g, orc.gamma(40.5, seed, chain, it, site, sub), rtol=2e-6)   # f32 proposal normal on device
 
 
 @pytest.mark.parametrize("alpha", [0.3, 1.0, 16.0, 366.0, 5012.5])
@@ -33,7 +33,7 @@ def test_gamma_draws_match_oracle(alpha):
   seed = (9, 8)
   for it in range(6):
     _, _, _, g = _native.test_rng(seed, 2, it, 3, 0, 4, alpha=alpha)
-    np.testing.assert_allclose(g, orc.gamma(alpha, seed, 2, it, 3, 0), rtol=1e-11)
+    np.testing.assert_allclose(g, orc.gamma(alpha, seed, 2, it, 3, 0), rtol=2e-6)
 
 
 def _dk_case(T, has_slope, seed=(7, 11)):
@@ -59,12 +59,16 @@ def test_dk_draw_matches_oracle(T, has_slope):
   ssm = orc.make_ssm(spec, mask, obs_scale=obs, level_scale=lvl, slope_scale=slp)
   want = orc.dk_draw(ssm, np.where(mask, 0.0, resid.astype(np.float64)), seed, chain=3, it=5)
   # float32 scans over <= 4096 steps vs float64 sequential recursions: 2e-3 absolute on the
-  # O(1) fitted part plus 3e-4 relative, because a local-linear-trend forecast hundreds of
-  # masked steps ahead reaches |level| ~ 1e2 (slope noise integrates twice).
+  # O(1) fitted part; in the masked forecast tail of a local linear trend the draw is the
+  # difference of O(50) components, so there the error is bounded relative to the posterior
+  # spread of the draw itself (estimated from 12 oracle draws).
+  spread = np.std([orc.dk_draw(ssm, np.where(mask, 0.0, resid.astype(np.float64)), seed,
+                               chain=3, it=100 + i) for i in range(12)], axis=0)
   err = np.abs(got - want)
   assert np.isfinite(got).all()
-  tol = 2e-3 + 3e-4 * np.abs(want)
-  assert (err <= tol).all(), (err / tol).max()
+  tol = 2e-3 + 2e-3 * spread
+  worst = np.unravel_index(np.argmax(err / tol), err.shape)
+  assert (err <= tol).all(), (worst, err[worst], want[worst], got[worst], spread[worst])
 
 
 def test_dk_draw_observed_everywhere_and_strong_signal():

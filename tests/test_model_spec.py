@@ -1,0 +1,43 @@
+"""The product's model constants (causalimpact/_model.py) equal the oracle's independent
+restatement (oracle/ci_oracle.py) of causalimpact_lib.py:398-500, :563-581."""
+import numpy as np
+import pytest
+
+from causalimpact import _model
+from causalimpact import _synthetic as syn
+from oracle import ci_oracle as orc
+
+
+@pytest.mark.parametrize("p,has_slope,seasons", [
+    (0, False, ()), (1, False, ()), (10, True, ()), (3, False, ((7, 1), (4, (2, 1, 1, 1)))),
+])
+def test_series_params_match_oracle_spec(p, has_slope, seasons):
+  y, mask, X, _ = syn.make_sampler_inputs(120, p, seed=p + 1)
+  mask[[0, 4]] = True   # missing first observation: both sides use the first observed value
+  mine = _model.series_params(y, mask, X, prior_level_sd=0.1, has_slope=has_slope,
+                              num_seasonal_blocks=len(seasons))
+  ref = orc.default_spec(y, mask, X, prior_level_sd=0.1, has_slope=has_slope, seasons=seasons)
+  for k, v in mine.items():
+    if k == "drift_scale0":
+      np.testing.assert_allclose(v, ref[k], rtol=1e-14)
+    else:
+      np.testing.assert_allclose(v, ref[k], rtol=1e-14, err_msg=k)
+  counts, flags = _model.expand_seasons(seasons, 120)
+  assert counts == ref["num_seasons"]
+  for k in range(len(seasons)):
+    np.testing.assert_array_equal(flags[k], ref["season_change"][k])
+
+
+def test_season_calendar_shapes():
+  # int: every season lasts s steps; changes at s-1, 2s-1, ...
+  f = _model.season_change_flags(10, 3, 2)
+  np.testing.assert_array_equal(f, [0, 1, 0, 1, 0, 1, 0, 1, 0, 1])
+  # per-season lengths (2,1,1,1): cycle of 5 with changes after steps 1,2,3,4
+  f = _model.season_change_flags(10, 4, (2, 1, 1, 1))
+  np.testing.assert_array_equal(f, [0, 1, 1, 1, 1, 0, 1, 1, 1, 1])
+  # per-cycle table wraps after both cycles (causalimpact_lib_test.py:748-750)
+  f = _model.season_change_flags(16, 6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1)))
+  np.testing.assert_array_equal(f[:8], [0, 1, 0, 1, 1, 1, 1, 1])
+  np.testing.assert_array_equal(f[8:], f[:8])
+  with pytest.raises(ValueError):
+    _model.season_change_flags(10, 3, (1, 2))

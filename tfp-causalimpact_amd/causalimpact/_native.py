@@ -75,6 +75,7 @@ def load():
   L.ci_session_fetch.argtypes = [C.c_void_p, C.POINTER(Outputs)]
   L.ci_session_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
   L.ci_session_destroy.argtypes = [C.c_void_p]
+  L.ci_session_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   L.ci_test_rng.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
                             C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
   L.ci_test_dk_draw.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p, C.c_void_p,
@@ -90,7 +91,8 @@ def exported_symbols() -> Sequence[str]:
   """Every entry point include/causalimpact_amd.h declares."""
   return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_fit_gibbs",
           "ci_session_create", "ci_session_run", "ci_session_fetch",
-          "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_test_rng",
+          "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_session_profile",
+          "ci_test_rng",
           "ci_test_dk_draw")
 
 
@@ -210,6 +212,12 @@ class Session:
     b = C.c_double(0)
     _check(self._lib.ci_session_algorithmic_bytes(self._h, C.byref(b)))
     return float(b.value)
+
+  def profile(self, enable=True):
+    """Enables per-phase cycle counters for the next run(); returns the previous run's."""
+    cyc = np.zeros(16, np.int64)
+    _check(self._lib.ci_session_profile(self._h, int(enable), cyc.ctypes.data))
+    return cyc
 
   def close(self):
     if self._h:

@@ -142,6 +142,8 @@ struct ci_session {
   DevBuf<uint8_t> mask;
   DevBuf<double> xtx, omega;
   DevBuf<ci::DevSeriesParams> sp;
+  DevBuf<long long> prof;
+  bool profile = false;
 };
 
 extern "C" {
@@ -267,6 +269,12 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
   a.out_obs = s->o_obs.p; a.out_level_scale = s->o_lscale.p; a.out_slope_scale = s->o_sscale.p;
   a.out_weights = s->o_w.p; a.out_level = s->o_level.p; a.out_slope = s->o_slope.p;
   a.out_pred_mean = s->o_pm.p; a.out_traj = s->o_traj.p;
+  a.prof = nullptr;
+  if (s->profile) {
+    if (!s->prof.p) HIP_TRY(s->prof.alloc(16));
+    HIP_TRY(hipMemsetAsync(s->prof.p, 0, 16 * sizeof(long long), s->stream));
+    a.prof = s->prof.p;
+  }
   if (pb.P > 0) {
     hipLaunchKernelGGL(ci::setup_regression_kernel, dim3(pb.num_series), dim3(256), 0, s->stream,
                        pb.T, pb.P, s->Xt.p, s->mask.p, s->xtx.p, s->omega.p);
@@ -317,12 +325,22 @@ int ci_session_algorithmic_bytes(const ci_session* s, double* bytes) {
   return 0;
 }
 
+int ci_session_profile(ci_session* s, int enable, int64_t* cycles16) {
+  if (!s) return fail("session is NULL");
+  s->profile = enable != 0;
+  if (cycles16) {
+    if (!s->prof.p) { memset(cycles16, 0, 16 * sizeof(int64_t)); return 0; }
+    HIP_TRY(hipMemcpy(cycles16, s->prof.p, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
 int ci_session_destroy(ci_session* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->pb.device);
   s->y.release(); s->Xt.release(); s->o_obs.release(); s->o_lscale.release(); s->o_sscale.release();
   s->o_w.release(); s->o_level.release(); s->o_slope.release(); s->o_pm.release();
-  s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->sp.release();
+  s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->sp.release(); s->prof.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);

@@ -62,6 +62,7 @@ struct KArgs {
   float* out_slope;        // [B,C,S,T]
   float* out_pred_mean;    // [B,C,T]
   float* out_traj;         // [B,C,S,T]
+  long long* prof;         // optional [16] per-phase cycle counters (block 0, thread 0)
 };
 
 // ------------------------------------------------------------------------------------
@@ -71,6 +72,23 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+
+// Per-phase cycle accounting (s_memtime) for DESIGN.md's time budget; one thread records.
+struct Prof {
+  long long* p;
+  long long t;
+  __device__ __forceinline__ void start(long long* ptr, bool active) {
+    p = active ? ptr : nullptr;
+    if (p) t = clock64();
+  }
+  __device__ __forceinline__ void tick(int slot) {
+    if (p) {
+      const long long n = clock64();
+      p[slot] += n - t;
+      t = n;
+    }
+  }
+};
 
 template <class E> struct Arr { float f[sizeof(E) / 4]; };
 
@@ -163,7 +181,8 @@ template <int D> struct DkModel {
 template <int D, int L>
 __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
                                         uint32_t maskbits, const Rng& rng, uint32_t iter, int tid,
-                                        int lane, int wave, float* slots, Vec<D> (&xout)[L]) {
+                                        int lane, int wave, float* slots, Vec<D> (&xout)[L],
+                                        Prof& prof) {
   const uint32_t t0 = (uint32_t)tid * L;
   Vec<D> q;
 #pragma unroll
@@ -215,6 +234,7 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
     }
   }
 
+  prof.tick(4);
   // ---- (2) Kalman filter as an associative scan over (A, b, C, eta, J)
   const Mat<D> Tm = trans_mat<D>();
   FElem<D> ftot = felem_identity<D>();
@@ -272,6 +292,7 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
       ftot, [](const FElem<D>& a, const FElem<D>& b) { return felem_combine(a, b); },
       felem_identity<D>(), slots + NW * 16, lane, wave);
 
+  prof.tick(5);
   // local sequential Kalman pass over the owned steps (predicted-form quantities kept)
   Vec<D> ap[L];
   Mat<D> Pp[L];
@@ -318,6 +339,7 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
     }
   }
 
+  prof.tick(6);
   // ---- (3) backward recursion r_{t-1} = (I - K_t Z)' T' r_t + Z' v_t / F_t as a suffix scan
   auto step_map = [&](int l) {
     AElem<D> e;
@@ -349,6 +371,7 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
       xout[l] = vadd(sm, xp[l]);
     }
   }
+  prof.tick(7);
 }
 
 // ------------------------------------------------------------------------------------
@@ -374,7 +397,7 @@ __device__ __forceinline__ void sweep_pair(const double* sa, double* da, int n, 
                                            double* dp, int np, int k, bool reverse, int lane) {
   const double sgn = reverse ? -1.0 : 1.0;
   {
-    const double rd = 1.0 / sa[k * n + k];
+    const double rd = fast_rcp(sa[k * n + k]);
     for (int i = lane >> 4; i < n; i += 4)
       for (int j = lane & 15; j < n; j += 16) {
         const double aik = sa[i * n + k], akj = sa[k * n + j];
@@ -386,7 +409,7 @@ __device__ __forceinline__ void sweep_pair(const double* sa, double* da, int n, 
       }
   }
   {
-    const double rd = 1.0 / sp[k * np + k];
+    const double rd = fast_rcp(sp[k * np + k]);
     for (int i = lane >> 4; i < np; i += 4)
       for (int j = lane & 15; j < np; j += 16) {
         const double aik = sp[i * np + k], akj = sp[k * np + j];
@@ -400,13 +423,188 @@ __device__ __forceinline__ void sweep_pair(const double* sa, double* da, int n, 
   wave_sync();
 }
 
+// ---- register-resident regression block (P <= 16) ---------------------------------------
+// Lane j < P holds column j of the swept matrices: c[i] = Aug[i][j], p[i] = Pri[i][j] (i < P),
+// cb = Aug[P][j] (the swept X~'targets row); `corner` = Aug[P][P] is wave-uniform.  A sweep
+// on pivot j broadcasts lane j's column with v_readlane: no LDS, no barriers.  The columns are
+// ext_vector_type values so that the wave-uniform pivot index lowers to indexed register
+// moves: one compact copy of the code (the instruction cache is 64 KB per CU pair; a
+// 16-way static switch over pivots made this section fetch-bound) and no scratch.
+typedef double dvec16 __attribute__((ext_vector_type(16)));
+
+struct RegCols {
+  dvec16 c, p;
+  double cb, corner;
+};
+
+struct StepCtx {
+  double b0;          // prior scale of sigma^2_obs
+  double a_post_m1;   // posterior concentration - 1
+  double logit_pi;
+};
+
+// One event on feature j (wave-uniform): either a forced sweep-in, or a Gibbs flip proposal
+// (spike_and_slab `_resample_all_features` step) followed by the sweep when accepted.
+__device__ __forceinline__ void step_regs(RegCols& m, unsigned long long& S, int j, bool force,
+                                          double u, const StepCtx& sc, int lane) {
+  const bool in = ((S >> j) & 1ull) != 0ull;
+  const double cjj = m.c[j];
+  const double pjj = m.p[j];
+  bool flip = true;
+  if (!force) {
+    // lane j's numbers are the real ones; the other lanes compute harmless garbage
+    const double sg = in ? -1.0 : 1.0;
+    const double ap = sg * cjj;         // Schur pivot (feature out) or V_jj (feature in), > 0
+    const double pp = sg * pjj;
+    const double rap = fast_rcp(ap);
+    const double beta_old = sc.b0 + 0.5 * m.corner;
+    const double x = -0.5 * sg * m.cb * m.cb * rap * fast_rcp(beta_old);  // beta_new/beta_old - 1
+    const double delta = 0.5 * (double)__logf((float)(pp * rap)) + sg * sc.logit_pi -
+                         sc.a_post_m1 * fast_log1p(x);
+    const float prob = 1.0f / (1.0f + __expf(-(float)delta));
+    flip = ((__ballot(u < (double)prob) >> j) & 1ull) != 0ull;
+  }
+  if (flip) {
+    const double sgn = in ? -1.0 : 1.0;   // inverse sweep removes an included feature
+    const bool isk = lane == j;
+    const double cbk = readlane_d(m.cb, j);
+    const double rd = fast_rcp(readlane_d(cjj, j));
+    const double rdp = fast_rcp(readlane_d(pjj, j));
+    const double t = isk ? 1.0 : cjj * rd;
+    const double tp = isk ? 1.0 : pjj * rdp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {      // entry i == j is overwritten below
+      const double ci = readlane_d(m.c[i], j);
+      const double pi = readlane_d(m.p[i], j);
+      m.c[i] = isk ? sgn * ci * rd : m.c[i] - ci * t;
+      m.p[i] = isk ? sgn * pi * rdp : m.p[i] - pi * tp;
+    }
+    m.c[j] = isk ? -rd : sgn * t;
+    m.p[j] = isk ? -rdp : sgn * tp;
+    m.cb = isk ? sgn * cbk * rd : m.cb - cbk * t;
+    m.corner -= cbk * cbk * rd;
+    S ^= (1ull << j);
+  }
+}
+
+__device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
+                                                       const DevSeriesParams& sp,
+                                                       double prev_obs_scale, const Rng& rng,
+                                                       uint32_t iter, int lane, Prof& prof) {
+  const double prev_var = prev_obs_scale * prev_obs_scale;
+  const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
+  const bool all_in = sp.nonzero_prob >= 1.0;
+  const bool live = lane < P;
+  const int col = live ? lane : 0;
+  const double* __restrict__ omega = R.omega;
+  const double* __restrict__ xtx = R.xtx;
+  RegCols m;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double om = 0.0, xx = 0.0;
+    if (live && i < P) {
+      om = omega[i * P + col] * prev_var;
+      xx = xtx[i * P + col];
+    }
+    m.p[i] = om;
+    m.c[i] = om + xx;
+  }
+  m.cb = live ? R.bvec[col] : 0.0;
+  m.corner = R.bvec[P];
+  unsigned long long pending = __ballot(live && (all_in || R.w[col] != 0.f));
+  unsigned long long S = 0ull;
+  // visiting order = stable argsort of P uniforms; lane s also holds the flip uniform of step s
+  double uflip = 2.0;
+  int rank = -1;
+  StepCtx sc;
+  sc.b0 = sp.obs_scale;
+  sc.a_post_m1 = a_post - 1.0;
+  sc.logit_pi = 0.0;
+  if (!all_in) {
+    const double uperm = live ? uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)lane) : 2.0;
+    uflip = live ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)lane) : 2.0;
+    rank = 0;
+    for (int kk = 0; kk < P; ++kk) {
+      const double uk = readlane_d(uperm, kk);
+      rank += (uk < uperm || (uk == uperm && kk < lane)) ? 1 : 0;
+    }
+    if (!live) rank = -1;
+    sc.logit_pi = (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
+  }
+  int s = 0;
+  for (;;) {
+    int j;
+    bool force;
+    double u = 2.0;
+    if (pending != 0ull) {                       // sweep in the features included last iteration
+      j = __ffsll((long long)pending) - 1;
+      pending &= pending - 1ull;
+      force = true;
+    } else if (!all_in && s < P) {               // then one flip proposal per feature
+      j = __ffsll((long long)__ballot(rank == s)) - 1;
+      u = readlane_d(uflip, s);
+      force = false;
+      ++s;
+    } else {
+      break;
+    }
+    step_regs(m, S, __builtin_amdgcn_readfirstlane(j), force, u, sc, lane);
+  }
+  prof.tick(10);
+  const double beta_post = sp.obs_scale + 0.5 * m.corner;
+  const double g = gamma_wave(a_post, rng, iter, SITE_OBSVAR, 0, lane);
+  double var = beta_post * fast_rcp(g);
+  if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
+  const double new_scale = (double)__fsqrt_rn((float)var);
+  prof.tick(11);
+
+  // weights_S ~ N(mean, var * M_S^{-1}):  M_S = L L' (right-looking, column-per-lane; the
+  // trailing matrix stays symmetric, so lane j reads L[j][k] as its OWN row-k entry), then
+  // L' u = z with lane i owning column i.
+  float zf[1];
+  fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)col, zf);
+  dvec16 l;   // unswept M = Omega * prev_var + XtX
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    l[i] = (live && i < P) ? omega[i * P + col] * prev_var + xtx[i * P + col] : 0.0;
+  for (unsigned long long mm = S; mm != 0ull; mm &= mm - 1ull) {
+    const int kq = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+    const double lk = l[kq];
+    const double rs = fast_rsqrt(readlane_d(lk, kq));
+    const bool isk = lane == kq;
+    const bool trailing = lane > kq;          // columns < kq are already final
+    const double ljk = lk * rs;               // L[lane][kq] by symmetry (lane > kq)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {            // rows i <= kq get garbage that is never read,
+      const double cik = readlane_d(l[i], kq) * rs;   // except row kq, rewritten below
+      l[i] = isk ? cik : (trailing && i > kq ? l[i] - cik * ljk : l[i]);
+    }
+    if (isk) l[kq] = ljk;                      // sqrt(d)
+  }
+  double acc = 0.0, umine = 0.0;
+  for (unsigned long long mm = S; mm != 0ull;) {
+    const int i = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mm));   // descending
+    mm &= ~(1ull << i);
+    const double li = l[i];
+    const double ui = readlane_d(((double)zf[0] - acc) * fast_rcp(li), i);
+    acc += li * ui;
+    if (lane == i) umine = ui;
+  }
+  const bool mine = live && ((S >> col) & 1ull) != 0ull;
+  if (live) R.w[lane] = mine ? (float)(m.cb + new_scale * umine) : 0.f;
+  wave_sync();
+  prof.tick(12);
+  return new_scale;
+}
+
 // Draws (sigma^2_obs, weights) for iteration `iter`.  Executed by all 64 lanes of wave 0
 // with uniform control flow.  Returns the new observation-noise scale.
 // spike_and_slab.SpikeSlabSampler.sample_noise_variance_and_weights with
 // experimental_use_weight_adjustment=True (causalimpact_lib.py:387-388).
 __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
                                                   const DevSeriesParams& sp, double prev_obs_scale,
-                                                  const Rng& rng, uint32_t iter, int lane) {
+                                                  const Rng& rng, uint32_t iter, int lane,
+                                                  Prof& prof) {
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
@@ -433,6 +631,7 @@ __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
       cur ^= 1;
     }
   }
+  prof.tick(9);
   if (!all_in) {
     // visiting order = stable argsort of P uniforms
     if (lane < P) {
@@ -474,6 +673,7 @@ __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
       }
     }
   }
+  prof.tick(10);
   const double* A = R.aug[cur];
   const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
   const double g = gamma_wave(a_post, rng, iter, SITE_OBSVAR, 0, lane);
@@ -488,6 +688,7 @@ __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
   if (mynz) R.idx[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
   if (lane < P) R.w[lane] = 0.f;
   wave_sync();
+  prof.tick(11);
   // Cholesky of M_S = Omega_S * prev_var + XtX_S  (right-looking, in LDS)
   for (int i = lane >> 4; i < na; i += 4)
     for (int j = lane & 15; j < na; j += 16) {
@@ -519,6 +720,7 @@ __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
     R.w[f] = (float)(A[f * n + P] + new_scale * R.zv[lane]);
   }
   wave_sync();
+  prof.tick(12);
   return new_scale;
 }
 
@@ -527,7 +729,7 @@ __device__ __forceinline__ double scale_draw(double conc, double scale, double u
                                              double ss, const Rng& rng, uint32_t iter,
                                              uint32_t site, int lane) {
   const double g = gamma_wave(conc + 0.5 * n, rng, iter, site, 0, lane);
-  const double s = sqrt((scale + 0.5 * ss) / g);
+  const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
   return s < ub ? s : ub;
 }
 
@@ -550,6 +752,7 @@ struct SerialCtx {
   size_t chain_lin;
   Rng rng;
   int P, T, D, W, S, n_iter;
+  long long* prof;
 };
 
 struct LdsLayout {
@@ -592,9 +795,11 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
 //   * reduce the per-wave partial sums,
 //   * draw the scales of iteration it-1 from the path drawn in it-1 and emit its scalars,
 //   * draw (sigma^2_obs, weights) of iteration it.
-static __device__ __noinline__ void serial_section(SerialCtx* cx, int it, int lane) {
+static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int lane) {
   const int P = cx->P, T = cx->T;
   const RegLds& R = cx->R;
+  Prof prof;
+  prof.start(cx->prof, cx->prof != nullptr && lane == 0);
   for (int j = lane; j < P + 3; j += 64) {
     double s = 0.0;
     for (int w = 0; w < NW; ++w) s += (double)cx->red[w * (P + 4) + j];
@@ -625,8 +830,13 @@ static __device__ __noinline__ void serial_section(SerialCtx* cx, int it, int la
       if (cx->out_weights && lane < P) cx->out_weights[o * P + lane] = R.w[lane];
     }
   }
-  if (P > 0 && it < cx->n_iter)
-    obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, cx->rng, (uint32_t)it, lane);
+  prof.tick(8);
+  if (P > 0 && it < cx->n_iter) {
+    if (P <= 16)
+      obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, cx->rng, (uint32_t)it, lane, prof);
+    else
+      obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, cx->rng, (uint32_t)it, lane, prof);
+  }
   if (lane == 0) {
     cx->obs_scale = obs_scale;
     cx->level_scale = level_scale;
@@ -697,6 +907,7 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
     cx->chain_lin = chain_lin;
     cx->rng = rng;
     cx->P = P; cx->T = T; cx->D = D; cx->W = a.W; cx->S = a.S; cx->n_iter = a.W + a.S;
+    cx->prof = (blockIdx.x == 0) ? a.prof : nullptr;
     scal[8] = (float)cx->sp.init_level_loc;
     scal[9] = (float)(cx->sp.init_level_scale * cx->sp.init_level_scale);
     scal[10] = (float)(cx->sp.init_slope_scale * cx->sp.init_slope_scale);
@@ -738,6 +949,8 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
   float* o_traj = a.out_traj ? a.out_traj + chain_lin * a.S * T : nullptr;
 
   const int n_iter = a.W + a.S;
+  Prof prof;
+  prof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && tid == 0);
   for (int it = 0; it <= n_iter; ++it) {
     // ---- partial sums over the owned steps (targets use the CURRENT level)
     {
@@ -793,10 +1006,12 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
       }
     }
     __syncthreads();
+    prof.tick(0);
 
     // ---- serial section: scale draws for iteration it-1, regression draw for iteration it
     if (wave == 0) serial_section(cx, it, lane);
     __syncthreads();
+    prof.tick(1);
 
     // ---- emit iteration it-1: level / slope / posterior-predictive trajectory
     if (it > a.W) {
@@ -839,6 +1054,7 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
         }
       }
     }
+    prof.tick(2);
     if (it == n_iter) break;
 
     // ---- residual and the latent-path draw of iteration it
@@ -872,7 +1088,8 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
       }
     }
     Vec<D> x[L];
-    dk_draw<D, L>(md, resid, maskbits, rng, (uint32_t)it, tid, lane, wave, slots, x);
+    prof.tick(3);
+    dk_draw<D, L>(md, resid, maskbits, rng, (uint32_t)it, tid, lane, wave, slots, x, prof);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       lev[l] = x[l].v[0];
@@ -913,7 +1130,9 @@ __global__ __launch_bounds__(NT) void test_dk_kernel(int T, const float* resid_g
   }
   Rng g{k0, k1, chain};
   Vec<D> x[L];
-  dk_draw<D, L>(md, resid, maskbits, g, iter, tid, lane, wave, slots, x);
+  Prof prof;
+  prof.start(nullptr, false);
+  dk_draw<D, L>(md, resid, maskbits, g, iter, tid, lane, wave, slots, x, prof);
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const int t = t0 + l;

@@ -1,0 +1,116 @@
+"""Host wrapper == the real reference, on both sides of the hot path.
+
+Fixtures in tests/golden/ were produced by tests/golden/make_golden.py, which imports the
+reference's own pandas code (CausalImpactData, _compute_impact) under TF stubs.  Here the
+build's re-implementation must reproduce them to 1e-12.
+"""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from causalimpact import causalimpact_lib as lib
+from causalimpact import data as cid
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = json.load(open(os.path.join(GOLD, "index.json")))
+
+
+def _load(name):
+  meta = json.load(open(os.path.join(GOLD, f"{name}.json")))
+  prep = np.load(os.path.join(GOLD, f"{name}_prep.npz"))
+  df = pd.read_csv(os.path.join(GOLD, f"{name}_input.csv"), index_col=0)
+  if meta["index_kind"] == "datetime":
+    df.index = pd.to_datetime(df.index)
+    pre = tuple(pd.to_datetime(p) for p in meta["pre_period_in"])
+    post = tuple(pd.to_datetime(p) for p in meta["post_period_in"])
+    if name == "no_covariates_str_periods":   # the reference was driven with strings here
+      pre, post = tuple(meta["pre_period_in"]), tuple(meta["post_period_in"])
+  else:
+    pre = tuple(int(p) for p in meta["pre_period_in"])
+    post = tuple(int(p) for p in meta["post_period_in"])
+  return meta, prep, df, pre, post
+
+
+def _frame_from_json(js, like: pd.DataFrame):
+  cols = {}
+  for c in js["columns"]:
+    vals = js["data"][c]
+    if c.endswith("_start") or c.endswith("_end"):
+      cols[c] = vals
+    else:
+      cols[c] = [np.nan if v is None else v for v in vals]
+  return pd.DataFrame(cols, index=like.index)[js["columns"]]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_data_preparation_matches_reference(name):
+  meta, prep, df, pre, post = _load(name)
+  ci = cid.CausalImpactData(df, pre, post, standardize_data=meta["standardize"], dtype=np.float64)
+  assert [str(p) for p in ci.pre_period] == meta["pre_period"]
+  assert [str(p) for p in ci.post_period] == meta["post_period"]
+  assert str(ci.outcome_column) == meta["outcome_column"]
+  np.testing.assert_allclose(ci.outcome_ts.time_series, prep["y"], rtol=1e-12, equal_nan=True)
+  np.testing.assert_array_equal(ci.outcome_ts.is_missing, prep["is_missing"])
+  assert ci.num_steps_forecast == int(prep["num_steps_forecast"])
+  if ci.feature_ts is None:
+    assert prep["feature_values"].shape[1] == 0
+  else:
+    np.testing.assert_allclose(ci.feature_ts.values, prep["feature_values"], rtol=1e-12)
+    assert [str(c) for c in ci.feature_ts.columns] == list(prep["feature_columns"])
+  if meta["standardize"]:
+    np.testing.assert_allclose(ci.outcome_scaler.mean_, prep["outcome_mean"], rtol=1e-13)
+    np.testing.assert_allclose(ci.outcome_scaler.stddev_, prep["outcome_std"], rtol=1e-13)
+  else:
+    assert ci.outcome_scaler is None
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_impact_postprocessing_matches_reference(name):
+  meta, prep, df, pre, post = _load(name)
+  ci = cid.CausalImpactData(df, pre, post, standardize_data=meta["standardize"], dtype=np.float64)
+  series, summary = lib._compute_impact(prep["fake_means"], prep["fake_trajectories"], ci,
+                                        meta["alpha"])
+  assert list(series.columns) == meta["series"]["columns"]          # SURVEY Appendix E order
+  assert list(summary.columns) == meta["summary"]["columns"]
+  assert list(summary.index) == ["average", "cumulative"]
+  assert [str(i) for i in series.index] == meta["series"]["index"]
+  want_series = _frame_from_json(meta["series"], series)
+  for c in meta["series"]["columns"]:
+    if c.endswith("_start") or c.endswith("_end"):
+      if isinstance(want_series[c].iloc[0], str):
+        assert [str(v) for v in series[c]] == list(want_series[c]), c
+      else:   # integer index: stored as numbers
+        np.testing.assert_array_equal(series[c].to_numpy(float), want_series[c].to_numpy(float))
+    else:
+      np.testing.assert_allclose(series[c].to_numpy(float), want_series[c].to_numpy(float),
+                                 rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=c)
+  for c in meta["summary"]["columns"]:
+    np.testing.assert_allclose(summary[c].to_numpy(float),
+                               np.array(meta["summary"]["data"][c], float), rtol=1e-12,
+                               atol=1e-13, err_msg=c)
+
+
+def test_argument_errors_match_reference_behaviour():
+  _, prep, df, pre, post = _load("datacsv_nan")
+  ci = cid.CausalImpactData(df, pre, post)
+  with pytest.raises(ValueError, match="`alpha` must be between 0 and 1"):
+    lib._compute_impact(prep["fake_means"], prep["fake_trajectories"], ci, alpha=1.5)
+  with pytest.raises(TypeError, match="Received unknown"):          # causalimpact_lib_test.py:231-240
+    lib.fit_causalimpact(df, pre, post, some_unknown_arg=3)
+  with pytest.raises(KeyError):
+    cid.CausalImpactData(df, pre, post, outcome_column="nope")
+  bad = df.copy()
+  bad.iloc[5, 1] = np.nan
+  with pytest.raises(ValueError, match="cannot have any missing values"):
+    cid.CausalImpactData(bad, pre, post)
+  with pytest.raises(ValueError, match="pre_period and post_period cannot overlap"):
+    cid.CausalImpactData(df, (df.index[0], df.index[50]), (df.index[40], df.index[-1]))
+  with pytest.raises(ValueError, match="pre_period must span at least 3 time points"):
+    cid.CausalImpactData(df, (df.index[0], df.index[1]), (df.index[40], df.index[-1]))
+  with pytest.raises(ValueError, match="Period end must be after period start"):
+    cid.CausalImpactData(df, (df.index[10], df.index[1]), (df.index[40], df.index[-1]))
+  assert lib.InferenceOptions().num_warmup_steps == 100              # ceil(900 / 9)
+  assert lib.InferenceOptions(num_results=1000).num_warmup_steps == 112

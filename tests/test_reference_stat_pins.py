@@ -1,0 +1,143 @@
+"""The reference's own statistical tolerance tests (causalimpact/causalimpact_lib_test.py),
+re-stated against this build.  Each test runs on the CPU oracle (that is what pins the
+oracle) and, marked `gpu`, on the HIP path with the same tolerances.
+"""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import ref_pins_common as rp
+from causalimpact import causalimpact_lib as lib
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BACKENDS = ["oracle", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("prior_level_sd", [0.01, 0.1, 0.5])
+def test_prior_level_sd_is_used(backend, prior_level_sd):
+  # causalimpact_lib_test.py:242-271: mean(level_scale) within 20 % of the prior scale
+  data = rp.load_datacsv(GOLD)
+  res = rp.fit(backend, data, (data.index[0], data.index[19]), (data.index[20], data.index[-1]),
+               seed=(0, 0), num_results=100, num_warmup=100, prior_level_sd=prior_level_sd)
+  np.testing.assert_allclose(np.mean(res.posterior_samples.level_scale), prior_level_sd,
+                             atol=0.2 * prior_level_sd)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_model_training_with_covariates_bounds(backend):
+  # :319-338 and :286-295, :361-379
+  data = rp.load_datacsv(GOLD)
+  res = rp.fit(backend, data, (data.index[0], data.index[59]), (data.index[60], data.index[-1]),
+               seed=(1, 1), num_results=10, num_warmup=100)
+  ps = res.posterior_samples
+  assert not np.isnan(ps.level).any() and not np.isnan(ps.weights).any()
+  assert (np.asarray(ps.observation_noise_scale) <= 1.2).all()
+  assert (np.asarray(ps.level_scale) <= 1).all()
+  assert ps.weights.shape[-1] == 3            # 2 features + intercept
+  assert (np.asarray(ps.weights) == 0).sum() == 0
+  assert res.series.index.equals(data.index)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_no_covariates_dims(backend):
+  # :340-359
+  data = rp.load_datacsv(GOLD)
+  res = rp.fit(backend, data["y"], (data.index[0], data.index[59]),
+               (data.index[60], data.index[-1]), seed=3, num_results=10)
+  assert res.posterior_samples.weights is None
+  assert res.posterior_samples.observation_noise_scale.shape[0] == 10
+  assert res.series.index.equals(data.index)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("extra_tail", [False, True])
+def test_summary_cumulative_effect(backend, extra_tail):
+  # :504-535: cumulative effect ~ 250 (rtol .2) whether or not data continues after the post-period
+  n = 150 if extra_tail else 100
+  df = rp.create_test_data(5, 50, num_timesteps=n, seed=4)
+  res = rp.fit(backend, df, (df.index[0], df.index[49]), (df.index[50], df.index[99]), seed=0,
+               num_results=10)
+  np.testing.assert_allclose(res.summary.loc["cumulative", "abs_effect"], 250, rtol=0.2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("seed", [(13, 37), 14])
+def test_evaluate_is_deterministic(backend, seed):
+  # :462-502
+  df = rp.create_test_data(5, 50, seed=2)
+  a = rp.fit(backend, df.copy(), (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
+             seed=seed, num_results=10)
+  b = rp.fit(backend, df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]), seed=seed,
+             num_results=10)
+  pd.testing.assert_frame_equal(a.series, b.series)
+  pd.testing.assert_frame_equal(a.summary, b.summary)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_numeric_impact_values(backend):
+  # :655-702: effect (5, 250) to 1e-3 and relative interval widths <= 1 %
+  rng = np.random.default_rng(11)
+  n, start, effect = 100, 50, 5.0
+  y = rng.normal(size=n, scale=0.0001)
+  y[start:] += effect
+  df = pd.DataFrame({"y": y}, index=pd.date_range("2018-01-01", periods=n, freq="D"))
+  res = rp.fit(backend, df, (df.index[0], df.index[start - 1]), (df.index[start], df.index[-1]),
+               seed=None if backend == "gpu" else 5, num_results=1000)
+  s = res.summary
+  np.testing.assert_allclose(s["abs_effect"], (effect, effect * (n - start)), rtol=1e-3, atol=1e-3)
+  width = (s["abs_effect_upper"] - s["abs_effect_lower"]) / s["abs_effect"]
+  assert width["average"] <= 0.01 and width["cumulative"] <= 0.01
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_gap_and_tail_nan_layout(backend):
+  # :564-653: only observed + posterior_* survive in the gap and after the post-period;
+  # missing pre-period observations blank the effect columns (:814-844)
+  rng = np.random.default_rng(1)
+  n = 120
+  df = pd.DataFrame({"y": rng.normal(size=n), "x1": rng.normal(size=n)})
+  df.loc[2:4, "y"] = np.nan
+  res = rp.fit(backend, df, (0, 59), (70, 99), seed=1, num_results=10)
+  s = res.series
+  kept = ["observed", "posterior_mean", "posterior_lower", "posterior_upper"]
+  periods = ["pre_period_start", "pre_period_end", "post_period_start", "post_period_end"]
+  effects = s.columns.difference(kept + periods)
+  assert s.shape == (n, 14)
+  for lo, hi in [(60, 69), (100, 119)]:
+    assert s.loc[lo:hi, effects].isna().all(axis=None)
+    assert s.loc[lo:hi, kept].notna().all(axis=None)
+  assert s.loc[2:4, effects].isna().all(axis=None)
+  assert s.loc[2:4, ["posterior_mean", "posterior_lower", "posterior_upper"]].notna().all(axis=None)
+  assert (s.loc[5:59, "cumulative_effects_mean"] == 0).all()
+  assert s.loc[70:99, effects].notna().all(axis=None)
+
+
+SEASONAL_BACKENDS = ["oracle"]   # the device path gains seasonal blocks in a later step
+
+
+@pytest.mark.parametrize("backend", SEASONAL_BACKENDS)
+def test_numeric_impact_values_with_seasonality(backend):
+  # :704-773: abs_effect_sd 9.5 +- 1 without seasonal terms, 0.5 +- 0.1 with them;
+  # seasonal_levels shapes [1000, 300, 0] / [1000, 300, 3]
+  rng = np.random.default_rng(3)
+  n, start, effect = 300, 290, 2.5
+  five = [[8., 8., 4., 3., -4.][x % 5] for x in range(n)]
+  seven = [10 * [1., 4., 5., 2., -1., -2., -3.][x % 7] for x in range(n)]
+  eight = [[1., 1., 3., 3., 4.5, 2.0, -7., 0.][x % 8] for x in range(n)]
+  y = rng.normal(size=n, scale=0.4) + seven + five + eight
+  y[start:] += effect
+  df = pd.DataFrame({"y": y}, index=pd.date_range("2018-01-01", periods=n, freq="D"))
+  pre, post = (df.index[0], df.index[start - 1]), (df.index[start], df.index[-1])
+  plain = rp.fit(backend, df, pre, post, seed=1, num_results=1000)
+  seasons = [lib.Seasons(num_seasons=4, num_steps_per_season=(2, 1, 1, 1)),
+             lib.Seasons(num_seasons=7),
+             lib.Seasons(num_seasons=6,
+                         num_steps_per_season=((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1)))]
+  seasonal = rp.fit(backend, df, pre, post, seed=1, num_results=1000, seasons=seasons)
+  assert abs(plain.summary["abs_effect_sd"]["average"] - 9.5) <= 1.0
+  assert abs(seasonal.summary["abs_effect_sd"]["average"] - 0.5) <= 0.1
+  assert tuple(plain.posterior_samples.seasonal_levels.shape) == (1000, 300, 0)
+  assert tuple(seasonal.posterior_samples.seasonal_levels.shape) == (1000, 300, 3)

@@ -1,5 +1,15 @@
 """MI355X-native drop-in for the hot path of google/tfp-causalimpact.
 
-Mirrors /root/reference/causalimpact/__init__.py:29-37 (same public names).
+Same public names as /root/reference/causalimpact/__init__.py:29-37.  `plot` is out of
+scope; `summary` renders the text report.
 """
 __version__ = "0.2.0+mi355x.r1"
+
+from causalimpact.causalimpact_lib import CausalImpactAnalysis
+from causalimpact.causalimpact_lib import CausalImpactPosteriorSamples
+from causalimpact.causalimpact_lib import DataOptions
+from causalimpact.causalimpact_lib import fit_causalimpact
+from causalimpact.causalimpact_lib import InferenceOptions
+from causalimpact.causalimpact_lib import ModelOptions
+from causalimpact.causalimpact_lib import Seasons
+from causalimpact.indices import InputDateType

@@ -1,0 +1,415 @@
+"""fit_causalimpact() on MI355X: the reference's public surface over the HIP Gibbs kernel.
+
+Drop-in for /root/reference/causalimpact/causalimpact_lib.py: same function / dataclass
+names, argument meaning, result frames and error behaviour.  What changed underneath:
+
+  * `_train_causalimpact_sts` (reference :503-606) no longer builds a TFP model and traces a
+    tf.function; it packs plain arrays and calls the C-ABI (`_native.fit_gibbs`), which runs
+    every Gibbs iteration of every chain inside one persistent HIP kernel.
+  * tensors in the results are numpy arrays (subclass with a `.numpy()` method so code written
+    against the reference keeps working).
+  * extensions BASELINE.json asks for, all optional: `InferenceOptions.num_chains`,
+    `InferenceOptions.devices`, `ModelOptions.local_linear_trend`.
+
+Host-side post-processing (reference :635-1093) is re-implemented on numpy arrays and pinned
+against the reference's own output by tests/test_golden_postprocessing.py.
+"""
+import dataclasses
+import math
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import pandas as pd
+
+from causalimpact import _model
+from causalimpact import _native
+from causalimpact import data as cid
+from causalimpact import posterior_processing
+from causalimpact.indices import InputDateType
+from causalimpact.indices import OutputDateType
+from causalimpact.indices import OutputPeriodType
+
+_SeedType = Union[int, Tuple[int, int], Sequence[int]]
+_KEPT_AFTER_POST = ["observed", "posterior_mean", "posterior_lower", "posterior_upper"]
+
+
+class Tensor(np.ndarray):
+  """numpy array that also answers `.numpy()` like the reference's tf.Tensor results."""
+
+  def numpy(self):
+    return np.asarray(self)
+
+
+def _tensor(a) -> Tensor:
+  return np.asarray(a).view(Tensor)
+
+
+@dataclasses.dataclass
+class CausalImpactPosteriorSamples:
+  """Draws of the model's latents (reference :44-58).  Leading axis = pooled draws
+  (chains x num_results, chain-major)."""
+  observation_noise_scale: np.ndarray           # [draws]
+  level_scale: Optional[np.ndarray]             # [draws]
+  level: Optional[np.ndarray]                   # [draws, T]
+  weights: Optional[np.ndarray]                 # [draws, covariates + 1] or None
+  seasonal_drift_scales: Optional[np.ndarray]   # [draws, K] or None
+  seasonal_levels: Optional[np.ndarray]         # [draws, T, K]
+  slope_scale: Optional[np.ndarray] = None      # [draws]      (local_linear_trend only)
+  slope: Optional[np.ndarray] = None            # [draws, T]   (local_linear_trend only)
+
+
+@dataclasses.dataclass
+class CausalImpactAnalysis:
+  """series / summary frames + posterior draws (reference :61-144; schemas SURVEY App. E)."""
+  series: pd.DataFrame
+  summary: pd.DataFrame
+  posterior_samples: CausalImpactPosteriorSamples
+  diagnostics: Optional[Dict[str, Any]] = None   # split-R-hat per scalar when num_chains > 1
+
+
+@dataclasses.dataclass
+class DataOptions:
+  """reference :147-159.  dtype may be numpy / python float types (or anything with a
+  `.name` of "float32"/"float64"); the kernel computes in float32 either way."""
+  outcome_column: Optional[str] = None
+  standardize_data: bool = True
+  dtype: Any = np.float32
+
+
+@dataclasses.dataclass(frozen=True)
+class Seasons:
+  """One seasonal effect (reference :162-180): int, per-season tuple or per-cycle table."""
+  num_seasons: int
+  num_steps_per_season: Union[int, Tuple[int, ...], Tuple[Tuple[int, ...], ...]] = 1
+
+
+@dataclasses.dataclass
+class ModelOptions:
+  """reference :183-203 (+ local_linear_trend, the BASELINE cfg2 extension)."""
+  prior_level_sd: float = 0.01
+  seasons: List[Seasons] = dataclasses.field(default_factory=list)
+  local_linear_trend: bool = False
+
+
+@dataclasses.dataclass
+class InferenceOptions:
+  """reference :206-220 (+ num_chains / devices extensions; defaults reproduce one chain)."""
+  num_results: int = 900
+  num_warmup_steps: Optional[int] = None
+  num_chains: int = 1
+  devices: Optional[Sequence[int]] = None
+
+  def __post_init__(self):
+    if self.num_warmup_steps is None:
+      self.num_warmup_steps = math.ceil(self.num_results / 9)
+
+
+def fit_causalimpact(data: pd.DataFrame,
+                     pre_period: Tuple[InputDateType, InputDateType],
+                     post_period: Tuple[InputDateType, InputDateType],
+                     alpha: float = 0.05,
+                     seed: Optional[_SeedType] = None,
+                     data_options: Optional[DataOptions] = None,
+                     model_options: Optional[ModelOptions] = None,
+                     inference_options: Optional[InferenceOptions] = None,
+                     **kwargs) -> CausalImpactAnalysis:
+  """Fits the CausalImpact model and summarises the effect (reference :223-339)."""
+  data_options = data_options if data_options is not None else DataOptions()
+  model_options = model_options if model_options is not None else ModelOptions()
+  inference_options = inference_options if inference_options is not None else InferenceOptions()
+  experimental_model = kwargs.pop("experimental_model", None)
+  kwargs.pop("experimental_tf_function_cache_key_addition", 0)   # no graph cache to key
+  if kwargs:
+    raise TypeError(f"Received unknown {kwargs=}")
+  if experimental_model is not None:
+    raise NotImplementedError(
+        "experimental_model takes a tfp.sts.StructuralTimeSeries; this build has no TFP. Use "
+        "ModelOptions(local_linear_trend=..., seasons=...) instead.")
+
+  ci_data = cid.CausalImpactData(
+      data=data, pre_period=pre_period, post_period=post_period,
+      outcome_column=data_options.outcome_column,
+      standardize_data=data_options.standardize_data, dtype=data_options.dtype)
+  samples, posterior_means, posterior_trajectories = _train_causalimpact_sts(
+      ci_data=ci_data, prior_level_sd=model_options.prior_level_sd, seed=seed,
+      num_results=inference_options.num_results,
+      num_warmup_steps=inference_options.num_warmup_steps, dtype=data_options.dtype,
+      seasons=model_options.seasons, num_chains=inference_options.num_chains,
+      devices=inference_options.devices, local_linear_trend=model_options.local_linear_trend)
+  series, summary = _compute_impact(posterior_means=posterior_means,
+                                    posterior_trajectories=posterior_trajectories,
+                                    ci_data=ci_data, alpha=alpha)
+  has_weights = samples["weights"].shape[-1] > 0
+  has_seasons = samples["seasonal_drift_scales"].shape[-1] > 0
+  posterior = CausalImpactPosteriorSamples(
+      observation_noise_scale=_tensor(samples["observation_noise_scale"]),
+      level_scale=_tensor(samples["level_scale"]),
+      level=_tensor(samples["level"]),
+      weights=_tensor(samples["weights"]) if has_weights else None,                 # :330-331
+      seasonal_drift_scales=(_tensor(samples["seasonal_drift_scales"])
+                             if has_seasons else None),                              # :332-334
+      seasonal_levels=_tensor(samples["seasonal_levels"]),                           # :312-322
+      slope_scale=_tensor(samples["slope_scale"]) if model_options.local_linear_trend else None,
+      slope=_tensor(samples["slope"]) if model_options.local_linear_trend else None)
+  return CausalImpactAnalysis(series, summary, posterior, samples.get("diagnostics"))
+
+
+def _sanitize_seed(seed: Optional[_SeedType]) -> Tuple[int, int]:
+  """int s -> (0, s); pair -> pair; None -> fresh entropy (reference :535-543)."""
+  if seed is None:
+    return tuple(int(v) for v in np.random.SeedSequence().generate_state(2))
+  if isinstance(seed, (int, np.integer)):
+    return (0, int(seed) & 0xFFFFFFFF)
+  pair = np.asarray(seed).reshape(-1)
+  if pair.shape[0] != 2:
+    raise ValueError(f"seed must be an int or a pair of ints, got {seed!r}")
+  return (int(pair[0]) & 0xFFFFFFFF, int(pair[1]) & 0xFFFFFFFF)
+
+
+def split_rhat(draws: np.ndarray) -> float:
+  """Split-R-hat of [chains, draws] (Gelman et al. 2013); NaN for degenerate input."""
+  draws = np.asarray(draws, np.float64)
+  half = draws.shape[1] // 2
+  if half < 2:
+    return float("nan")
+  z = np.concatenate([draws[:, :half], draws[:, half:2 * half]], axis=0)
+  within = z.var(axis=1, ddof=1).mean()
+  between = half * z.mean(axis=1).var(ddof=1)
+  if within <= 0:
+    return float("nan")
+  return float(np.sqrt(((half - 1) / half * within + between / half) / within))
+
+
+def _train_causalimpact_sts(*,
+                            ci_data: cid.CausalImpactData,
+                            prior_level_sd,
+                            seed: Optional[_SeedType],
+                            num_results: int,
+                            num_warmup_steps: int,
+                            model=None,
+                            dtype=np.float32,
+                            seasons: Sequence[Seasons] = (),
+                            experimental_tf_function_cache_key_addition: int = 0,
+                            num_chains: int = 1,
+                            devices: Optional[Sequence[int]] = None,
+                            local_linear_trend: bool = False):
+  """Runs the Gibbs sampler on the GPU(s) (reference :503-606).
+
+  Returns (samples dict, posterior_means [T], posterior_trajectories [draws, T]); draws are
+  pooled over chains, chain-major.  Chain c uses RNG stream c regardless of how chains are
+  spread over `devices`, so results are invariant to the device count.
+  """
+  del experimental_tf_function_cache_key_addition
+  if model is not None:
+    raise NotImplementedError("custom tfp.sts models are not supported by the HIP path")
+  seed_pair = _sanitize_seed(seed)
+  np_dtype = cid._as_numpy_dtype(dtype)  # pylint: disable=protected-access
+
+  design = None if ci_data.feature_ts is None else np.asarray(ci_data.feature_ts.values,
+                                                              dtype=np.float64)    # :545-546
+  # Post-period handled as missing observations: forecasting == sampling (:548-562).
+  n_after = ci_data.model_after_pre_data.shape[0]
+  y = np.concatenate([np.asarray(ci_data.outcome_ts.time_series, np.float64),
+                      np.full(n_after, np.nan)])
+  mask = np.concatenate([np.asarray(ci_data.outcome_ts.is_missing, bool),
+                         np.ones(n_after, bool)])
+  T = y.shape[0]
+  outcome_sd = float(np.nanstd(np.asarray(ci_data.outcome_ts.time_series, np.float64), ddof=1))
+  num_seasons, season_change = _model.expand_seasons(seasons, T)
+  params = _model.series_params(y, mask, design, prior_level_sd=prior_level_sd,
+                                num_seasonal_blocks=len(num_seasons),
+                                has_slope=local_linear_trend, outcome_sd=outcome_sd)
+  P = 0 if design is None else design.shape[1]
+  K = len(num_seasons)
+
+  devs = list(devices) if devices else [0]
+  shares = np.array_split(np.arange(num_chains), len(devs))
+  parts = []
+  for dev, chain_ids in zip(devs, shares):
+    if len(chain_ids) == 0:
+      continue
+    pb = _native.make_problem(T=T, P=P, has_slope=local_linear_trend, num_seasons=num_seasons,
+                              num_warmup=num_warmup_steps, num_results=num_results,
+                              num_chains=len(chain_ids), chain_offset=int(chain_ids[0]),
+                              seed=seed_pair, device=dev)
+    parts.append(_native.fit_gibbs(pb, y[None], mask[None],
+                                   None if design is None else design[None], season_change,
+                                   _native.make_params([params])))
+  out = {k: np.concatenate([p[k][0] for p in parts], axis=0) for k in parts[0]}   # [C, ...]
+
+  def pool(a):   # [C, S, ...] -> [C*S, ...]
+    return a.reshape((a.shape[0] * a.shape[1],) + a.shape[2:]).astype(np_dtype, copy=False)
+
+  samples = dict(
+      observation_noise_scale=pool(out["observation_noise_scale"]),
+      level_scale=pool(out["level_scale"]), slope_scale=pool(out["slope_scale"]),
+      weights=pool(out["weights"]), level=pool(out["level"]), slope=pool(out["slope"]),
+      seasonal_drift_scales=pool(out["seasonal_drift_scales"]),
+      seasonal_levels=pool(out["seasonal_levels"]))
+  assert samples["weights"].shape[-1] == P and samples["seasonal_levels"].shape[-1] == K
+  if num_chains > 1:
+    samples["diagnostics"] = {
+        "split_rhat": {k: split_rhat(out[k]) for k in ("observation_noise_scale", "level_scale")},
+        "num_chains": num_chains}
+  posterior_means = out["posterior_means"].mean(axis=0).astype(np_dtype, copy=False)      # :627
+  posterior_trajectories = pool(out["posterior_trajectories"])                            # :631
+  return samples, posterior_means, posterior_trajectories
+
+
+# --------------------------------------------------------------------------------------
+# impact post-processing (reference :635-1093) -- numpy inside, the reference's frames outside
+# --------------------------------------------------------------------------------------
+def _compute_impact(posterior_means, posterior_trajectories, ci_data: cid.CausalImpactData,
+                    alpha: float = 0.05) -> Tuple[pd.DataFrame, pd.DataFrame]:
+  """(series, summary) from the sampler's predictive draws (reference :635-705)."""
+  if not 0 < alpha < 1:
+    raise ValueError("`alpha` must be between 0 and 1.")
+  observed_pre = ci_data.pre_data[ci_data.outcome_column]
+  observed_post = ci_data.after_pre_data[ci_data.outcome_column]
+  in_post = (observed_post.index >= ci_data.post_period[0]) & (observed_post.index <=
+                                                              ci_data.post_period[1])
+  observed_post = observed_post.loc[in_post]
+  observed_full = pd.concat([observed_pre, observed_post], axis=0)
+  quantiles = (alpha / 2.0, 1.0 - alpha / 2.0)
+  trajectories, trajectory_summary = _sample_posterior_predictive(
+      posterior_means=posterior_means, posterior_trajectories=posterior_trajectories,
+      ci_data=ci_data, quantiles=quantiles)
+  trajectory_dict = _compute_impact_trajectories(trajectories, observed_full,
+                                                 treatment_start=ci_data.post_period[0])
+  series = _compute_impact_estimates(posterior_trajectory_summary=trajectory_summary,
+                                     trajectory_dict=trajectory_dict,
+                                     observed_ts_full=observed_full, ci_data=ci_data,
+                                     quantiles=quantiles)
+  summary = _compute_summary(posterior_trajectory_summary=trajectory_summary,
+                             trajectory_dict=trajectory_dict, observed_ts_post=observed_post,
+                             post_period=ci_data.post_period, quantiles=quantiles, alpha=alpha)
+  return series, summary
+
+
+def _sample_posterior_predictive(posterior_means, posterior_trajectories,
+                                 ci_data: cid.CausalImpactData, quantiles: Tuple[float, float]):
+  """Data-scale trajectories (T x draws) and their mean/quantile summary (reference :708-767)."""
+  if any((q < 0) | (q > 1) for q in quantiles):
+    raise ValueError("All elements of `quantiles` must be in (0, 1). Got %s" % (quantiles,))
+  if quantiles[0] > quantiles[1]:
+    raise ValueError("`quantiles` must be sorted in ascending order. Got %s" % (quantiles,))
+  means = posterior_processing.process_posterior_quantities(ci_data, posterior_means,
+                                                            ["posterior_mean"])
+  trajectories = _package_posterior_trajectories(posterior_trajectories, ci_data)
+  bands = posterior_processing.calculate_trajectory_quantiles(trajectories, "posterior", quantiles)
+  return trajectories, means.join(bands)
+
+
+def _package_posterior_trajectories(posterior_trajectories,
+                                    ci_data: cid.CausalImpactData) -> pd.DataFrame:
+  """[draws, T] -> T x draws frame named sample_1..sample_n, unscaled (reference :770-790)."""
+  names = [f"sample_{i + 1}" for i in range(np.shape(posterior_trajectories)[0])]
+  return posterior_processing.process_posterior_quantities(ci_data, posterior_trajectories, names)
+
+
+def _compute_impact_trajectories(posterior_trajectories: pd.DataFrame,
+                                 observed_ts_full: pd.Series,
+                                 treatment_start: OutputDateType) -> Dict[str, pd.DataFrame]:
+  """Per-draw point effects (observed - predicted) and their running sum from the treatment
+  start; NaN observations give NaN effects and are skipped by the running sum
+  (reference :793-837)."""
+  idx, cols = posterior_trajectories.index, posterior_trajectories.columns
+  pred = posterior_trajectories.to_numpy(dtype=np.float64)
+  obs = observed_ts_full.reindex(idx).to_numpy(dtype=np.float64)
+  point = -(pred - obs[:, None])
+  base = np.where(np.asarray(idx < treatment_start)[:, None], 0.0, point)
+  holes = np.isnan(base)
+  cumulative = np.cumsum(np.where(holes, 0.0, base), axis=0)
+  cumulative[holes] = np.nan
+  return {
+      "predictions": posterior_trajectories,
+      "point_effects": pd.DataFrame(point, index=idx, columns=cols),
+      "cumulative_effects": pd.DataFrame(cumulative, index=idx, columns=cols),
+  }
+
+
+def _compute_impact_estimates(posterior_trajectory_summary: pd.DataFrame,
+                              trajectory_dict: Dict[str, pd.DataFrame],
+                              observed_ts_full: pd.Series, ci_data: cid.CausalImpactData,
+                              quantiles: Tuple[float, float]) -> pd.DataFrame:
+  """The 14-column `series` frame over the full input index (reference :840-931)."""
+  idx = posterior_trajectory_summary.index
+  obs = observed_ts_full.reindex(idx)
+  point_mean = obs - posterior_trajectory_summary["posterior_mean"]
+  base = point_mean.where(~(idx < ci_data.post_period[0]), 0.0)
+  cum_mean = base.cumsum()                                 # skips NaN like the reference
+  frame = pd.concat([
+      obs.rename("observed"), posterior_trajectory_summary,
+      point_mean.rename("point_effects_mean"),
+      posterior_processing.calculate_trajectory_quantiles(trajectory_dict["point_effects"],
+                                                          "point_effects", quantiles),
+      cum_mean.rename("cumulative_effects_mean"),
+      posterior_processing.calculate_trajectory_quantiles(trajectory_dict["cumulative_effects"],
+                                                          "cumulative_effects", quantiles),
+  ], axis=1)
+  effect_cols = frame.columns.difference(_KEPT_AFTER_POST)
+  # between pre- and post-period, and after the post-period: predictions only (:899-907)
+  outside = (((frame.index > ci_data.pre_period[1]) & (frame.index < ci_data.post_period[0])) |
+             (frame.index > ci_data.post_period[1]))
+  frame.loc[outside, effect_cols] = np.nan
+  # no observation => no effect (NaN, not 0) (:909-915)
+  frame.loc[np.isnan(frame["observed"].to_numpy(dtype=np.float64)), effect_cols] = np.nan
+  frame = frame.reindex(ci_data.data.index, fill_value=np.nan)
+  frame["observed"] = ci_data.data[ci_data.outcome_column]
+  frame["pre_period_start"] = ci_data.pre_period[0]
+  frame["pre_period_end"] = ci_data.pre_period[1]
+  frame["post_period_start"] = ci_data.post_period[0]
+  frame["post_period_end"] = ci_data.post_period[1]
+  return frame
+
+
+def _compute_summary(posterior_trajectory_summary: pd.DataFrame,
+                     trajectory_dict: Dict[str, pd.DataFrame], observed_ts_post: pd.Series,
+                     post_period: OutputPeriodType, quantiles: Tuple[float, float],
+                     alpha: float) -> pd.DataFrame:
+  """The 2 x 15 `summary` frame over the post-period (reference :934-1093)."""
+
+  def window(frame):
+    keep = (frame.index >= post_period[0]) & (frame.index <= post_period[1])
+    return frame.loc[keep]
+
+  post_mean = window(posterior_trajectory_summary)["posterior_mean"].to_numpy(dtype=np.float64)
+  pred = window(trajectory_dict["predictions"]).to_numpy(dtype=np.float64)        # [T_post, draws]
+  point = window(trajectory_dict["point_effects"]).to_numpy(dtype=np.float64)
+  obs = observed_ts_post.to_numpy(dtype=np.float64)
+  obs_mean, obs_sum = float(np.nanmean(obs)), float(np.nansum(obs))
+
+  def sd(v):
+    return float(np.std(v, ddof=1))
+
+  def band(v):
+    lo, hi = np.quantile(v, quantiles)
+    return float(lo), float(hi)
+
+  pred_mean, pred_sum = pred.mean(axis=0), pred.sum(axis=0)
+  with np.errstate(invalid="ignore"):
+    point_mean_t, point_sum_t = np.nanmean(point, axis=0), np.nansum(point, axis=0)
+  rel = obs_sum / pred_sum - 1.0
+  avg_pred, cum_pred = float(post_mean.mean()), float(post_mean.sum())
+  rows = {
+      "actual": (obs_mean, obs_sum),
+      "predicted": (avg_pred, cum_pred),
+      "predicted_lower": (band(pred_mean)[0], band(pred_sum)[0]),
+      "predicted_upper": (band(pred_mean)[1], band(pred_sum)[1]),
+      "predicted_sd": (sd(pred_mean), sd(pred_sum)),
+      "abs_effect": (obs_mean - avg_pred, obs_sum - cum_pred),
+      "abs_effect_lower": (band(point_mean_t)[0], band(point_sum_t)[0]),
+      "abs_effect_upper": (band(point_mean_t)[1], band(point_sum_t)[1]),
+      "abs_effect_sd": (sd(point_mean_t), sd(point_sum_t)),
+      "rel_effect": (float(rel.mean()),) * 2,
+      "rel_effect_lower": (band(rel)[0],) * 2,
+      "rel_effect_upper": (band(rel)[1],) * 2,
+      "rel_effect_sd": (sd(rel),) * 2,
+  }
+  summary = pd.DataFrame({k: {"average": v[0], "cumulative": v[1]} for k, v in rows.items()})
+  # one-sided tail area of the observed total among the sampled totals, the observed total
+  # included so that p stays in (0, 1)   (:1077-1091)
+  pool = np.append(pred_sum, obs_sum)
+  summary["p_value"] = min(float((obs_sum <= pool).mean()), float((obs_sum >= pool).mean()))
+  summary["alpha"] = alpha
+  return summary

@@ -103,3 +103,38 @@ def test_invariants_pinned_by_reference_tests():
   assert (got["level_scale"] <= spec["outcome_sd"] + 1e-6).all()
   # :376-379  P <= 3 => no exactly-zero weights
   assert (got["weights"] == 0).sum() == 0
+
+
+@pytest.mark.parametrize("T,p,has_slope,seasons", [
+    (60, 0, 0, ((3, 1),)),                              # smallest: one block, no regression
+    (90, 1, 0, ((4, (2, 1, 1, 1)), (2, 3))),            # per-season lengths + an n=2 block
+    (120, 4, 1, ((7, 1),)),                             # weekly effect + trend + flips (P=5)
+    (300, 0, 0, ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))),
+])
+def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, seasons):
+  """Seasonal kernel (full n-effect state, fast state smoother) vs the oracle's
+  (n-1)-dimensional Durbin-Koopman draw, same random numbers."""
+  from causalimpact import _model
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
+  rng = np.random.default_rng(0)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0) + 0.1 * rng.normal(size=T)
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
+  counts, flags = _model.expand_seasons(seasons, T)
+  S, K = 4, len(seasons)
+  pb = _native.make_problem(T=T, P=spec["P"], has_slope=has_slope, num_seasons=counts,
+                            num_warmup=0, num_results=S, seed=(2, 6))
+  got = _native.fit_gibbs(pb, y[None], mask[None], None if X is None else X[None], flags,
+                          _native.make_params([spec]))
+  w = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=0, seed=(2, 6))
+  np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=5e-3)
+  np.testing.assert_allclose(got["seasonal_levels"][0, 0], w["seasonal"], atol=5e-3)
+  np.testing.assert_allclose(got["seasonal_drift_scales"][0, 0], w["drift_scales"], rtol=2e-2)
+  np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=5e-3)
+  np.testing.assert_allclose(got["level_scale"][0, 0], w["level_scale"], rtol=5e-3)
+  if has_slope:
+    np.testing.assert_allclose(got["slope"][0, 0], w["slope"], atol=5e-3)
+  if spec["P"]:
+    np.testing.assert_allclose(got["weights"][0, 0], w["weights"], atol=5e-3)
+  np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
+  np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=5e-3)
+  assert got["seasonal_levels"].shape == (1, 1, S, T, K)

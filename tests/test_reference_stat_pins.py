@@ -115,7 +115,7 @@ def test_gap_and_tail_nan_layout(backend):
   assert s.loc[70:99, effects].notna().all(axis=None)
 
 
-SEASONAL_BACKENDS = ["oracle"]   # the device path gains seasonal blocks in a later step
+SEASONAL_BACKENDS = BACKENDS
 
 
 @pytest.mark.parametrize("backend", SEASONAL_BACKENDS)

@@ -11,6 +11,10 @@
 
 #include "../../include/causalimpact_amd.h"
 #include "ci_kernels.h"
+#define CI_SEASONAL_DECL_ONLY
+#include "ci_seasonal.h"
+
+extern "C" void* ci_gibbs_seasonal_fn(void);
 
 // One object file per (D, L) instantiation (ci_inst.hip).
 #define CI_DECL(D, L)                                                                          \
@@ -144,6 +148,11 @@ struct ci_session {
   DevBuf<ci::DevSeriesParams> sp;
   DevBuf<long long> prof;
   bool profile = false;
+  // seasonal models
+  int D_full = 0, dred = 0;
+  DevBuf<uint8_t> season_change;
+  DevBuf<ci::DevSeasonalParams> ssp;
+  DevBuf<float> p1_chol, o_drift, o_seasonal;
 };
 
 extern "C" {
@@ -164,12 +173,20 @@ static int validate(const ci_problem* pb) {
     return fail("ABI mismatch: caller %d, library %d", pb->abi_version, CI_ABI_VERSION);
   if (pb->T < 3) return fail("T must be >= 3, got %d", pb->T);
   if (pb->P < 0 || pb->P > ci::MAXP) return fail("P must be in [0, %d], got %d", ci::MAXP, pb->P);
-  if (pb->num_blocks != 0)
-    return fail("seasonal blocks are not implemented on the device path yet (num_blocks=%d)",
-                pb->num_blocks);
+  if (pb->num_blocks < 0 || pb->num_blocks > CI_MAX_BLOCKS)
+    return fail("num_blocks must be in [0, %d], got %d", CI_MAX_BLOCKS, pb->num_blocks);
+  if (pb->num_blocks > 0) {
+    int dfull = pb->has_slope ? 2 : 1;
+    for (int k = 0; k < pb->num_blocks; ++k) {
+      if (pb->num_seasons[k] < 2) return fail("num_seasons[%d] must be >= 2", k);
+      dfull += pb->num_seasons[k];
+    }
+    if (dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
+    if (pb->P > 16) return fail("seasonal models support P <= 16 on the device path, got %d", pb->P);
+  }
   if (pb->num_warmup < 0 || pb->num_results < 1) return fail("need num_warmup >= 0, num_results >= 1");
   if (pb->num_chains < 1 || pb->num_series < 1) return fail("need num_chains >= 1, num_series >= 1");
-  if (steps_per_thread(pb->T) == 0)
+  if (pb->num_blocks == 0 && steps_per_thread(pb->T) == 0)
     return fail("T=%d exceeds the register-resident path (max %d)", pb->T, ci::NT * 16);
   return 0;
 }
@@ -177,22 +194,36 @@ static int validate(const ci_problem* pb) {
 int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask, const float* X,
                       const uint8_t* season_change, const ci_series_params* params,
                       ci_session** out) {
-  (void)season_change;
   if (validate(pb)) return 1;
   if (!y || !mask || !params || !out) return fail("NULL argument");
+  if (pb->num_blocks > 0 && !season_change) return fail("season_change is NULL but num_blocks > 0");
   if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
   HIP_TRY(hipSetDevice(pb->device));
   ci_session* s = new ci_session();
   s->pb = *pb;
   const int T = pb->T, P = pb->P, B = pb->num_series, C = pb->num_chains, S = pb->num_results;
   const int D = pb->has_slope ? 2 : 1;
-  s->L = steps_per_thread(T);
-  // X lives in LDS when the whole layout fits in 160 KiB (leave room for a second block).
-  const ci::LdsLayout with_x = ci::make_layout(P, D, ci::NT * s->L, 1);
-  s->x_in_lds = (P > 0 && with_x.total <= 150 * 1024) ? 1 : 0;
-  s->lds_bytes = ci::make_layout(P, D, ci::NT * s->L, s->x_in_lds).total;
-  s->fn = pick_kernel(D, s->L);
-  if (!s->fn) { delete s; return fail("no kernel for L=%d", s->L); }
+  const int K = pb->num_blocks;
+  if (K == 0) {
+    s->L = steps_per_thread(T);
+    // X lives in LDS when the whole layout fits in 160 KiB (leave room for a second block).
+    const ci::LdsLayout with_x = ci::make_layout(P, D, ci::NT * s->L, 1);
+    s->x_in_lds = (P > 0 && with_x.total <= 150 * 1024) ? 1 : 0;
+    s->lds_bytes = ci::make_layout(P, D, ci::NT * s->L, s->x_in_lds).total;
+    s->fn = pick_kernel(D, s->L);
+    if (!s->fn) { delete s; return fail("no kernel for L=%d", s->L); }
+  } else {
+    s->D_full = D;
+    s->dred = D;
+    for (int k = 0; k < K; ++k) { s->D_full += pb->num_seasons[k]; s->dred += pb->num_seasons[k] - 1; }
+    s->lds_bytes = ci::make_slayout(T, P, K, s->D_full, s->dred, pb->has_slope).total;
+    if (s->lds_bytes > 160 * 1024) {
+      const size_t need = s->lds_bytes;
+      delete s;
+      return fail("seasonal model needs %zu bytes of LDS per chain (max 163840): reduce T", need);
+    }
+    s->fn = (KernelFn)ci_gibbs_seasonal_fn();
+  }
   HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)s->lds_bytes));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -214,6 +245,52 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   HIP_TRY(s->o_slope.alloc(pb->has_slope ? BCS * T : 0));
   HIP_TRY(s->o_pm.alloc((size_t)B * C * T));
   HIP_TRY(s->o_traj.alloc(BCS * T));
+  if (K > 0) {
+    HIP_TRY(s->season_change.alloc((size_t)K * T));
+    HIP_TRY(s->ssp.alloc(B));
+    HIP_TRY(s->p1_chol.alloc((size_t)B * s->dred * s->dred));
+    HIP_TRY(s->o_drift.alloc(BCS * K));
+    HIP_TRY(s->o_seasonal.alloc(BCS * T * K));
+    HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
+    std::vector<ci::DevSeasonalParams> ssh(B);
+    std::vector<float> ch((size_t)B * s->dred * s->dred, 0.f);
+    for (int b = 0; b < B; ++b) {
+      const ci_series_params& q = params[b];
+      ssh[b].drift_conc = q.drift_conc; ssh[b].drift_scale = q.drift_scale; ssh[b].drift_ub = q.drift_ub;
+      ssh[b].init_seasonal_scale = q.init_seasonal_scale;
+      for (int k = 0; k < CI_MAX_BLOCKS; ++k) ssh[b].drift_scale0[k] = q.drift_scale0[k];
+      // lower Cholesky factor of the prior covariance of x_0 in the (n-1)-effect coordinates:
+      // diag(level, [slope]) (+) sd^2 (I - 11'/n) per block   
+      const int dr = s->dred;
+      std::vector<double> A((size_t)dr * dr, 0.0);
+      A[0] = q.init_level_scale * q.init_level_scale;
+      int o = 1;
+      if (pb->has_slope) { A[(size_t)1 * dr + 1] = q.init_slope_scale * q.init_slope_scale; o = 2; }
+      for (int k = 0; k < K; ++k) {
+        const int n = pb->num_seasons[k];
+        const double v = q.init_seasonal_scale * q.init_seasonal_scale;
+        for (int i = 0; i < n - 1; ++i)
+          for (int j = 0; j < n - 1; ++j)
+            A[(size_t)(o + i) * dr + o + j] = v * ((i == j ? 1.0 : 0.0) - 1.0 / n);
+        o += n - 1;
+      }
+      for (int j = 0; j < dr; ++j) {
+        double sdiag = A[(size_t)j * dr + j];
+        for (int k2 = 0; k2 < j; ++k2) sdiag -= A[(size_t)j * dr + k2] * A[(size_t)j * dr + k2];
+        const double ljj = std::sqrt(sdiag);
+        A[(size_t)j * dr + j] = ljj;
+        for (int i = j + 1; i < dr; ++i) {
+          double t2 = A[(size_t)i * dr + j];
+          for (int k2 = 0; k2 < j; ++k2) t2 -= A[(size_t)i * dr + k2] * A[(size_t)j * dr + k2];
+          A[(size_t)i * dr + j] = t2 / ljj;
+        }
+        for (int i = 0; i < j; ++i) A[(size_t)i * dr + j] = 0.0;
+      }
+      for (size_t e = 0; e < A.size(); ++e) ch[(size_t)b * dr * dr + e] = (float)A[e];
+    }
+    HIP_TRY(hipMemcpy(s->ssp.p, ssh.data(), B * sizeof(ci::DevSeasonalParams), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->p1_chol.p, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
 
   // host-side staging: zero masked outcomes, transpose X to feature-major, count observations
   std::vector<float> yh(BT);
@@ -281,8 +358,19 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
-  hipLaunchKernelGGL(s->fn, dim3(pb.num_series * pb.num_chains), dim3(ci::NT), s->lds_bytes,
-                     s->stream, a);
+  if (pb.num_blocks > 0) {
+    ci::SArgs sa;
+    sa.k = a;
+    sa.K = pb.num_blocks; sa.has_slope = pb.has_slope; sa.dred = s->dred;
+    for (int k = 0; k < ci::SMAXK; ++k) sa.nseas[k] = k < pb.num_blocks ? pb.num_seasons[k] : 0;
+    sa.season_change = s->season_change.p; sa.ssp = s->ssp.p; sa.p1_chol = s->p1_chol.p;
+    sa.out_drift = s->o_drift.p; sa.out_seasonal = s->o_seasonal.p;
+    hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(pb.num_series * pb.num_chains), dim3(64),
+                       s->lds_bytes, s->stream, sa);
+  } else {
+    hipLaunchKernelGGL(s->fn, dim3(pb.num_series * pb.num_chains), dim3(ci::NT), s->lds_bytes,
+                       s->stream, a);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -304,6 +392,8 @@ int ci_session_fetch(ci_session* s, ci_outputs* o) {
   HIP_TRY(get(o->level, s->o_level));
   HIP_TRY(get(o->posterior_means, s->o_pm));
   HIP_TRY(get(o->posterior_trajectories, s->o_traj));
+  HIP_TRY(get(o->seasonal_drift_scales, s->o_drift));
+  HIP_TRY(get(o->seasonal_levels, s->o_seasonal));
   if (o->slope) {
     if (s->pb.has_slope) HIP_TRY(get(o->slope, s->o_slope));
     else memset(o->slope, 0, s->o_level.n * sizeof(float));
@@ -341,6 +431,8 @@ int ci_session_destroy(ci_session* s) {
   s->y.release(); s->Xt.release(); s->o_obs.release(); s->o_lscale.release(); s->o_sscale.release();
   s->o_w.release(); s->o_level.release(); s->o_slope.release(); s->o_pm.release();
   s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->sp.release(); s->prof.release();
+  s->season_change.release(); s->ssp.release(); s->p1_chol.release(); s->o_drift.release();
+  s->o_seasonal.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);

@@ -112,7 +112,7 @@ int ci_session_fetch(ci_session* session, ci_outputs* outputs);
 /* Bytes the kernel must move per run (algorithmic bytes, DESIGN.md "Roofline"). */
 int ci_session_algorithmic_bytes(const ci_session* session, double* bytes);
 /* Developer aid: when enabled, the next ci_session_run() accumulates shader-clock cycles of
- * the kernel's phases (block 0) into 16 counters; cycles16 (optional) receives the counters
+ * the kernel's phases (block 0) into 32 counters; cycles16 (optional, 32 entries) receives the counters
  * of the previous run.  Slot meaning: DESIGN.md "Time budget". */
 int ci_session_profile(ci_session* session, int enable, int64_t* cycles16);
 int ci_session_destroy(ci_session* session);

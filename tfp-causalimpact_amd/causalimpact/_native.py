@@ -215,7 +215,7 @@ class Session:
 
   def profile(self, enable=True):
     """Enables per-phase cycle counters for the next run(); returns the previous run's."""
-    cyc = np.zeros(16, np.int64)
+    cyc = np.zeros(32, np.int64)
     _check(self._lib.ci_session_profile(self._h, int(enable), cyc.ctypes.data))
     return cyc
 

@@ -18,7 +18,7 @@ extern "C" void* ci_gibbs_seasonal_fn(void);
 
 // One object file per (D, L) instantiation (ci_inst.hip).
 #define CI_DECL(D, L)                                                                          \
-  extern "C" void* ci_gibbs_fn_d##D##_l##L(void);                                              \
+  extern "C" void* ci_gibbs_fn_d##D##_l##L(int);                                              \
   extern "C" void ci_launch_dk_d##D##_l##L(int, const float*, const uint8_t*, float, float,    \
                                            float, float, float, float, uint32_t, uint32_t,     \
                                            uint32_t, uint32_t, float*);
@@ -81,8 +81,8 @@ static __global__ void test_rng_kernel(uint32_t k0, uint32_t k1, uint32_t chain,
 
 namespace {
 using KernelFn = void (*)(ci::KArgs);
-KernelFn pick_kernel(int D, int L) {
-#define CI_CASE(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs_fn_d##DD##_l##LL();
+KernelFn pick_kernel(int D, int L, int pm) {
+#define CI_CASE(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs_fn_d##DD##_l##LL(pm);
   CI_CASE(1, 1) CI_CASE(1, 2) CI_CASE(1, 4) CI_CASE(1, 8) CI_CASE(1, 16)
   CI_CASE(2, 1) CI_CASE(2, 2) CI_CASE(2, 4) CI_CASE(2, 8) CI_CASE(2, 16)
 #undef CI_CASE
@@ -210,7 +210,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     const ci::LdsLayout with_x = ci::make_layout(P, D, ci::NT * s->L, 1);
     s->x_in_lds = (P > 0 && with_x.total <= 150 * 1024) ? 1 : 0;
     s->lds_bytes = ci::make_layout(P, D, ci::NT * s->L, s->x_in_lds).total;
-    s->fn = pick_kernel(D, s->L);
+    const int pm = (P == 0) ? 0 : ((P <= 16 && s->x_in_lds) ? 1 : 2);
+    s->fn = pick_kernel(D, s->L, pm);
     if (!s->fn) { delete s; return fail("no kernel for L=%d", s->L); }
   } else {
     s->D_full = D;
@@ -348,8 +349,8 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
   a.out_pred_mean = s->o_pm.p; a.out_traj = s->o_traj.p;
   a.prof = nullptr;
   if (s->profile) {
-    if (!s->prof.p) HIP_TRY(s->prof.alloc(16));
-    HIP_TRY(hipMemsetAsync(s->prof.p, 0, 16 * sizeof(long long), s->stream));
+    if (!s->prof.p) HIP_TRY(s->prof.alloc(32));
+    HIP_TRY(hipMemsetAsync(s->prof.p, 0, 32 * sizeof(long long), s->stream));
     a.prof = s->prof.p;
   }
   if (pb.P > 0) {
@@ -419,8 +420,8 @@ int ci_session_profile(ci_session* s, int enable, int64_t* cycles16) {
   if (!s) return fail("session is NULL");
   s->profile = enable != 0;
   if (cycles16) {
-    if (!s->prof.p) { memset(cycles16, 0, 16 * sizeof(int64_t)); return 0; }
-    HIP_TRY(hipMemcpy(cycles16, s->prof.p, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (!s->prof.p) { memset(cycles16, 0, 32 * sizeof(int64_t)); return 0; }
+    HIP_TRY(hipMemcpy(cycles16, s->prof.p, 32 * sizeof(int64_t), hipMemcpyDeviceToHost));
   }
   return 0;
 }

@@ -1,5 +1,6 @@
 // ci_inst.hip -- one (D, L) instantiation of the Gibbs kernel per object file so the
-// instantiations build in parallel (make -j).  Compile with -DCI_D=<1|2> -DCI_L=<1|2|4|8|16>.
+// instantiations build in parallel (make -j).  Compile with -DCI_D=<1|2> -DCI_L=<1|2|4|8|16>;
+// the three regression modes (ci_kernels.h "PM") are instantiated together.
 #include <hip/hip_runtime.h>
 
 #include "ci_kernels.h"
@@ -16,9 +17,11 @@
 
 extern "C" {
 
-// Returns the device-function handle of gibbs_kernel<CI_D, CI_L>.
-void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(void) {
-  return (void*)(&ci::gibbs_kernel<CI_D, CI_L>);
+// Returns the device-function handle of gibbs_kernel<CI_D, CI_L, pm>.
+void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(int pm) {
+  if (pm == 0) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 0>);
+  if (pm == 1) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 1>);
+  return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 2>);
 }
 
 // Launches the one-draw Durbin-Koopman test kernel on the default stream.

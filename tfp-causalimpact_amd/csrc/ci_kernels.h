@@ -159,10 +159,56 @@ __device__ __forceinline__ E block_scan_excl_bwd(const E& tot, Op op, const E& i
   return op(ex, ws);
 }
 
+// L consecutive floats of an LDS row starting at a 4*L-byte aligned index, as wide loads.
+template <int L>
+__device__ __forceinline__ void lds_row_load(const float* p, float (&v)[L]) {
+  if constexpr (L % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < L / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else if constexpr (L == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = p[0];
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// Same sum through the DPP crossbar (no LDS round trips): inclusive scan inside each row of
+// 16 lanes (row_shr 1, 2, 4, 8), then row_bcast15 / row_bcast31 carry the row totals; lane 63
+// holds the wave total, returned wave-uniform.  ~6 dependent VALU ops instead of 6
+// ds_bpermute round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF,
+                                                        true));
+}
+// lane 63 of the result holds the wave total (every lane holds its inclusive prefix)
+__device__ __forceinline__ float wave_prefix_dpp(float v) {
+  v = dpp_add<0x111, 0xF>(v);
+  v = dpp_add<0x112, 0xF>(v);
+  v = dpp_add<0x114, 0xF>(v);
+  v = dpp_add<0x118, 0xF>(v);
+  v = dpp_add<0x142, 0xA>(v);
+  v = dpp_add<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add<0x111, 0xF>(v);   // row_shr:1
+  v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);   // row_shr:8
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 -> rows 1, 3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ------------------------------------------------------------------------------------
@@ -424,174 +470,220 @@ __device__ __forceinline__ void sweep_pair(const double* sa, double* da, int n, 
 }
 
 // ---- register-resident regression block (P <= 16) ---------------------------------------
-// Lane j < P holds column j of the swept matrices: c[i] = Aug[i][j], p[i] = Pri[i][j] (i < P),
-// cb = Aug[P][j] (the swept X~'targets row); `corner` = Aug[P][P] is wave-uniform.  A sweep
-// on pivot j broadcasts lane j's column with v_readlane: no LDS, no barriers.  The columns are
-// ext_vector_type values so that the wave-uniform pivot index lowers to indexed register
-// moves: one compact copy of the code (the instruction cache is 64 KB per CU pair; a
-// 16-way static switch over pivots made this section fetch-bound) and no scratch.
-typedef double dvec16 __attribute__((ext_vector_type(16)));
-
-struct RegCols {
-  dvec16 c, p;
-  double cb, corner;
+// Quadrant layout: lane = j + 16 q holds rows 4q..4q+3 of column j of the swept augmented
+// matrix (c) and of the swept prior precision (p), plus -- replicated over q -- the swept
+// X~'targets entry cb_j and the two diagonals.  A sweep on the (wave-uniform) pivot k is 4
+// rows of work per lane: the pivot column/row arrive through ds_bpermute / v_readlane, no LDS
+// memory and no barrier.  Because every lane tracks its own diagonal, ALL flip proposals are
+// evaluated at once; they are re-evaluated only after an accepted flip, which reproduces the
+// sequential scan of spike_and_slab._resample_all_features decision for decision.
+// (Register indices must be compile-time constants or the compiler demotes the columns to
+// scratch: the row-within-quadrant index of the pivot is dispatched through a 4-way switch.)
+struct QCols {
+  double c[4], p[4];
+  double cb, diag, pdiag, corner;
 };
 
-struct StepCtx {
-  double b0;          // prior scale of sigma^2_obs
-  double a_post_m1;   // posterior concentration - 1
-  double logit_pi;
-};
+__device__ __forceinline__ double bperm_d(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 
-// One event on feature j (wave-uniform): either a forced sweep-in, or a Gibbs flip proposal
-// (spike_and_slab `_resample_all_features` step) followed by the sweep when accepted.
-__device__ __forceinline__ void step_regs(RegCols& m, unsigned long long& S, int j, bool force,
-                                          double u, const StepCtx& sc, int lane) {
-  const bool in = ((S >> j) & 1ull) != 0ull;
-  const double cjj = m.c[j];
-  const double pjj = m.p[j];
-  bool flip = true;
-  if (!force) {
-    // lane j's numbers are the real ones; the other lanes compute harmless garbage
-    const double sg = in ? -1.0 : 1.0;
-    const double ap = sg * cjj;         // Schur pivot (feature out) or V_jj (feature in), > 0
-    const double pp = sg * pjj;
-    const double rap = fast_rcp(ap);
-    const double beta_old = sc.b0 + 0.5 * m.corner;
-    const double x = -0.5 * sg * m.cb * m.cb * rap * fast_rcp(beta_old);  // beta_new/beta_old - 1
-    const double delta = 0.5 * (double)__logf((float)(pp * rap)) + sg * sc.logit_pi -
-                         sc.a_post_m1 * fast_log1p(x);
-    const float prob = 1.0f / (1.0f + __expf(-(float)delta));
-    flip = ((__ballot(u < (double)prob) >> j) & 1ull) != 0ull;
-  }
-  if (flip) {
-    const double sgn = in ? -1.0 : 1.0;   // inverse sweep removes an included feature
-    const bool isk = lane == j;
-    const double cbk = readlane_d(m.cb, j);
-    const double rd = fast_rcp(readlane_d(cjj, j));
-    const double rdp = fast_rcp(readlane_d(pjj, j));
-    const double t = isk ? 1.0 : cjj * rd;
-    const double tp = isk ? 1.0 : pjj * rdp;
+template <int KR>
+__device__ __forceinline__ void sweep_q_kr(QCols& m, int k, bool reverse, int lane) {
+  const double sgn = reverse ? -1.0 : 1.0;
+  const int kq = k >> 2, j = lane & 15, q = lane >> 4;
+  const double ckr = m.c[KR], pkr = m.p[KR];
+  const double rd = fast_rcp(readlane_d(ckr, k + 16 * kq));
+  const double rdp = fast_rcp(readlane_d(pkr, k + 16 * kq));
+  const double rowk = bperm_d(ckr, j + 16 * kq);      // A[k][j]
+  const double prowk = bperm_d(pkr, j + 16 * kq);
+  const double cbk = readlane_d(m.cb, k);
+  const bool isk = j == k;
+  const double t = isk ? 1.0 : rowk * rd;
+  const double tp = isk ? 1.0 : prowk * rdp;
+  double colk[4], pcolk[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {      // entry i == j is overwritten below
-      const double ci = readlane_d(m.c[i], j);
-      const double pi = readlane_d(m.p[i], j);
-      m.c[i] = isk ? sgn * ci * rd : m.c[i] - ci * t;
-      m.p[i] = isk ? sgn * pi * rdp : m.p[i] - pi * tp;
-    }
-    m.c[j] = isk ? -rd : sgn * t;
-    m.p[j] = isk ? -rdp : sgn * tp;
-    m.cb = isk ? sgn * cbk * rd : m.cb - cbk * t;
-    m.corner -= cbk * cbk * rd;
-    S ^= (1ull << j);
+  for (int r = 0; r < 4; ++r) {                       // all 16 ds_bpermute in flight together
+    colk[r] = bperm_d(m.c[r], k + 16 * q);            // A[4q + r][k]
+    pcolk[r] = bperm_d(m.p[r], k + 16 * q);
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    m.c[r] = isk ? sgn * colk[r] * rd : m.c[r] - colk[r] * t;
+    m.p[r] = isk ? sgn * pcolk[r] * rdp : m.p[r] - pcolk[r] * tp;
+  }
+  const double nck = isk ? -rd : sgn * t, npk = isk ? -rdp : sgn * tp;   // row k of my column
+  m.c[KR] = (q == kq) ? nck : m.c[KR];
+  m.p[KR] = (q == kq) ? npk : m.p[KR];
+  m.cb = isk ? sgn * cbk * rd : m.cb - cbk * t;
+  m.diag = isk ? -rd : m.diag - rowk * rowk * rd;
+  m.pdiag = isk ? -rdp : m.pdiag - prowk * prowk * rdp;
+  m.corner -= cbk * cbk * rd;
+}
+
+__device__ __forceinline__ void sweep_q(QCols& m, int k, bool reverse, int lane) {
+  switch (k & 3) {
+    case 0: sweep_q_kr<0>(m, k, reverse, lane); break;
+    case 1: sweep_q_kr<1>(m, k, reverse, lane); break;
+    case 2: sweep_q_kr<2>(m, k, reverse, lane); break;
+    default: sweep_q_kr<3>(m, k, reverse, lane); break;
+  }
+}
+
+// One pivot of the right-looking Cholesky in the quadrant layout (row-in-quadrant KR static).
+template <int KR>
+__device__ __forceinline__ void chol_q_kr(double (&l)[4], int k, int lane) {
+  const int kq = k >> 2, j = lane & 15, q = lane >> 4;
+  const double lkr = l[KR];
+  const double dk = readlane_d(lkr, k + 16 * kq);
+  const double rs = fast_rsqrt(dk);
+  const double ljk = bperm_d(lkr, j + 16 * kq) * rs;      // L[j][k], j > k (symmetry)
+  const bool isk = j == k, trailing = j > k;
+  double cik[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) cik[r] = bperm_d(l[r], k + 16 * q);   // A[i][k], in flight together
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * q + r;
+    const double c = cik[r] * rs;                                   // L[i][k]
+    l[r] = (i > k) ? (isk ? c : (trailing ? l[r] - c * ljk : l[r])) : l[r];
+  }
+  l[KR] = (isk && q == kq) ? dk * rs : l[KR];             // sqrt(d)
+}
+
+// One step of the back substitution L' u = z for pivot i (row-in-quadrant IR static).
+template <int IR>
+__device__ __forceinline__ void backsub_q_ir(const double (&l)[4], int i, float z, double& acc,
+                                             double& umine, int lane) {
+  const int iq = i >> 2, j = lane & 15, q = lane >> 4;
+  const double lir = l[IR];
+  const double tot = readlane_d(acc, i) + readlane_d(acc, i + 16) + readlane_d(acc, i + 32) +
+                     readlane_d(acc, i + 48);
+  const double lii = readlane_d(lir, i + 16 * iq);
+  const double zi = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), i));
+  const double ui = (zi - tot) * fast_rcp(lii);
+  if (q == iq) acc += lir * ui;          // row i of every pending column
+  if (j == i) umine = ui;
 }
 
 __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
                                                        const DevSeriesParams& sp,
-                                                       double prev_obs_scale, const Rng& rng,
-                                                       uint32_t iter, int lane, Prof& prof) {
+                                                       double prev_obs_scale, double g_obs,
+                                                       const Rng& rng, uint32_t iter, int lane,
+                                                       Prof& prof) {
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
-  const bool live = lane < P;
-  const int col = live ? lane : 0;
+  const int j = lane & 15, q = lane >> 4;
+  const bool live = j < P;
+  const int col = live ? j : 0;
   const double* __restrict__ omega = R.omega;
   const double* __restrict__ xtx = R.xtx;
-  RegCols m;
+  QCols m;
+  double l[4];   // unswept M = Omega * prev_var + XtX, kept for the weights' Cholesky
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * q + r;
     double om = 0.0, xx = 0.0;
     if (live && i < P) {
       om = omega[i * P + col] * prev_var;
       xx = xtx[i * P + col];
     }
-    m.p[i] = om;
-    m.c[i] = om + xx;
+    m.p[r] = om;
+    m.c[r] = om + xx;
+    l[r] = om + xx;
+  }
+  {
+    const double od = live ? omega[col * P + col] * prev_var : 1.0;
+    m.pdiag = od;
+    m.diag = live ? od + xtx[col * P + col] : 1.0;
   }
   m.cb = live ? R.bvec[col] : 0.0;
   m.corner = R.bvec[P];
-  unsigned long long pending = __ballot(live && (all_in || R.w[col] != 0.f));
   unsigned long long S = 0ull;
-  // visiting order = stable argsort of P uniforms; lane s also holds the flip uniform of step s
-  double uflip = 2.0;
-  int rank = -1;
-  StepCtx sc;
-  sc.b0 = sp.obs_scale;
-  sc.a_post_m1 = a_post - 1.0;
-  sc.logit_pi = 0.0;
+  {
+    unsigned long long pending = __ballot(q == 0 && live && (all_in || R.w[col] != 0.f));
+    for (; pending != 0ull; pending &= pending - 1ull) {   // sweep in last iteration's features
+      const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+      sweep_q(m, k, false, lane);
+      S |= 1ull << k;
+    }
+  }
+  prof.tick(9);
   if (!all_in) {
-    const double uperm = live ? uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)lane) : 2.0;
-    uflip = live ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)lane) : 2.0;
-    rank = 0;
+    // visiting order = stable argsort of P uniforms (rank_j = step at which feature j is visited)
+    const double uperm = live ? uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j) : 2.0;
+    int rank = 0;
     for (int kk = 0; kk < P; ++kk) {
       const double uk = readlane_d(uperm, kk);
-      rank += (uk < uperm || (uk == uperm && kk < lane)) ? 1 : 0;
+      rank += (uk < uperm || (uk == uperm && kk < j)) ? 1 : 0;
     }
-    if (!live) rank = -1;
-    sc.logit_pi = (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
-  }
-  int s = 0;
-  for (;;) {
-    int j;
-    bool force;
-    double u = 2.0;
-    if (pending != 0ull) {                       // sweep in the features included last iteration
-      j = __ffsll((long long)pending) - 1;
-      pending &= pending - 1ull;
-      force = true;
-    } else if (!all_in && s < P) {               // then one flip proposal per feature
-      j = __ffsll((long long)__ballot(rank == s)) - 1;
-      u = readlane_d(uflip, s);
-      force = false;
-      ++s;
-    } else {
-      break;
+    const double uflip = live ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)rank) : 2.0;
+    const double logit_pi =
+        (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
+    int s_cur = 0;
+    for (;;) {
+      // every lane evaluates the flip of ITS feature against the current swept state
+      const bool in = ((S >> j) & 1ull) != 0ull;
+      const double sg = in ? -1.0 : 1.0;
+      const double rap = fast_rcp(sg * m.diag);          // 1 / Schur pivot (out) or 1 / V_jj (in)
+      const double beta_old = sp.obs_scale + 0.5 * m.corner;
+      const double x = -0.5 * sg * m.cb * m.cb * rap * fast_rcp(beta_old);
+      const double delta = 0.5 * (double)__logf((float)(sg * m.pdiag * rap)) + sg * logit_pi -
+                           (a_post - 1.0) * fast_log1p(x);
+      const float prob = 1.0f / (1.0f + __expf(-(float)delta));
+      const bool acc = live && q == 0 && rank >= s_cur && uflip < (double)prob;
+      // the earliest accepted proposal in visiting order is the one the sequential scan takes
+      unsigned long long cand = __ballot(acc);
+      if (cand == 0ull) break;
+      int best = -1, best_rank = 1 << 20;
+      for (; cand != 0ull; cand &= cand - 1ull) {
+        const int jj = __ffsll((long long)cand) - 1;
+        const int rj = __builtin_amdgcn_readlane(rank, jj);
+        if (rj < best_rank) { best_rank = rj; best = jj; }
+      }
+      best = __builtin_amdgcn_readfirstlane(best);
+      sweep_q(m, best, ((S >> best) & 1ull) != 0ull, lane);
+      S ^= 1ull << best;
+      s_cur = best_rank + 1;
     }
-    step_regs(m, S, __builtin_amdgcn_readfirstlane(j), force, u, sc, lane);
   }
   prof.tick(10);
   const double beta_post = sp.obs_scale + 0.5 * m.corner;
-  const double g = gamma_wave(a_post, rng, iter, SITE_OBSVAR, 0, lane);
-  double var = beta_post * fast_rcp(g);
+  double var = beta_post * fast_rcp(g_obs);
   if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
   const double new_scale = (double)__fsqrt_rn((float)var);
   prof.tick(11);
 
-  // weights_S ~ N(mean, var * M_S^{-1}):  M_S = L L' (right-looking, column-per-lane; the
-  // trailing matrix stays symmetric, so lane j reads L[j][k] as its OWN row-k entry), then
-  // L' u = z with lane i owning column i.
+  // weights_S ~ N(mean, var * M_S^{-1}):  M_S = L L' (right-looking; the trailing matrix stays
+  // symmetric, so lane (j, q) reads L[j][k] as row k of its OWN column), then L' u = z.
   float zf[1];
   fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)col, zf);
-  dvec16 l;   // unswept M = Omega * prev_var + XtX
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-    l[i] = (live && i < P) ? omega[i * P + col] * prev_var + xtx[i * P + col] : 0.0;
   for (unsigned long long mm = S; mm != 0ull; mm &= mm - 1ull) {
-    const int kq = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
-    const double lk = l[kq];
-    const double rs = fast_rsqrt(readlane_d(lk, kq));
-    const bool isk = lane == kq;
-    const bool trailing = lane > kq;          // columns < kq are already final
-    const double ljk = lk * rs;               // L[lane][kq] by symmetry (lane > kq)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {            // rows i <= kq get garbage that is never read,
-      const double cik = readlane_d(l[i], kq) * rs;   // except row kq, rewritten below
-      l[i] = isk ? cik : (trailing && i > kq ? l[i] - cik * ljk : l[i]);
+    const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+    switch (k & 3) {
+      case 0: chol_q_kr<0>(l, k, lane); break;
+      case 1: chol_q_kr<1>(l, k, lane); break;
+      case 2: chol_q_kr<2>(l, k, lane); break;
+      default: chol_q_kr<3>(l, k, lane); break;
     }
-    if (isk) l[kq] = ljk;                      // sqrt(d)
   }
   double acc = 0.0, umine = 0.0;
   for (unsigned long long mm = S; mm != 0ull;) {
     const int i = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mm));   // descending
     mm &= ~(1ull << i);
-    const double li = l[i];
-    const double ui = readlane_d(((double)zf[0] - acc) * fast_rcp(li), i);
-    acc += li * ui;
-    if (lane == i) umine = ui;
+    switch (i & 3) {
+      case 0: backsub_q_ir<0>(l, i, zf[0], acc, umine, lane); break;
+      case 1: backsub_q_ir<1>(l, i, zf[0], acc, umine, lane); break;
+      case 2: backsub_q_ir<2>(l, i, zf[0], acc, umine, lane); break;
+      default: backsub_q_ir<3>(l, i, zf[0], acc, umine, lane); break;
+    }
   }
-  const bool mine = live && ((S >> col) & 1ull) != 0ull;
-  if (live) R.w[lane] = mine ? (float)(m.cb + new_scale * umine) : 0.f;
+  if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(m.cb + new_scale * umine) : 0.f;
   wave_sync();
   prof.tick(12);
   return new_scale;
@@ -603,8 +695,8 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
 // experimental_use_weight_adjustment=True (causalimpact_lib.py:387-388).
 __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
                                                   const DevSeriesParams& sp, double prev_obs_scale,
-                                                  const Rng& rng, uint32_t iter, int lane,
-                                                  Prof& prof) {
+                                                  double g_obs, const Rng& rng, uint32_t iter,
+                                                  int lane, Prof& prof) {
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
@@ -676,8 +768,7 @@ __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
   prof.tick(10);
   const double* A = R.aug[cur];
   const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
-  const double g = gamma_wave(a_post, rng, iter, SITE_OBSVAR, 0, lane);
-  double var = beta_post / g;
+  double var = beta_post / g_obs;
   if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
   const double new_scale = sqrt(var);
 
@@ -780,9 +871,9 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_nz = take(sizeof(int) * Pp);
   l.off_perm = take(sizeof(int) * Pp);
   l.off_idx = take(sizeof(int) * Pp);
-  l.off_w = take(sizeof(float) * Pp);
+  l.off_w = take(sizeof(float) * (Pp > 16 ? Pp : 16));
   l.off_scal = take(sizeof(float) * 16);
-  l.off_red = take(sizeof(float) * NW * (Pp + 4));
+  l.off_red = take(sizeof(float) * NW * ((Pp > 16 ? Pp : 16) + 4));
   l.off_slots = take(sizeof(float) * 3 * NW * 16);
   l.off_xlast = take(sizeof(float) * NT * D);
   l.off_tg = take(sizeof(float) * 16);
@@ -795,29 +886,65 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
 //   * reduce the per-wave partial sums,
 //   * draw the scales of iteration it-1 from the path drawn in it-1 and emit its scalars,
 //   * draw (sigma^2_obs, weights) of iteration it.
+// PM (regression mode) prunes dead code per instantiation -- the whole per-iteration path must
+// stay inside the 64 KB instruction cache: 0 = no regression, 1 = P <= 16 with X in LDS
+// (register-resident block), 2 = general (LDS block, X possibly streamed from L2).
+template <int PM>
 static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int lane) {
-  const int P = cx->P, T = cx->T;
+  const int P = (PM == 0) ? 0 : cx->P, T = cx->T;
   const RegLds& R = cx->R;
   Prof prof;
   prof.start(cx->prof, cx->prof != nullptr && lane == 0);
-  for (int j = lane; j < P + 3; j += 64) {
-    double s = 0.0;
-    for (int w = 0; w < NW; ++w) s += (double)cx->red[w * (P + 4) + j];
-    R.bvec[j] = s;
+  {
+    const int RS = (P > 16 ? P : 16) + 4;
+    for (int j = lane; j < P + 3; j += 64) {
+      const int src = j < P ? j : RS - 4 + (j - P);
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += (double)cx->red[w * RS + src];
+      R.bvec[j] = s;
+    }
   }
   wave_sync();
   double obs_scale = cx->obs_scale, level_scale = cx->level_scale, slope_scale = cx->slope_scale;
   double emit_obs = obs_scale;
+  // all gamma draws of this section in one wave pass: level / slope / obs scale of iteration
+  // it-1 (gibbs_sampler._resample_scale) and sigma^2_obs of iteration it (spike-and-slab)
+  GammaReq req[4];
+  double gam[4] = {1.0, 1.0, 1.0, 1.0};
+  int nreq = 0, i_level = -1, i_slope = -1, i_obs_prev = -1, i_obsvar = -1;
   if (it > 0) {
     const uint32_t pit = (uint32_t)(it - 1);
-    level_scale = scale_draw(cx->sp.level_conc, cx->sp.level_scale, cx->sp.level_ub,
-                             (double)(T - 1), R.bvec[P + 1], cx->rng, pit, SITE_LEVEL_SCALE, lane);
+    i_level = nreq;
+    req[nreq++] = GammaReq{cx->sp.level_conc + 0.5 * (double)(T - 1), pit, SITE_LEVEL_SCALE, 0};
+    if (cx->D == 2) {
+      i_slope = nreq;
+      req[nreq++] = GammaReq{cx->sp.slope_conc + 0.5 * (double)(T - 1), pit, SITE_SLOPE_SCALE, 0};
+    }
+    if (P == 0) {
+      i_obs_prev = nreq;
+      req[nreq++] = GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, pit, SITE_OBS_SCALE, 0};
+    }
+  }
+  if (P > 0 && it < cx->n_iter) {
+    i_obsvar = nreq;
+    req[nreq++] = GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, (uint32_t)it, SITE_OBSVAR, 0};
+  }
+  for (int qq = nreq; qq < 4; ++qq) req[qq] = GammaReq{1.0, 0, 0, 0};
+  if (nreq > 0) gamma_wave4(req, nreq, gam, cx->rng, lane);
+  auto clipped_scale = [](double scale, double ss, double g, double ub) {
+    const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
+    return s < ub ? s : ub;
+  };
+  if (it > 0) {
+    level_scale = clipped_scale(cx->sp.level_scale, R.bvec[P + 1], gam[i_level < 0 ? 0 : i_level],
+                                cx->sp.level_ub);
     if (cx->D == 2)
-      slope_scale = scale_draw(cx->sp.slope_conc, cx->sp.slope_scale, cx->sp.slope_ub,
-                               (double)(T - 1), R.bvec[P + 2], cx->rng, pit, SITE_SLOPE_SCALE, lane);
+      slope_scale = clipped_scale(cx->sp.slope_scale, R.bvec[P + 2], gam[i_slope < 0 ? 0 : i_slope],
+                                  cx->sp.slope_ub);
     if (P == 0)
-      obs_scale = scale_draw(cx->sp.obs_conc, cx->sp.obs_scale, cx->sp.obs_ub, cx->sp.n_obs,
-                             R.bvec[P], cx->rng, pit, SITE_OBS_SCALE, lane);
+      obs_scale = clipped_scale(cx->sp.obs_scale, R.bvec[P], gam[i_obs_prev < 0 ? 0 : i_obs_prev],
+                                cx->sp.obs_ub);
     emit_obs = obs_scale;
     const int s = it - 1 - cx->W;
     if (s >= 0) {
@@ -832,10 +959,11 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int
   }
   prof.tick(8);
   if (P > 0 && it < cx->n_iter) {
-    if (P <= 16)
-      obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, cx->rng, (uint32_t)it, lane, prof);
-    else
-      obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, cx->rng, (uint32_t)it, lane, prof);
+    const double g_obs = gam[i_obsvar < 0 ? 0 : i_obsvar];
+    if constexpr (PM == 1)
+      obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof);
+    else if constexpr (PM == 2)
+      obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof);
   }
   if (lane == 0) {
     cx->obs_scale = obs_scale;
@@ -849,13 +977,13 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int
   wave_sync();
 }
 
-template <int D, int L>
+template <int D, int L, int PM>
 __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int series = blockIdx.x / a.C, chain = blockIdx.x % a.C;
-  const int T = a.T, P = a.P;
+  const int T = a.T, P = (PM == 0) ? 0 : a.P;
   constexpr int TPAD = NT * L;
   const LdsLayout lay = make_layout(P, D, TPAD, a.x_in_lds);
   SerialCtx* cx = (SerialCtx*)(smem + lay.off_ctx);
@@ -866,6 +994,7 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
   float* wls = (float*)(smem + lay.off_w);
   const float* Xs = (const float*)(smem + lay.off_x);
   const size_t chain_lin = (size_t)series * a.C + chain;
+  const int RS = (P > 16 ? P : 16) + 4;   // stride of the per-wave partial-sum rows
 
   Rng rng;
   rng.k0 = a.seed0;
@@ -962,19 +1091,47 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
         tg[l] = obs ? (yv[l] - lev[l]) : 0.f;
         yty = fmaf(tg[l], tg[l], yty);
       }
-      for (int j = 0; j < P; ++j) {
-        float pj = 0.f;
-        if (a.x_in_lds) {
+      prof.tick(15);
+      if constexpr (PM == 1) {
+        // register-resident path: 16 independent accumulators, DPP reductions interleave
+        float pj[16];
+        // branch-free: rows >= P re-read row P-1 and are masked out, so all 16 wide LDS loads
+        // are in flight before the first FMA (per-feature branches exposed the LDS latency)
 #pragma unroll
-          for (int l = 0; l < L; ++l) pj = fmaf(Xs[j * TPAD + t0 + l], tg[l], pj);
-        } else {
+        for (int j = 0; j < 16; ++j) {
+          const int jj = j < P ? j : P - 1;
+          float xr[L];
+          lds_row_load<L>(Xs + jj * TPAD + t0, xr);
+          float s = 0.f;
 #pragma unroll
-          for (int l = 0; l < L; ++l)
-            if (t0 + l < T) pj = fmaf(Xg[(size_t)j * T + t0 + l], tg[l], pj);
+          for (int l = 0; l < L; ++l) s = fmaf(xr[l], tg[l], s);
+          pj[j] = s;
         }
-        const float s = wave_sum(pj);
-        if (lane == 0) red[wave * (P + 4) + j] = s;
+        prof.tick(16);
+        // 16 independent DPP prefix chains interleave; lane 63 (which holds the totals)
+        // stores them in one predicated block
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pj[j] = wave_prefix_dpp(pj[j]);
+        if (lane == 63) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) red[wave * RS + j] = pj[j];
+        }
+      } else if constexpr (PM == 2) {
+        for (int j = 0; j < P; ++j) {
+          float pj = 0.f;
+          if (a.x_in_lds) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) pj = fmaf(Xs[j * TPAD + t0 + l], tg[l], pj);
+          } else {
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+              if (t0 + l < T) pj = fmaf(Xg[(size_t)j * T + t0 + l], tg[l], pj);
+          }
+          const float s = wave_sum_dpp(pj);
+          if (lane == 0) red[wave * RS + j] = s;
+        }
       }
+      prof.tick(13);
       // level / slope increments ending at the owned steps need the previous thread's last state
       xlast[tid * D] = lev[L - 1];
       if constexpr (D == 2) xlast[tid * D + 1] = slp[L - 1];
@@ -998,18 +1155,19 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
         pl = lev[l];
         if constexpr (D == 2) ps = slp[l];
       }
-      const float s0 = wave_sum(yty), s1 = wave_sum(ssl), s2 = wave_sum(sss);
-      if (lane == 0) {
-        red[wave * (P + 4) + P] = s0;
-        red[wave * (P + 4) + P + 1] = s1;
-        red[wave * (P + 4) + P + 2] = s2;
+      prof.tick(14);
+      const float s0 = wave_prefix_dpp(yty), s1 = wave_prefix_dpp(ssl), s2 = wave_prefix_dpp(sss);
+      if (lane == 63) {
+        red[wave * RS + RS - 4] = s0;
+        red[wave * RS + RS - 3] = s1;
+        red[wave * RS + RS - 2] = s2;
       }
     }
     __syncthreads();
     prof.tick(0);
 
     // ---- serial section: scale draws for iteration it-1, regression draw for iteration it
-    if (wave == 0) serial_section(cx, it, lane);
+    if (wave == 0) serial_section<PM>(cx, it, lane);
     __syncthreads();
     prof.tick(1);
 
@@ -1061,15 +1219,29 @@ __global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
     float resid[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) xw[l] = 0.f;
-    for (int j = 0; j < P; ++j) {
-      const float wj = wls[j];
-      if (a.x_in_lds) {
+    if constexpr (PM == 1) {
+      float wv[16];
+      lds_row_load<16>(wls, wv);           // the weights vector is padded to 16 floats
 #pragma unroll
-        for (int l = 0; l < L; ++l) xw[l] = fmaf(Xs[j * TPAD + t0 + l], wj, xw[l]);
-      } else {
+      for (int j = 0; j < 16; ++j) {
+        const int jj = j < P ? j : P - 1;
+        const float wj = j < P ? wv[j] : 0.f;
+        float xr[L];
+        lds_row_load<L>(Xs + jj * TPAD + t0, xr);
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-          if (t0 + l < T) xw[l] = fmaf(Xg[(size_t)j * T + t0 + l], wj, xw[l]);
+        for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
+      }
+    } else if constexpr (PM == 2) {
+      for (int j = 0; j < P; ++j) {
+        const float wj = wls[j];
+        if (a.x_in_lds) {
+#pragma unroll
+          for (int l = 0; l < L; ++l) xw[l] = fmaf(Xs[j * TPAD + t0 + l], wj, xw[l]);
+        } else {
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+            if (t0 + l < T) xw[l] = fmaf(Xg[(size_t)j * T + t0 + l], wj, xw[l]);
+        }
       }
     }
 #pragma unroll

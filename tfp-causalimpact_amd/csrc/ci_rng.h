@@ -185,4 +185,56 @@ static __device__ __noinline__ double gamma_wave(double alpha, const Rng& g, uin
   return readlane_d(gval, first);
 }
 
+// Up to four independent Gamma(alpha_q, 1) draws in one pass: quadrant q = lane >> 4 evaluates
+// attempts of draw q (attempt index = 16 * round + (lane & 15)); identical results to four
+// gamma_wave() calls because the first accepted attempt index wins either way.
+struct GammaReq {
+  double alpha;
+  uint32_t iter, site, sub;
+};
+static __device__ __forceinline__ void gamma_wave4(const GammaReq (&req)[4], int nreq, double (&out)[4],
+                                                const Rng& g, int lane) {
+  const int q = lane >> 4, at = lane & 15;
+  const GammaReq mine = req[q < nreq ? q : 0];
+  const double a = mine.alpha < 1.0 ? mine.alpha + 1.0 : mine.alpha;
+  const double d = a - 1.0 / 3.0;
+  const double c = fast_rsqrt(9.0 * d);
+  unsigned pending = (1u << nreq) - 1u;
+#pragma unroll 1
+  for (int round = 0; round < 4 && pending != 0u; ++round) {
+    const U4 r = site_call(g, mine.iter, mine.site, mine.sub, (uint32_t)(16 * round + at));
+    float xf, unused;
+    box_muller_f(r.x, r.y, xf, unused);
+    const double x = (double)xf;
+    const double cx = c * x;
+    const double t = 1.0 + cx;
+    const double v = t * t * t;
+    bool ok = false;
+    double gval = d;
+    if (v > 0.0) {
+      const double lhs = (double)__logf(u01f(r.z));
+      ok = lhs < 0.5 * x * x + d * (1.0 - v + 3.0 * fast_log1p(cx));
+      gval = d * v;
+      if (mine.alpha < 1.0) gval *= pow(u01d(r.w), 1.0 / mine.alpha);
+    }
+    const unsigned long long m = __ballot(ok && q < nreq);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      if ((pending >> qq) & 1u) {
+        const unsigned bits = (unsigned)((m >> (16 * qq)) & 0xFFFFull);
+        if (bits != 0u) {
+          out[qq] = readlane_d(gval, 16 * qq + __ffs((int)bits) - 1);
+          pending &= ~(1u << qq);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq)
+    if ((pending >> qq) & 1u) {   // 64 rejections: unreachable in practice (oracle: same fallback)
+      const double aa = req[qq].alpha < 1.0 ? req[qq].alpha + 1.0 : req[qq].alpha;
+      out[qq] = aa - 1.0 / 3.0;
+    }
+}
+
 }  // namespace ci

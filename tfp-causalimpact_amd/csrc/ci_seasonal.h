@@ -292,7 +292,10 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       }
     }
     if (it == n_iter) break;
-    if (P > 0) obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, rng, (uint32_t)it, lane, prof);
+    if (P > 0) {
+      const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
+      obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof);
+    }
     wave_sync();
 
     // ---- (3) residual, normals of this iteration

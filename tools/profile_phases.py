@@ -16,7 +16,8 @@ from causalimpact import _synthetic as syn  # noqa: E402
 SLOTS = ["partial sums + reduce", "serial section (wave 0) total", "emit", "residual X w",
          "dk: normals + prior-sim scan", "dk: filter elements + scan", "dk: local Kalman pass",
          "dk: backward scan + fix-up", "serial: gather + scale draws", "serial: build + sweep-in",
-         "serial: flips", "serial: gamma + active set", "serial: chol + weights"]
+         "serial: flips", "serial: gamma + active set", "serial: chol + weights",
+         "  (0a) X'targets partials + DPP sums", "  (0b) boundary exchange + increments", "  (0a1) loop top + targets", "  (0a2) X reads + fma"]
 
 
 def main():

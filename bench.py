@@ -61,15 +61,25 @@ def _cpu_baseline(y, mask, X, min_seconds=10.0):
          "sample": f"{chains} chains x ({W}+{S}) Gibbs iterations of the cfg2 series, float64 C "
                    f"restatement (oracle/ci_oracle.c), {dt1:.1f} s"}
   if ncpu > 1:
-    per = max(1, math.ceil(chains / 2))
+    # one process per core (capped at 64 so the sample stays ~10-20 s), 4 chains each
+    nproc, per = min(ncpu, 64), 4
     ctx = mp.get_context("fork")
-    t1 = time.perf_counter()
-    with ctx.Pool(ncpu) as pool:
-      pool.starmap(_cpu_chain, [(y, mask, X, spec, S, W, 1000 + i) for i in range(ncpu * per)])
-    dtn = time.perf_counter() - t1
-    res["all_cores"] = {"value": ncpu * per * S / dtn, "cores": ncpu,
-                        "sample": f"{ncpu * per} chains over {ncpu} processes, {dtn:.1f} s"}
+    with ctx.Pool(nproc) as pool:
+      pool.map(_cpu_noop, range(nproc))          # start the workers before timing
+      t1 = time.perf_counter()
+      pool.starmap(_cpu_chain, [(y, mask, X, spec, S, W, 1000 + i) for i in range(nproc * per)],
+                   chunksize=per)
+      dtn = time.perf_counter() - t1
+    res["all_cores"] = {"value": nproc * per * S / dtn, "cores": nproc,
+                        "sample": f"{nproc * per} chains over {nproc} processes "
+                                  f"(host has {ncpu} cores), {dtn:.1f} s"}
   return res
+
+
+def _cpu_noop(_):
+  from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
+  orc.lib()
+  return 0
 
 
 def _cpu_chain(y, mask, X, spec, S, W, chain):
@@ -79,14 +89,14 @@ def _cpu_chain(y, mask, X, spec, S, W, chain):
   return 0
 
 
-def _split_rhat(x):
-  """x: [chains, draws] -> split-R-hat (Gelman et al. 2013)."""
-  c, n = x.shape
-  h = n // 2
-  z = np.concatenate([x[:, :h], x[:, h:2 * h]], axis=0)
-  w = z.var(axis=1, ddof=1).mean()
-  b = h * z.mean(axis=1).var(ddof=1)
-  return float(np.sqrt(((h - 1) / h * w + b / h) / w))
+def _pmc_traffic():
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc.json, written
+  by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+  path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+  if not os.path.exists(path):
+    return None
+  with open(path) as f:
+    return json.load(f).get("hbm_bytes_per_launch")
 
 
 def main():
@@ -146,16 +156,13 @@ def main():
   sess.run()
   res = sess.fetch()
   dt_pcie = time.perf_counter() - t1
-  obs = res["observation_noise_scale"][0]            # [C, S]
-  lvl = res["level_scale"][0]
-  if dist is not None:
-    import torch  # pylint: disable=import-outside-toplevel
-    mine = torch.from_numpy(np.stack([obs, lvl])).cuda()
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    allc = torch.cat(gathered, dim=1).cpu().numpy()
-    obs, lvl = allc[0], allc[1]
-  rhat = {"observation_noise_scale": _split_rhat(obs), "level_scale": _split_rhat(lvl)}
+  # chain gather + split-R-hat across ranks (RCCL all-gather / all-reduce; no-op at N=1)
+  from causalimpact import _distributed  # pylint: disable=import-outside-toplevel
+  local = {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
+  comb = _distributed.fit_sharded(lambda first, count: local, world * C,
+                                  gather_keys=("posterior_means",),
+                                  device="cuda" if dist is not None else None)
+  rhat = comb["split_rhat"]
 
   samples_per_step = world * C * CFG["num_results"]
   value = samples_per_step * args.steps / dt
@@ -172,8 +179,8 @@ def main():
                  "chains_per_gpu": C, "chains_total": world * C,
                  "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
       "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                   "kernel": "ci::gibbs_kernel<2,4>", "kernel_ms": k_ms,
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(),
+                   "kernel": "ci::gibbs_kernel<2,4,1>", "kernel_ms": k_ms,
                    "algorithmic_bytes_per_launch": alg_bytes,
                    "note": "one workgroup per chain: 8 of 256 CUs busy; the fit is bound by the "
                            "(W+S)-long sequential Gibbs dependency, not by HBM (DESIGN.md)"},

@@ -138,3 +138,28 @@ def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, season
   np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
   np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=5e-3)
   assert got["seasonal_levels"].shape == (1, 1, S, T, K)
+
+
+def test_batch_of_series_equals_single_series_runs():
+  """BASELINE cfg5 shape in miniature: B independent series in one launch (one workgroup per
+  (series, chain)) give exactly what B separate launches give."""
+  T, p, B, C = 120, 3, 5, 2
+  ys, masks, Xs, specs = [], [], [], []
+  for b in range(B):
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 100 + b)
+    ys.append(y); masks.append(mask); Xs.append(X)
+    specs.append(orc.default_spec(y, mask, X))
+  P = specs[0]["P"]
+  pb = _native.make_problem(T=T, P=P, has_slope=0, num_warmup=4, num_results=6, num_chains=C,
+                            num_series=B, seed=(8, 8))
+  batch = _native.fit_gibbs(pb, np.stack(ys), np.stack(masks), np.stack(Xs), None,
+                            _native.make_params(specs))
+  for b in range(B):
+    pb1 = _native.make_problem(T=T, P=P, has_slope=0, num_warmup=4, num_results=6, num_chains=C,
+                               num_series=1, seed=(8, 8))
+    one = _native.fit_gibbs(pb1, ys[b][None], masks[b][None], Xs[b][None], None,
+                            _native.make_params([specs[b]]))
+    for k in ("level", "weights", "observation_noise_scale", "posterior_trajectories",
+              "posterior_means"):
+      np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
+  assert not np.array_equal(batch["level"][0], batch["level"][1])

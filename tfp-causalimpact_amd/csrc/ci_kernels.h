@@ -131,10 +131,11 @@ __device__ __forceinline__ E block_scan_excl_fwd(const E& tot, Op op, const E& i
   }
   if (lane == 63) lds_store_e(slots + wave * N, incl);
   __syncthreads();
-  E wp = ident;
-  for (int ww = 0; ww < wave; ++ww) wp = op(wp, lds_load_e<E>(slots + ww * N));
   E ex = shfl_up_e(incl, 1);
   if (lane == 0) ex = ident;
+  if (wave == 0) return ex;
+  E wp = lds_load_e<E>(slots);
+  for (int ww = 1; ww < wave; ++ww) wp = op(wp, lds_load_e<E>(slots + ww * N));
   return op(wp, ex);
 }
 
@@ -152,10 +153,11 @@ __device__ __forceinline__ E block_scan_excl_bwd(const E& tot, Op op, const E& i
   }
   if (lane == 0) lds_store_e(slots + wave * N, incl);
   __syncthreads();
-  E ws = ident;
-  for (int ww = wave + 1; ww < NW; ++ww) ws = op(ws, lds_load_e<E>(slots + ww * N));
   E ex = shfl_down_e(incl, 1);
   if (lane == 63) ex = ident;
+  if (wave == NW - 1) return ex;
+  E ws = lds_load_e<E>(slots + (wave + 1) * N);
+  for (int ww = wave + 2; ww < NW; ++ww) ws = op(ws, lds_load_e<E>(slots + ww * N));
   return op(ex, ws);
 }
 
@@ -978,7 +980,10 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int
 }
 
 template <int D, int L, int PM>
-__global__ __launch_bounds__(NT) void gibbs_kernel(KArgs a) {
+#ifndef CI_MIN_WAVES
+#define CI_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

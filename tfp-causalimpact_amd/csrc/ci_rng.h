@@ -116,16 +116,20 @@ __device__ __forceinline__ double uniform_d(const Rng& g, uint32_t iter, uint32_
 
 // ---- cheap float64 helpers for the serial (wave 0) section.  IEEE f64 division / sqrt /
 // log expand to long ocml sequences; a float32 hardware seed plus Newton steps is ~10 ops.
+// (v_rcp_f32 / v_rsq_f32 are accurate to ~1 ulp = 6e-8; one Newton step squares that to
+//  ~1e-14, a second one reaches the float64 rounding floor.  Each step is 2-3 DEPENDENT f64
+//  ops at ~10+ cycles with one wave per SIMD, so the second step is kept only for rcp.)
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = (double)__builtin_amdgcn_rcpf((float)d);
-  r = r * (2.0 - d * r);
-  r = r * (2.0 - d * r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
   return r;
 }
 __device__ __forceinline__ double fast_rsqrt(double d) {
   double r = (double)__builtin_amdgcn_rsqf((float)d);
-  r = r * (1.5 - 0.5 * d * r * r);
-  r = r * (1.5 - 0.5 * d * r * r);
+  const double h = 0.5 * d;
+  r = fma(r, fma(-h * r, r, 0.5), r);
+  r = fma(r, fma(-h * r, r, 0.5), r);
   return r;
 }
 // log(1 + x): atanh series (|x| < 0.3, ~1e-15) else float32 hardware log (|log| is large

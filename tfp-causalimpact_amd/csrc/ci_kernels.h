@@ -492,91 +492,98 @@ __device__ __forceinline__ double bperm_d(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
-template <int KR>
+template <int KR, bool WITH_P>
 __device__ __forceinline__ void sweep_q_kr(QCols& m, int k, bool reverse, int lane) {
   const double sgn = reverse ? -1.0 : 1.0;
   const int kq = k >> 2, j = lane & 15, q = lane >> 4;
   const double ckr = m.c[KR], pkr = m.p[KR];
   const double rd = fast_rcp(readlane_d(ckr, k + 16 * kq));
-  const double rdp = fast_rcp(readlane_d(pkr, k + 16 * kq));
   const double rowk = bperm_d(ckr, j + 16 * kq);      // A[k][j]
-  const double prowk = bperm_d(pkr, j + 16 * kq);
   const double cbk = readlane_d(m.cb, k);
   const bool isk = j == k;
   const double t = isk ? 1.0 : rowk * rd;
-  const double tp = isk ? 1.0 : prowk * rdp;
+  double rdp = 0.0, prowk = 0.0, tp = 0.0;
+  if constexpr (WITH_P) {
+    rdp = fast_rcp(readlane_d(pkr, k + 16 * kq));
+    prowk = bperm_d(pkr, j + 16 * kq);
+    tp = isk ? 1.0 : prowk * rdp;
+  }
   double colk[4], pcolk[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {                       // all 16 ds_bpermute in flight together
+  for (int r = 0; r < 4; ++r) {                       // all ds_bpermute in flight together
     colk[r] = bperm_d(m.c[r], k + 16 * q);            // A[4q + r][k]
-    pcolk[r] = bperm_d(m.p[r], k + 16 * q);
+    if constexpr (WITH_P) pcolk[r] = bperm_d(m.p[r], k + 16 * q);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     m.c[r] = isk ? sgn * colk[r] * rd : m.c[r] - colk[r] * t;
-    m.p[r] = isk ? sgn * pcolk[r] * rdp : m.p[r] - pcolk[r] * tp;
+    if constexpr (WITH_P) m.p[r] = isk ? sgn * pcolk[r] * rdp : m.p[r] - pcolk[r] * tp;
   }
-  const double nck = isk ? -rd : sgn * t, npk = isk ? -rdp : sgn * tp;   // row k of my column
-  m.c[KR] = (q == kq) ? nck : m.c[KR];
-  m.p[KR] = (q == kq) ? npk : m.p[KR];
+  m.c[KR] = (q == kq) ? (isk ? -rd : sgn * t) : m.c[KR];       // row k of my column
   m.cb = isk ? sgn * cbk * rd : m.cb - cbk * t;
   m.diag = isk ? -rd : m.diag - rowk * rowk * rd;
-  m.pdiag = isk ? -rdp : m.pdiag - prowk * prowk * rdp;
   m.corner -= cbk * cbk * rd;
+  if constexpr (WITH_P) {
+    m.p[KR] = (q == kq) ? (isk ? -rdp : sgn * tp) : m.p[KR];
+    m.pdiag = isk ? -rdp : m.pdiag - prowk * prowk * rdp;
+  }
 }
 
+template <bool WITH_P>
 __device__ __forceinline__ void sweep_q(QCols& m, int k, bool reverse, int lane) {
   switch (k & 3) {
-    case 0: sweep_q_kr<0>(m, k, reverse, lane); break;
-    case 1: sweep_q_kr<1>(m, k, reverse, lane); break;
-    case 2: sweep_q_kr<2>(m, k, reverse, lane); break;
-    default: sweep_q_kr<3>(m, k, reverse, lane); break;
+    case 0: sweep_q_kr<0, WITH_P>(m, k, reverse, lane); break;
+    case 1: sweep_q_kr<1, WITH_P>(m, k, reverse, lane); break;
+    case 2: sweep_q_kr<2, WITH_P>(m, k, reverse, lane); break;
+    default: sweep_q_kr<3, WITH_P>(m, k, reverse, lane); break;
   }
 }
 
-// One pivot of the right-looking Cholesky in the quadrant layout (row-in-quadrant KR static).
+// Swept prior precision carried from one Gibbs iteration to the next.  Omega itself never
+// changes (only its scale sigma^2_prev does, handled analytically) and the included set at the
+// start of an iteration is the set at the end of the previous one, so the prior block needs a
+// sweep only when a flip is accepted -- not a rebuild every iteration.
+struct PriorCarry {
+  double p[4], pdiag;
+  unsigned long long S;
+  int valid;
+};
+
+// Reverse sweep of the posterior block only (no RHS row, no prior columns), returning the
+// lane's coefficient A[k][j] / A[k][k] = V_jk / V_kk.  Used by the weights draw below.
 template <int KR>
-__device__ __forceinline__ void chol_q_kr(double (&l)[4], int k, int lane) {
+__device__ __forceinline__ double unsweep_q_kr(QCols& m, int k, int lane) {
   const int kq = k >> 2, j = lane & 15, q = lane >> 4;
-  const double lkr = l[KR];
-  const double dk = readlane_d(lkr, k + 16 * kq);
-  const double rs = fast_rsqrt(dk);
-  const double ljk = bperm_d(lkr, j + 16 * kq) * rs;      // L[j][k], j > k (symmetry)
-  const bool isk = j == k, trailing = j > k;
-  double cik[4];
+  const double ckr = m.c[KR];
+  const double rd = fast_rcp(readlane_d(ckr, k + 16 * kq));
+  const double rowk = bperm_d(ckr, j + 16 * kq);
+  const bool isk = j == k;
+  const double t = isk ? 1.0 : rowk * rd;
+  double colk[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) cik[r] = bperm_d(l[r], k + 16 * q);   // A[i][k], in flight together
+  for (int r = 0; r < 4; ++r) colk[r] = bperm_d(m.c[r], k + 16 * q);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = 4 * q + r;
-    const double c = cik[r] * rs;                                   // L[i][k]
-    l[r] = (i > k) ? (isk ? c : (trailing ? l[r] - c * ljk : l[r])) : l[r];
-  }
-  l[KR] = (isk && q == kq) ? dk * rs : l[KR];             // sqrt(d)
+  for (int r = 0; r < 4; ++r) m.c[r] = isk ? -colk[r] * rd : m.c[r] - colk[r] * t;
+  m.c[KR] = (q == kq) ? (isk ? -rd : -t) : m.c[KR];
+  m.diag = isk ? -rd : m.diag - rowk * rowk * rd;
+  return t;
 }
-
-// One step of the back substitution L' u = z for pivot i (row-in-quadrant IR static).
-template <int IR>
-__device__ __forceinline__ void backsub_q_ir(const double (&l)[4], int i, float z, double& acc,
-                                             double& umine, int lane) {
-  const int iq = i >> 2, j = lane & 15, q = lane >> 4;
-  const double lir = l[IR];
-  const double tot = readlane_d(acc, i) + readlane_d(acc, i + 16) + readlane_d(acc, i + 32) +
-                     readlane_d(acc, i + 48);
-  const double lii = readlane_d(lir, i + 16 * iq);
-  const double zi = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), i));
-  const double ui = (zi - tot) * fast_rcp(lii);
-  if (q == iq) acc += lir * ui;          // row i of every pending column
-  if (j == i) umine = ui;
+__device__ __forceinline__ double unsweep_q(QCols& m, int k, int lane) {
+  switch (k & 3) {
+    case 0: return unsweep_q_kr<0>(m, k, lane);
+    case 1: return unsweep_q_kr<1>(m, k, lane);
+    case 2: return unsweep_q_kr<2>(m, k, lane);
+    default: return unsweep_q_kr<3>(m, k, lane);
+  }
 }
 
 __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
                                                        const DevSeriesParams& sp,
                                                        double prev_obs_scale, double g_obs,
                                                        const Rng& rng, uint32_t iter, int lane,
-                                                       Prof& prof) {
+                                                       Prof& prof, PriorCarry& pc) {
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
@@ -586,32 +593,35 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
   const double* __restrict__ omega = R.omega;
   const double* __restrict__ xtx = R.xtx;
   QCols m;
-  double l[4];   // unswept M = Omega * prev_var + XtX, kept for the weights' Cholesky
+  const bool fresh = pc.valid == 0;      // first iteration: nothing swept yet
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * q + r;
     double om = 0.0, xx = 0.0;
     if (live && i < P) {
-      om = omega[i * P + col] * prev_var;
+      om = omega[i * P + col];
       xx = xtx[i * P + col];
     }
-    m.p[r] = om;
-    m.c[r] = om + xx;
-    l[r] = om + xx;
+    m.p[r] = fresh ? om : pc.p[r];       // UNIT-scale prior precision (swept on pc.S)
+    m.c[r] = om * prev_var + xx;
   }
   {
-    const double od = live ? omega[col * P + col] * prev_var : 1.0;
-    m.pdiag = od;
-    m.diag = live ? od + xtx[col * P + col] : 1.0;
+    const double od = live ? omega[col * P + col] : 1.0;
+    m.pdiag = fresh ? od : pc.pdiag;
+    m.diag = live ? od * prev_var + xtx[col * P + col] : 1.0;
   }
   m.cb = live ? R.bvec[col] : 0.0;
   m.corner = R.bvec[P];
   unsigned long long S = 0ull;
   {
-    unsigned long long pending = __ballot(q == 0 && live && (all_in || R.w[col] != 0.f));
-    for (; pending != 0ull; pending &= pending - 1ull) {   // sweep in last iteration's features
+    // features included at the end of the previous iteration (== weights != 0): the posterior
+    // block is rebuilt (sigma^2_prev and the targets changed) and swept in; the prior block is
+    // already swept on exactly this set
+    unsigned long long pending = fresh ? (all_in ? __ballot(q == 0 && live) : 0ull) : pc.S;
+    const bool sweep_prior_too = fresh;
+    for (; pending != 0ull; pending &= pending - 1ull) {
       const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
-      sweep_q(m, k, false, lane);
+      if (sweep_prior_too) sweep_q<true>(m, k, false, lane); else sweep_q<false>(m, k, false, lane);
       S |= 1ull << k;
     }
   }
@@ -628,6 +638,7 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
     const double logit_pi =
         (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
     int s_cur = 0;
+    const double inv_prev_var = fast_rcp(prev_var);
     for (;;) {
       // every lane evaluates the flip of ITS feature against the current swept state
       const bool in = ((S >> j) & 1ull) != 0ull;
@@ -635,8 +646,11 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
       const double rap = fast_rcp(sg * m.diag);          // 1 / Schur pivot (out) or 1 / V_jj (in)
       const double beta_old = sp.obs_scale + 0.5 * m.corner;
       const double x = -0.5 * sg * m.cb * m.cb * rap * fast_rcp(beta_old);
-      const double delta = 0.5 * (double)__logf((float)(sg * m.pdiag * rap)) + sg * logit_pi -
-                           (a_post - 1.0) * fast_log1p(x);
+      // unit-scale prior block: Schur pivots scale with sigma^2_prev, inverse-block entries
+      // with 1 / sigma^2_prev
+      const double pscale = in ? inv_prev_var : prev_var;
+      const double delta = 0.5 * (double)__logf((float)(sg * m.pdiag * pscale * rap)) +
+                           sg * logit_pi - (a_post - 1.0) * fast_log1p(x);
       const float prob = 1.0f / (1.0f + __expf(-(float)delta));
       const bool acc = live && q == 0 && rank >= s_cur && uflip < (double)prob;
       // the earliest accepted proposal in visiting order is the one the sequential scan takes
@@ -649,43 +663,44 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
         if (rj < best_rank) { best_rank = rj; best = jj; }
       }
       best = __builtin_amdgcn_readfirstlane(best);
-      sweep_q(m, best, ((S >> best) & 1ull) != 0ull, lane);
+      sweep_q<true>(m, best, ((S >> best) & 1ull) != 0ull, lane);
       S ^= 1ull << best;
       s_cur = best_rank + 1;
     }
   }
   prof.tick(10);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pc.p[r] = m.p[r];
+  pc.pdiag = m.pdiag;
+  pc.S = S;
+  pc.valid = 1;
   const double beta_post = sp.obs_scale + 0.5 * m.corner;
   double var = beta_post * fast_rcp(g_obs);
   if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
   const double new_scale = (double)__fsqrt_rn((float)var);
   prof.tick(11);
 
-  // weights_S ~ N(mean, var * M_S^{-1}):  M_S = L L' (right-looking; the trailing matrix stays
-  // symmetric, so lane (j, q) reads L[j][k] as row k of its OWN column), then L' u = z.
+  // weights_S ~ N(mean, var * V), V = M_S^{-1} = -(swept block).  Un-sweep the included
+  // features in DESCENDING order: feature a is drawn from its current conditional
+  // N(mu_a, V_aa), then the reverse sweep conditions the rest on it (V_rr -= V_ra V_ar / V_aa,
+  // mu_r += V_ra / V_aa (u_a - mu_a)).  This is exactly u = L^{-T} z with M_S = L L' (the
+  // oracle's Cholesky route): u_n = z_n / L_nn, u_{n-1} | u_n, ... -- but it reuses the swept
+  // state instead of factorising M_S and back-substituting.
   float zf[1];
   fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)col, zf);
-  for (unsigned long long mm = S; mm != 0ull; mm &= mm - 1ull) {
-    const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
-    switch (k & 3) {
-      case 0: chol_q_kr<0>(l, k, lane); break;
-      case 1: chol_q_kr<1>(l, k, lane); break;
-      case 2: chol_q_kr<2>(l, k, lane); break;
-      default: chol_q_kr<3>(l, k, lane); break;
-    }
-  }
-  double acc = 0.0, umine = 0.0;
+  const double mean = m.cb;
+  double mu = 0.0, umine = 0.0;
   for (unsigned long long mm = S; mm != 0ull;) {
-    const int i = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mm));   // descending
-    mm &= ~(1ull << i);
-    switch (i & 3) {
-      case 0: backsub_q_ir<0>(l, i, zf[0], acc, umine, lane); break;
-      case 1: backsub_q_ir<1>(l, i, zf[0], acc, umine, lane); break;
-      case 2: backsub_q_ir<2>(l, i, zf[0], acc, umine, lane); break;
-      default: backsub_q_ir<3>(l, i, zf[0], acc, umine, lane); break;
-    }
+    const int aidx = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mm));   // descending
+    mm &= ~(1ull << aidx);
+    const double vaa = -readlane_d(m.diag, aidx);
+    const double mua = readlane_d(mu, aidx);
+    const double za = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zf[0]), aidx));
+    const double ua = mua + (double)__fsqrt_rn((float)vaa) * za;
+    const double t = unsweep_q(m, aidx, lane);
+    if (j == aidx) umine = ua; else mu += t * (ua - mua);
   }
-  if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(m.cb + new_scale * umine) : 0.f;
+  if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(mean + new_scale * umine) : 0.f;
   wave_sync();
   prof.tick(12);
   return new_scale;
@@ -892,9 +907,12 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
 // stay inside the 64 KB instruction cache: 0 = no regression, 1 = P <= 16 with X in LDS
 // (register-resident block), 2 = general (LDS block, X possibly streamed from L2).
 template <int PM>
-static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int lane) {
+static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLds& R,
+                                                      const float* red, float* scal, int it,
+                                                      int lane, PriorCarry& pc) {
+  // (R, red, scal are passed in rather than read from cx: loaded from the LDS context they
+  //  would be generic pointers and every access a flat_* instruction)
   const int P = (PM == 0) ? 0 : cx->P, T = cx->T;
-  const RegLds& R = cx->R;
   Prof prof;
   prof.start(cx->prof, cx->prof != nullptr && lane == 0);
   {
@@ -903,7 +921,7 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int
       const int src = j < P ? j : RS - 4 + (j - P);
       double s = 0.0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) s += (double)cx->red[w * RS + src];
+      for (int w = 0; w < NW; ++w) s += (double)red[w * RS + src];
       R.bvec[j] = s;
     }
   }
@@ -912,41 +930,32 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int
   double emit_obs = obs_scale;
   // all gamma draws of this section in one wave pass: level / slope / obs scale of iteration
   // it-1 (gibbs_sampler._resample_scale) and sigma^2_obs of iteration it (spike-and-slab)
-  GammaReq req[4];
-  double gam[4] = {1.0, 1.0, 1.0, 1.0};
-  int nreq = 0, i_level = -1, i_slope = -1, i_obs_prev = -1, i_obsvar = -1;
-  if (it > 0) {
-    const uint32_t pit = (uint32_t)(it - 1);
-    i_level = nreq;
-    req[nreq++] = GammaReq{cx->sp.level_conc + 0.5 * (double)(T - 1), pit, SITE_LEVEL_SCALE, 0};
-    if (cx->D == 2) {
-      i_slope = nreq;
-      req[nreq++] = GammaReq{cx->sp.slope_conc + 0.5 * (double)(T - 1), pit, SITE_SLOPE_SCALE, 0};
-    }
-    if (P == 0) {
-      i_obs_prev = nreq;
-      req[nreq++] = GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, pit, SITE_OBS_SCALE, 0};
-    }
-  }
-  if (P > 0 && it < cx->n_iter) {
-    i_obsvar = nreq;
-    req[nreq++] = GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, (uint32_t)it, SITE_OBSVAR, 0};
-  }
-  for (int qq = nreq; qq < 4; ++qq) req[qq] = GammaReq{1.0, 0, 0, 0};
-  if (nreq > 0) gamma_wave4(req, nreq, gam, cx->rng, lane);
+  // quadrant 0: level scale, 1: slope scale, 2: observation noise (scale of it-1 when there is
+  // no regression, sigma^2_obs of iteration it otherwise -- never both)
+  const bool have_prev = it > 0;
+  const bool want_obsvar = P > 0 && it < cx->n_iter;
+  const uint32_t pit = (uint32_t)(it > 0 ? it - 1 : 0);
+  const GammaReq rq_level{cx->sp.level_conc + 0.5 * (double)(T - 1), pit, SITE_LEVEL_SCALE, 0};
+  const GammaReq rq_slope{cx->sp.slope_conc + 0.5 * (double)(T - 1), pit, SITE_SLOPE_SCALE, 0};
+  const GammaReq rq_obs = want_obsvar
+      ? GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, (uint32_t)it, SITE_OBSVAR, 0}
+      : GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, pit, SITE_OBS_SCALE, 0};
+  const unsigned active = (have_prev ? 1u : 0u) | ((have_prev && cx->D == 2) ? 2u : 0u) |
+                          ((want_obsvar || (have_prev && P == 0)) ? 4u : 0u);
+  double g_level = 1.0, g_slope = 1.0, g_obs = 1.0;
+  prof.tick(17);
+  if (active) gamma_wave3(rq_level, rq_slope, rq_obs, active, g_level, g_slope, g_obs, cx->rng, lane);
+  prof.tick(18);
   auto clipped_scale = [](double scale, double ss, double g, double ub) {
     const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
     return s < ub ? s : ub;
   };
   if (it > 0) {
-    level_scale = clipped_scale(cx->sp.level_scale, R.bvec[P + 1], gam[i_level < 0 ? 0 : i_level],
-                                cx->sp.level_ub);
+    level_scale = clipped_scale(cx->sp.level_scale, R.bvec[P + 1], g_level, cx->sp.level_ub);
     if (cx->D == 2)
-      slope_scale = clipped_scale(cx->sp.slope_scale, R.bvec[P + 2], gam[i_slope < 0 ? 0 : i_slope],
-                                  cx->sp.slope_ub);
+      slope_scale = clipped_scale(cx->sp.slope_scale, R.bvec[P + 2], g_slope, cx->sp.slope_ub);
     if (P == 0)
-      obs_scale = clipped_scale(cx->sp.obs_scale, R.bvec[P], gam[i_obs_prev < 0 ? 0 : i_obs_prev],
-                                cx->sp.obs_ub);
+      obs_scale = clipped_scale(cx->sp.obs_scale, R.bvec[P], g_obs, cx->sp.obs_ub);
     emit_obs = obs_scale;
     const int s = it - 1 - cx->W;
     if (s >= 0) {
@@ -961,9 +970,8 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int
   }
   prof.tick(8);
   if (P > 0 && it < cx->n_iter) {
-    const double g_obs = gam[i_obsvar < 0 ? 0 : i_obsvar];
     if constexpr (PM == 1)
-      obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof);
+      obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, pc);
     else if constexpr (PM == 2)
       obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof);
   }
@@ -971,10 +979,10 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, int it, int
     cx->obs_scale = obs_scale;
     cx->level_scale = level_scale;
     cx->slope_scale = slope_scale;
-    cx->scal[SC_OBS_DK] = (float)obs_scale;
-    cx->scal[SC_OBS_EMIT] = (float)emit_obs;
-    cx->scal[SC_LEVEL] = (float)level_scale;
-    cx->scal[SC_SLOPE] = (float)slope_scale;
+    scal[SC_OBS_DK] = (float)obs_scale;
+    scal[SC_OBS_EMIT] = (float)emit_obs;
+    scal[SC_LEVEL] = (float)level_scale;
+    scal[SC_SLOPE] = (float)slope_scale;
   }
   wave_sync();
 }
@@ -1011,12 +1019,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   const uint8_t* mg = a.mask + (size_t)series * T;
   const float* Xg = a.Xt + (size_t)series * P * T;
   const int t0 = tid * L;
-  if (tid == 0) {
-    cx->sp = a.sp[series];
-    cx->obs_scale = cx->sp.obs_scale0;           // causalimpact_lib.py:566-572
-    cx->level_scale = cx->sp.level_scale0;
-    cx->slope_scale = cx->sp.slope_scale0;
-    RegLds R;
+  RegLds R;
+  {
     R.xtx = (double*)(smem + lay.off_xtx);
     R.omega = (double*)(smem + lay.off_omega);
     R.aug[0] = (double*)(smem + lay.off_aug0);
@@ -1031,6 +1035,12 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     R.perm = (int*)(smem + lay.off_perm);
     R.idx = (int*)(smem + lay.off_idx);
     R.w = wls;
+  }
+  if (tid == 0) {
+    cx->sp = a.sp[series];
+    cx->obs_scale = cx->sp.obs_scale0;           // causalimpact_lib.py:566-572
+    cx->level_scale = cx->sp.level_scale0;
+    cx->slope_scale = cx->sp.slope_scale0;
     cx->R = R;
     cx->scal = scal;
     cx->red = red;
@@ -1083,6 +1093,12 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   float* o_traj = a.out_traj ? a.out_traj + chain_lin * a.S * T : nullptr;
 
   const int n_iter = a.W + a.S;
+  PriorCarry pc;
+  pc.valid = 0;
+  pc.S = 0ull;
+  pc.pdiag = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
   Prof prof;
   prof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && tid == 0);
   for (int it = 0; it <= n_iter; ++it) {
@@ -1172,7 +1188,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     prof.tick(0);
 
     // ---- serial section: scale draws for iteration it-1, regression draw for iteration it
-    if (wave == 0) serial_section<PM>(cx, it, lane);
+    if (wave == 0) serial_section<PM>(cx, R, red, scal, it, lane, pc);
     __syncthreads();
     prof.tick(1);
 

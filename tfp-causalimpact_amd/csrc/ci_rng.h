@@ -29,8 +29,11 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
                                             uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32x32->64 multiply (v_mad_u64_u32) per product instead of mul_hi + mul_lo
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -158,6 +161,36 @@ __device__ __forceinline__ double readlane_d(double v, int l) {   // l must be w
   return __hiloint2double(hi, lo);
 }
 
+// Marsaglia-Tsang acceptance bound  0.5 x^2 + d (1 - v + log v),  v = (1 + z)^3, z = c x.
+// With 9 d c^2 = 1 the quadratic terms cancel EXACTLY and what is left is
+//   3 d * sum_{k>=4} (-1)^(k+1) z^k / k  =  3 d z^4 (-1/4 + z/5 - z^2/6 + ...),
+// free of cancellation, so float32 suffices for |z| < 0.4 (remainder < 2e-7 relative); the
+// float64 closed form is kept for large |z| (small shapes).
+__device__ __forceinline__ double mt_accept_bound(double x, double d, double z) {
+  const float zf = (float)z;
+  if (fabsf(zf) < 0.4f) {
+    float q = 1.0f / 18.0f;
+    q = fmaf(q, -zf, 1.0f / 17.0f);
+    q = fmaf(q, -zf, 1.0f / 16.0f);
+    q = fmaf(q, -zf, 1.0f / 15.0f);
+    q = fmaf(q, -zf, 1.0f / 14.0f);
+    q = fmaf(q, -zf, 1.0f / 13.0f);
+    q = fmaf(q, -zf, 1.0f / 12.0f);
+    q = fmaf(q, -zf, 1.0f / 11.0f);
+    q = fmaf(q, -zf, 1.0f / 10.0f);
+    q = fmaf(q, -zf, 1.0f / 9.0f);
+    q = fmaf(q, -zf, 1.0f / 8.0f);
+    q = fmaf(q, -zf, 1.0f / 7.0f);
+    q = fmaf(q, -zf, 1.0f / 6.0f);
+    q = fmaf(q, -zf, 1.0f / 5.0f);
+    q = fmaf(q, -zf, 1.0f / 4.0f);      // q = 1/4 - z/5 + z^2/6 - ...
+    const float z2 = zf * zf;
+    return -3.0 * d * (double)(z2 * z2 * q);
+  }
+  const double t = 1.0 + z;
+  return 0.5 * x * x + d * (1.0 - t * t * t + 3.0 * fast_log1p(z));
+}
+
 // Gamma(alpha, 1), Marsaglia-Tsang.  The 64 lanes of the calling wavefront evaluate
 // attempts 0..63 at once; the first accepted attempt (lowest index) wins, which is the
 // sequential oracle's answer.  Must be called by a full, converged wave.  The proposal
@@ -179,7 +212,7 @@ static __device__ __noinline__ double gamma_wave(double alpha, const Rng& g, uin
   double gval = d;
   if (v > 0.0) {
     const double lhs = (double)__logf(u01f(r.z));
-    ok = lhs < 0.5 * x * x + d * (1.0 - v + 3.0 * fast_log1p(cx));
+    ok = lhs < mt_accept_bound(x, d, cx);
     gval = d * v;
     if (alpha < 1.0) gval *= pow(u01d(r.w), 1.0 / alpha);
   }
@@ -189,24 +222,30 @@ static __device__ __noinline__ double gamma_wave(double alpha, const Rng& g, uin
   return readlane_d(gval, first);
 }
 
-// Up to four independent Gamma(alpha_q, 1) draws in one pass: quadrant q = lane >> 4 evaluates
-// attempts of draw q (attempt index = 16 * round + (lane & 15)); identical results to four
-// gamma_wave() calls because the first accepted attempt index wins either way.
+// Three independent Gamma(alpha_q, 1) draws in one pass: quadrant q = lane >> 4 (q < 3)
+// evaluates attempts of draw q (attempt index = 16 * round + (lane & 15)); identical results to
+// three gamma_wave() calls because the first accepted attempt index wins either way.  Requests
+// are plain scalars (an array indexed by the lane's quadrant would live in scratch memory).
 struct GammaReq {
   double alpha;
   uint32_t iter, site, sub;
 };
-static __device__ __forceinline__ void gamma_wave4(const GammaReq (&req)[4], int nreq, double (&out)[4],
-                                                const Rng& g, int lane) {
+__device__ __forceinline__ void gamma_wave3(const GammaReq& r0, const GammaReq& r1,
+                                            const GammaReq& r2, unsigned active, double& g0,
+                                            double& g1, double& g2, const Rng& g, int lane) {
   const int q = lane >> 4, at = lane & 15;
-  const GammaReq mine = req[q < nreq ? q : 0];
-  const double a = mine.alpha < 1.0 ? mine.alpha + 1.0 : mine.alpha;
+  const double alpha = q == 1 ? r1.alpha : (q == 2 ? r2.alpha : r0.alpha);
+  const uint32_t iter = q == 1 ? r1.iter : (q == 2 ? r2.iter : r0.iter);
+  const uint32_t site = q == 1 ? r1.site : (q == 2 ? r2.site : r0.site);
+  const uint32_t sub = q == 1 ? r1.sub : (q == 2 ? r2.sub : r0.sub);
+  const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
   const double d = a - 1.0 / 3.0;
   const double c = fast_rsqrt(9.0 * d);
-  unsigned pending = (1u << nreq) - 1u;
+  const bool mine_active = q < 3 && ((active >> q) & 1u) != 0u;
+  unsigned pending = active & 7u;
 #pragma unroll 1
   for (int round = 0; round < 4 && pending != 0u; ++round) {
-    const U4 r = site_call(g, mine.iter, mine.site, mine.sub, (uint32_t)(16 * round + at));
+    const U4 r = site_call(g, iter, site, sub, (uint32_t)(16 * round + at));
     float xf, unused;
     box_muller_f(r.x, r.y, xf, unused);
     const double x = (double)xf;
@@ -217,28 +256,21 @@ static __device__ __forceinline__ void gamma_wave4(const GammaReq (&req)[4], int
     double gval = d;
     if (v > 0.0) {
       const double lhs = (double)__logf(u01f(r.z));
-      ok = lhs < 0.5 * x * x + d * (1.0 - v + 3.0 * fast_log1p(cx));
+      ok = lhs < mt_accept_bound(x, d, cx);
       gval = d * v;
-      if (mine.alpha < 1.0) gval *= pow(u01d(r.w), 1.0 / mine.alpha);
+      if (alpha < 1.0) gval *= pow(u01d(r.w), 1.0 / alpha);
     }
-    const unsigned long long m = __ballot(ok && q < nreq);
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      if ((pending >> qq) & 1u) {
-        const unsigned bits = (unsigned)((m >> (16 * qq)) & 0xFFFFull);
-        if (bits != 0u) {
-          out[qq] = readlane_d(gval, 16 * qq + __ffs((int)bits) - 1);
-          pending &= ~(1u << qq);
-        }
-      }
-    }
+    const unsigned long long m = __ballot(ok && mine_active);
+    const unsigned b0 = (unsigned)(m & 0xFFFFull), b1 = (unsigned)((m >> 16) & 0xFFFFull),
+                   b2 = (unsigned)((m >> 32) & 0xFFFFull);
+    if ((pending & 1u) && b0) { g0 = readlane_d(gval, __ffs((int)b0) - 1); pending &= ~1u; }
+    if ((pending & 2u) && b1) { g1 = readlane_d(gval, 16 + __ffs((int)b1) - 1); pending &= ~2u; }
+    if ((pending & 4u) && b2) { g2 = readlane_d(gval, 32 + __ffs((int)b2) - 1); pending &= ~4u; }
   }
-#pragma unroll
-  for (int qq = 0; qq < 4; ++qq)
-    if ((pending >> qq) & 1u) {   // 64 rejections: unreachable in practice (oracle: same fallback)
-      const double aa = req[qq].alpha < 1.0 ? req[qq].alpha + 1.0 : req[qq].alpha;
-      out[qq] = aa - 1.0 / 3.0;
-    }
+  // 64 rejections in a row: unreachable in practice; same fallback as the oracle
+  if (pending & 1u) g0 = (r0.alpha < 1.0 ? r0.alpha + 1.0 : r0.alpha) - 1.0 / 3.0;
+  if (pending & 2u) g1 = (r1.alpha < 1.0 ? r1.alpha + 1.0 : r1.alpha) - 1.0 / 3.0;
+  if (pending & 4u) g2 = (r2.alpha < 1.0 ? r2.alpha + 1.0 : r2.alpha) - 1.0 / 3.0;
 }
 
 }  // namespace ci

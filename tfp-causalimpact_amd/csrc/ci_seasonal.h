@@ -152,6 +152,9 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   const float p1e = (float)(ss.init_seasonal_scale * ss.init_seasonal_scale);
   Prof prof;
   prof.start(nullptr, false);
+  PriorCarry pc;
+  pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
+  for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
 
   auto zsum = [&](float x) -> float {   // Z x for a lane-distributed vector
     float s = readlane_f(x, 0);
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     if (it == n_iter) break;
     if (P > 0) {
       const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
-      obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof);
+      obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
     }
     wave_sync();
 

@@ -17,7 +17,8 @@ SLOTS = ["partial sums + reduce", "serial section (wave 0) total", "emit", "resi
          "dk: normals + prior-sim scan", "dk: filter elements + scan", "dk: local Kalman pass",
          "dk: backward scan + fix-up", "serial: gather + scale draws", "serial: build + sweep-in",
          "serial: flips", "serial: gamma + active set", "serial: chol + weights",
-         "  (0a) X'targets partials + DPP sums", "  (0b) boundary exchange + increments", "  (0a1) loop top + targets", "  (0a2) X reads + fma"]
+         "  (0a) X'targets partials + DPP sums", "  (0b) boundary exchange + increments", "  (0a1) loop top + targets", "  (0a2) X reads + fma", "  (8a) gather partial sums",
+         "  (8b) gamma_wave4"]
 
 
 def main():

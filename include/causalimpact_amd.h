@@ -117,6 +117,15 @@ int ci_session_algorithmic_bytes(const ci_session* session, double* bytes);
 int ci_session_profile(ci_session* session, int enable, int64_t* cycles16);
 int ci_session_destroy(ci_session* session);
 
+/* Kalman-filter log-likelihood of the trend + regression model for num_evals parameter sets
+ * (the objective an HMC / VI fit would use; the reference never
+ * evaluates it directly -- upstream it is LinearGaussianStateSpaceModel.log_prob).
+ *   theta [num_evals, 3 + P] float64: (sigma_obs, sigma_level, sigma_slope, weights[P])
+ *   loglik [num_evals] float64.   One series (num_series must be 1), no seasonal blocks. */
+int ci_kalman_loglik(const ci_problem* problem, const ci_series_params* params, const float* y,
+                     const uint8_t* mask, const float* X, int32_t num_evals, const double* theta,
+                     double* loglik);
+
 /* ---- component entry points used by the parity tests (tests/test_gpu_*.py) ---- */
 /* normals/uniforms/gammas of the specified Philox stream, computed on device. */
 int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t iter, uint32_t site,

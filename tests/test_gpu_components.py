@@ -83,3 +83,29 @@ def test_dk_draw_observed_everywhere_and_strong_signal():
   ssm = orc.make_ssm(spec, mask, obs_scale=0.1, level_scale=1.0, slope_scale=0.2)
   want = orc.dk_draw(ssm, resid.astype(np.float64), (1, 2), chain=0, it=0)
   assert np.abs(got - want).max() < 5e-3 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("T,p,has_slope", [(100, 0, 0), (100, 1, 1), (1000, 10, 1), (3000, 3, 0)])
+def test_kalman_loglik_matches_oracle(T, p, has_slope):
+  """device log-likelihood vs the oracle's (which is pinned to the
+  dense multivariate-normal log-density in tests/test_oracle_math.py).  float32 filter and a
+  float32 sum of <= 0.7 T terms: relative tolerance 2e-5, absolute 2e-3."""
+  from causalimpact import _synthetic as syn
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 11)
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope))
+  P = spec["P"]
+  rng = np.random.default_rng(0)
+  E = 7
+  theta = np.zeros((E, 3 + P))
+  theta[:, 0] = rng.uniform(0.2, 1.0, E)
+  theta[:, 1] = rng.uniform(0.005, 0.2, E)
+  theta[:, 2] = rng.uniform(0.001, 0.02, E) if has_slope else 0.0
+  theta[:, 3:] = 0.3 * rng.normal(size=(E, P))
+  pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_warmup=0, num_results=1)
+  got = _native.kalman_loglik(pb, _native.make_params([spec]), y, mask, X, theta)
+  for e in range(E):
+    ssm = orc.make_ssm(spec, mask, obs_scale=theta[e, 0], level_scale=theta[e, 1],
+                       slope_scale=theta[e, 2])
+    resid = np.where(mask, 0.0, y) - (X @ theta[e, 3:] if P else 0.0)
+    want = orc.kalman_loglik(ssm, resid)
+    np.testing.assert_allclose(got[e], want, rtol=2e-5, atol=2e-3)

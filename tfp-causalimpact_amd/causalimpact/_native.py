@@ -76,6 +76,8 @@ def load():
   L.ci_session_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
   L.ci_session_destroy.argtypes = [C.c_void_p]
   L.ci_session_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+  L.ci_kalman_loglik.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
   L.ci_test_rng.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
                             C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
   L.ci_test_dk_draw.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p, C.c_void_p,
@@ -92,7 +94,7 @@ def exported_symbols() -> Sequence[str]:
   return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_fit_gibbs",
           "ci_session_create", "ci_session_run", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_session_profile",
-          "ci_test_rng",
+          "ci_kalman_loglik", "ci_test_rng",
           "ci_test_dk_draw")
 
 
@@ -229,6 +231,21 @@ class Session:
       self.close()
     except Exception:  # pylint: disable=broad-except
       pass
+
+
+def kalman_loglik(pb: Problem, params, y, mask, X, theta) -> np.ndarray:
+  """Log-likelihood l(theta_e) for every row theta_e = (sigma_obs, sigma_level, sigma_slope,
+  weights...) of `theta` (row H of SURVEY.md section 8)."""
+  L = load()
+  T, P = pb.T, pb.P
+  m8 = np.ascontiguousarray(np.asarray(mask, bool).astype(np.uint8))
+  y32 = np.ascontiguousarray(np.where(m8 != 0, np.float32(0), np.asarray(y, np.float32)))
+  X32 = np.ascontiguousarray(np.asarray(X, np.float32).reshape(T, P)) if P > 0 else None
+  th = np.ascontiguousarray(np.asarray(theta, np.float64).reshape(-1, 3 + P))
+  out = np.zeros(th.shape[0], np.float64)
+  _check(L.ci_kalman_loglik(C.byref(pb), params, y32.ctypes.data, m8.ctypes.data, _ptr(X32),
+                            th.shape[0], th.ctypes.data, out.ctypes.data))
+  return out
 
 
 def test_rng(seed, chain, it, site, sub, n, alpha, device=0):

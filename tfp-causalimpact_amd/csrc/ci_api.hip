@@ -21,7 +21,10 @@ extern "C" void* ci_gibbs_seasonal_fn(void);
   extern "C" void* ci_gibbs_fn_d##D##_l##L(int);                                              \
   extern "C" void ci_launch_dk_d##D##_l##L(int, const float*, const uint8_t*, float, float,    \
                                            float, float, float, float, uint32_t, uint32_t,     \
-                                           uint32_t, uint32_t, float*);
+                                           uint32_t, uint32_t, float*);                           \
+  extern "C" void ci_launch_loglik_d##D##_l##L(int, int, int, const float*, const uint8_t*,       \
+                                               const float*, const double*, float, float, float,  \
+                                               double*, hipStream_t);
 CI_DECL(1, 1) CI_DECL(1, 2) CI_DECL(1, 4) CI_DECL(1, 8) CI_DECL(1, 16)
 CI_DECL(2, 1) CI_DECL(2, 2) CI_DECL(2, 4) CI_DECL(2, 8) CI_DECL(2, 16)
 #undef CI_DECL
@@ -470,6 +473,48 @@ int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t ite
   HIP_TRY(hipMemcpy(normals, dn.p, 2 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(gamma_draw, dg.p, sizeof(double), hipMemcpyDeviceToHost));
   du.release(); dn.release(); dg.release();
+  return 0;
+}
+
+int ci_kalman_loglik(const ci_problem* pb, const ci_series_params* params, const float* y,
+                     const uint8_t* mask, const float* X, int32_t num_evals, const double* theta,
+                     double* loglik) {
+  if (validate(pb)) return 1;
+  if (pb->num_blocks != 0) return fail("ci_kalman_loglik: seasonal blocks not supported yet");
+  if (!params || !y || !mask || !theta || !loglik || num_evals < 1) return fail("bad argument");
+  if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
+  HIP_TRY(hipSetDevice(pb->device));
+  const int T = pb->T, P = pb->P, D = pb->has_slope ? 2 : 1, L = steps_per_thread(T);
+  DevBuf<float> dy, dxt;
+  DevBuf<uint8_t> dm;
+  DevBuf<double> dth, dout;
+  HIP_TRY(dy.alloc(T));
+  HIP_TRY(dm.alloc(T));
+  HIP_TRY(dxt.alloc((size_t)P * T));
+  HIP_TRY(dth.alloc((size_t)num_evals * (3 + P)));
+  HIP_TRY(dout.alloc(num_evals));
+  HIP_TRY(hipMemcpy(dy.p, y, T * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dm.p, mask, T, hipMemcpyHostToDevice));
+  if (P > 0) {
+    std::vector<float> xt((size_t)P * T);
+    for (int t = 0; t < T; ++t)
+      for (int j = 0; j < P; ++j) xt[(size_t)j * T + t] = X[(size_t)t * P + j];
+    HIP_TRY(hipMemcpy(dxt.p, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemcpy(dth.p, theta, (size_t)num_evals * (3 + P) * sizeof(double), hipMemcpyHostToDevice));
+  const float a1 = (float)params->init_level_loc;
+  const float p10 = (float)(params->init_level_scale * params->init_level_scale);
+  const float p11 = (float)(params->init_slope_scale * params->init_slope_scale);
+#define CI_LL_CASE(DD, LL)                                                                      \
+  if (D == DD && L == LL)                                                                       \
+    ci_launch_loglik_d##DD##_l##LL(T, P, num_evals, dy.p, dm.p, dxt.p, dth.p, a1, p10, p11, dout.p, 0);
+  CI_LL_CASE(1, 1) CI_LL_CASE(1, 2) CI_LL_CASE(1, 4) CI_LL_CASE(1, 8) CI_LL_CASE(1, 16)
+  CI_LL_CASE(2, 1) CI_LL_CASE(2, 2) CI_LL_CASE(2, 4) CI_LL_CASE(2, 8) CI_LL_CASE(2, 16)
+#undef CI_LL_CASE
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(loglik, dout.p, num_evals * sizeof(double), hipMemcpyDeviceToHost));
+  dy.release(); dm.release(); dxt.release(); dth.release(); dout.release();
   return 0;
 }
 

@@ -45,4 +45,13 @@ void CI_CAT(ci_launch_dk_d, CI_D, _l, CI_L)(int T, const float* resid, const uin
                      md, k0, k1, chain, iter, out);
 }
 
+// Launches the log-likelihood kernel for E parameter sets on `stream`.
+void CI_CAT(ci_launch_loglik_d, CI_D, _l, CI_L)(int T, int P, int E, const float* y,
+                                               const uint8_t* mask, const float* Xt,
+                                               const double* theta, float a1, float p10,
+                                               float p11, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL((ci::loglik_kernel<CI_D, CI_L>), dim3(E), dim3(ci::NT), 0, stream, T, P, y,
+                     mask, Xt, theta, a1, p10, p11, out);
+}
+
 }  // extern "C"

@@ -225,6 +225,124 @@ template <int D> struct DkModel {
   Vec<D> p1;      // prior variances of x_0 (diagonal)
 };
 
+// ------------------------------------------------------------------------------------
+// Time-parallel Kalman filter of the trend block on data ytil (Z = e_0'): associative scan
+// over (A, b, C, eta, J), then a local sequential pass that leaves, for every owned step, the
+// predicted mean a_t, predicted covariance P_t, gain K_t = P_t Z'/F_t and v_t/F_t (0 where
+// masked).  F_t itself is returned in fvar (1 where masked).  `a1e` is the prior mean of x_0.
+// Contains one __syncthreads().
+// ------------------------------------------------------------------------------------
+template <int D, int L>
+__device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const Vec<D>& a1e,
+                                                   const Vec<D>& q, const float (&ytil)[L],
+                                                   uint32_t maskbits, int tid, int lane, int wave,
+                                                   float* slots16, Vec<D> (&ap)[L],
+                                                   Mat<D> (&Pp)[L], Vec<D> (&kf)[L], float (&vf)[L],
+                                                   float (&fvar)[L], Prof& prof) {
+  // ---- (2) Kalman filter as an associative scan over (A, b, C, eta, J)
+  const Mat<D> Tm = trans_mat<D>();
+  FElem<D> ftot = felem_identity<D>();
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const bool obs = ((maskbits >> l) & 1u) == 0u;
+    FElem<D> e;
+    if (tid == 0 && l == 0) {
+      // prior element: A = 0, (b, C) = moments of x_0 after its own update
+      e.A = mzero<D>();
+      e.eta = vzero<D>();
+      e.J = mzero<D>();
+      e.b = a1e;
+      e.C = mzero<D>();
+#pragma unroll
+      for (int i = 0; i < D; ++i) e.C.m[i][i] = md.p1.v[i];
+      if (obs) {
+        const float F = md.p1.v[0] + md.H;
+        const float k0 = md.p1.v[0] / F;
+        e.b.v[0] = fmaf(k0, ytil[l] - a1e.v[0], a1e.v[0]);
+        e.C.m[0][0] = md.p1.v[0] * md.H / F;
+      }
+    } else if (obs) {
+      // S = Z Q Z' + H ; K = Q Z'/S ; A = (I - K Z) T ; b = K y ; C = (I - K Z) Q
+      // eta = T' Z' y / S ; J = T' Z' Z T / S          (Z = e_0')
+      const float Sv = q.v[0] + md.H;
+      const float rS = 1.0f / Sv;
+      const float hk = md.H * rS;
+      e.A = Tm;
+#pragma unroll
+      for (int j = 0; j < D; ++j) e.A.m[0][j] = hk * Tm.m[0][j];
+      e.b = vzero<D>();
+      e.b.v[0] = q.v[0] * rS * ytil[l];
+      e.C = mzero<D>();
+      e.C.m[0][0] = hk * q.v[0];
+      if constexpr (D == 2) e.C.m[1][1] = q.v[1];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        e.eta.v[i] = Tm.m[0][i] * ytil[l] * rS;
+#pragma unroll
+        for (int j = 0; j < D; ++j) e.J.m[i][j] = Tm.m[0][i] * Tm.m[0][j] * rS;
+      }
+    } else {
+      e.A = Tm;
+      e.b = vzero<D>();
+      e.C = mzero<D>();
+#pragma unroll
+      for (int i = 0; i < D; ++i) e.C.m[i][i] = q.v[i];
+      e.eta = vzero<D>();
+      e.J = mzero<D>();
+    }
+    ftot = (l == 0) ? e : felem_combine(ftot, e);
+  }
+  const FElem<D> fpre = block_scan_excl_fwd(
+      ftot, [](const FElem<D>& a, const FElem<D>& b) { return felem_combine(a, b); },
+      felem_identity<D>(), slots16, lane, wave);
+  prof.tick(5);
+
+  // local sequential Kalman pass over the owned steps (predicted-form quantities kept)
+  {
+    Vec<D> mf = fpre.b;
+    Mat<D> Pf = fpre.C;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const bool obs = ((maskbits >> l) & 1u) == 0u;
+      Vec<D> a;
+      Mat<D> P;
+      if (tid == 0 && l == 0) {
+        a = a1e;
+        P = mzero<D>();
+#pragma unroll
+        for (int i = 0; i < D; ++i) P.m[i][i] = md.p1.v[i];
+      } else {
+        a = trans_apply(mf);
+        P = trans_cov(Pf, q);
+      }
+      ap[l] = a;
+      Pp[l] = P;
+      if (obs) {
+        const float v = ytil[l] - a.v[0];
+        const float Fv = P.m[0][0] + md.H;
+        const float rF = 1.0f / Fv;
+        fvar[l] = Fv;
+        vf[l] = v * rF;
+#pragma unroll
+        for (int i = 0; i < D; ++i) kf[l].v[i] = P.m[i][0] * rF;
+#pragma unroll
+        for (int i = 0; i < D; ++i) mf.v[i] = fmaf(kf[l].v[i], v, a.v[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int j = 0; j < D; ++j) Pf.m[i][j] = P.m[i][j] - kf[l].v[i] * P.m[0][j];
+        symmetrize(Pf);
+      } else {
+        vf[l] = 0.f;
+        fvar[l] = 1.f;
+        kf[l] = vzero<D>();
+        mf = a;
+        Pf = P;
+      }
+    }
+  }
+}
+
 // slots: 3 regions of NW * 16 floats.  Contains 3 __syncthreads().
 template <int D, int L>
 __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
@@ -283,109 +401,13 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
   }
 
   prof.tick(4);
-  // ---- (2) Kalman filter as an associative scan over (A, b, C, eta, J)
-  const Mat<D> Tm = trans_mat<D>();
-  FElem<D> ftot = felem_identity<D>();
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const bool obs = ((maskbits >> l) & 1u) == 0u;
-    FElem<D> e;
-    if (tid == 0 && l == 0) {
-      // prior element: A = 0, (b, C) = moments of x_0 after its own update
-      e.A = mzero<D>();
-      e.eta = vzero<D>();
-      e.J = mzero<D>();
-      e.b = a1e;
-      e.C = mzero<D>();
-#pragma unroll
-      for (int i = 0; i < D; ++i) e.C.m[i][i] = md.p1.v[i];
-      if (obs) {
-        const float F = md.p1.v[0] + md.H;
-        const float k0 = md.p1.v[0] / F;
-        e.b.v[0] = fmaf(k0, ytil[l] - a1e.v[0], a1e.v[0]);
-        e.C.m[0][0] = md.p1.v[0] * md.H / F;
-      }
-    } else if (obs) {
-      // S = Z Q Z' + H ; K = Q Z'/S ; A = (I - K Z) T ; b = K y ; C = (I - K Z) Q
-      // eta = T' Z' y / S ; J = T' Z' Z T / S          (Z = e_0')
-      const float Sv = q.v[0] + md.H;
-      const float rS = 1.0f / Sv;
-      const float hk = md.H * rS;
-      e.A = Tm;
-#pragma unroll
-      for (int j = 0; j < D; ++j) e.A.m[0][j] = hk * Tm.m[0][j];
-      e.b = vzero<D>();
-      e.b.v[0] = q.v[0] * rS * ytil[l];
-      e.C = mzero<D>();
-      e.C.m[0][0] = hk * q.v[0];
-      if constexpr (D == 2) e.C.m[1][1] = q.v[1];
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        e.eta.v[i] = Tm.m[0][i] * ytil[l] * rS;
-#pragma unroll
-        for (int j = 0; j < D; ++j) e.J.m[i][j] = Tm.m[0][i] * Tm.m[0][j] * rS;
-      }
-    } else {
-      e.A = Tm;
-      e.b = vzero<D>();
-      e.C = mzero<D>();
-#pragma unroll
-      for (int i = 0; i < D; ++i) e.C.m[i][i] = q.v[i];
-      e.eta = vzero<D>();
-      e.J = mzero<D>();
-    }
-    ftot = (l == 0) ? e : felem_combine(ftot, e);
-  }
-  const FElem<D> fpre = block_scan_excl_fwd(
-      ftot, [](const FElem<D>& a, const FElem<D>& b) { return felem_combine(a, b); },
-      felem_identity<D>(), slots + NW * 16, lane, wave);
-
-  prof.tick(5);
-  // local sequential Kalman pass over the owned steps (predicted-form quantities kept)
+  // ---- (2) Kalman filter (associative scan + local pass)
   Vec<D> ap[L];
   Mat<D> Pp[L];
   Vec<D> kf[L];
-  float vf[L];
-  {
-    Vec<D> mf = fpre.b;
-    Mat<D> Pf = fpre.C;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const bool obs = ((maskbits >> l) & 1u) == 0u;
-      Vec<D> a;
-      Mat<D> P;
-      if (tid == 0 && l == 0) {
-        a = a1e;
-        P = mzero<D>();
-#pragma unroll
-        for (int i = 0; i < D; ++i) P.m[i][i] = md.p1.v[i];
-      } else {
-        a = trans_apply(mf);
-        P = trans_cov(Pf, q);
-      }
-      ap[l] = a;
-      Pp[l] = P;
-      if (obs) {
-        const float v = ytil[l] - a.v[0];
-        const float rF = 1.0f / (P.m[0][0] + md.H);
-        vf[l] = v * rF;
-#pragma unroll
-        for (int i = 0; i < D; ++i) kf[l].v[i] = P.m[i][0] * rF;
-#pragma unroll
-        for (int i = 0; i < D; ++i) mf.v[i] = fmaf(kf[l].v[i], v, a.v[i]);
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-          for (int j = 0; j < D; ++j) Pf.m[i][j] = P.m[i][j] - kf[l].v[i] * P.m[0][j];
-        symmetrize(Pf);
-      } else {
-        vf[l] = 0.f;
-        kf[l] = vzero<D>();
-        mf = a;
-        Pf = P;
-      }
-    }
-  }
+  float vf[L], fvar[L];
+  kalman_filter_pass<D, L>(md, a1e, q, ytil, maskbits, tid, lane, wave, slots + NW * 16, ap, Pp,
+                           kf, vf, fvar, prof);
 
   prof.tick(6);
   // ---- (3) backward recursion r_{t-1} = (I - K_t Z)' T' r_t + Z' v_t / F_t as a suffix scan
@@ -1333,6 +1355,73 @@ __global__ __launch_bounds__(NT) void test_dk_kernel(int T, const float* resid_g
 #pragma unroll
       for (int i = 0; i < D; ++i) out[(size_t)t * D + i] = x[l].v[i];
   }
+}
+
+// ------------------------------------------------------------------------------------
+// Kalman-filter log-likelihood of the trend + regression model,
+// one workgroup per parameter set:  l(theta) = sum_{t observed} log N(v_t; 0, F_t).
+// theta[e] = (sigma_obs, sigma_level, sigma_slope, weights[P]).  Same associative filter as
+// the sampler; oracle: ci_oracle_kalman_loglik (pinned to the dense MVN log-density).
+// ------------------------------------------------------------------------------------
+template <int D, int L>
+__global__ __launch_bounds__(NT) void loglik_kernel(int T, int P, const float* __restrict__ y,
+                                                    const uint8_t* __restrict__ mask,
+                                                    const float* __restrict__ Xt,
+                                                    const double* __restrict__ theta, float a1,
+                                                    float p10, float p11,
+                                                    double* __restrict__ out) {
+  __shared__ float slots[NW * 16];
+  __shared__ float part[NW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* th = theta + (size_t)blockIdx.x * (3 + P);
+  const int t0 = tid * L;
+  float resid[L];
+  uint32_t maskbits = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    float r = 0.f;
+    if (t < T && !mask[t]) {
+      r = y[t];
+      for (int j = 0; j < P; ++j) r = fmaf(-Xt[(size_t)j * T + t], (float)th[3 + j], r);
+    } else {
+      maskbits |= 1u << l;
+    }
+    resid[l] = r;
+  }
+  DkModel<D> md;
+  const float so = (float)th[0];
+  md.H = so * so;
+  md.sig.v[0] = (float)th[1];
+  md.a1 = vzero<D>();
+  md.a1.v[0] = a1;
+  md.p1.v[0] = p10;
+  if constexpr (D == 2) {
+    md.sig.v[1] = (float)th[2];
+    md.p1.v[1] = p11;
+  }
+  Vec<D> q;
+#pragma unroll
+  for (int i = 0; i < D; ++i) q.v[i] = md.sig.v[i] * md.sig.v[i];
+  Vec<D> ap[L];
+  Mat<D> Pp[L];
+  Vec<D> kf[L];
+  float vf[L], fvar[L];
+  Prof prof;
+  prof.start(nullptr, false);
+  kalman_filter_pass<D, L>(md, md.a1, q, resid, maskbits, tid, lane, wave, slots, ap, Pp, kf, vf,
+                           fvar, prof);
+  float acc = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    if (((maskbits >> l) & 1u) == 0u)
+      acc -= 0.5f * (1.8378770664093453f + __logf(fvar[l]) + vf[l] * vf[l] * fvar[l]);
+  }
+  const float w = wave_prefix_dpp(acc);
+  if (lane == 63) part[wave] = w;
+  __syncthreads();
+  if (tid == 0) out[blockIdx.x] = (double)part[0] + (double)part[1] + (double)part[2] + (double)part[3];
 }
 
 }  // namespace ci

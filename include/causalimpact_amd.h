@@ -126,6 +126,25 @@ int ci_kalman_loglik(const ci_problem* problem, const ci_series_params* params, 
                      const uint8_t* mask, const float* X, int32_t num_evals, const double* theta,
                      double* loglik);
 
+/* Device-resident variant for samplers that evaluate l(theta) many times (HMC leapfrogs):
+ * data stay in HBM; each eval moves only theta in and (loglik, grad) out.
+ *   grad [num_evals, 3 + P] float64 = dl/d(sigma_obs, sigma_level, sigma_slope, weights);
+ *   NULL skips the backward pass.
+ * ci_ll_session_draw_latents draws, for each theta row, one latent path (Durbin-Koopman) and
+ * one posterior-predictive trajectory (what one_step_predictive, causalimpact_lib.py:620-631,
+ * does with GibbsSamplerState draws): level/slope/loc/traj are [num_draws, T] float32; RNG
+ * stream (seed, chain = rng_chain, iteration = iter0 + draw). */
+typedef struct ci_ll_session ci_ll_session;
+int ci_ll_session_create(const ci_problem* problem, const ci_series_params* params, const float* y,
+                         const uint8_t* mask, const float* X, int32_t max_evals,
+                         ci_ll_session** session);
+int ci_ll_session_eval(ci_ll_session* session, int32_t num_evals, const double* theta,
+                       double* loglik, double* grad);
+int ci_ll_session_draw_latents(ci_ll_session* session, int32_t num_draws, const double* theta,
+                               const uint32_t seed[2], uint32_t rng_chain, uint32_t iter0,
+                               float* level, float* slope, float* loc, float* traj);
+int ci_ll_session_destroy(ci_ll_session* session);
+
 /* ---- component entry points used by the parity tests (tests/test_gpu_*.py) ---- */
 /* normals/uniforms/gammas of the specified Philox stream, computed on device. */
 int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t iter, uint32_t site,

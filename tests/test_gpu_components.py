@@ -109,3 +109,66 @@ def test_kalman_loglik_matches_oracle(T, p, has_slope):
     resid = np.where(mask, 0.0, y) - (X @ theta[e, 3:] if P else 0.0)
     want = orc.kalman_loglik(ssm, resid)
     np.testing.assert_allclose(got[e], want, rtol=2e-5, atol=2e-3)
+
+
+def _ll_setup(T, p, has_slope, E=5, seed=0):
+  from causalimpact import _synthetic as syn
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 11)
+  mask[[3, 9]] = True
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope))
+  P = spec["P"]
+  rng = np.random.default_rng(seed)
+  theta = np.zeros((E, 3 + P))
+  theta[:, 0] = rng.uniform(0.3, 0.9, E)
+  theta[:, 1] = rng.uniform(0.02, 0.2, E)
+  theta[:, 2] = rng.uniform(0.005, 0.03, E) if has_slope else 0.0
+  theta[:, 3:] = 0.3 * rng.normal(size=(E, P))
+  pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_warmup=0, num_results=1, seed=(4, 2))
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=64)
+  return y, mask, X, spec, theta, sess
+
+
+def _oracle_ll(spec, y, mask, X, th):
+  ssm = orc.make_ssm(spec, mask, obs_scale=th[0], level_scale=th[1], slope_scale=th[2])
+  resid = np.where(mask, 0.0, y) - (X @ th[3:] if spec["P"] else 0.0)
+  return orc.kalman_loglik(ssm, resid)
+
+
+@pytest.mark.parametrize("T,p,has_slope", [(80, 2, 1), (300, 0, 0), (1000, 10, 1)])
+def test_loglik_score_matches_finite_differences_of_oracle(T, p, has_slope):
+  """Row H: device score (two suffix scans) vs central differences of the float64 oracle
+  log-likelihood.  float32 recursions: 2 % relative on each component's scale."""
+  y, mask, X, spec, theta, sess = _ll_setup(T, p, has_slope)
+  ll, grad = sess.evaluate(theta)
+  for e in range(theta.shape[0]):
+    np.testing.assert_allclose(ll[e], _oracle_ll(spec, y, mask, X, theta[e]), rtol=2e-5, atol=2e-3)
+    fd = np.zeros(theta.shape[1])
+    for i in range(theta.shape[1]):
+      if i == 2 and not has_slope:
+        continue
+      h = 1e-6 * max(1.0, abs(theta[e, i]))
+      a, b = theta[e].copy(), theta[e].copy()
+      a[i] += h
+      b[i] -= h
+      fd[i] = (_oracle_ll(spec, y, mask, X, a) - _oracle_ll(spec, y, mask, X, b)) / (2 * h)
+    scale = np.maximum(np.abs(fd), 1e-2 * np.abs(fd).max())
+    assert (np.abs(grad[e] - fd) <= 2e-2 * scale + 1e-2).all(), (grad[e], fd)
+  sess.close()
+
+
+def test_latent_draws_for_given_parameters_match_oracle():
+  T, p, has_slope = 200, 3, 1
+  y, mask, X, spec, theta, sess = _ll_setup(T, p, has_slope, E=3)
+  out = sess.draw_latents(theta, seed=(4, 2), rng_chain=7, iter0=10)
+  for e in range(3):
+    th = theta[e]
+    ssm = orc.make_ssm(spec, mask, obs_scale=th[0], level_scale=th[1], slope_scale=th[2])
+    resid = np.where(mask, 0.0, y - X @ th[3:])
+    want = orc.dk_draw(ssm, resid, (4, 2), chain=7, it=10 + e)
+    np.testing.assert_allclose(out["level"][e], want[:, 0], atol=3e-3)
+    np.testing.assert_allclose(out["slope"][e], want[:, 1], atol=3e-3)
+    loc = want[:, 0] + X @ th[3:]
+    np.testing.assert_allclose(out["loc"][e], loc, atol=3e-3)
+    zp = np.array([orc.normal((4, 2), 7, 10 + e, orc.SITES["PRED"], 0, t) for t in range(T)])
+    np.testing.assert_allclose(out["traj"][e], loc + th[0] * zp, atol=5e-3)
+  sess.close()

@@ -78,6 +78,13 @@ def load():
   L.ci_session_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   L.ci_kalman_loglik.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+  L.ci_ll_session_create.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+  L.ci_ll_session_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+  L.ci_ll_session_draw_latents.argtypes = [C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+  L.ci_ll_session_destroy.argtypes = [C.c_void_p]
   L.ci_test_rng.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
                             C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
   L.ci_test_dk_draw.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p, C.c_void_p,
@@ -94,7 +101,8 @@ def exported_symbols() -> Sequence[str]:
   return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_fit_gibbs",
           "ci_session_create", "ci_session_run", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_session_profile",
-          "ci_kalman_loglik", "ci_test_rng",
+          "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_eval",
+          "ci_ll_session_draw_latents", "ci_ll_session_destroy", "ci_test_rng",
           "ci_test_dk_draw")
 
 
@@ -246,6 +254,51 @@ def kalman_loglik(pb: Problem, params, y, mask, X, theta) -> np.ndarray:
   _check(L.ci_kalman_loglik(C.byref(pb), params, y32.ctypes.data, m8.ctypes.data, _ptr(X32),
                             th.shape[0], th.ctypes.data, out.ctypes.data))
   return out
+
+
+class LogLikSession:
+  """Device-resident log-likelihood / score evaluator and latent-path drawer for one series."""
+
+  def __init__(self, pb: Problem, params, y, mask, X, max_evals: int):
+    self._lib = load()
+    self.T, self.P, self.D = pb.T, pb.P, 2 if pb.has_slope else 1
+    self.max_evals = int(max_evals)
+    m8 = np.ascontiguousarray(np.asarray(mask, bool).astype(np.uint8))
+    y32 = np.ascontiguousarray(np.where(m8 != 0, np.float32(0), np.asarray(y, np.float32)))
+    X32 = (np.ascontiguousarray(np.asarray(X, np.float32).reshape(self.T, self.P))
+           if self.P > 0 else None)
+    self._h = C.c_void_p()
+    _check(self._lib.ci_ll_session_create(C.byref(pb), params, y32.ctypes.data, m8.ctypes.data,
+                                          _ptr(X32), self.max_evals, C.byref(self._h)))
+
+  def evaluate(self, theta, want_grad=True):
+    th = np.ascontiguousarray(np.asarray(theta, np.float64).reshape(-1, 3 + self.P))
+    ll = np.zeros(th.shape[0], np.float64)
+    grad = np.zeros_like(th) if want_grad else None
+    _check(self._lib.ci_ll_session_eval(self._h, th.shape[0], th.ctypes.data, ll.ctypes.data,
+                                        _ptr(grad)))
+    return ll, grad
+
+  def draw_latents(self, theta, seed, rng_chain=0, iter0=0):
+    th = np.ascontiguousarray(np.asarray(theta, np.float64).reshape(-1, 3 + self.P))
+    E = th.shape[0]
+    out = {k: np.zeros((E, self.T), np.float32) for k in ("level", "slope", "loc", "traj")}
+    s = (C.c_uint32 * 2)(*seed_pair(seed))
+    _check(self._lib.ci_ll_session_draw_latents(
+        self._h, E, th.ctypes.data, s, int(rng_chain), int(iter0), out["level"].ctypes.data,
+        out["slope"].ctypes.data, out["loc"].ctypes.data, out["traj"].ctypes.data))
+    return out
+
+  def close(self):
+    if self._h:
+      self._lib.ci_ll_session_destroy(self._h)
+      self._h = C.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
 
 
 def test_rng(seed, chain, it, site, sub, n, alpha, device=0):

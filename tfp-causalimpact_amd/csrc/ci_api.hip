@@ -24,7 +24,14 @@ extern "C" void* ci_gibbs_seasonal_fn(void);
                                            uint32_t, uint32_t, float*);                           \
   extern "C" void ci_launch_loglik_d##D##_l##L(int, int, int, const float*, const uint8_t*,       \
                                                const float*, const double*, float, float, float,  \
-                                               double*, hipStream_t);
+                                               double*, hipStream_t);                             \
+  extern "C" void ci_launch_llgrad_d##D##_l##L(int, int, int, const float*, const uint8_t*,       \
+                                               const float*, const double*, float, float, float,  \
+                                               double*, double*, hipStream_t);                    \
+  extern "C" void ci_launch_latents_d##D##_l##L(int, int, int, const float*, const uint8_t*,      \
+                                                const float*, const double*, float, float, float, \
+                                                uint32_t, uint32_t, uint32_t, uint32_t, float*,   \
+                                                float*, float*, float*, hipStream_t);
 CI_DECL(1, 1) CI_DECL(1, 2) CI_DECL(1, 4) CI_DECL(1, 8) CI_DECL(1, 16)
 CI_DECL(2, 1) CI_DECL(2, 2) CI_DECL(2, 4) CI_DECL(2, 8) CI_DECL(2, 16)
 #undef CI_DECL
@@ -476,46 +483,127 @@ int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t ite
   return 0;
 }
 
-int ci_kalman_loglik(const ci_problem* pb, const ci_series_params* params, const float* y,
-                     const uint8_t* mask, const float* X, int32_t num_evals, const double* theta,
-                     double* loglik) {
+struct ci_ll_session {
+  int T = 0, P = 0, D = 1, L = 1, device = 0, max_evals = 0;
+  float a1 = 0, p10 = 0, p11 = 0;
+  DevBuf<float> y, xt, level, slope, loc, traj;
+  DevBuf<uint8_t> mask;
+  DevBuf<double> theta, ll, grad;
+  size_t draw_cap = 0;
+};
+
+int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, const float* y,
+                         const uint8_t* mask, const float* X, int32_t max_evals,
+                         ci_ll_session** out) {
   if (validate(pb)) return 1;
-  if (pb->num_blocks != 0) return fail("ci_kalman_loglik: seasonal blocks not supported yet");
-  if (!params || !y || !mask || !theta || !loglik || num_evals < 1) return fail("bad argument");
+  if (pb->num_blocks != 0) return fail("log-likelihood path: seasonal blocks not supported yet");
+  if (!params || !y || !mask || !out || max_evals < 1) return fail("bad argument");
   if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
   HIP_TRY(hipSetDevice(pb->device));
-  const int T = pb->T, P = pb->P, D = pb->has_slope ? 2 : 1, L = steps_per_thread(T);
-  DevBuf<float> dy, dxt;
-  DevBuf<uint8_t> dm;
-  DevBuf<double> dth, dout;
-  HIP_TRY(dy.alloc(T));
-  HIP_TRY(dm.alloc(T));
-  HIP_TRY(dxt.alloc((size_t)P * T));
-  HIP_TRY(dth.alloc((size_t)num_evals * (3 + P)));
-  HIP_TRY(dout.alloc(num_evals));
-  HIP_TRY(hipMemcpy(dy.p, y, T * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dm.p, mask, T, hipMemcpyHostToDevice));
+  ci_ll_session* s = new ci_ll_session();
+  s->T = pb->T; s->P = pb->P; s->D = pb->has_slope ? 2 : 1; s->L = steps_per_thread(pb->T);
+  s->device = pb->device; s->max_evals = max_evals;
+  s->a1 = (float)params->init_level_loc;
+  s->p10 = (float)(params->init_level_scale * params->init_level_scale);
+  s->p11 = (float)(params->init_slope_scale * params->init_slope_scale);
+  const int T = s->T, P = s->P;
+  HIP_TRY(s->y.alloc(T));
+  HIP_TRY(s->mask.alloc(T));
+  HIP_TRY(s->xt.alloc((size_t)P * T));
+  HIP_TRY(s->theta.alloc((size_t)max_evals * (3 + P)));
+  HIP_TRY(s->ll.alloc(max_evals));
+  HIP_TRY(s->grad.alloc((size_t)max_evals * (3 + P)));
+  std::vector<float> yh(T);
+  for (int t = 0; t < T; ++t) yh[t] = mask[t] ? 0.f : y[t];
+  HIP_TRY(hipMemcpy(s->y.p, yh.data(), T * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->mask.p, mask, T, hipMemcpyHostToDevice));
   if (P > 0) {
     std::vector<float> xt((size_t)P * T);
     for (int t = 0; t < T; ++t)
       for (int j = 0; j < P; ++j) xt[(size_t)j * T + t] = X[(size_t)t * P + j];
-    HIP_TRY(hipMemcpy(dxt.p, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->xt.p, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
   }
-  HIP_TRY(hipMemcpy(dth.p, theta, (size_t)num_evals * (3 + P) * sizeof(double), hipMemcpyHostToDevice));
-  const float a1 = (float)params->init_level_loc;
-  const float p10 = (float)(params->init_level_scale * params->init_level_scale);
-  const float p11 = (float)(params->init_slope_scale * params->init_slope_scale);
-#define CI_LL_CASE(DD, LL)                                                                      \
-  if (D == DD && L == LL)                                                                       \
-    ci_launch_loglik_d##DD##_l##LL(T, P, num_evals, dy.p, dm.p, dxt.p, dth.p, a1, p10, p11, dout.p, 0);
+  *out = s;
+  return 0;
+}
+
+int ci_ll_session_eval(ci_ll_session* s, int32_t num_evals, const double* theta, double* loglik,
+                       double* grad) {
+  if (!s || !theta || !loglik) return fail("NULL argument");
+  if (num_evals < 1 || num_evals > s->max_evals) return fail("num_evals out of range");
+  HIP_TRY(hipSetDevice(s->device));
+  const int T = s->T, P = s->P, D = s->D, L = s->L, E = num_evals;
+  HIP_TRY(hipMemcpy(s->theta.p, theta, (size_t)E * (3 + P) * sizeof(double), hipMemcpyHostToDevice));
+#define CI_LL_CASE(DD, LL)                                                                        \
+  if (D == DD && L == LL) {                                                                       \
+    if (grad)                                                                                     \
+      ci_launch_llgrad_d##DD##_l##LL(T, P, E, s->y.p, s->mask.p, s->xt.p, s->theta.p, s->a1,      \
+                                     s->p10, s->p11, s->ll.p, s->grad.p, 0);                      \
+    else                                                                                          \
+      ci_launch_loglik_d##DD##_l##LL(T, P, E, s->y.p, s->mask.p, s->xt.p, s->theta.p, s->a1,      \
+                                     s->p10, s->p11, s->ll.p, 0);                                 \
+  }
   CI_LL_CASE(1, 1) CI_LL_CASE(1, 2) CI_LL_CASE(1, 4) CI_LL_CASE(1, 8) CI_LL_CASE(1, 16)
   CI_LL_CASE(2, 1) CI_LL_CASE(2, 2) CI_LL_CASE(2, 4) CI_LL_CASE(2, 8) CI_LL_CASE(2, 16)
 #undef CI_LL_CASE
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(loglik, dout.p, num_evals * sizeof(double), hipMemcpyDeviceToHost));
-  dy.release(); dm.release(); dxt.release(); dth.release(); dout.release();
+  HIP_TRY(hipMemcpy(loglik, s->ll.p, E * sizeof(double), hipMemcpyDeviceToHost));
+  if (grad)
+    HIP_TRY(hipMemcpy(grad, s->grad.p, (size_t)E * (3 + P) * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
+}
+
+int ci_ll_session_draw_latents(ci_ll_session* s, int32_t num_draws, const double* theta,
+                               const uint32_t seed[2], uint32_t rng_chain, uint32_t iter0,
+                               float* level, float* slope, float* loc, float* traj) {
+  if (!s || !theta || !seed || !level || !loc || !traj) return fail("NULL argument");
+  if (num_draws < 1 || num_draws > s->max_evals) return fail("num_draws out of range");
+  HIP_TRY(hipSetDevice(s->device));
+  const int T = s->T, P = s->P, D = s->D, L = s->L, E = num_draws;
+  const size_t need = (size_t)E * T;
+  if (need > s->draw_cap) {
+    s->level.release(); s->slope.release(); s->loc.release(); s->traj.release();
+    HIP_TRY(s->level.alloc(need)); HIP_TRY(s->slope.alloc(need));
+    HIP_TRY(s->loc.alloc(need)); HIP_TRY(s->traj.alloc(need));
+    s->draw_cap = need;
+  }
+  HIP_TRY(hipMemcpy(s->theta.p, theta, (size_t)E * (3 + P) * sizeof(double), hipMemcpyHostToDevice));
+#define CI_LAT_CASE(DD, LL)                                                                       \
+  if (D == DD && L == LL)                                                                         \
+    ci_launch_latents_d##DD##_l##LL(T, P, E, s->y.p, s->mask.p, s->xt.p, s->theta.p, s->a1,       \
+                                    s->p10, s->p11, seed[0], seed[1], rng_chain, iter0,           \
+                                    s->level.p, s->slope.p, s->loc.p, s->traj.p, 0);
+  CI_LAT_CASE(1, 1) CI_LAT_CASE(1, 2) CI_LAT_CASE(1, 4) CI_LAT_CASE(1, 8) CI_LAT_CASE(1, 16)
+  CI_LAT_CASE(2, 1) CI_LAT_CASE(2, 2) CI_LAT_CASE(2, 4) CI_LAT_CASE(2, 8) CI_LAT_CASE(2, 16)
+#undef CI_LAT_CASE
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(level, s->level.p, need * sizeof(float), hipMemcpyDeviceToHost));
+  if (slope) {
+    if (D == 2) HIP_TRY(hipMemcpy(slope, s->slope.p, need * sizeof(float), hipMemcpyDeviceToHost));
+    else memset(slope, 0, need * sizeof(float));
+  }
+  HIP_TRY(hipMemcpy(loc, s->loc.p, need * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(traj, s->traj.p, need * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ci_ll_session_destroy(ci_ll_session* s) {
+  if (!s) return 0;
+  (void)hipSetDevice(s->device);
+  s->y.release(); s->xt.release(); s->mask.release(); s->theta.release(); s->ll.release();
+  s->grad.release(); s->level.release(); s->slope.release(); s->loc.release(); s->traj.release();
+  delete s;
+  return 0;
+}
+
+int ci_kalman_loglik(const ci_problem* pb, const ci_series_params* params, const float* y,
+                     const uint8_t* mask, const float* X, int32_t num_evals, const double* theta,
+                     double* loglik) {
+  ci_ll_session* s = nullptr;
+  if (ci_ll_session_create(pb, params, y, mask, X, num_evals, &s)) return 1;
+  const int rc = ci_ll_session_eval(s, num_evals, theta, loglik, nullptr);
+  ci_ll_session_destroy(s);
+  return rc;
 }
 
 int ci_test_dk_draw(const ci_problem* pb, const ci_series_params* params, const float* resid,

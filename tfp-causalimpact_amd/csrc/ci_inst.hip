@@ -54,4 +54,26 @@ void CI_CAT(ci_launch_loglik_d, CI_D, _l, CI_L)(int T, int P, int E, const float
                      mask, Xt, theta, a1, p10, p11, out);
 }
 
+void CI_CAT(ci_launch_llgrad_d, CI_D, _l, CI_L)(int T, int P, int E, const float* y,
+                                               const uint8_t* mask, const float* Xt,
+                                               const double* theta, float a1, float p10,
+                                               float p11, double* out_ll, double* out_grad,
+                                               hipStream_t stream) {
+  const size_t lds = sizeof(float) * (3 * ci::NW * 16 + ci::NW * (P + 4));
+  hipLaunchKernelGGL((ci::loglik_grad_kernel<CI_D, CI_L>), dim3(E), dim3(ci::NT), lds, stream, T, P,
+                     y, mask, Xt, theta, a1, p10, p11, out_ll, out_grad);
+}
+
+void CI_CAT(ci_launch_latents_d, CI_D, _l, CI_L)(int T, int P, int E, const float* y,
+                                                const uint8_t* mask, const float* Xt,
+                                                const double* theta, float a1, float p10,
+                                                float p11, uint32_t k0, uint32_t k1,
+                                                uint32_t rng_chain, uint32_t iter0, float* level,
+                                                float* slope, float* loc, float* traj,
+                                                hipStream_t stream) {
+  hipLaunchKernelGGL((ci::latents_kernel<CI_D, CI_L>), dim3(E), dim3(ci::NT), 0, stream, T, P, y,
+                     mask, Xt, theta, a1, p10, p11, k0, k1, rng_chain, iter0, level, slope, loc,
+                     traj);
+}
+
 }  // extern "C"

@@ -1424,4 +1424,271 @@ __global__ __launch_bounds__(NT) void loglik_kernel(int T, int P, const float* _
   if (tid == 0) out[blockIdx.x] = (double)part[0] + (double)part[1] + (double)part[2] + (double)part[3];
 }
 
+// ------------------------------------------------------------------------------------
+// Score of the Kalman log-likelihood (Koopman & Shephard 1992):
+//   e_t = v_t/F_t - K_t' T' r_t,   dl/dbeta = sum_obs x_t e_t,
+//   dl/dH = 1/2 sum_obs (e_t^2 - D_t),  D_t = 1/F_t + K_t' (T' N_t T) K_t,
+//   dl/dQ_ii = 1/2 sum_{t<T-1} (r_t[i]^2 - N_t[i][i]),
+// with r_{t-1} = (I - K_t Z)' T' r_t + Z' v_t/F_t and N_{t-1} = (T (I - K_t Z))' N_t (T (I - K_t Z))
+// + Z'Z/F_t (K_t = 0 and no Z terms at masked steps).  Both recursions are suffix scans
+// (affine maps for r, congruence maps N -> L' N L + C for N).  Checked against central
+// finite differences of the float64 oracle (tests/test_gpu_components.py).
+// ------------------------------------------------------------------------------------
+template <int D> struct NElem {
+  Mat<D> Lm;
+  Mat<D> C;
+};
+template <int D> __device__ __forceinline__ NElem<D> nelem_identity() {
+  NElem<D> e;
+  e.Lm = meye<D>();
+  e.C = mzero<D>();
+  return e;
+}
+// outer acts after inner:  N -> Lo' (Li' N Li + Ci) Lo + Co
+template <int D>
+__device__ __forceinline__ NElem<D> nelem_compose(const NElem<D>& o, const NElem<D>& i) {
+  NElem<D> r;
+  r.Lm = mm(i.Lm, o.Lm);
+  r.C = madd(mtm(o.Lm, mm(i.C, o.Lm)), o.C);
+  symmetrize(r.C);
+  return r;
+}
+
+template <int D, int L>
+__global__ __launch_bounds__(NT) void loglik_grad_kernel(int T, int P, const float* __restrict__ y,
+                                                         const uint8_t* __restrict__ mask,
+                                                         const float* __restrict__ Xt,
+                                                         const double* __restrict__ theta, float a1,
+                                                         float p10, float p11,
+                                                         double* __restrict__ out_ll,
+                                                         double* __restrict__ out_grad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+  float* slots = (float*)smem_g;                 // 3 * NW * 16
+  float* part = slots + 3 * NW * 16;             // NW * (P + 4)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* th = theta + (size_t)blockIdx.x * (3 + P);
+  const int t0 = tid * L;
+  float resid[L];
+  uint32_t maskbits = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    float r = 0.f;
+    if (t < T && !mask[t]) {
+      r = y[t];
+      for (int j = 0; j < P; ++j) r = fmaf(-Xt[(size_t)j * T + t], (float)th[3 + j], r);
+    } else {
+      maskbits |= 1u << l;
+    }
+    resid[l] = r;
+  }
+  DkModel<D> md;
+  const float so = (float)th[0];
+  md.H = so * so;
+  md.sig.v[0] = (float)th[1];
+  md.a1 = vzero<D>();
+  md.a1.v[0] = a1;
+  md.p1.v[0] = p10;
+  if constexpr (D == 2) {
+    md.sig.v[1] = (float)th[2];
+    md.p1.v[1] = p11;
+  }
+  Vec<D> q;
+#pragma unroll
+  for (int i = 0; i < D; ++i) q.v[i] = md.sig.v[i] * md.sig.v[i];
+  Vec<D> ap[L];
+  Mat<D> Pp[L];
+  Vec<D> kf[L];
+  float vf[L], fvar[L];
+  Prof prof;
+  prof.start(nullptr, false);
+  kalman_filter_pass<D, L>(md, md.a1, q, resid, maskbits, tid, lane, wave, slots, ap, Pp, kf, vf,
+                           fvar, prof);
+  float ll = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+    if (((maskbits >> l) & 1u) == 0u)
+      ll -= 0.5f * (1.8378770664093453f + __logf(fvar[l]) + vf[l] * vf[l] * fvar[l]);
+
+  // per-step maps
+  Mat<D> Tt = meye<D>();
+  if constexpr (D == 2) Tt.m[1][0] = 1.f;               // T'
+  const Mat<D> Tm = trans_mat<D>();
+  auto ikz = [&](int l) {                                // I - K Z  (Z = e_0')
+    Mat<D> m = meye<D>();
+#pragma unroll
+    for (int i = 0; i < D; ++i) m.m[i][0] -= kf[l].v[i];
+    return m;
+  };
+  auto r_map = [&](int l) {
+    AElem<D> e;
+    Mat<D> ikzt = meye<D>();
+#pragma unroll
+    for (int j = 0; j < D; ++j) ikzt.m[0][j] -= kf[l].v[j];
+    e.M = mm(ikzt, Tt);
+    e.c = vzero<D>();
+    e.c.v[0] = vf[l];
+    return e;
+  };
+  auto n_map = [&](int l) {
+    NElem<D> e;
+    e.Lm = mm(Tm, ikz(l));
+    e.C = mzero<D>();
+    if (((maskbits >> l) & 1u) == 0u) e.C.m[0][0] = 1.0f / fvar[l];
+    return e;
+  };
+  AElem<D> atot = r_map(L - 1);
+  NElem<D> ntot = n_map(L - 1);
+#pragma unroll
+  for (int l = L - 2; l >= 0; --l) {
+    atot = aelem_compose(r_map(l), atot);
+    ntot = nelem_compose(n_map(l), ntot);
+  }
+  const AElem<D> asuf = block_scan_excl_bwd(
+      atot, [](const AElem<D>& o, const AElem<D>& i) { return aelem_compose(o, i); },
+      aelem_identity<D>(), slots + NW * 16, lane, wave);
+  const NElem<D> nsuf = block_scan_excl_bwd(
+      ntot, [](const NElem<D>& o, const NElem<D>& i) { return nelem_compose(o, i); },
+      nelem_identity<D>(), slots + 2 * NW * 16, lane, wave);
+
+  float gH = 0.f, gQ[D], e_l[L];
+#pragma unroll
+  for (int i = 0; i < D; ++i) gQ[i] = 0.f;
+  {
+    Vec<D> r = asuf.c;       // r_t, N_t entering this thread's last step
+    Mat<D> N = nsuf.C;
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+      const int t = t0 + l;
+      if (t + 1 < T) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) gQ[i] += 0.5f * (r.v[i] * r.v[i] - N.m[i][i]);
+      }
+      const Vec<D> rT = mv(Tt, r);
+      const Mat<D> NT = mm(Tt, mm(N, Tm));
+      e_l[l] = 0.f;
+      if (((maskbits >> l) & 1u) == 0u) {
+        float kr = 0.f;
+#pragma unroll
+        for (int i = 0; i < D; ++i) kr = fmaf(kf[l].v[i], rT.v[i], kr);
+        const float e = vf[l] - kr;
+        const Vec<D> nk = mv(NT, kf[l]);
+        float dt = 1.0f / fvar[l];
+#pragma unroll
+        for (int i = 0; i < D; ++i) dt = fmaf(kf[l].v[i], nk.v[i], dt);
+        gH += 0.5f * (e * e - dt);
+        e_l[l] = e;
+        const Mat<D> m = ikz(l);
+        r = mtv(m, rT);
+        r.v[0] += vf[l];
+        N = mtm(m, mm(NT, m));
+        N.m[0][0] += 1.0f / fvar[l];
+        symmetrize(N);
+      } else {
+        r = rT;
+        N = NT;
+      }
+    }
+  }
+  // block sums: ll, dH, dQ[0], dQ[1], then dbeta_j
+  const int NS = P + 4;
+  auto put = [&](int slot, float v) {
+    const float w = wave_prefix_dpp(v);
+    if (lane == 63) part[wave * NS + slot] = w;
+  };
+  put(0, ll);
+  put(1, gH);
+  put(2, gQ[0]);
+  put(3, D == 2 ? gQ[D - 1] : 0.f);
+  for (int j = 0; j < P; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+      if (t0 + l < T) s = fmaf(Xt[(size_t)j * T + t0 + l], e_l[l], s);
+    put(4 + j, s);
+  }
+  __syncthreads();
+  if (tid < NS) {
+    double s = 0.0;
+    for (int w = 0; w < NW; ++w) s += (double)part[w * NS + tid];
+    if (tid == 0) out_ll[blockIdx.x] = s;
+    else {
+      double* g = out_grad + (size_t)blockIdx.x * (3 + P);
+      if (tid == 1) g[0] = 2.0 * th[0] * s;            // d/d sigma_obs   = 2 sigma dl/dH
+      else if (tid == 2) g[1] = 2.0 * th[1] * s;       // d/d sigma_level
+      else if (tid == 3) g[2] = (D == 2) ? 2.0 * th[2] * s : 0.0;
+      else g[3 + (tid - 4)] = s;                       // d/d beta_j
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Latent path + posterior-predictive trajectory for GIVEN parameter draws (one workgroup per
+// draw): what one_step_predictive needs after an HMC fit, where the latents are not part of
+// the chain state.  theta[e] = (sigma_obs, sigma_level, sigma_slope, weights[P]); RNG stream:
+// chain = rng_chain, iteration = e.
+// ------------------------------------------------------------------------------------
+template <int D, int L>
+__global__ __launch_bounds__(NT) void latents_kernel(int T, int P, const float* __restrict__ y,
+                                                     const uint8_t* __restrict__ mask,
+                                                     const float* __restrict__ Xt,
+                                                     const double* __restrict__ theta, float a1,
+                                                     float p10, float p11, uint32_t k0, uint32_t k1,
+                                                     uint32_t rng_chain, uint32_t iter0,
+                                                     float* __restrict__ out_level,
+                                                     float* __restrict__ out_slope,
+                                                     float* __restrict__ out_loc,
+                                                     float* __restrict__ out_traj) {
+  __shared__ float slots[3 * NW * 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* th = theta + (size_t)blockIdx.x * (3 + P);
+  const int t0 = tid * L;
+  float resid[L], xw[L];
+  uint32_t maskbits = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    float s = 0.f;
+    if (t < T)
+      for (int j = 0; j < P; ++j) s = fmaf(Xt[(size_t)j * T + t], (float)th[3 + j], s);
+    xw[l] = s;
+    const bool m = (t >= T) || mask[t] != 0;
+    if (m) maskbits |= 1u << l;
+    resid[l] = m ? 0.f : y[t] - s;
+  }
+  DkModel<D> md;
+  const float so = (float)th[0];
+  md.H = so * so;
+  md.sig.v[0] = (float)th[1];
+  md.a1 = vzero<D>();
+  md.a1.v[0] = a1;
+  md.p1.v[0] = p10;
+  if constexpr (D == 2) {
+    md.sig.v[1] = (float)th[2];
+    md.p1.v[1] = p11;
+  }
+  Rng g{k0, k1, rng_chain};
+  const uint32_t iter = iter0 + blockIdx.x;
+  Vec<D> x[L];
+  Prof prof;
+  prof.start(nullptr, false);
+  dk_draw<D, L>(md, resid, maskbits, g, iter, tid, lane, wave, slots, x, prof);
+  float zp[L];
+  fill_normals<L>(g, iter, SITE_PRED, 0, (uint32_t)t0, zp);
+  const size_t row = (size_t)blockIdx.x * T;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    if (t < T) {
+      const float loc = x[l].v[0] + xw[l];
+      out_level[row + t] = x[l].v[0];
+      if constexpr (D == 2) { if (out_slope) out_slope[row + t] = x[l].v[1]; }
+      out_loc[row + t] = loc;
+      out_traj[row + t] = fmaf(so, zp[l], loc);
+    }
+  }
+}
+
 }  // namespace ci

@@ -115,7 +115,8 @@ def main():
     if world == 1 and args.gpus > 1:
       raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
   dist = None
-  if world > 1:
+  # CI_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU smoke test)
+  if world > 1 or os.environ.get("CI_BENCH_FORCE_DIST") == "1":
     import torch  # pylint: disable=import-outside-toplevel
     import torch.distributed as dist  # pylint: disable=import-outside-toplevel
     torch.cuda.set_device(local_rank)

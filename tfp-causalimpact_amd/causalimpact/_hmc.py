@@ -1,0 +1,201 @@
+"""Hamiltonian Monte Carlo over the model's parameters, likelihood and score on the GPU.
+
+EXTENSION: the reference release is Gibbs-only -- there is no
+`_run_hmc` in /root/reference -- but BASELINE.json's configs 1 and 3 ask for an HMC fit, so
+this mirrors what `tfp.sts.fit_with_hmc` does upstream, with the pieces re-designed for the
+device: the target's expensive part, the Kalman-filter log-likelihood l(theta) and its score,
+are ONE kernel launch per leapfrog step for ALL chains (`ci_ll_session_eval`: associative
+filter scan + two suffix scans); latent paths and posterior-predictive trajectories are drawn
+afterwards for every retained theta (`ci_ll_session_draw_latents`).  Parity with TFP: unpinned
+(no reference call site, no reference test); it is validated against this build's Gibbs
+posterior on the same data (tests/test_gpu_hmc.py).
+
+Model / target.  theta = (beta, log sigma_obs, log sigma_level[, log sigma_slope]);
+  log p(theta | y) = l(sigma, beta) + sum_k log IG(sigma_k^2; a_k, b_k) + log|d sigma^2/d log sigma|
+                     - 1/2 beta' Omega beta,
+with the reference's inverse-gamma variance priors (causalimpact_lib.py:424-443) and, because
+the spike-and-slab prior has no density, the Gaussian slab of that prior alone:
+Omega = 0.01 (X'X/2 + diag(X'X)/2) / T (causalimpact_lib.py:451-453).  The reference's hard
+upper bounds on the scales (:432, :442) are not part of this target.
+
+Sampler.  Fixed-length leapfrog trajectories, per-chain step size by dual averaging
+(Nesterov 2009 / Hoffman & Gelman 2014, target acceptance 0.75) during warm-up, diagonal mass
+matrix estimated once from the middle of warm-up (pooled over chains).  Momentum and
+accept/reject randomness is host-side numpy (Philox bit generator keyed by the seed pair).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from causalimpact import _native
+
+
+def _unpack(theta_u: np.ndarray, P: int, has_slope: bool):
+  """unconstrained [C, dim] -> device layout [C, 3 + P] = (s_obs, s_level, s_slope, beta)."""
+  C = theta_u.shape[0]
+  out = np.zeros((C, 3 + P))
+  lam = np.clip(theta_u[:, P:], -30.0, 30.0)   # diverging trajectories are rejected anyway
+  out[:, 0] = np.exp(lam[:, 0])
+  out[:, 1] = np.exp(lam[:, 1])
+  if has_slope:
+    out[:, 2] = np.exp(lam[:, 2])
+  out[:, 3:] = theta_u[:, :P]
+  return out
+
+
+class _Target:
+  """log posterior and gradient for all chains at once (one device call)."""
+
+  def __init__(self, sess, spec, omega, P, has_slope):
+    self.sess, self.P, self.has_slope, self.omega = sess, P, has_slope, omega
+    self.ig = [(spec["obs_conc"], spec["obs_scale"]), (spec["level_conc"], spec["level_scale"])]
+    if has_slope:
+      self.ig.append((spec["slope_conc"], spec["slope_scale"]))
+    self.dim = P + len(self.ig)
+    self.calls = 0
+
+  def __call__(self, theta_u):
+    P = self.P
+    dev = _unpack(theta_u, P, self.has_slope)
+    ll, g = self.sess.evaluate(dev, want_grad=True)
+    self.calls += 1
+    lp = ll.copy()
+    grad = np.zeros_like(theta_u)
+    beta = theta_u[:, :P]
+    if P:
+      ob = beta @ self.omega
+      lp -= 0.5 * np.sum(beta * ob, axis=1)
+      grad[:, :P] = g[:, 3:] - ob
+    for k, (a, b) in enumerate(self.ig):
+      lam = theta_u[:, P + k]
+      lam = np.clip(lam, -30.0, 30.0)
+      lp += -2.0 * a * lam - b * np.exp(-2.0 * lam)
+      grad[:, P + k] = dev[:, k] * g[:, k] - 2.0 * a + 2.0 * b * np.exp(-2.0 * lam)
+    bad = ~np.isfinite(lp)
+    lp[bad] = -np.inf
+    grad[bad] = 0.0
+    return lp, grad
+
+
+def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_warmup: int,
+            num_chains: int, seed, device: int = 0, chain_offset: int = 0, num_leapfrog: int = 15,
+            target_accept: float = 0.75, initial_step_size: float = 0.05) -> Dict[str, np.ndarray]:
+  """Returns the same arrays as `_native.fit_gibbs` (leading series axis of 1) plus
+  `hmc_accept_rate`, `hmc_step_size` [C] and `hmc_target_calls`."""
+  y = np.asarray(y, np.float64)
+  mask = np.asarray(mask, bool)
+  T = y.shape[0]
+  P = 0 if X is None else int(np.asarray(X).shape[1])
+  C, S, W = int(num_chains), int(num_results), int(num_warmup)
+  pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_warmup=0, num_results=1,
+                            seed=seed, device=device)
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X,
+                               max_evals=max(C, min(256, C * S)))
+  omega = None
+  if P:
+    X64 = np.asarray(X, np.float64)
+    xtx = X64.T @ X64
+    omega = 0.01 * (0.5 * xtx + 0.5 * np.diag(np.diag(xtx))) / T        # :451-453
+  target = _Target(sess, spec, omega, P, has_slope)
+  dim = target.dim
+  s0, s1 = _native.seed_pair(seed)
+  rng = np.random.Generator(np.random.Philox(key=[(s0 << 32) | s1, 0x484D43 + chain_offset]))
+
+  # start from the initial Gibbs state (causalimpact_lib.py:566-581) with a little jitter
+  theta = np.zeros((C, dim))
+  theta[:, P] = np.log(spec["obs_scale0"])
+  theta[:, P + 1] = np.log(max(spec["level_scale0"], 1e-4))
+  if has_slope:
+    theta[:, P + 2] = np.log(max(spec["slope_scale0"], 1e-4))
+  theta += 0.01 * rng.normal(size=theta.shape)
+  lp, grad = target(theta)
+
+  inv_mass = np.ones(dim)
+  # dual averaging state per chain
+  eps = np.full(C, initial_step_size)
+  mu = np.log(10.0 * eps)
+  hbar = np.zeros(C)
+  log_eps_bar = np.zeros(C)
+  t_da = np.zeros(C)
+  gamma_da, t0_da, kappa_da = 0.05, 10.0, 0.75
+  window = (int(0.25 * W), int(0.75 * W))
+  collected = []
+  draws = np.zeros((C, S, dim))
+  accepted = np.zeros(C)
+
+  def restart_dual_averaging():
+    nonlocal mu, hbar, log_eps_bar, t_da
+    mu = np.log(10.0 * eps)
+    hbar = np.zeros(C)
+    log_eps_bar = np.zeros(C)
+    t_da = np.zeros(C)
+
+  for it in range(W + S):
+    mom = rng.normal(size=(C, dim)) / np.sqrt(inv_mass)
+    h0 = -lp + 0.5 * np.sum(mom * mom * inv_mass, axis=1)
+    th, g, p = theta.copy(), grad.copy(), mom.copy()
+    e = eps[:, None]
+    lp_new = lp
+    for _ in range(num_leapfrog):
+      p = p + 0.5 * e * g
+      th = th + e * inv_mass * p
+      lp_new, g = target(th)
+      p = p + 0.5 * e * g
+    h1 = -lp_new + 0.5 * np.sum(p * p * inv_mass, axis=1)
+    log_acc = np.where(np.isfinite(h1), h0 - h1, -np.inf)
+    acc_prob = np.exp(np.minimum(0.0, log_acc))
+    take = np.log(rng.random(C)) < log_acc
+    theta[take], lp[take], grad[take] = th[take], lp_new[take], g[take]
+    if it < W:
+      # dual averaging of log step size
+      t_da += 1.0
+      hbar = (1 - 1 / (t_da + t0_da)) * hbar + (target_accept - acc_prob) / (t_da + t0_da)
+      log_eps = mu - np.sqrt(t_da) / gamma_da * hbar
+      eta = t_da ** (-kappa_da)
+      log_eps_bar = eta * log_eps + (1 - eta) * log_eps_bar
+      eps = np.exp(log_eps)
+      if window[0] <= it < window[1]:
+        collected.append(theta.copy())
+      if it == window[1] - 1 and len(collected) >= 10:
+        pooled = np.concatenate(collected, axis=0)
+        var = pooled.var(axis=0) + 1e-8
+        inv_mass = var / var.mean() if np.all(np.isfinite(var)) else inv_mass
+        eps = np.exp(log_eps_bar)
+        restart_dual_averaging()
+      if it == W - 1:
+        eps = np.exp(log_eps_bar)
+    else:
+      draws[:, it - W] = theta
+      accepted += take
+
+  # latent paths + predictive trajectories for every retained draw
+  dev = _unpack(draws.reshape(C * S, dim), P, has_slope)
+  level = np.zeros((C * S, T), np.float32)
+  slope = np.zeros((C * S, T), np.float32)
+  loc = np.zeros((C * S, T), np.float32)
+  traj = np.zeros((C * S, T), np.float32)
+  step = sess.max_evals
+  for c in range(C):
+    for lo in range(0, S, step):
+      hi = min(S, lo + step)
+      rows = slice(c * S + lo, c * S + hi)
+      out = sess.draw_latents(dev[rows], seed, rng_chain=chain_offset + c, iter0=lo)
+      level[rows], slope[rows], loc[rows], traj[rows] = (out["level"], out["slope"], out["loc"],
+                                                          out["traj"])
+  calls = target.calls
+  sess.close()
+  dev3 = dev.reshape(C, S, 3 + P)
+  return dict(
+      observation_noise_scale=dev3[None, :, :, 0].astype(np.float32),
+      level_scale=dev3[None, :, :, 1].astype(np.float32),
+      slope_scale=dev3[None, :, :, 2].astype(np.float32),
+      seasonal_drift_scales=np.zeros((1, C, S, 0), np.float32),
+      weights=dev3[None, :, :, 3:].astype(np.float32),
+      level=level.reshape(1, C, S, T), slope=slope.reshape(1, C, S, T),
+      seasonal_levels=np.zeros((1, C, S, T, 0), np.float32),
+      posterior_means=loc.reshape(C, S, T).mean(axis=1)[None].astype(np.float32),
+      posterior_trajectories=traj.reshape(1, C, S, T),
+      hmc_accept_rate=accepted / max(S, 1), hmc_step_size=eps.copy(),
+      hmc_target_calls=np.array(calls))

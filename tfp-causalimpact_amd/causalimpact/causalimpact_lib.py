@@ -93,11 +93,13 @@ class ModelOptions:
 
 @dataclasses.dataclass
 class InferenceOptions:
-  """reference :206-220 (+ num_chains / devices extensions; defaults reproduce one chain)."""
+  """reference :206-220 (+ num_chains / devices / sampler extensions; defaults reproduce the
+  reference: one Gibbs chain)."""
   num_results: int = 900
   num_warmup_steps: Optional[int] = None
   num_chains: int = 1
   devices: Optional[Sequence[int]] = None
+  sampler: str = "gibbs"          # "gibbs" (the reference's sampler) or "hmc" (extension, _hmc.py)
 
   def __post_init__(self):
     if self.num_warmup_steps is None:
@@ -135,7 +137,8 @@ def fit_causalimpact(data: pd.DataFrame,
       num_results=inference_options.num_results,
       num_warmup_steps=inference_options.num_warmup_steps, dtype=data_options.dtype,
       seasons=model_options.seasons, num_chains=inference_options.num_chains,
-      devices=inference_options.devices, local_linear_trend=model_options.local_linear_trend)
+      devices=inference_options.devices, local_linear_trend=model_options.local_linear_trend,
+      sampler=inference_options.sampler)
   series, summary = _compute_impact(posterior_means=posterior_means,
                                     posterior_trajectories=posterior_trajectories,
                                     ci_data=ci_data, alpha=alpha)
@@ -192,7 +195,8 @@ def _train_causalimpact_sts(*,
                             experimental_tf_function_cache_key_addition: int = 0,
                             num_chains: int = 1,
                             devices: Optional[Sequence[int]] = None,
-                            local_linear_trend: bool = False):
+                            local_linear_trend: bool = False,
+                            sampler: str = "gibbs"):
   """Runs the Gibbs sampler on the GPU(s) (reference :503-606).
 
   Returns (samples dict, posterior_means [T], posterior_trajectories [draws, T]); draws are
@@ -222,11 +226,23 @@ def _train_causalimpact_sts(*,
   P = 0 if design is None else design.shape[1]
   K = len(num_seasons)
 
+  if sampler not in ("gibbs", "hmc"):
+    raise ValueError(f"sampler must be 'gibbs' or 'hmc', got {sampler!r}")
+  if sampler == "hmc" and K > 0:
+    raise NotImplementedError("the HMC extension does not support seasonal effects yet")
   devs = list(devices) if devices else [0]
   shares = np.array_split(np.arange(num_chains), len(devs))
   parts = []
   for dev, chain_ids in zip(devs, shares):
     if len(chain_ids) == 0:
+      continue
+    if sampler == "hmc":
+      from causalimpact import _hmc  # pylint: disable=import-outside-toplevel
+      res = _hmc.fit_hmc(y, mask, design, params, has_slope=local_linear_trend,
+                         num_results=num_results, num_warmup=num_warmup_steps,
+                         num_chains=len(chain_ids), seed=seed_pair, device=dev,
+                         chain_offset=int(chain_ids[0]))
+      parts.append({k: v for k, v in res.items() if not k.startswith("hmc_")})
       continue
     pb = _native.make_problem(T=T, P=P, has_slope=local_linear_trend, num_seasons=num_seasons,
                               num_warmup=num_warmup_steps, num_results=num_results,

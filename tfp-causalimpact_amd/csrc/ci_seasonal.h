@@ -44,8 +44,8 @@ struct SArgs {
 };
 
 struct SLayout {
-  size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, kf, rs, Pa, Pb, pzv, zi, x0r, mask, chg,
-      ei, ej, xtx, omega, bvec, w, total;
+  size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, Pa, Pb, pzv, zi, x0r, mask,
+      cbits, egg, emeta, d2, xtx, omega, bvec, w, total;
 };
 
 __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int dred,
@@ -53,22 +53,25 @@ __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int 
   SLayout l;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
-  const size_t Tf = sizeof(float) * (size_t)((T + 3) & ~3);
-  const int Pp = P > 0 ? P : 1;
+  const size_t TS = (size_t)((T + 3) & ~3);
+  const size_t Tf = sizeof(float) * TS;
+  const int Pp = P > 0 ? P : 1, Kp = K > 0 ? K : 1;
   l.xtx = take(sizeof(double) * Pp * Pp);
   l.omega = take(sizeof(double) * Pp * Pp);
   l.bvec = take(sizeof(double) * (Pp + 4));
   l.yv = take(Tf); l.lev = take(Tf); l.slp = take(has_slope ? Tf : 16); l.xw = take(Tf);
   l.ytil = take(Tf); l.vf = take(Tf); l.zl = take(Tf); l.zs = take(has_slope ? Tf : 16);
   l.zo = take(Tf);
-  l.seas = take(Tf * K); l.zk = take(Tf * K);
+  l.seas = take(Tf * Kp); l.zk = take(Tf * Kp); l.gd = take(Tf * Kp);
   l.kf = take(sizeof(float) * (size_t)T * D); l.rs = take(sizeof(float) * (size_t)T * D);
   l.Pa = take(sizeof(float) * D * D); l.Pb = take(sizeof(float) * D * D);
   l.pzv = take(sizeof(float) * D); l.zi = take(sizeof(float) * (dred + 1));
   l.x0r = take(sizeof(float) * (dred + 1));
-  l.w = take(sizeof(float) * Pp);
-  l.mask = take((size_t)T); l.chg = take((size_t)T * K);
-  l.ei = take((size_t)D * D); l.ej = take((size_t)D * D);
+  l.egg = take(sizeof(float) * D * D);
+  l.emeta = take(sizeof(uint32_t) * D * D);
+  l.d2 = take(sizeof(float) * SMAXK);
+  l.w = take(sizeof(float) * (Pp > 16 ? Pp : 16));
+  l.mask = take(TS); l.cbits = take(TS);
   l.total = o;
   return l;
 }
@@ -82,11 +85,16 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   const int series = blockIdx.x / g.C, chain = blockIdx.x % g.C;
   const size_t chain_lin = (size_t)series * g.C + chain;
   const int trend = a.has_slope ? 2 : 1;
+  // block geometry in registers: every loop over blocks is fully unrolled with static indices
   int off[SMAXK], nsz[SMAXK], roff[SMAXK];
   int D = trend;
   {
     int rr = trend;
-    for (int k = 0; k < K; ++k) { off[k] = D; nsz[k] = a.nseas[k]; roff[k] = rr; D += nsz[k]; rr += nsz[k] - 1; }
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k) {
+      off[k] = D; roff[k] = rr; nsz[k] = (k < K) ? a.nseas[k] : 0;
+      if (k < K) { D += nsz[k]; rr += nsz[k] - 1; }
+    }
   }
   const SLayout L = make_slayout(T, P, K, D, a.dred, a.has_slope);
   float* yv = (float*)(smem + L.yv); float* lev = (float*)(smem + L.lev);
@@ -94,13 +102,15 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   float* ytil = (float*)(smem + L.ytil); float* vf = (float*)(smem + L.vf);
   float* zl = (float*)(smem + L.zl); float* zs = (float*)(smem + L.zs);
   float* zo = (float*)(smem + L.zo); float* seas = (float*)(smem + L.seas);
-  float* zk = (float*)(smem + L.zk); float* kf = (float*)(smem + L.kf);
+  float* zk = (float*)(smem + L.zk); float* gd = (float*)(smem + L.gd);
+  float* kf = (float*)(smem + L.kf);
   float* rs = (float*)(smem + L.rs); float* Pcur = (float*)(smem + L.Pa);
   float* Pnxt = (float*)(smem + L.Pb); float* pzv = (float*)(smem + L.pzv);
   float* zi = (float*)(smem + L.zi); float* x0r = (float*)(smem + L.x0r);
-  uint8_t* msk = smem + L.mask; uint8_t* chg = smem + L.chg;
-  uint8_t* ei = smem + L.ei; uint8_t* ej = smem + L.ej;
-  const int TS = (T + 3) & ~3;       // row stride of the [K][T] float arrays
+  float* egg = (float*)(smem + L.egg); float* d2 = (float*)(smem + L.d2);
+  uint32_t* emeta = (uint32_t*)(smem + L.emeta);   // i | si<<6 | j<<12 | sj<<18 | bi<<24 | bj<<28
+  uint8_t* msk = smem + L.mask; uint8_t* cbv = smem + L.cbits;
+  const int TS = (T + 3) & ~3;       // padded length of every T-array (4-step blocks)
   RegLds R;
   R.xtx = (double*)(smem + L.xtx); R.omega = (double*)(smem + L.omega);
   R.bvec = (double*)(smem + L.bvec); R.w = (float*)(smem + L.w);
@@ -113,103 +123,121 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   const float* Xg = g.Xt + (size_t)series * P * T;
   const float* chol1 = a.p1_chol + (size_t)series * a.dred * a.dred;
 
-  // ---- lane roles: component `lane` of the state, block membership
-  int blk = -1, pos = 0, nb = 1, boff = 0;
-  for (int k = 0; k < K; ++k)
-    if (lane >= off[k] && lane < off[k] + nsz[k]) { blk = k; pos = lane - off[k]; nb = nsz[k]; boff = off[k]; }
+  // ---- lane roles: component `lane` of the state, block membership, shift partners
+  int blk = -1, pos = 0, nb = 1, boff = 0, rbase = 0;
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k)
+    if (k < K && lane >= off[k] && lane < off[k] + nsz[k]) {
+      blk = k; pos = lane - off[k]; nb = nsz[k]; boff = off[k]; rbase = roff[k];
+    }
   const bool comp = lane < D;
   const bool isz = comp && (lane == 0 || (blk >= 0 && pos == 0));   // rows of Z
+  const int fwd_src = blk >= 0 ? boff + (pos + 1 == nb ? 0 : pos + 1) : lane;   // x'_p = x_{p+1}
+  const int bwd_src = blk >= 0 ? boff + (pos == 0 ? nb - 1 : pos - 1) : lane;   // (T'r)_p = r_{p-1}
+  const float gpos = blk >= 0 ? ((pos == nb - 1) ? 1.f - 1.f / (float)nb : -1.f / (float)nb) : 0.f;
+  const int blk0 = blk >= 0 ? blk : 0;
 
   // ---- stage constants
-  for (int t = lane; t < T; t += 64) {
-    const bool m = g.mask[(size_t)series * T + t] != 0;
+  for (int t = lane; t < TS; t += 64) {
+    const bool in = t < T;
+    const bool m = in ? g.mask[(size_t)series * T + t] != 0 : true;
     msk[t] = m ? 1 : 0;
     yv[t] = m ? 0.f : g.y[(size_t)series * T + t];
-    lev[t] = 0.f; xw[t] = 0.f;
-    if (a.has_slope) slp[t] = 0.f;
-    for (int k = 0; k < K; ++k) { seas[k * TS + t] = 0.f; chg[k * T + t] = a.season_change[(size_t)k * T + t]; }
+    lev[t] = 0.f; xw[t] = 0.f; ytil[t] = 0.f; vf[t] = 0.f; zl[t] = 0.f; zo[t] = 0.f;
+    if (a.has_slope) { slp[t] = 0.f; zs[t] = 0.f; }
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        seas[k * TS + t] = 0.f; zk[k * TS + t] = 0.f; gd[k * TS + t] = 0.f;
+        if (in && a.season_change[(size_t)k * T + t]) bits |= 1u << k;
+      }
+    cbv[t] = (uint8_t)bits;
   }
   for (int e = lane; e < P * P; e += 64) {
     R.xtx[e] = g.xtx[(size_t)series * P * P + e];
     R.omega[e] = g.omega[(size_t)series * P * P + e];
   }
-  for (int e = lane; e < D * D; e += 64) { ei[e] = (uint8_t)(e / D); ej[e] = (uint8_t)(e % D); }
-  if (lane < P) R.w[lane] = 0.f;
+  // per-entry tables of the covariance time update P <- T P T' + Q
+  for (int e = lane; e < D * D; e += 64) {
+    const int i = e / D, j = e - i * D;
+    int bi = 15, bj = 15, si = i, sj = j;
+    float gi = 0.f, gj = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        if (i >= off[k] && i < off[k] + nsz[k]) {
+          bi = k; const int p = i - off[k]; si = off[k] + (p + 1 == nsz[k] ? 0 : p + 1);
+          gi = (p == nsz[k] - 1) ? 1.f - 1.f / (float)nsz[k] : -1.f / (float)nsz[k];
+        }
+        if (j >= off[k] && j < off[k] + nsz[k]) {
+          bj = k; const int p = j - off[k]; sj = off[k] + (p + 1 == nsz[k] ? 0 : p + 1);
+          gj = (p == nsz[k] - 1) ? 1.f - 1.f / (float)nsz[k] : -1.f / (float)nsz[k];
+        }
+      }
+    egg[e] = (bi == bj && bi != 15) ? gi * gj : 0.f;
+    emeta[e] = (uint32_t)i | ((uint32_t)si << 6) | ((uint32_t)j << 12) | ((uint32_t)sj << 18) |
+               ((uint32_t)bi << 24) | ((uint32_t)bj << 28);
+  }
+  if (lane < 16) R.w[lane] = 0.f;
   wave_sync();
   double n_changes[SMAXK];
-  for (int k = 0; k < K; ++k) {
-    float c = 0.f;
-    for (int t = lane; t + 1 < T; t += 64) c += chg[k * T + t] ? 1.f : 0.f;
-    n_changes[k] = (double)wave_sum(c);
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k) {
+    n_changes[k] = 0.0;
+    if (k < K) {
+      float c = 0.f;
+      for (int t = lane; t + 1 < T; t += 64) c += ((cbv[t] >> k) & 1) ? 1.f : 0.f;
+      n_changes[k] = (double)wave_sum_dpp(c);
+    }
   }
 
   double obs_scale = sp.obs_scale0, level_scale = sp.level_scale0, slope_scale = sp.slope_scale0;
   double drift[SMAXK];
-  for (int k = 0; k < K; ++k) drift[k] = ss.drift_scale0[k];
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k) drift[k] = (k < K) ? ss.drift_scale0[k] : 0.0;
   float ssl = 0.f, sss = 0.f, ssd = 0.f;   // lane 0 / lane 1 / lane off[k] accumulate
   const float p1l = (float)(sp.init_level_scale * sp.init_level_scale);
   const float p1s = (float)(sp.init_slope_scale * sp.init_slope_scale);
   const float p1e = (float)(ss.init_seasonal_scale * ss.init_seasonal_scale);
   Prof prof;
-  prof.start(nullptr, false);
+  prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && lane == 0);
   PriorCarry pc;
   pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
+#pragma unroll
   for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
 
   auto zsum = [&](float x) -> float {   // Z x for a lane-distributed vector
     float s = readlane_f(x, 0);
-    for (int k = 0; k < K; ++k) s += readlane_f(x, off[k]);
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) s += readlane_f(x, off[k]);
     return s;
   };
   // x <- T_t x : cyclic shift of the blocks that change season at t (+ level += slope)
-  auto transition = [&](float x, int t) -> float {
-    const float nxt = __shfl_down(x, 1, 64);
-    float r = x;
-    for (int k = 0; k < K; ++k) {
-      if (chg[k * T + t]) {
-        const float first = readlane_f(x, off[k]);
-        if (blk == k) r = (pos == nb - 1) ? first : nxt;
-      }
-    }
+  auto transition = [&](float x, unsigned cb) -> float {
+    const float sh = __shfl(x, fwd_src, 64);
+    float r = (blk >= 0 && ((cb >> blk) & 1u)) ? sh : x;
     if (a.has_slope) {
       const float s1 = readlane_f(x, 1);
       if (lane == 0) r += s1;
     }
     return r;
   };
-  // x <- T_t' x
-  auto transition_T = [&](float x, int t) -> float {
-    const float prv = __shfl_up(x, 1, 64);
-    float r = x;
-    for (int k = 0; k < K; ++k) {
-      if (chg[k * T + t]) {
-        const float last = readlane_f(x, off[k] + nsz[k] - 1);
-        if (blk == k) r = (pos == 0) ? last : prv;
-      }
-    }
+  auto transition_T = [&](float x, unsigned cb) -> float {   // x <- T_t' x
+    const float sh = __shfl(x, bwd_src, 64);
+    float r = (blk >= 0 && ((cb >> blk) & 1u)) ? sh : x;
     if (a.has_slope) {
       const float r0 = readlane_f(x, 0);
       if (lane == 1) r += r0;
     }
     return r;
   };
-  // disturbance of the prior simulation entering at transition t (after the shift)
-  auto sim_noise = [&](float x, int t, float sl, float ssl_, const double* dr) -> float {
-    float r = x;
-    if (lane == 0) r = fmaf(sl, zl[t], r);
-    if (a.has_slope && lane == 1) r = fmaf(ssl_, zs[t], r);
-    for (int k = 0; k < K; ++k) {
-      if (chg[k * T + t] && blk == k) {
-        const float w = (float)dr[k] * zk[k * TS + t];
-        r += (pos == nb - 1) ? w - w / (float)nb : -w / (float)nb;
-      }
-    }
-    return r;
-  };
+  auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+  auto ldb4 = [](const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); };
+  auto at4 = [](const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
 
   const int n_iter = g.W + g.S;
-  float pm_acc_dummy = 0.f;
-  (void)pm_acc_dummy;
   for (int it = 0; it <= n_iter; ++it) {
     // ---- (1) X~'targets, y'y from the current latents
     {
@@ -218,7 +246,9 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
         float tg = 0.f;
         if (!msk[t]) {
           tg = yv[t] - lev[t];
-          for (int k = 0; k < K; ++k) tg -= seas[k * TS + t];
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k)
+            if (k < K) tg -= seas[k * TS + t];
         }
         ytil[t] = tg;            // reused as the targets buffer here
         yty = fmaf(tg, tg, yty);
@@ -227,13 +257,14 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       for (int j = 0; j < P; ++j) {
         float pj = 0.f;
         for (int t = lane; t < T; t += 64) pj = fmaf(Xg[(size_t)j * T + t], ytil[t], pj);
-        const float s = wave_sum(pj);
+        const float s = wave_sum_dpp(pj);
         if (lane == 0) R.bvec[j] = (double)s;
       }
-      const float s0 = wave_sum(yty);
+      const float s0 = wave_sum_dpp(yty);
       if (lane == 0) R.bvec[P] = (double)s0;
       wave_sync();
     }
+    prof.tick(20);
     // ---- (2) scale draws of iteration it-1, regression draw of iteration it
     double emit_obs = obs_scale;
     if (it > 0) {
@@ -246,13 +277,15 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
         slope_scale = scale_draw(sp.slope_conc, sp.slope_scale, sp.slope_ub, (double)(T - 1), v_s,
                                  rng, pit, SITE_SLOPE_SCALE, lane);
       }
-      for (int k = 0; k < K; ++k) {
-        const double v_d = (double)readlane_f(ssd, off[k]);
-        const double gk = gamma_wave(ss.drift_conc + 0.5 * n_changes[k], rng, pit, SITE_DRIFT_SCALE,
-                                     (uint32_t)k, lane);
-        const double sd = (double)__fsqrt_rn((float)((ss.drift_scale + 0.5 * v_d) * fast_rcp(gk)));
-        drift[k] = sd < ss.drift_ub ? sd : ss.drift_ub;
-      }
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K) {
+          const double v_d = (double)readlane_f(ssd, off[k]);
+          const double gk = gamma_wave(ss.drift_conc + 0.5 * n_changes[k], rng, pit,
+                                       SITE_DRIFT_SCALE, (uint32_t)k, lane);
+          const double sd = (double)__fsqrt_rn((float)((ss.drift_scale + 0.5 * v_d) * fast_rcp(gk)));
+          drift[k] = sd < ss.drift_ub ? sd : ss.drift_ub;
+        }
       if (P == 0)
         obs_scale = scale_draw(sp.obs_conc, sp.obs_scale, sp.obs_ub, sp.n_obs, R.bvec[P], rng, pit,
                                SITE_OBS_SCALE, lane);
@@ -265,7 +298,11 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
           if (g.out_level_scale) g.out_level_scale[o] = (float)level_scale;
           if (g.out_slope_scale) g.out_slope_scale[o] = (float)(a.has_slope ? slope_scale : 0.0);
         }
-        if (a.out_drift && lane < K) a.out_drift[o * K + lane] = (float)drift[lane < K ? lane : 0];
+        if (a.out_drift) {
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k)
+            if (k < K && lane == k) a.out_drift[o * K + k] = (float)drift[k];
+        }
         if (g.out_weights && lane < P) g.out_weights[o * P + lane] = R.w[lane];
         // level / seasonal contributions / posterior-predictive trajectory of iteration it-1
         const float so = (float)emit_obs;
@@ -273,15 +310,18 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
         for (int c = lane; c < (T + 3) / 4; c += 64) {
           float zp[4];
           normals4(site_call(rng, pit, SITE_PRED, 0, (uint32_t)c), zp);
+#pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int t = 4 * c + q;
             if (t < T) {
               float loc = lev[t] + xw[t];
-              for (int k = 0; k < K; ++k) {
-                const float sv = seas[k * TS + t];
-                loc += sv;
-                if (a.out_seasonal) a.out_seasonal[(row + t) * K + k] = sv;
-              }
+#pragma unroll
+              for (int k = 0; k < SMAXK; ++k)
+                if (k < K) {
+                  const float sv = seas[k * TS + t];
+                  loc += sv;
+                  if (a.out_seasonal) a.out_seasonal[(row + t) * K + k] = sv;
+                }
               if (g.out_level) g.out_level[row + t] = lev[t];
               if (g.out_slope && a.has_slope) g.out_slope[row + t] = slp[t];
               if (g.out_traj) g.out_traj[row + t] = fmaf(so, zp[q], loc);
@@ -300,6 +340,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
     }
     wave_sync();
+    prof.tick(21);
 
     // ---- (3) residual, normals of this iteration
     for (int t = lane; t < T; t += 64) {
@@ -310,23 +351,32 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     for (int c = lane; c < (T + 3) / 4; c += 64) {
       float z4[4];
       normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_LEVEL, 0, (uint32_t)c), z4);
-      for (int q = 0; q < 4; ++q) if (4 * c + q < T) zl[4 * c + q] = z4[q];
+      *reinterpret_cast<float4*>(zl + 4 * c) = make_float4(z4[0], z4[1], z4[2], z4[3]);
       normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_OBS, 0, (uint32_t)c), z4);
-      for (int q = 0; q < 4; ++q) if (4 * c + q < T) zo[4 * c + q] = z4[q];
+      *reinterpret_cast<float4*>(zo + 4 * c) = make_float4(z4[0], z4[1], z4[2], z4[3]);
       if (a.has_slope) {
         normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SLOPE, 0, (uint32_t)c), z4);
-        for (int q = 0; q < 4; ++q) if (4 * c + q < T) zs[4 * c + q] = z4[q];
+        *reinterpret_cast<float4*>(zs + 4 * c) = make_float4(z4[0], z4[1], z4[2], z4[3]);
       }
-      for (int k = 0; k < K; ++k) {
-        normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SEAS, (uint32_t)k, (uint32_t)c), z4);
-        for (int q = 0; q < 4; ++q) if (4 * c + q < T) zk[k * TS + 4 * c + q] = z4[q];
-      }
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K) {
+          normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SEAS, (uint32_t)k, (uint32_t)c), z4);
+          *reinterpret_cast<float4*>(zk + k * TS + 4 * c) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        }
     }
     if (lane < a.dred) {
       float z1[1];
       fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)lane, z1);
       zi[lane] = z1[0];
     }
+    float mydrift = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        if (blk == k) mydrift = (float)drift[k];
+        if (lane == 0) d2[k] = (float)(drift[k] * drift[k]);
+      }
     wave_sync();
     // x+_0 = chol(P_1) z in the oracle's reduced coordinates, folded into the prior mean
     if (lane < a.dred) {
@@ -339,124 +389,198 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     if (lane == 0) a1e = (float)sp.init_level_loc + x0r[0];
     if (a.has_slope && lane == 1) a1e = x0r[1];
     if (blk >= 0) {
-      if (pos < nb - 1) a1e = x0r[roff[blk] + pos];
-      else { float s = 0.f; for (int q = 0; q < nb - 1; ++q) s += x0r[roff[blk] + q]; a1e = -s; }
+      if (pos < nb - 1) a1e = x0r[rbase + pos];
+      else { float s = 0.f; for (int q = 0; q < nb - 1; ++q) s += x0r[rbase + q]; a1e = -s; }
     }
     const float so = (float)obs_scale, sl = (float)level_scale, ssc = (float)slope_scale;
-    const float H = so * so;
+    const float H = so * so, ql = sl * sl, qs = ssc * ssc;
+    const float* zkb = zk + blk0 * TS;
+    const float dg = mydrift * gpos;            // this lane's share of a unit drift shock
+    prof.tick(22);
 
-    // ---- (4) pass 0: simulate x+ (zero initial state) and form y~ = resid - y+
+    // ---- (4) pass 0: simulate x+ (zero initial state) and form y~ = resid - y+.
+    // Every pass walks time in blocks of 4 steps so that the per-step scalars arrive as one
+    // batch of 16-byte LDS loads instead of one exposed round trip each.
     {
       float xp = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const float zx = zsum(xp);
-        if (lane == 0) ytil[t] = (yv[t] - xw[t]) - (zx + so * zo[t]);
-        if (t + 1 < T) xp = sim_noise(transition(xp, t), t, sl, ssc, drift);
+      for (int t4 = 0; t4 < T; t4 += 4) {
+        const float4 zo4 = ld4(zo + t4), zl4 = ld4(zl + t4), zk4 = ld4(zkb + t4);
+        const float4 yv4 = ld4(yv + t4), xw4 = ld4(xw + t4);
+        float4 zs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.has_slope) zs4 = ld4(zs + t4);
+        const uint32_t cb4 = ldb4(cbv + t4);
+        float yt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t4 + q;
+          const float zx = zsum(xp);
+          yt[q] = (at4(yv4, q) - at4(xw4, q)) - (zx + so * at4(zo4, q));
+          if (t + 1 < T) {
+            const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
+            float r = transition(xp, cb);
+            if (lane == 0) r = fmaf(sl, at4(zl4, q), r);
+            if (a.has_slope && lane == 1) r = fmaf(ssc, at4(zs4, q), r);
+            if (blk >= 0 && ((cb >> blk) & 1u)) r = fmaf(dg, at4(zk4, q), r);
+            xp = r;
+          }
+        }
+        if (lane == 0) *reinterpret_cast<float4*>(ytil + t4) = make_float4(yt[0], yt[1], yt[2], yt[3]);
       }
     }
+    prof.tick(23);
     // prior covariance of x_0 in full-effect form: sd^2 (I - 11'/n) per block
     for (int e = lane; e < D * D; e += 64) {
-      const int i = ei[e], j = ej[e];
+      const uint32_t mt = emeta[e];
+      const int i = mt & 63u, j = (mt >> 12) & 63u;
+      const unsigned bi = (mt >> 24) & 15u, bj = mt >> 28;
       float v = 0.f;
-      if (i == j && i == 0) v = p1l;
-      else if (a.has_slope && i == j && i == 1) v = p1s;
-      else if (i >= trend && j >= trend) {
-        int bi = -1, bj = -2, nn = 1;
-        for (int k = 0; k < K; ++k) {
-          if (i >= off[k] && i < off[k] + nsz[k]) { bi = k; nn = nsz[k]; }
-          if (j >= off[k] && j < off[k] + nsz[k]) bj = k;
-        }
-        if (bi == bj) v = p1e * ((i == j ? 1.f : 0.f) - 1.f / (float)nn);
+      if (e == 0) v = p1l;
+      else if (a.has_slope && i == 1 && j == 1) v = p1s;
+      else if (bi != 15u && bi == bj) {
+        int nn = 1;
+#pragma unroll
+        for (int k = 0; k < SMAXK; ++k) if (k < K && bi == (unsigned)k) nn = nsz[k];
+        v = p1e * ((i == j ? 1.f : 0.f) - 1.f / (float)nn);
       }
       Pcur[e] = v;
     }
     wave_sync();
+    prof.tick(24);
 
-    // ---- (5) pass 1: Kalman filter, storing K_t and v_t / F_t
+    // ---- (5) pass 1: Kalman filter, storing K_t and v_t / F_t.  The measurement update and the
+    // time update of the covariance are ONE sweep over the D x D entries:
+    //   P'[i][j] = P[si][sj] - pz[si] pz[sj] / F + Q[i][j]      (si, sj: sources under the shifts)
+    // with the per-entry table lookups issued before the dependent loads.
     {
       float am = a1e;
-      for (int t = 0; t < T; ++t) {
-        const bool obs = msk[t] == 0;
-        float kfi = 0.f;
-        if (obs) {
-          float pz = 0.f;
-          if (comp) {
-            pz = Pcur[lane * D + 0];
-            for (int k = 0; k < K; ++k) pz += Pcur[lane * D + off[k]];
-            pzv[lane] = pz;
-          }
-          const float F = zsum(pz) + H;
-          const float rF = 1.0f / F;
-          const float v = ytil[t] - zsum(am);
-          kfi = pz * rF;
-          if (lane == 0) vf[t] = v * rF;
-          am = fmaf(kfi, v, am);
-          wave_sync();
-          for (int e = lane; e < D * D; e += 64) Pcur[e] -= pzv[ei[e]] * pzv[ej[e]] * rF;
-          wave_sync();
-        } else if (lane == 0) {
-          vf[t] = 0.f;
-        }
-        if (comp) kf[(size_t)t * D + lane] = kfi;
-        if (t + 1 < T) {
-          am = transition(am, t);
-          bool moved = a.has_slope != 0;
-          for (int k = 0; k < K; ++k) moved = moved || chg[k * T + t] != 0;
-          if (!moved) {
-            if (lane == 0) Pcur[0] += sl * sl;
-            wave_sync();
-          } else {
-            for (int e = lane; e < D * D; e += 64) {
-              const int i = ei[e], j = ej[e];
-              // source index of row/column under the block shifts
-              int si = i, sj = j, bi = -1, bj = -2, nn = 1;
-              for (int k = 0; k < K; ++k) {
-                const bool ci = i >= off[k] && i < off[k] + nsz[k];
-                const bool cj = j >= off[k] && j < off[k] + nsz[k];
-                if (ci) { bi = k; nn = nsz[k]; }
-                if (cj) bj = k;
-                if (chg[k * T + t]) {
-                  if (ci) si = off[k] + (i - off[k] + 1) % nsz[k];
-                  if (cj) sj = off[k] + (j - off[k] + 1) % nsz[k];
-                }
-              }
-              float v = Pcur[si * D + sj];
-              if (a.has_slope) {       // level <- level + slope
-                if (i == 0) v += Pcur[1 * D + sj];
-                if (j == 0) v += Pcur[si * D + 1];
-                if (i == 0 && j == 0) v += Pcur[1 * D + 1];
-              }
-              if (i == 0 && j == 0) v += sl * sl;
-              if (a.has_slope && i == 1 && j == 1) v += ssc * ssc;
-              if (bi == bj && bi >= 0 && chg[bi * T + t]) {
-                const float dk = (float)drift[bi], inv = 1.0f / (float)nn;
-                const float gi = (i - off[bi] == nn - 1) ? 1.f - inv : -inv;
-                const float gj = (j - off[bi] == nn - 1) ? 1.f - inv : -inv;
-                v += dk * dk * gi * gj;
-              }
-              Pnxt[e] = v;
+      const int DD = D * D;
+      uint32_t mt0[4];          // the first 256 entries' tables stay in registers
+      float gq0[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = lane + 64 * u;
+        mt0[u] = (e < DD) ? emeta[e] : 0u;
+        gq0[u] = (e < DD) ? egg[e] : 0.f;
+      }
+      for (int t4 = 0; t4 < T; t4 += 4) {
+        const float4 yt4 = ld4(ytil + t4);
+        const uint32_t cb4 = ldb4(cbv + t4), mk4 = ldb4(msk + t4);
+        float vfq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t4 + q;
+          vfq[q] = 0.f;
+          if (t >= T) continue;
+          const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+          const unsigned cb = (t + 1 < T) ? ((cb4 >> (8 * q)) & 0xFFu) : 0u;
+          float kfi = 0.f, rF = 0.f;
+          if (obs) {
+            float pz = 0.f;
+            if (comp) {
+              pz = Pcur[lane * D];
+#pragma unroll
+              for (int k = 0; k < SMAXK; ++k)
+                if (k < K) pz += Pcur[lane * D + off[k]];
+              pzv[lane] = pz;
             }
-            wave_sync();
-            float* tmp = Pcur; Pcur = Pnxt; Pnxt = tmp;
+            const float F = zsum(pz) + H;
+            rF = 1.0f / F;
+            const float v = at4(yt4, q) - zsum(am);
+            kfi = pz * rF;
+            vfq[q] = v * rF;
+            am = fmaf(kfi, v, am);
+          } else if (comp) {
+            pzv[lane] = 0.f;
           }
+          if (comp) kf[(size_t)t * D + lane] = kfi;
+          if (t + 1 == T) continue;
+          am = transition(am, cb);
+          wave_sync();
+          if (!obs && cb == 0u && !a.has_slope) {
+            if (lane == 0) Pcur[0] += ql;
+            wave_sync();
+            continue;
+          }
+          for (int e0 = lane; e0 < DD; e0 += 64 * 4) {
+            uint32_t mt[4];
+            float gq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int e = e0 + 64 * u;
+              if (e0 == lane) { mt[u] = mt0[u]; gq[u] = gq0[u]; }
+              else {
+                mt[u] = (e < DD) ? emeta[e] : 0u;
+                gq[u] = (e < DD) ? egg[e] : 0.f;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int e = e0 + 64 * u;
+              if (e < DD) {
+                const unsigned bi = (mt[u] >> 24) & 15u, bj = mt[u] >> 28;
+                const bool ci = bi != 15u && ((cb >> bi) & 1u), cj = bj != 15u && ((cb >> bj) & 1u);
+                const int i = mt[u] & 63u, j = (mt[u] >> 12) & 63u;
+                const int si = ci ? (int)((mt[u] >> 6) & 63u) : i;
+                const int sj = cj ? (int)((mt[u] >> 18) & 63u) : j;
+                float v = Pcur[__mul24(si, D) + sj] - pzv[si] * pzv[sj] * rF;
+                if (a.has_slope) {       // level <- level + slope
+                  if (i == 0) v += Pcur[D + sj] - pzv[1] * pzv[sj] * rF;
+                  if (j == 0) v += Pcur[__mul24(si, D) + 1] - pzv[si] * pzv[1] * rF;
+                  if (i == 0 && j == 0) v += Pcur[D + 1] - pzv[1] * pzv[1] * rF;
+                  if (i == 1 && j == 1) v += qs;
+                }
+                if (e == 0) v += ql;
+                if (ci && bi == bj) v = fmaf(d2[bi], gq[u], v);
+                Pnxt[e] = v;
+              }
+            }
+          }
+          wave_sync();
+          float* tmp = Pcur; Pcur = Pnxt; Pnxt = tmp;
         }
+        if (lane == 0) *reinterpret_cast<float4*>(vf + t4) = make_float4(vfq[0], vfq[1], vfq[2], vfq[3]);
       }
     }
     wave_sync();
-    // ---- (6) pass 2: backward recursion, rs[t] = r_{t-1}
+    prof.tick(25);
+    // ---- (6) pass 2: backward recursion, rs[t] = r_{t-1}; then gd[k][t] = g . r_{t-1} per block
+    // (the projection the forward reconstruction needs at season changes)
     {
       float r = 0.f;
-      for (int t = T - 1; t >= 0; --t) {
-        r = (t + 1 < T) ? transition_T(r, t) : 0.f;
-        if (msk[t] == 0) {
-          const float kfi = comp ? kf[(size_t)t * D + lane] : 0.f;
-          const float kr = wave_sum(kfi * r);
-          if (isz) r += vf[t] - kr;
+      for (int t4 = ((T - 1) & ~3); t4 >= 0; t4 -= 4) {
+        const float4 vf4 = ld4(vf + t4);
+        const uint32_t cb4 = ldb4(cbv + t4), mk4 = ldb4(msk + t4);
+        float kfq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kfq[q] = (comp && t4 + q < T) ? kf[(size_t)(t4 + q) * D + lane] : 0.f;
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
+          const int t = t4 + q;
+          if (t >= T) continue;
+          r = (t + 1 < T) ? transition_T(r, (cb4 >> (8 * q)) & 0xFFu) : 0.f;
+          if (((mk4 >> (8 * q)) & 0xFFu) == 0u) {
+            const float kr = wave_sum_dpp(kfq[q] * r);
+            if (isz) r += at4(vf4, q) - kr;
+          }
+          if (comp) rs[(size_t)t * D + lane] = r;
         }
-        if (comp) rs[(size_t)t * D + lane] = r;
       }
     }
     wave_sync();
+    // g . r_{t-1} per block, time-parallel: g = e_last - 1/n
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        const float rn = 1.0f / (float)nsz[k];
+        for (int t = lane; t < T; t += 64) {
+          const float* rr = rs + (size_t)t * D + off[k];
+          float sb = 0.f;
+          for (int q = 0; q < nsz[k]; ++q) sb += rr[q];
+          gd[k * TS + t] = rr[nsz[k] - 1] - sb * rn;
+        }
+      }
+    wave_sync();
+    prof.tick(26);
     // ---- (7) pass 3: reconstruct x^ forward, re-simulate x+, write the draw, gather statistics
     {
       float xh = a1e;
@@ -472,44 +596,69 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       }
       float xp = 0.f, prev = 0.f, prev_next = 0.f;
       ssl = 0.f; sss = 0.f; ssd = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const float xt = xh + xp;
-        if (t > 0) {
-          if (lane == 0) {
-            float dl = xt - prev;
-            if (a.has_slope) dl -= prev_next;       // slope_{t-1} is lane 1 = "next" of lane 0
-            ssl = fmaf(dl, dl, ssl);
+      unsigned cb_prev = 0u;
+      const float* gdb = gd + blk0 * TS;
+      const float dgd = mydrift * dg;            // sigma_d^2 g_i
+      for (int t4 = 0; t4 < T; t4 += 4) {
+        const float4 zl4 = ld4(zl + t4), zk4 = ld4(zkb + t4);
+        float4 zs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.has_slope) zs4 = ld4(zs + t4);
+        const uint32_t cb4 = ldb4(cbv + t4);
+        float rnq[4], gdq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {       // r_t = rs[t + 1] and g . r_t of this lane's block
+          const int t1 = t4 + q + 1;
+          rnq[q] = (comp && t1 < T) ? rs[(size_t)t1 * D + lane] : 0.f;
+          gdq[q] = (t1 < T) ? gdb[t1] : 0.f;
+        }
+        float xo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t4 + q;
+          xo[q] = 0.f;
+          if (t >= T) continue;
+          const float xt = xh + xp;
+          xo[q] = xt;
+          if (t > 0) {
+            if (lane == 0) {
+              float dl = xt - prev;
+              if (a.has_slope) dl -= prev_next;       // slope_{t-1} is lane 1 = "next" of lane 0
+              ssl = fmaf(dl, dl, ssl);
+            }
+            if (a.has_slope && lane == 1) { const float ds = xt - prev; sss = fmaf(ds, ds, sss); }
+            if (blk >= 0 && pos == 0 && ((cb_prev >> blk) & 1u)) {
+              const float w = (float)nb * (prev_next - xt);   // n (e_{t-1,1} - e_{t,0})
+              ssd = fmaf(w, w, ssd);
+            }
           }
-          if (a.has_slope && lane == 1) { const float ds = xt - prev; sss = fmaf(ds, ds, sss); }
-          if (blk >= 0 && pos == 0 && chg[blk * T + t - 1]) {
-            const float w = (float)nb * (prev_next - xt);   // n (e_{t-1,1} - e_{t,0})
-            ssd = fmaf(w, w, ssd);
+          prev = xt;
+          prev_next = __shfl_down(xt, 1, 64);
+          if (t + 1 < T) {
+            const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
+            const bool mych = blk >= 0 && ((cb >> blk) & 1u);
+            float h = transition(xh, cb);
+            if (lane == 0) h = fmaf(ql, rnq[q], h);
+            if (a.has_slope && lane == 1) h = fmaf(qs, rnq[q], h);
+            if (mych) h = fmaf(dgd, gdq[q], h);
+            xh = h;
+            float r = transition(xp, cb);
+            if (lane == 0) r = fmaf(sl, at4(zl4, q), r);
+            if (a.has_slope && lane == 1) r = fmaf(ssc, at4(zs4, q), r);
+            if (mych) r = fmaf(dg, at4(zk4, q), r);
+            xp = r;
+            cb_prev = cb;
           }
         }
-        if (lane == 0) lev[t] = xt;
-        if (a.has_slope && lane == 1) slp[t] = xt;
-        if (blk >= 0 && pos == 0) seas[blk * TS + t] = xt;
-        prev = xt;
-        prev_next = __shfl_down(xt, 1, 64);
-        if (t + 1 < T) {
-          xh = transition(xh, t);
-          const float rn = comp ? rs[(size_t)(t + 1) * D + lane] : 0.f;
-          if (lane == 0) xh = fmaf(sl * sl, rn, xh);
-          if (a.has_slope && lane == 1) xh = fmaf(ssc * ssc, rn, xh);
-          if (blk >= 0 && chg[blk * T + t]) {
-            float sb = 0.f;
-            for (int q = 0; q < nb; ++q) sb += rs[(size_t)(t + 1) * D + boff + q];
-            const float inv = 1.0f / (float)nb;
-            const float gdot = rs[(size_t)(t + 1) * D + boff + nb - 1] - sb * inv;
-            const float gi = (pos == nb - 1) ? 1.f - inv : -inv;
-            const float dk = (float)drift[blk];
-            xh = fmaf(dk * dk * gi, gdot, xh);
-          }
-          xp = sim_noise(transition(xp, t), t, sl, ssc, drift);
-        }
+        // the observed components of the draw, 4 steps at a time
+        if (lane == 0) *reinterpret_cast<float4*>(lev + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+        if (a.has_slope && lane == 1)
+          *reinterpret_cast<float4*>(slp + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+        if (blk >= 0 && pos == 0)
+          *reinterpret_cast<float4*>(seas + blk * TS + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
       }
     }
     wave_sync();
+    prof.tick(27);
   }
   if (g.out_pred_mean) {
     const float inv = 1.0f / (float)(g.S > 0 ? g.S : 1);

@@ -65,8 +65,12 @@ typedef struct ci_problem {
   int32_t num_series;           /* B */
   uint32_t seed[2];             /* sanitized seed pair (int s -> (0,s)) :535-543 */
   int32_t device;               /* HIP device ordinal */
-  int32_t reserved;
+  int32_t flags;                /* CI_FLAG_* (0 = let the library choose the kernel) */
 } ci_problem;
+
+/* Seasonal models: use the one-wavefront-per-chain sequential kernel even where the
+ * time-parallel kernel (one seasonal block, state dim <= 8) applies.  Test/diagnostic knob. */
+#define CI_FLAG_SEQUENTIAL_SEASONAL 1
 
 /* Caller-allocated result buffers (float32, chain-major so per-device shards
  * are contiguous).  == GibbsSamplerState stack + (means, trajectories) returned

@@ -105,25 +105,35 @@ def test_invariants_pinned_by_reference_tests():
   assert (got["weights"] == 0).sum() == 0
 
 
-@pytest.mark.parametrize("T,p,has_slope,seasons", [
-    (60, 0, 0, ((3, 1),)),                              # smallest: one block, no regression
-    (90, 1, 0, ((4, (2, 1, 1, 1)), (2, 3))),            # per-season lengths + an n=2 block
-    (120, 4, 1, ((7, 1),)),                             # weekly effect + trend + flips (P=5)
-    (300, 0, 0, ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))),
+SEQ = _native.FLAG_SEQUENTIAL_SEASONAL
+
+
+@pytest.mark.parametrize("T,p,has_slope,seasons,flags", [
+    (60, 0, 0, ((3, 1),), 0),                           # smallest: one block, no regression
+    (90, 1, 0, ((4, (2, 1, 1, 1)), (2, 3)), 0),         # per-season lengths + an n=2 block
+    (120, 4, 1, ((7, 1),), SEQ),                        # weekly effect + trend + flips (P=5)
+    (300, 0, 0, ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1)))), 0),
+    # one weekly block: the time-parallel kernel (ci_wide.h)
+    (120, 4, 1, ((7, 1),), 0),                          # same case as above, other kernel
+    (120, 0, 0, ((7, 1),), 0),                          # no regression
+    (300, 2, 0, ((7, 2),), 0),                          # two steps per season, P=3 (pi=1)
+    (1030, 20, 0, ((7, 1),), 0),                        # P=21: LDS regression block, padded chunks
+    (777, 6, 1, ((7, (1, 2, 1, 1, 1, 1, 3)),), 0),      # ragged seasons, trend
 ])
-def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, seasons):
-  """Seasonal kernel (full n-effect state, fast state smoother) vs the oracle's
-  (n-1)-dimensional Durbin-Koopman draw, same random numbers."""
+def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, seasons, flags):
+  """Seasonal kernels vs the oracle's (n-1)-dimensional Durbin-Koopman draw, same random
+  numbers: the one-wavefront sequential kernel (full n-effect state, fast state smoother) and
+  the time-parallel kernel (chunked Sarkka scan in the oracle's coordinates)."""
   from causalimpact import _model
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
   rng = np.random.default_rng(0)
   y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0) + 0.1 * rng.normal(size=T)
   spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
-  counts, flags = _model.expand_seasons(seasons, T)
+  counts, flg = _model.expand_seasons(seasons, T)
   S, K = 4, len(seasons)
   pb = _native.make_problem(T=T, P=spec["P"], has_slope=has_slope, num_seasons=counts,
-                            num_warmup=0, num_results=S, seed=(2, 6))
-  got = _native.fit_gibbs(pb, y[None], mask[None], None if X is None else X[None], flags,
+                            num_warmup=0, num_results=S, seed=(2, 6), flags=flags)
+  got = _native.fit_gibbs(pb, y[None], mask[None], None if X is None else X[None], flg,
                           _native.make_params([spec]))
   w = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=0, seed=(2, 6))
   np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=5e-3)
@@ -138,6 +148,30 @@ def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, season
   np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
   np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=5e-3)
   assert got["seasonal_levels"].shape == (1, 1, S, T, K)
+
+
+def test_baseline_cfg4_shape_matches_oracle_per_draw():
+  """BASELINE 'T=10000, 50 covariates + Seasonal(num_seasons=7)' at full size: the first
+  draws agree with the oracle per random number (level / seasonal effect to 1e-3, weights and
+  inclusion pattern exactly)."""
+  from causalimpact import _model
+  T, p, seasons, S = 10000, 50, ((7, 1),), 2
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 11)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  spec = orc.default_spec(y, mask, X, has_slope=False, seasons=seasons)
+  assert spec["P"] == 51
+  counts, flg = _model.expand_seasons(seasons, T)
+  pb = _native.make_problem(T=T, P=51, has_slope=0, num_seasons=counts, num_warmup=0,
+                            num_results=S, seed=(4, 4))
+  got = _native.fit_gibbs(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+  w = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=0, seed=(4, 4))
+  np.testing.assert_array_equal(got["weights"][0, 0] != 0, w["weights"] != 0)
+  np.testing.assert_allclose(got["weights"][0, 0], w["weights"], atol=1e-3)
+  np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=1e-3)
+  np.testing.assert_allclose(got["seasonal_levels"][0, 0], w["seasonal"], atol=1e-3)
+  np.testing.assert_allclose(got["seasonal_drift_scales"][0, 0], w["drift_scales"], rtol=2e-2)
+  np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=5e-3)
+  np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=5e-3)
 
 
 def test_batch_of_series_equals_single_series_runs():

@@ -13,8 +13,11 @@
 #include "ci_kernels.h"
 #define CI_SEASONAL_DECL_ONLY
 #include "ci_seasonal.h"
+#include "ci_wide.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(void);
+extern "C" void* ci_gibbs_wide_fn_tr1_ns7(void);
+extern "C" void* ci_gibbs_wide_fn_tr2_ns7(void);
 
 // One object file per (D, L) instantiation (ci_inst.hip).
 #define CI_DECL(D, L)                                                                          \
@@ -137,6 +140,20 @@ template <class T> struct DevBuf {
 
 
 
+// Time-parallel trend + seasonal kernel (ci_wide.h): which instantiations exist.
+void* pick_wide_kernel(int has_slope, int num_seasons) {
+  if (num_seasons == 7) return has_slope ? ci_gibbs_wide_fn_tr2_ns7() : ci_gibbs_wide_fn_tr1_ns7();
+  return nullptr;
+}
+bool use_wide(const ci_problem* pb) {
+  return pb->num_blocks == 1 && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
+         pick_wide_kernel(pb->has_slope, pb->num_seasons[0]) != nullptr;
+}
+int wide_steps_per_thread(int T) {
+  int lc = (T + ci::NT - 1) / ci::NT;
+  return (lc + 3) & ~3;
+}
+
 int steps_per_thread(int T) {
   for (int L = 1; L <= 16; L *= 2)
     if (ci::NT * L >= T) return L;
@@ -163,6 +180,10 @@ struct ci_session {
   DevBuf<uint8_t> season_change;
   DevBuf<ci::DevSeasonalParams> ssp;
   DevBuf<float> p1_chol, o_drift, o_seasonal;
+  // time-parallel seasonal kernel
+  bool wide = false;
+  int Lc = 0;
+  DevBuf<float> ws;
 };
 
 extern "C" {
@@ -191,8 +212,13 @@ static int validate(const ci_problem* pb) {
       if (pb->num_seasons[k] < 2) return fail("num_seasons[%d] must be >= 2", k);
       dfull += pb->num_seasons[k];
     }
-    if (dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
-    if (pb->P > 16) return fail("seasonal models support P <= 16 on the device path, got %d", pb->P);
+    if (use_wide(pb)) {
+      if (wide_steps_per_thread(pb->T) > ci::WIDE_MAX_LC)
+        return fail("T=%d exceeds the time-parallel seasonal path (max %d)", pb->T, ci::NT * ci::WIDE_MAX_LC);
+    } else {
+      if (dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
+      if (pb->P > 16) return fail("this seasonal model supports P <= 16 on the device path, got %d", pb->P);
+    }
   }
   if (pb->num_warmup < 0 || pb->num_results < 1) return fail("need num_warmup >= 0, num_results >= 1");
   if (pb->num_chains < 1 || pb->num_series < 1) return fail("need num_chains >= 1, num_series >= 1");
@@ -227,13 +253,19 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     s->D_full = D;
     s->dred = D;
     for (int k = 0; k < K; ++k) { s->D_full += pb->num_seasons[k]; s->dred += pb->num_seasons[k] - 1; }
-    s->lds_bytes = ci::make_slayout(T, P, K, s->D_full, s->dred, pb->has_slope).total;
+    s->wide = use_wide(pb);
+    if (s->wide) {
+      s->Lc = wide_steps_per_thread(T);
+      s->lds_bytes = ci::make_wlayout(P, s->dred).total;
+      s->fn = (KernelFn)pick_wide_kernel(pb->has_slope, pb->num_seasons[0]);
+    } else
+      s->lds_bytes = ci::make_slayout(T, P, K, s->D_full, s->dred, pb->has_slope).total;
     if (s->lds_bytes > 160 * 1024) {
       const size_t need = s->lds_bytes;
       delete s;
       return fail("seasonal model needs %zu bytes of LDS per chain (max 163840): reduce T", need);
     }
-    s->fn = (KernelFn)ci_gibbs_seasonal_fn();
+    if (!s->wide) s->fn = (KernelFn)ci_gibbs_seasonal_fn();
   }
   HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)s->lds_bytes));
@@ -262,6 +294,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     HIP_TRY(s->p1_chol.alloc((size_t)B * s->dred * s->dred));
     HIP_TRY(s->o_drift.alloc(BCS * K));
     HIP_TRY(s->o_seasonal.alloc(BCS * T * K));
+    if (s->wide) HIP_TRY(s->ws.alloc((size_t)B * C * ci::wide_workspace_floats(s->dred, s->Lc)));
     HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
     std::vector<ci::DevSeasonalParams> ssh(B);
     std::vector<float> ch((size_t)B * s->dred * s->dred, 0.f);
@@ -376,8 +409,9 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
     for (int k = 0; k < ci::SMAXK; ++k) sa.nseas[k] = k < pb.num_blocks ? pb.num_seasons[k] : 0;
     sa.season_change = s->season_change.p; sa.ssp = s->ssp.p; sa.p1_chol = s->p1_chol.p;
     sa.out_drift = s->o_drift.p; sa.out_seasonal = s->o_seasonal.p;
-    hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(pb.num_series * pb.num_chains), dim3(64),
-                       s->lds_bytes, s->stream, sa);
+    sa.ws = s->ws.p; sa.Lc = s->Lc;
+    hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(pb.num_series * pb.num_chains),
+                       dim3(s->wide ? ci::NT : 64), s->lds_bytes, s->stream, sa);
   } else {
     hipLaunchKernelGGL(s->fn, dim3(pb.num_series * pb.num_chains), dim3(ci::NT), s->lds_bytes,
                        s->stream, a);
@@ -443,7 +477,7 @@ int ci_session_destroy(ci_session* s) {
   s->o_w.release(); s->o_level.release(); s->o_slope.release(); s->o_pm.release();
   s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->sp.release(); s->prof.release();
   s->season_change.release(); s->ssp.release(); s->p1_chol.release(); s->o_drift.release();
-  s->o_seasonal.release();
+  s->o_seasonal.release(); s->ws.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);

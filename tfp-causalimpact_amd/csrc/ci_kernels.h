@@ -32,7 +32,7 @@ namespace ci {
 
 constexpr int NT = 256;   // threads per workgroup
 constexpr int NW = 4;     // wavefronts per workgroup
-constexpr int MAXP = 48;  // design columns supported by the LDS-resident regression block
+constexpr int MAXP = 52;  // design columns supported by the LDS-resident regression block
 
 struct DevSeriesParams {
   double level_conc, level_scale, level_ub;

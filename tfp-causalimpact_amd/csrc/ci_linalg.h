@@ -147,6 +147,47 @@ __device__ __forceinline__ Mat<2> minv(const Mat<2>& a) {
   return r;
 }
 
+// General d x d inverse: Gauss-Jordan with partial pivoting, fully unrolled so that every
+// register index is static (row swaps are select chains).  Used for (I + C J) in the filtering
+// operator when d > 2.
+template <int D> __device__ __forceinline__ Mat<D> minv(const Mat<D>& M) {
+  Mat<D> a = M, inv = meye<D>();
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+#pragma unroll
+    for (int r = c + 1; r < D; ++r) {
+      const bool sw = fabsf(a.m[r][c]) > fabsf(a.m[c][c]);
+#pragma unroll
+      for (int j = c; j < D; ++j) {
+        const float u = a.m[c][j], v = a.m[r][j];
+        a.m[c][j] = sw ? v : u;
+        a.m[r][j] = sw ? u : v;
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float u = inv.m[c][j], v = inv.m[r][j];
+        inv.m[c][j] = sw ? v : u;
+        inv.m[r][j] = sw ? u : v;
+      }
+    }
+    const float rp = 1.0f / a.m[c][c];
+#pragma unroll
+    for (int j = c + 1; j < D; ++j) a.m[c][j] *= rp;
+#pragma unroll
+    for (int j = 0; j < D; ++j) inv.m[c][j] *= rp;
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      if (r == c) continue;
+      const float f = a.m[r][c];
+#pragma unroll
+      for (int j = c + 1; j < D; ++j) a.m[r][j] = fmaf(-f, a.m[c][j], a.m[r][j]);
+#pragma unroll
+      for (int j = 0; j < D; ++j) inv.m[r][j] = fmaf(-f, inv.m[c][j], inv.m[r][j]);
+    }
+  }
+  return inv;
+}
+
 // ---- transition of the trend block: LocalLevel (D=1) T=[1]; LocalLinearTrend (D=2)
 // T=[[1,1],[0,1]]  (tfp.sts.LocalLevel / LocalLinearTrend state-space models).
 template <int D> __device__ __forceinline__ Mat<D> trans_mat() {

@@ -41,6 +41,8 @@ struct SArgs {
   const float* p1_chol;              // [B,dred,dred] lower Cholesky factor of the prior cov of x_0
   float* out_drift;                  // [B,C,S,K]
   float* out_seasonal;               // [B,C,S,T,K]
+  float* ws;                         // time-parallel kernel (ci_wide.h): per-chain HBM workspace
+  int Lc;                            //   and steps per thread
 };
 
 struct SLayout {

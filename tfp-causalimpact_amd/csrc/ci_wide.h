@@ -1,0 +1,859 @@
+// ci_wide.h -- time-parallel Gibbs kernel for trend + one seasonal block, any series length.
+//
+// Model: LocalLevel / LocalLinearTrend (TR = 1 / 2 trend dims) + one
+// tfp.sts.Seasonal(num_seasons = NS, constrain_mean_effect_to_zero=True) block carried in the
+// oracle's (NS-1)-effect coordinates (oracle/ci_oracle.c: apply_transition, propagate_cov,
+// initial_moments), state dim d = TR + NS - 1 <= 8.  This is BASELINE config "T=10000,
+// 50 covariates + Seasonal(num_seasons=7)"  and every daily series
+// with a weekly cycle.
+//
+// One 256-thread workgroup per (series, chain).  Thread i owns the Lc = ceil(T/256) (rounded up
+// to 4) consecutive steps [i Lc, (i+1) Lc).  Every recursion of the Durbin-Koopman draw
+// (oracle: ci_oracle_dk_draw) is cut the same way:
+//   per-thread pass over the chunk  ->  block scan of 256 chunk elements  ->  per-thread pass
+// so the sequential depth is O(Lc + log 256) instead of T:
+//   * prior simulation x+   : elements (steps, season changes mod NS, offset vector);
+//   * Kalman filter         : Sarkka & Garcia-Fernandez (2021) elements (A, b, C, eta, J), d x d
+//                             dense; a chunk's element is built by an O(d^2)-per-step recursion
+//                             (not by d^3 combines), only the 256-element scan pays d^3;
+//   * backward recursion r  : affine maps (M, c), d x d dense;
+//   * x~_t = x+_t + a_t + P_t r_{t-1} in the last per-thread pass.
+// Per-step intermediates (y~, x+ + a_t, P_t, K_t, v_t/F_t) live in a per-chain HBM workspace laid
+// out [step-in-chunk][field][thread] so that every access is a fully coalesced 1 KiB row and each
+// thread only ever reads what it wrote.  The regression block, scale draws and random streams are
+// the ones of ci_kernels.h (same sites, same counters), so draws agree with the oracle per
+// random number.
+#pragma once
+#include "ci_kernels.h"
+#include "ci_seasonal.h"   // SArgs, DevSeasonalParams (declarations only in this TU)
+
+namespace ci {
+
+constexpr int WIDE_MAX_LC = 64;       // T <= 16384
+
+template <int TR, int NS> struct WDim {
+  static constexpr int D = TR + NS - 1;
+  static constexpr int O = TR;          // first effect of the seasonal block
+  static constexpr int N1 = NS - 1;
+  static constexpr int NPS = D * (D + 1) / 2;
+  // per-step private fields: y~ | a_t + x+_t | P_t (upper triangle) | K_t | v_t / F_t
+  static constexpr int F_YT = 0, F_AX = 1, F_PS = 1 + D, F_KF = 1 + D + NPS, F_VF = 1 + 2 * D + NPS;
+  static constexpr int NF = 2 + 2 * D + NPS;
+};
+
+// floats of HBM workspace per chain
+__host__ __device__ inline size_t wide_workspace_floats(int D, int Lc) {
+  const size_t TP = (size_t)NT * Lc;
+  const size_t nf = 2 + 2 * D + D * (D + 1) / 2;
+  return (6 + nf) * TP + TP / 2;   // 6 shared T-arrays, private fields, mask + change bytes
+}
+
+// ---- x <- T_t x and friends (oracle: apply_transition / apply_transition_T) ---------------
+template <int TR, int NS>
+__device__ __forceinline__ void w_season_shift(Vec<TR + NS - 1>& x) {
+  constexpr int O = TR, N1 = NS - 1;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < N1; ++i) s += x.v[O + i];
+#pragma unroll
+  for (int i = 0; i + 1 < N1; ++i) x.v[O + i] = x.v[O + i + 1];
+  x.v[O + N1 - 1] = -s;
+}
+template <int TR, int NS>
+__device__ __forceinline__ void w_apply(Vec<TR + NS - 1>& x, bool ch) {
+  if constexpr (TR == 2) x.v[0] += x.v[1];
+  if (ch) w_season_shift<TR, NS>(x);
+}
+template <int TR, int NS>
+__device__ __forceinline__ void w_apply_t(Vec<TR + NS - 1>& x, bool ch) {
+  constexpr int O = TR, N1 = NS - 1;
+  if constexpr (TR == 2) x.v[1] += x.v[0];
+  if (ch) {
+    const float last = x.v[O + N1 - 1];
+#pragma unroll
+    for (int j = N1 - 1; j >= 1; --j) x.v[O + j] = x.v[O + j - 1] - last;
+    x.v[O] = -last;
+  }
+}
+// A <- T A
+template <int TR, int NS>
+__device__ __forceinline__ void w_left(Mat<TR + NS - 1>& A, bool ch) {
+  constexpr int D = TR + NS - 1, O = TR, N1 = NS - 1;
+  if constexpr (TR == 2) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) A.m[0][j] += A.m[1][j];
+  }
+  if (ch) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < N1; ++i) s += A.m[O + i][j];
+#pragma unroll
+      for (int i = 0; i + 1 < N1; ++i) A.m[O + i][j] = A.m[O + i + 1][j];
+      A.m[O + N1 - 1][j] = -s;
+    }
+  }
+}
+// A <- A T'
+template <int TR, int NS>
+__device__ __forceinline__ void w_right_t(Mat<TR + NS - 1>& A, bool ch) {
+  constexpr int D = TR + NS - 1, O = TR, N1 = NS - 1;
+  if constexpr (TR == 2) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) A.m[i][0] += A.m[i][1];
+  }
+  if (ch) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < N1; ++j) s += A.m[i][O + j];
+#pragma unroll
+      for (int j = 0; j + 1 < N1; ++j) A.m[i][O + j] = A.m[i][O + j + 1];
+      A.m[i][O + N1 - 1] = -s;
+    }
+  }
+}
+// A <- T' A
+template <int TR, int NS>
+__device__ __forceinline__ void w_left_t(Mat<TR + NS - 1>& A, bool ch) {
+  constexpr int D = TR + NS - 1, O = TR, N1 = NS - 1;
+  if constexpr (TR == 2) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) A.m[1][j] += A.m[0][j];
+  }
+  if (ch) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float last = A.m[O + N1 - 1][j];
+#pragma unroll
+      for (int r = N1 - 1; r >= 1; --r) A.m[O + r][j] = A.m[O + r - 1][j] - last;
+      A.m[O][j] = -last;
+    }
+  }
+}
+
+struct WideScal {
+  float H, so, sl, ss, sdn;   // obs variance / scale, level, slope scales, drift scale / NS
+  float ql, qs, qd;           // level, slope variances, (drift scale / NS)^2
+};
+
+// P <- T P T' + Q_t  (oracle: propagate_cov)
+template <int TR, int NS>
+__device__ __forceinline__ void w_cov_predict(Mat<TR + NS - 1>& P, bool ch, const WideScal& sc) {
+  constexpr int O = TR, N1 = NS - 1;
+  w_left<TR, NS>(P, ch);
+  w_right_t<TR, NS>(P, ch);
+  P.m[0][0] += sc.ql;
+  if constexpr (TR == 2) P.m[1][1] += sc.qs;
+  if (ch) {
+#pragma unroll
+    for (int i = 0; i < N1; ++i)
+#pragma unroll
+      for (int j = 0; j < N1; ++j) P.m[O + i][O + j] += sc.qd;
+  }
+  symmetrize(P);
+}
+
+// ---- prior-simulation element: x_out = Phi x_in + s, Phi fixed by (steps, changes mod NS) ----
+template <int D> struct WPElem {
+  float k;
+  int m;
+  Vec<D> s;
+};
+template <int TR, int NS>
+__device__ __forceinline__ WPElem<TR + NS - 1> wpelem_combine(const WPElem<TR + NS - 1>& e1,
+                                                              const WPElem<TR + NS - 1>& e2) {
+  WPElem<TR + NS - 1> r;
+  r.k = e1.k + e2.k;
+  int m = e1.m + e2.m;
+  r.m = m >= NS ? m - NS : m;
+  r.s = e1.s;
+  if constexpr (TR == 2) r.s.v[0] = fmaf(e2.k, r.s.v[1], r.s.v[0]);
+#pragma unroll 1
+  for (int i = 0; i < e2.m; ++i) w_season_shift<TR, NS>(r.s);
+#pragma unroll
+  for (int i = 0; i < TR + NS - 1; ++i) r.s.v[i] += e2.s.v[i];
+  return r;
+}
+
+// ---- block scans with the operator kept in ROLLED loops (a d = 8 combine is ~6k instructions;
+// unrolling the 6 wave levels would blow the instruction cache) -----------------------------
+template <class E, class Op>
+__device__ __forceinline__ E block_scan_excl_fwd_rolled(const E& tot, Op op, const E& ident,
+                                                        float* slots, int lane, int wave) {
+  constexpr int N = sizeof(E) / 4;
+  E incl = tot;
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {
+    const E o = shfl_up_e(incl, off);
+    if (lane >= off) incl = op(o, incl);
+  }
+  if (lane == 63) lds_store_e(slots + wave * N, incl);
+  __syncthreads();
+  E ex = shfl_up_e(incl, 1);
+  if (lane == 0) ex = ident;
+  // prefix of the earlier waves' totals followed by ex: one rolled loop, one operator instance
+  E acc = (wave == 0) ? ex : lds_load_e<E>(slots);
+#pragma unroll 1
+  for (int ww = 1; ww <= wave; ++ww) {
+    const E nxt = (ww < wave) ? lds_load_e<E>(slots + ww * N) : ex;
+    acc = op(acc, nxt);
+  }
+  return acc;
+}
+template <class E, class Op>
+__device__ __forceinline__ E block_scan_excl_bwd_rolled(const E& tot, Op op, const E& ident,
+                                                        float* slots, int lane, int wave) {
+  constexpr int N = sizeof(E) / 4;
+  E incl = tot;
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {
+    const E o = shfl_down_e(incl, off);
+    if (lane + off < 64) incl = op(incl, o);
+  }
+  if (lane == 0) lds_store_e(slots + wave * N, incl);
+  __syncthreads();
+  E ex = shfl_down_e(incl, 1);
+  if (lane == 63) ex = ident;
+  // ex o W_{wave+1} o ... o W_{NW-1}   (op(outer, inner): the LAST wave's map acts first)
+  E acc = ex;
+#pragma unroll 1
+  for (int ww = wave + 1; ww < NW; ++ww) acc = op(acc, lds_load_e<E>(slots + ww * N));
+  return acc;
+}
+
+struct WLayout {
+  size_t xtx, omega, aug0, aug1, pri0, pri1, chol, bvec, zv, uperm, nz, perm, idx, w, scal, red,
+      pslots, fslots, aslots, edge, total;
+};
+__host__ __device__ inline WLayout make_wlayout(int P, int D) {
+  WLayout l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
+  const int Pp = P > 0 ? P : 1;
+  const bool big = P > 16;    // the LDS-resident regression block is only used for P > 16
+  l.xtx = take(sizeof(double) * Pp * Pp);
+  l.omega = take(sizeof(double) * Pp * Pp);
+  l.aug0 = take(big ? sizeof(double) * (Pp + 1) * (Pp + 1) : 16);
+  l.aug1 = take(big ? sizeof(double) * (Pp + 1) * (Pp + 1) : 16);
+  l.pri0 = take(big ? sizeof(double) * Pp * Pp : 16);
+  l.pri1 = take(big ? sizeof(double) * Pp * Pp : 16);
+  l.chol = take(big ? sizeof(double) * Pp * Pp : 16);
+  l.bvec = take(sizeof(double) * (Pp + 4));
+  l.zv = take(sizeof(double) * Pp);
+  l.uperm = take(sizeof(double) * Pp);
+  l.nz = take(sizeof(int) * Pp);
+  l.perm = take(sizeof(int) * Pp);
+  l.idx = take(sizeof(int) * Pp);
+  l.w = take(sizeof(float) * (Pp > 16 ? Pp : 16));
+  l.scal = take(sizeof(float) * 16);
+  l.red = take(sizeof(float) * NW * ((Pp > 16 ? Pp : 16) + 4));
+  l.pslots = take(sizeof(float) * NW * (D + 2));
+  l.fslots = take(sizeof(float) * NW * (3 * D * D + 2 * D));
+  l.aslots = take(sizeof(float) * NW * (D * D + D));
+  l.edge = take(sizeof(float) * (NW + 1) * D);
+  l.total = o;
+  return l;
+}
+
+// ------------------------------------------------------------------------------------
+// One Durbin-Koopman draw, time-parallel.  Leaves level / slope / seasonal effect of the draw in
+// levw / slpw / seaw and this thread's share of the scale statistics in ssl / sss / ssd.
+// Contains 4 __syncthreads().
+// ------------------------------------------------------------------------------------
+template <int TR, int NS>
+__device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + NS - 1>& a1e,
+                                             const Mat<TR + NS - 1>& P1, int T, int Lc,
+                                             const float* __restrict__ resid,
+                                             const uint8_t* __restrict__ msk,
+                                             const uint8_t* __restrict__ cbv,
+                                             float* __restrict__ wsp, float* __restrict__ levw,
+                                             float* __restrict__ slpw, float* __restrict__ seaw,
+                                             const Rng& rng, uint32_t iter, int tid, int lane,
+                                             int wave, float* pslots, float* fslots, float* aslots,
+                                             float* edge, float& ssl, float& sss, float& ssd,
+                                             Prof& prof) {
+  using W = WDim<TR, NS>;
+  constexpr int D = W::D, O = W::O, N1 = W::N1, NF = W::NF;
+  const int t0 = tid * Lc;
+  auto at4 = [](const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
+
+  // ---- (1) prior simulation: chunk elements, scan
+  WPElem<D> pe;
+  {
+    Vec<D> s = vzero<D>();
+    int m = 0;
+#pragma unroll 1
+    for (int g4 = 0; g4 < Lc; g4 += 4) {
+      const int t4 = t0 + g4;
+      float zl4[4], zs4[4], zk4[4];
+      normals4(site_call(rng, iter, SITE_PRIOR_LEVEL, 0, (uint32_t)(t4 >> 2)), zl4);
+      if constexpr (TR == 2) normals4(site_call(rng, iter, SITE_PRIOR_SLOPE, 0, (uint32_t)(t4 >> 2)), zs4);
+      normals4(site_call(rng, iter, SITE_PRIOR_SEAS, 0, (uint32_t)(t4 >> 2)), zk4);
+      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
+        w_apply<TR, NS>(s, ch);
+        s.v[0] = fmaf(sc.sl, zl4[q], s.v[0]);
+        if constexpr (TR == 2) s.v[1] = fmaf(sc.ss, zs4[q], s.v[1]);
+        if (ch) {
+          const float dz = sc.sdn * zk4[q];
+#pragma unroll
+          for (int i = 0; i < N1; ++i) s.v[O + i] -= dz;
+          m += 1;
+        }
+      }
+    }
+    pe.k = (float)Lc;
+    pe.m = m % NS;
+    pe.s = s;
+  }
+  WPElem<D> pid;
+  pid.k = 0.f; pid.m = 0; pid.s = vzero<D>();
+  const WPElem<D> ppre = block_scan_excl_fwd_rolled(
+      pe, [](const WPElem<D>& x, const WPElem<D>& y) { return wpelem_combine<TR, NS>(x, y); }, pid,
+      pslots, lane, wave);
+  prof.tick(4);
+
+  // ---- (2) x+ from the chunk's prefix, y~ = resid - y+, and the chunk's filtering element
+  FElem<D> fe = felem_identity<D>();
+  if (tid == 0) {
+    fe.A = mzero<D>();
+    fe.b = a1e;
+    fe.C = P1;
+  }
+  {
+    Vec<D> x = ppre.s;
+#pragma unroll 1
+    for (int g4 = 0; g4 < Lc; g4 += 4) {
+      const int t4 = t0 + g4;
+      float zl4[4], zs4[4], zk4[4], zo4[4];
+      normals4(site_call(rng, iter, SITE_PRIOR_LEVEL, 0, (uint32_t)(t4 >> 2)), zl4);
+      if constexpr (TR == 2) normals4(site_call(rng, iter, SITE_PRIOR_SLOPE, 0, (uint32_t)(t4 >> 2)), zs4);
+      normals4(site_call(rng, iter, SITE_PRIOR_SEAS, 0, (uint32_t)(t4 >> 2)), zk4);
+      normals4(site_call(rng, iter, SITE_PRIOR_OBS, 0, (uint32_t)(t4 >> 2)), zo4);
+      const float4 r4 = *reinterpret_cast<const float4*>(resid + t4);
+      const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
+      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
+        const float zo = q == 0 ? zo4[0] : q == 1 ? zo4[1] : q == 2 ? zo4[2] : zo4[3];
+        const float zl = q == 0 ? zl4[0] : q == 1 ? zl4[1] : q == 2 ? zl4[2] : zl4[3];
+        const float zk = q == 0 ? zk4[0] : q == 1 ? zk4[1] : q == 2 ? zk4[2] : zk4[3];
+        const float yt = at4(r4, q) - (x.v[0] + x.v[O] + sc.so * zo);
+        float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
+        wl[W::F_YT * NT] = yt;
+#pragma unroll
+        for (int i = 0; i < D; ++i) wl[(W::F_AX + i) * NT] = x.v[i];
+        if (obs) {
+          // fold observation y~_t into (A, b, C, eta, J):  x_t | x_start ~ N(A x_start + b, C)
+          float za[D], cz[D];
+#pragma unroll
+          for (int j = 0; j < D; ++j) za[j] = fe.A.m[0][j] + fe.A.m[O][j];
+#pragma unroll
+          for (int i = 0; i < D; ++i) cz[i] = fe.C.m[i][0] + fe.C.m[i][O];
+          const float zb = fe.b.v[0] + fe.b.v[O];
+          const float Sv = cz[0] + cz[O] + sc.H;
+          const float rS = 1.0f / Sv;
+          const float e = (yt - zb) * rS;
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            fe.eta.v[i] = fmaf(za[i], e, fe.eta.v[i]);
+            fe.b.v[i] = fmaf(cz[i], e, fe.b.v[i]);
+            const float ki = cz[i] * rS;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              fe.J.m[i][j] = fmaf(za[i] * za[j], rS, fe.J.m[i][j]);
+              fe.A.m[i][j] = fmaf(-ki, za[j], fe.A.m[i][j]);
+              fe.C.m[i][j] = fmaf(-(cz[i] * cz[j]), rS, fe.C.m[i][j]);
+            }
+          }
+        }
+        // time update t -> t+1
+        w_left<TR, NS>(fe.A, ch);
+        w_apply<TR, NS>(fe.b, ch);
+        w_cov_predict<TR, NS>(fe.C, ch, sc);
+        w_apply<TR, NS>(x, ch);
+        x.v[0] = fmaf(sc.sl, zl, x.v[0]);
+        if constexpr (TR == 2) {
+          const float zs = q == 0 ? zs4[0] : q == 1 ? zs4[1] : q == 2 ? zs4[2] : zs4[3];
+          x.v[1] = fmaf(sc.ss, zs, x.v[1]);
+        }
+        if (ch) {
+          const float dz = sc.sdn * zk;
+#pragma unroll
+          for (int i = 0; i < N1; ++i) x.v[O + i] -= dz;
+        }
+      }
+    }
+  }
+  prof.tick(5);
+  const FElem<D> fpre = block_scan_excl_fwd_rolled(
+      fe, [](const FElem<D>& x, const FElem<D>& y) { return felem_combine(x, y); },
+      felem_identity<D>(), fslots, lane, wave);
+  prof.tick(6);
+
+  // ---- (3) local Kalman filter from the predicted moments at the start of the chunk
+  {
+    Vec<D> am;
+    Mat<D> Pm;
+    if (tid == 0) { am = a1e; Pm = P1; } else { am = fpre.b; Pm = fpre.C; }
+#pragma unroll 1
+    for (int g4 = 0; g4 < Lc; g4 += 4) {
+      const int t4 = t0 + g4;
+      const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
+      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
+        float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
+        const float yt = wl[W::F_YT * NT];
+#pragma unroll
+        for (int i = 0; i < D; ++i) wl[(W::F_AX + i) * NT] += am.v[i];
+        {
+          int e = 0;
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) wl[(W::F_PS + e++) * NT] = Pm.m[i][j];
+        }
+        float vf = 0.f;
+        float kf[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) kf[i] = 0.f;
+        if (obs) {
+          float pz[D];
+#pragma unroll
+          for (int i = 0; i < D; ++i) pz[i] = Pm.m[i][0] + Pm.m[i][O];
+          const float Fv = pz[0] + pz[O] + sc.H;
+          const float rF = 1.0f / Fv;
+          const float v = yt - (am.v[0] + am.v[O]);
+          vf = v * rF;
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            kf[i] = pz[i] * rF;
+            am.v[i] = fmaf(kf[i], v, am.v[i]);
+#pragma unroll
+            for (int j = 0; j < D; ++j) Pm.m[i][j] = fmaf(-(pz[i] * pz[j]), rF, Pm.m[i][j]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) wl[(W::F_KF + i) * NT] = kf[i];
+        wl[W::F_VF * NT] = vf;
+        w_apply<TR, NS>(am, ch);
+        w_cov_predict<TR, NS>(Pm, ch, sc);
+      }
+    }
+  }
+  prof.tick(7);
+
+  // ---- (4) backward recursion r <- T' r ; r += Z'(v/F - K'r): chunk maps, suffix scan
+  AElem<D> ae = aelem_identity<D>();
+#pragma unroll 1
+  for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
+    const int t4 = t0 + g4;
+    const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
+    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
+#pragma unroll 1
+    for (int q = 3; q >= 0; --q) {
+      const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+      const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
+      const float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
+      w_left_t<TR, NS>(ae.M, ch);
+      w_apply_t<TR, NS>(ae.c, ch);
+      if (obs) {
+        float kf[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) kf[i] = wl[(W::F_KF + i) * NT];
+        const float vf = wl[W::F_VF * NT];
+        float kc = 0.f;
+#pragma unroll
+        for (int i = 0; i < D; ++i) kc = fmaf(kf[i], ae.c.v[i], kc);
+        const float add = vf - kc;
+        ae.c.v[0] += add;
+        ae.c.v[O] += add;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          float kr = 0.f;
+#pragma unroll
+          for (int i = 0; i < D; ++i) kr = fmaf(kf[i], ae.M.m[i][j], kr);
+          ae.M.m[0][j] -= kr;
+          ae.M.m[O][j] -= kr;
+        }
+      }
+    }
+  }
+  prof.tick(8);
+  const AElem<D> asuf = block_scan_excl_bwd_rolled(
+      ae, [](const AElem<D>& o, const AElem<D>& i) { return aelem_compose(o, i); },
+      aelem_identity<D>(), aslots, lane, wave);
+  prof.tick(9);
+
+  // ---- (5) r through the chunk, x~_t = (a_t + x+_t) + P_t r_{t-1}, statistics of the draw
+  ssl = 0.f; sss = 0.f; ssd = 0.f;
+  auto stats = [&](const Vec<D>& xt, const Vec<D>& xn, bool ch) {
+    float dl = xn.v[0] - xt.v[0];
+    if constexpr (TR == 2) {
+      dl -= xt.v[1];
+      const float ds = xn.v[1] - xt.v[1];
+      sss = fmaf(ds, ds, sss);
+    }
+    ssl = fmaf(dl, dl, ssl);
+    if (ch) {
+      float w;
+      if constexpr (NS >= 3) w = (float)NS * (xt.v[O + 1] - xn.v[O]);
+      else w = -2.0f * (xn.v[O] + xt.v[O]);
+      ssd = fmaf(w, w, ssd);
+    }
+  };
+  Vec<D> xlast = vzero<D>(), xfirst = vzero<D>();
+  {
+    Vec<D> r = asuf.c;      // the maps of all later chunks applied to r = 0
+    Vec<D> xn = vzero<D>();
+#pragma unroll 1
+    for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
+      const int t4 = t0 + g4;
+      const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
+      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
+#pragma unroll 1
+      for (int q = 3; q >= 0; --q) {
+        const int t = t4 + q;
+        const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
+        const float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
+        Vec<D> xt;
+#pragma unroll
+        for (int i = 0; i < D; ++i) xt.v[i] = wl[(W::F_AX + i) * NT];
+        Mat<D> Pm;
+        {
+          int e = 0;
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) {
+              const float v = wl[(W::F_PS + e++) * NT];
+              Pm.m[i][j] = v;
+              Pm.m[j][i] = v;
+            }
+        }
+        w_apply_t<TR, NS>(r, ch);
+        if (obs) {
+          float kr = 0.f;
+#pragma unroll
+          for (int i = 0; i < D; ++i) kr = fmaf(wl[(W::F_KF + i) * NT], r.v[i], kr);
+          const float add = wl[W::F_VF * NT] - kr;
+          r.v[0] += add;
+          r.v[O] += add;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int j = 0; j < D; ++j) xt.v[i] = fmaf(Pm.m[i][j], r.v[j], xt.v[i]);
+        if (t < T) {
+          levw[t] = xt.v[0];
+          if constexpr (TR == 2) slpw[t] = xt.v[1];
+          seaw[t] = xt.v[O];
+        }
+        if (g4 + q == Lc - 1) xlast = xt;
+        else if (t + 1 < T) stats(xt, xn, ch);
+        xn = xt;
+      }
+    }
+    xfirst = xn;
+  }
+  // increment across the chunk boundary: the next thread's first step
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) edge[wave * D + i] = xfirst.v[i];
+  }
+  __syncthreads();
+  {
+    Vec<D> nf;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      nf.v[i] = __shfl_down(xfirst.v[i], 1, 64);
+      if (lane == 63) nf.v[i] = (wave + 1 < NW) ? edge[(wave + 1) * D + i] : 0.f;
+    }
+    const int t = t0 + Lc - 1;
+    if (t + 1 < T) stats(xlast, nf, cbv[t] != 0);
+  }
+  prof.tick(10);
+}
+
+// ------------------------------------------------------------------------------------
+// the persistent Gibbs kernel (same iteration structure as gibbs_kernel / the oracle's
+// ci_oracle_fit_gibbs; gibbs_sampler.fit_with_gibbs_sampling called at causalimpact_lib.py:365)
+// ------------------------------------------------------------------------------------
+template <int TR, int NS>
+__global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
+  using W = WDim<TR, NS>;
+  constexpr int D = W::D, O = W::O, N1 = W::N1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const KArgs& g = a.k;
+  const int T = g.T, P = g.P, Lc = a.Lc;
+  const int TP = NT * Lc;
+  const int series = blockIdx.x / g.C, chain = blockIdx.x % g.C;
+  const size_t chain_lin = (size_t)series * g.C + chain;
+  const WLayout lay = make_wlayout(P, D);
+  RegLds R;
+  R.xtx = (double*)(smem + lay.xtx); R.omega = (double*)(smem + lay.omega);
+  R.aug[0] = (double*)(smem + lay.aug0); R.aug[1] = (double*)(smem + lay.aug1);
+  R.pri[0] = (double*)(smem + lay.pri0); R.pri[1] = (double*)(smem + lay.pri1);
+  R.chol = (double*)(smem + lay.chol); R.bvec = (double*)(smem + lay.bvec);
+  R.zv = (double*)(smem + lay.zv); R.uperm = (double*)(smem + lay.uperm);
+  R.nz = (int*)(smem + lay.nz); R.perm = (int*)(smem + lay.perm); R.idx = (int*)(smem + lay.idx);
+  R.w = (float*)(smem + lay.w);
+  float* scal = (float*)(smem + lay.scal);
+  float* red = (float*)(smem + lay.red);
+  float* pslots = (float*)(smem + lay.pslots);
+  float* fslots = (float*)(smem + lay.fslots);
+  float* aslots = (float*)(smem + lay.aslots);
+  float* edge = (float*)(smem + lay.edge);
+  const int RS = (P > 16 ? P : 16) + 4;
+
+  // per-chain HBM workspace
+  float* ws = a.ws + chain_lin * wide_workspace_floats(D, Lc);
+  float* tgw = ws;                  // targets y - level - seasonal (observed steps)
+  float* residw = tgw + TP;         // y - X w
+  float* levw = residw + TP;
+  float* slpw = levw + TP;
+  float* seaw = slpw + TP;
+  float* xww = seaw + TP;           // X w
+  float* wsp = xww + TP;            // private per-step fields [Lc][NF][NT]
+  uint8_t* mskp = (uint8_t*)(wsp + (size_t)W::NF * TP);   // mask, padded with 1
+  uint8_t* cbp = mskp + TP;                               // season-change flags, padded with 0
+
+  const DevSeriesParams sp = g.sp[series];
+  const DevSeasonalParams ss = a.ssp[series];
+  Rng rng{g.seed0, g.seed1, (uint32_t)(g.chain_offset + chain)};
+  const float* yg = g.y + (size_t)series * T;
+  const float* Xg = g.Xt + (size_t)series * P * T;
+  const float* chol1 = a.p1_chol + (size_t)series * D * D;
+
+  float nch = 0.f;
+  for (int t = tid; t < TP; t += NT) {
+    const bool in = t < T;
+    mskp[t] = in ? (g.mask[(size_t)series * T + t] != 0 ? 1 : 0) : 1;
+    const uint8_t c = in ? (a.season_change[t] != 0 ? 1 : 0) : 0;
+    cbp[t] = c;
+    if (t + 1 < T && c) nch += 1.f;
+    levw[t] = 0.f; slpw[t] = 0.f; seaw[t] = 0.f; xww[t] = 0.f; residw[t] = 0.f; tgw[t] = 0.f;
+  }
+  for (int e = tid; e < P * P; e += NT) {
+    R.xtx[e] = g.xtx[(size_t)series * P * P + e];
+    R.omega[e] = g.omega[(size_t)series * P * P + e];
+  }
+  if (tid < 16 || tid < P) R.w[tid] = 0.f;
+  {
+    const float s = wave_sum_dpp(nch);
+    if (lane == 0) red[wave] = s;
+  }
+  __syncthreads();
+  const double n_changes = (double)(red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+
+  double obs_scale = sp.obs_scale0, level_scale = sp.level_scale0, slope_scale = sp.slope_scale0;
+  double drift = ss.drift_scale0[0];
+  const float p1l = (float)(sp.init_level_scale * sp.init_level_scale);
+  const float p1s = (float)(sp.init_slope_scale * sp.init_slope_scale);
+  const float p1e = (float)(ss.init_seasonal_scale * ss.init_seasonal_scale);
+  Mat<D> P1 = mzero<D>();
+  P1.m[0][0] = p1l;
+  if constexpr (TR == 2) P1.m[1][1] = p1s;
+#pragma unroll
+  for (int i = 0; i < N1; ++i)
+#pragma unroll
+    for (int j = 0; j < N1; ++j) P1.m[O + i][O + j] = p1e * ((i == j ? 1.f : 0.f) - 1.f / (float)NS);
+  float ssl = 0.f, sss = 0.f, ssd = 0.f;
+  PriorCarry pc;
+  pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
+  Prof prof;
+  prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && tid == 0);
+
+  const int n_iter = g.W + g.S;
+  for (int it = 0; it <= n_iter; ++it) {
+    // ---- (1) targets, y'y, X~'targets (time interleaved over threads: coalesced)
+    {
+      float yty = 0.f;
+      for (int t = tid; t < T; t += NT) {
+        float tg = 0.f;
+        if (!mskp[t]) tg = yg[t] - levw[t] - seaw[t];
+        tgw[t] = tg;
+        yty = fmaf(tg, tg, yty);
+      }
+      for (int j0 = 0; j0 < P; j0 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = tid; t < T; t += NT) {
+          const float tg = tgw[t];      // written by this same thread above
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q < P ? j0 + q : P - 1;
+            acc[q] = fmaf(Xg[(size_t)j * T + t], tg, acc[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float s = wave_sum_dpp(acc[q]);
+          if (lane == 0 && j0 + q < P) red[wave * RS + j0 + q] = s;
+        }
+      }
+      const float s0 = wave_sum_dpp(yty), s1 = wave_sum_dpp(ssl), s2 = wave_sum_dpp(sss),
+                  s3 = wave_sum_dpp(ssd);
+      if (lane == 0) {
+        red[wave * RS + RS - 4] = s0;
+        red[wave * RS + RS - 3] = s1;
+        red[wave * RS + RS - 2] = s2;
+        red[wave * RS + RS - 1] = s3;
+      }
+    }
+    __syncthreads();
+    prof.tick(0);
+
+    // ---- (2) serial section (wave 0): scales of iteration it-1, regression draw of iteration it
+    if (wave == 0) {
+      for (int j = lane; j < P + 4; j += 64) {
+        const int src = j < P ? j : RS - 4 + (j - P);
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += (double)red[w * RS + src];
+        R.bvec[j] = s;
+      }
+      wave_sync();
+      double emit_obs = obs_scale;
+      if (it > 0) {
+        const uint32_t pit = (uint32_t)(it - 1);
+        level_scale = scale_draw(sp.level_conc, sp.level_scale, sp.level_ub, (double)(T - 1),
+                                 R.bvec[P + 1], rng, pit, SITE_LEVEL_SCALE, lane);
+        if constexpr (TR == 2)
+          slope_scale = scale_draw(sp.slope_conc, sp.slope_scale, sp.slope_ub, (double)(T - 1),
+                                   R.bvec[P + 2], rng, pit, SITE_SLOPE_SCALE, lane);
+        {
+          const double gk = gamma_wave(ss.drift_conc + 0.5 * n_changes, rng, pit, SITE_DRIFT_SCALE, 0, lane);
+          const double sd = (double)__fsqrt_rn((float)((ss.drift_scale + 0.5 * R.bvec[P + 3]) * fast_rcp(gk)));
+          drift = sd < ss.drift_ub ? sd : ss.drift_ub;
+        }
+        if (P == 0)
+          obs_scale = scale_draw(sp.obs_conc, sp.obs_scale, sp.obs_ub, sp.n_obs, R.bvec[P], rng, pit,
+                                 SITE_OBS_SCALE, lane);
+        emit_obs = obs_scale;
+        const int s = it - 1 - g.W;
+        if (s >= 0) {
+          const size_t o = chain_lin * g.S + s;
+          if (lane == 0) {
+            if (g.out_obs) g.out_obs[o] = (float)obs_scale;
+            if (g.out_level_scale) g.out_level_scale[o] = (float)level_scale;
+            if (g.out_slope_scale) g.out_slope_scale[o] = (float)(TR == 2 ? slope_scale : 0.0);
+            if (a.out_drift) a.out_drift[o] = (float)drift;
+          }
+          if (g.out_weights)
+            for (int j = lane; j < P; j += 64) g.out_weights[o * P + j] = R.w[j];
+        }
+      }
+      if (P > 0 && it < n_iter) {
+        const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
+        if (P <= 16)
+          obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
+        else
+          obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof);
+      }
+      if (lane == 0) {
+        scal[0] = (float)obs_scale;
+        scal[1] = (float)emit_obs;
+        scal[2] = (float)level_scale;
+        scal[3] = (float)slope_scale;
+        scal[4] = (float)drift;
+      }
+    }
+    __syncthreads();
+    prof.tick(1);
+
+    // ---- (3) emit iteration it-1: latents and the posterior-predictive trajectory
+    if (it > g.W) {
+      const int s = it - 1 - g.W;
+      const size_t o = chain_lin * g.S + s;
+      const size_t row = o * T;
+      const float so = scal[1];
+      for (int c = tid; c < (T + 3) / 4; c += NT) {
+        float zp[4];
+        normals4(site_call(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)c), zp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = 4 * c + q;
+          if (t < T) {
+            const float lv = levw[t], sv = seaw[t];
+            const float loc = lv + sv + xww[t];
+            if (g.out_level) g.out_level[row + t] = lv;
+            if (g.out_slope && TR == 2) g.out_slope[row + t] = slpw[t];
+            if (a.out_seasonal) a.out_seasonal[row + t] = sv;
+            if (g.out_traj) g.out_traj[row + t] = fmaf(so, zp[q], loc);
+            if (g.out_pred_mean) {
+              float* pm = g.out_pred_mean + chain_lin * T + t;   // running sum, scaled at the end
+              *pm = (s == 0 ? 0.f : *pm) + loc;
+            }
+          }
+        }
+      }
+    }
+    prof.tick(2);
+    if (it == n_iter) break;
+    __syncthreads();     // (3) reads xww through a different thread mapping than (4) writes it
+
+    // ---- (4) X w and the residual
+    for (int t = tid; t < TP; t += NT) {
+      float s = 0.f, yv = 0.f;
+      if (t < T) {
+        for (int j = 0; j < P; ++j) s = fmaf(Xg[(size_t)j * T + t], R.w[j], s);
+        yv = mskp[t] ? 0.f : yg[t];
+      }
+      xww[t] = s;
+      residw[t] = yv - s;
+    }
+    // x+_0 = chol(P_1) z, folded into the filter's prior mean (see dk_draw in ci_kernels.h)
+    Vec<D> a1e = vzero<D>();
+    a1e.v[0] = (float)sp.init_level_loc;
+    if (tid == 0) {
+      float z[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        float z1[1];
+        fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)i, z1);
+        z[i] = z1[0];
+      }
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) s = fmaf(chol1[i * D + j], z[j], s);
+        a1e.v[i] += s;
+      }
+    }
+    WideScal sc;
+    sc.so = scal[0]; sc.H = sc.so * sc.so;
+    sc.sl = scal[2]; sc.ql = sc.sl * sc.sl;
+    sc.ss = scal[3]; sc.qs = sc.ss * sc.ss;
+    sc.sdn = scal[4] * (1.0f / (float)NS); sc.qd = sc.sdn * sc.sdn;
+    __syncthreads();
+    prof.tick(3);
+    wide_dk_draw<TR, NS>(sc, a1e, P1, T, Lc, residw, mskp, cbp, wsp, levw, slpw, seaw, rng,
+                         (uint32_t)it, tid, lane, wave, pslots, fslots, aslots, edge, ssl, sss, ssd,
+                         prof);
+    __syncthreads();
+  }
+  __syncthreads();     // the running sums were accumulated through the emission's thread mapping
+  if (g.out_pred_mean) {
+    const float inv = 1.0f / (float)(g.S > 0 ? g.S : 1);
+    for (int t = tid; t < T; t += NT) g.out_pred_mean[chain_lin * T + t] *= inv;
+  }
+}
+
+}  // namespace ci

@@ -1,0 +1,13 @@
+// ci_wide.hip -- one (TR, NS) instantiation of the time-parallel trend + seasonal Gibbs kernel
+// per object file.  Compile with -DCI_TR=<1|2> -DCI_NS=<seasons>.
+#include <hip/hip_runtime.h>
+
+#define CI_SEASONAL_DECL_ONLY
+#include "ci_wide.h"
+
+#define CI_CAT_(a, b, c, d) a##b##c##d
+#define CI_CAT(a, b, c, d) CI_CAT_(a, b, c, d)
+
+extern "C" void* CI_CAT(ci_gibbs_wide_fn_tr, CI_TR, _ns, CI_NS)(void) {
+  return (void*)(&ci::gibbs_wide_kernel<CI_TR, CI_NS>);
+}

@@ -35,6 +35,7 @@ def _fit_both(T, p, has_slope, W, S, C=1, seed=(5, 9), data_seed=0, chain_offset
     (300, 4, 1),    # P=5 => pi=0.6, inclusion flips, local linear trend
     (1000, 10, 1),  # BASELINE cfg2 shape
     (700, 10, 0),   # L=4 with padding, local level
+    (500, 24, 0),   # P=25 > 16: LDS-resident regression block (in-place sweeps)
 ])
 def test_first_iterations_match_oracle_per_draw(T, p, has_slope):
   S = 4

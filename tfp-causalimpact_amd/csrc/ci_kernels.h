@@ -450,7 +450,7 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
 struct RegLds {
   double* xtx;     // [P*P]
   double* omega;   // [P*P]
-  double* aug[2];  // [(P+1)^2] swept augmented matrix [[M, b],[b', y'y]], double buffered
+  double* aug[2];  // [(P+1)^2] swept augmented matrix [[M, b],[b', y'y]] ([1] unused)
   double* pri[2];  // [P*P]     swept prior precision
   double* chol;    // [P*P]
   double* bvec;    // [P+4]     reduced X~'targets, y'y, ss_level, ss_slope
@@ -462,34 +462,53 @@ struct RegLds {
   float* w;        // [P]
 };
 
-// One symmetric sweep (or its inverse) of both matrices on pivot k: src -> dst.
-__device__ __forceinline__ void sweep_pair(const double* sa, double* da, int n, const double* sp,
-                                           double* dp, int np, int k, bool reverse, int lane) {
+// One symmetric sweep (or its inverse) of both matrices on pivot k, in place.  The pivot row
+// (== pivot column: swept symmetric matrices stay symmetric) is first copied to `tmp`, so no
+// lane reads an entry another lane is rewriting.  Entries are walked in LINEAR order, 64 lanes x 8
+// per trip, with no predicates at all: the matrices are padded to a multiple of 512 doubles
+// (sweep_padded) and whatever lands in the padding is never read.  General entries get one FMA;
+// the pivot row / column are rewritten afterwards (LDS operations of one wave complete in
+// program order, so the later stores win).  n, np <= 64; tmp: 128 doubles.
+__host__ __device__ inline size_t sweep_padded(size_t entries) { return (entries + 511) & ~(size_t)511; }
+
+__device__ __forceinline__ void sweep_one(double* __restrict__ M, int m, const double* __restrict__ t,
+                                          int k, double sgn, int lane) {
+  const double rd = fast_rcp(t[k]);
+  const int qd = 64 / m, rm = 64 - qd * m;     // (i, j) of entry e + 64 from (i, j) of entry e
+  int i = 0, j = lane;
+  while (j >= m) { j -= m; ++i; }
+  const int trips = (m * m + 511) >> 9;
+  double* Me = M + lane;
+#pragma unroll 1
+  for (int it = 0; it < trips; ++it) {
+    double mv[8], ti[8], tj[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      mv[u] = Me[64 * u];
+      ti[u] = t[i];
+      tj[u] = t[j];
+      j += rm; i += qd;
+      if (j >= m) { j -= m; ++i; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) Me[64 * u] = mv[u] - (ti[u] * rd) * tj[u];
+    Me += 512;
+  }
+  if (lane < m) {
+    const double pv = (lane == k) ? -rd : sgn * t[lane] * rd;
+    M[k * m + lane] = pv;
+    M[lane * m + k] = pv;
+  }
+}
+
+__device__ __forceinline__ void sweep_pair(double* A, int n, double* Pm, int np, int k,
+                                           bool reverse, int lane, double* tmp) {
   const double sgn = reverse ? -1.0 : 1.0;
-  {
-    const double rd = fast_rcp(sa[k * n + k]);
-    for (int i = lane >> 4; i < n; i += 4)
-      for (int j = lane & 15; j < n; j += 16) {
-        const double aik = sa[i * n + k], akj = sa[k * n + j];
-        double nv;
-        if (i == k) nv = (j == k) ? -rd : sgn * akj * rd;
-        else if (j == k) nv = sgn * aik * rd;
-        else nv = sa[i * n + j] - aik * akj * rd;
-        da[i * n + j] = nv;
-      }
-  }
-  {
-    const double rd = fast_rcp(sp[k * np + k]);
-    for (int i = lane >> 4; i < np; i += 4)
-      for (int j = lane & 15; j < np; j += 16) {
-        const double aik = sp[i * np + k], akj = sp[k * np + j];
-        double nv;
-        if (i == k) nv = (j == k) ? -rd : sgn * akj * rd;
-        else if (j == k) nv = sgn * aik * rd;
-        else nv = sp[i * np + j] - aik * akj * rd;
-        dp[i * np + j] = nv;
-      }
-  }
+  if (lane < n) tmp[lane] = A[k * n + lane];
+  if (lane < np) tmp[64 + lane] = Pm[k * np + lane];
+  wave_sync();
+  sweep_one(A, n, tmp, k, sgn, lane);
+  sweep_one(Pm, np, tmp + 64, k, sgn, lane);
   wave_sync();
 }
 
@@ -735,31 +754,51 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
 __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
                                                   const DevSeriesParams& sp, double prev_obs_scale,
                                                   double g_obs, const Rng& rng, uint32_t iter,
-                                                  int lane, Prof& prof) {
+                                                  int lane, Prof& prof, bool first) {
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
-  int cur = 0;
-  for (int i = lane >> 4; i < n; i += 4)
-    for (int j = lane & 15; j < n; j += 16) {
-      double v;
-      if (i < P && j < P) v = R.omega[i * P + j] * prev_var + R.xtx[i * P + j];
-      else if (i == P && j == P) v = R.bvec[P];
-      else v = R.bvec[i < j ? i : j];
-      R.aug[0][i * n + j] = v;
-      if (i < P && j < P) R.pri[0][i * P + j] = R.omega[i * P + j] * prev_var;
+  constexpr int cur = 0;
+  double* tmp = R.chol;            // free until the final Cholesky (P > 16 => P*P >= 128)
+  {
+    // augmented matrix [[Omega s + X'X, X'r], [r'X, r'r]] and the scaled prior precision, linear
+    // entry order, branch-free (clamped loads + selects; stores past the end land in the padding)
+    const int qd = 64 / n, rm = 64 - qd * n;
+    int i = 0, j = lane;
+    while (j >= n) { j -= n; ++i; }
+    for (int e = lane; e < n * n; e += 64) {
+      const int ic = i < P ? i : P - 1, jc = j < P ? j : P - 1;
+      const double inner = R.omega[ic * P + jc] * prev_var + R.xtx[ic * P + jc];
+      const double edge = R.bvec[(i == P && j == P) ? P : (i < j ? i : j)];
+      R.aug[0][e] = (i < P && j < P) ? inner : edge;
+      j += rm; i += qd;
+      if (j >= n) { j -= n; ++i; }
     }
+    // The prior precision is kept swept on the CURRENT model at unit scale, from iteration to
+    // iteration (the model at the start of an iteration is the one the previous iteration ended
+    // with): sweeping s * Omega gives s * (unswept block), (swept block) / s, so only the logs
+    // below see the scale.  It is built once.
+    if (first)
+      for (int e = lane; e < P * P; e += 64) R.pri[0][e] = R.omega[e];
+  }
+  int nz0 = 0;
   if (lane < P) {
-    R.nz[lane] = all_in ? 1 : (R.w[lane] != 0.f ? 1 : 0);
+    nz0 = all_in ? 1 : (R.w[lane] != 0.f ? 1 : 0);
+    R.nz[lane] = nz0;
     if (!all_in) R.uperm[lane] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)lane);
   }
   wave_sync();
   // sweep in the currently included features
-  for (int j = 0; j < P; ++j) {
-    if (R.nz[j]) {
-      sweep_pair(R.aug[cur], R.aug[cur ^ 1], n, R.pri[cur], R.pri[cur ^ 1], P, j, false, lane);
-      cur ^= 1;
+  for (unsigned long long todo = __ballot(nz0 != 0); todo; todo &= todo - 1ull) {
+    const int k = __ffsll((long long)todo) - 1;
+    if (first) {
+      sweep_pair(R.aug[0], n, R.pri[0], P, k, false, lane, tmp);
+    } else {
+      if (lane < n) tmp[lane] = R.aug[0][k * n + lane];
+      wave_sync();
+      sweep_one(R.aug[0], n, tmp, k, 1.0, lane);
+      wave_sync();
     }
   }
   prof.tick(9);
@@ -775,33 +814,46 @@ __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
       R.perm[rank] = lane;
     }
     wave_sync();
+    // Lane s evaluates the proposal at visiting position s on the CURRENT model; the first
+    // position (>= the scan position) that flips is applied and the later ones re-evaluated.
+    // That is spike_and_slab._resample_all_features decision for decision, with as many
+    // evaluation rounds as accepted flips + 1 instead of P.
     const double logit_pi = log(sp.nonzero_prob) - log1p(-sp.nonzero_prob);
-    for (int s = 0; s < P; ++s) {
-      const int j = R.perm[s];
+    const int myj = lane < P ? R.perm[lane] : 0;
+    const double myu = lane < P ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)lane) : 2.0;
+    int s_cur = 0;
+    while (true) {
+      bool flip = false;
+      if (lane < P && lane >= s_cur) {
+        const double* A = R.aug[0];
+        const bool in = R.nz[myj] != 0;
+        const double ajj = A[myj * n + myj], ajb = A[myj * n + P], corner = A[P * n + P];
+        const double pju = R.pri[0][myj * P + myj];      // unit scale
+        const double beta_old = sp.obs_scale + 0.5 * corner;
+        double delta;
+        if (!in) {
+          const double pjj = pju * prev_var;
+          const double beta_new = sp.obs_scale + 0.5 * (corner - ajb * ajb / ajj);
+          delta = 0.5 * log(pjj) - 0.5 * log(ajj) + logit_pi -
+                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
+        } else {
+          const double V = -ajj, Vp = -pju / prev_var;
+          const double beta_new = sp.obs_scale + 0.5 * (corner + ajb * ajb / V);
+          delta = 0.5 * log(Vp) - 0.5 * log(V) - logit_pi -
+                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
+        }
+        flip = myu < 1.0 / (1.0 + exp(-delta));
+      }
+      const unsigned long long bal = __ballot(flip);
+      if (bal == 0ull) break;
+      const int s_star = __ffsll((long long)bal) - 1;
+      const int j = R.perm[s_star];
       const bool in = R.nz[j] != 0;
-      const double* A = R.aug[cur];
-      const double ajj = A[j * n + j], ajb = A[j * n + P], corner = A[P * n + P];
-      const double pjj = R.pri[cur][j * P + j];
-      const double beta_old = sp.obs_scale + 0.5 * corner;
-      double delta;
-      if (!in) {
-        const double beta_new = sp.obs_scale + 0.5 * (corner - ajb * ajb / ajj);
-        delta = 0.5 * log(pjj) - 0.5 * log(ajj) + logit_pi -
-                (a_post - 1.0) * (log(beta_new) - log(beta_old));
-      } else {
-        const double V = -ajj, Vp = -pjj;
-        const double beta_new = sp.obs_scale + 0.5 * (corner + ajb * ajb / V);
-        delta = 0.5 * log(Vp) - 0.5 * log(V) - logit_pi -
-                (a_post - 1.0) * (log(beta_new) - log(beta_old));
-      }
-      const double u = uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)s);
-      const bool flip = u < 1.0 / (1.0 + exp(-delta));
-      if (flip) {
-        sweep_pair(R.aug[cur], R.aug[cur ^ 1], n, R.pri[cur], R.pri[cur ^ 1], P, j, in, lane);
-        cur ^= 1;
-        if (lane == 0) R.nz[j] = in ? 0 : 1;
-        wave_sync();
-      }
+      wave_sync();
+      sweep_pair(R.aug[0], n, R.pri[0], P, j, in, lane, tmp);
+      if (lane == 0) R.nz[j] = in ? 0 : 1;
+      wave_sync();
+      s_cur = s_star + 1;
     }
   }
   prof.tick(10);
@@ -899,10 +951,10 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_ctx = take(sizeof(SerialCtx));
   l.off_xtx = take(sizeof(double) * Pp * Pp);
   l.off_omega = take(sizeof(double) * Pp * Pp);
-  l.off_aug0 = take(sizeof(double) * (Pp + 1) * (Pp + 1));
-  l.off_aug1 = take(sizeof(double) * (Pp + 1) * (Pp + 1));
-  l.off_pri0 = take(sizeof(double) * Pp * Pp);
-  l.off_pri1 = take(sizeof(double) * Pp * Pp);
+  l.off_aug0 = take(sizeof(double) * sweep_padded((size_t)(Pp + 1) * (Pp + 1)));
+  l.off_aug1 = take(16);      // (sweeps are in place: no second buffer)
+  l.off_pri0 = take(sizeof(double) * sweep_padded((size_t)Pp * Pp));
+  l.off_pri1 = take(16);
   l.off_chol = take(sizeof(double) * Pp * Pp);
   l.off_bvec = take(sizeof(double) * (Pp + 4));
   l.off_zv = take(sizeof(double) * Pp);
@@ -995,7 +1047,7 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
     if constexpr (PM == 1)
       obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, pc);
     else if constexpr (PM == 2)
-      obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof);
+      obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, it == 0);
   }
   if (lane == 0) {
     cx->obs_scale = obs_scale;

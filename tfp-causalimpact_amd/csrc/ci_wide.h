@@ -236,11 +236,11 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   const bool big = P > 16;    // the LDS-resident regression block is only used for P > 16
   l.xtx = take(sizeof(double) * Pp * Pp);
   l.omega = take(sizeof(double) * Pp * Pp);
-  l.aug0 = take(big ? sizeof(double) * (Pp + 1) * (Pp + 1) : 16);
-  l.aug1 = take(big ? sizeof(double) * (Pp + 1) * (Pp + 1) : 16);
-  l.pri0 = take(big ? sizeof(double) * Pp * Pp : 16);
-  l.pri1 = take(big ? sizeof(double) * Pp * Pp : 16);
-  l.chol = take(big ? sizeof(double) * Pp * Pp : 16);
+  l.aug0 = take(big ? sizeof(double) * sweep_padded((size_t)(Pp + 1) * (Pp + 1)) : 16);
+  l.aug1 = take(16);
+  l.pri0 = take(big ? sizeof(double) * sweep_padded((size_t)Pp * Pp) : 16);
+  l.pri1 = take(16);
+  l.chol = take(big ? sizeof(double) * Pp * Pp : 16);   // also the sweeps' pivot-row scratch
   l.bvec = take(sizeof(double) * (Pp + 4));
   l.zv = take(sizeof(double) * Pp);
   l.uperm = take(sizeof(double) * Pp);
@@ -316,7 +316,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
   const WPElem<D> ppre = block_scan_excl_fwd_rolled(
       pe, [](const WPElem<D>& x, const WPElem<D>& y) { return wpelem_combine<TR, NS>(x, y); }, pid,
       pslots, lane, wave);
-  prof.tick(4);
+  prof.tick(20);
 
   // ---- (2) x+ from the chunk's prefix, y~ = resid - y+, and the chunk's filtering element
   FElem<D> fe = felem_identity<D>();
@@ -392,11 +392,11 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
       }
     }
   }
-  prof.tick(5);
+  prof.tick(21);
   const FElem<D> fpre = block_scan_excl_fwd_rolled(
       fe, [](const FElem<D>& x, const FElem<D>& y) { return felem_combine(x, y); },
       felem_identity<D>(), fslots, lane, wave);
-  prof.tick(6);
+  prof.tick(22);
 
   // ---- (3) local Kalman filter from the predicted moments at the start of the chunk
   {
@@ -451,7 +451,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
       }
     }
   }
-  prof.tick(7);
+  prof.tick(23);
 
   // ---- (4) backward recursion r <- T' r ; r += Z'(v/F - K'r): chunk maps, suffix scan
   AElem<D> ae = aelem_identity<D>();
@@ -489,11 +489,11 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
       }
     }
   }
-  prof.tick(8);
+  prof.tick(24);
   const AElem<D> asuf = block_scan_excl_bwd_rolled(
       ae, [](const AElem<D>& o, const AElem<D>& i) { return aelem_compose(o, i); },
       aelem_identity<D>(), aslots, lane, wave);
-  prof.tick(9);
+  prof.tick(25);
 
   // ---- (5) r through the chunk, x~_t = (a_t + x+_t) + P_t r_{t-1}, statistics of the draw
   ssl = 0.f; sss = 0.f; ssd = 0.f;
@@ -583,7 +583,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
     const int t = t0 + Lc - 1;
     if (t + 1 < T) stats(xlast, nf, cbv[t] != 0);
   }
-  prof.tick(10);
+  prof.tick(26);
 }
 
 // ------------------------------------------------------------------------------------
@@ -691,18 +691,54 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         tgw[t] = tg;
         yty = fmaf(tg, tg, yty);
       }
-      for (int j0 = 0; j0 < P; j0 += 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = tid; t < T; t += NT) {
-          const float tg = tgw[t];      // written by this same thread above
+      __syncthreads();      // tgw is read back through another thread mapping below
+      // 8 design rows x 4 steps per pass, the 4 steps as one 16-byte load when rows are 16-byte
+      // aligned: one wave per SIMD here, so memory latency is hidden by bytes in flight per
+      // thread, not by occupancy
+      const bool vec4 = (T & 3) == 0;
+      for (int j0 = 0; j0 < P; j0 += 8) {
+        float acc[8];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = j0 + q < P ? j0 + q : P - 1;
-            acc[q] = fmaf(Xg[(size_t)j * T + t], tg, acc[q]);
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        if (vec4) {
+          for (int c4 = tid; c4 < (T >> 2); c4 += NT) {
+            const float4 tg = *reinterpret_cast<const float4*>(tgw + 4 * c4);
+            float4 xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int j = j0 + q < P ? j0 + q : P - 1;
+              xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              acc[q] += xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
+          }
+        } else {
+          for (int tb = tid; tb < T; tb += 4 * NT) {
+            float tg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int t = tb + u * NT;
+              tg[u] = t < T ? tgw[t] : 0.f;
+            }
+            float xv[8][4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int j = j0 + q < P ? j0 + q : P - 1;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int t = tb + u * NT;
+                xv[q][u] = Xg[(size_t)j * T + (t < T ? t : T - 1)];
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[q] = fmaf(xv[q][u], tg[u], acc[q]);
           }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
           const float s = wave_sum_dpp(acc[q]);
           if (lane == 0 && j0 + q < P) red[wave * RS + j0 + q] = s;
         }
@@ -764,7 +800,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         if (P <= 16)
           obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
         else
-          obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof);
+          obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, it == 0);
       }
       if (lane == 0) {
         scal[0] = (float)obs_scale;
@@ -809,14 +845,64 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     __syncthreads();     // (3) reads xww through a different thread mapping than (4) writes it
 
     // ---- (4) X w and the residual
-    for (int t = tid; t < TP; t += NT) {
-      float s = 0.f, yv = 0.f;
-      if (t < T) {
-        for (int j = 0; j < P; ++j) s = fmaf(Xg[(size_t)j * T + t], R.w[j], s);
-        yv = mskp[t] ? 0.f : yg[t];
+    if ((T & 3) == 0) {
+      for (int c4 = tid; c4 < (TP >> 2); c4 += NT) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), yv = s;
+        if (4 * c4 < T) {
+          for (int j0 = 0; j0 < P; j0 += 8) {
+            float4 xv[8];
+            float wj[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int j = j0 + q < P ? j0 + q : P - 1;
+              wj[q] = j0 + q < P ? R.w[j] : 0.f;
+              xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              s.x = fmaf(xv[q].x, wj[q], s.x); s.y = fmaf(xv[q].y, wj[q], s.y);
+              s.z = fmaf(xv[q].z, wj[q], s.z); s.w = fmaf(xv[q].w, wj[q], s.w);
+            }
+          }
+          const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * c4);
+          const uint32_t mk = *reinterpret_cast<const uint32_t*>(mskp + 4 * c4);
+          yv.x = (mk & 0xFFu) ? 0.f : y4.x; yv.y = (mk & 0xFF00u) ? 0.f : y4.y;
+          yv.z = (mk & 0xFF0000u) ? 0.f : y4.z; yv.w = (mk & 0xFF000000u) ? 0.f : y4.w;
+        }
+        *reinterpret_cast<float4*>(xww + 4 * c4) = s;
+        *reinterpret_cast<float4*>(residw + 4 * c4) = make_float4(yv.x - s.x, yv.y - s.y, yv.z - s.z, yv.w - s.w);
       }
-      xww[t] = s;
-      residw[t] = yv - s;
+    } else {
+      for (int tb = tid; tb < TP; tb += 4 * NT) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < P; j0 += 8) {
+          float xv[8][4], wj[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q < P ? j0 + q : P - 1;
+            wj[q] = j0 + q < P ? R.w[j] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int t = tb + u * NT;
+              xv[q][u] = Xg[(size_t)j * T + (t < T ? t : T - 1)];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] = fmaf(xv[q][u], wj[q], s[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = tb + u * NT;
+          if (t < TP) {
+            const float yv = (t < T && !mskp[t]) ? yg[t] : 0.f;
+            const float sv = t < T ? s[u] : 0.f;
+            xww[t] = sv;
+            residw[t] = yv - sv;
+          }
+        }
+      }
     }
     // x+_0 = chol(P_1) z, folded into the filter's prior mean (see dk_draw in ci_kernels.h)
     Vec<D> a1e = vzero<D>();

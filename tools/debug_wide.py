@@ -44,13 +44,37 @@ def perf(T, p, has_slope, C=8, W=12, S=100):
   ms = min(sess.run() for _ in range(2))
   sess.profile(True); sess.run(); cyc = sess.profile(False)
   it = W + S
-  names = ["sums", "serial", "emit", "Xw", "P elem+scan", "x+ / F elem", "F scan", "filter", "r elem",
-           "r scan", "draw+stats"]
+  names = {0: "sums", 1: "serial(rest)", 9: "ss sweep-in", 10: "ss flips", 11: "ss gather", 12: "ss weights",
+           2: "emit", 3: "Xw", 20: "P elem+scan", 21: "x+ / F elem", 22: "F scan", 23: "filter",
+           24: "r elem", 25: "r scan", 26: "draw+stats"}
   print(f"perf T={T} P={spec['P']} slope={has_slope} C={C}: {ms:.1f} ms per launch, {ms/it*1e3:.0f} us/iteration,"
         f" {C*S/ms*1e3:.0f} samples/s")
-  print("   kcycles/iteration: " + "  ".join(f"{n}: {cyc[i]/it/1e3:.1f}" for i, n in enumerate(names)))
+  print("   kcycles/iteration: " + "  ".join(f"{n}: {cyc[i]/it/1e3:.1f}" for i, n in names.items()))
+
+def perf_flagship(T, p, has_slope=0, C=8, W=12, S=100):
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope))
+  pb = _native.make_problem(T=T, P=spec["P"], has_slope=has_slope, num_warmup=W, num_results=S,
+                            num_chains=C, seed=(1, 2))
+  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  sess.run()
+  ms = min(sess.run() for _ in range(2))
+  out = sess.fetch(["weights"])
+  sess.profile(True); sess.run(); cyc = sess.profile(False)
+  it = W + S
+  print(f"flagship T={T} P={spec['P']}: {ms/it*1e3:.0f} us/iteration; mean #nonzero weights "
+        f"{(out['weights'] != 0).sum(-1).mean():.1f}")
+  print("   kcycles/iteration: " + "  ".join(f"{i}: {cyc[i]/it/1e3:.1f}" for i in range(19) if cyc[i]))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "ss":
+  perf_flagship(1000, 50)
+  perf_flagship(1000, 20)
+
 
 if __name__ == "__main__":
+  if len(sys.argv) > 1 and sys.argv[1] == "ss":
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == "perf":
     perf(1000, 5, 0); perf(1000, 10, 1); perf(10000, 50, 0, S=40, W=4); perf(10000, 0, 0, S=40, W=4)
     run(10000, 50, 0, ((7, 1),), S=2)

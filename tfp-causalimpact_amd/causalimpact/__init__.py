@@ -13,3 +13,13 @@ from causalimpact.causalimpact_lib import InferenceOptions
 from causalimpact.causalimpact_lib import ModelOptions
 from causalimpact.causalimpact_lib import Seasons
 from causalimpact.indices import InputDateType
+from causalimpact.summary import summary
+
+
+def plot(*args, **kwargs):
+  """Not part of this build: the reference draws Altair charts
+  from `CausalImpactAnalysis.series`, which this build returns with the same schema -- the
+  reference's `causalimpact.plot` works on it unchanged."""
+  raise NotImplementedError(
+      "plot() is not provided by the MI355X build; pass the analysis to the reference's "
+      "causalimpact.plot (same CausalImpactAnalysis.series schema)")

@@ -77,7 +77,7 @@ def _summary_table(s, alpha: float, p_value: float) -> str:
   out.append("Posterior probability of an effect: " + "{0:.2%}".format(1 - p_value))
   out.append("")
   out.append('For more details run the command: summary(impact, output_format="report")')
-  return "\n".join(out) + "\n"
+  return "\n".join(out)
 
 
 def _report(s, alpha: float, p_value: float) -> str:

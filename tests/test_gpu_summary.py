@@ -1,0 +1,87 @@
+"""On-device summarisation (csrc/ci_summary.h) against the host arithmetic
+it replaces.  The device path orders its float64 operations like the numpy code and returns
+order statistics (numpy's own interpolation is applied to them), so the two paths must agree
+to round-off -- tolerance 1e-10 relative, far below any "float32 tolerance"."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import causalimpact as ci
+from causalimpact import _native, _model
+from causalimpact import _synthetic as syn
+from oracle import ci_oracle as orc
+from test_golden_postprocessing import CASES, _load
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_frames_equal(a: pd.DataFrame, b: pd.DataFrame, rtol=1e-10):
+  assert list(a.columns) == list(b.columns) and list(a.index) == list(b.index)
+  for c in a.columns:
+    if a[c].dtype.kind in "fc":
+      np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=rtol,
+                                 atol=1e-12, equal_nan=True, err_msg=str(c))
+    else:
+      assert (a[c] == b[c]).all(), c
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_device_summary_equals_host_postprocessing_on_reference_cases(name):
+  """The reference's own edge cases (NaN outcomes, gap between periods, tail after the
+  post-period, no covariates, integer index, unstandardised data)."""
+  meta, _, df, pre, post = _load(name)
+  kw = dict(alpha=meta["alpha"], seed=3,
+            data_options=ci.DataOptions(standardize_data=meta["standardize"]))
+  dev = ci.fit_causalimpact(df, pre, post, inference_options=ci.InferenceOptions(
+      num_results=200, num_chains=3), **kw)
+  host = ci.fit_causalimpact(df, pre, post, inference_options=ci.InferenceOptions(
+      num_results=200, num_chains=3, summarize_on_device=False), **kw)
+  _assert_frames_equal(dev.series, host.series)
+  _assert_frames_equal(dev.summary, host.summary)
+  assert ci.summary(dev) == ci.summary(host)
+
+
+def test_order_statistics_and_running_sums_match_numpy():
+  T, p, C, S = 257, 2, 5, 123          # N = 615 draws: not a multiple of anything
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 4)
+  spec = orc.default_spec(y, mask, X)
+  pb = _native.make_problem(T=T, P=spec["P"], has_slope=0, num_warmup=20, num_results=S,
+                            num_chains=C, seed=(9, 9))
+  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  sess.run()
+  traj = sess.fetch(["posterior_trajectories"])["posterior_trajectories"].reshape(C * S, T)
+  rng = np.random.default_rng(0)
+  obs = rng.normal(size=T) * 3 + 10
+  obs[[5, 200, 230]] = np.nan
+  start, stop = 180, 240
+  flags = (np.arange(T) >= start).astype(np.uint8) | (((np.arange(T) >= start) &
+                                                       (np.arange(T) <= stop)).astype(np.uint8) << 1)
+  ranks = [0, 7, 15, 307, 599, 606, 613, 614]
+  scale, shift = 2.5, -1.25
+  got = sess.summarize(scale, shift, obs, flags, ranks)
+  sess.close()
+  value = traj.astype(np.float64) * scale + shift                 # [N, T]
+  np.testing.assert_array_equal(got["value_order"], np.sort(value, axis=0)[ranks])
+  point = -(value - obs[None, :])
+  base = np.where((np.arange(T) < start)[None, :], 0.0, point)
+  holes = np.isnan(base)
+  cum = np.cumsum(np.where(holes, 0.0, base), axis=1)
+  cum[holes] = np.nan
+  np.testing.assert_array_equal(got["cum_order"], np.sort(cum, axis=0)[ranks])
+  win = (flags & 2) != 0
+  np.testing.assert_array_equal(got["per_draw"][0], value.T[win].sum(axis=0))
+  np.testing.assert_array_equal(got["per_draw"][1], np.nansum(point.T[win], axis=0))
+
+
+def test_summarize_argument_errors():
+  T = 50
+  y, mask, X, _ = syn.make_sampler_inputs(T, 0, 1)
+  spec = orc.default_spec(y, mask, X)
+  pb = _native.make_problem(T=T, P=0, has_slope=0, num_warmup=2, num_results=8, num_chains=1)
+  sess = _native.Session(pb, y[None], mask[None], None, None, _native.make_params([spec]))
+  with pytest.raises(_native.NativeError, match="finished ci_session_run"):
+    sess.summarize(1.0, 0.0, np.zeros(T), np.zeros(T, np.uint8), [0])
+  sess.run()
+  with pytest.raises(_native.NativeError, match="out of range"):
+    sess.summarize(1.0, 0.0, np.zeros(T), np.zeros(T, np.uint8), [8])
+  sess.close()

@@ -76,6 +76,8 @@ def load():
   L.ci_session_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
   L.ci_session_destroy.argtypes = [C.c_void_p]
   L.ci_session_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+  L.ci_session_summarize.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_kalman_loglik.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
   L.ci_ll_session_create.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
@@ -101,6 +103,7 @@ def exported_symbols() -> Sequence[str]:
   return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_fit_gibbs",
           "ci_session_create", "ci_session_run", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_session_profile",
+          "ci_session_summarize",
           "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_eval",
           "ci_ll_session_draw_latents", "ci_ll_session_destroy", "ci_test_rng",
           "ci_test_dk_draw")
@@ -232,6 +235,21 @@ class Session:
     cyc = np.zeros(32, np.int64)
     _check(self._lib.ci_session_profile(self._h, int(enable), cyc.ctypes.data))
     return cyc
+
+  def summarize(self, scale: float, shift: float, observed, flags, ranks) -> Dict[str, np.ndarray]:
+    """On-device order statistics / running effect sums of the pooled predictive draws
+    (ci_session_summarize).  Returns value_order [R,T], cum_order [R,T], per_draw [2,N]."""
+    T, N = self.pb.T, self.pb.num_chains * self.pb.num_results
+    obs = np.ascontiguousarray(observed, dtype=np.float64).reshape(T)
+    fl = np.ascontiguousarray(flags, dtype=np.uint8).reshape(T)
+    rk = np.ascontiguousarray(ranks, dtype=np.int32)
+    vo = np.empty((rk.size, T), np.float64)
+    co = np.empty((rk.size, T), np.float64)
+    pd_ = np.empty((2, N), np.float64)
+    _check(self._lib.ci_session_summarize(self._h, float(scale), float(shift), obs.ctypes.data,
+                                          fl.ctypes.data, int(rk.size), rk.ctypes.data,
+                                          vo.ctypes.data, co.ctypes.data, pd_.ctypes.data))
+    return dict(value_order=vo, cum_order=co, per_draw=pd_)
 
   def close(self):
     if self._h:

@@ -100,6 +100,10 @@ class InferenceOptions:
   num_chains: int = 1
   devices: Optional[Sequence[int]] = None
   sampler: str = "gibbs"          # "gibbs" (the reference's sampler) or "hmc" (extension, _hmc.py)
+  # Quantiles / effect sums of the T x (chains * draws) predictive draws computed on the GPU that
+  # holds them (csrc/ci_summary.h) instead of pandas on the host.  Single-device Gibbs fits only;
+  # `False` keeps the reference's host arithmetic (and downloads the trajectories).
+  summarize_on_device: bool = True
 
   def __post_init__(self):
     if self.num_warmup_steps is None:
@@ -132,16 +136,26 @@ def fit_causalimpact(data: pd.DataFrame,
       data=data, pre_period=pre_period, post_period=post_period,
       outcome_column=data_options.outcome_column,
       standardize_data=data_options.standardize_data, dtype=data_options.dtype)
-  samples, posterior_means, posterior_trajectories = _train_causalimpact_sts(
+  if not 0 < alpha < 1:
+    raise ValueError("`alpha` must be between 0 and 1.")
+  on_one_device = (inference_options.sampler == "gibbs" and
+                   len(inference_options.devices or [0]) == 1 and
+                   inference_options.summarize_on_device)
+  request = _device_summary_request(ci_data, alpha) if on_one_device else None
+  samples, posterior_means, posterior_trajectories, device_summary = _run_sampler(
       ci_data=ci_data, prior_level_sd=model_options.prior_level_sd, seed=seed,
       num_results=inference_options.num_results,
       num_warmup_steps=inference_options.num_warmup_steps, dtype=data_options.dtype,
       seasons=model_options.seasons, num_chains=inference_options.num_chains,
       devices=inference_options.devices, local_linear_trend=model_options.local_linear_trend,
-      sampler=inference_options.sampler)
-  series, summary = _compute_impact(posterior_means=posterior_means,
-                                    posterior_trajectories=posterior_trajectories,
-                                    ci_data=ci_data, alpha=alpha)
+      sampler=inference_options.sampler, summary_request=request)
+  if device_summary is not None:
+    series, summary = _compute_impact_device(posterior_means, device_summary, request, ci_data,
+                                             alpha)
+  else:
+    series, summary = _compute_impact(posterior_means=posterior_means,
+                                      posterior_trajectories=posterior_trajectories,
+                                      ci_data=ci_data, alpha=alpha)
   has_weights = samples["weights"].shape[-1] > 0
   has_seasons = samples["seasonal_drift_scales"].shape[-1] > 0
   posterior = CausalImpactPosteriorSamples(
@@ -204,6 +218,18 @@ def _train_causalimpact_sts(*,
   spread over `devices`, so results are invariant to the device count.
   """
   del experimental_tf_function_cache_key_addition
+  return _run_sampler(ci_data=ci_data, prior_level_sd=prior_level_sd, seed=seed,
+                      num_results=num_results, num_warmup_steps=num_warmup_steps, model=model,
+                      dtype=dtype, seasons=seasons, num_chains=num_chains, devices=devices,
+                      local_linear_trend=local_linear_trend, sampler=sampler)[:3]
+
+
+def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps, model=None,
+                 dtype=np.float32, seasons=(), num_chains=1, devices=None,
+                 local_linear_trend=False, sampler="gibbs", summary_request=None):
+  """_train_causalimpact_sts plus, when `summary_request` is given (single device, Gibbs), the
+  on-device summary of the predictive draws; the [draws, T] trajectories then stay in HBM and
+  are returned as None."""
   if model is not None:
     raise NotImplementedError("custom tfp.sts models are not supported by the HIP path")
   seed_pair = _sanitize_seed(seed)
@@ -233,6 +259,7 @@ def _train_causalimpact_sts(*,
   devs = list(devices) if devices else [0]
   shares = np.array_split(np.arange(num_chains), len(devs))
   parts = []
+  device_summary = None
   for dev, chain_ids in zip(devs, shares):
     if len(chain_ids) == 0:
       continue
@@ -248,6 +275,23 @@ def _train_causalimpact_sts(*,
                               num_warmup=num_warmup_steps, num_results=num_results,
                               num_chains=len(chain_ids), chain_offset=int(chain_ids[0]),
                               seed=seed_pair, device=dev)
+    if summary_request is not None and len(devs) == 1:
+      sess = _native.Session(pb, y[None], mask[None], None if design is None else design[None],
+                             season_change, _native.make_params([params]))
+      try:
+        sess.run()
+        parts.append(sess.fetch([k for k in _native._OUT_FIELDS  # pylint: disable=protected-access
+                                 if k != "posterior_trajectories"]))
+        qs = _quantile_ranks(len(chain_ids) * num_results, summary_request["quantiles"])
+        n_draws = len(chain_ids) * num_results
+        want = sorted({r for lo, hi, _ in qs for r in (lo, hi)} |
+                      {n_draws - 1 - r for lo, hi, _ in qs for r in (lo, hi)})
+        summary_request["ranks"] = want
+        device_summary = sess.summarize(
+            **{k: summary_request[k] for k in ("scale", "shift", "observed", "flags", "ranks")})
+      finally:
+        sess.close()
+      continue
     parts.append(_native.fit_gibbs(pb, y[None], mask[None],
                                    None if design is None else design[None], season_change,
                                    _native.make_params([params])))
@@ -268,8 +312,9 @@ def _train_causalimpact_sts(*,
         "split_rhat": {k: split_rhat(out[k]) for k in ("observation_noise_scale", "level_scale")},
         "num_chains": num_chains}
   posterior_means = out["posterior_means"].mean(axis=0).astype(np_dtype, copy=False)      # :627
-  posterior_trajectories = pool(out["posterior_trajectories"])                            # :631
-  return samples, posterior_means, posterior_trajectories
+  posterior_trajectories = (pool(out["posterior_trajectories"])                           # :631
+                            if "posterior_trajectories" in out else None)
+  return samples, posterior_means, posterior_trajectories, device_summary
 
 
 # --------------------------------------------------------------------------------------
@@ -299,6 +344,107 @@ def _compute_impact(posterior_means, posterior_trajectories, ci_data: cid.Causal
   summary = _compute_summary(posterior_trajectory_summary=trajectory_summary,
                              trajectory_dict=trajectory_dict, observed_ts_post=observed_post,
                              post_period=ci_data.post_period, quantiles=quantiles, alpha=alpha)
+  return series, summary
+
+
+def _observed_series(ci_data: cid.CausalImpactData):
+  observed_pre = ci_data.pre_data[ci_data.outcome_column]
+  observed_post = ci_data.after_pre_data[ci_data.outcome_column]
+  in_post = (observed_post.index >= ci_data.post_period[0]) & (observed_post.index <=
+                                                              ci_data.post_period[1])
+  observed_post = observed_post.loc[in_post]
+  return observed_post, pd.concat([observed_pre, observed_post], axis=0)
+
+
+def _quantile_ranks(num_draws: int, quantiles):
+  """numpy's 'linear' quantile of n values: lerp(x_(lo), x_(lo+1), gamma) -- the order
+  statistics it needs and the interpolation weight (numpy/lib/_function_base_impl.py
+  _quantile: virtual index q (n - 1), previous = floor, next = previous + 1 clipped)."""
+  out = []
+  for q in quantiles:
+    virtual = (num_draws - 1) * np.float64(q)
+    lo = int(np.floor(virtual))
+    if lo >= num_draws - 1:
+      lo, hi, gamma = num_draws - 1, num_draws - 1, np.float64(0.0)
+    else:
+      hi, gamma = lo + 1, virtual - lo
+    out.append((lo, hi, gamma))
+  return out
+
+
+def _device_summary_request(ci_data: cid.CausalImpactData, alpha: float) -> Dict:
+  """Arguments of ci_session_summarize for this analysis (see include/causalimpact_amd.h)."""
+  _, observed_full = _observed_series(ci_data)
+  idx = posterior_processing.model_index(ci_data)
+  obs = observed_full.reindex(idx).to_numpy(dtype=np.float64)
+  after_start = ~np.asarray(idx < ci_data.post_period[0])
+  window = np.asarray((idx >= ci_data.post_period[0]) & (idx <= ci_data.post_period[1]))
+  if ci_data.standardize_data:
+    scale = float(np.ravel(ci_data.outcome_scaler.stddev_)[0])
+    shift = float(np.ravel(ci_data.outcome_scaler.mean_)[0])
+  else:
+    scale, shift = 1.0, 0.0
+  return dict(scale=scale, shift=shift, observed=obs,
+              flags=after_start.astype(np.uint8) | (window.astype(np.uint8) << 1),
+              quantiles=(alpha / 2.0, 1.0 - alpha / 2.0),
+              ranks=None)   # filled in by _run_sampler once the number of draws is known
+
+
+def _lerp_order_stats(order: Dict[int, np.ndarray], lo: int, hi: int, gamma) -> np.ndarray:
+  """numpy's own interpolation of two order statistics (so results match np.quantile bit for
+  bit): the quantile of the 2-point sample {x_(lo), x_(hi)} at `gamma` is lerp(x_lo, x_hi, gamma)."""
+  pair = np.stack([order[lo], order[hi]])
+  with np.errstate(invalid="ignore"):
+    return np.quantile(pair, gamma, axis=0)
+
+
+def _compute_impact_device(posterior_means, device_summary: Dict, request: Dict,
+                           ci_data: cid.CausalImpactData, alpha: float):
+  """(series, summary) from the on-device summary (csrc/ci_summary.h) -- same frames as
+  _compute_impact, which stays the host reference of this arithmetic."""
+  quantiles = (alpha / 2.0, 1.0 - alpha / 2.0)
+  observed_post, observed_full = _observed_series(ci_data)
+  idx = posterior_processing.model_index(ci_data)
+  obs = request["observed"]
+  ranks = list(request["ranks"])
+  num_draws = device_summary["per_draw"].shape[1]
+  value_order = {r: device_summary["value_order"][i] for i, r in enumerate(ranks)}
+  cum_order = {r: device_summary["cum_order"][i] for i, r in enumerate(ranks)}
+  (lo_a, hi_a, g_a), (lo_b, hi_b, g_b) = _quantile_ranks(num_draws, quantiles)
+
+  def frame(prefix, lower, upper):
+    return pd.DataFrame({prefix + "_lower": lower, prefix + "_upper": upper}, index=idx)
+
+  means = posterior_processing.process_posterior_quantities(ci_data, posterior_means,
+                                                            ["posterior_mean"])
+  trajectory_summary = means.join(frame("posterior",
+                                        _lerp_order_stats(value_order, lo_a, hi_a, g_a),
+                                        _lerp_order_stats(value_order, lo_b, hi_b, g_b)))
+  # point effect = -(value - observed) is decreasing in the value: its k-th smallest is the
+  # (N-1-k)-th smallest value, mapped
+  mirrored = {k: -(value_order[num_draws - 1 - k] - obs) for k in {lo_a, hi_a, lo_b, hi_b}}
+  bands = {
+      "point_effects": frame("point_effects", _lerp_order_stats(mirrored, lo_a, hi_a, g_a),
+                             _lerp_order_stats(mirrored, lo_b, hi_b, g_b)),
+      "cumulative_effects": frame("cumulative_effects",
+                                  _lerp_order_stats(cum_order, lo_a, hi_a, g_a),
+                                  _lerp_order_stats(cum_order, lo_b, hi_b, g_b)),
+  }
+  series = _compute_impact_estimates(posterior_trajectory_summary=trajectory_summary,
+                                     trajectory_dict=None, observed_ts_full=observed_full,
+                                     ci_data=ci_data, quantiles=quantiles, bands=bands)
+  window = (request["flags"] & 2) != 0
+  n_obs_window = int(np.sum(~np.isnan(obs[window])))
+  pred_sum, point_sum = device_summary["per_draw"]
+  with np.errstate(invalid="ignore", divide="ignore"):
+    per_draw = dict(pred_mean=pred_sum / int(window.sum()), pred_sum=pred_sum,
+                    point_mean_t=point_sum / n_obs_window if n_obs_window else
+                    np.full_like(point_sum, np.nan),
+                    point_sum_t=point_sum)
+  summary = _compute_summary(posterior_trajectory_summary=trajectory_summary,
+                             trajectory_dict=None, observed_ts_post=observed_post,
+                             post_period=ci_data.post_period, quantiles=quantiles, alpha=alpha,
+                             per_draw=per_draw)
   return series, summary
 
 
@@ -347,8 +493,14 @@ def _compute_impact_trajectories(posterior_trajectories: pd.DataFrame,
 def _compute_impact_estimates(posterior_trajectory_summary: pd.DataFrame,
                               trajectory_dict: Dict[str, pd.DataFrame],
                               observed_ts_full: pd.Series, ci_data: cid.CausalImpactData,
-                              quantiles: Tuple[float, float]) -> pd.DataFrame:
-  """The 14-column `series` frame over the full input index (reference :840-931)."""
+                              quantiles: Tuple[float, float],
+                              bands: Optional[Dict[str, pd.DataFrame]] = None) -> pd.DataFrame:
+  """The 14-column `series` frame over the full input index (reference :840-931).  `bands`:
+  precomputed quantile frames of the effect trajectories (on-device summary)."""
+  if bands is None:
+    bands = {k: posterior_processing.calculate_trajectory_quantiles(trajectory_dict[k], k,
+                                                                    quantiles)
+             for k in ("point_effects", "cumulative_effects")}
   idx = posterior_trajectory_summary.index
   obs = observed_ts_full.reindex(idx)
   point_mean = obs - posterior_trajectory_summary["posterior_mean"]
@@ -357,11 +509,9 @@ def _compute_impact_estimates(posterior_trajectory_summary: pd.DataFrame,
   frame = pd.concat([
       obs.rename("observed"), posterior_trajectory_summary,
       point_mean.rename("point_effects_mean"),
-      posterior_processing.calculate_trajectory_quantiles(trajectory_dict["point_effects"],
-                                                          "point_effects", quantiles),
+      bands["point_effects"],
       cum_mean.rename("cumulative_effects_mean"),
-      posterior_processing.calculate_trajectory_quantiles(trajectory_dict["cumulative_effects"],
-                                                          "cumulative_effects", quantiles),
+      bands["cumulative_effects"],
   ], axis=1)
   effect_cols = frame.columns.difference(_KEPT_AFTER_POST)
   # between pre- and post-period, and after the post-period: predictions only (:899-907)
@@ -382,16 +532,15 @@ def _compute_impact_estimates(posterior_trajectory_summary: pd.DataFrame,
 def _compute_summary(posterior_trajectory_summary: pd.DataFrame,
                      trajectory_dict: Dict[str, pd.DataFrame], observed_ts_post: pd.Series,
                      post_period: OutputPeriodType, quantiles: Tuple[float, float],
-                     alpha: float) -> pd.DataFrame:
-  """The 2 x 15 `summary` frame over the post-period (reference :934-1093)."""
+                     alpha: float, per_draw: Optional[Dict[str, np.ndarray]] = None) -> pd.DataFrame:
+  """The 2 x 15 `summary` frame over the post-period (reference :934-1093).  `per_draw`:
+  precomputed per-draw window means / totals (on-device summary)."""
 
   def window(frame):
     keep = (frame.index >= post_period[0]) & (frame.index <= post_period[1])
     return frame.loc[keep]
 
   post_mean = window(posterior_trajectory_summary)["posterior_mean"].to_numpy(dtype=np.float64)
-  pred = window(trajectory_dict["predictions"]).to_numpy(dtype=np.float64)        # [T_post, draws]
-  point = window(trajectory_dict["point_effects"]).to_numpy(dtype=np.float64)
   obs = observed_ts_post.to_numpy(dtype=np.float64)
   obs_mean, obs_sum = float(np.nanmean(obs)), float(np.nansum(obs))
 
@@ -402,9 +551,15 @@ def _compute_summary(posterior_trajectory_summary: pd.DataFrame,
     lo, hi = np.quantile(v, quantiles)
     return float(lo), float(hi)
 
-  pred_mean, pred_sum = pred.mean(axis=0), pred.sum(axis=0)
-  with np.errstate(invalid="ignore"):
-    point_mean_t, point_sum_t = np.nanmean(point, axis=0), np.nansum(point, axis=0)
+  if per_draw is None:
+    pred = window(trajectory_dict["predictions"]).to_numpy(dtype=np.float64)      # [T_post, draws]
+    point = window(trajectory_dict["point_effects"]).to_numpy(dtype=np.float64)
+    pred_mean, pred_sum = pred.mean(axis=0), pred.sum(axis=0)
+    with np.errstate(invalid="ignore"):
+      point_mean_t, point_sum_t = np.nanmean(point, axis=0), np.nansum(point, axis=0)
+  else:
+    pred_mean, pred_sum = per_draw["pred_mean"], per_draw["pred_sum"]
+    point_mean_t, point_sum_t = per_draw["point_mean_t"], per_draw["point_sum_t"]
   rel = obs_sum / pred_sum - 1.0
   avg_pred, cum_pred = float(post_mean.mean()), float(post_mean.sum())
   rows = {

@@ -1,0 +1,139 @@
+// ci_summary.h -- on-device summarisation of the pooled posterior-predictive draws
+// (reference: causalimpact_lib.py:793-837 point / cumulative effect
+// trajectories, posterior_processing.py:25-60 per-timestep quantiles, :966-1017 per-draw
+// post-period totals).  Once the sampler takes ~20 ms, numpy's T x (C*S) quantiles (250 ms at
+// cfg2) are the wall time of fit_causalimpact; these kernels are HBM-bound streaming passes.
+//
+// Arithmetic is float64 and ordered exactly like the numpy code it replaces (separately rounded
+// multiply/add for the scaler, sequential running sums over time), and quantiles come back as
+// ORDER STATISTICS (the host applies numpy's own interpolation), so the device path reproduces
+// the host frames to round-off, not to "float32 tolerance".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ci {
+
+constexpr int SUMM_MAX_RANKS = 8;
+
+// [N, T] float32 draws (model scale) -> [T, N] float64 on the data scale:
+// standardize.py:60-64 `values * stddev + mean` (two roundings, no FMA).
+// grid (ceil(T/64), ceil(N/64)), block (64, 4).
+__global__ __launch_bounds__(256) void summ_transpose_kernel(int N, int T,
+                                                             const float* __restrict__ traj,
+                                                             double scale, double shift,
+                                                             double* __restrict__ predT) {
+  __shared__ double tile[64][65];
+  const int t0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + ty + 4 * i, t = t0 + tx;
+    if (n < N && t < T)
+      tile[ty + 4 * i][tx] = __dadd_rn(__dmul_rn((double)traj[(size_t)n * T + t], scale), shift);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = t0 + ty + 4 * i, n = n0 + tx;
+    if (n < N && t < T) predT[(size_t)t * N + n] = tile[tx][ty + 4 * i];
+  }
+}
+
+// One thread per draw, sequential over time (coalesced over draws):
+//   point = -(pred - obs)                      (:822)   NaN where there is no observation
+//   cum_t = running sum of point from the treatment start, NaN steps skipped but reported NaN
+//   pred_sum / point_sum over the post-period window (:985-1017; nansum for the effects).
+// flags[t]: bit 0 = t >= treatment start, bit 1 = inside the post-period window.
+__global__ __launch_bounds__(256) void summ_cumsum_kernel(int N, int T,
+                                                          const double* __restrict__ predT,
+                                                          const double* __restrict__ obs,
+                                                          const uint8_t* __restrict__ flags,
+                                                          double* __restrict__ cumT,
+                                                          double* __restrict__ per_draw) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double c = 0.0, pred_sum = 0.0, point_sum = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const double p = predT[(size_t)t * N + n];
+    const double point = -__dsub_rn(p, obs[t]);
+    const unsigned f = flags[t];
+    const double base = (f & 1u) ? point : 0.0;
+    const bool hole = base != base;
+    c = __dadd_rn(c, hole ? 0.0 : base);
+    cumT[(size_t)t * N + n] = hole ? base : c;
+    if (f & 2u) {
+      pred_sum = __dadd_rn(pred_sum, p);
+      point_sum = __dadd_rn(point_sum, (point != point) ? 0.0 : point);
+    }
+  }
+  per_draw[n] = pred_sum;
+  per_draw[(size_t)N + n] = point_sum;
+}
+
+__device__ __forceinline__ unsigned long long summ_key(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double summ_unkey(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+// Order statistics of every row of M [rows, N] (float64): out[r, row] = ranks[r]-th smallest.
+// One 256-thread workgroup per row; most-significant-digit radix select, 8 passes of 8 bits, all
+// R ranks carried through the same sweeps of the row (which stays in L2: N * 8 bytes).
+__global__ __launch_bounds__(256) void summ_select_kernel(int N, int rows, int R,
+                                                          const int* __restrict__ ranks,
+                                                          const double* __restrict__ M,
+                                                          double* __restrict__ out) {
+  __shared__ unsigned hist[SUMM_MAX_RANKS][256];
+  __shared__ unsigned long long prefix[SUMM_MAX_RANKS];
+  __shared__ unsigned krem[SUMM_MAX_RANKS];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* x = M + (size_t)row * N;
+  if (tid < R) { prefix[tid] = 0ull; krem[tid] = (unsigned)ranks[tid]; }
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    const unsigned long long mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    for (int e = tid; e < R * 256; e += 256) (&hist[0][0])[e] = 0u;
+    __syncthreads();
+    unsigned long long pf[SUMM_MAX_RANKS];
+#pragma unroll
+    for (int r = 0; r < SUMM_MAX_RANKS; ++r) pf[r] = r < R ? prefix[r] : ~0ull;
+    for (int i = tid; i < N; i += 256) {
+      const unsigned long long key = summ_key(x[i]);
+      const unsigned bin = (unsigned)(key >> shift) & 255u;
+      const unsigned long long hi = key & mask;
+#pragma unroll
+      for (int r = 0; r < SUMM_MAX_RANKS; ++r)
+        if (r < R && hi == pf[r]) atomicAdd(&hist[r][bin], 1u);
+    }
+    __syncthreads();
+    // wave w resolves ranks w, w+4: lane l owns bins 4l..4l+3
+    for (int r = wave; r < R; r += 4) {
+      const unsigned h0 = hist[r][4 * lane], h1 = hist[r][4 * lane + 1], h2 = hist[r][4 * lane + 2],
+                     h3 = hist[r][4 * lane + 3];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      const unsigned excl = incl - mine, k = krem[r];
+      if (k >= excl && k < incl) {
+        unsigned before = excl, bin = 4 * lane;
+        if (k >= before + h0) { before += h0; ++bin;
+          if (k >= before + h1) { before += h1; ++bin;
+            if (k >= before + h2) { before += h2; ++bin; } } }
+        prefix[r] |= (unsigned long long)bin << shift;
+        krem[r] = k - before;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < R) out[(size_t)tid * rows + row] = summ_unkey(prefix[tid]);
+}
+
+}  // namespace ci

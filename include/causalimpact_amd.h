@@ -121,22 +121,23 @@ int ci_session_algorithmic_bytes(const ci_session* session, double* bytes);
 int ci_session_profile(ci_session* session, int enable, int64_t* cycles16);
 int ci_session_destroy(ci_session* session);
 
-/* On-device summarisation of the pooled posterior-predictive draws of a finished run
- * (num_series must be 1): replaces the T x (C*S) pandas/numpy work of _compute_impact
+/* On-device summarisation of the pooled posterior-predictive draws of a finished run, for all
+ * B series of the session at once: replaces the T x (C*S) pandas/numpy work of _compute_impact
  * (causalimpact_lib.py:793-837 effect trajectories, posterior_processing.py:25-60 quantiles,
  * :966-1017 per-draw post-period totals).  All results are float64 on the data scale:
- *   value[n, t]  = trajectory[n, t] * scale + shift            (standardize.py:60-64)
- *   point[n, t]  = -(value[n, t] - observed[t])                 NaN where observed[t] is NaN
- *   cum[n, t]    = running sum of point from the treatment start (NaN steps skipped, reported NaN)
- * observed [T] data-scale outcome, NaN = no observation; flags [T]: bit 0 = t >= treatment
- * start, bit 1 = inside the post-period window.  ranks: num_ranks (<= 8) 0-based order
- * statistics over the N = C*S draws (the caller interpolates quantiles from them exactly as
- * numpy does).  Outputs (host, caller-allocated, any may be NULL):
- *   value_order [num_ranks, T], cum_order [num_ranks, T],
- *   per_draw [2, N]: sum over the window of value, and of point (NaN skipped). */
-int ci_session_summarize(ci_session* session, double scale, double shift, const double* observed,
-                         const uint8_t* flags, int32_t num_ranks, const int32_t* ranks,
-                         double* value_order, double* cum_order, double* per_draw);
+ *   value[b, n, t] = trajectory[b, n, t] * scale[b] + shift[b]   (standardize.py:60-64)
+ *   point[b, n, t] = -(value[b, n, t] - observed[b, t])           NaN where observed is NaN
+ *   cum[b, n, t]   = running sum of point from the treatment start (NaN steps skipped, reported NaN)
+ * scale, shift [B]; observed [B,T] data-scale outcome, NaN = no observation; flags [B,T]: bit 0
+ * = t >= treatment start, bit 1 = inside the post-period window.  ranks: num_ranks (<= 8)
+ * 0-based order statistics over the N = C*S draws of a series (the caller interpolates
+ * quantiles from them exactly as numpy does).  Outputs (host, caller-allocated, any may be NULL):
+ *   value_order [B, num_ranks, T], cum_order [B, num_ranks, T],
+ *   per_draw [B, 2, N]: sum over the window of value, and of point (NaN skipped). */
+int ci_session_summarize(ci_session* session, const double* scale, const double* shift,
+                         const double* observed, const uint8_t* flags, int32_t num_ranks,
+                         const int32_t* ranks, double* value_order, double* cum_order,
+                         double* per_draw);
 
 /* Kalman-filter log-likelihood of the trend + regression model for num_evals parameter sets
  * (the objective an HMC / VI fit would use; the reference never

@@ -1,0 +1,96 @@
+"""Batched API: vectorised data preparation == per-series CausalImpactData
+(CPU); a batch launch == B separate fit_causalimpact calls (GPU)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import causalimpact as ci
+from causalimpact import batch
+from causalimpact import data as cid
+from causalimpact import _synthetic as syn
+
+
+def _frames(B, T, p, seed=0, dates=True):
+  idx = pd.date_range("2021-01-04", periods=T, freq="D") if dates else pd.RangeIndex(T)
+  out = []
+  for b in range(B):
+    y, X = syn.make_raw_series(T, p, seed + b, effect=5.0 + b)
+    df = pd.DataFrame(np.column_stack([y, X]), index=idx,
+                      columns=["y"] + [f"x{j}" for j in range(p)])
+    out.append(df)
+  out[1].iloc[[3, 17], 0] = np.nan          # missing pre-period outcomes
+  if p:
+    out[2].iloc[:, 1] = 7.0                 # constant covariate: left unscaled
+  return out
+
+
+@pytest.mark.parametrize("standardize", [True, False])
+def test_prepare_batch_equals_causal_impact_data(standardize):
+  T, p = 90, 2
+  frames = _frames(4, T, p)
+  idx = frames[0].index
+  pre, post = (idx[5], idx[59]), (idx[63], idx[84])       # rows before the pre-period, a gap, a tail
+  values = np.stack([f.to_numpy(float) for f in frames])
+  prep = batch.prepare_batch(values, idx, pre, post, standardize)
+  for b, f in enumerate(frames):
+    one = cid.CausalImpactData(f, pre, post, standardize_data=standardize, dtype=np.float64)
+    n_pre = len(one.outcome_ts.time_series)
+    assert prep.num_pre == n_pre and prep.y.shape[1] == n_pre + one.num_steps_forecast
+    np.testing.assert_allclose(prep.y[b, :n_pre], one.outcome_ts.time_series, rtol=1e-12,
+                               equal_nan=True)
+    assert prep.mask[b, n_pre:].all() and np.isnan(prep.y[b, n_pre:]).all()
+    np.testing.assert_array_equal(prep.mask[b, :n_pre], one.outcome_ts.is_missing)
+    np.testing.assert_allclose(prep.design[b], one.feature_ts.values, rtol=1e-12)
+    if standardize:
+      np.testing.assert_allclose(prep.outcome_mean[b], one.outcome_scaler.mean_, rtol=1e-13)
+      np.testing.assert_allclose(prep.outcome_sd[b], one.outcome_scaler.stddev_, rtol=1e-13)
+  assert list(idx[prep.model_rows]) == list(idx[5:])
+
+
+def test_prepare_batch_rejects_what_the_reference_rejects():
+  T = 40
+  v = np.random.default_rng(0).normal(size=(2, T, 2))
+  idx = pd.RangeIndex(T)
+  bad = v.copy(); bad[1, :, 0] = 3.0
+  with pytest.raises(ValueError, match="cannot be constant"):
+    batch.prepare_batch(bad, idx, (0, 19), (20, 39))
+  bad = v.copy(); bad[0, 4, 1] = np.nan
+  with pytest.raises(ValueError, match="cannot have any missing values"):
+    batch.prepare_batch(bad, idx, (0, 19), (20, 39))
+  with pytest.raises(ValueError):
+    batch.prepare_batch(v, idx, (0, 25), (20, 39))           # overlapping periods
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,dates", [(2, True), (0, False)])
+def test_batch_fit_equals_separate_fits(p, dates):
+  T, B = 100, 5
+  frames = _frames(B, T, p, dates=dates)
+  idx = frames[0].index
+  pre, post = (idx[0], idx[69]), (idx[72], idx[95])
+  opts = ci.InferenceOptions(num_results=150, num_chains=2)
+  got = ci.fit_causalimpact_batch(frames, pre, post, alpha=0.1, seed=5, inference_options=opts,
+                                  names=[f"geo{b}" for b in range(B)])
+  assert len(got) == B and got.summary.shape == (2 * B, 15)
+  for b, f in enumerate(frames):
+    one = ci.fit_causalimpact(f, pre, post, alpha=0.1, seed=5, inference_options=opts)
+    np.testing.assert_allclose(got.summary.loc[f"geo{b}"].to_numpy(float),
+                               one.summary.to_numpy(float), rtol=2e-5, atol=1e-7)
+    mine = got[b]
+    assert list(mine.series.columns) == list(one.series.columns)
+    num = [c for c in one.series.columns if one.series[c].dtype.kind == "f"]
+    np.testing.assert_allclose(mine.series[num].to_numpy(float), one.series[num].to_numpy(float),
+                               rtol=2e-5, atol=1e-6, equal_nan=True)
+    assert ci.summary(mine) == ci.summary(one)
+  assert set(got.diagnostics) == {"split_rhat", "ess_bulk"}
+
+
+@pytest.mark.gpu
+def test_batch_accepts_an_array():
+  T, B = 80, 3
+  v = np.stack([f.to_numpy(float) for f in _frames(B, T, 1, seed=9)])
+  got = ci.fit_causalimpact_batch(v, (0, 55), (56, 79), seed=1,
+                                  inference_options=ci.InferenceOptions(num_results=50))
+  assert got.summary.index.get_level_values(0).unique().tolist() == [0, 1, 2]
+  assert np.isfinite(got.summary["abs_effect"].to_numpy()).all()
+  assert got.diagnostics is None

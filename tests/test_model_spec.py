@@ -41,3 +41,21 @@ def test_season_calendar_shapes():
   np.testing.assert_array_equal(f[8:], f[:8])
   with pytest.raises(ValueError):
     _model.season_change_flags(10, 3, (1, 2))
+
+
+def test_effective_sample_size_on_known_processes():
+  from causalimpact import causalimpact_lib as lib
+  rng = np.random.default_rng(0)
+  iid = rng.normal(size=(4, 2000))
+  assert 0.8 * 8000 < lib.effective_sample_size(iid) < 1.25 * 8000
+  phi = 0.9
+  ar = np.zeros((4, 4000))
+  e = rng.normal(size=ar.shape)
+  for t in range(1, ar.shape[1]):
+    ar[:, t] = phi * ar[:, t - 1] + e[:, t]
+  want = ar.size * (1 - phi) / (1 + phi)
+  assert 0.6 * want < lib.effective_sample_size(ar) < 1.6 * want
+  assert np.isnan(lib.effective_sample_size(np.zeros((2, 6))))
+  # chains stuck at different levels: R-hat large, ESS tiny
+  stuck = rng.normal(size=(4, 500)) * 0.01 + np.arange(4)[:, None]
+  assert lib.effective_sample_size(stuck) < 20 and lib.split_rhat(stuck) > 5

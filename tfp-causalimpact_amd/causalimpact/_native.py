@@ -76,7 +76,7 @@ def load():
   L.ci_session_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
   L.ci_session_destroy.argtypes = [C.c_void_p]
   L.ci_session_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-  L.ci_session_summarize.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+  L.ci_session_summarize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_kalman_loglik.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -236,19 +236,25 @@ class Session:
     _check(self._lib.ci_session_profile(self._h, int(enable), cyc.ctypes.data))
     return cyc
 
-  def summarize(self, scale: float, shift: float, observed, flags, ranks) -> Dict[str, np.ndarray]:
-    """On-device order statistics / running effect sums of the pooled predictive draws
-    (ci_session_summarize).  Returns value_order [R,T], cum_order [R,T], per_draw [2,N]."""
-    T, N = self.pb.T, self.pb.num_chains * self.pb.num_results
-    obs = np.ascontiguousarray(observed, dtype=np.float64).reshape(T)
-    fl = np.ascontiguousarray(flags, dtype=np.uint8).reshape(T)
+  def summarize(self, scale, shift, observed, flags, ranks) -> Dict[str, np.ndarray]:
+    """On-device order statistics / running effect sums of the pooled predictive draws of every
+    series (ci_session_summarize).  scale, shift: scalars or [B]; observed, flags: [T] or [B,T].
+    Returns value_order [B,R,T], cum_order [B,R,T], per_draw [B,2,N] (leading axis dropped when
+    the session holds one series)."""
+    B, T, N = self.pb.num_series, self.pb.T, self.pb.num_chains * self.pb.num_results
+    sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, np.float64), (B,)))
+    sh = np.ascontiguousarray(np.broadcast_to(np.asarray(shift, np.float64), (B,)))
+    obs = np.ascontiguousarray(np.broadcast_to(np.asarray(observed, np.float64), (B, T)))
+    fl = np.ascontiguousarray(np.broadcast_to(np.asarray(flags, np.uint8), (B, T)))
     rk = np.ascontiguousarray(ranks, dtype=np.int32)
-    vo = np.empty((rk.size, T), np.float64)
-    co = np.empty((rk.size, T), np.float64)
-    pd_ = np.empty((2, N), np.float64)
-    _check(self._lib.ci_session_summarize(self._h, float(scale), float(shift), obs.ctypes.data,
+    vo = np.empty((B, rk.size, T), np.float64)
+    co = np.empty((B, rk.size, T), np.float64)
+    pd_ = np.empty((B, 2, N), np.float64)
+    _check(self._lib.ci_session_summarize(self._h, sc.ctypes.data, sh.ctypes.data, obs.ctypes.data,
                                           fl.ctypes.data, int(rk.size), rk.ctypes.data,
                                           vo.ctypes.data, co.ctypes.data, pd_.ctypes.data))
+    if B == 1:
+      vo, co, pd_ = vo[0], co[0], pd_[0]
     return dict(value_order=vo, cum_order=co, per_draw=pd_)
 
   def close(self):

@@ -1,0 +1,267 @@
+"""Many independent series in one launch (BASELINE "batch of 512 independent series, T=500,
+5 covariates").
+
+`fit_causalimpact_batch` is the batched form of `fit_causalimpact` for B series that share an
+index and the pre/post periods (the same calendar for many geos / products):
+  * data preparation (data.py:105-137, standardize.py:42-55) is vectorised over series in numpy
+    -- no per-series pandas;
+  * one kernel launch per device runs all B x chains Gibbs fits (one workgroup per
+    (series, chain)); series are sharded over `InferenceOptions.devices`, no collective;
+  * the T x draws post-processing of every series runs on the device that holds the draws
+    (csrc/ci_summary.h); only order statistics and per-draw totals come back;
+  * the (B*2) x 15 summary table is assembled with numpy; a per-series `CausalImpactAnalysis`
+    (14-column `series` frame) is built lazily on indexing.
+Series b of a batch equals `fit_causalimpact` on series b alone with the same seed (same random
+streams: they are keyed by chain, not by series).
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import dataclasses
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import pandas as pd
+
+from causalimpact import _model
+from causalimpact import _native
+from causalimpact import causalimpact_lib as lib
+from causalimpact import data as cid
+from causalimpact import indices
+
+
+@dataclasses.dataclass
+class PreparedBatch:
+  """What the sampler consumes for B series (the batched CausalImpactData)."""
+  values: np.ndarray          # [B, T_all, 1+p] raw data
+  index: pd.Index             # [T_all]
+  pre_period: Tuple[Any, Any]
+  post_period: Tuple[Any, Any]
+  standardize_data: bool
+  model_rows: np.ndarray      # positions (into index) of the T steps handed to the sampler
+  num_pre: int
+  y: np.ndarray               # [B, T] standardised outcome, NaN where missing / forecast
+  mask: np.ndarray            # [B, T] bool
+  design: Optional[np.ndarray]   # [B, T, P] standardised covariates + intercept, or None
+  outcome_mean: np.ndarray    # [B] pre-period mean of the outcome (0 if not standardised)
+  outcome_sd: np.ndarray      # [B] pre-period sd (ddof=1)     (1 if not standardised)
+
+
+def prepare_batch(values: np.ndarray, index: pd.Index, pre_period, post_period,
+                  standardize_data: bool = True) -> PreparedBatch:
+  """Vectorised CausalImpactData.__init__ (data.py:77-137) for [B, T_all, 1+p] values whose
+  first column is the outcome."""
+  values = np.asarray(values, dtype=np.float64)
+  if values.ndim != 3:
+    raise ValueError("`values` must be [num_series, num_timesteps, 1 + num_covariates]")
+  B, T_all, ncol = values.shape
+  index = pd.Index(index)
+  if len(index) != T_all:
+    raise ValueError("`index` must have one entry per timestep")
+  probe = pd.DataFrame({"y": np.zeros(T_all)}, index=index)
+  pre, post = indices.parse_and_validate_date_data(data=probe, pre_period=pre_period,
+                                                  post_period=post_period)
+  outcome = values[:, :, 0]
+  with np.errstate(invalid="ignore"):
+    if np.any(np.nanstd(outcome, axis=1) == 0):
+      raise ValueError("Input response cannot be constant.")
+  if np.any(np.sum(~np.isnan(outcome), axis=1) < 3):
+    raise ValueError("Input data must have at least 3 observations.")
+  if ncol > 1 and np.isnan(values[:, :, 1:]).any():
+    raise ValueError("Input data cannot have any missing values.")
+  in_pre = np.asarray((index >= pre[0]) & (index <= pre[1]))
+  after = np.asarray(index > pre[1])
+  rows = np.concatenate([np.flatnonzero(in_pre), np.flatnonzero(after)])
+  n_pre = int(in_pre.sum())
+  model = values[:, rows, :]                               # [B, T, 1+p]
+  if standardize_data:
+    with np.errstate(invalid="ignore"):
+      mu = np.nanmean(model[:, :n_pre, :], axis=1)         # [B, 1+p]
+      sd = np.nanstd(model[:, :n_pre, :], axis=1, ddof=1)
+    scaled = np.where((sd > 0)[:, None, :], (model - mu[:, None, :]) /
+                      np.where(sd > 0, sd, 1.0)[:, None, :], model)
+    o_mu, o_sd = mu[:, 0].copy(), sd[:, 0].copy()
+  else:
+    scaled = model
+    o_mu, o_sd = np.zeros(B), np.ones(B)
+  y = scaled[:, :, 0].copy()
+  y[:, n_pre:] = np.nan
+  mask = np.isnan(y)
+  design = None
+  if ncol > 1:
+    design = np.concatenate([scaled[:, :, 1:], np.ones((B, len(rows), 1))], axis=2)
+  return PreparedBatch(values=values, index=index, pre_period=pre, post_period=post,
+                       standardize_data=standardize_data, model_rows=rows, num_pre=n_pre, y=y,
+                       mask=mask, design=design, outcome_mean=o_mu, outcome_sd=o_sd)
+
+
+class CausalImpactBatchAnalysis:
+  """Results for B series.  `summary`: DataFrame indexed by (series, average|cumulative) with the
+  reference's 15 summary columns; `analysis[b]` / iteration: per-series CausalImpactAnalysis
+  (the `series` frame is assembled on first access); `diagnostics`: split-R-hat / ESS per series
+  when more than one chain was run."""
+
+  def __init__(self, prepared, names, alpha, posterior_means, device_summary, ranks, columns,
+               diagnostics):
+    self._prep, self._names, self.alpha = prepared, list(names), alpha
+    self._means, self._dsum, self._ranks, self._columns = posterior_means, device_summary, ranks, columns
+    self.diagnostics = diagnostics
+    self._cache: Dict[int, lib.CausalImpactAnalysis] = {}
+    self.summary = self._build_summary()
+
+  def __len__(self):
+    return len(self._names)
+
+  def _request(self, b: int) -> Dict:
+    p = self._prep
+    idx = p.index[p.model_rows]
+    in_post = np.asarray((idx >= p.post_period[0]) & (idx <= p.post_period[1]))
+    obs = p.values[b, p.model_rows, 0].copy()
+    obs[p.num_pre:][~in_post[p.num_pre:]] = np.nan        # gap / tail: predictions only
+    flags = (~np.asarray(idx < p.post_period[0])).astype(np.uint8) | (in_post.astype(np.uint8) << 1)
+    return dict(scale=float(p.outcome_sd[b]) if p.standardize_data else 1.0,
+                shift=float(p.outcome_mean[b]) if p.standardize_data else 0.0,
+                observed=obs, flags=flags, ranks=self._ranks,
+                quantiles=(self.alpha / 2.0, 1.0 - self.alpha / 2.0))
+
+  def _build_summary(self) -> pd.DataFrame:
+    p = self._prep
+    quantiles = (self.alpha / 2.0, 1.0 - self.alpha / 2.0)
+    frames = []
+    for b in range(len(self)):
+      rq = self._request(b)
+      win = (rq["flags"] & 2) != 0
+      obs_w = rq["observed"][win]
+      post_mean = (self._means[b].astype(np.float64) * rq["scale"] + rq["shift"])[win]
+      pred_sum, point_sum = self._dsum["per_draw"][b]
+      n_obs = int(np.sum(~np.isnan(obs_w)))
+      with np.errstate(invalid="ignore", divide="ignore"):
+        rows, p_value = lib._summary_rows(            # pylint: disable=protected-access
+            post_mean, obs_w, pred_sum / int(win.sum()), pred_sum,
+            point_sum / n_obs if n_obs else np.full_like(point_sum, np.nan), point_sum, quantiles)
+      f = pd.DataFrame({k: {"average": v[0], "cumulative": v[1]} for k, v in rows.items()})
+      f["p_value"] = p_value
+      f["alpha"] = self.alpha
+      frames.append(f)
+    return pd.concat(frames, keys=self._names, names=["series", None])
+
+  def __getitem__(self, b: int) -> lib.CausalImpactAnalysis:
+    b = range(len(self))[b]
+    if b not in self._cache:
+      p = self._prep
+      df = pd.DataFrame(p.values[b], index=p.index, columns=self._columns)
+      ci_data = cid.CausalImpactData(df, p.pre_period, p.post_period,
+                                     standardize_data=p.standardize_data)
+      dsum = {k: v[b] for k, v in self._dsum.items()}
+      rq = lib._device_summary_request(ci_data, self.alpha)   # pylint: disable=protected-access
+      rq["ranks"] = self._ranks
+      series, summary = lib._compute_impact_device(            # pylint: disable=protected-access
+          self._means[b], dsum, rq, ci_data, self.alpha)
+      self._cache[b] = lib.CausalImpactAnalysis(series, summary, None,
+                                                None if self.diagnostics is None else
+                                                {k: v[b] for k, v in self.diagnostics.items()})
+    return self._cache[b]
+
+  def __iter__(self):
+    return (self[b] for b in range(len(self)))
+
+
+def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
+                           pre_period, post_period, alpha: float = 0.05, seed=None,
+                           data_options: Optional[lib.DataOptions] = None,
+                           model_options: Optional[lib.ModelOptions] = None,
+                           inference_options: Optional[lib.InferenceOptions] = None,
+                           index: Optional[pd.Index] = None,
+                           names: Optional[Sequence[Any]] = None) -> CausalImpactBatchAnalysis:
+  """`fit_causalimpact` for B series at once.
+
+  data: a sequence of DataFrames with identical index and column layout (outcome first, or
+  `DataOptions.outcome_column`), or an array [B, T, 1 + covariates] (outcome first) with
+  `index` (default: 0..T-1).  Other arguments as `fit_causalimpact`.  Latent-state draws are not
+  downloaded (B x chains x draws x T values); the per-series frames and the summary table are.
+  """
+  data_options = data_options or lib.DataOptions()
+  model_options = model_options or lib.ModelOptions()
+  inference_options = inference_options or lib.InferenceOptions()
+  if not 0 < alpha < 1:
+    raise ValueError("`alpha` must be between 0 and 1.")
+  if inference_options.sampler != "gibbs":
+    raise NotImplementedError("batched fits use the Gibbs sampler")
+  if isinstance(data, np.ndarray):
+    values = np.asarray(data, np.float64)
+    index = pd.RangeIndex(values.shape[1]) if index is None else pd.Index(index)
+    columns = ["y"] + [f"x{j}" for j in range(values.shape[2] - 1)]
+  else:
+    frames = [pd.DataFrame(d) for d in data]
+    if not frames:
+      raise ValueError("`data` is empty")
+    first = frames[0]
+    oc = data_options.outcome_column if data_options.outcome_column is not None else first.columns[0]
+    columns = [oc] + [c for c in first.columns if c != oc]
+    for f in frames:
+      if not f.index.equals(first.index) or list(f.columns) != list(first.columns):
+        raise ValueError("all series of a batch must share the index and the columns")
+    values = np.stack([f[columns].to_numpy(dtype=np.float64) for f in frames])
+    index = first.index
+  B = values.shape[0]
+  names = list(range(B)) if names is None else list(names)
+  prep = prepare_batch(values, index, pre_period, post_period, data_options.standardize_data)
+  T = prep.y.shape[1]
+  P = 0 if prep.design is None else prep.design.shape[2]
+  num_seasons, season_change = _model.expand_seasons(model_options.seasons, T)
+  # the sampler sees the outcome in DataOptions.dtype (data.py:121-128), priors included
+  y_model = prep.y.astype(cid._as_numpy_dtype(data_options.dtype)).astype(np.float64)  # pylint: disable=protected-access
+  with np.errstate(invalid="ignore"):
+    pre_sd = np.nanstd(y_model[:, :prep.num_pre], axis=1, ddof=1)
+  params = [_model.series_params(y_model[b], prep.mask[b],
+                                 None if prep.design is None else prep.design[b],
+                                 prior_level_sd=model_options.prior_level_sd,
+                                 num_seasonal_blocks=len(num_seasons),
+                                 has_slope=model_options.local_linear_trend,
+                                 outcome_sd=float(pre_sd[b])) for b in range(B)]
+  seed_pair = lib._sanitize_seed(seed)   # pylint: disable=protected-access
+  C, S = inference_options.num_chains, inference_options.num_results
+  qs = lib._quantile_ranks(C * S, (alpha / 2.0, 1.0 - alpha / 2.0))   # pylint: disable=protected-access
+  ranks = sorted({r for lo, hi, _ in qs for r in (lo, hi)} |
+                 {C * S - 1 - r for lo, hi, _ in qs for r in (lo, hi)})
+  idx = index[prep.model_rows]
+  in_post = np.asarray((idx >= prep.post_period[0]) & (idx <= prep.post_period[1]))
+  flags = (~np.asarray(idx < prep.post_period[0])).astype(np.uint8) | (in_post.astype(np.uint8) << 1)
+  observed = values[:, prep.model_rows, 0].copy()
+  observed[:, prep.num_pre:][:, ~in_post[prep.num_pre:]] = np.nan
+  devs = list(inference_options.devices) if inference_options.devices else [0]
+  shards = [s for s in np.array_split(np.arange(B), len(devs)) if len(s)]
+
+  def run(dev, ids):
+    pb = _native.make_problem(T=T, P=P, has_slope=model_options.local_linear_trend,
+                              num_seasons=num_seasons, num_warmup=inference_options.num_warmup_steps,
+                              num_results=S, num_chains=C, num_series=len(ids), seed=seed_pair,
+                              device=dev)
+    sess = _native.Session(pb, y_model[ids], prep.mask[ids],
+                           None if prep.design is None else prep.design[ids], season_change,
+                           _native.make_params([params[b] for b in ids]))
+    try:
+      sess.run()
+      out = sess.fetch(["posterior_means", "observation_noise_scale", "level_scale"])
+      dsum = sess.summarize(prep.outcome_sd[ids] if prep.standardize_data else 1.0,
+                            prep.outcome_mean[ids] if prep.standardize_data else 0.0,
+                            observed[ids], flags, ranks)
+      if len(ids) == 1:
+        dsum = {k: v[None] for k, v in dsum.items()}
+    finally:
+      sess.close()
+    return out, dsum
+
+  with concurrent.futures.ThreadPoolExecutor(max_workers=len(shards)) as pool:
+    results = list(pool.map(lambda a: run(*a), zip(devs, shards)))
+  means = np.concatenate([r[0]["posterior_means"].mean(axis=1) for r in results], axis=0)   # [B, T]
+  dsum = {k: np.concatenate([r[1][k] for r in results], axis=0) for k in results[0][1]}
+  diagnostics = None
+  if C > 1:
+    keys = ("observation_noise_scale", "level_scale")
+    stacked = {k: np.concatenate([r[0][k] for r in results], axis=0) for k in keys}   # [B, C, S]
+    diagnostics = {
+        "split_rhat": [{k: lib.split_rhat(stacked[k][b]) for k in keys} for b in range(B)],
+        "ess_bulk": [{k: lib.effective_sample_size(stacked[k][b]) for k in keys} for b in range(B)],
+    }
+  return CausalImpactBatchAnalysis(prep, names, alpha, means, dsum, ranks, columns, diagnostics)

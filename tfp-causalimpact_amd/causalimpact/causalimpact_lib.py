@@ -197,6 +197,38 @@ def split_rhat(draws: np.ndarray) -> float:
   return float(np.sqrt(((half - 1) / half * within + between / half) / within))
 
 
+def effective_sample_size(draws: np.ndarray) -> float:
+  """Bulk effective sample size of [chains, draws] scalar draws: split chains, FFT
+  autocovariances, Geyer's initial monotone positive sequence (Gelman et al. 2013, ch. 11;
+  Vehtari et al. 2021).  NaN for degenerate input.  (SURVEY.md 8(f) N3 -- absent upstream.)"""
+  x = np.asarray(draws, np.float64)
+  half = x.shape[1] // 2
+  if half < 4:
+    return float("nan")
+  z = np.concatenate([x[:, :half], x[:, half:2 * half]], axis=0)       # [2C, n]
+  m, n = z.shape
+  zc = z - z.mean(axis=1, keepdims=True)
+  size = 1 << int(np.ceil(np.log2(2 * n)))
+  f = np.fft.rfft(zc, size, axis=1)
+  acov = np.fft.irfft(f * np.conj(f), size, axis=1)[:, :n] / n          # biased, per chain
+  within = acov[:, 0].mean() * n / (n - 1.0)
+  var_plus = acov[:, 0].mean() + (z.mean(axis=1).var(ddof=1) if m > 1 else 0.0)
+  if not np.isfinite(var_plus) or var_plus <= 0:
+    return float("nan")
+  rho = 1.0 - (within - acov.mean(axis=0) * n / (n - 1.0)) / var_plus
+  rho[0] = 1.0
+  # sums of adjacent pairs must be positive and non-increasing
+  tau, prev = -1.0, np.inf
+  for k in range(0, n - 1, 2):
+    pair = rho[k] + rho[k + 1]
+    if pair < 0:
+      break
+    pair = min(pair, prev)
+    tau += 2.0 * pair
+    prev = pair
+  return float(m * n / max(tau, 1.0 / np.log10(max(m * n, 10))))
+
+
 def _train_causalimpact_sts(*,
                             ci_data: cid.CausalImpactData,
                             prior_level_sd,
@@ -310,6 +342,8 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
   if num_chains > 1:
     samples["diagnostics"] = {
         "split_rhat": {k: split_rhat(out[k]) for k in ("observation_noise_scale", "level_scale")},
+        "ess_bulk": {k: effective_sample_size(out[k])
+                     for k in ("observation_noise_scale", "level_scale")},
         "num_chains": num_chains}
   posterior_means = out["posterior_means"].mean(axis=0).astype(np_dtype, copy=False)      # :627
   posterior_trajectories = (pool(out["posterior_trajectories"])                           # :631
@@ -529,19 +563,9 @@ def _compute_impact_estimates(posterior_trajectory_summary: pd.DataFrame,
   return frame
 
 
-def _compute_summary(posterior_trajectory_summary: pd.DataFrame,
-                     trajectory_dict: Dict[str, pd.DataFrame], observed_ts_post: pd.Series,
-                     post_period: OutputPeriodType, quantiles: Tuple[float, float],
-                     alpha: float, per_draw: Optional[Dict[str, np.ndarray]] = None) -> pd.DataFrame:
-  """The 2 x 15 `summary` frame over the post-period (reference :934-1093).  `per_draw`:
-  precomputed per-draw window means / totals (on-device summary)."""
-
-  def window(frame):
-    keep = (frame.index >= post_period[0]) & (frame.index <= post_period[1])
-    return frame.loc[keep]
-
-  post_mean = window(posterior_trajectory_summary)["posterior_mean"].to_numpy(dtype=np.float64)
-  obs = observed_ts_post.to_numpy(dtype=np.float64)
+def _summary_rows(post_mean, obs, pred_mean, pred_sum, point_mean_t, point_sum_t, quantiles):
+  """The numbers of the `summary` frame (reference :966-1091) from the post-period posterior
+  mean [T_w], observations [T_w] and per-draw window means / totals [draws]."""
   obs_mean, obs_sum = float(np.nanmean(obs)), float(np.nansum(obs))
 
   def sd(v):
@@ -551,15 +575,6 @@ def _compute_summary(posterior_trajectory_summary: pd.DataFrame,
     lo, hi = np.quantile(v, quantiles)
     return float(lo), float(hi)
 
-  if per_draw is None:
-    pred = window(trajectory_dict["predictions"]).to_numpy(dtype=np.float64)      # [T_post, draws]
-    point = window(trajectory_dict["point_effects"]).to_numpy(dtype=np.float64)
-    pred_mean, pred_sum = pred.mean(axis=0), pred.sum(axis=0)
-    with np.errstate(invalid="ignore"):
-      point_mean_t, point_sum_t = np.nanmean(point, axis=0), np.nansum(point, axis=0)
-  else:
-    pred_mean, pred_sum = per_draw["pred_mean"], per_draw["pred_sum"]
-    point_mean_t, point_sum_t = per_draw["point_mean_t"], per_draw["point_sum_t"]
   rel = obs_sum / pred_sum - 1.0
   avg_pred, cum_pred = float(post_mean.mean()), float(post_mean.sum())
   rows = {
@@ -577,10 +592,38 @@ def _compute_summary(posterior_trajectory_summary: pd.DataFrame,
       "rel_effect_upper": (band(rel)[1],) * 2,
       "rel_effect_sd": (sd(rel),) * 2,
   }
-  summary = pd.DataFrame({k: {"average": v[0], "cumulative": v[1]} for k, v in rows.items()})
   # one-sided tail area of the observed total among the sampled totals, the observed total
   # included so that p stays in (0, 1)   (:1077-1091)
   pool = np.append(pred_sum, obs_sum)
-  summary["p_value"] = min(float((obs_sum <= pool).mean()), float((obs_sum >= pool).mean()))
+  p_value = min(float((obs_sum <= pool).mean()), float((obs_sum >= pool).mean()))
+  return rows, p_value
+
+
+def _compute_summary(posterior_trajectory_summary: pd.DataFrame,
+                     trajectory_dict: Dict[str, pd.DataFrame], observed_ts_post: pd.Series,
+                     post_period: OutputPeriodType, quantiles: Tuple[float, float],
+                     alpha: float, per_draw: Optional[Dict[str, np.ndarray]] = None) -> pd.DataFrame:
+  """The 2 x 15 `summary` frame over the post-period (reference :934-1093).  `per_draw`:
+  precomputed per-draw window means / totals (on-device summary)."""
+
+  def window(frame):
+    keep = (frame.index >= post_period[0]) & (frame.index <= post_period[1])
+    return frame.loc[keep]
+
+  post_mean = window(posterior_trajectory_summary)["posterior_mean"].to_numpy(dtype=np.float64)
+  obs = observed_ts_post.to_numpy(dtype=np.float64)
+  if per_draw is None:
+    pred = window(trajectory_dict["predictions"]).to_numpy(dtype=np.float64)      # [T_post, draws]
+    point = window(trajectory_dict["point_effects"]).to_numpy(dtype=np.float64)
+    pred_mean, pred_sum = pred.mean(axis=0), pred.sum(axis=0)
+    with np.errstate(invalid="ignore"):
+      point_mean_t, point_sum_t = np.nanmean(point, axis=0), np.nansum(point, axis=0)
+  else:
+    pred_mean, pred_sum = per_draw["pred_mean"], per_draw["pred_sum"]
+    point_mean_t, point_sum_t = per_draw["point_mean_t"], per_draw["point_sum_t"]
+  rows, p_value = _summary_rows(post_mean, obs, pred_mean, pred_sum, point_mean_t, point_sum_t,
+                                quantiles)
+  summary = pd.DataFrame({k: {"average": v[0], "cumulative": v[1]} for k, v in rows.items()})
+  summary["p_value"] = p_value
   summary["alpha"] = alpha
   return summary

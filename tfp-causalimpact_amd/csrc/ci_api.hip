@@ -430,50 +430,53 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
   return 0;
 }
 
-int ci_session_summarize(ci_session* s, double scale, double shift, const double* observed,
-                         const uint8_t* flags, int32_t num_ranks, const int32_t* ranks,
-                         double* value_order, double* cum_order, double* per_draw) {
-  if (!s || !observed || !flags || !ranks) return fail("NULL argument");
+int ci_session_summarize(ci_session* s, const double* scale, const double* shift,
+                         const double* observed, const uint8_t* flags, int32_t num_ranks,
+                         const int32_t* ranks, double* value_order, double* cum_order,
+                         double* per_draw) {
+  if (!s || !scale || !shift || !observed || !flags || !ranks) return fail("NULL argument");
   if (!s->ran) return fail("ci_session_summarize needs a finished ci_session_run");
   const ci_problem& pb = s->pb;
-  if (pb.num_series != 1) return fail("summarisation supports num_series == 1, got %d", pb.num_series);
   if (num_ranks < 1 || num_ranks > ci::SUMM_MAX_RANKS)
     return fail("num_ranks must be in [1, %d], got %d", ci::SUMM_MAX_RANKS, num_ranks);
-  const int T = pb.T, N = pb.num_chains * pb.num_results;
+  const int T = pb.T, N = pb.num_chains * pb.num_results, B = pb.num_series;
   for (int r = 0; r < num_ranks; ++r)
     if (ranks[r] < 0 || ranks[r] >= N) return fail("rank %d out of range [0, %d)", ranks[r], N);
   HIP_TRY(hipSetDevice(pb.device));
-  const size_t TN = (size_t)T * N;
+  const size_t BTN = (size_t)B * T * N;
   if (!s->s_value.p) {
-    HIP_TRY(s->s_value.alloc(TN));
-    HIP_TRY(s->s_cum.alloc(TN));
-    HIP_TRY(s->s_obs.alloc(T));
-    HIP_TRY(s->s_flags.alloc(T));
+    HIP_TRY(s->s_value.alloc(BTN));
+    HIP_TRY(s->s_cum.alloc(BTN));
+    HIP_TRY(s->s_obs.alloc((size_t)B * T + 2 * B));
+    HIP_TRY(s->s_flags.alloc((size_t)B * T));
     HIP_TRY(s->s_ranks.alloc(ci::SUMM_MAX_RANKS));
-    HIP_TRY(s->s_order.alloc((size_t)2 * ci::SUMM_MAX_RANKS * T));
-    HIP_TRY(s->s_draw.alloc((size_t)2 * N));
+    HIP_TRY(s->s_order.alloc((size_t)2 * B * ci::SUMM_MAX_RANKS * T));
+    HIP_TRY(s->s_draw.alloc((size_t)B * 2 * N));
   }
-  HIP_TRY(hipMemcpyAsync(s->s_obs.p, observed, T * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->s_flags.p, flags, T, hipMemcpyHostToDevice, s->stream));
+  double* d_scale = s->s_obs.p + (size_t)B * T;
+  double* d_shift = d_scale + B;
+  HIP_TRY(hipMemcpyAsync(s->s_obs.p, observed, (size_t)B * T * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(d_scale, scale, B * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(d_shift, shift, B * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->s_flags.p, flags, (size_t)B * T, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->s_ranks.p, ranks, num_ranks * sizeof(int), hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(ci::summ_transpose_kernel, dim3((T + 63) / 64, (N + 63) / 64), dim3(64, 4), 0,
-                     s->stream, N, T, s->o_traj.p, scale, shift, s->s_value.p);
-  hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, N, T,
+  hipLaunchKernelGGL(ci::summ_transpose_kernel, dim3((T + 63) / 64, (N + 63) / 64, B), dim3(64, 4), 0,
+                     s->stream, N, T, s->o_traj.p, d_scale, d_shift, s->s_value.p);
+  hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s->stream, N, T,
                      s->s_value.p, s->s_obs.p, s->s_flags.p, s->s_cum.p, s->s_draw.p);
   double* ord_value = s->s_order.p;
-  double* ord_cum = s->s_order.p + (size_t)ci::SUMM_MAX_RANKS * T;
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), 0, s->stream, N, T, num_ranks,
+  double* ord_cum = s->s_order.p + (size_t)B * ci::SUMM_MAX_RANKS * T;
+  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(B * T), dim3(256), 0, s->stream, N, T, num_ranks,
                      s->s_ranks.p, s->s_value.p, ord_value);
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), 0, s->stream, N, T, num_ranks,
+  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(B * T), dim3(256), 0, s->stream, N, T, num_ranks,
                      s->s_ranks.p, s->s_cum.p, ord_cum);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
-  if (value_order)
-    HIP_TRY(hipMemcpy(value_order, ord_value, (size_t)num_ranks * T * sizeof(double), hipMemcpyDeviceToHost));
-  if (cum_order)
-    HIP_TRY(hipMemcpy(cum_order, ord_cum, (size_t)num_ranks * T * sizeof(double), hipMemcpyDeviceToHost));
+  const size_t ord_bytes = (size_t)B * num_ranks * T * sizeof(double);
+  if (value_order) HIP_TRY(hipMemcpy(value_order, ord_value, ord_bytes, hipMemcpyDeviceToHost));
+  if (cum_order) HIP_TRY(hipMemcpy(cum_order, ord_cum, ord_bytes, hipMemcpyDeviceToHost));
   if (per_draw)
-    HIP_TRY(hipMemcpy(per_draw, s->s_draw.p, (size_t)2 * N * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(per_draw, s->s_draw.p, (size_t)B * 2 * N * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -18,12 +18,16 @@ constexpr int SUMM_MAX_RANKS = 8;
 
 // [N, T] float32 draws (model scale) -> [T, N] float64 on the data scale:
 // standardize.py:60-64 `values * stddev + mean` (two roundings, no FMA).
-// grid (ceil(T/64), ceil(N/64)), block (64, 4).
+// grid (ceil(T/64), ceil(N/64), B), block (64, 4); series b uses (scale[b], shift[b]).
 __global__ __launch_bounds__(256) void summ_transpose_kernel(int N, int T,
-                                                             const float* __restrict__ traj,
-                                                             double scale, double shift,
-                                                             double* __restrict__ predT) {
+                                                             const float* __restrict__ traj_all,
+                                                             const double* __restrict__ scales,
+                                                             const double* __restrict__ shifts,
+                                                             double* __restrict__ predT_all) {
   __shared__ double tile[64][65];
+  const float* traj = traj_all + (size_t)blockIdx.z * N * T;
+  double* predT = predT_all + (size_t)blockIdx.z * N * T;
+  const double scale = scales[blockIdx.z], shift = shifts[blockIdx.z];
   const int t0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
   const int tx = threadIdx.x, ty = threadIdx.y;
 #pragma unroll
@@ -45,14 +49,21 @@ __global__ __launch_bounds__(256) void summ_transpose_kernel(int N, int T,
 //   cum_t = running sum of point from the treatment start, NaN steps skipped but reported NaN
 //   pred_sum / point_sum over the post-period window (:985-1017; nansum for the effects).
 // flags[t]: bit 0 = t >= treatment start, bit 1 = inside the post-period window.
+// grid (ceil(N/256), B).
 __global__ __launch_bounds__(256) void summ_cumsum_kernel(int N, int T,
-                                                          const double* __restrict__ predT,
-                                                          const double* __restrict__ obs,
-                                                          const uint8_t* __restrict__ flags,
-                                                          double* __restrict__ cumT,
-                                                          double* __restrict__ per_draw) {
+                                                          const double* __restrict__ predT_all,
+                                                          const double* __restrict__ obs_all,
+                                                          const uint8_t* __restrict__ flags_all,
+                                                          double* __restrict__ cumT_all,
+                                                          double* __restrict__ per_draw_all) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  const size_t b = blockIdx.y;
+  const double* predT = predT_all + b * N * T;
+  double* cumT = cumT_all + b * N * T;
+  const double* obs = obs_all + b * T;
+  const uint8_t* flags = flags_all + b * T;
+  double* per_draw = per_draw_all + b * 2 * N;
   double c = 0.0, pred_sum = 0.0, point_sum = 0.0;
   for (int t = 0; t < T; ++t) {
     const double p = predT[(size_t)t * N + n];
@@ -80,10 +91,11 @@ __device__ __forceinline__ double summ_unkey(unsigned long long k) {
   return __longlong_as_double((long long)b);
 }
 
-// Order statistics of every row of M [rows, N] (float64): out[r, row] = ranks[r]-th smallest.
+// Order statistics of every row of M [B*T, N] (float64): out[b, r, t] = ranks[r]-th smallest of
+// row b*T + t.
 // One 256-thread workgroup per row; most-significant-digit radix select, 8 passes of 8 bits, all
 // R ranks carried through the same sweeps of the row (which stays in L2: N * 8 bytes).
-__global__ __launch_bounds__(256) void summ_select_kernel(int N, int rows, int R,
+__global__ __launch_bounds__(256) void summ_select_kernel(int N, int T, int R,
                                                           const int* __restrict__ ranks,
                                                           const double* __restrict__ M,
                                                           double* __restrict__ out) {
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(256) void summ_select_kernel(int N, int rows, int R
     }
     __syncthreads();
   }
-  if (tid < R) out[(size_t)tid * rows + row] = summ_unkey(prefix[tid]);
+  if (tid < R) out[((size_t)(row / T) * R + tid) * T + row % T] = summ_unkey(prefix[tid]);
 }
 
 }  // namespace ci

@@ -1,0 +1,73 @@
+"""Measures the BASELINE configs that are not the bench line (bench.py = cfg2) on one MI355X and
+writes one JSON line per config (committed as profiles/r01_configs.json):
+  cfg4: T=10000, 50 covariates + Seasonal(num_seasons=7), 1000 samples (1 and 8 chains)
+  cfg5: 512 independent series, T=500, 5 covariates (what one GPU does with its 64-series share,
+        and all 512 on one GPU)
+Throughput = retained draws / Gibbs-kernel time (HIP events), inputs resident in HBM, plus the
+end-to-end time of the batched API for cfg5."""
+import json
+import sys
+import time
+
+import numpy as np
+import pandas as pd
+
+sys.path.insert(0, "tfp-causalimpact_amd"); sys.path.insert(0, ".")
+import causalimpact as ci
+from causalimpact import _model, _native
+from causalimpact import _synthetic as syn
+
+
+def cfg4(chains, S=1000):
+  T, p = 10000, 50
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 0)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  spec = _model.series_params(y, mask, X, num_seasonal_blocks=1)
+  counts, flg = _model.expand_seasons((ci.Seasons(num_seasons=7),), T)
+  W = -(-S // 9)
+  pb = _native.make_problem(T=T, P=X.shape[1], has_slope=0, num_seasons=counts, num_warmup=W,
+                            num_results=S, num_chains=chains, seed=(0, 1))
+  sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+  sess.run()
+  ms = min(sess.run() for _ in range(2))
+  nbytes = sess.algorithmic_bytes()
+  sess.close()
+  return {"config": "cfg4", "workload": "T=10000, 50 covariates (P=51), LocalLevel + Seasonal(7) + spike-slab",
+          "chains": chains, "num_results": S, "num_warmup": W, "kernel_ms": ms,
+          "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": chains * S / ms * 1e3,
+          "algorithmic_GBps": nbytes / ms / 1e6}
+
+
+def cfg5(B, S=1000):
+  T, p = 500, 5
+  frames = []
+  for b in range(B):
+    y, X = syn.make_raw_series(T, p, b)
+    frames.append(np.column_stack([y, X]))
+  values = np.stack(frames)
+  opts = ci.InferenceOptions(num_results=S)
+  ci.fit_causalimpact_batch(values[:2], (0, 349), (350, 499), seed=1, inference_options=opts)
+  t0 = time.time()
+  res = ci.fit_causalimpact_batch(values, (0, 349), (350, 499), seed=1, inference_options=opts)
+  wall = time.time() - t0
+  # kernel time of the same launch
+  prep = ci.batch.prepare_batch(values, pd.RangeIndex(T), (0, 349), (350, 499))
+  params = [_model.series_params(prep.y[b], prep.mask[b], prep.design[b]) for b in range(B)]
+  W = opts.num_warmup_steps
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_warmup=W, num_results=S, num_chains=1,
+                            num_series=B, seed=(0, 1))
+  sess = _native.Session(pb, prep.y, prep.mask, prep.design, None, _native.make_params(params))
+  sess.run()
+  ms = min(sess.run() for _ in range(2))
+  nbytes = sess.algorithmic_bytes()
+  sess.close()
+  return {"config": "cfg5", "workload": "independent series, T=500, 5 covariates (P=6), LocalLevel + spike-slab",
+          "series": B, "num_results": S, "num_warmup": W, "kernel_ms": ms,
+          "samples_per_s": B * S / ms * 1e3, "algorithmic_GBps": nbytes / ms / 1e6,
+          "batched_api_wall_s": wall, "batched_api_samples_per_s": B * S / wall,
+          "mean_abs_effect": float(res.summary.xs("average", level=1)["abs_effect"].mean())}
+
+
+if __name__ == "__main__":
+  for line in (cfg4(1), cfg4(8), cfg5(64), cfg5(512)):
+    print(json.dumps(line))

@@ -165,6 +165,22 @@ int ci_ll_session_eval(ci_ll_session* session, int32_t num_evals, const double* 
 int ci_ll_session_draw_latents(ci_ll_session* session, int32_t num_draws, const double* theta,
                                const uint32_t seed[2], uint32_t rng_chain, uint32_t iter0,
                                float* level, float* slope, float* loc, float* traj);
+/* Hamiltonian Monte Carlo over theta = (beta, log sigma_obs, log sigma_level[, log sigma_slope])
+ * entirely on the device: one workgroup per chain runs num_warmup + num_results iterations of
+ * num_leapfrog steps (log-likelihood + score by the same time-parallel scans as
+ * ci_ll_session_eval), with dual-averaging step-size adaptation and a per-chain diagonal mass
+ * estimate during warm-up.  Target: l(theta) + the reference's inverse-gamma variance priors
+ * (causalimpact_lib.py:424-443) + the Gaussian slab of the weights prior (:451-453).
+ * EXTENSION (upstream analogue tfp.sts.fit_with_hmc; the reference
+ * itself has no HMC path).  RNG stream (seed, chain = chain_offset + c): results do not depend
+ * on how chains are split over devices.  Outputs (host): draws [num_chains, num_results, 3 + P]
+ * float64 rows (sigma_obs, sigma_level, sigma_slope, beta) -- feed them to
+ * ci_ll_session_draw_latents for latent paths / predictive trajectories; accept_rate,
+ * step_size [num_chains] (optional). */
+int ci_ll_session_hmc(ci_ll_session* session, int32_t num_chains, int32_t chain_offset,
+                      int32_t num_warmup, int32_t num_results, int32_t num_leapfrog,
+                      double target_accept, double initial_step_size, const uint32_t seed[2],
+                      double* draws, double* accept_rate, double* step_size);
 int ci_ll_session_destroy(ci_ll_session* session);
 
 /* ---- component entry points used by the parity tests (tests/test_gpu_*.py) ---- */

@@ -52,3 +52,31 @@ def test_hmc_rejects_unsupported_options():
   with pytest.raises(ValueError, match="sampler must be"):
     lib.fit_causalimpact(df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
                          inference_options=lib.InferenceOptions(num_results=10, sampler="nuts"))
+
+
+def test_device_hmc_agrees_with_host_driven_hmc_and_splits_like_gibbs():
+  """The on-device chain (csrc/ci_hmc.h) against the numpy-driven sampler it replaced (same
+  target, one device call per leapfrog step), and the multi-GPU rule: chain c's draws do not
+  depend on which launch ran it."""
+  from causalimpact import _hmc, _model
+  from causalimpact import _synthetic as syn
+  T, p = 300, 3
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 12)
+  spec = _model.series_params(y, mask, X, has_slope=True)
+  kw = dict(has_slope=True, num_results=300, num_warmup=300, seed=(3, 4))
+  dev = _hmc.fit_hmc(y, mask, X, spec, num_chains=6, **kw)
+  host = _hmc.fit_hmc_host(y, mask, X, spec, num_chains=6, **kw)
+  assert (dev["hmc_accept_rate"] > 0.5).all() and (dev["hmc_accept_rate"] < 0.99).all()
+  for key, tol in (("observation_noise_scale", 0.05), ("level_scale", 0.25)):
+    np.testing.assert_allclose(dev[key].mean(), host[key].mean(), rtol=tol, err_msg=key)
+  np.testing.assert_allclose(dev["weights"].mean(axis=(0, 1, 2))[:p],
+                             host["weights"].mean(axis=(0, 1, 2))[:p], atol=0.03)
+  sd_d, sd_h = dev["weights"][0, :, :, 0].std(), host["weights"][0, :, :, 0].std()
+  assert 0.7 < sd_d / sd_h < 1.4
+  np.testing.assert_allclose(dev["posterior_means"].mean(axis=1), host["posterior_means"].mean(axis=1),
+                             atol=0.1)
+  # chains {0..5} in one launch == chains {0,1,2} and {3,4,5} in two launches
+  a = _hmc.fit_hmc(y, mask, X, spec, num_chains=3, chain_offset=0, **kw)
+  b = _hmc.fit_hmc(y, mask, X, spec, num_chains=3, chain_offset=3, **kw)
+  for key in ("observation_noise_scale", "weights", "level", "posterior_trajectories"):
+    np.testing.assert_array_equal(np.concatenate([a[key], b[key]], axis=1), dev[key], err_msg=key)

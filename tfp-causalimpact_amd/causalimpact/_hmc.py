@@ -79,11 +79,70 @@ class _Target:
     return lp, grad
 
 
+def _package(sess, dev, seed, chain_offset, C, S, T, P):
+  """Latent paths + predictive trajectories for every retained draw; the arrays of
+  `_native.fit_gibbs` (leading series axis of 1)."""
+  level = np.zeros((C * S, T), np.float32)
+  slope = np.zeros((C * S, T), np.float32)
+  loc = np.zeros((C * S, T), np.float32)
+  traj = np.zeros((C * S, T), np.float32)
+  step = sess.max_evals
+  for c in range(C):
+    for lo in range(0, S, step):
+      hi = min(S, lo + step)
+      rows = slice(c * S + lo, c * S + hi)
+      out = sess.draw_latents(dev[rows], seed, rng_chain=chain_offset + c, iter0=lo)
+      level[rows], slope[rows], loc[rows], traj[rows] = (out["level"], out["slope"], out["loc"],
+                                                          out["traj"])
+  dev3 = dev.reshape(C, S, 3 + P)
+  return dict(
+      observation_noise_scale=dev3[None, :, :, 0].astype(np.float32),
+      level_scale=dev3[None, :, :, 1].astype(np.float32),
+      slope_scale=dev3[None, :, :, 2].astype(np.float32),
+      seasonal_drift_scales=np.zeros((1, C, S, 0), np.float32),
+      weights=dev3[None, :, :, 3:].astype(np.float32),
+      level=level.reshape(1, C, S, T), slope=slope.reshape(1, C, S, T),
+      seasonal_levels=np.zeros((1, C, S, T, 0), np.float32),
+      posterior_means=loc.reshape(C, S, T).mean(axis=1)[None].astype(np.float32),
+      posterior_trajectories=traj.reshape(1, C, S, T))
+
+
 def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_warmup: int,
             num_chains: int, seed, device: int = 0, chain_offset: int = 0, num_leapfrog: int = 15,
             target_accept: float = 0.75, initial_step_size: float = 0.05) -> Dict[str, np.ndarray]:
-  """Returns the same arrays as `_native.fit_gibbs` (leading series axis of 1) plus
-  `hmc_accept_rate`, `hmc_step_size` [C] and `hmc_target_calls`."""
+  """HMC with the whole chain on the device (csrc/ci_hmc.h: one workgroup per chain, no host
+  round trip per leapfrog step).  Returns the arrays of `_native.fit_gibbs` (leading series axis
+  of 1) plus `hmc_accept_rate`, `hmc_step_size` [C] and `hmc_target_calls`."""
+  y = np.asarray(y, np.float64)
+  mask = np.asarray(mask, bool)
+  T = y.shape[0]
+  P = 0 if X is None else int(np.asarray(X).shape[1])
+  C, S, W = int(num_chains), int(num_results), int(num_warmup)
+  pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_warmup=0, num_results=1,
+                            seed=seed, device=device)
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X,
+                               max_evals=max(C, min(1024, C * S)))
+  try:
+    draws, acc, eps = sess.hmc(num_chains=C, num_warmup=W, num_results=S,
+                               num_leapfrog=num_leapfrog, target_accept=target_accept,
+                               initial_step_size=initial_step_size, seed=seed,
+                               chain_offset=chain_offset)
+    out = _package(sess, draws.reshape(C * S, 3 + P), seed, chain_offset, C, S, T, P)
+  finally:
+    sess.close()
+  out.update(hmc_accept_rate=acc, hmc_step_size=eps,
+             hmc_target_calls=np.int64((W + S) * num_leapfrog + 1))
+  return out
+
+
+def fit_hmc_host(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_warmup: int,
+                 num_chains: int, seed, device: int = 0, chain_offset: int = 0,
+                 num_leapfrog: int = 15, target_accept: float = 0.75,
+                 initial_step_size: float = 0.05) -> Dict[str, np.ndarray]:
+  """The same sampler with momentum / accept logic in numpy and one device call per leapfrog
+  step (`ci_ll_session_eval`): the statistical reference of the device kernel
+  (tests/test_gpu_hmc.py), ~14x slower.  Mass matrix pooled over chains here, per chain on the
+  device; different random streams -- the two agree in distribution, not per draw."""
   y = np.asarray(y, np.float64)
   mask = np.asarray(mask, bool)
   T = y.shape[0]
@@ -170,32 +229,10 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
       draws[:, it - W] = theta
       accepted += take
 
-  # latent paths + predictive trajectories for every retained draw
   dev = _unpack(draws.reshape(C * S, dim), P, has_slope)
-  level = np.zeros((C * S, T), np.float32)
-  slope = np.zeros((C * S, T), np.float32)
-  loc = np.zeros((C * S, T), np.float32)
-  traj = np.zeros((C * S, T), np.float32)
-  step = sess.max_evals
-  for c in range(C):
-    for lo in range(0, S, step):
-      hi = min(S, lo + step)
-      rows = slice(c * S + lo, c * S + hi)
-      out = sess.draw_latents(dev[rows], seed, rng_chain=chain_offset + c, iter0=lo)
-      level[rows], slope[rows], loc[rows], traj[rows] = (out["level"], out["slope"], out["loc"],
-                                                          out["traj"])
+  out = _package(sess, dev, seed, chain_offset, C, S, T, P)
   calls = target.calls
   sess.close()
-  dev3 = dev.reshape(C, S, 3 + P)
-  return dict(
-      observation_noise_scale=dev3[None, :, :, 0].astype(np.float32),
-      level_scale=dev3[None, :, :, 1].astype(np.float32),
-      slope_scale=dev3[None, :, :, 2].astype(np.float32),
-      seasonal_drift_scales=np.zeros((1, C, S, 0), np.float32),
-      weights=dev3[None, :, :, 3:].astype(np.float32),
-      level=level.reshape(1, C, S, T), slope=slope.reshape(1, C, S, T),
-      seasonal_levels=np.zeros((1, C, S, T, 0), np.float32),
-      posterior_means=loc.reshape(C, S, T).mean(axis=1)[None].astype(np.float32),
-      posterior_trajectories=traj.reshape(1, C, S, T),
-      hmc_accept_rate=accepted / max(S, 1), hmc_step_size=eps.copy(),
-      hmc_target_calls=np.array(calls))
+  out.update(hmc_accept_rate=accepted / max(S, 1), hmc_step_size=eps.copy(),
+             hmc_target_calls=np.array(calls))
+  return out

@@ -87,6 +87,9 @@ def load():
                                            C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_ll_session_destroy.argtypes = [C.c_void_p]
+  L.ci_ll_session_hmc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_double, C.c_double, C.POINTER(C.c_uint32), C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
   L.ci_test_rng.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
                             C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
   L.ci_test_dk_draw.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p, C.c_void_p,
@@ -105,7 +108,7 @@ def exported_symbols() -> Sequence[str]:
           "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_session_profile",
           "ci_session_summarize",
           "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_eval",
-          "ci_ll_session_draw_latents", "ci_ll_session_destroy", "ci_test_rng",
+          "ci_ll_session_draw_latents", "ci_ll_session_hmc", "ci_ll_session_destroy", "ci_test_rng",
           "ci_test_dk_draw")
 
 
@@ -316,6 +319,20 @@ class LogLikSession:
         self._h, E, th.ctypes.data, s, int(rng_chain), int(iter0), out["level"].ctypes.data,
         out["slope"].ctypes.data, out["loc"].ctypes.data, out["traj"].ctypes.data))
     return out
+
+  def hmc(self, *, num_chains, num_warmup, num_results, num_leapfrog=15, target_accept=0.75,
+          initial_step_size=0.05, seed=(0, 0), chain_offset=0):
+    """The whole HMC fit on the device (ci_ll_session_hmc): draws [C, S, 3+P], accept, eps [C]."""
+    Cn, S = int(num_chains), int(num_results)
+    draws = np.zeros((Cn, S, 3 + self.P), np.float64)
+    acc = np.zeros(Cn, np.float64)
+    eps = np.zeros(Cn, np.float64)
+    sd = (C.c_uint32 * 2)(*seed_pair(seed))
+    _check(self._lib.ci_ll_session_hmc(self._h, Cn, int(chain_offset), int(num_warmup), S,
+                                       int(num_leapfrog), float(target_accept),
+                                       float(initial_step_size), sd, draws.ctypes.data,
+                                       acc.ctypes.data, eps.ctypes.data))
+    return draws, acc, eps
 
   def close(self):
     if self._h:

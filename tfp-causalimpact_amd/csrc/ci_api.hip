@@ -2,6 +2,7 @@
 // Plain HIP runtime: no torch, no TensorFlow.  One ci_session == one device-resident fit.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include "ci_seasonal.h"
 #include "ci_wide.h"
 #include "ci_summary.h"
+#include "ci_hmc.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(void);
 extern "C" void* ci_gibbs_wide_fn_tr1_ns7(void);
@@ -35,7 +37,8 @@ extern "C" void* ci_gibbs_wide_fn_tr2_ns7(void);
   extern "C" void ci_launch_latents_d##D##_l##L(int, int, int, const float*, const uint8_t*,      \
                                                 const float*, const double*, float, float, float, \
                                                 uint32_t, uint32_t, uint32_t, uint32_t, float*,   \
-                                                float*, float*, float*, hipStream_t);
+                                                float*, float*, float*, hipStream_t);             \
+  extern "C" void ci_launch_hmc_d##D##_l##L(const ci::HmcArgs*, hipStream_t);
 CI_DECL(1, 1) CI_DECL(1, 2) CI_DECL(1, 4) CI_DECL(1, 8) CI_DECL(1, 16)
 CI_DECL(2, 1) CI_DECL(2, 2) CI_DECL(2, 4) CI_DECL(2, 8) CI_DECL(2, 16)
 #undef CI_DECL
@@ -583,6 +586,9 @@ struct ci_ll_session {
   DevBuf<uint8_t> mask;
   DevBuf<double> theta, ll, grad;
   size_t draw_cap = 0;
+  // on-device HMC (ci_hmc.h)
+  DevBuf<double> omega, h_draws, h_acc, h_eps;
+  ci_series_params prm;
 };
 
 int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, const float* y,
@@ -610,13 +616,68 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
   for (int t = 0; t < T; ++t) yh[t] = mask[t] ? 0.f : y[t];
   HIP_TRY(hipMemcpy(s->y.p, yh.data(), T * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->mask.p, mask, T, hipMemcpyHostToDevice));
+  s->prm = *params;
   if (P > 0) {
     std::vector<float> xt((size_t)P * T);
     for (int t = 0; t < T; ++t)
       for (int j = 0; j < P; ++j) xt[(size_t)j * T + t] = X[(size_t)t * P + j];
     HIP_TRY(hipMemcpy(s->xt.p, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+    // Gaussian slab of the weights prior: Omega = 0.01 (X'X/2 + diag(X'X)/2) / T, all rows
+    // (causalimpact_lib.py:451-453)
+    std::vector<double> om((size_t)P * P, 0.0);
+    for (int t = 0; t < T; ++t)
+      for (int i = 0; i < P; ++i)
+        for (int j = 0; j < P; ++j)
+          om[(size_t)i * P + j] += (double)X[(size_t)t * P + i] * (double)X[(size_t)t * P + j];
+    for (int i = 0; i < P; ++i)
+      for (int j = 0; j < P; ++j)
+        om[(size_t)i * P + j] = 0.01 * (i == j ? om[(size_t)i * P + j] : 0.5 * om[(size_t)i * P + j]) / T;
+    HIP_TRY(s->omega.alloc((size_t)P * P));
+    HIP_TRY(hipMemcpy(s->omega.p, om.data(), om.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   *out = s;
+  return 0;
+}
+
+int ci_ll_session_hmc(ci_ll_session* s, int32_t num_chains, int32_t chain_offset,
+                      int32_t num_warmup, int32_t num_results, int32_t num_leapfrog,
+                      double target_accept, double initial_step_size, const uint32_t seed[2],
+                      double* draws, double* accept_rate, double* step_size) {
+  if (!s || !seed || !draws) return fail("NULL argument");
+  if (num_chains < 1 || num_results < 1 || num_warmup < 0 || num_leapfrog < 1)
+    return fail("need num_chains >= 1, num_results >= 1, num_warmup >= 0, num_leapfrog >= 1");
+  if (!(target_accept > 0.0 && target_accept < 1.0) || !(initial_step_size > 0.0))
+    return fail("need 0 < target_accept < 1 and initial_step_size > 0");
+  HIP_TRY(hipSetDevice(s->device));
+  const int P = s->P, C = num_chains, S = num_results;
+  s->h_draws.release(); s->h_acc.release(); s->h_eps.release();
+  HIP_TRY(s->h_draws.alloc((size_t)C * S * (3 + P)));
+  HIP_TRY(s->h_acc.alloc(C));
+  HIP_TRY(s->h_eps.alloc(C));
+  ci::HmcArgs a;
+  a.T = s->T; a.P = P; a.C = C; a.W = num_warmup; a.S = S; a.n_leap = num_leapfrog;
+  a.chain_offset = chain_offset; a.seed0 = seed[0]; a.seed1 = seed[1];
+  a.y = s->y.p; a.mask = s->mask.p; a.Xt = s->xt.p; a.omega = s->omega.p;
+  const ci_series_params& q = s->prm;
+  a.ig_a[0] = q.obs_conc; a.ig_b[0] = q.obs_scale;
+  a.ig_a[1] = q.level_conc; a.ig_b[1] = q.level_scale;
+  a.ig_a[2] = q.slope_conc; a.ig_b[2] = q.slope_scale;
+  a.init_log[0] = std::log(q.obs_scale0);
+  a.init_log[1] = std::log(std::max(q.level_scale0, 1e-4));
+  a.init_log[2] = std::log(std::max(q.slope_scale0, 1e-4));
+  a.a1 = s->a1; a.p10 = s->p10; a.p11 = s->p11;
+  a.target_accept = target_accept; a.eps0 = initial_step_size;
+  a.draws = s->h_draws.p; a.accept_rate = s->h_acc.p; a.step_size = s->h_eps.p;
+  const int D = s->D, L = s->L;
+#define CI_HMC_CASE(DD, LL) if (D == DD && L == LL) ci_launch_hmc_d##DD##_l##LL(&a, 0);
+  CI_HMC_CASE(1, 1) CI_HMC_CASE(1, 2) CI_HMC_CASE(1, 4) CI_HMC_CASE(1, 8) CI_HMC_CASE(1, 16)
+  CI_HMC_CASE(2, 1) CI_HMC_CASE(2, 2) CI_HMC_CASE(2, 4) CI_HMC_CASE(2, 8) CI_HMC_CASE(2, 16)
+#undef CI_HMC_CASE
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(draws, s->h_draws.p, s->h_draws.n * sizeof(double), hipMemcpyDeviceToHost));
+  if (accept_rate) HIP_TRY(hipMemcpy(accept_rate, s->h_acc.p, C * sizeof(double), hipMemcpyDeviceToHost));
+  if (step_size) HIP_TRY(hipMemcpy(step_size, s->h_eps.p, C * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -685,6 +746,7 @@ int ci_ll_session_destroy(ci_ll_session* s) {
   (void)hipSetDevice(s->device);
   s->y.release(); s->xt.release(); s->mask.release(); s->theta.release(); s->ll.release();
   s->grad.release(); s->level.release(); s->slope.release(); s->loc.release(); s->traj.release();
+  s->omega.release(); s->h_draws.release(); s->h_acc.release(); s->h_eps.release();
   delete s;
   return 0;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ci_kernels.h"
+#include "ci_hmc.h"
 
 #ifndef CI_D
 #error "define CI_D"
@@ -74,6 +75,12 @@ void CI_CAT(ci_launch_latents_d, CI_D, _l, CI_L)(int T, int P, int E, const floa
   hipLaunchKernelGGL((ci::latents_kernel<CI_D, CI_L>), dim3(E), dim3(ci::NT), 0, stream, T, P, y,
                      mask, Xt, theta, a1, p10, p11, k0, k1, rng_chain, iter0, level, slope, loc,
                      traj);
+}
+
+// Runs the on-device HMC fit: one workgroup per chain.
+void CI_CAT(ci_launch_hmc_d, CI_D, _l, CI_L)(const ci::HmcArgs* args, hipStream_t stream) {
+  const size_t lds = ci::hmc_lds_bytes(args->P);
+  hipLaunchKernelGGL((ci::hmc_kernel<CI_D, CI_L>), dim3(args->C), dim3(ci::NT), lds, stream, *args);
 }
 
 }  // extern "C"

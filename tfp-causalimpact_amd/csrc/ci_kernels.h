@@ -1506,20 +1506,17 @@ __device__ __forceinline__ NElem<D> nelem_compose(const NElem<D>& o, const NElem
   return r;
 }
 
+// Log-likelihood and score of ONE parameter set th = (sigma_obs, sigma_level, sigma_slope, beta[P])
+// by the whole 256-thread workgroup: ll -> *out_ll, d ll / d th -> out_grad[3 + P].  Contains
+// __syncthreads(); slots: 3 * NW * 16 floats, part: NW * (P + 4) floats (LDS).  The results are
+// written by threads 0 .. P+3: the caller synchronises before reading them.
 template <int D, int L>
-__global__ __launch_bounds__(NT) void loglik_grad_kernel(int T, int P, const float* __restrict__ y,
-                                                         const uint8_t* __restrict__ mask,
-                                                         const float* __restrict__ Xt,
-                                                         const double* __restrict__ theta, float a1,
-                                                         float p10, float p11,
-                                                         double* __restrict__ out_ll,
-                                                         double* __restrict__ out_grad) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
-  float* slots = (float*)smem_g;                 // 3 * NW * 16
-  float* part = slots + 3 * NW * 16;             // NW * (P + 4)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const double* th = theta + (size_t)blockIdx.x * (3 + P);
+__device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __restrict__ y,
+                                                  const uint8_t* __restrict__ mask,
+                                                  const float* __restrict__ Xt, const double* th,
+                                                  float a1, float p10, float p11, float* slots,
+                                                  float* part, double* out_ll, double* out_grad,
+                                                  int tid, int lane, int wave) {
   const int t0 = tid * L;
   float resid[L];
   uint32_t maskbits = 0;
@@ -1664,15 +1661,33 @@ __global__ __launch_bounds__(NT) void loglik_grad_kernel(int T, int P, const flo
   if (tid < NS) {
     double s = 0.0;
     for (int w = 0; w < NW; ++w) s += (double)part[w * NS + tid];
-    if (tid == 0) out_ll[blockIdx.x] = s;
+    if (tid == 0) *out_ll = s;
     else {
-      double* g = out_grad + (size_t)blockIdx.x * (3 + P);
+      double* g = out_grad;
       if (tid == 1) g[0] = 2.0 * th[0] * s;            // d/d sigma_obs   = 2 sigma dl/dH
       else if (tid == 2) g[1] = 2.0 * th[1] * s;       // d/d sigma_level
       else if (tid == 3) g[2] = (D == 2) ? 2.0 * th[2] * s : 0.0;
       else g[3 + (tid - 4)] = s;                       // d/d beta_j
     }
   }
+}
+
+template <int D, int L>
+__global__ __launch_bounds__(NT) void loglik_grad_kernel(int T, int P, const float* __restrict__ y,
+                                                         const uint8_t* __restrict__ mask,
+                                                         const float* __restrict__ Xt,
+                                                         const double* __restrict__ theta, float a1,
+                                                         float p10, float p11,
+                                                         double* __restrict__ out_ll,
+                                                         double* __restrict__ out_grad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+  float* slots = (float*)smem_g;                 // 3 * NW * 16
+  float* part = slots + 3 * NW * 16;             // NW * (P + 4)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  loglik_grad_block<D, L>(T, P, y, mask, Xt, theta + (size_t)blockIdx.x * (3 + P), a1, p10, p11,
+                          slots, part, out_ll + blockIdx.x,
+                          out_grad + (size_t)blockIdx.x * (3 + P), tid, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------

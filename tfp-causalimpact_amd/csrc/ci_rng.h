@@ -16,7 +16,9 @@ enum Site : uint32_t {
   SITE_PERM = 1, SITE_FLIP = 2, SITE_OBSVAR = 3, SITE_WEIGHTS = 4, SITE_PRIOR_INIT = 5,
   SITE_PRIOR_LEVEL = 6, SITE_PRIOR_SLOPE = 7, SITE_PRIOR_OBS = 8, SITE_PRIOR_SEAS = 9,
   SITE_LEVEL_SCALE = 10, SITE_SLOPE_SCALE = 11, SITE_DRIFT_SCALE = 12, SITE_OBS_SCALE = 13,
-  SITE_PRED = 14
+  SITE_PRED = 14,
+  // HMC extension (ci_hmc.h): momentum, accept uniform, initial jitter
+  SITE_HMC_MOMENTUM = 15, SITE_HMC_ACCEPT = 16, SITE_HMC_INIT = 17
 };
 
 struct U4 { uint32_t x, y, z, w; };

@@ -15,3 +15,16 @@ for S, C in ((200, 8), (1000, 8)):
   dt = time.time() - t0
   print(f"HMC S={S} C={C}: {dt:.2f} s -> {S*C/dt:.0f} samples/s; rhat {an.diagnostics['split_rhat']}")
   print(an.summary[["abs_effect", "abs_effect_lower", "abs_effect_upper"]])
+
+# sampler alone (device chain + latent / trajectory draws), no host post-processing
+from causalimpact import _hmc, _model
+ys, mask, Xs, _ = syn.make_sampler_inputs(T, p, 0)
+spec = _model.series_params(ys, mask, Xs, has_slope=True)
+for C in (8, 64):
+  _hmc.fit_hmc(ys, mask, Xs, spec, has_slope=True, num_results=50, num_warmup=10, num_chains=2, seed=1)
+  t0 = time.time()
+  out = _hmc.fit_hmc(ys, mask, Xs, spec, has_slope=True, num_results=1000, num_warmup=112,
+                     num_chains=C, seed=1)
+  dt = time.time() - t0
+  print(f"fit_hmc alone C={C}: {dt:.3f} s -> {1000*C/dt:.0f} samples/s; accept {out['hmc_accept_rate'].mean():.2f}"
+        f" eps {out['hmc_step_size'].mean():.3f}")

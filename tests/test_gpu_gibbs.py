@@ -151,6 +151,32 @@ def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, season
   assert got["seasonal_levels"].shape == (1, 1, S, T, K)
 
 
+def test_time_parallel_and_sequential_seasonal_kernels_sample_the_same_posterior():
+  """Beyond the first draws (where the two kernels agree per random number): long runs of the
+  time-parallel kernel and of the sequential one give the same posterior summaries."""
+  from causalimpact import _model
+  T, p, seasons, S, C = 400, 3, ((7, 1),), 400, 4
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 21)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  spec = orc.default_spec(y, mask, X, has_slope=False, seasons=seasons)
+  counts, flg = _model.expand_seasons(seasons, T)
+  res = {}
+  for name, flags in (("wide", 0), ("seq", SEQ)):
+    pb = _native.make_problem(T=T, P=spec["P"], has_slope=0, num_seasons=counts, num_warmup=100,
+                              num_results=S, num_chains=C, seed=(8, 1), flags=flags)
+    res[name] = _native.fit_gibbs(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+  w, q = res["wide"], res["seq"]
+  for key, tol in (("observation_noise_scale", 0.02), ("level_scale", 0.05),
+                   ("seasonal_drift_scales", 0.10)):
+    np.testing.assert_allclose(w[key].mean(), q[key].mean(), rtol=tol, err_msg=key)
+  np.testing.assert_allclose(w["weights"].mean(axis=(0, 1, 2)), q["weights"].mean(axis=(0, 1, 2)),
+                             atol=0.02)
+  np.testing.assert_allclose(w["posterior_means"].mean(axis=(0, 1)),
+                             q["posterior_means"].mean(axis=(0, 1)), atol=0.05)
+  np.testing.assert_allclose(w["seasonal_levels"].mean(axis=(0, 1, 2))[:, 0],
+                             q["seasonal_levels"].mean(axis=(0, 1, 2))[:, 0], atol=0.03)
+
+
 def test_baseline_cfg4_shape_matches_oracle_per_draw():
   """BASELINE 'T=10000, 50 covariates + Seasonal(num_seasons=7)' at full size: the first
   draws agree with the oracle per random number (level / seasonal effect to 1e-3, weights and

@@ -65,17 +65,28 @@ __global__ __launch_bounds__(256) void summ_cumsum_kernel(int N, int T,
   const uint8_t* flags = flags_all + b * T;
   double* per_draw = per_draw_all + b * 2 * N;
   double c = 0.0, pred_sum = 0.0, point_sum = 0.0;
-  for (int t = 0; t < T; ++t) {
-    const double p = predT[(size_t)t * N + n];
-    const double point = -__dsub_rn(p, obs[t]);
-    const unsigned f = flags[t];
-    const double base = (f & 1u) ? point : 0.0;
-    const bool hole = base != base;
-    c = __dadd_rn(c, hole ? 0.0 : base);
-    cumT[(size_t)t * N + n] = hole ? base : c;
-    if (f & 2u) {
-      pred_sum = __dadd_rn(pred_sum, p);
-      point_sum = __dadd_rn(point_sum, (point != point) ? 0.0 : point);
+  // The sums are strictly sequential in t (numpy's rounding order); the loads are not: 8 rows
+  // are fetched ahead of the dependent adds.
+  for (int t8 = 0; t8 < T; t8 += 8) {
+    double p8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p8[u] = (t8 + u < T) ? predT[(size_t)(t8 + u) * N + n] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t8 + u;
+      if (t < T) {
+        const double p = p8[u];
+        const double point = -__dsub_rn(p, obs[t]);
+        const unsigned f = flags[t];
+        const double base = (f & 1u) ? point : 0.0;
+        const bool hole = base != base;
+        c = __dadd_rn(c, hole ? 0.0 : base);
+        cumT[(size_t)t * N + n] = hole ? base : c;
+        if (f & 2u) {
+          pred_sum = __dadd_rn(pred_sum, p);
+          point_sum = __dadd_rn(point_sum, (point != point) ? 0.0 : point);
+        }
+      }
     }
   }
   per_draw[n] = pred_sum;

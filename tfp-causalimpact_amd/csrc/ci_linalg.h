@@ -257,6 +257,125 @@ __device__ __forceinline__ FElem<D> felem_combine(const FElem<D>& e1, const FEle
   return r;
 }
 
+// ---- the same element with C and J stored as packed upper triangles, and a combine that
+// (i) never forms (I + C1 J2)^-1: one Gauss-Jordan elimination (no pivoting -- I + C1 J2 with
+//     C1, J2 positive semi-definite has eigenvalues >= 1; checked against pivoted LAPACK
+//     inverses in float32, tools/proto_wide_scan.py) solves for W^-1 [A1 | C1 | b1 + C1 eta2];
+// (ii) computes only the upper triangles of the two symmetric results.
+// ~2.8k FMAs at d = 7 instead of ~4.2k instructions, and 119 instead of 161 floats to shuffle.
+template <int D> struct FElemS {
+  Mat<D> A;
+  Vec<D> b;
+  float C[D * (D + 1) / 2];
+  Vec<D> eta;
+  float J[D * (D + 1) / 2];
+};
+template <int D> __host__ __device__ constexpr int symidx(int i, int j) {
+  return i <= j ? i * D - i * (i - 1) / 2 + (j - i) : j * D - j * (j - 1) / 2 + (i - j);
+}
+template <int D> __device__ __forceinline__ FElemS<D> felems_pack(const FElem<D>& e) {
+  FElemS<D> r;
+  r.A = e.A; r.b = e.b; r.eta = e.eta;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      r.C[symidx<D>(i, j)] = 0.5f * (e.C.m[i][j] + e.C.m[j][i]);
+      r.J[symidx<D>(i, j)] = 0.5f * (e.J.m[i][j] + e.J.m[j][i]);
+    }
+  return r;
+}
+template <int D> __device__ __forceinline__ FElemS<D> felems_identity() {
+  return felems_pack(felem_identity<D>());
+}
+template <int D>
+__device__ __forceinline__ FElemS<D> felems_combine(const FElemS<D>& e1, const FElemS<D>& e2) {
+  // W = I + C1 J2 ; right-hand sides RA = A1, RC = C1, u = b1 + C1 eta2
+  Mat<D> W, RA = e1.A, RC;
+  Vec<D> u;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    float ui = e1.b.v[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = (i == j) ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fmaf(e1.C[symidx<D>(i, k)], e2.J[symidx<D>(k, j)], s);
+      W.m[i][j] = s;
+      RC.m[i][j] = e1.C[symidx<D>(i, j)];
+      ui = fmaf(e1.C[symidx<D>(i, j)], e2.eta.v[j], ui);
+    }
+    u.v[i] = ui;
+  }
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    const float rp = 1.0f / W.m[c][c];
+#pragma unroll
+    for (int j = c + 1; j < D; ++j) W.m[c][j] *= rp;
+#pragma unroll
+    for (int j = 0; j < D; ++j) { RA.m[c][j] *= rp; RC.m[c][j] *= rp; }
+    u.v[c] *= rp;
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      if (r == c) continue;
+      const float f = W.m[r][c];
+#pragma unroll
+      for (int j = c + 1; j < D; ++j) W.m[r][j] = fmaf(-f, W.m[c][j], W.m[r][j]);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        RA.m[r][j] = fmaf(-f, RA.m[c][j], RA.m[r][j]);
+        RC.m[r][j] = fmaf(-f, RC.m[c][j], RC.m[r][j]);
+      }
+      u.v[r] = fmaf(-f, u.v[c], u.v[r]);
+    }
+  }
+  FElemS<D> r;
+  r.A = mm(e2.A, RA);
+  r.b = vadd(mv(e2.A, u), e2.b);
+  {
+    const Mat<D> T1 = mm(e2.A, RC);               // A2 W^-1 C1
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) {
+        float s = e2.C[symidx<D>(i, j)];
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = fmaf(T1.m[i][k], e2.A.m[j][k], s);
+        r.C[symidx<D>(i, j)] = s;
+      }
+  }
+  {
+    Mat<D> T2;                                    // J2 W^-1 A1
+    Vec<D> w = e2.eta;                            // eta2 - J2 b1
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = fmaf(e2.J[symidx<D>(i, k)], RA.m[k][j], s);
+        T2.m[i][j] = s;
+        w.v[i] = fmaf(-e2.J[symidx<D>(i, j)], e1.b.v[j], w.v[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float s = e1.eta.v[i];
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fmaf(RA.m[k][i], w.v[k], s);
+      r.eta.v[i] = s;
+#pragma unroll
+      for (int j = i; j < D; ++j) {
+        float t = e1.J[symidx<D>(i, j)];
+#pragma unroll
+        for (int k = 0; k < D; ++k) t = fmaf(e1.A.m[k][i], T2.m[k][j], t);
+        r.J[symidx<D>(i, j)] = t;
+      }
+    }
+  }
+  return r;
+}
+
 // Affine map r_out = M r_in + c (backward smoothing recursion).
 template <int D> struct AElem {
   Mat<D> M;

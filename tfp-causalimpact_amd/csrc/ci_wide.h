@@ -393,16 +393,22 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
     }
   }
   prof.tick(21);
-  const FElem<D> fpre = block_scan_excl_fwd_rolled(
-      fe, [](const FElem<D>& x, const FElem<D>& y) { return felem_combine(x, y); },
-      felem_identity<D>(), fslots, lane, wave);
+  const FElemS<D> fpre = block_scan_excl_fwd_rolled(
+      felems_pack(fe), [](const FElemS<D>& x, const FElemS<D>& y) { return felems_combine(x, y); },
+      felems_identity<D>(), fslots, lane, wave);
   prof.tick(22);
 
   // ---- (3) local Kalman filter from the predicted moments at the start of the chunk
   {
     Vec<D> am;
     Mat<D> Pm;
-    if (tid == 0) { am = a1e; Pm = P1; } else { am = fpre.b; Pm = fpre.C; }
+    if (tid == 0) { am = a1e; Pm = P1; } else {
+      am = fpre.b;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Pm.m[i][j] = fpre.C[symidx<D>(i, j)];
+    }
 #pragma unroll 1
     for (int g4 = 0; g4 < Lc; g4 += 4) {
       const int t4 = t0 + g4;

@@ -19,6 +19,21 @@ def model(TR, NS):
   Z = np.zeros(D); Z[0] = 1.0; Z[o] = 1.0
   return D, o, Tm, Tc, Z
 
+def gj_nopivot(M):
+  n = M.shape[-1]
+  a = M.copy(); inv = np.broadcast_to(np.eye(n, dtype=M.dtype), M.shape).copy()
+  for c in range(n):
+    rp = (M.dtype.type(1) / a[:, c, c])[:, None]
+    a[:, c, :] = a[:, c, :] * rp; inv[:, c, :] = inv[:, c, :] * rp
+    for r in range(n):
+      if r == c: continue
+      f = a[:, r, c][:, None].copy()
+      a[:, r, :] = a[:, r, :] - f * a[:, c, :]
+      inv[:, r, :] = inv[:, r, :] - f * inv[:, c, :]
+  return inv
+
+INV = None
+
 def run(T=10000, TR=1, NS=7, steps_per_season=1, dt=np.float32, seed=0, so=0.45, sl=0.01, ss=0.003, sd=0.002):
   rng = np.random.default_rng(seed)
   D, o, Tm, Tc, Z = model(TR, NS)
@@ -79,7 +94,7 @@ def run(T=10000, TR=1, NS=7, steps_per_season=1, dt=np.float32, seed=0, so=0.45,
   def combine(e1, e2):
     A1, b1, C1, n1_, J1 = e1; A2, b2, C2, n2, J2 = e2
     M = I + C1 @ J2
-    Mi = np.linalg.inv(M.astype(dt)).astype(dt)
+    Mi = (gj_nopivot(M.astype(dt)) if INV == 'nopivot' else np.linalg.inv(M.astype(dt))).astype(dt)
     G = Mi @ A1; A2Mi = A2 @ Mi
     rA = A2 @ G
     rb = np.einsum('nij,nj->ni', A2Mi, b1 + np.einsum('nij,nj->ni', C1, n2)) + b2
@@ -105,6 +120,14 @@ def run(T=10000, TR=1, NS=7, steps_per_season=1, dt=np.float32, seed=0, so=0.45,
     errP = max(errP, np.max(np.abs(e[2][i] - Pf[t])) / np.max(np.abs(Pf[t])))
   print(f"T={T} TR={TR} NS={NS} sps={steps_per_season} dtype={dt.__name__}: max |mean err|/sd = {errm:.2e}, rel cov err = {errP:.2e}, max|J|={np.max(np.abs(e[4])):.1e}")
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "nopivot":
+  INV = 'nopivot'
+  for T in (1000, 10000):
+    for TR in (1, 2):
+      run(T=T, TR=TR)
+      run(T=T, TR=TR, so=0.05, sl=0.2, sd=0.1)     # high signal-to-noise: large C J
+  run(T=10000, TR=1, steps_per_season=3)
+  sys.exit(0)
 if __name__ == "__main__":
   for T in (1000, 10000):
     for TR in (1, 2):

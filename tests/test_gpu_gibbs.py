@@ -120,6 +120,8 @@ SEQ = _native.FLAG_SEQUENTIAL_SEASONAL
     (300, 2, 0, ((7, 2),), 0),                          # two steps per season, P=3 (pi=1)
     (1030, 20, 0, ((7, 1),), 0),                        # P=21: LDS regression block, padded chunks
     (777, 6, 1, ((7, (1, 2, 1, 1, 1, 1, 3)),), 0),      # ragged seasons, trend
+    (37, 0, 1, ((7, 1),), 0),                           # shorter than one chunk row, T % 4 != 0
+    (64, 2, 0, ((7, 30),), 0),                          # long seasons: two changes in the series
 ])
 def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, seasons, flags):
   """Seasonal kernels vs the oracle's (n-1)-dimensional Durbin-Koopman draw, same random
@@ -129,6 +131,9 @@ def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, season
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
   rng = np.random.default_rng(0)
   y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0) + 0.1 * rng.normal(size=T)
+  if T >= 100:                                          # missing outcomes inside the pre-period
+    mask = mask.copy()
+    mask[[2, 3, 40, T // 2]] = True
   spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
   counts, flg = _model.expand_seasons(seasons, T)
   S, K = 4, len(seasons)

@@ -122,6 +122,9 @@ SEQ = _native.FLAG_SEQUENTIAL_SEASONAL
     (777, 6, 1, ((7, (1, 2, 1, 1, 1, 1, 3)),), 0),      # ragged seasons, trend
     (37, 0, 1, ((7, 1),), 0),                           # shorter than one chunk row, T % 4 != 0
     (64, 2, 0, ((7, 30),), 0),                          # long seasons: two changes in the series
+    (200, 2, 1, ((4, 3),), 0),                          # quarterly-type block, trend (d = 5)
+    (150, 0, 0, ((2, 1),), 0),                          # n = 2: a single free effect
+    (330, 5, 0, ((5, 1),), 0), (96, 1, 1, ((3, 2),), 0), (240, 3, 0, ((6, (1, 1, 2, 1, 1, 3)),), 0),
 ])
 def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, seasons, flags):
   """Seasonal kernels vs the oracle's (n-1)-dimensional Durbin-Koopman draw, same random

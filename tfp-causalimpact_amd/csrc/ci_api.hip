@@ -19,8 +19,11 @@
 #include "ci_hmc.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(void);
-extern "C" void* ci_gibbs_wide_fn_tr1_ns7(void);
-extern "C" void* ci_gibbs_wide_fn_tr2_ns7(void);
+#define CI_WIDE_DECL(NS)                                  \
+  extern "C" void* ci_gibbs_wide_fn_tr1_ns##NS(void);     \
+  extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);
+CI_WIDE_DECL(2) CI_WIDE_DECL(3) CI_WIDE_DECL(4) CI_WIDE_DECL(5) CI_WIDE_DECL(6) CI_WIDE_DECL(7)
+#undef CI_WIDE_DECL
 
 // One object file per (D, L) instantiation (ci_inst.hip).
 #define CI_DECL(D, L)                                                                          \
@@ -146,7 +149,10 @@ template <class T> struct DevBuf {
 
 // Time-parallel trend + seasonal kernel (ci_wide.h): which instantiations exist.
 void* pick_wide_kernel(int has_slope, int num_seasons) {
-  if (num_seasons == 7) return has_slope ? ci_gibbs_wide_fn_tr2_ns7() : ci_gibbs_wide_fn_tr1_ns7();
+#define CI_WIDE_CASE(NS) \
+  if (num_seasons == NS) return has_slope ? ci_gibbs_wide_fn_tr2_ns##NS() : ci_gibbs_wide_fn_tr1_ns##NS();
+  CI_WIDE_CASE(2) CI_WIDE_CASE(3) CI_WIDE_CASE(4) CI_WIDE_CASE(5) CI_WIDE_CASE(6) CI_WIDE_CASE(7)
+#undef CI_WIDE_CASE
   return nullptr;
 }
 bool use_wide(const ci_problem* pb) {

@@ -36,6 +36,8 @@ def _fit_both(T, p, has_slope, W, S, C=1, seed=(5, 9), data_seed=0, chain_offset
     (1000, 10, 1),  # BASELINE cfg2 shape
     (700, 10, 0),   # L=4 with padding, local level
     (500, 24, 0),   # P=25 > 16: LDS-resident regression block (in-place sweeps)
+    (5000, 3, 0),   # T > 4096: trend-only series on the time-parallel kernel (inert seasonal block)
+    (9000, 2, 1),   # same with a local linear trend
 ])
 def test_first_iterations_match_oracle_per_draw(T, p, has_slope):
   S = 4
@@ -50,9 +52,11 @@ def test_first_iterations_match_oracle_per_draw(T, p, has_slope):
   if P:
     np.testing.assert_array_equal(got["weights"][0, 0] != 0, w["weights"] != 0)
     np.testing.assert_allclose(got["weights"][0, 0], w["weights"], atol=5e-3)
-  np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=5e-3)
-  np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
-  np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=5e-3)
+  # float32 trend recursions over thousands of steps: tolerance relative to the path's range
+  lev_tol = 5e-3 if T <= 4096 else 5e-3 + 2e-3 * float(np.ptp(w["level"]))
+  np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=lev_tol)
+  np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=2 * lev_tol)
+  np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=lev_tol)
 
 
 def test_chain_ids_do_not_depend_on_launch_split():

@@ -199,6 +199,8 @@ struct ci_session {
   DevBuf<uint8_t> s_flags;
   DevBuf<int> s_ranks;
   bool ran = false;
+  ci_problem kpb;          // what the kernel runs (== pb except for long trend-only series)
+  bool inert_block = false;
 };
 
 extern "C" {
@@ -237,8 +239,9 @@ static int validate(const ci_problem* pb) {
   }
   if (pb->num_warmup < 0 || pb->num_results < 1) return fail("need num_warmup >= 0, num_results >= 1");
   if (pb->num_chains < 1 || pb->num_series < 1) return fail("need num_chains >= 1, num_series >= 1");
-  if (pb->num_blocks == 0 && steps_per_thread(pb->T) == 0)
-    return fail("T=%d exceeds the register-resident path (max %d)", pb->T, ci::NT * 16);
+  if (pb->num_blocks == 0 && steps_per_thread(pb->T) == 0 &&
+      wide_steps_per_thread(pb->T) > ci::WIDE_MAX_LC)
+    return fail("T=%d exceeds the longest supported series (%d)", pb->T, ci::NT * ci::WIDE_MAX_LC);
   return 0;
 }
 
@@ -252,9 +255,27 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   HIP_TRY(hipSetDevice(pb->device));
   ci_session* s = new ci_session();
   s->pb = *pb;
+  const ci_problem* caller_pb = pb;
+  // Trend-only series longer than the register-resident kernel holds (T > 4096) run on the
+  // time-parallel kernel (ci_wide.h) with one INERT seasonal block: 2 seasons, zero initial
+  // variance, no season changes => its effect is identically 0, the model and every random
+  // number of the trend / regression draws are unchanged (the block's own drift-scale draw uses
+  // its own Philox site).
+  s->kpb = *pb;
+  const bool long_trend = pb->num_blocks == 0 && steps_per_thread(pb->T) == 0;
+  std::vector<uint8_t> no_changes;
+  if (long_trend) {
+    s->kpb.num_blocks = 1;
+    s->kpb.num_seasons[0] = 2;
+    s->kpb.flags &= ~CI_FLAG_SEQUENTIAL_SEASONAL;
+    no_changes.assign((size_t)pb->T, 0);
+    season_change = no_changes.data();
+  }
+  pb = &s->kpb;
   const int T = pb->T, P = pb->P, B = pb->num_series, C = pb->num_chains, S = pb->num_results;
   const int D = pb->has_slope ? 2 : 1;
   const int K = pb->num_blocks;
+  (void)caller_pb;
   if (K == 0) {
     s->L = steps_per_thread(T);
     // X lives in LDS when the whole layout fits in 160 KiB (leave room for a second block).
@@ -307,8 +328,11 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     HIP_TRY(s->season_change.alloc((size_t)K * T));
     HIP_TRY(s->ssp.alloc(B));
     HIP_TRY(s->p1_chol.alloc((size_t)B * s->dred * s->dred));
-    HIP_TRY(s->o_drift.alloc(BCS * K));
-    HIP_TRY(s->o_seasonal.alloc(BCS * T * K));
+    s->inert_block = long_trend;
+    if (!long_trend) {
+      HIP_TRY(s->o_drift.alloc(BCS * K));
+      HIP_TRY(s->o_seasonal.alloc(BCS * T * K));
+    }
     if (s->wide) HIP_TRY(s->ws.alloc((size_t)B * C * ci::wide_workspace_floats(s->dred, s->Lc)));
     HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
     std::vector<ci::DevSeasonalParams> ssh(B);
@@ -316,8 +340,12 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     for (int b = 0; b < B; ++b) {
       const ci_series_params& q = params[b];
       ssh[b].drift_conc = q.drift_conc; ssh[b].drift_scale = q.drift_scale; ssh[b].drift_ub = q.drift_ub;
-      ssh[b].init_seasonal_scale = q.init_seasonal_scale;
+      ssh[b].init_seasonal_scale = long_trend ? 0.0 : q.init_seasonal_scale;
       for (int k = 0; k < CI_MAX_BLOCKS; ++k) ssh[b].drift_scale0[k] = q.drift_scale0[k];
+      if (long_trend) {      // the inert block's drift scale is drawn but never used
+        ssh[b].drift_conc = 1.0; ssh[b].drift_scale = 1.0; ssh[b].drift_ub = 1.0;
+        for (int k = 0; k < CI_MAX_BLOCKS; ++k) ssh[b].drift_scale0[k] = 0.0;
+      }
       // lower Cholesky factor of the prior covariance of x_0 in the (n-1)-effect coordinates:
       // diag(level, [slope]) (+) sd^2 (I - 11'/n) per block   
       const int dr = s->dred;
@@ -327,7 +355,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       if (pb->has_slope) { A[(size_t)1 * dr + 1] = q.init_slope_scale * q.init_slope_scale; o = 2; }
       for (int k = 0; k < K; ++k) {
         const int n = pb->num_seasons[k];
-        const double v = q.init_seasonal_scale * q.init_seasonal_scale;
+        const double v = long_trend ? 0.0 : q.init_seasonal_scale * q.init_seasonal_scale;
         for (int i = 0; i < n - 1; ++i)
           for (int j = 0; j < n - 1; ++j)
             A[(size_t)(o + i) * dr + o + j] = v * ((i == j ? 1.0 : 0.0) - 1.0 / n);
@@ -336,12 +364,12 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       for (int j = 0; j < dr; ++j) {
         double sdiag = A[(size_t)j * dr + j];
         for (int k2 = 0; k2 < j; ++k2) sdiag -= A[(size_t)j * dr + k2] * A[(size_t)j * dr + k2];
-        const double ljj = std::sqrt(sdiag);
+        const double ljj = sdiag > 0.0 ? std::sqrt(sdiag) : 0.0;
         A[(size_t)j * dr + j] = ljj;
         for (int i = j + 1; i < dr; ++i) {
           double t2 = A[(size_t)i * dr + j];
           for (int k2 = 0; k2 < j; ++k2) t2 -= A[(size_t)i * dr + k2] * A[(size_t)j * dr + k2];
-          A[(size_t)i * dr + j] = t2 / ljj;
+          A[(size_t)i * dr + j] = ljj > 0.0 ? t2 / ljj : 0.0;
         }
         for (int i = 0; i < j; ++i) A[(size_t)i * dr + j] = 0.0;
       }
@@ -417,11 +445,12 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
-  if (pb.num_blocks > 0) {
+  const ci_problem& kpb = s->kpb;
+  if (kpb.num_blocks > 0) {
     ci::SArgs sa;
     sa.k = a;
-    sa.K = pb.num_blocks; sa.has_slope = pb.has_slope; sa.dred = s->dred;
-    for (int k = 0; k < ci::SMAXK; ++k) sa.nseas[k] = k < pb.num_blocks ? pb.num_seasons[k] : 0;
+    sa.K = kpb.num_blocks; sa.has_slope = kpb.has_slope; sa.dred = s->dred;
+    for (int k = 0; k < ci::SMAXK; ++k) sa.nseas[k] = k < kpb.num_blocks ? kpb.num_seasons[k] : 0;
     sa.season_change = s->season_change.p; sa.ssp = s->ssp.p; sa.p1_chol = s->p1_chol.p;
     sa.out_drift = s->o_drift.p; sa.out_seasonal = s->o_seasonal.p;
     sa.ws = s->ws.p; sa.Lc = s->Lc;

@@ -940,7 +940,7 @@ struct SerialCtx {
 struct LdsLayout {
   size_t off_ctx, off_xtx, off_omega, off_aug0, off_aug1, off_pri0, off_pri1, off_chol, off_bvec,
       off_zv, off_uperm, off_nz, off_perm, off_idx, off_w, off_scal, off_red, off_slots, off_xlast,
-      off_tg, off_x, total;
+      off_tg, off_gam, off_x, total;
 };
 
 __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_in_lds) {
@@ -968,6 +968,7 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_slots = take(sizeof(float) * 3 * NW * 16);
   l.off_xlast = take(sizeof(float) * NT * D);
   l.off_tg = take(sizeof(float) * 16);
+  l.off_gam = take(sizeof(double) * 8);      // gamma draws handed from wave 1 to the serial wave
   l.off_x = take(x_in_lds ? sizeof(float) * (size_t)Pp * tpad : 16);
   l.total = o;
   return l;
@@ -980,10 +981,35 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
 // PM (regression mode) prunes dead code per instantiation -- the whole per-iteration path must
 // stay inside the 64 KB instruction cache: 0 = no regression, 1 = P <= 16 with X in LDS
 // (register-resident block), 2 = general (LDS block, X possibly streamed from L2).
+// The gamma variates the serial section of iteration `it` consumes (level / slope scale of
+// iteration it-1, and sigma^2_obs of iteration it or the observation scale of it-1).  They depend
+// on nothing but the shape parameters, so an otherwise idle wave draws them one iteration ahead
+// (double-buffered in LDS) while wave 0 is in the serial section: 2.6k cycles off the critical
+// path of every Gibbs iteration.  out[0..2] = (g_level, g_slope, g_obs).
+template <int PM>
+static __device__ __forceinline__ void serial_gammas(const SerialCtx* cx, int it, int lane,
+                                                     double* out) {
+  const int P = (PM == 0) ? 0 : cx->P, T = cx->T;
+  const bool have_prev = it > 0;
+  const bool want_obsvar = P > 0 && it < cx->n_iter;
+  const uint32_t pit = (uint32_t)(it > 0 ? it - 1 : 0);
+  const GammaReq rq_level{cx->sp.level_conc + 0.5 * (double)(T - 1), pit, SITE_LEVEL_SCALE, 0};
+  const GammaReq rq_slope{cx->sp.slope_conc + 0.5 * (double)(T - 1), pit, SITE_SLOPE_SCALE, 0};
+  const GammaReq rq_obs = want_obsvar
+      ? GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, (uint32_t)it, SITE_OBSVAR, 0}
+      : GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, pit, SITE_OBS_SCALE, 0};
+  const unsigned active = (have_prev ? 1u : 0u) | ((have_prev && cx->D == 2) ? 2u : 0u) |
+                          ((want_obsvar || (have_prev && P == 0)) ? 4u : 0u);
+  double g_level = 1.0, g_slope = 1.0, g_obs = 1.0;
+  if (active) gamma_wave3(rq_level, rq_slope, rq_obs, active, g_level, g_slope, g_obs, cx->rng, lane);
+  if (lane == 0) { out[0] = g_level; out[1] = g_slope; out[2] = g_obs; }
+}
+
 template <int PM>
 static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLds& R,
                                                       const float* red, float* scal, int it,
-                                                      int lane, PriorCarry& pc) {
+                                                      int lane, PriorCarry& pc,
+                                                      const double* gam) {
   // (R, red, scal are passed in rather than read from cx: loaded from the LDS context they
   //  would be generic pointers and every access a flat_* instruction)
   const int P = (PM == 0) ? 0 : cx->P, T = cx->T;
@@ -1002,23 +1028,10 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
   wave_sync();
   double obs_scale = cx->obs_scale, level_scale = cx->level_scale, slope_scale = cx->slope_scale;
   double emit_obs = obs_scale;
-  // all gamma draws of this section in one wave pass: level / slope / obs scale of iteration
-  // it-1 (gibbs_sampler._resample_scale) and sigma^2_obs of iteration it (spike-and-slab)
-  // quadrant 0: level scale, 1: slope scale, 2: observation noise (scale of it-1 when there is
-  // no regression, sigma^2_obs of iteration it otherwise -- never both)
-  const bool have_prev = it > 0;
-  const bool want_obsvar = P > 0 && it < cx->n_iter;
-  const uint32_t pit = (uint32_t)(it > 0 ? it - 1 : 0);
-  const GammaReq rq_level{cx->sp.level_conc + 0.5 * (double)(T - 1), pit, SITE_LEVEL_SCALE, 0};
-  const GammaReq rq_slope{cx->sp.slope_conc + 0.5 * (double)(T - 1), pit, SITE_SLOPE_SCALE, 0};
-  const GammaReq rq_obs = want_obsvar
-      ? GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, (uint32_t)it, SITE_OBSVAR, 0}
-      : GammaReq{cx->sp.obs_conc + 0.5 * cx->sp.n_obs, pit, SITE_OBS_SCALE, 0};
-  const unsigned active = (have_prev ? 1u : 0u) | ((have_prev && cx->D == 2) ? 2u : 0u) |
-                          ((want_obsvar || (have_prev && P == 0)) ? 4u : 0u);
-  double g_level = 1.0, g_slope = 1.0, g_obs = 1.0;
+  // the gamma draws of this section were made by wave 1 during the previous iteration
+  // (serial_gammas): level / slope scale of iteration it-1, sigma^2_obs of iteration it
   prof.tick(17);
-  if (active) gamma_wave3(rq_level, rq_slope, rq_obs, active, g_level, g_slope, g_obs, cx->rng, lane);
+  const double g_level = gam[0], g_slope = gam[1], g_obs = gam[2];
   prof.tick(18);
   auto clipped_scale = [](double scale, double ss, double g, double ub) {
     const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
@@ -1155,6 +1168,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     if (tid < P) wls[tid] = 0.f;                   // weights = 0            :575-578
   }
   __syncthreads();
+  double* gam = (double*)(smem + lay.off_gam);
+  if (wave == 1) serial_gammas<PM>(cx, 0, lane, gam);     // (no draw is active at it = 0 but P > 0's)
   const float init_loc = scal[8], init_var = scal[9], init_svar = scal[10];
 
   // chain state
@@ -1262,7 +1277,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     prof.tick(0);
 
     // ---- serial section: scale draws for iteration it-1, regression draw for iteration it
-    if (wave == 0) serial_section<PM>(cx, R, red, scal, it, lane, pc);
+    if (wave == 0) serial_section<PM>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1));
+    else if (wave == 1 && it < n_iter) serial_gammas<PM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));
     __syncthreads();
     prof.tick(1);
 

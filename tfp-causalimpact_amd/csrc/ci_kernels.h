@@ -344,21 +344,29 @@ __device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const V
 }
 
 // slots: 3 regions of NW * 16 floats.  Contains 3 __syncthreads().
+// The 3 L normals thread `owner` consumes in dk_draw (level, slope, observation disturbances of
+// its L steps).  They depend on (seed, chain, iteration) only, so the Gibbs kernel draws them
+// while wave 0 is in the serial section.
+template <int D, int L>
+__device__ __forceinline__ void dk_normals(const Rng& rng, uint32_t iter, int owner, float (&zl)[L],
+                                           float (&zs)[L], float (&zo)[L]) {
+  const uint32_t t0 = (uint32_t)owner * L;
+  fill_normals<L>(rng, iter, SITE_PRIOR_LEVEL, 0, t0, zl);
+  if constexpr (D == 2) fill_normals<L>(rng, iter, SITE_PRIOR_SLOPE, 0, t0, zs);
+  fill_normals<L>(rng, iter, SITE_PRIOR_OBS, 0, t0, zo);
+}
+
 template <int D, int L>
 __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
                                         uint32_t maskbits, const Rng& rng, uint32_t iter, int tid,
                                         int lane, int wave, float* slots, Vec<D> (&xout)[L],
-                                        Prof& prof) {
-  const uint32_t t0 = (uint32_t)tid * L;
+                                        Prof& prof, const float (&zl)[L], const float (&zs)[L],
+                                        const float (&zo)[L], const float* zinit = nullptr) {
   Vec<D> q;
 #pragma unroll
   for (int i = 0; i < D; ++i) q.v[i] = md.sig.v[i] * md.sig.v[i];
 
   // ---- (1) simulate x+ from the prior with zero initial mean: a scan of x <- T x + n_t
-  float zl[L], zs[L], zo[L];
-  fill_normals<L>(rng, iter, SITE_PRIOR_LEVEL, 0, t0, zl);
-  if constexpr (D == 2) fill_normals<L>(rng, iter, SITE_PRIOR_SLOPE, 0, t0, zs);
-  fill_normals<L>(rng, iter, SITE_PRIOR_OBS, 0, t0, zo);
   // The initial draw x+_0 = chol(P_1) z is NOT propagated through the simulated path (it
   // would grow like t * slope+_0 and cancel against the smoother in float32).  By linearity
   // it is folded into the filter's prior mean instead:
@@ -370,7 +378,8 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       float zi[1];
-      fill_normals<1>(rng, iter, SITE_PRIOR_INIT, 0, (uint32_t)i, zi);
+      if (zinit) zi[0] = zinit[i];       // drawn ahead by an idle wave (same site, same index)
+      else fill_normals<1>(rng, iter, SITE_PRIOR_INIT, 0, (uint32_t)i, zi);
       a1e.v[i] = fmaf(__fsqrt_rn(md.p1.v[i]), zi[0], md.a1.v[i]);
     }
   }
@@ -442,6 +451,18 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
     }
   }
   prof.tick(7);
+}
+
+template <int D, int L>
+__device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
+                                        uint32_t maskbits, const Rng& rng, uint32_t iter, int tid,
+                                        int lane, int wave, float* slots, Vec<D> (&xout)[L],
+                                        Prof& prof) {
+  float zl[L], zs[L], zo[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) zs[l] = 0.f;
+  dk_normals<D, L>(rng, iter, tid, zl, zs, zo);
+  dk_draw<D, L>(md, resid, maskbits, rng, iter, tid, lane, wave, slots, xout, prof, zl, zs, zo);
 }
 
 // ------------------------------------------------------------------------------------
@@ -940,7 +961,7 @@ struct SerialCtx {
 struct LdsLayout {
   size_t off_ctx, off_xtx, off_omega, off_aug0, off_aug1, off_pri0, off_pri1, off_chol, off_bvec,
       off_zv, off_uperm, off_nz, off_perm, off_idx, off_w, off_scal, off_red, off_slots, off_xlast,
-      off_tg, off_gam, off_x, total;
+      off_tg, off_gam, off_nz0, off_x, total;
 };
 
 __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_in_lds) {
@@ -969,6 +990,7 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_xlast = take(sizeof(float) * NT * D);
   l.off_tg = take(sizeof(float) * 16);
   l.off_gam = take(sizeof(double) * 8);      // gamma draws handed from wave 1 to the serial wave
+  l.off_nz0 = take(sizeof(float) * (4 * 64 * (tpad / NT) + 4));   // wave 0's normals, drawn by waves 1-3
   l.off_x = take(x_in_lds ? sizeof(float) * (size_t)Pp * tpad : 16);
   l.total = o;
   return l;
@@ -1169,6 +1191,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   }
   __syncthreads();
   double* gam = (double*)(smem + lay.off_gam);
+  float* nz0 = (float*)(smem + lay.off_nz0);
   if (wave == 1) serial_gammas<PM>(cx, 0, lane, gam);     // (no draw is active at it = 0 but P > 0's)
   const float init_loc = scal[8], init_var = scal[9], init_svar = scal[10];
 
@@ -1191,6 +1214,51 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   Prof prof;
   prof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && tid == 0);
   for (int it = 0; it <= n_iter; ++it) {
+    // ---- emit iteration it-1: level / slope / posterior-predictive trajectory
+    auto emit = [&](float so, const float* zp_lds) {
+      const int s = it - 1 - a.W;
+      float zp[L];
+      if (zp_lds) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) zp[l] = zp_lds[l * 64 + lane];
+      } else {
+        fill_normals<L>(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)t0, zp);
+      }
+      float tr[L];
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const float loc = lev[l] + xw[l];
+        pm_acc[l] += loc;
+        tr[l] = fmaf(so, zp[l], loc);
+      }
+      const size_t row = (size_t)s * T;
+      bool vec_done = false;
+      if constexpr (L % 4 == 0) {
+        if ((T & 3) == 0) {
+          vec_done = true;
+#pragma unroll
+          for (int q = 0; q < L / 4; ++q) {
+            const int t = t0 + 4 * q;
+            if (t < T) {
+              if (o_level) *(float4*)(o_level + row + t) = make_float4(lev[4 * q], lev[4 * q + 1], lev[4 * q + 2], lev[4 * q + 3]);
+              if (o_slope) *(float4*)(o_slope + row + t) = make_float4(slp[4 * q], slp[4 * q + 1], slp[4 * q + 2], slp[4 * q + 3]);
+              if (o_traj) *(float4*)(o_traj + row + t) = make_float4(tr[4 * q], tr[4 * q + 1], tr[4 * q + 2], tr[4 * q + 3]);
+            }
+          }
+        }
+      }
+      if (!vec_done) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const int t = t0 + l;
+          if (t < T) {
+            if (o_level) o_level[row + t] = lev[l];
+            if (o_slope) o_slope[row + t] = slp[l];
+            if (o_traj) o_traj[row + t] = tr[l];
+          }
+        }
+      }
+    };
     // ---- partial sums over the owned steps (targets use the CURRENT level)
     {
       float tg[L];
@@ -1273,55 +1341,56 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         red[wave * RS + RS - 2] = s2;
       }
     }
+    // sigma_obs of iteration it-1's regression draw: the noise scale of its predictive trajectory
+    // when there is a regression (read before wave 0 rewrites it in the serial section)
+    const float so_prev = scal[SC_OBS_DK];
     __syncthreads();
     prof.tick(0);
 
     // ---- serial section: scale draws for iteration it-1, regression draw for iteration it
-    if (wave == 0) serial_section<PM>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1));
-    else if (wave == 1 && it < n_iter) serial_gammas<PM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));
+    // (wave 0).  Meanwhile waves 1-3 do everything that does not depend on its results: next
+    // iteration's gamma variates, the emission of iteration it-1, their own Durbin-Koopman
+    // normals and -- one disturbance type each -- wave 0's.
+    float zl[L], zs[L], zo[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) zs[l] = 0.f;
+    if (wave == 0) {
+      serial_section<PM>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1));
+    } else {
+      if (wave == 1 && it < n_iter) serial_gammas<PM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));
+      if constexpr (PM != 0) {
+        if (it > a.W) {
+          emit(so_prev, nullptr);
+          if (wave == 3) {      // wave 0's predictive normals of iteration it-1
+            float zp0[L];
+            fill_normals<L>(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)(lane * L), zp0);
+#pragma unroll
+            for (int l = 0; l < L; ++l) nz0[(3 * L + l) * 64 + lane] = zp0[l];
+          }
+        }
+      }
+      if (wave == 2 && it < n_iter && lane < D) {     // x+_0 normals of thread 0
+        float zi[1];
+        fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)lane, zi);
+        nz0[4 * L * 64 + lane] = zi[0];
+      }
+      if (it < n_iter) {
+        dk_normals<D, L>(rng, (uint32_t)it, tid, zl, zs, zo);
+        if (D == 2 || wave != 2) {
+          const uint32_t site = wave == 1 ? SITE_PRIOR_LEVEL : (wave == 2 ? SITE_PRIOR_SLOPE : SITE_PRIOR_OBS);
+          float z0[L];
+          fill_normals<L>(rng, (uint32_t)it, site, 0, (uint32_t)(lane * L), z0);
+#pragma unroll
+          for (int l = 0; l < L; ++l) nz0[((wave - 1) * L + l) * 64 + lane] = z0[l];
+        }
+      }
+    }
     __syncthreads();
     prof.tick(1);
 
-    // ---- emit iteration it-1: level / slope / posterior-predictive trajectory
     if (it > a.W) {
-      const int s = it - 1 - a.W;
-      const float so = scal[SC_OBS_EMIT];
-      float zp[L];
-      fill_normals<L>(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)t0, zp);
-      float tr[L];
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const float loc = lev[l] + xw[l];
-        pm_acc[l] += loc;
-        tr[l] = fmaf(so, zp[l], loc);
-      }
-      const size_t row = (size_t)s * T;
-      bool vec_done = false;
-      if constexpr (L % 4 == 0) {
-        if ((T & 3) == 0) {
-          vec_done = true;
-#pragma unroll
-          for (int q = 0; q < L / 4; ++q) {
-            const int t = t0 + 4 * q;
-            if (t < T) {
-              if (o_level) *(float4*)(o_level + row + t) = make_float4(lev[4 * q], lev[4 * q + 1], lev[4 * q + 2], lev[4 * q + 3]);
-              if (o_slope) *(float4*)(o_slope + row + t) = make_float4(slp[4 * q], slp[4 * q + 1], slp[4 * q + 2], slp[4 * q + 3]);
-              if (o_traj) *(float4*)(o_traj + row + t) = make_float4(tr[4 * q], tr[4 * q + 1], tr[4 * q + 2], tr[4 * q + 3]);
-            }
-          }
-        }
-      }
-      if (!vec_done) {
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-          const int t = t0 + l;
-          if (t < T) {
-            if (o_level) o_level[row + t] = lev[l];
-            if (o_slope) o_slope[row + t] = slp[l];
-            if (o_traj) o_traj[row + t] = tr[l];
-          }
-        }
-      }
+      if constexpr (PM == 0) emit(scal[SC_OBS_EMIT], nullptr);
+      else if (wave == 0) emit(so_prev, nz0 + 3 * L * 64);   // waves 1-3 emitted during the serial section
     }
     prof.tick(2);
     if (it == n_iter) break;
@@ -1372,7 +1441,16 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     }
     Vec<D> x[L];
     prof.tick(3);
-    dk_draw<D, L>(md, resid, maskbits, rng, (uint32_t)it, tid, lane, wave, slots, x, prof);
+    if (wave == 0) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        zl[l] = nz0[(0 * L + l) * 64 + lane];
+        if constexpr (D == 2) zs[l] = nz0[(1 * L + l) * 64 + lane];
+        zo[l] = nz0[(2 * L + l) * 64 + lane];
+      }
+    }
+    dk_draw<D, L>(md, resid, maskbits, rng, (uint32_t)it, tid, lane, wave, slots, x, prof, zl, zs, zo,
+                  nz0 + 4 * L * 64);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       lev[l] = x[l].v[0];

@@ -641,11 +641,45 @@ __device__ __forceinline__ double unsweep_q(QCols& m, int k, int lane) {
   }
 }
 
+// Visiting order of the flip proposals (stable argsort of P uniforms: rank = step at which
+// feature j is visited) and the uniform each proposal is tested against.  All 64 lanes, j = lane & 15.
+__device__ __forceinline__ void spike_slab_perm(const Rng& rng, uint32_t iter, int P, int j,
+                                                bool live, int& rank, double& uflip) {
+  const double uperm = live ? uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j) : 2.0;
+  rank = 0;
+  for (int kk = 0; kk < P; ++kk) {
+    const double uk = readlane_d(uperm, kk);
+    rank += (uk < uperm || (uk == uperm && kk < j)) ? 1 : 0;
+  }
+  uflip = live ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)rank) : 2.0;
+}
+// The register-resident block's randomness for iteration `iter`, written to `pre` (LDS, 32
+// doubles) by a wave that is not in the serial section.
+__device__ __forceinline__ void spike_slab_randoms(const Rng& rng, uint32_t iter, int P, int lane,
+                                                   double* pre) {
+  const int j = lane & 15;
+  const bool live = j < P;
+  int rank;
+  double uflip;
+  spike_slab_perm(rng, iter, P, j, live, rank, uflip);
+  float zf[1];
+  fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)(live ? j : 0), zf);
+  if (lane < 16) {
+    pre[lane] = uflip;
+    reinterpret_cast<int*>(pre + 16)[lane] = rank;
+    reinterpret_cast<float*>(pre + 24)[lane] = zf[0];
+  }
+}
+
 __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
                                                        const DevSeriesParams& sp,
                                                        double prev_obs_scale, double g_obs,
                                                        const Rng& rng, uint32_t iter, int lane,
-                                                       Prof& prof, PriorCarry& pc) {
+                                                       Prof& prof, PriorCarry& pc,
+                                                       const double* pre = nullptr) {
+  // pre (optional, LDS): this iteration's data-independent randomness, drawn one iteration
+  // ahead by an idle wave (spike_slab_randoms): [0,16) flip uniforms by feature, [16,24) visiting
+  // ranks (int), [24,32) weight normals (float)
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
@@ -690,13 +724,14 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
   prof.tick(9);
   if (!all_in) {
     // visiting order = stable argsort of P uniforms (rank_j = step at which feature j is visited)
-    const double uperm = live ? uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j) : 2.0;
     int rank = 0;
-    for (int kk = 0; kk < P; ++kk) {
-      const double uk = readlane_d(uperm, kk);
-      rank += (uk < uperm || (uk == uperm && kk < j)) ? 1 : 0;
+    double uflip = 2.0;
+    if (pre) {
+      rank = reinterpret_cast<const int*>(pre + 16)[j];
+      uflip = pre[j];
+    } else {
+      spike_slab_perm(rng, iter, P, j, live, rank, uflip);
     }
-    const double uflip = live ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)rank) : 2.0;
     const double logit_pi =
         (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
     int s_cur = 0;
@@ -749,7 +784,8 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
   // oracle's Cholesky route): u_n = z_n / L_nn, u_{n-1} | u_n, ... -- but it reuses the swept
   // state instead of factorising M_S and back-substituting.
   float zf[1];
-  fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)col, zf);
+  if (pre) zf[0] = reinterpret_cast<const float*>(pre + 24)[col];
+  else fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)col, zf);
   const double mean = m.cb;
   double mu = 0.0, umine = 0.0;
   for (unsigned long long mm = S; mm != 0ull;) {
@@ -989,7 +1025,8 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_slots = take(sizeof(float) * 3 * NW * 16);
   l.off_xlast = take(sizeof(float) * NT * D);
   l.off_tg = take(sizeof(float) * 16);
-  l.off_gam = take(sizeof(double) * 8);      // gamma draws handed from wave 1 to the serial wave
+  l.off_gam = take(sizeof(double) * (8 + 64));   // gamma draws (wave 1) and regression-block randomness
+                                                 // (wave 2) handed to the serial wave, double-buffered
   l.off_nz0 = take(sizeof(float) * (4 * 64 * (tpad / NT) + 4));   // wave 0's normals, drawn by waves 1-3
   l.off_x = take(x_in_lds ? sizeof(float) * (size_t)Pp * tpad : 16);
   l.total = o;
@@ -1031,7 +1068,7 @@ template <int PM>
 static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLds& R,
                                                       const float* red, float* scal, int it,
                                                       int lane, PriorCarry& pc,
-                                                      const double* gam) {
+                                                      const double* gam, const double* pre) {
   // (R, red, scal are passed in rather than read from cx: loaded from the LDS context they
   //  would be generic pointers and every access a flat_* instruction)
   const int P = (PM == 0) ? 0 : cx->P, T = cx->T;
@@ -1080,7 +1117,8 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
   prof.tick(8);
   if (P > 0 && it < cx->n_iter) {
     if constexpr (PM == 1)
-      obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, pc);
+      obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, pc,
+                                       pre);
     else if constexpr (PM == 2)
       obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, it == 0);
   }
@@ -1193,6 +1231,9 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   double* gam = (double*)(smem + lay.off_gam);
   float* nz0 = (float*)(smem + lay.off_nz0);
   if (wave == 1) serial_gammas<PM>(cx, 0, lane, gam);     // (no draw is active at it = 0 but P > 0's)
+  if constexpr (PM == 1) {
+    if (wave == 2) spike_slab_randoms(rng, 0u, P, lane, gam + 8);
+  }
   const float init_loc = scal[8], init_var = scal[9], init_svar = scal[10];
 
   // chain state
@@ -1355,9 +1396,13 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) zs[l] = 0.f;
     if (wave == 0) {
-      serial_section<PM>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1));
+      serial_section<PM>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1));
     } else {
       if (wave == 1 && it < n_iter) serial_gammas<PM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));
+      if constexpr (PM == 1) {
+        if (wave == 2 && it + 1 < n_iter)
+          spike_slab_randoms(rng, (uint32_t)(it + 1), P, lane, gam + 8 + 32 * ((it + 1) & 1));
+      }
       if constexpr (PM != 0) {
         if (it > a.W) {
           emit(so_prev, nullptr);

@@ -125,25 +125,59 @@ class CausalImpactBatchAnalysis:
                 quantiles=(self.alpha / 2.0, 1.0 - self.alpha / 2.0))
 
   def _build_summary(self) -> pd.DataFrame:
-    p = self._prep
+    """The reference's 15 summary columns (causalimpact_lib.py:934-1093) for every series at
+    once: the same numpy reductions as `_summary_rows`, along axis 1 of [B, draws] arrays."""
+    p, B = self._prep, len(self)
     quantiles = (self.alpha / 2.0, 1.0 - self.alpha / 2.0)
-    frames = []
-    for b in range(len(self)):
-      rq = self._request(b)
-      win = (rq["flags"] & 2) != 0
-      obs_w = rq["observed"][win]
-      post_mean = (self._means[b].astype(np.float64) * rq["scale"] + rq["shift"])[win]
-      pred_sum, point_sum = self._dsum["per_draw"][b]
-      n_obs = int(np.sum(~np.isnan(obs_w)))
-      with np.errstate(invalid="ignore", divide="ignore"):
-        rows, p_value = lib._summary_rows(            # pylint: disable=protected-access
-            post_mean, obs_w, pred_sum / int(win.sum()), pred_sum,
-            point_sum / n_obs if n_obs else np.full_like(point_sum, np.nan), point_sum, quantiles)
-      f = pd.DataFrame({k: {"average": v[0], "cumulative": v[1]} for k, v in rows.items()})
-      f["p_value"] = p_value
-      f["alpha"] = self.alpha
-      frames.append(f)
-    return pd.concat(frames, keys=self._names, names=["series", None])
+    rq = self._request(0)
+    win = (rq["flags"] & 2) != 0
+    n_win = int(win.sum())
+    idx = p.index[p.model_rows]
+    in_post = np.asarray((idx >= p.post_period[0]) & (idx <= p.post_period[1]))
+    obs = p.values[:, p.model_rows, 0].copy()
+    obs[:, p.num_pre:][:, ~in_post[p.num_pre:]] = np.nan
+    obs_w = obs[:, win]                                                    # [B, T_w]
+    scale = p.outcome_sd if p.standardize_data else np.ones(B)
+    shift = p.outcome_mean if p.standardize_data else np.zeros(B)
+    post_mean = (self._means.astype(np.float64) * scale[:, None] + shift[:, None])[:, win]
+    pred_sum, point_sum = self._dsum["per_draw"][:, 0], self._dsum["per_draw"][:, 1]   # [B, N]
+    n_obs = np.sum(~np.isnan(obs_w), axis=1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+      obs_mean, obs_sum = np.nanmean(obs_w, axis=1), np.nansum(obs_w, axis=1)
+      pred_mean = pred_sum / n_win
+      point_mean = np.where(n_obs[:, None] > 0, point_sum / np.maximum(n_obs, 1)[:, None], np.nan)
+      rel = obs_sum[:, None] / pred_sum - 1.0
+
+      def band(x):
+        return np.quantile(x, quantiles, axis=1)
+
+      def sd(x):
+        return np.std(x, axis=1, ddof=1)
+
+      avg_pred, cum_pred = post_mean.mean(axis=1), post_mean.sum(axis=1)
+      cols = {
+          "actual": (obs_mean, obs_sum),
+          "predicted": (avg_pred, cum_pred),
+          "predicted_lower": (band(pred_mean)[0], band(pred_sum)[0]),
+          "predicted_upper": (band(pred_mean)[1], band(pred_sum)[1]),
+          "predicted_sd": (sd(pred_mean), sd(pred_sum)),
+          "abs_effect": (obs_mean - avg_pred, obs_sum - cum_pred),
+          "abs_effect_lower": (band(point_mean)[0], band(point_sum)[0]),
+          "abs_effect_upper": (band(point_mean)[1], band(point_sum)[1]),
+          "abs_effect_sd": (sd(point_mean), sd(point_sum)),
+          "rel_effect": (rel.mean(axis=1),) * 2,
+          "rel_effect_lower": (band(rel)[0],) * 2,
+          "rel_effect_upper": (band(rel)[1],) * 2,
+          "rel_effect_sd": (sd(rel),) * 2,
+      }
+    pool_le = ((obs_sum[:, None] <= pred_sum).sum(axis=1) + 1) / (pred_sum.shape[1] + 1)
+    pool_ge = ((obs_sum[:, None] >= pred_sum).sum(axis=1) + 1) / (pred_sum.shape[1] + 1)
+    p_value = np.minimum(pool_le, pool_ge)
+    data = {k: np.stack(v, axis=1).reshape(-1) for k, v in cols.items()}      # (b, avg|cum) order
+    data["p_value"] = np.repeat(p_value, 2)
+    data["alpha"] = np.full(2 * B, self.alpha)
+    index = pd.MultiIndex.from_product([self._names, ["average", "cumulative"]], names=["series", None])
+    return pd.DataFrame(data, index=index)
 
   def __getitem__(self, b: int) -> lib.CausalImpactAnalysis:
     b = range(len(self))[b]

@@ -236,3 +236,21 @@ def test_batch_of_series_equals_single_series_runs():
               "posterior_means"):
       np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
   assert not np.array_equal(batch["level"][0], batch["level"][1])
+
+
+def test_fit_causalimpact_over_several_device_shares_equals_one_launch():
+  """`InferenceOptions.devices` shards chains over devices, one host thread each.  With the
+  single test GPU listed twice the two shares run concurrently on it; pooled draws must be the
+  ones of a single launch (chain ids keep their RNG streams)."""
+  import pandas as pd
+  import causalimpact as ci
+  y, X = syn.make_raw_series(160, 2, 3)
+  df = pd.DataFrame(np.column_stack([y, X]), columns=["y", "x0", "x1"])
+  kw = dict(seed=11, model_options=ci.ModelOptions(local_linear_trend=True))
+  one = ci.fit_causalimpact(df, (0, 109), (110, 159), inference_options=ci.InferenceOptions(
+      num_results=60, num_chains=4, summarize_on_device=False), **kw)
+  two = ci.fit_causalimpact(df, (0, 109), (110, 159), inference_options=ci.InferenceOptions(
+      num_results=60, num_chains=4, devices=[0, 0]), **kw)
+  np.testing.assert_array_equal(one.posterior_samples.level, two.posterior_samples.level)
+  np.testing.assert_array_equal(one.posterior_samples.weights, two.posterior_samples.weights)
+  np.testing.assert_allclose(one.summary.to_numpy(float), two.summary.to_numpy(float), rtol=1e-12)

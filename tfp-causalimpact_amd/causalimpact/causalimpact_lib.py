@@ -292,17 +292,16 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
   shares = np.array_split(np.arange(num_chains), len(devs))
   parts = []
   device_summary = None
-  for dev, chain_ids in zip(devs, shares):
-    if len(chain_ids) == 0:
-      continue
+  def run_on(dev, chain_ids):
+    """One device's share of the chains (chain ids keep their global RNG streams)."""
+    nonlocal device_summary
     if sampler == "hmc":
       from causalimpact import _hmc  # pylint: disable=import-outside-toplevel
       res = _hmc.fit_hmc(y, mask, design, params, has_slope=local_linear_trend,
                          num_results=num_results, num_warmup=num_warmup_steps,
                          num_chains=len(chain_ids), seed=seed_pair, device=dev,
                          chain_offset=int(chain_ids[0]))
-      parts.append({k: v for k, v in res.items() if not k.startswith("hmc_")})
-      continue
+      return {k: v for k, v in res.items() if not k.startswith("hmc_")}
     pb = _native.make_problem(T=T, P=P, has_slope=local_linear_trend, num_seasons=num_seasons,
                               num_warmup=num_warmup_steps, num_results=num_results,
                               num_chains=len(chain_ids), chain_offset=int(chain_ids[0]),
@@ -312,8 +311,8 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
                              season_change, _native.make_params([params]))
       try:
         sess.run()
-        parts.append(sess.fetch([k for k in _native._OUT_FIELDS  # pylint: disable=protected-access
-                                 if k != "posterior_trajectories"]))
+        part = sess.fetch([k for k in _native._OUT_FIELDS  # pylint: disable=protected-access
+                           if k != "posterior_trajectories"])
         qs = _quantile_ranks(len(chain_ids) * num_results, summary_request["quantiles"])
         n_draws = len(chain_ids) * num_results
         want = sorted({r for lo, hi, _ in qs for r in (lo, hi)} |
@@ -323,10 +322,19 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
             **{k: summary_request[k] for k in ("scale", "shift", "observed", "flags", "ranks")})
       finally:
         sess.close()
-      continue
-    parts.append(_native.fit_gibbs(pb, y[None], mask[None],
-                                   None if design is None else design[None], season_change,
-                                   _native.make_params([params])))
+      return part
+    return _native.fit_gibbs(pb, y[None], mask[None], None if design is None else design[None],
+                             season_change, _native.make_params([params]))
+
+  work = [(dev, ids) for dev, ids in zip(devs, shares) if len(ids)]
+  if len(work) == 1:
+    parts = [run_on(*work[0])]
+  else:
+    # the library calls are synchronous and release the GIL: one host thread per device runs
+    # the shares concurrently (no collective: chains are independent)
+    import concurrent.futures  # pylint: disable=import-outside-toplevel
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(work)) as pool_:
+      parts = list(pool_.map(lambda a: run_on(*a), work))
   out = {k: np.concatenate([p[k][0] for p in parts], axis=0) for k in parts[0]}   # [C, ...]
 
   def pool(a):   # [C, S, ...] -> [C*S, ...]

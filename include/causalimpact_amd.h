@@ -138,6 +138,13 @@ int ci_session_summarize(ci_session* session, const double* scale, const double*
                          const double* observed, const uint8_t* flags, int32_t num_ranks,
                          const int32_t* ranks, double* value_order, double* cum_order,
                          double* per_draw);
+/* The same summary for draws that are on the host (pooled from several devices / processes, or
+ * produced by the HMC path): trajectories [num_draws, T] float32 are uploaded to `device`,
+ * summarised there and the (one-series) results returned as above. */
+int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float* trajectories,
+                       double scale, double shift, const double* observed, const uint8_t* flags,
+                       int32_t num_ranks, const int32_t* ranks, double* value_order,
+                       double* cum_order, double* per_draw);
 
 /* Kalman-filter log-likelihood of the trend + regression model for num_evals parameter sets
  * (the objective an HMC / VI fit would use; the reference never

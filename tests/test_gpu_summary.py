@@ -85,3 +85,18 @@ def test_summarize_argument_errors():
   with pytest.raises(_native.NativeError, match="out of range"):
     sess.summarize(1.0, 0.0, np.zeros(T), np.zeros(T, np.uint8), [8])
   sess.close()
+
+
+def test_host_pooled_draws_are_summarised_on_device_too():
+  """Multi-device shares and the HMC path pool their draws on the host; `ci_summarize_draws`
+  uploads them and gives the frames of the pure-host arithmetic."""
+  import ref_pins_common as rp
+  df = rp.create_test_data(8.0, 70, num_timesteps=100, seed=3)
+  pre, post = (df.index[0], df.index[69]), (df.index[72], df.index[-2])
+  for opts in (dict(num_results=120, num_chains=4, devices=[0, 0]),
+               dict(num_results=60, num_warmup_steps=80, num_chains=3, sampler="hmc")):
+    dev = ci.fit_causalimpact(df, pre, post, seed=2, inference_options=ci.InferenceOptions(**opts))
+    host = ci.fit_causalimpact(df, pre, post, seed=2, inference_options=ci.InferenceOptions(
+        summarize_on_device=False, **opts))
+    _assert_frames_equal(dev.series, host.series)
+    _assert_frames_equal(dev.summary, host.summary)

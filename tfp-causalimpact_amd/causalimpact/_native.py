@@ -78,6 +78,9 @@ def load():
   L.ci_session_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   L.ci_session_summarize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+  L.ci_summarize_draws.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
+                                   C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_kalman_loglik.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
   L.ci_ll_session_create.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
@@ -106,7 +109,7 @@ def exported_symbols() -> Sequence[str]:
   return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_fit_gibbs",
           "ci_session_create", "ci_session_run", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_session_profile",
-          "ci_session_summarize",
+          "ci_session_summarize", "ci_summarize_draws",
           "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_eval",
           "ci_ll_session_draw_latents", "ci_ll_session_hmc", "ci_ll_session_destroy", "ci_test_rng",
           "ci_test_dk_draw")
@@ -173,6 +176,22 @@ def _stage_inputs(pb: Problem, y, mask, X, season_change):
   if K > 0:
     sc = np.ascontiguousarray(np.asarray(season_change, dtype=np.uint8).reshape(K, T))
   return y32, mask8, X32, sc
+
+
+def summarize_draws(trajectories, scale, shift, observed, flags, ranks, device=0):
+  """ci_summarize_draws: on-device summary of host-resident [draws, T] float32 trajectories."""
+  tr = np.ascontiguousarray(trajectories, dtype=np.float32)
+  N, T = tr.shape
+  obs = np.ascontiguousarray(observed, dtype=np.float64).reshape(T)
+  fl = np.ascontiguousarray(flags, dtype=np.uint8).reshape(T)
+  rk = np.ascontiguousarray(ranks, dtype=np.int32)
+  vo = np.empty((rk.size, T), np.float64)
+  co = np.empty((rk.size, T), np.float64)
+  pd_ = np.empty((2, N), np.float64)
+  _check(load().ci_summarize_draws(int(device), N, T, tr.ctypes.data, float(scale), float(shift),
+                                   obs.ctypes.data, fl.ctypes.data, int(rk.size), rk.ctypes.data,
+                                   vo.ctypes.data, co.ctypes.data, pd_.ctypes.data))
+  return dict(value_order=vo, cum_order=co, per_draw=pd_)
 
 
 def _alloc_outputs(pb: Problem, want: Optional[Sequence[str]] = None):

@@ -255,9 +255,7 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
                                  outcome_sd=float(pre_sd[b])) for b in range(B)]
   seed_pair = lib._sanitize_seed(seed)   # pylint: disable=protected-access
   C, S = inference_options.num_chains, inference_options.num_results
-  qs = lib._quantile_ranks(C * S, (alpha / 2.0, 1.0 - alpha / 2.0))   # pylint: disable=protected-access
-  ranks = sorted({r for lo, hi, _ in qs for r in (lo, hi)} |
-                 {C * S - 1 - r for lo, hi, _ in qs for r in (lo, hi)})
+  ranks = lib._summary_ranks(C * S, (alpha / 2.0, 1.0 - alpha / 2.0))   # pylint: disable=protected-access
   idx = index[prep.model_rows]
   in_post = np.asarray((idx >= prep.post_period[0]) & (idx <= prep.post_period[1]))
   flags = (~np.asarray(idx < prep.post_period[0])).astype(np.uint8) | (in_post.astype(np.uint8) << 1)

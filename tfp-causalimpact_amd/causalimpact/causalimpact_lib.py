@@ -138,10 +138,8 @@ def fit_causalimpact(data: pd.DataFrame,
       standardize_data=data_options.standardize_data, dtype=data_options.dtype)
   if not 0 < alpha < 1:
     raise ValueError("`alpha` must be between 0 and 1.")
-  on_one_device = (inference_options.sampler == "gibbs" and
-                   len(inference_options.devices or [0]) == 1 and
-                   inference_options.summarize_on_device)
-  request = _device_summary_request(ci_data, alpha) if on_one_device else None
+  request = (_device_summary_request(ci_data, alpha) if inference_options.summarize_on_device
+             else None)
   samples, posterior_means, posterior_trajectories, device_summary = _run_sampler(
       ci_data=ci_data, prior_level_sd=model_options.prior_level_sd, seed=seed,
       num_results=inference_options.num_results,
@@ -149,6 +147,12 @@ def fit_causalimpact(data: pd.DataFrame,
       seasons=model_options.seasons, num_chains=inference_options.num_chains,
       devices=inference_options.devices, local_linear_trend=model_options.local_linear_trend,
       sampler=inference_options.sampler, summary_request=request)
+  if request is not None and device_summary is None:
+    # draws pooled on the host (several devices, or the HMC path): summarise them on one device
+    request["ranks"] = _summary_ranks(posterior_trajectories.shape[0], request["quantiles"])
+    device_summary = _native.summarize_draws(
+        posterior_trajectories, request["scale"], request["shift"], request["observed"],
+        request["flags"], request["ranks"], device=(inference_options.devices or [0])[0])
   if device_summary is not None:
     series, summary = _compute_impact_device(posterior_means, device_summary, request, ci_data,
                                              alpha)
@@ -313,11 +317,8 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
         sess.run()
         part = sess.fetch([k for k in _native._OUT_FIELDS  # pylint: disable=protected-access
                            if k != "posterior_trajectories"])
-        qs = _quantile_ranks(len(chain_ids) * num_results, summary_request["quantiles"])
-        n_draws = len(chain_ids) * num_results
-        want = sorted({r for lo, hi, _ in qs for r in (lo, hi)} |
-                      {n_draws - 1 - r for lo, hi, _ in qs for r in (lo, hi)})
-        summary_request["ranks"] = want
+        summary_request["ranks"] = _summary_ranks(len(chain_ids) * num_results,
+                                                  summary_request["quantiles"])
         device_summary = sess.summarize(
             **{k: summary_request[k] for k in ("scale", "shift", "observed", "flags", "ranks")})
       finally:
@@ -412,6 +413,14 @@ def _quantile_ranks(num_draws: int, quantiles):
       hi, gamma = lo + 1, virtual - lo
     out.append((lo, hi, gamma))
   return out
+
+
+def _summary_ranks(num_draws: int, quantiles) -> List[int]:
+  """Order statistics the two quantiles need, and their mirror images (effect = observed - value
+  reverses the order)."""
+  qs = _quantile_ranks(num_draws, quantiles)
+  return sorted({r for lo, hi, _ in qs for r in (lo, hi)} |
+                {num_draws - 1 - r for lo, hi, _ in qs for r in (lo, hi)})
 
 
 def _device_summary_request(ci_data: cid.CausalImpactData, alpha: float) -> Dict:

@@ -518,6 +518,71 @@ int ci_session_summarize(ci_session* s, const double* scale, const double* shift
   return 0;
 }
 
+int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float* trajectories,
+                       double scale, double shift, const double* observed, const uint8_t* flags,
+                       int32_t num_ranks, const int32_t* ranks, double* value_order,
+                       double* cum_order, double* per_draw) {
+  if (!trajectories || !observed || !flags || !ranks) return fail("NULL argument");
+  if (num_draws < 1 || T < 1) return fail("need num_draws >= 1 and T >= 1");
+  if (num_ranks < 1 || num_ranks > ci::SUMM_MAX_RANKS)
+    return fail("num_ranks must be in [1, %d], got %d", ci::SUMM_MAX_RANKS, num_ranks);
+  const int N = num_draws;
+  for (int r = 0; r < num_ranks; ++r)
+    if (ranks[r] < 0 || ranks[r] >= N) return fail("rank %d out of range [0, %d)", ranks[r], N);
+  HIP_TRY(hipSetDevice(device));
+  const size_t TN = (size_t)T * N;
+  DevBuf<float> d_traj;
+  DevBuf<double> d_value, d_cum, d_obs, d_order, d_draw;
+  DevBuf<uint8_t> d_flags;
+  DevBuf<int> d_ranks;
+  auto cleanup = [&]() {
+    d_traj.release(); d_value.release(); d_cum.release(); d_obs.release(); d_order.release();
+    d_draw.release(); d_flags.release(); d_ranks.release();
+  };
+#define CI_TRY_CLEAN(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      cleanup();                                                                             \
+      return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                        \
+  } while (0)
+  CI_TRY_CLEAN(d_traj.alloc(TN));
+  CI_TRY_CLEAN(d_value.alloc(TN));
+  CI_TRY_CLEAN(d_cum.alloc(TN));
+  CI_TRY_CLEAN(d_obs.alloc((size_t)T + 2));
+  CI_TRY_CLEAN(d_flags.alloc(T));
+  CI_TRY_CLEAN(d_ranks.alloc(ci::SUMM_MAX_RANKS));
+  CI_TRY_CLEAN(d_order.alloc((size_t)2 * ci::SUMM_MAX_RANKS * T));
+  CI_TRY_CLEAN(d_draw.alloc((size_t)2 * N));
+  const double ss[2] = {scale, shift};
+  CI_TRY_CLEAN(hipMemcpy(d_traj.p, trajectories, TN * sizeof(float), hipMemcpyHostToDevice));
+  CI_TRY_CLEAN(hipMemcpy(d_obs.p, observed, T * sizeof(double), hipMemcpyHostToDevice));
+  CI_TRY_CLEAN(hipMemcpy(d_obs.p + T, ss, 2 * sizeof(double), hipMemcpyHostToDevice));
+  CI_TRY_CLEAN(hipMemcpy(d_flags.p, flags, T, hipMemcpyHostToDevice));
+  CI_TRY_CLEAN(hipMemcpy(d_ranks.p, ranks, num_ranks * sizeof(int), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ci::summ_transpose_kernel, dim3((T + 63) / 64, (N + 63) / 64, 1), dim3(64, 4), 0,
+                     0, N, T, d_traj.p, d_obs.p + T, d_obs.p + T + 1, d_value.p);
+  hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, 0, N, T,
+                     d_value.p, d_obs.p, d_flags.p, d_cum.p, d_draw.p);
+  double* ord_value = d_order.p;
+  double* ord_cum = d_order.p + (size_t)ci::SUMM_MAX_RANKS * T;
+  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), 0, 0, N, T, num_ranks, d_ranks.p,
+                     d_value.p, ord_value);
+  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), 0, 0, N, T, num_ranks, d_ranks.p,
+                     d_cum.p, ord_cum);
+  CI_TRY_CLEAN(hipGetLastError());
+  CI_TRY_CLEAN(hipDeviceSynchronize());
+  const size_t ord_bytes = (size_t)num_ranks * T * sizeof(double);
+  if (value_order) CI_TRY_CLEAN(hipMemcpy(value_order, ord_value, ord_bytes, hipMemcpyDeviceToHost));
+  if (cum_order) CI_TRY_CLEAN(hipMemcpy(cum_order, ord_cum, ord_bytes, hipMemcpyDeviceToHost));
+  if (per_draw)
+    CI_TRY_CLEAN(hipMemcpy(per_draw, d_draw.p, (size_t)2 * N * sizeof(double), hipMemcpyDeviceToHost));
+#undef CI_TRY_CLEAN
+  cleanup();
+  return 0;
+}
+
 int ci_session_fetch(ci_session* s, ci_outputs* o) {
   if (!s || !o) return fail("NULL argument");
   HIP_TRY(hipSetDevice(s->pb.device));

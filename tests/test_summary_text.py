@@ -70,3 +70,13 @@ def test_argument_errors_match_reference():
     ci.summary(an, alpha=0.3)
   with pytest.raises(ValueError, match="must be either 'summary' or 'report'"):
     ci.summary(an, output_format="nope")
+
+
+def test_summary_numbers_agree_with_the_text():
+  an = _fake_analysis(0.459329)
+  num = ci.summary_numbers(an)
+  text = ci.summary(an, alpha=0.1)
+  assert str(num["average"]["actual"]) in text and str(num["cumulative"]["predicted"]) in text
+  lo, hi = num["average"]["abs_effect_interval"]
+  assert lo <= hi and f"[{lo}, {hi}]" in text
+  assert num["p_value"] == 0.459 and abs(num["alpha"] - 0.1) < 1e-12

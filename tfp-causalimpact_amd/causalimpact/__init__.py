@@ -14,6 +14,7 @@ from causalimpact.causalimpact_lib import ModelOptions
 from causalimpact.causalimpact_lib import Seasons
 from causalimpact.indices import InputDateType
 from causalimpact.summary import summary
+from causalimpact.summary import summary_numbers
 from causalimpact.batch import CausalImpactBatchAnalysis
 from causalimpact.batch import fit_causalimpact_batch
 

@@ -28,6 +28,7 @@ from causalimpact import _native
 from causalimpact import causalimpact_lib as lib
 from causalimpact import data as cid
 from causalimpact import indices
+from causalimpact import standardize
 
 
 @dataclasses.dataclass
@@ -75,11 +76,7 @@ def prepare_batch(values: np.ndarray, index: pd.Index, pre_period, post_period,
   n_pre = int(in_pre.sum())
   model = values[:, rows, :]                               # [B, T, 1+p]
   if standardize_data:
-    with np.errstate(invalid="ignore"):
-      mu = np.nanmean(model[:, :n_pre, :], axis=1)         # [B, 1+p]
-      sd = np.nanstd(model[:, :n_pre, :], axis=1, ddof=1)
-    scaled = np.where((sd > 0)[:, None, :], (model - mu[:, None, :]) /
-                      np.where(sd > 0, sd, 1.0)[:, None, :], model)
+    scaled, mu, sd = standardize.standardize_batch(model, n_pre)
     o_mu, o_sd = mu[:, 0].copy(), sd[:, 0].copy()
   else:
     scaled = model

@@ -39,3 +39,29 @@ class Scaler:
   def inverse_transform(self, values):
     self._require_fit()
     return values * self.stddev_ + self.mean_
+
+
+def standardize_batch(values: np.ndarray, num_fit_rows: int, ddof: int = 1):
+  """`Scaler().fit(rows[:num_fit_rows]).transform(rows)` for a stack of series at once.
+
+  values: [num_series, num_rows, num_columns] float64; the statistics come from the first
+  `num_fit_rows` rows of each series (the pre-period), NaNs ignored; columns whose spread is zero
+  (or undefined) pass through unscaled, exactly like `Scaler.transform`.  Returns
+  (scaled [B, rows, cols], mean [B, cols], stddev [B, cols]).  Used by the batched API
+  (causalimpact/batch.py) so that B series need no per-series pandas objects.
+  """
+  values = np.asarray(values, dtype=np.float64)
+  head = values[:, :num_fit_rows, :]
+  with np.errstate(invalid="ignore"):
+    mean = np.nanmean(head, axis=1)
+    stddev = np.nanstd(head, axis=1, ddof=ddof)
+  usable = stddev > 0
+  safe = np.where(usable, stddev, 1.0)
+  scaled = np.where(usable[:, None, :], (values - mean[:, None, :]) / safe[:, None, :], values)
+  return scaled, mean, stddev
+
+
+def unstandardize(values: np.ndarray, mean: float, stddev: float) -> np.ndarray:
+  """`Scaler.inverse_transform` for plain arrays and scalar statistics: two roundings
+  (multiply, then add) -- the order the on-device summarisation reproduces (csrc/ci_summary.h)."""
+  return np.asarray(values, dtype=np.float64) * np.float64(stddev) + np.float64(mean)

@@ -192,3 +192,41 @@ def summary(ci_model, output_format: str = "summary", alpha: Optional[float] = N
   if output_format == "summary":
     return _summary_table(s, float(alpha), p_value)
   return _report(s, float(alpha), p_value)
+
+
+def summary_numbers(ci_model) -> dict:
+  """The figures of the text summary as a nested dict of floats, rounded the way the text shows
+  them -- for callers that want the table without parsing it:
+
+      {"alpha": 0.05, "p_value": 0.038, "probability_of_effect": 0.9615,
+       "average":    {"actual": 155.2, "predicted": 124.5, "predicted_sd": 0.55,
+                      "predicted_interval": (123.5, 125.5), "abs_effect": 30.6, ...},
+       "cumulative": {...}}
+
+  Intervals are (lower, upper) with lower <= upper even when the stored columns are reversed
+  (effects of negative sign), as in the text; relative quantities are fractions, not percent.
+  """
+  s = ci_model.summary.transpose().to_dict()
+  p_value = float(ci_model.summary["p_value"].iloc[0])
+  out = {"alpha": float(ci_model.summary.alpha.mean()), "p_value": round(p_value, 3),
+         "probability_of_effect": round(1.0 - p_value, 4)}
+  for row in ("average", "cumulative"):
+    r = s[row]
+
+    def pair(lo, hi, nd):
+      a, b = round(float(r[lo]), nd), round(float(r[hi]), nd)
+      return (min(a, b), max(a, b))
+
+    out[row] = {
+        "actual": round(float(r["actual"]), 1),
+        "predicted": round(float(r["predicted"]), 1),
+        "predicted_sd": round(float(r["predicted_sd"]), 2),
+        "predicted_interval": pair("predicted_lower", "predicted_upper", 1),
+        "abs_effect": round(float(r["abs_effect"]), 1),
+        "abs_effect_sd": round(float(r["abs_effect_sd"]), 2),
+        "abs_effect_interval": pair("abs_effect_lower", "abs_effect_upper", 1),
+        "rel_effect": round(float(r["rel_effect"]), 3),
+        "rel_effect_sd": round(float(r["rel_effect_sd"]), 3),
+        "rel_effect_interval": pair("rel_effect_lower", "rel_effect_upper", 3),
+    }
+  return out

@@ -486,11 +486,11 @@ struct RegLds {
 // One symmetric sweep (or its inverse) of both matrices on pivot k, in place.  The pivot row
 // (== pivot column: swept symmetric matrices stay symmetric) is first copied to `tmp`, so no
 // lane reads an entry another lane is rewriting.  Entries are walked in LINEAR order, 64 lanes x 8
-// per trip, with no predicates at all: the matrices are padded to a multiple of 512 doubles
+// per trip, with no predicates at all: the matrices are padded to a multiple of 1024 doubles
 // (sweep_padded) and whatever lands in the padding is never read.  General entries get one FMA;
 // the pivot row / column are rewritten afterwards (LDS operations of one wave complete in
 // program order, so the later stores win).  n, np <= 64; tmp: 128 doubles.
-__host__ __device__ inline size_t sweep_padded(size_t entries) { return (entries + 511) & ~(size_t)511; }
+__host__ __device__ inline size_t sweep_padded(size_t entries) { return (entries + 1023) & ~(size_t)1023; }
 
 __device__ __forceinline__ void sweep_one(double* __restrict__ M, int m, const double* __restrict__ t,
                                           int k, double sgn, int lane) {
@@ -960,6 +960,203 @@ __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
   }
   wave_sync();
   prof.tick(12);
+  return new_scale;
+}
+
+// ------------------------------------------------------------------------------------
+// The same regression draw executed by the WHOLE workgroup (P > 16 in the time-parallel kernel,
+// where the serial section would otherwise idle three waves for ~0.3M cycles at P = 51).
+// Control flow is uniform without any broadcast: every wave evaluates the (cheap) proposals and
+// ballots on the same LDS state, so all waves take the same decisions; the (expensive) sweeps
+// spread their entries over all 256 threads.  Barriers are __syncthreads(); every thread returns
+// the same new observation-noise scale.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void sweep_one_block(double* __restrict__ M, int m,
+                                                const double* __restrict__ t, int k, double sgn,
+                                                int tid) {
+  const double rd = fast_rcp(t[k]);
+  const int qd = NT / m, rm = NT - qd * m;       // (i, j) of entry e + 256 from (i, j) of entry e
+  int i = tid / m, j = tid - i * m;
+  const int trips = (m * m + 1023) >> 10;
+  double* Me = M + tid;
+#pragma unroll 1
+  for (int it = 0; it < trips; ++it) {
+    double mv[4], ti[4], tj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mv[u] = Me[NT * u];
+      ti[u] = t[i];
+      tj[u] = t[j];
+      j += rm; i += qd;
+      if (j >= m) { j -= m; ++i; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Me[NT * u] = mv[u] - (ti[u] * rd) * tj[u];
+    Me += 4 * NT;
+  }
+}
+// tmp: 256 doubles (pivot rows of both matrices, padded so that the gathers of padding entries
+// stay in bounds).
+__device__ __forceinline__ void sweep_pair_block(double* A, int n, double* Pm, int np, int k,
+                                                 bool reverse, bool with_prior, int tid,
+                                                 double* tmp) {
+  const double sgn = reverse ? -1.0 : 1.0;
+  if (tid < 128) tmp[tid] = tid < n ? A[k * n + tid] : 1.0;
+  else tmp[tid] = (with_prior && tid - 128 < np) ? Pm[k * np + (tid - 128)] : 1.0;
+  __syncthreads();
+  sweep_one_block(A, n, tmp, k, sgn, tid);
+  if (with_prior) sweep_one_block(Pm, np, tmp + 128, k, sgn, tid);
+  __syncthreads();       // general entries written before the pivot row / column are rewritten
+  if (tid < n) {
+    const double rd = fast_rcp(tmp[k]);
+    const double pv = (tid == k) ? -rd : sgn * tmp[tid] * rd;
+    A[k * n + tid] = pv;
+    A[tid * n + k] = pv;
+  } else if (with_prior && tid >= 128 && tid - 128 < np) {
+    const int l = tid - 128;
+    const double rd = fast_rcp(tmp[128 + k]);
+    const double pv = (l == k) ? -rd : sgn * tmp[128 + l] * rd;
+    Pm[k * np + l] = pv;
+    Pm[l * np + k] = pv;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
+                                                        const DevSeriesParams& sp,
+                                                        double prev_obs_scale, double g_obs,
+                                                        const Rng& rng, uint32_t iter, int tid,
+                                                        bool first) {
+  const int lane = tid & 63;
+  const int n = P + 1;
+  const double prev_var = prev_obs_scale * prev_obs_scale;
+  const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
+  const bool all_in = sp.nonzero_prob >= 1.0;
+  double* tmp = R.chol;            // free until the final Cholesky (P > 16 => P*P >= 256)
+  {
+    int i = tid / n, j = tid - (tid / n) * n;
+    const int qd = NT / n, rm = NT - qd * n;
+    for (int e = tid; e < n * n; e += NT) {
+      const int ic = i < P ? i : P - 1, jc = j < P ? j : P - 1;
+      const double inner = R.omega[ic * P + jc] * prev_var + R.xtx[ic * P + jc];
+      const double edge = R.bvec[(i == P && j == P) ? P : (i < j ? i : j)];
+      R.aug[0][e] = (i < P && j < P) ? inner : edge;
+      j += rm; i += qd;
+      if (j >= n) { j -= n; ++i; }
+    }
+    if (first)
+      for (int e = tid; e < P * P; e += NT) R.pri[0][e] = R.omega[e];
+  }
+  // per-feature state is computed redundantly by every wave (lane = feature), written once
+  int nz0 = 0;
+  if (lane < P) nz0 = all_in ? 1 : (R.w[lane] != 0.f ? 1 : 0);
+  if (tid < P) {
+    R.nz[tid] = nz0;
+    if (!all_in) R.uperm[tid] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)tid);
+  }
+  __syncthreads();
+  for (unsigned long long todo = __ballot(nz0 != 0); todo; todo &= todo - 1ull)
+    sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, first, tid, tmp);
+  if (!all_in) {
+    if (tid < P) {
+      const double uj = R.uperm[tid];
+      int rank = 0;
+      for (int k = 0; k < P; ++k) {
+        const double uk = R.uperm[k];
+        rank += (uk < uj || (uk == uj && k < tid)) ? 1 : 0;
+      }
+      R.perm[rank] = tid;
+    }
+    __syncthreads();
+    const double logit_pi = log(sp.nonzero_prob) - log1p(-sp.nonzero_prob);
+    const int myj = lane < P ? R.perm[lane] : 0;
+    const double myu = lane < P ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)lane) : 2.0;
+    int s_cur = 0;
+    while (true) {
+      bool flip = false;
+      if (lane < P && lane >= s_cur) {
+        const double* A = R.aug[0];
+        const bool in = R.nz[myj] != 0;
+        const double ajj = A[myj * n + myj], ajb = A[myj * n + P], corner = A[P * n + P];
+        const double pju = R.pri[0][myj * P + myj];      // unit scale
+        const double beta_old = sp.obs_scale + 0.5 * corner;
+        double delta;
+        if (!in) {
+          const double pjj = pju * prev_var;
+          const double beta_new = sp.obs_scale + 0.5 * (corner - ajb * ajb / ajj);
+          delta = 0.5 * log(pjj) - 0.5 * log(ajj) + logit_pi -
+                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
+        } else {
+          const double V = -ajj, Vp = -pju / prev_var;
+          const double beta_new = sp.obs_scale + 0.5 * (corner + ajb * ajb / V);
+          delta = 0.5 * log(Vp) - 0.5 * log(V) - logit_pi -
+                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
+        }
+        flip = myu < 1.0 / (1.0 + exp(-delta));
+      }
+      const unsigned long long bal = __ballot(flip);     // identical in every wave
+      if (bal == 0ull) break;
+      const int s_star = __ffsll((long long)bal) - 1;
+      const int j = R.perm[s_star];
+      const bool in = R.nz[j] != 0;
+      __syncthreads();                                   // everyone has read nz / the matrices
+      sweep_pair_block(R.aug[0], n, R.pri[0], P, j, in, true, tid, tmp);
+      if (tid == 0) R.nz[j] = in ? 0 : 1;
+      __syncthreads();
+      s_cur = s_star + 1;
+    }
+  }
+  const double* A = R.aug[0];
+  const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
+  double var = beta_post / g_obs;
+  if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
+  const double new_scale = sqrt(var);
+
+  // active set in increasing feature order (every wave computes it, wave 0 stores it)
+  const int mynz = (lane < P) ? R.nz[lane] : 0;
+  const unsigned long long bal = __ballot(mynz != 0);
+  const int na = __popcll(bal);
+  __syncthreads();                         // tmp (== chol) and w are about to be rewritten
+  if (tid < 64) {
+    if (mynz) R.idx[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
+    if (lane < P) R.w[lane] = 0.f;
+  }
+  __syncthreads();
+  // M_S = Omega_S * prev_var + XtX_S, then a left-looking Cholesky by wave 0: lane i owns row i
+  // (na <= 64), two wave barriers per column, reciprocal square roots instead of divisions
+  for (int e = tid; e < na * na; e += NT) {
+    const int i = e / na, j = e - i * na;
+    const int fi = R.idx[i], fj = R.idx[j];
+    R.chol[e] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
+  }
+  if (tid < na) R.zv[tid] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[tid]);
+  __syncthreads();
+  if (tid < 64) {
+    for (int k = 0; k < na; ++k) {
+      double sdot = 0.0;
+      if (lane >= k && lane < na) {
+        sdot = R.chol[lane * na + k];
+        for (int j = 0; j < k; ++j) sdot -= R.chol[lane * na + j] * R.chol[k * na + j];
+      }
+      const double skk = readlane_d(sdot, k);
+      const double rs = fast_rsqrt(skk);
+      if (lane >= k && lane < na) R.chol[lane * na + k] = (lane == k) ? skk * rs : sdot * rs;
+      wave_sync();
+    }
+    // solve L' u = z (column-oriented back substitution); u overwrites zv
+    for (int i = na - 1; i >= 0; --i) {
+      const double ui = R.zv[i] * fast_rcp(R.chol[i * na + i]);
+      wave_sync();
+      if (lane == 0) R.zv[i] = ui;
+      if (lane < i) R.zv[lane] -= R.chol[i * na + lane] * ui;
+      wave_sync();
+    }
+    if (lane < na) {
+      const int f = R.idx[lane];
+      R.w[f] = (float)(A[f * n + P] + new_scale * R.zv[lane]);
+    }
+  }
+  __syncthreads();
   return new_scale;
 }
 

@@ -226,7 +226,7 @@ __device__ __forceinline__ E block_scan_excl_bwd_rolled(const E& tot, Op op, con
 
 struct WLayout {
   size_t xtx, omega, aug0, aug1, pri0, pri1, chol, bvec, zv, uperm, nz, perm, idx, w, scal, red,
-      pslots, fslots, aslots, edge, total;
+      pslots, fslots, aslots, edge, st, total;
 };
 __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   WLayout l;
@@ -254,6 +254,7 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   l.fslots = take(sizeof(float) * NW * (3 * D * D + 2 * D));
   l.aslots = take(sizeof(float) * NW * (D * D + D));
   l.edge = take(sizeof(float) * (NW + 1) * D);
+  l.st = take(sizeof(double) * 4);      // serial wave -> block: previous sigma_obs, gamma variate
   l.total = o;
   return l;
 }
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   float* fslots = (float*)(smem + lay.fslots);
   float* aslots = (float*)(smem + lay.aslots);
   float* edge = (float*)(smem + lay.edge);
+  double* st = (double*)(smem + lay.st);
   const int RS = (P > 16 ? P : 16) + 4;
 
   // per-chain HBM workspace
@@ -803,10 +805,12 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       }
       if (P > 0 && it < n_iter) {
         const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
-        if (P <= 16)
+        if (P <= 16) {
           obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
-        else
-          obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, it == 0);
+        } else if (lane == 0) {       // drawn by the whole workgroup below
+          st[0] = obs_scale;
+          st[1] = g_obs;
+        }
       }
       if (lane == 0) {
         scal[0] = (float)obs_scale;
@@ -817,6 +821,14 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       }
     }
     __syncthreads();
+    if (P > 16 && it < n_iter) {
+      // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
+      prof.tick(9);
+      obs_scale = spike_slab_draw_block(R, P, sp, st[0], st[1], rng, (uint32_t)it, tid, it == 0);
+      if (tid == 0) scal[0] = (float)obs_scale;
+      __syncthreads();
+      prof.tick(10);
+    }
     prof.tick(1);
 
     // ---- (3) emit iteration it-1: latents and the posterior-predictive trajectory

@@ -44,7 +44,7 @@ def perf(T, p, has_slope, C=8, W=12, S=100):
   ms = min(sess.run() for _ in range(2))
   sess.profile(True); sess.run(); cyc = sess.profile(False)
   it = W + S
-  names = {0: "sums", 1: "serial(rest)", 9: "ss sweep-in", 10: "ss flips", 11: "ss gather", 12: "ss weights",
+  names = {0: "sums", 1: "serial(rest)", 9: "ss sweep-in (P<=16) | serial pre", 10: "ss flips (P<=16) | block regression (P>16)", 11: "ss gather", 12: "ss weights",
            2: "emit", 3: "Xw", 20: "P elem+scan", 21: "x+ / F elem", 22: "F scan", 23: "filter",
            24: "r elem", 25: "r scan", 26: "draw+stats"}
   print(f"perf T={T} P={spec['P']} slope={has_slope} C={C}: {ms:.1f} ms per launch, {ms/it*1e3:.0f} us/iteration,"

@@ -30,6 +30,7 @@
 namespace ci {
 
 constexpr int WIDE_MAX_LC = 64;       // T <= 16384
+constexpr int XR = 8;               // design rows per pass of the X'targets / X w loops
 
 template <int TR, int NS> struct WDim {
   static constexpr int D = TR + NS - 1;
@@ -700,25 +701,25 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         yty = fmaf(tg, tg, yty);
       }
       __syncthreads();      // tgw is read back through another thread mapping below
-      // 8 design rows x 4 steps per pass, the 4 steps as one 16-byte load when rows are 16-byte
+      // XR design rows x 4 steps per pass, the 4 steps as one 16-byte load when rows are 16-byte
       // aligned: one wave per SIMD here, so memory latency is hidden by bytes in flight per
       // thread, not by occupancy
       const bool vec4 = (T & 3) == 0;
-      for (int j0 = 0; j0 < P; j0 += 8) {
-        float acc[8];
+      for (int j0 = 0; j0 < P; j0 += XR) {
+        float acc[XR];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        for (int q = 0; q < XR; ++q) acc[q] = 0.f;
         if (vec4) {
           for (int c4 = tid; c4 < (T >> 2); c4 += NT) {
             const float4 tg = *reinterpret_cast<const float4*>(tgw + 4 * c4);
-            float4 xv[8];
+            float4 xv[XR];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < XR; ++q) {
               const int j = j0 + q < P ? j0 + q : P - 1;
               xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < XR; ++q)
               acc[q] += xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
           }
         } else {
@@ -729,9 +730,9 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
               const int t = tb + u * NT;
               tg[u] = t < T ? tgw[t] : 0.f;
             }
-            float xv[8][4];
+            float xv[XR][4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < XR; ++q) {
               const int j = j0 + q < P ? j0 + q : P - 1;
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
@@ -740,13 +741,13 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
               }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < XR; ++q)
 #pragma unroll
               for (int u = 0; u < 4; ++u) acc[q] = fmaf(xv[q][u], tg[u], acc[q]);
           }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < XR; ++q) {
           const float s = wave_sum_dpp(acc[q]);
           if (lane == 0 && j0 + q < P) red[wave * RS + j0 + q] = s;
         }
@@ -867,17 +868,17 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       for (int c4 = tid; c4 < (TP >> 2); c4 += NT) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), yv = s;
         if (4 * c4 < T) {
-          for (int j0 = 0; j0 < P; j0 += 8) {
-            float4 xv[8];
-            float wj[8];
+          for (int j0 = 0; j0 < P; j0 += XR) {
+            float4 xv[XR];
+            float wj[XR];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < XR; ++q) {
               const int j = j0 + q < P ? j0 + q : P - 1;
               wj[q] = j0 + q < P ? R.w[j] : 0.f;
               xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < XR; ++q) {
               s.x = fmaf(xv[q].x, wj[q], s.x); s.y = fmaf(xv[q].y, wj[q], s.y);
               s.z = fmaf(xv[q].z, wj[q], s.z); s.w = fmaf(xv[q].w, wj[q], s.w);
             }
@@ -893,10 +894,10 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     } else {
       for (int tb = tid; tb < TP; tb += 4 * NT) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j0 = 0; j0 < P; j0 += 8) {
-          float xv[8][4], wj[8];
+        for (int j0 = 0; j0 < P; j0 += XR) {
+          float xv[XR][4], wj[XR];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
+          for (int q = 0; q < XR; ++q) {
             const int j = j0 + q < P ? j0 + q : P - 1;
             wj[q] = j0 + q < P ? R.w[j] : 0.f;
 #pragma unroll
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
             }
           }
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
+          for (int q = 0; q < XR; ++q)
 #pragma unroll
             for (int u = 0; u < 4; ++u) s[u] = fmaf(xv[q][u], wj[q], s[u]);
         }

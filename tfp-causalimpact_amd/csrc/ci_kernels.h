@@ -1222,7 +1222,7 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_slots = take(sizeof(float) * 3 * NW * 16);
   l.off_xlast = take(sizeof(float) * NT * D);
   l.off_tg = take(sizeof(float) * 16);
-  l.off_gam = take(sizeof(double) * (8 + 64));   // gamma draws (wave 1) and regression-block randomness
+  l.off_gam = take(sizeof(double) * (8 + 64 + 4));   // gamma draws (wave 1) and regression-block randomness
                                                  // (wave 2) handed to the serial wave, double-buffered
   l.off_nz0 = take(sizeof(float) * (4 * 64 * (tpad / NT) + 4));   // wave 0's normals, drawn by waves 1-3
   l.off_x = take(x_in_lds ? sizeof(float) * (size_t)Pp * tpad : 16);
@@ -1265,7 +1265,8 @@ template <int PM>
 static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLds& R,
                                                       const float* red, float* scal, int it,
                                                       int lane, PriorCarry& pc,
-                                                      const double* gam, const double* pre) {
+                                                      const double* gam, const double* pre,
+                                                      double* block_st) {
   // (R, red, scal are passed in rather than read from cx: loaded from the LDS context they
   //  would be generic pointers and every access a flat_* instruction)
   const int P = (PM == 0) ? 0 : cx->P, T = cx->T;
@@ -1316,8 +1317,13 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
     if constexpr (PM == 1)
       obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, pc,
                                        pre);
-    else if constexpr (PM == 2)
-      obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, it == 0);
+    else if constexpr (PM == 2) {
+      if (P > 16) {            // drawn by the whole workgroup right after this section
+        if (lane == 0) { block_st[0] = obs_scale; block_st[1] = g_obs; }
+      } else {
+        obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, it == 0);
+      }
+    }
   }
   if (lane == 0) {
     cx->obs_scale = obs_scale;
@@ -1593,7 +1599,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) zs[l] = 0.f;
     if (wave == 0) {
-      serial_section<PM>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1));
+      serial_section<PM>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1),
+                         gam + 72);
     } else {
       if (wave == 1 && it < n_iter) serial_gammas<PM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));
       if constexpr (PM == 1) {
@@ -1628,6 +1635,18 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
       }
     }
     __syncthreads();
+    if constexpr (PM == 2) {
+      if (P > 16 && it < n_iter) {
+        // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
+        const double ns = spike_slab_draw_block(R, P, cx->sp, gam[72], gam[73], rng, (uint32_t)it, tid,
+                                                it == 0);
+        if (tid == 0) {
+          cx->obs_scale = ns;
+          scal[SC_OBS_DK] = (float)ns;
+        }
+        __syncthreads();
+      }
+    }
     prof.tick(1);
 
     if (it > a.W) {

@@ -336,7 +336,8 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
     import concurrent.futures  # pylint: disable=import-outside-toplevel
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(work)) as pool_:
       parts = list(pool_.map(lambda a: run_on(*a), work))
-  out = {k: np.concatenate([p[k][0] for p in parts], axis=0) for k in parts[0]}   # [C, ...]
+  out = ({k: v[0] for k, v in parts[0].items()} if len(parts) == 1 else              # [C, ...]
+         {k: np.concatenate([p[k][0] for p in parts], axis=0) for k in parts[0]})
 
   def pool(a):   # [C, S, ...] -> [C*S, ...]
     return a.reshape((a.shape[0] * a.shape[1],) + a.shape[2:]).astype(np_dtype, copy=False)

@@ -49,6 +49,11 @@ def test_hmc_rejects_unsupported_options():
     lib.fit_causalimpact(df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
                          model_options=lib.ModelOptions(seasons=[lib.Seasons(7)]),
                          inference_options=lib.InferenceOptions(num_results=10, sampler="hmc"))
+  from causalimpact import _native
+  big = rp.create_test_data(5.0, 4000, num_timesteps=5000, seed=1)
+  with pytest.raises(_native.NativeError, match="exceeds the register-resident scans"):
+    lib.fit_causalimpact(big, (big.index[0], big.index[3999]), (big.index[4000], big.index[-1]),
+                         inference_options=lib.InferenceOptions(num_results=10, sampler="hmc"))
   with pytest.raises(ValueError, match="sampler must be"):
     lib.fit_causalimpact(df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
                          inference_options=lib.InferenceOptions(num_results=10, sampler="nuts"))

@@ -696,6 +696,9 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
                          ci_ll_session** out) {
   if (validate(pb)) return 1;
   if (pb->num_blocks != 0) return fail("log-likelihood path: seasonal blocks not supported yet");
+  if (steps_per_thread(pb->T) == 0)
+    return fail("log-likelihood path: T=%d exceeds the register-resident scans (max %d)", pb->T,
+                ci::NT * 16);
   if (!params || !y || !mask || !out || max_evals < 1) return fail("bad argument");
   if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
   HIP_TRY(hipSetDevice(pb->device));

@@ -94,3 +94,20 @@ def test_batch_accepts_an_array():
   assert got.summary.index.get_level_values(0).unique().tolist() == [0, 1, 2]
   assert np.isfinite(got.summary["abs_effect"].to_numpy()).all()
   assert got.diagnostics is None
+
+
+@pytest.mark.gpu
+def test_batch_with_a_weekly_seasonal_block_equals_separate_fits():
+  T, B = 140, 3
+  frames = _frames(B, T, 1, seed=30)
+  idx = frames[0].index
+  for b, f in enumerate(frames):
+    f["y"] += 3.0 * np.sin(2 * np.pi * (np.arange(T) + b) / 7.0)
+  pre, post = (idx[0], idx[97]), (idx[98], idx[-1])
+  kw = dict(seed=8, inference_options=ci.InferenceOptions(num_results=120),
+            model_options=ci.ModelOptions(seasons=[ci.Seasons(num_seasons=7)]))
+  got = ci.fit_causalimpact_batch(frames, pre, post, **kw)
+  for b, f in enumerate(frames):
+    one = ci.fit_causalimpact(f, pre, post, **kw)
+    np.testing.assert_allclose(got.summary.loc[b].to_numpy(float), one.summary.to_numpy(float),
+                               rtol=2e-5, atol=1e-7)

@@ -38,6 +38,7 @@ def _fit_both(T, p, has_slope, W, S, C=1, seed=(5, 9), data_seed=0, chain_offset
     (500, 24, 0),   # P=25 > 16: LDS-resident regression block (in-place sweeps)
     (5000, 3, 0),   # T > 4096: trend-only series on the time-parallel kernel (inert seasonal block)
     (9000, 2, 1),   # same with a local linear trend
+    (40000, 1, 0),  # 157 steps per thread (the kernel's own limit is 65536 steps)
 ])
 def test_first_iterations_match_oracle_per_draw(T, p, has_slope):
   S = 4

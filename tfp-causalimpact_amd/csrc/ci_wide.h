@@ -1,4 +1,4 @@
-// ci_wide.h -- time-parallel Gibbs kernel for trend + one seasonal block, any series length.
+// ci_wide.h -- time-parallel Gibbs kernel for trend + one seasonal block, any series length (up to 65536 steps).
 //
 // Model: LocalLevel / LocalLinearTrend (TR = 1 / 2 trend dims) + one
 // tfp.sts.Seasonal(num_seasons = NS, constrain_mean_effect_to_zero=True) block carried in the
@@ -29,7 +29,7 @@
 
 namespace ci {
 
-constexpr int WIDE_MAX_LC = 64;       // T <= 16384
+constexpr int WIDE_MAX_LC = 256;      // T <= 65536
 constexpr int XR = 8;               // design rows per pass of the X'targets / X w loops
 
 template <int TR, int NS> struct WDim {

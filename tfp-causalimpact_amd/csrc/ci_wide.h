@@ -864,17 +864,21 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     __syncthreads();     // (3) reads xww through a different thread mapping than (4) writes it
 
     // ---- (4) X w and the residual
+    // only the INCLUDED features' rows are streamed (a zero weight contributes an exact zero)
+    const unsigned long long included = __ballot(lane < P && R.w[lane < P ? lane : 0] != 0.f);
     if ((T & 3) == 0) {
       for (int c4 = tid; c4 < (TP >> 2); c4 += NT) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), yv = s;
         if (4 * c4 < T) {
-          for (int j0 = 0; j0 < P; j0 += XR) {
+          for (unsigned long long todo = included; todo != 0ull;) {
             float4 xv[XR];
             float wj[XR];
 #pragma unroll
             for (int q = 0; q < XR; ++q) {
-              const int j = j0 + q < P ? j0 + q : P - 1;
-              wj[q] = j0 + q < P ? R.w[j] : 0.f;
+              const bool have = todo != 0ull;
+              const int j = have ? __ffsll((long long)todo) - 1 : 0;
+              todo &= todo - 1ull;
+              wj[q] = have ? R.w[j] : 0.f;
               xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
             }
 #pragma unroll

@@ -203,6 +203,29 @@ __device__ __forceinline__ float wave_prefix_dpp(float v) {
   v = dpp_add<0x143, 0xC>(v);
   return v;
 }
+// 16 values per lane -> lane l holds the wave-wide sum of value (l & 15).  Reduce-scatter over
+// the 16 lanes of each row: at every step a lane keeps the half of its values whose index bit
+// matches its own lane bit and adds the partner's copy of that half (partners: row_ror:8,
+// row_half_mirror, quad_perm [2,3,0,1], quad_perm [1,0,3,2] -- each an involution pairing lanes
+// with complementary bit and equal higher bits); then the four rows are added.
+template <int CTRL> __device__ __forceinline__ float dpp_take(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_reduce_scatter16(const float (&v)[16], int lane) {
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) a[q] = (b3 ? v[8 + q] : v[q]) + dpp_take<0x128>(b3 ? v[q] : v[8 + q]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) b[q] = (b2 ? a[4 + q] : a[q]) + dpp_take<0x141>(b2 ? a[q] : a[4 + q]);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) c[q] = (b1 ? b[2 + q] : b[q]) + dpp_take<0x4E>(b1 ? b[q] : b[2 + q]);
+  float d = (b0 ? c[1] : c[0]) + dpp_take<0xB1>(b0 ? c[0] : c[1]);
+  d += __shfl_xor(d, 16, 64);
+  d += __shfl_xor(d, 32, 64);
+  return d;
+}
+
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v = dpp_add<0x111, 0xF>(v);   // row_shr:1
   v = dpp_add<0x112, 0xF>(v);   // row_shr:2
@@ -1530,14 +1553,11 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
           pj[j] = s;
         }
         prof.tick(16);
-        // 16 independent DPP prefix chains interleave; lane 63 (which holds the totals)
-        // stores them in one predicated block
-#pragma unroll
-        for (int j = 0; j < 16; ++j) pj[j] = wave_prefix_dpp(pj[j]);
-        if (lane == 63) {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) red[wave * RS + j] = pj[j];
-        }
+        // 16 wave sums as ONE reduce-scatter: lane l ends up with the total of feature l & 15
+        // (15 DPP exchange-adds + two cross-row shuffles instead of 16 six-step prefix chains),
+        // stored by lanes 0..15 in a single instruction
+        const float tot = wave_reduce_scatter16(pj, lane);
+        if (lane < 16) red[wave * RS + lane] = tot;
       } else if constexpr (PM == 2) {
         for (int j = 0; j < P; ++j) {
           float pj = 0.f;

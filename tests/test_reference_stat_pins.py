@@ -9,6 +9,7 @@ import pandas as pd
 import pytest
 
 import ref_pins_common as rp
+from causalimpact.summary import summary as ci_summary
 from causalimpact import causalimpact_lib as lib
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -141,3 +142,35 @@ def test_numeric_impact_values_with_seasonality(backend):
   assert abs(seasonal.summary["abs_effect_sd"]["average"] - 0.5) <= 0.1
   assert tuple(plain.posterior_samples.seasonal_levels.shape) == (1000, 300, 0)
   assert tuple(seasonal.posterior_samples.seasonal_levels.shape) == (1000, 300, 3)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_quickstart_recipe_reproduces_the_published_summary(backend):
+  """docs/quickstart.ipynb:279-298 (recipe) and :431-446 (published `summary()` output):
+  T=100, x1 = 100 + AR(1)(phi=0.999), y = 1.2 x1 + N(0,1), +10 from index 72, pre = [0, 70],
+  post = [71, 99], default options (900 draws, LocalLevel).  Published: absolute effect 9.7
+  (s.d. 0.32), 95% CI [9.1, 10.3], relative effect 7.9%, p = 0.001.  The notebook's TF random
+  streams cannot be reproduced here, so the pin is distributional: the true average effect is
+  10 * 28/29 = 9.66 and the published s.d. / interval width / tail area are properties of the
+  model on data of this recipe."""
+  rng = np.random.default_rng(20210614)
+  n = 100
+  x = np.zeros(n)
+  x[0] = rng.normal()
+  for t in range(1, n):
+    x[t] = 0.999 * x[t - 1] + rng.normal()
+  x1 = 100.0 + x
+  y = 1.2 * x1 + rng.normal(size=n)
+  y[72:] += 10.0
+  df = pd.DataFrame({"y": y, "x1": x1}, index=pd.date_range("2021-06-14", periods=n, freq="D"))
+  an = rp.fit(backend, df, (df.index[0], df.index[70]), (df.index[71], df.index[-1]), seed=(0, 1),
+              num_results=900)
+  s = an.summary
+  assert abs(s.loc["average", "abs_effect"] - 9.66) < 1.0
+  assert 0.2 < s.loc["average", "abs_effect_sd"] < 0.5                       # published 0.32
+  width = s.loc["average", "abs_effect_upper"] - s.loc["average", "abs_effect_lower"]
+  assert 0.8 < width < 2.0                                                   # published 1.2
+  assert 0.06 < s.loc["average", "rel_effect"] < 0.095                       # published 7.9 %
+  assert s.loc["average", "p_value"] <= 2.0 / 901 + 1e-12                    # published 0.001
+  text = ci_summary(an)
+  assert "Posterior tail-area probability p: 0.001" in text

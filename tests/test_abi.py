@@ -35,3 +35,51 @@ def test_struct_layouts_match_header_sizes():
   assert ctypes.sizeof(_native.SeriesParams) == 8 * 28
   assert ctypes.sizeof(_native.Problem) == 4 * (5 + 8 + 5 + 2 + 2)
   assert ctypes.sizeof(_native.Outputs) == 8 * 10
+
+
+def test_argument_validation_happens_before_any_device_call():
+  """The C-ABI checks its arguments first, so these errors are reachable without a GPU."""
+  import numpy as np
+  import pytest
+  from causalimpact import _native
+  T = 20
+  y = np.zeros((1, T), np.float32)
+  m = np.zeros((1, T), np.uint8)
+  spec = dict.fromkeys(_native._PARAM_FIELDS, 1.0)   # pylint: disable=protected-access
+  prm = _native.make_params([spec])
+
+  def create(**kw):
+    base = dict(T=T, P=0, has_slope=0, num_warmup=1, num_results=2)
+    base.update(kw)
+    pb = _native.make_problem(**base)
+    Tn, Pn = base["T"], base["P"]
+    X = np.zeros((1, Tn, Pn), np.float32) if Pn else None
+    return _native.Session(pb, np.zeros((1, Tn), np.float32), np.zeros((1, Tn), np.uint8), X,
+                           np.zeros((max(1, len(base.get("num_seasons", ()))), Tn), np.uint8)
+                           if base.get("num_seasons") else None, prm)
+
+  for kw, msg in [
+      (dict(T=2), "T must be >= 3"),
+      (dict(P=500), "P must be in"),
+      (dict(num_results=0), "num_results >= 1"),
+      (dict(num_chains=0), "num_chains >= 1"),
+      (dict(num_seasons=(1,)), r"num_seasons\[0\] must be >= 2"),
+      (dict(T=70000), "exceeds the longest supported series"),
+  ]:
+    with pytest.raises(_native.NativeError, match=msg):
+      create(**kw)
+  pb = _native.make_problem(T=T, P=0, has_slope=0, num_warmup=1, num_results=2)
+  pb.abi_version = 999
+  with pytest.raises(_native.NativeError, match="ABI mismatch"):
+    _native.Session(pb, y, m, None, None, prm)
+  pb = _native.make_problem(T=T, P=0, has_slope=0, num_warmup=1, num_results=2)
+  pb.num_blocks = 9
+  with pytest.raises(_native.NativeError, match="num_blocks must be in"):
+    _native.Session(pb, y, m, None, np.zeros((9, T), np.uint8), prm)
+  # straight through ctypes: a design matrix is required when P > 0
+  import ctypes as C
+  pb = _native.make_problem(T=T, P=3, has_slope=0, num_warmup=1, num_results=2)
+  h = C.c_void_p()
+  rc = _native.load().ci_session_create(C.byref(pb), y.ctypes.data, m.ctypes.data, None, None, prm,
+                                        C.byref(h))
+  assert rc != 0 and b"X is NULL" in _native.load().ci_last_error()

@@ -176,7 +176,7 @@ struct ci_session {
   ci_problem pb;
   int L = 0, x_in_lds = 0;
   size_t lds_bytes = 0;
-  KernelFn fn = nullptr;
+  KernelFn fn = nullptr, fn_prof = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<float> y, Xt, o_obs, o_lscale, o_sscale, o_w, o_level, o_slope, o_pm, o_traj;
@@ -284,7 +284,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     s->lds_bytes = ci::make_layout(P, D, ci::NT * s->L, s->x_in_lds).total;
     const int pm = (P == 0) ? 0 : ((P <= 16 && s->x_in_lds) ? 1 : 2);
     s->fn = pick_kernel(D, s->L, pm);
-    if (!s->fn) { delete s; return fail("no kernel for L=%d", s->L); }
+    s->fn_prof = pick_kernel(D, s->L, pm + 8);       // instrumented variant (ci_session_profile)
+    if (!s->fn || !s->fn_prof) { delete s; return fail("no kernel for L=%d", s->L); }
   } else {
     s->D_full = D;
     s->dred = D;
@@ -305,6 +306,9 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   }
   HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)s->lds_bytes));
+  if (s->fn_prof)
+    HIP_TRY(hipFuncSetAttribute((const void*)s->fn_prof, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)s->lds_bytes));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
@@ -457,8 +461,8 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
     hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(pb.num_series * pb.num_chains),
                        dim3(s->wide ? ci::NT : 64), s->lds_bytes, s->stream, sa);
   } else {
-    hipLaunchKernelGGL(s->fn, dim3(pb.num_series * pb.num_chains), dim3(ci::NT), s->lds_bytes,
-                       s->stream, a);
+    hipLaunchKernelGGL((s->profile && s->fn_prof) ? s->fn_prof : s->fn,
+                       dim3(pb.num_series * pb.num_chains), dim3(ci::NT), s->lds_bytes, s->stream, a);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, s->stream));

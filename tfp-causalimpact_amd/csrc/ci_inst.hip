@@ -18,11 +18,15 @@
 
 extern "C" {
 
-// Returns the device-function handle of gibbs_kernel<CI_D, CI_L, pm>.
+// Returns the device-function handle of gibbs_kernel<CI_D, CI_L, pm[, profiled]>: pm + 8 selects the
+// variant instrumented with per-phase cycle counters (ci_session_profile).
 void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(int pm) {
-  if (pm == 0) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 0>);
-  if (pm == 1) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 1>);
-  return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 2>);
+  if (pm == 0) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 0, false>);
+  if (pm == 1) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 1, false>);
+  if (pm == 2) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 2, false>);
+  if (pm == 8) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 0, true>);
+  if (pm == 9) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 1, true>);
+  return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 2, true>);
 }
 
 // Launches the one-draw Durbin-Koopman test kernel on the default stream.

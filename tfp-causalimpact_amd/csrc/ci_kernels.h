@@ -23,6 +23,7 @@
 //     how chains are spread over devices.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "ci_linalg.h"
@@ -88,6 +89,14 @@ struct Prof {
       t = n;
     }
   }
+};
+
+// The same interface compiled to nothing: the production instantiations of the Gibbs kernel carry
+// no profiling state (4 registers and ~25 predicated branches per iteration less; the kernel sits
+// at the 256-VGPR limit and the instrumented variant spills 40 bytes per lane).
+struct NoProf {
+  __device__ __forceinline__ void start(long long*, bool) {}
+  __device__ __forceinline__ void tick(int) {}
 };
 
 template <class E> struct Arr { float f[sizeof(E) / 4]; };
@@ -255,13 +264,13 @@ template <int D> struct DkModel {
 // masked).  F_t itself is returned in fvar (1 where masked).  `a1e` is the prior mean of x_0.
 // Contains one __syncthreads().
 // ------------------------------------------------------------------------------------
-template <int D, int L>
+template <int D, int L, class PF>
 __device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const Vec<D>& a1e,
                                                    const Vec<D>& q, const float (&ytil)[L],
                                                    uint32_t maskbits, int tid, int lane, int wave,
                                                    float* slots16, Vec<D> (&ap)[L],
                                                    Mat<D> (&Pp)[L], Vec<D> (&kf)[L], float (&vf)[L],
-                                                   float (&fvar)[L], Prof& prof) {
+                                                   float (&fvar)[L], PF& prof) {
   // ---- (2) Kalman filter as an associative scan over (A, b, C, eta, J)
   const Mat<D> Tm = trans_mat<D>();
   FElem<D> ftot = felem_identity<D>();
@@ -379,11 +388,11 @@ __device__ __forceinline__ void dk_normals(const Rng& rng, uint32_t iter, int ow
   fill_normals<L>(rng, iter, SITE_PRIOR_OBS, 0, t0, zo);
 }
 
-template <int D, int L>
+template <int D, int L, class PF>
 __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
                                         uint32_t maskbits, const Rng& rng, uint32_t iter, int tid,
                                         int lane, int wave, float* slots, Vec<D> (&xout)[L],
-                                        Prof& prof, const float (&zl)[L], const float (&zs)[L],
+                                        PF& prof, const float (&zl)[L], const float (&zs)[L],
                                         const float (&zo)[L], const float* zinit = nullptr) {
   Vec<D> q;
 #pragma unroll
@@ -476,11 +485,11 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
   prof.tick(7);
 }
 
-template <int D, int L>
+template <int D, int L, class PF>
 __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
                                         uint32_t maskbits, const Rng& rng, uint32_t iter, int tid,
                                         int lane, int wave, float* slots, Vec<D> (&xout)[L],
-                                        Prof& prof) {
+                                        PF& prof) {
   float zl[L], zs[L], zo[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) zs[l] = 0.f;
@@ -694,11 +703,12 @@ __device__ __forceinline__ void spike_slab_randoms(const Rng& rng, uint32_t iter
   }
 }
 
+template <class PF>
 __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
                                                        const DevSeriesParams& sp,
                                                        double prev_obs_scale, double g_obs,
                                                        const Rng& rng, uint32_t iter, int lane,
-                                                       Prof& prof, PriorCarry& pc,
+                                                       PF& prof, PriorCarry& pc,
                                                        const double* pre = nullptr) {
   // pre (optional, LDS): this iteration's data-independent randomness, drawn one iteration
   // ahead by an idle wave (spike_slab_randoms): [0,16) flip uniforms by feature, [16,24) visiting
@@ -831,10 +841,11 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
 // with uniform control flow.  Returns the new observation-noise scale.
 // spike_and_slab.SpikeSlabSampler.sample_noise_variance_and_weights with
 // experimental_use_weight_adjustment=True (causalimpact_lib.py:387-388).
+template <class PF>
 __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
                                                   const DevSeriesParams& sp, double prev_obs_scale,
                                                   double g_obs, const Rng& rng, uint32_t iter,
-                                                  int lane, Prof& prof, bool first) {
+                                                  int lane, PF& prof, bool first) {
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
@@ -1284,7 +1295,7 @@ static __device__ __forceinline__ void serial_gammas(const SerialCtx* cx, int it
   if (lane == 0) { out[0] = g_level; out[1] = g_slope; out[2] = g_obs; }
 }
 
-template <int PM>
+template <int PM, class PF>
 static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLds& R,
                                                       const float* red, float* scal, int it,
                                                       int lane, PriorCarry& pc,
@@ -1293,7 +1304,7 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
   // (R, red, scal are passed in rather than read from cx: loaded from the LDS context they
   //  would be generic pointers and every access a flat_* instruction)
   const int P = (PM == 0) ? 0 : cx->P, T = cx->T;
-  Prof prof;
+  PF prof;
   prof.start(cx->prof, cx->prof != nullptr && lane == 0);
   {
     const int RS = (P > 16 ? P : 16) + 4;
@@ -1360,11 +1371,12 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
   wave_sync();
 }
 
-template <int D, int L, int PM>
+template <int D, int L, int PM, bool PROF = false>
 #ifndef CI_MIN_WAVES
 #define CI_MIN_WAVES 2
 #endif
 __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
+  using PF = typename std::conditional<PROF, Prof, NoProf>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1478,7 +1490,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   pc.pdiag = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
-  Prof prof;
+  PF prof;
   prof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && tid == 0);
   for (int it = 0; it <= n_iter; ++it) {
     // ---- emit iteration it-1: level / slope / posterior-predictive trajectory
@@ -1619,7 +1631,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) zs[l] = 0.f;
     if (wave == 0) {
-      serial_section<PM>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1),
+      serial_section<PM, PF>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1),
                          gam + 72);
     } else {
       if (wave == 1 && it < n_iter) serial_gammas<PM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));

@@ -181,7 +181,7 @@ def main():
                  "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
       "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(),
-                   "kernel": "ci::gibbs_kernel<2,4,1>", "kernel_ms": k_ms,
+                   "kernel": "ci::gibbs_kernel<2,4,1,false>", "kernel_ms": k_ms,
                    "algorithmic_bytes_per_launch": alg_bytes,
                    "note": "one workgroup per chain: 8 of 256 CUs busy; the fit is bound by the "
                            "(W+S)-long sequential Gibbs dependency, not by HBM (DESIGN.md)"},

@@ -30,7 +30,7 @@ def main():
   fetch_kb, nf = per_launch(fetch_csv, "FETCH_SIZE")
   write_kb, nw = per_launch(write_csv, "WRITE_SIZE")
   out = {
-      "kernel": "ci::gibbs_kernel<2,4,1>",
+      "kernel": "ci::gibbs_kernel<2,4,1,false>",
       "launches": {"fetch_pass": nf, "write_pass": nw},
       "FETCH_SIZE_kb_per_launch_raw": fetch_kb,
       "WRITE_SIZE_kb_per_launch_raw": write_kb,

@@ -157,6 +157,66 @@ __device__ __forceinline__ void w_cov_predict(Mat<TR + NS - 1>& P, bool ch, cons
   symmetrize(P);
 }
 
+// P <- T P T' + Q_t on a PACKED upper triangle (symidx): the per-thread passes are VALU-issue bound
+// at one wave per SIMD, so the covariance is never expanded to d x d.  Trend block first
+// ([[1,1],[0,1]] on rows/columns 0,1), then the companion shift of the seasonal block in closed
+// form: entries move up-left by one, the last row/column is minus the row sums, the corner is the
+// total sum.
+template <int TR, int NS>
+__device__ __forceinline__ void w_cov_predict_sym(float (&C)[(TR + NS - 1) * (TR + NS) / 2], bool ch,
+                                                  const WideScal& sc) {
+  constexpr int D = TR + NS - 1, O = TR, N1 = NS - 1;
+  auto S = [](int i, int j) constexpr { return symidx<D>(i, j); };
+  if constexpr (TR == 2) {
+    // rows/cols (0,1) <- [[1,1],[0,1]] . [[1,0],[1,1]]
+    C[S(0, 0)] += 2.0f * C[S(0, 1)] + C[S(1, 1)];
+    C[S(0, 1)] += C[S(1, 1)];
+#pragma unroll
+    for (int j = 2; j < D; ++j) C[S(0, j)] += C[S(1, j)];
+  }
+  if (ch) {
+    float rs[N1];                 // row sums of the seasonal block
+    float cross[TR];              // row sums of the trend x seasonal block
+#pragma unroll
+    for (int p = 0; p < N1; ++p) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < N1; ++k) a += C[S(O + p, O + k)];
+      rs[p] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < N1; ++k) a += C[S(r, O + k)];
+      cross[r] = a;
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int p = 0; p < N1; ++p) tot += rs[p];
+    // shifted entries (ascending order: every source lies after its destination)
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+#pragma unroll
+      for (int q = 0; q + 1 < N1; ++q) C[S(r, O + q)] = C[S(r, O + q + 1)];
+      C[S(r, O + N1 - 1)] = -cross[r];
+    }
+#pragma unroll
+    for (int p = 0; p + 1 < N1; ++p) {
+#pragma unroll
+      for (int q = p; q + 1 < N1; ++q) C[S(O + p, O + q)] = C[S(O + p + 1, O + q + 1)];
+      C[S(O + p, O + N1 - 1)] = -rs[p + 1];
+    }
+    C[S(O + N1 - 1, O + N1 - 1)] = tot;
+#pragma unroll
+    for (int p = 0; p < N1; ++p)
+#pragma unroll
+      for (int q = p; q < N1; ++q) C[S(O + p, O + q)] += sc.qd;
+  }
+  C[S(0, 0)] += sc.ql;
+  if constexpr (TR == 2) C[S(1, 1)] += sc.qs;
+}
+
 // ---- prior-simulation element: x_out = Phi x_in + s, Phi fixed by (steps, changes mod NS) ----
 template <int D> struct WPElem {
   float k;
@@ -321,11 +381,14 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
   prof.tick(20);
 
   // ---- (2) x+ from the chunk's prefix, y~ = resid - y+, and the chunk's filtering element
-  FElem<D> fe = felem_identity<D>();
+  FElemS<D> fe = felems_identity<D>();
   if (tid == 0) {
     fe.A = mzero<D>();
     fe.b = a1e;
-    fe.C = P1;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) fe.C[symidx<D>(i, j)] = P1.m[i][j];
   }
   {
     Vec<D> x = ppre.s;
@@ -358,7 +421,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
 #pragma unroll
           for (int j = 0; j < D; ++j) za[j] = fe.A.m[0][j] + fe.A.m[O][j];
 #pragma unroll
-          for (int i = 0; i < D; ++i) cz[i] = fe.C.m[i][0] + fe.C.m[i][O];
+          for (int i = 0; i < D; ++i) cz[i] = fe.C[symidx<D>(i, 0)] + fe.C[symidx<D>(i, O)];
           const float zb = fe.b.v[0] + fe.b.v[O];
           const float Sv = cz[0] + cz[O] + sc.H;
           const float rS = 1.0f / Sv;
@@ -367,19 +430,20 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
           for (int i = 0; i < D; ++i) {
             fe.eta.v[i] = fmaf(za[i], e, fe.eta.v[i]);
             fe.b.v[i] = fmaf(cz[i], e, fe.b.v[i]);
-            const float ki = cz[i] * rS;
+            const float ki = cz[i] * rS, zi = za[i] * rS;
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-              fe.J.m[i][j] = fmaf(za[i] * za[j], rS, fe.J.m[i][j]);
-              fe.A.m[i][j] = fmaf(-ki, za[j], fe.A.m[i][j]);
-              fe.C.m[i][j] = fmaf(-(cz[i] * cz[j]), rS, fe.C.m[i][j]);
+            for (int j = 0; j < D; ++j) fe.A.m[i][j] = fmaf(-ki, za[j], fe.A.m[i][j]);
+#pragma unroll
+            for (int j = i; j < D; ++j) {       // symmetric parts: upper triangles only
+              fe.J[symidx<D>(i, j)] = fmaf(zi, za[j], fe.J[symidx<D>(i, j)]);
+              fe.C[symidx<D>(i, j)] = fmaf(-ki, cz[j], fe.C[symidx<D>(i, j)]);
             }
           }
         }
         // time update t -> t+1
         w_left<TR, NS>(fe.A, ch);
         w_apply<TR, NS>(fe.b, ch);
-        w_cov_predict<TR, NS>(fe.C, ch, sc);
+        w_cov_predict_sym<TR, NS>(fe.C, ch, sc);
         w_apply<TR, NS>(x, ch);
         x.v[0] = fmaf(sc.sl, zl, x.v[0]);
         if constexpr (TR == 2) {
@@ -396,7 +460,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
   }
   prof.tick(21);
   const FElemS<D> fpre = block_scan_excl_fwd_rolled(
-      felems_pack(fe), [](const FElemS<D>& x, const FElemS<D>& y) { return felems_combine(x, y); },
+      fe, [](const FElemS<D>& x, const FElemS<D>& y) { return felems_combine(x, y); },
       felems_identity<D>(), fslots, lane, wave);
   prof.tick(22);
 
@@ -538,18 +602,9 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
         Vec<D> xt;
 #pragma unroll
         for (int i = 0; i < D; ++i) xt.v[i] = wl[(W::F_AX + i) * NT];
-        Mat<D> Pm;
-        {
-          int e = 0;
+        float Ps[W::NPS];
 #pragma unroll
-          for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = i; j < D; ++j) {
-              const float v = wl[(W::F_PS + e++) * NT];
-              Pm.m[i][j] = v;
-              Pm.m[j][i] = v;
-            }
-        }
+        for (int e = 0; e < W::NPS; ++e) Ps[e] = wl[(W::F_PS + e) * NT];
         w_apply_t<TR, NS>(r, ch);
         if (obs) {
           float kr = 0.f;
@@ -562,7 +617,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
-          for (int j = 0; j < D; ++j) xt.v[i] = fmaf(Pm.m[i][j], r.v[j], xt.v[i]);
+          for (int j = 0; j < D; ++j) xt.v[i] = fmaf(Ps[symidx<D>(i, j)], r.v[j], xt.v[i]);
         if (t < T) {
           levw[t] = xt.v[0];
           if constexpr (TR == 2) slpw[t] = xt.v[1];

@@ -508,10 +508,15 @@ int ci_session_summarize(ci_session* s, const double* scale, const double* shift
                      s->s_value.p, s->s_obs.p, s->s_flags.p, s->s_cum.p, s->s_draw.p);
   double* ord_value = s->s_order.p;
   double* ord_cum = s->s_order.p + (size_t)B * ci::SUMM_MAX_RANKS * T;
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(B * T), dim3(256), 0, s->stream, N, T, num_ranks,
-                     s->s_ranks.p, s->s_value.p, ord_value);
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(B * T), dim3(256), 0, s->stream, N, T, num_ranks,
-                     s->s_ranks.p, s->s_cum.p, ord_cum);
+  const int stage = N <= ci::SUMM_STAGE_MAX_N ? 1 : 0;
+  const size_t stage_lds = stage ? (size_t)N * sizeof(double) : 0;
+  if (stage)
+    HIP_TRY(hipFuncSetAttribute((const void*)ci::summ_select_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(B * T), dim3(256), stage_lds, s->stream, N, T,
+                     num_ranks, s->s_ranks.p, s->s_value.p, ord_value, stage);
+  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(B * T), dim3(256), stage_lds, s->stream, N, T,
+                     num_ranks, s->s_ranks.p, s->s_cum.p, ord_cum, stage);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
   const size_t ord_bytes = (size_t)B * num_ranks * T * sizeof(double);
@@ -571,10 +576,15 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
                      d_value.p, d_obs.p, d_flags.p, d_cum.p, d_draw.p);
   double* ord_value = d_order.p;
   double* ord_cum = d_order.p + (size_t)ci::SUMM_MAX_RANKS * T;
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), 0, 0, N, T, num_ranks, d_ranks.p,
-                     d_value.p, ord_value);
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), 0, 0, N, T, num_ranks, d_ranks.p,
-                     d_cum.p, ord_cum);
+  const int stage = N <= ci::SUMM_STAGE_MAX_N ? 1 : 0;
+  const size_t stage_lds = stage ? (size_t)N * sizeof(double) : 0;
+  if (stage)
+    CI_TRY_CLEAN(hipFuncSetAttribute((const void*)ci::summ_select_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), stage_lds, 0, N, T, num_ranks,
+                     d_ranks.p, d_value.p, ord_value, stage);
+  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), stage_lds, 0, N, T, num_ranks,
+                     d_ranks.p, d_cum.p, ord_cum, stage);
   CI_TRY_CLEAN(hipGetLastError());
   CI_TRY_CLEAN(hipDeviceSynchronize());
   const size_t ord_bytes = (size_t)num_ranks * T * sizeof(double);

@@ -15,6 +15,7 @@
 namespace ci {
 
 constexpr int SUMM_MAX_RANKS = 8;
+constexpr int SUMM_STAGE_MAX_N = 16384;   // 128 KiB of LDS per row
 
 // [N, T] float32 draws (model scale) -> [T, N] float64 on the data scale:
 // standardize.py:60-64 `values * stddev + mean` (two roundings, no FMA).
@@ -105,16 +106,25 @@ __device__ __forceinline__ double summ_unkey(unsigned long long k) {
 // Order statistics of every row of M [B*T, N] (float64): out[b, r, t] = ranks[r]-th smallest of
 // row b*T + t.
 // One 256-thread workgroup per row; most-significant-digit radix select, 8 passes of 8 bits, all
-// R ranks carried through the same sweeps of the row (which stays in L2: N * 8 bytes).
+// R ranks carried through the same sweeps of the row.  When the row fits LDS (stage_row: N * 8
+// bytes of dynamic shared memory, N <= 16384) it is staged there once, so the matrix is read from
+// HBM exactly once; longer rows are swept from L2.
 __global__ __launch_bounds__(256) void summ_select_kernel(int N, int T, int R,
                                                           const int* __restrict__ ranks,
                                                           const double* __restrict__ M,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, int stage_row) {
   __shared__ unsigned hist[SUMM_MAX_RANKS][256];
   __shared__ unsigned long long prefix[SUMM_MAX_RANKS];
   __shared__ unsigned krem[SUMM_MAX_RANKS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char summ_dyn[];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double* x = M + (size_t)row * N;
+  if (stage_row) {
+    // the row is read from HBM exactly once (coalesced) and the 8 digit passes sweep LDS
+    double* buf = reinterpret_cast<double*>(summ_dyn);
+    for (int i = tid; i < N; i += 256) buf[i] = x[i];
+    x = buf;
+  }
   if (tid < R) { prefix[tid] = 0ull; krem[tid] = (unsigned)ranks[tid]; }
   for (int pass = 0; pass < 8; ++pass) {
     const int shift = 56 - 8 * pass;
@@ -122,21 +132,51 @@ __global__ __launch_bounds__(256) void summ_select_kernel(int N, int T, int R,
     for (int e = tid; e < R * 256; e += 256) (&hist[0][0])[e] = 0u;
     __syncthreads();
     unsigned long long pf[SUMM_MAX_RANKS];
+    int grp[SUMM_MAX_RANKS];        // ranks that still share a prefix share one histogram
 #pragma unroll
     for (int r = 0; r < SUMM_MAX_RANKS; ++r) pf[r] = r < R ? prefix[r] : ~0ull;
-    for (int i = tid; i < N; i += 256) {
-      const unsigned long long key = summ_key(x[i]);
+#pragma unroll
+    for (int r = 0; r < SUMM_MAX_RANKS; ++r) {
+      grp[r] = r;
+#pragma unroll
+      for (int q = SUMM_MAX_RANKS - 1; q >= 0; --q)
+        if (q < r && pf[q] == pf[r]) grp[r] = q;
+    }
+    for (int i0 = 0; i0 < N; i0 += 256) {
+      const int i = i0 + tid;
+      const bool in = i < N;
+      const unsigned long long key = summ_key(in ? x[i] : 0.0);
       const unsigned bin = (unsigned)(key >> shift) & 255u;
       const unsigned long long hi = key & mask;
 #pragma unroll
-      for (int r = 0; r < SUMM_MAX_RANKS; ++r)
-        if (r < R && hi == pf[r]) atomicAdd(&hist[r][bin], 1u);
+      for (int r = 0; r < SUMM_MAX_RANKS; ++r) {
+        if (r >= R || grp[r] != r) continue;                 // uniform
+        bool todo = in && hi == pf[r];
+        // The leading digits of similar doubles are identical (sign, exponent): almost every lane
+        // hits the same bin.  Two rounds of wave-aggregated counting take the dominant bins with
+        // one atomic each; whatever is left is spread out and uses plain atomics.
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+          const unsigned long long act = __ballot(todo);
+          if (act == 0ull) break;
+          const int leader = __ffsll((long long)act) - 1;
+          const unsigned lbin = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+          const unsigned long long same = __ballot(todo && bin == lbin);
+          if (lane == leader) atomicAdd(&hist[r][lbin], (unsigned)__popcll(same));
+          todo = todo && bin != lbin;
+        }
+        if (todo) atomicAdd(&hist[r][bin], 1u);
+      }
     }
     __syncthreads();
     // wave w resolves ranks w, w+4: lane l owns bins 4l..4l+3
     for (int r = wave; r < R; r += 4) {
-      const unsigned h0 = hist[r][4 * lane], h1 = hist[r][4 * lane + 1], h2 = hist[r][4 * lane + 2],
-                     h3 = hist[r][4 * lane + 3];
+      int g = r;
+#pragma unroll
+      for (int q = 0; q < SUMM_MAX_RANKS; ++q)
+        if (q == r) g = grp[q];
+      const unsigned h0 = hist[g][4 * lane], h1 = hist[g][4 * lane + 1], h2 = hist[g][4 * lane + 2],
+                     h3 = hist[g][4 * lane + 3];
       const unsigned mine = h0 + h1 + h2 + h3;
       unsigned incl = mine;
 #pragma unroll

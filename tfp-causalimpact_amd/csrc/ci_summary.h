@@ -66,19 +66,28 @@ __global__ __launch_bounds__(256) void summ_cumsum_kernel(int N, int T,
   const uint8_t* flags = flags_all + b * T;
   double* per_draw = per_draw_all + b * 2 * N;
   double c = 0.0, pred_sum = 0.0, point_sum = 0.0;
-  // The sums are strictly sequential in t (numpy's rounding order); the loads are not: 8 rows
-  // are fetched ahead of the dependent adds.
-  for (int t8 = 0; t8 < T; t8 += 8) {
-    double p8[8];
+  // The sums are strictly sequential in t (numpy's rounding order); the loads are not: 8
+  // rows (and their observations / flags) are fetched ahead of the dependent adds.
+  constexpr int AHEAD = 8;
+  for (int t8 = 0; t8 < T; t8 += AHEAD) {
+    double p8[AHEAD];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) p8[u] = (t8 + u < T) ? predT[(size_t)(t8 + u) * N + n] : 0.0;
+    for (int u = 0; u < AHEAD; ++u) p8[u] = (t8 + u < T) ? predT[(size_t)(t8 + u) * N + n] : 0.0;
+    double o8[AHEAD];
+    unsigned f8[AHEAD];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < AHEAD; ++u) {
+      const int tc = t8 + u < T ? t8 + u : T - 1;
+      o8[u] = obs[tc];
+      f8[u] = flags[tc];
+    }
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) {
       const int t = t8 + u;
       if (t < T) {
         const double p = p8[u];
-        const double point = -__dsub_rn(p, obs[t]);
-        const unsigned f = flags[t];
+        const double point = -__dsub_rn(p, o8[u]);
+        const unsigned f = f8[u];
         const double base = (f & 1u) ? point : 0.0;
         const bool hole = base != base;
         c = __dadd_rn(c, hole ? 0.0 : base);

@@ -55,17 +55,24 @@ namespace ci {
 // ------------------------------------------------------------------------------------
 static __global__ void setup_regression_kernel(int T, int P, const float* Xt, const uint8_t* mask,
                                         double* xtx, double* omega) {
-  const int series = blockIdx.x;
-  const float* X = Xt + (size_t)series * P * T;
+  // one wavefront per (series, i, j): lanes stride over time (both rows coalesced), float64 sums
+  const int e = blockIdx.x % (P * P), series = blockIdx.x / (P * P);
+  const int i = e / P, j = e % P, lane = threadIdx.x;
+  const float* xi = Xt + ((size_t)series * P + i) * T;
+  const float* xj = Xt + ((size_t)series * P + j) * T;
   const uint8_t* m = mask + (size_t)series * T;
-  for (int e = threadIdx.x; e < P * P; e += blockDim.x) {
-    const int i = e / P, j = e % P;
-    double so = 0.0, sa = 0.0;
-    for (int t = 0; t < T; ++t) {
-      const double v = (double)X[(size_t)i * T + t] * (double)X[(size_t)j * T + t];
-      sa += v;
-      if (!m[t]) so += v;
-    }
+  double so = 0.0, sa = 0.0;
+  for (int t = lane; t < T; t += 64) {
+    const double v = (double)xi[t] * (double)xj[t];
+    sa += v;
+    if (!m[t]) so += v;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    so += __shfl_xor(so, off, 64);
+    sa += __shfl_xor(sa, off, 64);
+  }
+  if (lane == 0) {
     xtx[(size_t)series * P * P + e] = so;
     omega[(size_t)series * P * P + e] = 0.01 * (i == j ? sa : 0.5 * sa) / (double)T;
   }
@@ -444,8 +451,8 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
     a.prof = s->prof.p;
   }
   if (pb.P > 0) {
-    hipLaunchKernelGGL(ci::setup_regression_kernel, dim3(pb.num_series), dim3(256), 0, s->stream,
-                       pb.T, pb.P, s->Xt.p, s->mask.p, s->xtx.p, s->omega.p);
+    hipLaunchKernelGGL(ci::setup_regression_kernel, dim3(pb.num_series * pb.P * pb.P), dim3(64), 0,
+                       s->stream, pb.T, pb.P, s->Xt.p, s->mask.p, s->xtx.p, s->omega.p);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(s->ev0, s->stream));

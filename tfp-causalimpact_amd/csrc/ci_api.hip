@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -138,19 +139,72 @@ int fail(const char* fmt, ...) {
       return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// Device allocations are recycled through a small per-process pool (exact-size match per
+// device, at most POOL_CAP bytes parked): a fit allocates ~10 buffers, 100+ MB of them outputs, and
+// hipMalloc / hipFree of those cost several milliseconds per fit_causalimpact() call -- comparable
+// to the 12 ms the sampler itself takes.  The pool holds no caller data and no pointers escape.
+struct PoolEntry { void* p; size_t bytes; int device; };
+std::mutex g_pool_mu;
+std::vector<PoolEntry> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_CAP = (size_t)2 << 30;
+
+hipError_t pool_alloc(void** out, size_t bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); ++i)
+      if (g_pool[i].bytes == bytes && g_pool[i].device == dev) {
+        *out = g_pool[i].p;
+        g_pool_bytes -= bytes;
+        g_pool[i] = g_pool.back();
+        g_pool.pop_back();
+        return hipSuccess;
+      }
+  }
+  e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {
+    // out of memory with buffers parked: give them back and retry once
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& pe : g_pool) { (void)hipSetDevice(pe.device); (void)hipFree(pe.p); }
+    g_pool.clear();
+    g_pool_bytes = 0;
+    (void)hipSetDevice(dev);
+    e = hipMalloc(out, bytes);
+  }
+  return e;
+}
+
+void pool_free(void* p, size_t bytes, int dev) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool_bytes + bytes <= POOL_CAP && g_pool.size() < 256) {
+      g_pool.push_back({p, bytes, dev});
+      g_pool_bytes += bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
 template <class T> struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  int device = 0;
   hipError_t alloc(size_t count) {
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T));
+    (void)hipGetDevice(&device);
+    return pool_alloc((void**)&p, count * sizeof(T));
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) pool_free((void*)p, n * sizeof(T), device);
     p = nullptr;
   }
 };
+
 
 
 

@@ -183,11 +183,14 @@ int ci_ll_session_draw_latents(ci_ll_session* session, int32_t num_draws, const 
  * on how chains are split over devices.  Outputs (host): draws [num_chains, num_results, 3 + P]
  * float64 rows (sigma_obs, sigma_level, sigma_slope, beta) -- feed them to
  * ci_ll_session_draw_latents for latent paths / predictive trajectories; accept_rate,
- * step_size [num_chains] (optional). */
+ * step_size [num_chains] (optional).  init_theta (optional): [num_chains, P + 2 (+1 with a
+ * slope)] unconstrained starting points (beta, log sigma_obs, log sigma_level[, log sigma_slope]),
+ * e.g. draws of a fitted surrogate posterior; NULL starts from the Gibbs sampler's initial state. */
 int ci_ll_session_hmc(ci_ll_session* session, int32_t num_chains, int32_t chain_offset,
                       int32_t num_warmup, int32_t num_results, int32_t num_leapfrog,
                       double target_accept, double initial_step_size, const uint32_t seed[2],
-                      double* draws, double* accept_rate, double* step_size);
+                      const double* init_theta, double* draws, double* accept_rate,
+                      double* step_size);
 int ci_ll_session_destroy(ci_ll_session* session);
 
 /* ---- component entry points used by the parity tests (tests/test_gpu_*.py) ---- */

@@ -85,3 +85,28 @@ def test_device_hmc_agrees_with_host_driven_hmc_and_splits_like_gibbs():
   b = _hmc.fit_hmc(y, mask, X, spec, num_chains=3, chain_offset=3, **kw)
   for key in ("observation_noise_scale", "weights", "level", "posterior_trajectories"):
     np.testing.assert_array_equal(np.concatenate([a[key], b[key]], axis=1), dev[key], err_msg=key)
+
+
+def test_surrogate_posterior_tracks_the_hmc_posterior_and_can_initialise_it():
+  """`build_factored_surrogate_posterior` analogue (mean-field VI on the device log-likelihood /
+  score): its mean sits inside the HMC posterior, its spread is not larger (mean-field
+  under-dispersion is expected), and chains started from its draws sample the same posterior."""
+  from causalimpact import _hmc, _model, _vi
+  from causalimpact import _synthetic as syn
+  T, p = 300, 3
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 12)
+  spec = _model.series_params(y, mask, X, has_slope=False)
+  vi = _vi.fit_surrogate_posterior(y, mask, X, spec, has_slope=False, seed=(3, 4))
+  assert vi["elbo"][-50:].mean() > vi["elbo"][:20].mean()
+  kw = dict(has_slope=False, num_results=300, num_warmup=300, num_chains=6, seed=(3, 4))
+  hmc = _hmc.fit_hmc(y, mask, X, spec, **kw)
+  hmc_vi = _hmc.fit_hmc(y, mask, X, spec, init="vi", **kw)
+  w_mean = hmc["weights"].mean(axis=(0, 1, 2))
+  w_sd = hmc["weights"].std(axis=(0, 1, 2))
+  np.testing.assert_allclose(vi["mean"][:p], w_mean[:p], atol=3 * w_sd[:p].max() + 0.02)
+  np.testing.assert_allclose(np.exp(vi["mean"][p + 1]), hmc["observation_noise_scale"].mean(), rtol=0.1)
+  assert (np.exp(vi["log_sd"][:p]) < 2.0 * w_sd[:p] + 0.01).all()
+  np.testing.assert_allclose(hmc_vi["weights"].mean(axis=(0, 1, 2))[:p], w_mean[:p], atol=0.03)
+  np.testing.assert_allclose(hmc_vi["observation_noise_scale"].mean(),
+                             hmc["observation_noise_scale"].mean(), rtol=0.05)
+  assert (hmc_vi["hmc_accept_rate"] > 0.5).all()

@@ -109,10 +109,15 @@ def _package(sess, dev, seed, chain_offset, C, S, T, P):
 
 def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_warmup: int,
             num_chains: int, seed, device: int = 0, chain_offset: int = 0, num_leapfrog: int = 15,
-            target_accept: float = 0.75, initial_step_size: float = 0.05) -> Dict[str, np.ndarray]:
+            target_accept: float = 0.75, initial_step_size: float = 0.05,
+            init: str = "gibbs") -> Dict[str, np.ndarray]:
   """HMC with the whole chain on the device (csrc/ci_hmc.h: one workgroup per chain, no host
   round trip per leapfrog step).  Returns the arrays of `_native.fit_gibbs` (leading series axis
-  of 1) plus `hmc_accept_rate`, `hmc_step_size` [C] and `hmc_target_calls`."""
+  of 1) plus `hmc_accept_rate`, `hmc_step_size` [C] and `hmc_target_calls`.
+
+  init: "gibbs" starts every chain at the Gibbs sampler's initial state (jittered); "vi" first
+  fits the mean-field surrogate posterior (`_vi.fit_surrogate_posterior`, what
+  `tfp.sts.fit_with_hmc` does upstream) and starts chain c at its c-th draw."""
   y = np.asarray(y, np.float64)
   mask = np.asarray(mask, bool)
   T = y.shape[0]
@@ -123,10 +128,20 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
   sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X,
                                max_evals=max(C, min(1024, C * S)))
   try:
+    init_theta = None
+    if init == "vi":
+      from causalimpact import _vi  # pylint: disable=import-outside-toplevel
+      vi = _vi.fit_surrogate_posterior(y, mask, X, spec, has_slope=has_slope, seed=seed,
+                                       device=device, sess=sess,
+                                       num_mc=min(32, sess.max_evals))
+      # chain c starts at the (chain_offset + c)-th draw, whatever the split over devices
+      init_theta = _vi.sample_surrogate(vi, chain_offset + C, seed=seed)[chain_offset:]
+    elif init != "gibbs":
+      raise ValueError(f"init must be 'gibbs' or 'vi', got {init!r}")
     draws, acc, eps = sess.hmc(num_chains=C, num_warmup=W, num_results=S,
                                num_leapfrog=num_leapfrog, target_accept=target_accept,
                                initial_step_size=initial_step_size, seed=seed,
-                               chain_offset=chain_offset)
+                               chain_offset=chain_offset, init_theta=init_theta)
     out = _package(sess, draws.reshape(C * S, 3 + P), seed, chain_offset, C, S, T, P)
   finally:
     sess.close()

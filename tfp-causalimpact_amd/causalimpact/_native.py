@@ -92,7 +92,7 @@ def load():
   L.ci_ll_session_destroy.argtypes = [C.c_void_p]
   L.ci_ll_session_hmc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_double, C.c_double, C.POINTER(C.c_uint32), C.c_void_p,
-                                  C.c_void_p, C.c_void_p]
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_test_rng.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
                             C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
   L.ci_test_dk_draw.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p, C.c_void_p,
@@ -340,16 +340,18 @@ class LogLikSession:
     return out
 
   def hmc(self, *, num_chains, num_warmup, num_results, num_leapfrog=15, target_accept=0.75,
-          initial_step_size=0.05, seed=(0, 0), chain_offset=0):
-    """The whole HMC fit on the device (ci_ll_session_hmc): draws [C, S, 3+P], accept, eps [C]."""
+          initial_step_size=0.05, seed=(0, 0), chain_offset=0, init_theta=None):
+    """The whole HMC fit on the device (ci_ll_session_hmc): draws [C, S, 3+P], accept, eps [C].
+    init_theta: optional [C, dim] unconstrained starting points."""
     Cn, S = int(num_chains), int(num_results)
+    init = None if init_theta is None else np.ascontiguousarray(init_theta, dtype=np.float64)
     draws = np.zeros((Cn, S, 3 + self.P), np.float64)
     acc = np.zeros(Cn, np.float64)
     eps = np.zeros(Cn, np.float64)
     sd = (C.c_uint32 * 2)(*seed_pair(seed))
     _check(self._lib.ci_ll_session_hmc(self._h, Cn, int(chain_offset), int(num_warmup), S,
                                        int(num_leapfrog), float(target_accept),
-                                       float(initial_step_size), sd, draws.ctypes.data,
+                                       float(initial_step_size), sd, _ptr(init), draws.ctypes.data,
                                        acc.ctypes.data, eps.ctypes.data))
     return draws, acc, eps
 

@@ -100,6 +100,8 @@ class InferenceOptions:
   num_chains: int = 1
   devices: Optional[Sequence[int]] = None
   sampler: str = "gibbs"          # "gibbs" (the reference's sampler) or "hmc" (extension, _hmc.py)
+  hmc_init: str = "gibbs"         # HMC chains start at the Gibbs initial state, or ("vi") at draws
+                                  # of a mean-field surrogate posterior (_vi.py), as tfp.sts.fit_with_hmc
   # Quantiles / effect sums of the T x (chains * draws) predictive draws computed on the GPU that
   # holds them (csrc/ci_summary.h) instead of pandas on the host.  Single-device Gibbs fits only;
   # `False` keeps the reference's host arithmetic (and downloads the trajectories).
@@ -146,7 +148,8 @@ def fit_causalimpact(data: pd.DataFrame,
       num_warmup_steps=inference_options.num_warmup_steps, dtype=data_options.dtype,
       seasons=model_options.seasons, num_chains=inference_options.num_chains,
       devices=inference_options.devices, local_linear_trend=model_options.local_linear_trend,
-      sampler=inference_options.sampler, summary_request=request)
+      sampler=inference_options.sampler, summary_request=request,
+      hmc_init=inference_options.hmc_init)
   if request is not None and device_summary is None:
     # draws pooled on the host (several devices, or the HMC path): summarise them on one device
     request["ranks"] = _summary_ranks(posterior_trajectories.shape[0], request["quantiles"])
@@ -262,7 +265,8 @@ def _train_causalimpact_sts(*,
 
 def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps, model=None,
                  dtype=np.float32, seasons=(), num_chains=1, devices=None,
-                 local_linear_trend=False, sampler="gibbs", summary_request=None):
+                 local_linear_trend=False, sampler="gibbs", summary_request=None,
+                 hmc_init="gibbs"):
   """_train_causalimpact_sts plus, when `summary_request` is given (single device, Gibbs), the
   on-device summary of the predictive draws; the [draws, T] trajectories then stay in HBM and
   are returned as None."""
@@ -304,7 +308,7 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
       res = _hmc.fit_hmc(y, mask, design, params, has_slope=local_linear_trend,
                          num_results=num_results, num_warmup=num_warmup_steps,
                          num_chains=len(chain_ids), seed=seed_pair, device=dev,
-                         chain_offset=int(chain_ids[0]))
+                         chain_offset=int(chain_ids[0]), init=hmc_init)
       return {k: v for k, v in res.items() if not k.startswith("hmc_")}
     pb = _native.make_problem(T=T, P=P, has_slope=local_linear_trend, num_seasons=num_seasons,
                               num_warmup=num_warmup_steps, num_results=num_results,

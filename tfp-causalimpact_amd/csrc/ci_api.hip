@@ -762,7 +762,7 @@ struct ci_ll_session {
   DevBuf<double> theta, ll, grad;
   size_t draw_cap = 0;
   // on-device HMC (ci_hmc.h)
-  DevBuf<double> omega, h_draws, h_acc, h_eps;
+  DevBuf<double> omega, h_draws, h_acc, h_eps, h_init;
   ci_series_params prm;
 };
 
@@ -820,7 +820,8 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
 int ci_ll_session_hmc(ci_ll_session* s, int32_t num_chains, int32_t chain_offset,
                       int32_t num_warmup, int32_t num_results, int32_t num_leapfrog,
                       double target_accept, double initial_step_size, const uint32_t seed[2],
-                      double* draws, double* accept_rate, double* step_size) {
+                      const double* init_theta, double* draws, double* accept_rate,
+                      double* step_size) {
   if (!s || !seed || !draws) return fail("NULL argument");
   if (num_chains < 1 || num_results < 1 || num_warmup < 0 || num_leapfrog < 1)
     return fail("need num_chains >= 1, num_results >= 1, num_warmup >= 0, num_leapfrog >= 1");
@@ -832,7 +833,14 @@ int ci_ll_session_hmc(ci_ll_session* s, int32_t num_chains, int32_t chain_offset
   HIP_TRY(s->h_draws.alloc((size_t)C * S * (3 + P)));
   HIP_TRY(s->h_acc.alloc(C));
   HIP_TRY(s->h_eps.alloc(C));
+  const int dim = P + (s->D == 2 ? 3 : 2);
+  s->h_init.release();
+  if (init_theta) {
+    HIP_TRY(s->h_init.alloc((size_t)C * dim));
+    HIP_TRY(hipMemcpy(s->h_init.p, init_theta, (size_t)C * dim * sizeof(double), hipMemcpyHostToDevice));
+  }
   ci::HmcArgs a;
+  a.init = init_theta ? s->h_init.p : nullptr;
   a.T = s->T; a.P = P; a.C = C; a.W = num_warmup; a.S = S; a.n_leap = num_leapfrog;
   a.chain_offset = chain_offset; a.seed0 = seed[0]; a.seed1 = seed[1];
   a.y = s->y.p; a.mask = s->mask.p; a.Xt = s->xt.p; a.omega = s->omega.p;
@@ -924,7 +932,7 @@ int ci_ll_session_destroy(ci_ll_session* s) {
   (void)hipSetDevice(s->device);
   s->y.release(); s->xt.release(); s->mask.release(); s->theta.release(); s->ll.release();
   s->grad.release(); s->level.release(); s->slope.release(); s->loc.release(); s->traj.release();
-  s->omega.release(); s->h_draws.release(); s->h_acc.release(); s->h_eps.release();
+  s->omega.release(); s->h_draws.release(); s->h_acc.release(); s->h_eps.release(); s->h_init.release();
   delete s;
   return 0;
 }

@@ -31,6 +31,8 @@ struct HmcArgs {
   double init_log[3];       // log of the initial scales (causalimpact_lib.py:566-572)
   float a1, p10, p11;
   double target_accept, eps0;
+  const double* init;       // optional [C, P + 2 or 3] unconstrained starting points (e.g. draws of a
+                            // fitted surrogate posterior); NULL = the Gibbs sampler's initial state
   double* draws;            // [C, S, 3 + P]  (sigma_obs, sigma_level, sigma_slope, beta)
   double* accept_rate;      // [C]
   double* step_size;        // [C]
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
       const int k = tid - P;
       v = a.init_log[k];
     }
-    th[tid] = v + 0.01 * normal_d(rng, 0u, SITE_HMC_INIT, 0, (uint32_t)tid);
+    if (a.init) th[tid] = a.init[(size_t)chain * dim + tid];
+    else th[tid] = v + 0.01 * normal_d(rng, 0u, SITE_HMC_INIT, 0, (uint32_t)tid);
     imass[tid] = 1.0;
   }
   __syncthreads();

@@ -306,6 +306,14 @@ static int validate(const ci_problem* pb) {
   return 0;
 }
 
+int ci_session_destroy(ci_session* s);
+
+// Releases a half-built session when ci_session_create leaves through an error path.
+struct SessionGuard {
+  ci_session* s;
+  ~SessionGuard() { if (s) ci_session_destroy(s); }
+};
+
 int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask, const float* X,
                       const uint8_t* season_change, const ci_series_params* params,
                       ci_session** out) {
@@ -315,6 +323,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
   HIP_TRY(hipSetDevice(pb->device));
   ci_session* s = new ci_session();
+  SessionGuard guard{s};
   s->pb = *pb;
   const ci_problem* caller_pb = pb;
   // Trend-only series longer than the register-resident kernel holds (T > 4096) run on the
@@ -346,7 +355,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     const int pm = (P == 0) ? 0 : ((P <= 16 && s->x_in_lds) ? 1 : 2);
     s->fn = pick_kernel(D, s->L, pm);
     s->fn_prof = pick_kernel(D, s->L, pm + 8);       // instrumented variant (ci_session_profile)
-    if (!s->fn || !s->fn_prof) { delete s; return fail("no kernel for L=%d", s->L); }
+    if (!s->fn || !s->fn_prof) return fail("no kernel for L=%d", s->L);
   } else {
     s->D_full = D;
     s->dred = D;
@@ -359,9 +368,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     } else
       s->lds_bytes = ci::make_slayout(T, P, K, s->D_full, s->dred, pb->has_slope).total;
     if (s->lds_bytes > 160 * 1024) {
-      const size_t need = s->lds_bytes;
-      delete s;
-      return fail("seasonal model needs %zu bytes of LDS per chain (max 163840): reduce T", need);
+      return fail("seasonal model needs %zu bytes of LDS per chain (max 163840): reduce T",
+                  s->lds_bytes);
     }
     if (!s->wide) s->fn = (KernelFn)ci_gibbs_seasonal_fn();
   }
@@ -455,7 +463,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       yh[i] = m ? 0.f : y[i];
       if (!m) {
         nobs += 1;
-        if (!std::isfinite(y[i])) { ci_session_destroy(s); return fail("y[%d,%d] is not finite but unmasked", b, t); }
+        if (!std::isfinite(y[i])) return fail("y[%d,%d] is not finite but unmasked", b, t);
       }
     }
     const ci_series_params& q = params[b];
@@ -480,6 +488,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
           xt[((size_t)b * P + j) * T + t] = X[((size_t)b * T + t) * P + j];
     HIP_TRY(hipMemcpy(s->Xt.p, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  guard.s = nullptr;
   *out = s;
   return 0;
 }
@@ -766,6 +775,12 @@ struct ci_ll_session {
   ci_series_params prm;
 };
 
+int ci_ll_session_destroy(ci_ll_session* s);
+struct LlSessionGuard {
+  ci_ll_session* s;
+  ~LlSessionGuard() { if (s) ci_ll_session_destroy(s); }
+};
+
 int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, const float* y,
                          const uint8_t* mask, const float* X, int32_t max_evals,
                          ci_ll_session** out) {
@@ -778,6 +793,7 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
   if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
   HIP_TRY(hipSetDevice(pb->device));
   ci_ll_session* s = new ci_ll_session();
+  LlSessionGuard guard{s};
   s->T = pb->T; s->P = pb->P; s->D = pb->has_slope ? 2 : 1; s->L = steps_per_thread(pb->T);
   s->device = pb->device; s->max_evals = max_evals;
   s->a1 = (float)params->init_level_loc;
@@ -813,6 +829,7 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
     HIP_TRY(s->omega.alloc((size_t)P * P));
     HIP_TRY(hipMemcpy(s->omega.p, om.data(), om.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  guard.s = nullptr;
   *out = s;
   return 0;
 }

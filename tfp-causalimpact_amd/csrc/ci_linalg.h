@@ -307,6 +307,21 @@ __device__ __forceinline__ FElemS<D> felems_combine(const FElemS<D>& e1, const F
     }
     u.v[i] = ui;
   }
+  // J2 A1 and eta2 - J2 b1 before the elimination: A1, b1 and J2 are dead while it runs (the
+  // combine sits at the register limit for d = 8)
+  Mat<D> T2;
+  Vec<D> w = e2.eta;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float sj = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) sj = fmaf(e2.J[symidx<D>(i, k)], e1.A.m[k][j], sj);
+      T2.m[i][j] = sj;
+      w.v[i] = fmaf(-e2.J[symidx<D>(i, j)], e1.b.v[j], w.v[i]);
+    }
+  }
 #pragma unroll
   for (int c = 0; c < D; ++c) {
     const float rp = 1.0f / W.m[c][c];
@@ -344,33 +359,19 @@ __device__ __forceinline__ FElemS<D> felems_combine(const FElemS<D>& e1, const F
         r.C[symidx<D>(i, j)] = s;
       }
   }
-  {
-    Mat<D> T2;                                    // J2 W^-1 A1
-    Vec<D> w = e2.eta;                            // eta2 - J2 b1
+  // r.J = G' (J2 A1) + J1 and r.eta = G' (eta2 - J2 b1) + eta1, G = W^-1 A1 = RA
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
+  for (int i = 0; i < D; ++i) {
+    float sv = e1.eta.v[i];
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        float s = 0.f;
+    for (int k = 0; k < D; ++k) sv = fmaf(RA.m[k][i], w.v[k], sv);
+    r.eta.v[i] = sv;
 #pragma unroll
-        for (int k = 0; k < D; ++k) s = fmaf(e2.J[symidx<D>(i, k)], RA.m[k][j], s);
-        T2.m[i][j] = s;
-        w.v[i] = fmaf(-e2.J[symidx<D>(i, j)], e1.b.v[j], w.v[i]);
-      }
-    }
+    for (int j = i; j < D; ++j) {
+      float t = e1.J[symidx<D>(i, j)];
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      float s = e1.eta.v[i];
-#pragma unroll
-      for (int k = 0; k < D; ++k) s = fmaf(RA.m[k][i], w.v[k], s);
-      r.eta.v[i] = s;
-#pragma unroll
-      for (int j = i; j < D; ++j) {
-        float t = e1.J[symidx<D>(i, j)];
-#pragma unroll
-        for (int k = 0; k < D; ++k) t = fmaf(e1.A.m[k][i], T2.m[k][j], t);
-        r.J[symidx<D>(i, j)] = t;
-      }
+      for (int k = 0; k < D; ++k) t = fmaf(RA.m[k][i], T2.m[k][j], t);
+      r.J[symidx<D>(i, j)] = t;
     }
   }
   return r;

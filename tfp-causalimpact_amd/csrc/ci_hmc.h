@@ -21,7 +21,7 @@ namespace ci {
 constexpr int HMC_MAXDIM = MAXP + 3;
 
 struct HmcArgs {
-  int T, P, C, W, S, n_leap, chain_offset;
+  int T, P, C, W, S, n_leap, chain_offset, x_in_lds;
   uint32_t seed0, seed1;
   const float* y;
   const uint8_t* mask;
@@ -64,6 +64,15 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
   double* dev = imass + HMC_MAXDIM;    // device layout of th: (s_obs, s_level, s_slope, beta)
   double* gdev = dev + HMC_MAXDIM;     // score in device layout
   double* sc = gdev + HMC_MAXDIM;      // scalars: [0] ll, [1] lp of the trajectory, [2] lp current
+  // feature-major design matrix, zero padded to NT * L columns, resident in LDS for the whole fit
+  // (every leapfrog step reads it twice: residual and d l / d beta)
+  constexpr int TPAD = NT * L;
+  float* Xs = (float*)(sc + 8);
+  const bool x_in_lds = a.x_in_lds != 0;
+  if (x_in_lds) {
+    for (int j = 0; j < P; ++j)
+      for (int t = tid; t < TPAD; t += NT) Xs[j * TPAD + t] = t < T ? a.Xt[(size_t)j * T + t] : 0.f;
+  }
   const int chain = blockIdx.x;
   Rng rng{a.seed0, a.seed1, (uint32_t)(a.chain_offset + chain)};
 
@@ -79,8 +88,12 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
     }
     if (D == 1 && tid == 0) dev[2] = 0.0;
     __syncthreads();
-    loglik_grad_block<D, L>(T, P, a.y, a.mask, a.Xt, dev, a.a1, a.p10, a.p11, slots, part, &sc[0],
-                            gdev, tid, lane, wave);
+    if (x_in_lds)
+      loglik_grad_block<D, L>(T, P, a.y, a.mask, Xs, dev, a.a1, a.p10, a.p11, slots, part, &sc[0],
+                              gdev, tid, lane, wave, TPAD);
+    else
+      loglik_grad_block<D, L>(T, P, a.y, a.mask, a.Xt, dev, a.a1, a.p10, a.p11, slots, part, &sc[0],
+                              gdev, tid, lane, wave);
     __syncthreads();
     if (wave == 0) {
       double contrib = 0.0, gi = 0.0;
@@ -223,9 +236,9 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
   }
 }
 
-__host__ __device__ inline size_t hmc_lds_bytes(int P) {
+__host__ __device__ inline size_t hmc_lds_bytes(int P, int tpad_if_x_in_lds) {
   const size_t f = (((size_t)(3 * NW * 16 + NW * (P + 4)) * sizeof(float)) + 15) & ~(size_t)15;
-  return f + sizeof(double) * (8 * HMC_MAXDIM + 8);
+  return f + sizeof(double) * (8 * HMC_MAXDIM + 8) + sizeof(float) * (size_t)P * tpad_if_x_in_lds;
 }
 
 }  // namespace ci

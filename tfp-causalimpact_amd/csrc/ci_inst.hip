@@ -83,8 +83,13 @@ void CI_CAT(ci_launch_latents_d, CI_D, _l, CI_L)(int T, int P, int E, const floa
 
 // Runs the on-device HMC fit: one workgroup per chain.
 void CI_CAT(ci_launch_hmc_d, CI_D, _l, CI_L)(const ci::HmcArgs* args, hipStream_t stream) {
-  const size_t lds = ci::hmc_lds_bytes(args->P);
-  hipLaunchKernelGGL((ci::hmc_kernel<CI_D, CI_L>), dim3(args->C), dim3(ci::NT), lds, stream, *args);
+  ci::HmcArgs a = *args;
+  const size_t with_x = ci::hmc_lds_bytes(a.P, ci::NT * CI_L);
+  a.x_in_lds = (a.P > 0 && with_x <= 150 * 1024) ? 1 : 0;
+  const size_t lds = a.x_in_lds ? with_x : ci::hmc_lds_bytes(a.P, 0);
+  (void)hipFuncSetAttribute((const void*)(&ci::hmc_kernel<CI_D, CI_L>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((ci::hmc_kernel<CI_D, CI_L>), dim3(a.C), dim3(ci::NT), lds, stream, a);
 }
 
 }  // extern "C"

@@ -1903,7 +1903,10 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
                                                   const float* __restrict__ Xt, const double* th,
                                                   float a1, float p10, float p11, float* slots,
                                                   float* part, double* out_ll, double* out_grad,
-                                                  int tid, int lane, int wave) {
+                                                  int tid, int lane, int wave, int xstride = 0) {
+  // Xt: feature-major design, row j at Xt + j * xs (xs = T for the matrix in HBM; callers that
+  // evaluate many parameter sets keep a zero-padded copy in LDS and pass its row length)
+  const size_t xs = xstride ? (size_t)xstride : (size_t)T;
   const int t0 = tid * L;
   float resid[L];
   uint32_t maskbits = 0;
@@ -1913,7 +1916,7 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
     float r = 0.f;
     if (t < T && !mask[t]) {
       r = y[t];
-      for (int j = 0; j < P; ++j) r = fmaf(-Xt[(size_t)j * T + t], (float)th[3 + j], r);
+      for (int j = 0; j < P; ++j) r = fmaf(-Xt[j * xs + t], (float)th[3 + j], r);
     } else {
       maskbits |= 1u << l;
     }
@@ -2041,7 +2044,7 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
     float s = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l)
-      if (t0 + l < T) s = fmaf(Xt[(size_t)j * T + t0 + l], e_l[l], s);
+      if (t0 + l < T) s = fmaf(Xt[j * xs + t0 + l], e_l[l], s);
     put(4 + j, s);
   }
   __syncthreads();

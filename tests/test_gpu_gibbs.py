@@ -239,6 +239,34 @@ def test_batch_of_series_equals_single_series_runs():
   assert not np.array_equal(batch["level"][0], batch["level"][1])
 
 
+def test_baseline_cfg5_full_size_batch_equals_single_series_runs_and_oracle():
+  """BASELINE 'batch of 512 independent series, T=500, 5 covariates' at full size (fewer
+  iterations): one launch of 512 workgroups; spot-checked series equal their own single-series
+  launch bit for bit and the oracle per draw."""
+  T, p, B, W, S = 500, 5, 512, 3, 5
+  ys, masks, Xs, specs = [], [], [], []
+  for b in range(B):
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 1000 + b)
+    ys.append(y); masks.append(mask); Xs.append(X)
+    specs.append(orc.default_spec(y, mask, X))
+  pb = _native.make_problem(T=T, P=6, has_slope=0, num_warmup=W, num_results=S, num_series=B,
+                            seed=(5, 12))
+  batch = _native.fit_gibbs(pb, np.stack(ys), np.stack(masks), np.stack(Xs), None,
+                            _native.make_params(specs),
+                            want=("level", "weights", "observation_noise_scale"))
+  assert np.isfinite(batch["level"]).all()
+  for b in (0, 255, 511):
+    pb1 = _native.make_problem(T=T, P=6, has_slope=0, num_warmup=W, num_results=S, seed=(5, 12))
+    one = _native.fit_gibbs(pb1, ys[b][None], masks[b][None], Xs[b][None], None,
+                            _native.make_params([specs[b]]),
+                            want=("level", "weights", "observation_noise_scale"))
+    for k in ("level", "weights", "observation_noise_scale"):
+      np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
+    w = orc.fit_gibbs(ys[b], masks[b], Xs[b], specs[b], num_results=S, num_warmup=W, seed=(5, 12))
+    np.testing.assert_allclose(batch["level"][b, 0], w["level"], atol=5e-3)
+    np.testing.assert_allclose(batch["weights"][b, 0], w["weights"], atol=5e-3)
+
+
 def test_fit_causalimpact_over_several_device_shares_equals_one_launch():
   """`InferenceOptions.devices` shards chains over devices, one host thread each.  With the
   single test GPU listed twice the two shares run concurrently on it; pooled draws must be the

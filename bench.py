@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- posterior samples/sec of the Gibbs hot path on MI355X.
+"""bench.py -- posterior samples/sec of the posterior-inference hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "cfg2"): T=1000, 10 covariates (+intercept => P=11),
+Default workload (BASELINE.json configs[1], "cfg2"): T=1000, 10 covariates (+intercept => P=11),
 LocalLinearTrend + spike-and-slab regression, 1000 retained Gibbs draws x 8 chains per GPU,
-W = ceil(1000/9) = 112 warm-up iterations, float32.  One "step" = one complete fit
-(all W+S iterations of all chains of this rank).  Chains are independent, so ranks shard
-them with no data-path collective (weak scaling: 8 chains per GPU); RCCL is used only
-after the timed region, to gather per-chain moments for the split-R-hat diagnostic.
+W = ceil(1000/9) = 112 warm-up iterations, float32.  `--sampler hmc` runs configs[2] ("cfg3"):
+the same series, windowed-adaptive HMC (15 leapfrog steps, 500 warm-up iterations, 1000 retained
+draws), 8 chains per GPU = 64 chains on 8 GPUs, plus the latent-path / predictive draw of every
+retained sample.  One "step" = one complete fit (all iterations of all chains of this rank).
+Chains are independent, so ranks shard them with no data-path collective (weak scaling: 8 chains
+per GPU); RCCL is used only after the timed region, to gather per-chain moments for the
+split-R-hat diagnostic.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--sampler gibbs|hmc]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -30,83 +33,159 @@ from causalimpact import _native  # noqa: E402
 from causalimpact import _synthetic as syn  # noqa: E402
 
 CFG = dict(T=1000, covariates=10, has_slope=1, num_results=1000, num_warmup=112,
-           chains_per_gpu=8, data_seed=2024, seed=(0, 20240927))
+           chains_per_gpu=8, data_seed=2024, seed=(0, 20240927),
+           hmc_warmup=500, hmc_leapfrog=15)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def _cpu_baseline(y, mask, X, min_seconds=10.0):
-  """Times the float64 CPU restatement (oracle/, kind="port") on host cores.
+def _cpu_chain(sampler, y, mask, X, spec, S, W, chain):
+  from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
+  if sampler == "hmc":
+    orc.fit_hmc(y, mask, X, spec, num_results=S, num_warmup=W, num_leapfrog=CFG["hmc_leapfrog"],
+                seed=CFG["seed"], chain=chain)
+  else:
+    orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=CFG["seed"], chain=chain,
+                  want=("obs_scale", "level_scale", "slope_scale", "weights", "level", "slope",
+                        "pred_mean", "trajectories"))
+  return 0
 
-  1 core: the cfg2 workload itself (8 chains x 1112 iterations), repeated until
-  >= min_seconds of CPU work.  All cores: the same chains spread over os.cpu_count()
-  processes.  The oracle is the checker here, never the product path.
-  """
+
+def _cpu_worker(sampler, y, mask, X, spec, S, W, first_chain, go, seconds, done):
+  """One host core: whole chains until `seconds` after the common start; reports how many."""
+  from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
+  orc.lib()
+  go.wait()
+  t0 = time.perf_counter()
+  n = 0
+  while time.perf_counter() - t0 < seconds:
+    _cpu_chain(sampler, y, mask, X, spec, S, W, first_chain + n)
+    n += 1
+  done.put((n, time.perf_counter() - t0))
+
+
+def _cpu_baseline(sampler, y, mask, X, min_seconds=10.0):
+  """Times the float64 CPU restatement (oracle/, kind="port") on the host's cores.
+
+  1 core: whole chains of the bench workload, repeated until >= min_seconds of CPU work.
+  All cores: one process per core (os.cpu_count() of them), each running whole chains until the
+  same deadline (bounded: ~min_seconds plus one chain).  The oracle is the checker here, never
+  the product path."""
   import multiprocessing as mp  # pylint: disable=import-outside-toplevel
   from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
   spec = orc.default_spec(y, mask, X, has_slope=bool(CFG["has_slope"]))
-  S, W = CFG["num_results"], CFG["num_warmup"]
-  want = ("obs_scale", "level_scale", "slope_scale", "weights", "level", "slope", "pred_mean",
-          "trajectories")
+  S = CFG["num_results"]
+  W = CFG["hmc_warmup"] if sampler == "hmc" else CFG["num_warmup"]
   orc.lib()
   t0 = time.perf_counter()
   chains = 0
   while time.perf_counter() - t0 < min_seconds:
-    orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=CFG["seed"], chain=chains,
-                  want=want)
+    _cpu_chain(sampler, y, mask, X, spec, S, W, chains)
     chains += 1
   dt1 = time.perf_counter() - t0
   one = chains * S / dt1
-  ncpu = os.cpu_count() or 1
+  what = (f"({W}+{S}) x {CFG['hmc_leapfrog']}-leapfrog HMC iterations + latent draws"
+          if sampler == "hmc" else f"({W}+{S}) Gibbs iterations")
   res = {"value": one, "unit": "posterior samples/sec", "cores": 1, "kind": "port",
-         "sample": f"{chains} chains x ({W}+{S}) Gibbs iterations of the cfg2 series, float64 C "
-                   f"restatement (oracle/ci_oracle.c), {dt1:.1f} s"}
+         "sample": f"{chains} chains x {what} of the bench series, float64 C restatement "
+                   f"(oracle/ci_oracle.c), {dt1:.1f} s"}
+  ncpu = os.cpu_count() or 1
   if ncpu > 1:
-    # one process per core (capped at 64 so the sample stays ~10-20 s), 4 chains each
-    nproc, per = min(ncpu, 64), 4
     ctx = mp.get_context("fork")
-    with ctx.Pool(nproc) as pool:
-      pool.map(_cpu_noop, range(nproc))          # start the workers before timing
-      t1 = time.perf_counter()
-      pool.starmap(_cpu_chain, [(y, mask, X, spec, S, W, 1000 + i) for i in range(nproc * per)],
-                   chunksize=per)
-      dtn = time.perf_counter() - t1
-    res["all_cores"] = {"value": nproc * per * S / dtn, "cores": nproc,
-                        "sample": f"{nproc * per} chains over {nproc} processes "
-                                  f"(host has {ncpu} cores), {dtn:.1f} s"}
+    go, done = ctx.Event(), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(sampler, y, mask, X, spec, S, W, 1000 + 4096 * i,
+                                                   go, min_seconds, done)) for i in range(ncpu)]
+    for pr in procs:
+      pr.start()
+    time.sleep(1.0)                              # workers load the library before the start signal
+    go.set()
+    got = [done.get() for _ in procs]
+    for pr in procs:
+      pr.join()
+    n_tot = sum(n for n, _ in got)
+    dtn = max(t for _, t in got)
+    res["all_cores"] = {"value": n_tot * S / dtn, "cores": ncpu,
+                        "sample": f"{n_tot} chains over {ncpu} processes (one per host core), "
+                                  f"{dtn:.1f} s"}
   return res
 
 
-def _cpu_noop(_):
-  from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
-  orc.lib()
-  return 0
-
-
-def _cpu_chain(y, mask, X, spec, S, W, chain):
-  from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
-  orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=CFG["seed"], chain=chain,
-                want=("obs_scale", "level", "trajectories", "weights"))
-  return 0
-
-
-def _pmc_traffic():
+def _pmc_traffic(sampler):
   """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc.json, written
   by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
-  path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-  if not os.path.exists(path):
-    return None
-  with open(path) as f:
-    return json.load(f).get("hbm_bytes_per_launch")
+  names = ("r02_cfg3_pmc.json",) if sampler == "hmc" else ("r02_pmc.json", "r01_pmc.json")
+  for name in names:
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+      with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_launch")
+  return None
+
+
+class _GibbsFit:
+  """cfg2: the persistent Gibbs kernel, inputs and outputs resident in HBM."""
+
+  def __init__(self, y, mask, X, C, rank, device):
+    spec = _model.series_params(y, mask, X, prior_level_sd=0.01, has_slope=bool(CFG["has_slope"]))
+    pb = _native.make_problem(T=CFG["T"], P=X.shape[1], has_slope=CFG["has_slope"],
+                              num_warmup=CFG["num_warmup"], num_results=CFG["num_results"],
+                              num_chains=C, chain_offset=rank * C, seed=CFG["seed"], device=device)
+    self.sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+    self.workload = ("cfg2: T=1000, 10 covariates (P=11), LocalLinearTrend + spike-and-slab "
+                     "regression, Gibbs, W=112, S=1000")
+
+  def run(self):
+    return {"kernel": self.sess.run()}
+
+  def fetch(self):
+    res = self.sess.fetch()
+    return {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
+
+  def note(self, C):
+    return ("one persistent workgroup per chain: %d of 256 CUs busy; the fit is bound by the "
+            "(W+S)-long sequential Gibbs dependency, not by HBM (DESIGN.md)" % C)
+
+
+class _HmcFit:
+  """cfg3: the on-device HMC chain + the latent / predictive pass."""
+
+  def __init__(self, y, mask, X, C, rank, device):
+    spec = _model.series_params(y, mask, X, prior_level_sd=0.01, has_slope=bool(CFG["has_slope"]))
+    pb = _native.make_problem(T=CFG["T"], P=X.shape[1], has_slope=CFG["has_slope"], num_warmup=0,
+                              num_results=1, seed=CFG["seed"], device=device)
+    self.sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8)
+    self.kw = dict(num_chains=C, chain_offset=rank * C, num_warmup=CFG["hmc_warmup"],
+                   num_results=CFG["num_results"], num_leapfrog=CFG["hmc_leapfrog"], seed=CFG["seed"])
+    self.workload = ("cfg3: T=1000, 10 covariates (P=11), LocalLinearTrend + Gaussian-slab "
+                     "regression, windowed-adaptive HMC, %d leapfrogs, W=%d, S=1000, latent path + "
+                     "predictive trajectory per draw" % (CFG["hmc_leapfrog"], CFG["hmc_warmup"]))
+
+  def run(self):
+    hmc_ms, lat_ms = self.sess.hmc_run(**self.kw)
+    return {"kernel": hmc_ms, "latents": lat_ms}
+
+  def fetch(self):
+    _, _, _, res = self.sess.hmc_fetch()
+    return {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
+
+  def note(self, C):
+    return ("one persistent workgroup per chain (%d of 256 CUs) runs (W+S) x leapfrog dependent "
+            "score evaluations; the latent / predictive pass (one workgroup per draw) fills the "
+            "chip; `achieved` counts the fit's algorithmic bytes over BOTH kernels' time" % C)
 
 
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=20)
-  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--steps", type=int, default=None)
+  ap.add_argument("--warmup", type=int, default=None)
+  ap.add_argument("--sampler", choices=("gibbs", "hmc"), default="gibbs")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--chains-per-gpu", type=int, default=CFG["chains_per_gpu"])
   args = ap.parse_args()
+  if args.steps is None:
+    args.steps = 20 if args.sampler == "gibbs" else 5
+  if args.warmup is None:
+    args.warmup = 3 if args.sampler == "gibbs" else 1
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
@@ -122,14 +201,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-  T, C = CFG["T"], args.chains_per_gpu
-  y, mask, X, _ = syn.make_sampler_inputs(T, CFG["covariates"], CFG["data_seed"])
-  spec = _model.series_params(y, mask, X, prior_level_sd=0.01, has_slope=bool(CFG["has_slope"]))
-  pb = _native.make_problem(T=T, P=X.shape[1], has_slope=CFG["has_slope"],
-                            num_warmup=CFG["num_warmup"], num_results=CFG["num_results"],
-                            num_chains=C, chain_offset=rank * C, seed=CFG["seed"],
-                            device=local_rank)
-  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  C = args.chains_per_gpu
+  y, mask, X, _ = syn.make_sampler_inputs(CFG["T"], CFG["covariates"], CFG["data_seed"])
+  fit = (_HmcFit if args.sampler == "hmc" else _GibbsFit)(y, mask, X, C, rank, local_rank)
 
   def sync():
     if dist is not None:
@@ -138,12 +212,12 @@ def main():
       torch.cuda.synchronize()
 
   for _ in range(args.warmup):
-    sess.run()
+    fit.run()
   sync()
   t0 = time.perf_counter()
   kernel_ms = []
   for _ in range(args.steps):
-    kernel_ms.append(sess.run())      # run() waits for the fit's stream
+    kernel_ms.append(fit.run())      # run() waits for the fit's stream
   sync()
   dt = time.perf_counter() - t0
   if dist is not None:
@@ -154,12 +228,11 @@ def main():
 
   # ---- after the timed region: PCIe-inclusive rate, chain gather + diagnostics (RCCL)
   t1 = time.perf_counter()
-  sess.run()
-  res = sess.fetch()
+  fit.run()
+  local = fit.fetch()
   dt_pcie = time.perf_counter() - t1
   # chain gather + split-R-hat across ranks (RCCL all-gather / all-reduce; no-op at N=1)
   from causalimpact import _distributed  # pylint: disable=import-outside-toplevel
-  local = {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
   comb = _distributed.fit_sharded(lambda first, count: local, world * C,
                                   gather_keys=("posterior_means",),
                                   device="cuda" if dist is not None else None)
@@ -167,32 +240,37 @@ def main():
 
   samples_per_step = world * C * CFG["num_results"]
   value = samples_per_step * args.steps / dt
-  k_ms = float(np.mean(kernel_ms))
-  alg_bytes = sess.algorithmic_bytes()
+  k_ms = float(np.mean([sum(k.values()) for k in kernel_ms]))
+  alg_bytes = fit.sess.algorithmic_bytes()
   achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+  roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(args.sampler),
+          "kernel": fit.sess.kernel_name(),
+          "kernel_ms": float(np.mean([k["kernel"] for k in kernel_ms])),
+          "algorithmic_bytes_per_launch": alg_bytes, "note": fit.note(C)}
+  if args.sampler == "hmc":
+    roof["latents_kernel_ms"] = float(np.mean([k["latents"] for k in kernel_ms]))
+    n_leap = (CFG["hmc_warmup"] + CFG["num_results"]) * CFG["hmc_leapfrog"]
+    roof["us_per_leapfrog"] = roof["kernel_ms"] * 1e3 / n_leap
+  else:
+    roof["us_per_gibbs_iteration"] = roof["kernel_ms"] * 1e3 / (CFG["num_warmup"] + CFG["num_results"])
   out = {
       "metric": "posterior samples/sec (T=1000, 10 covariates)",
       "value": value, "unit": "posterior samples/sec", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-      "config": {"workload": "cfg2: T=1000, 10 covariates (P=11), LocalLinearTrend + "
-                             "spike-and-slab regression, Gibbs, W=112, S=1000",
+      "config": {"workload": fit.workload, "sampler": args.sampler,
                  "chains_per_gpu": C, "chains_total": world * C,
                  "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
-      "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(),
-                   "kernel": "ci::gibbs_kernel<2,4,1,false>", "kernel_ms": k_ms,
-                   "algorithmic_bytes_per_launch": alg_bytes,
-                   "note": "one workgroup per chain: 8 of 256 CUs busy; the fit is bound by the "
-                           "(W+S)-long sequential Gibbs dependency, not by HBM (DESIGN.md)"},
+      "roofline": roof,
       "pcie_inclusive_value": C * CFG["num_results"] / dt_pcie,
       "split_rhat": rhat,
   }
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
-    out["cpu_baseline"] = _cpu_baseline(y, mask, X)
+    out["cpu_baseline"] = _cpu_baseline(args.sampler, y, mask, X)
   elif rank == 0:
     out["cpu_baseline"] = None
-  sess.close()
+  fit.sess.close()
   if rank == 0:
     print(json.dumps(out))
   if dist is not None:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CI_ABI_VERSION 1
+#define CI_ABI_VERSION 2
 #define CI_MAX_BLOCKS 8
 
 /* Per-series priors and initial Gibbs state.  One per series because every
@@ -93,6 +93,9 @@ typedef struct ci_session ci_session;  /* device-resident fit: inputs + outputs 
 const char* ci_last_error(void);
 int ci_abi_version(void);
 int ci_device_count(int* count);
+/* Device buffers of finished sessions are parked in a per-process pool (<= 2 GiB) for reuse by
+ * the next fit; this returns them to the driver. */
+int ci_pool_trim(void);
 
 /* One-shot: upload, run all W+S Gibbs iterations for B*C chains, download.
  *   y     [B,T]    float32 outcome (standardised); value ignored where mask != 0
@@ -115,6 +118,9 @@ int ci_session_run(ci_session* session, float* kernel_ms);
 int ci_session_fetch(ci_session* session, ci_outputs* outputs);
 /* Bytes the kernel must move per run (algorithmic bytes, DESIGN.md "Roofline"). */
 int ci_session_algorithmic_bytes(const ci_session* session, double* bytes);
+/* Name of the Gibbs kernel instantiation this session dispatches to, as a profiler shows it
+ * (e.g. "ci::gibbs_kernel<2,4,1,false>"); NUL-terminated, truncated to buflen. */
+int ci_session_kernel_name(const ci_session* session, char* buf, int32_t buflen);
 /* Developer aid: when enabled, the next ci_session_run() accumulates shader-clock cycles of
  * the kernel's phases (block 0) into 32 counters; cycles16 (optional, 32 entries) receives the counters
  * of the previous run.  Slot meaning: DESIGN.md "Time budget". */
@@ -172,25 +178,49 @@ int ci_ll_session_eval(ci_ll_session* session, int32_t num_evals, const double* 
 int ci_ll_session_draw_latents(ci_ll_session* session, int32_t num_draws, const double* theta,
                                const uint32_t seed[2], uint32_t rng_chain, uint32_t iter0,
                                float* level, float* slope, float* loc, float* traj);
-/* Hamiltonian Monte Carlo over theta = (beta, log sigma_obs, log sigma_level[, log sigma_slope])
- * entirely on the device: one workgroup per chain runs num_warmup + num_results iterations of
- * num_leapfrog steps (log-likelihood + score by the same time-parallel scans as
- * ci_ll_session_eval), with dual-averaging step-size adaptation and a per-chain diagonal mass
- * estimate during warm-up.  Target: l(theta) + the reference's inverse-gamma variance priors
- * (causalimpact_lib.py:424-443) + the Gaussian slab of the weights prior (:451-453).
- * EXTENSION (upstream analogue tfp.sts.fit_with_hmc; the reference
- * itself has no HMC path).  RNG stream (seed, chain = chain_offset + c): results do not depend
- * on how chains are split over devices.  Outputs (host): draws [num_chains, num_results, 3 + P]
- * float64 rows (sigma_obs, sigma_level, sigma_slope, beta) -- feed them to
- * ci_ll_session_draw_latents for latent paths / predictive trajectories; accept_rate,
- * step_size [num_chains] (optional).  init_theta (optional): [num_chains, P + 2 (+1 with a
- * slope)] unconstrained starting points (beta, log sigma_obs, log sigma_level[, log sigma_slope]),
- * e.g. draws of a fitted surrogate posterior; NULL starts from the Gibbs sampler's initial state. */
-int ci_ll_session_hmc(ci_ll_session* session, int32_t num_chains, int32_t chain_offset,
-                      int32_t num_warmup, int32_t num_results, int32_t num_leapfrog,
-                      double target_accept, double initial_step_size, const uint32_t seed[2],
-                      const double* init_theta, double* draws, double* accept_rate,
-                      double* step_size);
+/* Hamiltonian Monte Carlo over the model's parameters entirely on the device: one workgroup per
+ * chain runs num_warmup + num_results iterations of num_leapfrog steps (log-likelihood + score by
+ * the same time-parallel scans as ci_ll_session_eval).  Warm-up is the three-stage windowed scheme
+ * (step size by dual averaging -> doubling windows that re-estimate the diagonal mass -> step
+ * size), csrc/ci_hmc.h.  Then ONE launch draws the latent path and the posterior-predictive
+ * trajectory of every retained draw (what causalimpact_lib.py:609-632 does with the Gibbs
+ * states), and the fit stays resident in HBM until ci_ll_session_hmc_fetch.
+ * Target: l(theta) + the reference's inverse-gamma variance priors (causalimpact_lib.py:424-443)
+ * + a continuous regression prior (the spike-and-slab prior has no density):
+ *   CI_HMC_PRIOR_SLAB       the Gaussian slab of the reference's prior (:451-453);
+ *                           theta = (beta[P], log sigma_obs, log sigma_level[, log sigma_slope])
+ *   CI_HMC_PRIOR_HORSESHOE  the horseshoe of tfp.sts.SparseLinearRegression (what BASELINE.json's
+ *                           north_star names): beta_j = z_j ln_j sqrt(lv_j) gn sqrt(gv) s0;
+ *                           theta = (z[P], log ln[P], log lv[P], log gn, log gv, log scales)
+ * EXTENSION (upstream analogues tfp.sts.fit_with_hmc /
+ * tfp.experimental.mcmc.windowed_adaptive_hmc; the reference itself has no HMC path).  RNG stream
+ * (seed, chain = chain_offset + c): results do not depend on how chains are split over devices.
+ * init_theta (optional): [num_chains, dim] unconstrained starting points, e.g. draws of a fitted
+ * surrogate posterior; NULL starts from the Gibbs sampler's initial state.
+ * kernel_ms (optional, 2 floats): HIP-event durations on the session's stream of the HMC kernel
+ * and of the latent/predictive pass. */
+#define CI_HMC_PRIOR_SLAB 0
+#define CI_HMC_PRIOR_HORSESHOE 1
+typedef struct ci_hmc_options {
+  int32_t num_chains, chain_offset;
+  int32_t num_warmup, num_results, num_leapfrog;
+  int32_t prior;                 /* CI_HMC_PRIOR_* */
+  double target_accept;          /* dual-averaging target (0.75 upstream) */
+  double initial_step_size;
+  double horseshoe_scale;        /* s0 = weights_prior_scale (horseshoe only) */
+  uint32_t seed[2];
+} ci_hmc_options;
+int ci_ll_session_hmc_run(ci_ll_session* session, const ci_hmc_options* options,
+                          const double* init_theta, float* kernel_ms);
+/* Copies the finished fit to the host; every pointer may be NULL.  draws [num_chains,
+ * num_results, 3 + P] float64 rows (sigma_obs, sigma_level, sigma_slope, beta); accept_rate,
+ * step_size [num_chains]; outputs: the sample container of ci_fit_gibbs with B = 1 (seasonal
+ * fields ignored). */
+int ci_ll_session_hmc_fetch(ci_ll_session* session, double* draws, double* accept_rate,
+                            double* step_size, ci_outputs* outputs);
+int ci_ll_session_kernel_name(const ci_ll_session* session, char* buf, int32_t buflen);
+/* Algorithmic bytes of the last configured HMC fit (DESIGN.md "Roofline", cfg3). */
+int ci_ll_session_algorithmic_bytes(const ci_ll_session* session, double* bytes);
 int ci_ll_session_destroy(ci_ll_session* session);
 
 /* ---- component entry points used by the parity tests (tests/test_gpu_*.py) ---- */

@@ -657,3 +657,421 @@ int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out) {
   free(chol_post); free(mean); free(zw); free(nz); free(perm_u); free(perm);
   return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* Row H (extension): score of the Kalman          */
+/* log-likelihood and the HMC sampler of csrc/ci_hmc.h, restated in     */
+/* float64.  The reference has no HMC path (upstream analogues:          */
+/* tfp.sts.fit_with_hmc, tfp.experimental.mcmc.windowed_adaptive_hmc);   */
+/* parity with TFP unpinned.  The score is pinned by central differences */
+/* of ci_oracle_kalman_loglik (itself pinned to the dense MVN density).  */
+/* ------------------------------------------------------------------ */
+
+/* Koopman & Shephard (1992), in the filter-gain form of SURVEY.md Appendix F:
+ *   r_{t-1} = Z' v_t/F_t + (I - K_t Z)' T_t' r_t,      r_{T-1} = 0
+ *   N_{t-1} = Z'Z/F_t + (I - K_t Z)' T_t' N_t T_t (I - K_t Z),  N_{T-1} = 0
+ *   e_t = v_t/F_t - K_t' T_t' r_t = -dl/d data_t                 (observed t)
+ *   dl/dH = 1/2 sum_obs (e_t^2 - D_t),  D_t = 1/F_t + K_t' T_t' N_t T_t K_t
+ *   dl/dQ_t = 1/2 (r_t r_t' - N_t)  for the disturbance entering step t+1. */
+double ci_oracle_loglik_score(const ci_oracle_ssm* m, const double* data, double* e_out,
+                              double* g_scales) {
+  int d = m->d, T = m->T, K = m->num_blocks;
+  kf_store st;
+  st.a = NULL; st.P = NULL;
+  st.vf = (double*)malloc(sizeof(double) * T);
+  st.kf = (double*)malloc(sizeof(double) * T * d);
+  /* F_t is needed below: recover it from kf and a second pass would cost a filter; store it */
+  double* Fv = (double*)malloc(sizeof(double) * T);
+  {
+    /* forward pass (kalman_forward with F_t recorded) */
+    double a[CI_MAX_D], P[CI_MAX_D * CI_MAX_D], pz[CI_MAX_D];
+    double H = m->obs_scale * m->obs_scale;
+    initial_moments(m, a, P);
+    st.loglik = 0.0;
+    for (int t = 0; t < T; ++t) {
+      Fv[t] = 0.0;
+      if (!m->mask[t]) {
+        double v = data[t] - observe(m, a);
+        for (int i = 0; i < d; ++i) pz[i] = observe(m, &P[i * d]);
+        double F = observe(m, pz) + H;
+        Fv[t] = F;
+        st.loglik += -0.5 * (log(2.0 * M_PI) + log(F) + v * v / F);
+        for (int i = 0; i < d; ++i) {
+          double k = pz[i] / F;
+          st.kf[(size_t)t * d + i] = k;
+          a[i] += k * v;
+        }
+        for (int i = 0; i < d; ++i)
+          for (int j = 0; j < d; ++j) P[i * d + j] -= pz[i] * pz[j] / F;
+        st.vf[t] = v / F;
+      } else {
+        st.vf[t] = 0.0;
+        memset(&st.kf[(size_t)t * d], 0, sizeof(double) * d);
+      }
+      if (t + 1 < T) {
+        apply_transition(m, t, a);
+        propagate_cov(m, t, P);
+      }
+    }
+  }
+  double r[CI_MAX_D], N[CI_MAX_D * CI_MAX_D], z[CI_MAX_D], mk[CI_MAX_D], col[CI_MAX_D];
+  memset(r, 0, sizeof(r));
+  memset(N, 0, sizeof(N));
+  memset(z, 0, sizeof(z));
+  z[0] = 1.0;
+  for (int k = 0; k < K; ++k) z[block_offset(m, k)] = 1.0;
+  double gH = 0.0, gQl = 0.0, gQs = 0.0, gQd[CI_MAX_BLOCKS];
+  for (int k = 0; k < K; ++k) gQd[k] = 0.0;
+  for (int t = T - 1; t >= 0; --t) {
+    if (t + 1 < T) {
+      /* disturbance of the transition t -> t+1 */
+      gQl += 0.5 * (r[0] * r[0] - N[0]);
+      if (m->has_slope) gQs += 0.5 * (r[1] * r[1] - N[1 * d + 1]);
+      for (int k = 0; k < K; ++k) {
+        if (!m->season_change[(size_t)k * T + t]) continue;
+        int o = block_offset(m, k), n = m->num_seasons[k];
+        double sr = 0.0, sn = 0.0;
+        for (int i = 0; i < n - 1; ++i) {
+          sr += r[o + i];
+          for (int j = 0; j < n - 1; ++j) sn += N[(o + i) * d + (o + j)];
+        }
+        gQd[k] += 0.5 * (sr * sr - sn) / ((double)n * n);   /* Q = (sigma_d/n)^2 11' */
+      }
+      /* r <- T' r ;  N <- T' N T */
+      apply_transition_T(m, t, r);
+      for (int j = 0; j < d; ++j) {
+        for (int i = 0; i < d; ++i) col[i] = N[i * d + j];
+        apply_transition_T(m, t, col);
+        for (int i = 0; i < d; ++i) N[i * d + j] = col[i];
+      }
+      for (int i = 0; i < d; ++i) apply_transition_T(m, t, &N[i * d]);
+    }
+    if (e_out) e_out[t] = 0.0;
+    if (!m->mask[t]) {
+      const double* kf = &st.kf[(size_t)t * d];
+      double F = Fv[t], kr = 0.0, kmk = 0.0;
+      for (int i = 0; i < d; ++i) kr += kf[i] * r[i];
+      for (int i = 0; i < d; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) s += N[i * d + j] * kf[j];
+        mk[i] = s;
+      }
+      for (int i = 0; i < d; ++i) kmk += kf[i] * mk[i];
+      double e = st.vf[t] - kr;
+      if (e_out) e_out[t] = e;
+      gH += 0.5 * (e * e - (1.0 / F + kmk));
+      /* r_{t-1} = (I - K Z)' r + Z' v/F  = r + Z' (v/F - K'r) */
+      for (int i = 0; i < d; ++i) r[i] += z[i] * e;
+      /* N_{t-1} = (I - K Z)' N (I - K Z) + Z'Z/F */
+      for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+          N[i * d + j] += -z[i] * mk[j] - mk[i] * z[j] + z[i] * z[j] * (kmk + 1.0 / F);
+    }
+  }
+  if (g_scales) {
+    g_scales[0] = 2.0 * m->obs_scale * gH;
+    g_scales[1] = 2.0 * m->level_scale * gQl;
+    g_scales[2] = m->has_slope ? 2.0 * m->slope_scale * gQs : 0.0;
+    for (int k = 0; k < K; ++k) g_scales[3 + k] = 2.0 * m->drift_scale[k] * gQd[k];
+  }
+  double ll = st.loglik;
+  free(st.vf); free(st.kf); free(Fv);
+  return ll;
+}
+
+static double clamp30(double v) { return v < -30.0 ? -30.0 : (v > 30.0 ? 30.0 : v); }
+
+void ci_oracle_hmc_windows(int W, int* slow_begin, int* slow_end, int* first_end, int* base) {
+  if (W < 20) { *slow_begin = *slow_end = *first_end = W; *base = 0; return; }
+  int ib = 75, tb = 50, bw = 25;
+  if (ib + tb + bw > W) { ib = (int)(0.15 * W); tb = (int)(0.10 * W); bw = W - ib - tb; }
+  *slow_begin = ib; *slow_end = W - tb; *base = bw;
+  int e = ib + bw;
+  if (e + 2 * bw > *slow_end) e = *slow_end;
+  *first_end = e;
+}
+
+/* log posterior and gradient at the unconstrained point th (csrc/ci_hmc.h "Target"). */
+static double hmc_target(const ci_oracle_hmc_problem* pb, ci_oracle_ssm* m, const double* th,
+                         double* g, double* dev /* 3+K+P */, double* resid, double* e) {
+  const int T = pb->T, P = pb->P, K = pb->num_blocks;
+  const int hs = pb->prior_mode == 1;
+  const int off_sc = hs ? 3 * P + 2 : P;
+  const int nsc = 2 + (pb->has_slope ? 1 : 0) + K;
+  const int dim = off_sc + nsc;
+  double hsc[256];
+  double* beta = dev + 3 + K;
+  for (int j = 0; j < P; ++j) {
+    if (hs) {
+      hsc[j] = exp(clamp30(th[P + j]) + 0.5 * clamp30(th[2 * P + j]) + clamp30(th[3 * P]) +
+                   0.5 * clamp30(th[3 * P + 1])) * pb->hs_scale0;
+      beta[j] = th[j] * hsc[j];
+    } else {
+      beta[j] = th[j];
+    }
+  }
+  /* scale order in theta: obs, level, [slope], drift[K];  dev: obs, level, slope, drift[K] */
+  int q = off_sc;
+  m->obs_scale = exp(clamp30(th[q++]));
+  m->level_scale = exp(clamp30(th[q++]));
+  m->slope_scale = pb->has_slope ? exp(clamp30(th[q++])) : 0.0;
+  for (int k = 0; k < K; ++k) m->drift_scale[k] = exp(clamp30(th[q++]));
+  for (int t = 0; t < T; ++t) {
+    double r = 0.0;
+    if (!pb->mask[t]) {
+      r = pb->y[t];
+      for (int j = 0; j < P; ++j) r -= pb->X[(size_t)t * P + j] * beta[j];
+    }
+    resid[t] = r;
+  }
+  double gs[3 + CI_MAX_BLOCKS];
+  double lp = ci_oracle_loglik_score(m, resid, e, gs);
+  double gbeta[256];
+  for (int j = 0; j < P; ++j) {
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s += pb->X[(size_t)t * P + j] * e[t];
+    gbeta[j] = s;
+  }
+  /* scales: IG(a, b) on sigma^2 + Jacobian of lam = log sigma */
+  {
+    double sig[3 + CI_MAX_BLOCKS], gsig[3 + CI_MAX_BLOCKS];
+    int n = 0;
+    sig[n] = m->obs_scale; gsig[n++] = gs[0];
+    sig[n] = m->level_scale; gsig[n++] = gs[1];
+    if (pb->has_slope) { sig[n] = m->slope_scale; gsig[n++] = gs[2]; }
+    for (int k = 0; k < K; ++k) { sig[n] = m->drift_scale[k]; gsig[n++] = gs[3 + k]; }
+    for (int k = 0; k < nsc; ++k) {
+      double lam = clamp30(th[off_sc + k]), e2 = exp(-2.0 * lam);
+      lp += -2.0 * pb->ig_a[k] * lam - pb->ig_b[k] * e2;
+      g[off_sc + k] = sig[k] * gsig[k] - 2.0 * pb->ig_a[k] + 2.0 * pb->ig_b[k] * e2;
+    }
+  }
+  if (!hs) {
+    for (int i = 0; i < P; ++i) {
+      double ob = 0.0;
+      for (int k = 0; k < P; ++k) ob += th[k] * pb->omega[(size_t)k * P + i];
+      lp += -0.5 * th[i] * ob;
+      g[i] = gbeta[i] - ob;
+    }
+  } else {
+    double sgb = 0.0;
+    for (int j = 0; j < P; ++j) sgb += gbeta[j] * beta[j];
+    for (int j = 0; j < P; ++j) {
+      double zj = th[j];
+      lp += -0.5 * zj * zj;
+      g[j] = gbeta[j] * hsc[j] - zj;
+      double u = clamp30(th[P + j]), ee = exp(2.0 * u);
+      lp += -0.5 * ee + u;
+      g[P + j] = gbeta[j] * beta[j] - ee + 1.0;
+      u = clamp30(th[2 * P + j]); ee = exp(-u);
+      lp += -0.5 * u - 0.5 * ee;
+      g[2 * P + j] = 0.5 * gbeta[j] * beta[j] - 0.5 + 0.5 * ee;
+    }
+    double u = clamp30(th[3 * P]), ee = exp(2.0 * u);
+    lp += -0.5 * ee + u;
+    g[3 * P] = sgb - ee + 1.0;
+    u = clamp30(th[3 * P + 1]); ee = exp(-u);
+    lp += -0.5 * u - 0.5 * ee;
+    g[3 * P + 1] = 0.5 * sgb - 0.5 + 0.5 * ee;
+  }
+  if (!(lp == lp) || lp > 1e300 || lp < -1e300) {
+    lp = -INFINITY;
+    for (int i = 0; i < dim; ++i) g[i] = 0.0;
+  }
+  return lp;
+}
+
+int ci_oracle_hmc_dim(const ci_oracle_hmc_problem* pb) {
+  return (pb->prior_mode == 1 ? 3 * pb->P + 2 : pb->P) + 2 + (pb->has_slope ? 1 : 0) + pb->num_blocks;
+}
+
+double ci_oracle_hmc_logp(const ci_oracle_hmc_problem* pb, const double* theta, double* grad) {
+  ci_oracle_ssm m;
+  memset(&m, 0, sizeof(m));
+  m.T = pb->T; m.has_slope = pb->has_slope; m.num_blocks = pb->num_blocks;
+  for (int k = 0; k < pb->num_blocks; ++k) m.num_seasons[k] = pb->num_seasons[k];
+  m.d = ci_oracle_state_dim(pb->has_slope, pb->num_blocks, pb->num_seasons);
+  m.mask = pb->mask; m.season_change = pb->season_change;
+  m.init_level_loc = pb->init_level_loc; m.init_level_scale = pb->init_level_scale;
+  m.init_slope_scale = pb->init_slope_scale; m.init_seasonal_scale = pb->init_seasonal_scale;
+  double dev[3 + CI_MAX_BLOCKS + 256], g[1024];
+  double* resid = (double*)malloc(sizeof(double) * pb->T);
+  double* e = (double*)malloc(sizeof(double) * pb->T);
+  double lp = hmc_target(pb, &m, theta, g, dev, resid, e);
+  if (grad) memcpy(grad, g, sizeof(double) * ci_oracle_hmc_dim(pb));
+  free(resid); free(e);
+  return lp;
+}
+
+int ci_oracle_fit_hmc(const ci_oracle_hmc_problem* pb, double* draws, double* accept_rate,
+                      double* step_size) {
+  const int T = pb->T, P = pb->P, K = pb->num_blocks, W = pb->num_warmup, S = pb->num_results;
+  if (T < 1 || P < 0 || P > 255 || K < 0 || K > CI_MAX_BLOCKS) return -1;
+  const int hs = pb->prior_mode == 1;
+  const int off_sc = hs ? 3 * P + 2 : P;
+  const int nsc = 2 + (pb->has_slope ? 1 : 0) + K;
+  const int dim = off_sc + nsc;
+  if (dim > 1024) return -2;
+  ci_oracle_ssm m;
+  memset(&m, 0, sizeof(m));
+  m.T = T; m.has_slope = pb->has_slope; m.num_blocks = K;
+  for (int k = 0; k < K; ++k) m.num_seasons[k] = pb->num_seasons[k];
+  m.d = ci_oracle_state_dim(pb->has_slope, K, pb->num_seasons);
+  if (m.d > CI_MAX_D) return -3;
+  m.mask = pb->mask; m.season_change = pb->season_change;
+  m.init_level_loc = pb->init_level_loc; m.init_level_scale = pb->init_level_scale;
+  m.init_slope_scale = pb->init_slope_scale; m.init_seasonal_scale = pb->init_seasonal_scale;
+  const uint32_t chain = (uint32_t)pb->chain;
+  double theta[1024], grad[1024], th[1024], g[1024], mom[1024], imass[1024];
+  double wmean[1024], wm2[1024], dev[3 + CI_MAX_BLOCKS + 256];
+  double* resid = (double*)malloc(sizeof(double) * T);
+  double* e = (double*)malloc(sizeof(double) * T);
+  for (int i = 0; i < dim; ++i) {
+    double v = i >= off_sc ? pb->init_log[i - off_sc] : 0.0;
+    th[i] = pb->init ? pb->init[i]
+                     : v + 0.01 * ci_oracle_normal(pb->seed, chain, 0u, CI_SITE_HMC_INIT, 0, (uint32_t)i);
+    imass[i] = 1.0;
+    wmean[i] = 0.0; wm2[i] = 0.0;
+  }
+  double lp_cur = hmc_target(pb, &m, th, g, dev, resid, e);
+  memcpy(theta, th, sizeof(double) * dim);
+  memcpy(grad, g, sizeof(double) * dim);
+  double eps = pb->eps0, mu = log(10.0 * pb->eps0), hbar = 0.0, log_eps_bar = 0.0, t_da = 0.0;
+  const double gamma_da = 0.05, t0_da = 10.0, kappa_da = 0.75;
+  int slow_begin, slow_end, win_end, win_size;
+  ci_oracle_hmc_windows(W, &slow_begin, &slow_end, &win_end, &win_size);
+  double wn = 0.0, accepted = 0.0;
+  for (int it = 0; it < W + S; ++it) {
+    double kin = 0.0;
+    for (int i = 0; i < dim; ++i) {
+      double z = ci_oracle_normal(pb->seed, chain, (uint32_t)it, CI_SITE_HMC_MOMENTUM, 0, (uint32_t)i);
+      mom[i] = z / sqrt(imass[i]);
+      th[i] = theta[i];
+      g[i] = grad[i];
+      kin += 0.5 * mom[i] * mom[i] * imass[i];
+    }
+    double h0 = -lp_cur + kin, lp_new = lp_cur;
+    for (int l = 0; l < pb->num_leapfrog; ++l) {
+      for (int i = 0; i < dim; ++i) {
+        mom[i] += 0.5 * eps * g[i];
+        th[i] += eps * imass[i] * mom[i];
+      }
+      lp_new = hmc_target(pb, &m, th, g, dev, resid, e);
+      for (int i = 0; i < dim; ++i) mom[i] += 0.5 * eps * g[i];
+    }
+    double k1 = 0.0;
+    for (int i = 0; i < dim; ++i) k1 += 0.5 * mom[i] * mom[i] * imass[i];
+    double h1 = -lp_new + k1;
+    int fin = (h1 == h1) && h1 < 1e300 && h1 > -1e300;
+    double log_acc = fin ? h0 - h1 : -INFINITY;
+    double acc_prob = fin ? exp(log_acc < 0.0 ? log_acc : 0.0) : 0.0;
+    double u = ci_oracle_uniform(pb->seed, chain, (uint32_t)it, CI_SITE_HMC_ACCEPT, 0, 0);
+    int take = log(u) < log_acc;
+    if (take) {
+      memcpy(theta, th, sizeof(double) * dim);
+      memcpy(grad, g, sizeof(double) * dim);
+      lp_cur = lp_new;
+    }
+    if (it < W) {
+      t_da += 1.0;
+      hbar = (1.0 - 1.0 / (t_da + t0_da)) * hbar + (pb->target_accept - acc_prob) / (t_da + t0_da);
+      double log_eps = mu - sqrt(t_da) / gamma_da * hbar;
+      double eta = pow(t_da, -kappa_da);
+      log_eps_bar = eta * log_eps + (1.0 - eta) * log_eps_bar;
+      eps = exp(log_eps);
+      if (it >= slow_begin && it < slow_end) {
+        wn += 1.0;
+        for (int i = 0; i < dim; ++i) {
+          double x = theta[i], d0 = x - wmean[i];
+          wmean[i] += d0 / wn;
+          wm2[i] += d0 * (x - wmean[i]);
+        }
+        if (it + 1 == win_end) {
+          for (int i = 0; i < dim; ++i) {
+            if (wn >= 2.0) {
+              double var = wm2[i] / (wn - 1.0);
+              double v = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
+              if (v == v && v < 1e300 && v > 0.0) imass[i] = v;
+            }
+            wmean[i] = 0.0; wm2[i] = 0.0;
+          }
+          wn = 0.0;
+          eps = exp(log_eps_bar);
+          mu = log(10.0 * eps); hbar = 0.0; log_eps_bar = 0.0; t_da = 0.0;
+          if (win_end < slow_end) {
+            win_size *= 2;
+            int en = win_end + win_size;
+            if (en + 2 * win_size > slow_end) en = slow_end;
+            win_end = en;
+          }
+        }
+      }
+      if (it == W - 1 && t_da > 0.0) eps = exp(log_eps_bar);
+    } else {
+      accepted += take ? 1.0 : 0.0;
+      /* rows (sigma_obs, sigma_level, sigma_slope, drift[K], beta[P]) */
+      double* o = draws + (size_t)(it - W) * (3 + K + P);
+      int q = off_sc;
+      o[0] = exp(clamp30(theta[q++]));
+      o[1] = exp(clamp30(theta[q++]));
+      o[2] = pb->has_slope ? exp(clamp30(theta[q++])) : 0.0;
+      for (int k = 0; k < K; ++k) o[3 + k] = exp(clamp30(theta[q++]));
+      for (int j = 0; j < P; ++j) {
+        double b = theta[j];
+        if (hs)
+          b *= exp(clamp30(theta[P + j]) + 0.5 * clamp30(theta[2 * P + j]) + clamp30(theta[3 * P]) +
+                   0.5 * clamp30(theta[3 * P + 1])) * pb->hs_scale0;
+        o[3 + K + j] = b;
+      }
+    }
+  }
+  if (accept_rate) *accept_rate = accepted / (double)(S > 0 ? S : 1);
+  if (step_size) *step_size = eps;
+  free(resid); free(e);
+  return 0;
+}
+
+/* Latent path + posterior-predictive trajectory of every retained HMC draw, as the device does
+ * after the chain (latents_kernel): Durbin-Koopman draw with iteration = draw index, then
+ * loc = Z x + X beta, trajectory = loc + sigma_obs * eps (causalimpact_lib.py:620-631).
+ * draws rows as ci_oracle_fit_hmc writes them; outputs [S*T] (any may be NULL). */
+int ci_oracle_hmc_latents(const ci_oracle_hmc_problem* pb, const double* draws, int S,
+                          double* level, double* slope, double* loc_out, double* traj) {
+  const int T = pb->T, P = pb->P, K = pb->num_blocks;
+  ci_oracle_ssm m;
+  memset(&m, 0, sizeof(m));
+  m.T = T; m.has_slope = pb->has_slope; m.num_blocks = K;
+  for (int k = 0; k < K; ++k) m.num_seasons[k] = pb->num_seasons[k];
+  m.d = ci_oracle_state_dim(pb->has_slope, K, pb->num_seasons);
+  if (m.d > CI_MAX_D) return -3;
+  m.mask = pb->mask; m.season_change = pb->season_change;
+  m.init_level_loc = pb->init_level_loc; m.init_level_scale = pb->init_level_scale;
+  m.init_slope_scale = pb->init_slope_scale; m.init_seasonal_scale = pb->init_seasonal_scale;
+  const int d = m.d;
+  double* resid = (double*)malloc(sizeof(double) * T);
+  double* xw = (double*)malloc(sizeof(double) * T);
+  double* lat = (double*)malloc(sizeof(double) * T * d);
+  for (int s = 0; s < S; ++s) {
+    const double* o = draws + (size_t)s * (3 + K + P);
+    m.obs_scale = o[0]; m.level_scale = o[1]; m.slope_scale = o[2];
+    for (int k = 0; k < K; ++k) m.drift_scale[k] = o[3 + k];
+    for (int t = 0; t < T; ++t) {
+      double v = 0.0;
+      for (int j = 0; j < P; ++j) v += pb->X[(size_t)t * P + j] * o[3 + K + j];
+      xw[t] = v;
+      resid[t] = pb->mask[t] ? 0.0 : pb->y[t] - v;
+    }
+    ci_oracle_dk_draw(&m, resid, pb->seed, (uint32_t)pb->chain, (uint32_t)s, lat);
+    for (int t = 0; t < T; ++t) {
+      double lc = observe(&m, &lat[(size_t)t * d]) + xw[t];
+      if (level) level[(size_t)s * T + t] = lat[(size_t)t * d];
+      if (slope) slope[(size_t)s * T + t] = pb->has_slope ? lat[(size_t)t * d + 1] : 0.0;
+      if (loc_out) loc_out[(size_t)s * T + t] = lc;
+      if (traj)
+        traj[(size_t)s * T + t] = lc + o[0] * ci_oracle_normal(pb->seed, (uint32_t)pb->chain,
+                                                               (uint32_t)s, CI_SITE_PRED, 0, (uint32_t)t);
+    }
+  }
+  free(resid); free(xw); free(lat);
+  return 0;
+}

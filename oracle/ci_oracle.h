@@ -63,7 +63,9 @@ enum {
   CI_SITE_SLOPE_SCALE = 11,
   CI_SITE_DRIFT_SCALE = 12, /* sub = block */
   CI_SITE_OBS_SCALE = 13,   /* gamma attempts: sigma_obs (no-regression branch) */
-  CI_SITE_PRED = 14         /* normals: posterior-predictive noise */
+  CI_SITE_PRED = 14,        /* normals: posterior-predictive noise */
+  /* HMC extension (csrc/ci_hmc.h) */
+  CI_SITE_HMC_MOMENTUM = 15, CI_SITE_HMC_ACCEPT = 16, CI_SITE_HMC_INIT = 17
 };
 
 typedef struct {
@@ -153,6 +155,48 @@ void ci_oracle_dk_draw(const ci_oracle_ssm* m, const double* data,
 double ci_oracle_spike_slab_logp(int P, const double* xtx, const double* prior_prec,
                                  const double* xty, double yty, const uint8_t* nonzeros,
                                  double nonzero_prob, double post_conc, double prior_scale);
+
+/* ---- row H (extension): score of the log-likelihood and the HMC sampler of csrc/ci_hmc.h ---- */
+
+/* Log-likelihood of data[T] plus its score: e_out[T] = -dl/d data_t (0 where masked; so
+ * dl/dbeta = X'e for data = y - X beta), g_scales = dl/d(sigma_obs, sigma_level, sigma_slope,
+ * sigma_drift[K]).  Either output may be NULL. */
+double ci_oracle_loglik_score(const ci_oracle_ssm* m, const double* data, double* e_out,
+                              double* g_scales);
+
+typedef struct {
+  int32_t T, P, has_slope, num_blocks;
+  int32_t num_seasons[CI_MAX_BLOCKS];
+  int32_t num_warmup, num_results, num_leapfrog;
+  int32_t prior_mode;            /* 0 Gaussian slab, 1 horseshoe */
+  uint32_t seed[2];
+  int32_t chain;
+  int32_t reserved;
+  const double* y;               /* [T] */
+  const uint8_t* mask;           /* [T] */
+  const double* X;               /* [T*P] row-major */
+  const uint8_t* season_change;  /* [K*T] */
+  const double* omega;           /* [P*P] slab precision (prior_mode 0) */
+  const double* init;            /* [dim] unconstrained start, or NULL */
+  /* scales in theta order: obs, level, [slope], drift[K] */
+  double ig_a[3 + CI_MAX_BLOCKS], ig_b[3 + CI_MAX_BLOCKS], init_log[3 + CI_MAX_BLOCKS];
+  double hs_scale0, target_accept, eps0;
+  double init_level_loc, init_level_scale, init_slope_scale, init_seasonal_scale;
+} ci_oracle_hmc_problem;
+
+int ci_oracle_hmc_dim(const ci_oracle_hmc_problem* pb);
+/* log posterior (up to a constant) and its gradient at the unconstrained point theta[dim]. */
+double ci_oracle_hmc_logp(const ci_oracle_hmc_problem* pb, const double* theta, double* grad);
+/* Warm-up schedule: step size only on [0, slow_begin) and [slow_end, W); mass windows tile
+ * [slow_begin, slow_end), the first ending at first_end, each next one twice as long. */
+void ci_oracle_hmc_windows(int W, int* slow_begin, int* slow_end, int* first_end, int* base);
+/* One chain.  draws [S, 3 + K + P] rows (sigma_obs, sigma_level, sigma_slope, drift[K], beta[P]). */
+int ci_oracle_fit_hmc(const ci_oracle_hmc_problem* pb, double* draws, double* accept_rate,
+                      double* step_size);
+/* Latent path and posterior-predictive trajectory of each of the S draws (rows as above), as
+ * the device's latents pass: Durbin-Koopman draw with iteration = draw index.  Outputs [S*T]. */
+int ci_oracle_hmc_latents(const ci_oracle_hmc_problem* pb, const double* draws, int S,
+                          double* level, double* slope, double* loc, double* traj);
 
 #ifdef __cplusplus
 }

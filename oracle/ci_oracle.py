@@ -303,3 +303,147 @@ def spike_slab_logp(xtx, prior_prec, xty, yty, nonzeros, nonzero_prob, post_conc
   return float(lib().ci_oracle_spike_slab_logp(P, a.ctypes.data, b.ctypes.data, c.ctypes.data,
                                                float(yty), nz.ctypes.data, float(nonzero_prob),
                                                float(post_conc), float(prior_scale)))
+
+
+# ----------------------------------------------------------------------------
+# row H (extension): score of the log-likelihood, HMC sampler of csrc/ci_hmc.h
+# ----------------------------------------------------------------------------
+SITES.update(HMC_MOMENTUM=15, HMC_ACCEPT=16, HMC_INIT=17)
+
+
+class _HmcProblem(C.Structure):
+  _fields_ = [
+      ("T", C.c_int32), ("P", C.c_int32), ("has_slope", C.c_int32), ("num_blocks", C.c_int32),
+      ("num_seasons", C.c_int32 * _MAX_BLOCKS),
+      ("num_warmup", C.c_int32), ("num_results", C.c_int32), ("num_leapfrog", C.c_int32),
+      ("prior_mode", C.c_int32), ("seed", C.c_uint32 * 2), ("chain", C.c_int32),
+      ("reserved", C.c_int32),
+      ("y", C.c_void_p), ("mask", C.c_void_p), ("X", C.c_void_p), ("season_change", C.c_void_p),
+      ("omega", C.c_void_p), ("init", C.c_void_p),
+      ("ig_a", C.c_double * (3 + _MAX_BLOCKS)), ("ig_b", C.c_double * (3 + _MAX_BLOCKS)),
+      ("init_log", C.c_double * (3 + _MAX_BLOCKS)),
+      ("hs_scale0", C.c_double), ("target_accept", C.c_double), ("eps0", C.c_double),
+      ("init_level_loc", C.c_double), ("init_level_scale", C.c_double),
+      ("init_slope_scale", C.c_double), ("init_seasonal_scale", C.c_double),
+  ]
+
+
+def loglik_score(ssm, data):
+  """(loglik, e[T] = -dl/d data, dl/d(sigma_obs, sigma_level, sigma_slope, sigma_drift[K]))."""
+  L = lib()
+  L.ci_oracle_loglik_score.restype = C.c_double
+  L.ci_oracle_loglik_score.argtypes = [C.POINTER(_SSM), C.c_void_p, C.c_void_p, C.c_void_p]
+  d64 = np.ascontiguousarray(np.asarray(data, np.float64))
+  e = np.zeros(ssm.T)
+  gs = np.zeros(3 + _MAX_BLOCKS)
+  ll = float(L.ci_oracle_loglik_score(C.byref(ssm), d64.ctypes.data, e.ctypes.data, gs.ctypes.data))
+  return ll, e, gs[:3 + ssm.num_blocks]
+
+
+def slab_precision(X) -> np.ndarray:
+  """Omega = 0.01 (X'X/2 + diag(X'X)/2) / T over all rows (causalimpact_lib.py:451-453)."""
+  X64 = np.asarray(X, np.float64)
+  xtx = X64.T @ X64
+  return 0.01 * (0.5 * xtx + 0.5 * np.diag(np.diag(xtx))) / X64.shape[0]
+
+
+def hmc_windows(W: int):
+  L = lib()
+  v = [C.c_int(0) for _ in range(4)]
+  L.ci_oracle_hmc_windows.restype = None
+  L.ci_oracle_hmc_windows(C.c_int(int(W)), *[C.byref(x) for x in v])
+  return tuple(x.value for x in v)       # slow_begin, slow_end, first_end, base
+
+
+def _hmc_problem(y, mask, X, spec, *, num_results, num_warmup, num_leapfrog, prior, seed, chain,
+                 target_accept, initial_step_size, horseshoe_scale, init):
+  T, P = spec["T"], spec["P"]
+  K = len(spec["num_seasons"])
+  keep = dict(
+      y=np.ascontiguousarray(np.where(np.asarray(mask, bool), 0.0, np.asarray(y, np.float64))),
+      m=np.ascontiguousarray(np.asarray(mask, dtype=np.uint8)),
+      X=np.ascontiguousarray(np.asarray(X, np.float64)) if P > 0 else np.zeros((T, 0)),
+      sc=(np.ascontiguousarray(np.stack(spec["season_change"]).astype(np.uint8))
+          if K > 0 else np.zeros((0, T), np.uint8)))
+  keep["omega"] = np.ascontiguousarray(slab_precision(keep["X"])) if P > 0 else np.zeros((0, 0))
+  pb = _HmcProblem()
+  pb.T, pb.P, pb.has_slope, pb.num_blocks = T, P, int(spec["has_slope"]), K
+  for k in range(K):
+    pb.num_seasons[k] = spec["num_seasons"][k]
+  pb.num_warmup, pb.num_results, pb.num_leapfrog = int(num_warmup), int(num_results), int(num_leapfrog)
+  pb.prior_mode = {"slab": 0, "horseshoe": 1}[prior]
+  s = _u32pair(seed)
+  pb.seed[0], pb.seed[1] = s[0], s[1]
+  pb.chain = int(chain)
+  pb.y, pb.mask = keep["y"].ctypes.data, keep["m"].ctypes.data
+  pb.X = keep["X"].ctypes.data if P > 0 else None
+  pb.season_change = keep["sc"].ctypes.data if K > 0 else None
+  pb.omega = keep["omega"].ctypes.data if P > 0 else None
+  if init is not None:
+    keep["init"] = np.ascontiguousarray(init, dtype=np.float64)
+    pb.init = keep["init"].ctypes.data
+  igs = [(spec["obs_conc"], spec["obs_scale"], spec["obs_scale0"]),
+         (spec["level_conc"], spec["level_scale"], max(spec["level_scale0"], 1e-4))]
+  if spec["has_slope"]:
+    igs.append((spec["slope_conc"], spec["slope_scale"], max(spec["slope_scale0"], 1e-4)))
+  for k in range(K):
+    igs.append((spec["drift_conc"], spec["drift_scale"], max(spec["drift_scale0"][k], 1e-4)))
+  for i, (a, b, s0) in enumerate(igs):
+    pb.ig_a[i], pb.ig_b[i], pb.init_log[i] = float(a), float(b), math.log(s0)
+  pb.hs_scale0 = float(horseshoe_scale)
+  pb.target_accept, pb.eps0 = float(target_accept), float(initial_step_size)
+  for f in ("init_level_loc", "init_level_scale", "init_slope_scale", "init_seasonal_scale"):
+    setattr(pb, f, float(spec[f]))
+  pb._keep = keep
+  return pb
+
+
+def hmc_logp(y, mask, X, spec, theta, *, prior="slab", horseshoe_scale=0.1):
+  """log posterior (up to a constant) and gradient at the unconstrained point theta."""
+  L = lib()
+  L.ci_oracle_hmc_logp.restype = C.c_double
+  L.ci_oracle_hmc_logp.argtypes = [C.POINTER(_HmcProblem), C.c_void_p, C.c_void_p]
+  L.ci_oracle_hmc_dim.argtypes = [C.POINTER(_HmcProblem)]
+  pb = _hmc_problem(y, mask, X, spec, num_results=1, num_warmup=0, num_leapfrog=1, prior=prior,
+                    seed=0, chain=0, target_accept=0.75, initial_step_size=0.05,
+                    horseshoe_scale=horseshoe_scale, init=None)
+  dim = L.ci_oracle_hmc_dim(C.byref(pb))
+  th = np.ascontiguousarray(theta, dtype=np.float64)
+  assert th.shape == (dim,), (th.shape, dim)
+  g = np.zeros(dim)
+  lp = float(L.ci_oracle_hmc_logp(C.byref(pb), th.ctypes.data, g.ctypes.data))
+  return lp, g
+
+
+def fit_hmc(y, mask, X, spec, *, num_results, num_warmup, seed, chain=0, num_leapfrog=15,
+            prior="slab", target_accept=0.75, initial_step_size=0.05, horseshoe_scale=0.1,
+            init=None, latents=True):
+  """The HMC sampler of csrc/ci_hmc.h for one chain, float64.  Returns draws [S, 3 + K + P]
+  (sigma_obs, sigma_level, sigma_slope, drift[K], beta[P]), accept_rate, step_size and -- with
+  latents=True, trend + regression models -- level / slope / loc / trajectories [S, T] drawn as
+  the device does after the chain (Durbin-Koopman draw with iteration = draw index)."""
+  L = lib()
+  L.ci_oracle_fit_hmc.restype = C.c_int
+  L.ci_oracle_fit_hmc.argtypes = [C.POINTER(_HmcProblem), C.c_void_p, C.c_void_p, C.c_void_p]
+  pb = _hmc_problem(y, mask, X, spec, num_results=num_results, num_warmup=num_warmup,
+                    num_leapfrog=num_leapfrog, prior=prior, seed=seed, chain=chain,
+                    target_accept=target_accept, initial_step_size=initial_step_size,
+                    horseshoe_scale=horseshoe_scale, init=init)
+  S, T, P, K = int(num_results), spec["T"], spec["P"], len(spec["num_seasons"])
+  draws = np.zeros((S, 3 + K + P))
+  acc, eps = C.c_double(0), C.c_double(0)
+  rc = L.ci_oracle_fit_hmc(C.byref(pb), draws.ctypes.data, C.byref(acc), C.byref(eps))
+  if rc != 0:
+    raise RuntimeError(f"ci_oracle_fit_hmc failed rc={rc}")
+  out = dict(draws=draws, accept_rate=acc.value, step_size=eps.value)
+  if latents:
+    L.ci_oracle_hmc_latents.restype = C.c_int
+    L.ci_oracle_hmc_latents.argtypes = [C.POINTER(_HmcProblem), C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    arrs = {k: np.zeros((S, T)) for k in ("level", "slope", "loc", "trajectories")}
+    rc = L.ci_oracle_hmc_latents(C.byref(pb), draws.ctypes.data, S, arrs["level"].ctypes.data,
+                                 arrs["slope"].ctypes.data, arrs["loc"].ctypes.data,
+                                 arrs["trajectories"].ctypes.data)
+    if rc != 0:
+      raise RuntimeError(f"ci_oracle_hmc_latents failed rc={rc}")
+    out.update(arrs)
+  return out

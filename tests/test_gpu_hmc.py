@@ -110,3 +110,92 @@ def test_surrogate_posterior_tracks_the_hmc_posterior_and_can_initialise_it():
   np.testing.assert_allclose(hmc_vi["observation_noise_scale"].mean(),
                              hmc["observation_noise_scale"].mean(), rtol=0.05)
   assert (hmc_vi["hmc_accept_rate"] > 0.5).all()
+
+
+@pytest.mark.parametrize("prior,has_slope", [("slab", True), ("horseshoe", False)])
+def test_device_hmc_tracks_the_float64_oracle_draw_for_draw(prior, has_slope):
+  """csrc/ci_hmc.h against oracle/ci_oracle.c::ci_oracle_fit_hmc: same sampler, same Philox
+  stream, float32 scans on the device vs float64 recursions in the oracle.  The first
+  iterations (windowed warm-up included) must agree draw for draw; later ones separate as
+  round-off in the score is amplified by the leapfrog dynamics."""
+  from causalimpact import _model, _native
+  from causalimpact import _synthetic as syn
+  from oracle import ci_oracle as orc
+  T, p = 300, 3
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 12)
+  spec = _model.series_params(y, mask, X, has_slope=has_slope)
+  ospec = orc.default_spec(y, mask, X, has_slope=has_slope)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=has_slope, num_warmup=0, num_results=1,
+                            seed=(3, 4))
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8)
+  # W = 20: fast buffer [0, 3), one mass window [3, 18) (mass update + dual-averaging restart at
+  # its end), fast buffer [18, 20); short trajectories keep the float32 / float64 paths together
+  W, S, C, NL = 20, 2, 3, 4
+  sess.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=NL, seed=(3, 4),
+               chain_offset=5, prior=prior)
+  draws, acc, eps, arrs = sess.hmc_fetch()
+  sess.close()
+  for c in range(C):
+    want = orc.fit_hmc(y, mask, X, ospec, num_results=S, num_warmup=W, num_leapfrog=NL, seed=(3, 4),
+                       chain=5 + c, prior=prior)
+    np.testing.assert_allclose(eps[c], want["step_size"], rtol=3e-2)
+    np.testing.assert_allclose(draws[c], want["draws"], rtol=2e-2, atol=5e-3)
+    # latent pass: same parameter draws up to the tolerance above => close paths
+    np.testing.assert_allclose(arrs["level"][0, c], want["level"], atol=3e-2)
+    np.testing.assert_allclose(arrs["posterior_trajectories"][0, c], want["trajectories"], atol=5e-2)
+    np.testing.assert_allclose(arrs["posterior_means"][0, c], want["loc"].mean(axis=0), atol=3e-2)
+    np.testing.assert_allclose(arrs["observation_noise_scale"][0, c], draws[c, :, 0], rtol=1e-6)
+    np.testing.assert_allclose(arrs["weights"][0, c], draws[c, :, 3:], rtol=1e-6, atol=1e-7)
+
+
+def _pooled_stats(x):
+  """mean over chains x draws and its Monte-Carlo standard error from between-chain spread."""
+  cm = x.mean(axis=1)
+  return cm.mean(axis=0), cm.std(axis=0, ddof=1) / np.sqrt(cm.shape[0])
+
+
+def test_cfg3_full_size_64_chains_as_8_launches_and_against_oracle_and_gibbs():
+  """BASELINE cfg3: T=1000, 10 covariates (P=11), LocalLinearTrend, 64 HMC chains = 8 per GPU.
+  (a) the 8 per-GPU shares (chain_offset = 8 r) reproduce the single 64-chain launch bit for
+  bit; (b) pooled posterior summaries agree with the float64 oracle sampler within Monte-Carlo
+  error; (c) the counterfactual agrees with this build's Gibbs posterior on the same data."""
+  from causalimpact import _hmc, _model, _native
+  from causalimpact import _synthetic as syn
+  from oracle import ci_oracle as orc
+  T, p, W, S = 1000, 10, 200, 300
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 2024)
+  spec = _model.series_params(y, mask, X, has_slope=True)
+  kw = dict(has_slope=True, num_results=S, num_warmup=W, seed=(0, 20240927))
+  full = _hmc.fit_hmc(y, mask, X, spec, num_chains=64, **kw)
+  assert (full["hmc_accept_rate"] > 0.4).all() and (full["hmc_accept_rate"] < 0.995).all()
+  for r in (0, 3, 7):
+    part = _hmc.fit_hmc(y, mask, X, spec, num_chains=8, chain_offset=8 * r, **kw)
+    for key in ("observation_noise_scale", "level_scale", "slope_scale", "weights", "level",
+                "slope", "posterior_trajectories", "posterior_means"):
+      np.testing.assert_array_equal(part[key][0], full[key][0, 8 * r:8 * r + 8], err_msg=key)
+  # (b) oracle: 8 float64 chains of the same sampler (ids 0..7)
+  ospec = orc.default_spec(y, mask, X, has_slope=True)
+  oc = [orc.fit_hmc(y, mask, X, ospec, num_results=S, num_warmup=W, seed=(0, 20240927), chain=c)
+        for c in range(8)]
+  od = np.stack([o["draws"] for o in oc])                      # [8, S, 3 + P]
+  oloc = np.stack([o["loc"] for o in oc])                      # [8, S, T]
+  dev_draws = np.concatenate([full["observation_noise_scale"][0][..., None],
+                              full["level_scale"][0][..., None],
+                              full["slope_scale"][0][..., None], full["weights"][0]], axis=-1)
+  m_d, se_d = _pooled_stats(dev_draws)
+  m_o, se_o = _pooled_stats(od)
+  se = np.sqrt(se_d ** 2 + se_o ** 2)
+  assert (np.abs(m_d - m_o) <= 4.5 * se + 1e-3).all(), (m_d, m_o, se)
+  post = slice(700, 1000)
+  eff_d, eff_d_se = _pooled_stats(full["posterior_trajectories"][0][:, :, post].mean(axis=2)[..., None])
+  eff_o, eff_o_se = _pooled_stats(np.stack([o["trajectories"] for o in oc])[:, :, post].mean(axis=2)[..., None])
+  assert abs(eff_d[0] - eff_o[0]) <= 4.5 * np.hypot(eff_d_se[0], eff_o_se[0]) + 1e-3
+  # (c) Gibbs on the same data: the counterfactual mean over the post-period
+  pbg = _native.make_problem(T=T, P=p + 1, has_slope=1, num_warmup=112, num_results=1000,
+                             num_chains=8, seed=(0, 20240927))
+  g = _native.fit_gibbs(pbg, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  cf_g = g["posterior_means"][0][:, post].mean()
+  cf_h = full["posterior_means"][0][:, post].mean()
+  sd_g = g["posterior_trajectories"][0][:, :, post].mean(axis=2).std()
+  assert abs(cf_g - cf_h) < 0.25 * sd_g + 0.01, (cf_g, cf_h, sd_g)
+  np.testing.assert_allclose(np.mean(oloc[:, :, post]), cf_h, atol=0.25 * sd_g + 0.01)

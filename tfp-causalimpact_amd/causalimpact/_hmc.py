@@ -110,14 +110,19 @@ def _package(sess, dev, seed, chain_offset, C, S, T, P):
 def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_warmup: int,
             num_chains: int, seed, device: int = 0, chain_offset: int = 0, num_leapfrog: int = 15,
             target_accept: float = 0.75, initial_step_size: float = 0.05,
-            init: str = "gibbs") -> Dict[str, np.ndarray]:
-  """HMC with the whole chain on the device (csrc/ci_hmc.h: one workgroup per chain, no host
-  round trip per leapfrog step).  Returns the arrays of `_native.fit_gibbs` (leading series axis
-  of 1) plus `hmc_accept_rate`, `hmc_step_size` [C] and `hmc_target_calls`.
+            init: str = "gibbs", prior: str = "slab",
+            horseshoe_scale: float = 0.1) -> Dict[str, np.ndarray]:
+  """HMC with the whole fit on the device (csrc/ci_hmc.h: one workgroup per chain runs the
+  windowed warm-up and all sampling iterations; one more launch draws the latent path and the
+  predictive trajectory of every retained draw).  Returns the arrays of `_native.fit_gibbs`
+  (leading series axis of 1) plus `hmc_accept_rate`, `hmc_step_size` [C], `hmc_target_calls`
+  and `hmc_kernel_ms`.
 
+  prior: "slab" (the Gaussian slab of the reference's spike-and-slab prior) or "horseshoe" (the
+  prior of `tfp.sts.SparseLinearRegression`, weights_prior_scale = horseshoe_scale).
   init: "gibbs" starts every chain at the Gibbs sampler's initial state (jittered); "vi" first
   fits the mean-field surrogate posterior (`_vi.fit_surrogate_posterior`, what
-  `tfp.sts.fit_with_hmc` does upstream) and starts chain c at its c-th draw."""
+  `tfp.sts.fit_with_hmc` does upstream) and starts chain c at its c-th draw (slab prior only)."""
   y = np.asarray(y, np.float64)
   mask = np.asarray(mask, bool)
   T = y.shape[0]
@@ -125,11 +130,12 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
   C, S, W = int(num_chains), int(num_results), int(num_warmup)
   pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_warmup=0, num_results=1,
                             seed=seed, device=device)
-  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X,
-                               max_evals=max(C, min(1024, C * S)))
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=64)
   try:
     init_theta = None
     if init == "vi":
+      if prior != "slab":
+        raise NotImplementedError("the surrogate posterior is built for the slab prior only")
       from causalimpact import _vi  # pylint: disable=import-outside-toplevel
       vi = _vi.fit_surrogate_posterior(y, mask, X, spec, has_slope=has_slope, seed=seed,
                                        device=device, sess=sess,
@@ -138,14 +144,16 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
       init_theta = _vi.sample_surrogate(vi, chain_offset + C, seed=seed)[chain_offset:]
     elif init != "gibbs":
       raise ValueError(f"init must be 'gibbs' or 'vi', got {init!r}")
-    draws, acc, eps = sess.hmc(num_chains=C, num_warmup=W, num_results=S,
-                               num_leapfrog=num_leapfrog, target_accept=target_accept,
-                               initial_step_size=initial_step_size, seed=seed,
-                               chain_offset=chain_offset, init_theta=init_theta)
-    out = _package(sess, draws.reshape(C * S, 3 + P), seed, chain_offset, C, S, T, P)
+    ms = sess.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=num_leapfrog,
+                      target_accept=target_accept, initial_step_size=initial_step_size, seed=seed,
+                      chain_offset=chain_offset, init_theta=init_theta, prior=prior,
+                      horseshoe_scale=horseshoe_scale)
+    _, acc, eps, out = sess.hmc_fetch()
   finally:
     sess.close()
-  out.update(hmc_accept_rate=acc, hmc_step_size=eps,
+  out["seasonal_drift_scales"] = np.zeros((1, C, S, 0), np.float32)
+  out["seasonal_levels"] = np.zeros((1, C, S, T, 0), np.float32)
+  out.update(hmc_accept_rate=acc, hmc_step_size=eps, hmc_kernel_ms=np.asarray(ms),
              hmc_target_calls=np.int64((W + S) * num_leapfrog + 1))
   return out
 

@@ -13,7 +13,7 @@ from typing import Dict, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_BLOCKS = 8
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libcausalimpact_amd.so")
@@ -45,6 +45,17 @@ _OUT_FIELDS = ("observation_noise_scale", "level_scale", "slope_scale", "seasona
 
 class Outputs(C.Structure):
   _fields_ = [(f, C.c_void_p) for f in _OUT_FIELDS]
+
+
+class HmcOptions(C.Structure):
+  _fields_ = [
+      ("num_chains", C.c_int32), ("chain_offset", C.c_int32), ("num_warmup", C.c_int32),
+      ("num_results", C.c_int32), ("num_leapfrog", C.c_int32), ("prior", C.c_int32),
+      ("target_accept", C.c_double), ("initial_step_size", C.c_double),
+      ("horseshoe_scale", C.c_double), ("seed", C.c_uint32 * 2)]
+
+
+HMC_PRIORS = {"slab": 0, "horseshoe": 1}   # == CI_HMC_PRIOR_*
 
 
 class NativeError(RuntimeError):
@@ -90,9 +101,14 @@ def load():
                                            C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_ll_session_destroy.argtypes = [C.c_void_p]
-  L.ci_ll_session_hmc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                  C.c_double, C.c_double, C.POINTER(C.c_uint32), C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_void_p]
+  L.ci_ll_session_hmc_run.argtypes = [C.c_void_p, C.POINTER(HmcOptions), C.c_void_p,
+                                      C.POINTER(C.c_float)]
+  L.ci_ll_session_hmc_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(Outputs)]
+  L.ci_ll_session_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+  L.ci_pool_trim.argtypes = []
+  L.ci_session_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+  L.ci_ll_session_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
   L.ci_test_rng.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
                             C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
   L.ci_test_dk_draw.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p, C.c_void_p,
@@ -106,12 +122,14 @@ def load():
 
 def exported_symbols() -> Sequence[str]:
   """Every entry point include/causalimpact_amd.h declares."""
-  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_fit_gibbs",
+  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_pool_trim", "ci_fit_gibbs",
           "ci_session_create", "ci_session_run", "ci_session_fetch",
-          "ci_session_algorithmic_bytes", "ci_session_destroy", "ci_session_profile",
+          "ci_session_algorithmic_bytes", "ci_session_kernel_name", "ci_session_destroy",
+          "ci_session_profile", "ci_ll_session_kernel_name",
           "ci_session_summarize", "ci_summarize_draws",
           "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_eval",
-          "ci_ll_session_draw_latents", "ci_ll_session_hmc", "ci_ll_session_destroy", "ci_test_rng",
+          "ci_ll_session_draw_latents", "ci_ll_session_hmc_run", "ci_ll_session_hmc_fetch",
+          "ci_ll_session_algorithmic_bytes", "ci_ll_session_destroy", "ci_test_rng",
           "ci_test_dk_draw")
 
 
@@ -124,6 +142,11 @@ def device_count() -> int:
   n = C.c_int(0)
   _check(load().ci_device_count(C.byref(n)))
   return n.value
+
+
+def pool_trim():
+  """Returns the device buffers parked by finished sessions to the driver (ci_pool_trim)."""
+  _check(load().ci_pool_trim())
 
 
 def seed_pair(seed):
@@ -252,6 +275,11 @@ class Session:
     _check(self._lib.ci_session_algorithmic_bytes(self._h, C.byref(b)))
     return float(b.value)
 
+  def kernel_name(self) -> str:
+    buf = C.create_string_buffer(128)
+    _check(self._lib.ci_session_kernel_name(self._h, buf, 128))
+    return buf.value.decode()
+
   def profile(self, enable=True):
     """Enables per-phase cycle counters for the next run(); returns the previous run's."""
     cyc = np.zeros(32, np.int64)
@@ -339,21 +367,66 @@ class LogLikSession:
         out["slope"].ctypes.data, out["loc"].ctypes.data, out["traj"].ctypes.data))
     return out
 
-  def hmc(self, *, num_chains, num_warmup, num_results, num_leapfrog=15, target_accept=0.75,
-          initial_step_size=0.05, seed=(0, 0), chain_offset=0, init_theta=None):
-    """The whole HMC fit on the device (ci_ll_session_hmc): draws [C, S, 3+P], accept, eps [C].
-    init_theta: optional [C, dim] unconstrained starting points."""
-    Cn, S = int(num_chains), int(num_results)
+  def hmc_run(self, *, num_chains, num_warmup, num_results, num_leapfrog=15, target_accept=0.75,
+              initial_step_size=0.05, seed=(0, 0), chain_offset=0, init_theta=None, prior="slab",
+              horseshoe_scale=0.1):
+    """The whole HMC fit on the device (ci_ll_session_hmc_run): chain, latent paths and
+    predictive trajectories stay in HBM.  Returns (hmc_kernel_ms, latents_ms)."""
+    o = HmcOptions()
+    o.num_chains, o.chain_offset = int(num_chains), int(chain_offset)
+    o.num_warmup, o.num_results, o.num_leapfrog = int(num_warmup), int(num_results), int(num_leapfrog)
+    if prior not in HMC_PRIORS:
+      raise ValueError(f"prior must be one of {sorted(HMC_PRIORS)}, got {prior!r}")
+    o.prior = HMC_PRIORS[prior]
+    o.target_accept, o.initial_step_size = float(target_accept), float(initial_step_size)
+    o.horseshoe_scale = float(horseshoe_scale)
+    o.seed[0], o.seed[1] = seed_pair(seed)
     init = None if init_theta is None else np.ascontiguousarray(init_theta, dtype=np.float64)
+    if init is not None:
+      dim = (3 * self.P + 2 if prior == "horseshoe" else self.P) + self.D + 1
+      if init.shape != (int(num_chains), dim):
+        raise ValueError(f"init_theta must be [{int(num_chains)}, {dim}], got {init.shape}")
+    ms = (C.c_float * 2)()
+    _check(self._lib.ci_ll_session_hmc_run(self._h, C.byref(o), _ptr(init), ms))
+    self._hmc_shape = (int(num_chains), int(num_results))
+    return float(ms[0]), float(ms[1])
+
+  def hmc_fetch(self, want=None):
+    """Host copies of the finished fit: draws [C, S, 3+P] float64, accept_rate, step_size [C] and
+    the float32 sample container of `fit_gibbs` (leading series axis of 1)."""
+    Cn, S = self._hmc_shape
+    pb = make_problem(T=self.T, P=self.P, has_slope=self.D == 2, num_warmup=0, num_results=S,
+                      num_chains=Cn)
+    if want is None:
+      want = [f for f in _OUT_FIELDS if f not in ("seasonal_drift_scales", "seasonal_levels")]
+    out, arrs = _alloc_outputs(pb, want)
     draws = np.zeros((Cn, S, 3 + self.P), np.float64)
     acc = np.zeros(Cn, np.float64)
     eps = np.zeros(Cn, np.float64)
-    sd = (C.c_uint32 * 2)(*seed_pair(seed))
-    _check(self._lib.ci_ll_session_hmc(self._h, Cn, int(chain_offset), int(num_warmup), S,
-                                       int(num_leapfrog), float(target_accept),
-                                       float(initial_step_size), sd, _ptr(init), draws.ctypes.data,
-                                       acc.ctypes.data, eps.ctypes.data))
+    _check(self._lib.ci_ll_session_hmc_fetch(self._h, draws.ctypes.data, acc.ctypes.data,
+                                             eps.ctypes.data, C.byref(out)))
+    return draws, acc, eps, arrs
+
+  def hmc(self, **kw):
+    """hmc_run + the parameter draws only: draws [C, S, 3+P], accept_rate, step_size [C]."""
+    self.hmc_run(**kw)
+    Cn, S = self._hmc_shape
+    draws = np.zeros((Cn, S, 3 + self.P), np.float64)
+    acc = np.zeros(Cn, np.float64)
+    eps = np.zeros(Cn, np.float64)
+    _check(self._lib.ci_ll_session_hmc_fetch(self._h, draws.ctypes.data, acc.ctypes.data,
+                                             eps.ctypes.data, None))
     return draws, acc, eps
+
+  def algorithmic_bytes(self) -> float:
+    b = C.c_double(0)
+    _check(self._lib.ci_ll_session_algorithmic_bytes(self._h, C.byref(b)))
+    return float(b.value)
+
+  def kernel_name(self) -> str:
+    buf = C.create_string_buffer(128)
+    _check(self._lib.ci_ll_session_kernel_name(self._h, buf, 128))
+    return buf.value.decode()
 
   def close(self):
     if self._h:

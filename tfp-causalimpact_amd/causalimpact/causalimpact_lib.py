@@ -102,6 +102,8 @@ class InferenceOptions:
   sampler: str = "gibbs"          # "gibbs" (the reference's sampler) or "hmc" (extension, _hmc.py)
   hmc_init: str = "gibbs"         # HMC chains start at the Gibbs initial state, or ("vi") at draws
                                   # of a mean-field surrogate posterior (_vi.py), as tfp.sts.fit_with_hmc
+  hmc_prior: str = "slab"         # HMC regression prior: "slab" (Gaussian slab of the reference's
+                                  # spike-and-slab prior) or "horseshoe" (tfp.sts.SparseLinearRegression)
   # Quantiles / effect sums of the T x (chains * draws) predictive draws computed on the GPU that
   # holds them (csrc/ci_summary.h) instead of pandas on the host.  Single-device Gibbs fits only;
   # `False` keeps the reference's host arithmetic (and downloads the trajectories).
@@ -149,7 +151,7 @@ def fit_causalimpact(data: pd.DataFrame,
       seasons=model_options.seasons, num_chains=inference_options.num_chains,
       devices=inference_options.devices, local_linear_trend=model_options.local_linear_trend,
       sampler=inference_options.sampler, summary_request=request,
-      hmc_init=inference_options.hmc_init)
+      hmc_init=inference_options.hmc_init, hmc_prior=inference_options.hmc_prior)
   if request is not None and device_summary is None:
     # draws pooled on the host (several devices, or the HMC path): summarise them on one device
     request["ranks"] = _summary_ranks(posterior_trajectories.shape[0], request["quantiles"])
@@ -266,7 +268,7 @@ def _train_causalimpact_sts(*,
 def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps, model=None,
                  dtype=np.float32, seasons=(), num_chains=1, devices=None,
                  local_linear_trend=False, sampler="gibbs", summary_request=None,
-                 hmc_init="gibbs"):
+                 hmc_init="gibbs", hmc_prior="slab"):
   """_train_causalimpact_sts plus, when `summary_request` is given (single device, Gibbs), the
   on-device summary of the predictive draws; the [draws, T] trajectories then stay in HBM and
   are returned as None."""
@@ -308,7 +310,7 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
       res = _hmc.fit_hmc(y, mask, design, params, has_slope=local_linear_trend,
                          num_results=num_results, num_warmup=num_warmup_steps,
                          num_chains=len(chain_ids), seed=seed_pair, device=dev,
-                         chain_offset=int(chain_ids[0]), init=hmc_init)
+                         chain_offset=int(chain_ids[0]), init=hmc_init, prior=hmc_prior)
       return {k: v for k, v in res.items() if not k.startswith("hmc_")}
     pb = _native.make_problem(T=T, P=P, has_slope=local_linear_trend, num_seasons=num_seasons,
                               num_warmup=num_warmup_steps, num_results=num_results,

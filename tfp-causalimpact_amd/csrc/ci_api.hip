@@ -40,8 +40,8 @@ CI_WIDE_DECL(2) CI_WIDE_DECL(3) CI_WIDE_DECL(4) CI_WIDE_DECL(5) CI_WIDE_DECL(6) 
                                                double*, double*, hipStream_t);                    \
   extern "C" void ci_launch_latents_d##D##_l##L(int, int, int, const float*, const uint8_t*,      \
                                                 const float*, const double*, float, float, float, \
-                                                uint32_t, uint32_t, uint32_t, uint32_t, float*,   \
-                                                float*, float*, float*, hipStream_t);             \
+                                                uint32_t, uint32_t, uint32_t, uint32_t, int,      \
+                                                float*, float*, float*, float*, hipStream_t);     \
   extern "C" void ci_launch_hmc_d##D##_l##L(const ci::HmcArgs*, hipStream_t);
 CI_DECL(1, 1) CI_DECL(1, 2) CI_DECL(1, 4) CI_DECL(1, 8) CI_DECL(1, 16)
 CI_DECL(2, 1) CI_DECL(2, 2) CI_DECL(2, 4) CI_DECL(2, 8) CI_DECL(2, 16)
@@ -102,6 +102,31 @@ static __global__ void test_rng_kernel(uint32_t k0, uint32_t k1, uint32_t chain,
     for (int q = 0; q < 4; ++q)
       if (tid * 4 + q < n) nor[n + tid * 4 + q] = z4[q];
   }
+}
+
+// Per-chain mean over the S retained draws of the noise-free predictor (causalimpact_lib.py:627):
+// loc [C, S, T] -> pm [C, T].  One thread per (chain, t), coalesced over t.
+static __global__ void hmc_mean_kernel(int C, int S, int T, const float* __restrict__ loc,
+                                       float* __restrict__ pm) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (t >= T || c >= C) return;
+  const float* p = loc + (size_t)c * S * T + t;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += p[(size_t)s * T];
+  pm[(size_t)c * T + t] = acc / (float)S;
+}
+
+// (sigma_obs, sigma_level, sigma_slope, beta) rows in float64 -> the float32 sample container.
+static __global__ void hmc_unpack_kernel(int N, int P, const double* __restrict__ draws,
+                                         float* __restrict__ obs, float* __restrict__ lscale,
+                                         float* __restrict__ sscale, float* __restrict__ w) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double* r = draws + (size_t)n * (3 + P);
+  obs[n] = (float)r[0];
+  lscale[n] = (float)r[1];
+  sscale[n] = (float)r[2];
+  for (int j = 0; j < P; ++j) w[(size_t)n * P + j] = (float)r[3 + j];
 }
 
 
@@ -262,6 +287,7 @@ struct ci_session {
   bool ran = false;
   ci_problem kpb;          // what the kernel runs (== pb except for long trend-only series)
   bool inert_block = false;
+  std::string kernel_name; // the Gibbs kernel this session dispatches to (as rocprofv3 names it)
 };
 
 extern "C" {
@@ -273,6 +299,17 @@ int ci_abi_version(void) { return CI_ABI_VERSION; }
 int ci_device_count(int* count) {
   if (!count) return fail("count is NULL");
   HIP_TRY(hipGetDeviceCount(count));
+  return 0;
+}
+
+int ci_pool_trim(void) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  for (auto& pe : g_pool) { (void)hipSetDevice(pe.device); (void)hipFree(pe.p); }
+  g_pool.clear();
+  g_pool_bytes = 0;
+  (void)hipSetDevice(dev);
   return 0;
 }
 
@@ -356,6 +393,9 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     s->fn = pick_kernel(D, s->L, pm);
     s->fn_prof = pick_kernel(D, s->L, pm + 8);       // instrumented variant (ci_session_profile)
     if (!s->fn || !s->fn_prof) return fail("no kernel for L=%d", s->L);
+    char nm[96];
+    snprintf(nm, sizeof(nm), "ci::gibbs_kernel<%d,%d,%d,false>", D, s->L, pm);
+    s->kernel_name = nm;
   } else {
     s->D_full = D;
     s->dred = D;
@@ -372,6 +412,10 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
                   s->lds_bytes);
     }
     if (!s->wide) s->fn = (KernelFn)ci_gibbs_seasonal_fn();
+    char nm[96];
+    if (s->wide) snprintf(nm, sizeof(nm), "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
+    else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel");
+    s->kernel_name = nm;
   }
   HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)s->lds_bytes));
@@ -704,6 +748,19 @@ int ci_session_algorithmic_bytes(const ci_session* s, double* bytes) {
   return 0;
 }
 
+static int copy_name(const std::string& name, char* buf, int32_t buflen) {
+  if (!buf || buflen < 1) return fail("NULL / empty name buffer");
+  snprintf(buf, (size_t)buflen, "%s", name.c_str());
+  return 0;
+}
+
+int ci_session_kernel_name(const ci_session* s, char* buf, int32_t buflen) {
+  if (!s) return fail("session is NULL");
+  return copy_name(s->kernel_name, buf, buflen);
+}
+
+int ci_ll_session_kernel_name(const ci_ll_session* s, char* buf, int32_t buflen);
+
 int ci_session_profile(ci_session* s, int enable, int64_t* cycles16) {
   if (!s) return fail("session is NULL");
   s->profile = enable != 0;
@@ -770,8 +827,13 @@ struct ci_ll_session {
   DevBuf<uint8_t> mask;
   DevBuf<double> theta, ll, grad;
   size_t draw_cap = 0;
-  // on-device HMC (ci_hmc.h)
+  // on-device HMC (ci_hmc.h): the fit stays resident until ci_ll_session_hmc_fetch
   DevBuf<double> omega, h_draws, h_acc, h_eps, h_init;
+  DevBuf<float> h_level, h_slope, h_loc, h_traj, h_pm, h_obs, h_lscale, h_sscale, h_w;
+  int h_C = 0, h_S = 0;
+  bool h_ran = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   ci_series_params prm;
 };
 
@@ -796,6 +858,10 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
   LlSessionGuard guard{s};
   s->T = pb->T; s->P = pb->P; s->D = pb->has_slope ? 2 : 1; s->L = steps_per_thread(pb->T);
   s->device = pb->device; s->max_evals = max_evals;
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&s->ev0));
+  HIP_TRY(hipEventCreate(&s->ev1));
+  HIP_TRY(hipEventCreate(&s->ev2));
   s->a1 = (float)params->init_level_loc;
   s->p10 = (float)(params->init_level_scale * params->init_level_scale);
   s->p11 = (float)(params->init_slope_scale * params->init_slope_scale);
@@ -807,7 +873,10 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
   HIP_TRY(s->ll.alloc(max_evals));
   HIP_TRY(s->grad.alloc((size_t)max_evals * (3 + P)));
   std::vector<float> yh(T);
-  for (int t = 0; t < T; ++t) yh[t] = mask[t] ? 0.f : y[t];
+  for (int t = 0; t < T; ++t) {
+    yh[t] = mask[t] ? 0.f : y[t];
+    if (!mask[t] && !std::isfinite(y[t])) return fail("y[%d] is not finite but unmasked", t);
+  }
   HIP_TRY(hipMemcpy(s->y.p, yh.data(), T * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->mask.p, mask, T, hipMemcpyHostToDevice));
   s->prm = *params;
@@ -834,32 +903,51 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
   return 0;
 }
 
-int ci_ll_session_hmc(ci_ll_session* s, int32_t num_chains, int32_t chain_offset,
-                      int32_t num_warmup, int32_t num_results, int32_t num_leapfrog,
-                      double target_accept, double initial_step_size, const uint32_t seed[2],
-                      const double* init_theta, double* draws, double* accept_rate,
-                      double* step_size) {
-  if (!s || !seed || !draws) return fail("NULL argument");
-  if (num_chains < 1 || num_results < 1 || num_warmup < 0 || num_leapfrog < 1)
+int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const double* init_theta,
+                          float* kernel_ms) {
+  if (!s || !o) return fail("NULL argument");
+  if (o->num_chains < 1 || o->num_results < 1 || o->num_warmup < 0 || o->num_leapfrog < 1)
     return fail("need num_chains >= 1, num_results >= 1, num_warmup >= 0, num_leapfrog >= 1");
-  if (!(target_accept > 0.0 && target_accept < 1.0) || !(initial_step_size > 0.0))
+  if (!(o->target_accept > 0.0 && o->target_accept < 1.0) || !(o->initial_step_size > 0.0))
     return fail("need 0 < target_accept < 1 and initial_step_size > 0");
+  if (o->prior != CI_HMC_PRIOR_SLAB && o->prior != CI_HMC_PRIOR_HORSESHOE)
+    return fail("prior must be CI_HMC_PRIOR_SLAB or CI_HMC_PRIOR_HORSESHOE, got %d", o->prior);
+  if (o->prior == CI_HMC_PRIOR_HORSESHOE && !(o->horseshoe_scale > 0.0))
+    return fail("horseshoe prior needs horseshoe_scale > 0");
   HIP_TRY(hipSetDevice(s->device));
-  const int P = s->P, C = num_chains, S = num_results;
-  s->h_draws.release(); s->h_acc.release(); s->h_eps.release();
-  HIP_TRY(s->h_draws.alloc((size_t)C * S * (3 + P)));
-  HIP_TRY(s->h_acc.alloc(C));
-  HIP_TRY(s->h_eps.alloc(C));
-  const int dim = P + (s->D == 2 ? 3 : 2);
-  s->h_init.release();
+  const int P = s->P, C = o->num_chains, S = o->num_results, T = s->T;
+  const size_t N = (size_t)C * S;
+  if (s->h_C != C || s->h_S != S) {
+    s->h_draws.release(); s->h_acc.release(); s->h_eps.release();
+    s->h_level.release(); s->h_slope.release(); s->h_loc.release(); s->h_traj.release();
+    s->h_pm.release(); s->h_obs.release(); s->h_lscale.release(); s->h_sscale.release();
+    s->h_w.release();
+    HIP_TRY(s->h_draws.alloc(N * (3 + P)));
+    HIP_TRY(s->h_acc.alloc(C));
+    HIP_TRY(s->h_eps.alloc(C));
+    HIP_TRY(s->h_level.alloc(N * T));
+    HIP_TRY(s->h_slope.alloc(s->D == 2 ? N * T : 0));
+    HIP_TRY(s->h_loc.alloc(N * T));
+    HIP_TRY(s->h_traj.alloc(N * T));
+    HIP_TRY(s->h_pm.alloc((size_t)C * T));
+    HIP_TRY(s->h_obs.alloc(N));
+    HIP_TRY(s->h_lscale.alloc(N));
+    HIP_TRY(s->h_sscale.alloc(N));
+    HIP_TRY(s->h_w.alloc(N * P));
+    s->h_C = C; s->h_S = S;
+  }
+  s->h_ran = false;
+  const int dim = ci::hmc_dim(P, s->D, o->prior);
   if (init_theta) {
-    HIP_TRY(s->h_init.alloc((size_t)C * dim));
-    HIP_TRY(hipMemcpy(s->h_init.p, init_theta, (size_t)C * dim * sizeof(double), hipMemcpyHostToDevice));
+    if (s->h_init.n != (size_t)C * dim) { s->h_init.release(); HIP_TRY(s->h_init.alloc((size_t)C * dim)); }
+    HIP_TRY(hipMemcpyAsync(s->h_init.p, init_theta, (size_t)C * dim * sizeof(double),
+                           hipMemcpyHostToDevice, s->stream));
   }
   ci::HmcArgs a;
   a.init = init_theta ? s->h_init.p : nullptr;
-  a.T = s->T; a.P = P; a.C = C; a.W = num_warmup; a.S = S; a.n_leap = num_leapfrog;
-  a.chain_offset = chain_offset; a.seed0 = seed[0]; a.seed1 = seed[1];
+  a.T = T; a.P = P; a.C = C; a.W = o->num_warmup; a.S = S; a.n_leap = o->num_leapfrog;
+  a.chain_offset = o->chain_offset; a.seed0 = o->seed[0]; a.seed1 = o->seed[1];
+  a.prior_mode = o->prior; a.hs_scale0 = o->horseshoe_scale;
   a.y = s->y.p; a.mask = s->mask.p; a.Xt = s->xt.p; a.omega = s->omega.p;
   const ci_series_params& q = s->prm;
   a.ig_a[0] = q.obs_conc; a.ig_b[0] = q.obs_scale;
@@ -869,18 +957,87 @@ int ci_ll_session_hmc(ci_ll_session* s, int32_t num_chains, int32_t chain_offset
   a.init_log[1] = std::log(std::max(q.level_scale0, 1e-4));
   a.init_log[2] = std::log(std::max(q.slope_scale0, 1e-4));
   a.a1 = s->a1; a.p10 = s->p10; a.p11 = s->p11;
-  a.target_accept = target_accept; a.eps0 = initial_step_size;
+  a.target_accept = o->target_accept; a.eps0 = o->initial_step_size;
   a.draws = s->h_draws.p; a.accept_rate = s->h_acc.p; a.step_size = s->h_eps.p;
   const int D = s->D, L = s->L;
-#define CI_HMC_CASE(DD, LL) if (D == DD && L == LL) ci_launch_hmc_d##DD##_l##LL(&a, 0);
+  HIP_TRY(hipEventRecord(s->ev0, s->stream));
+#define CI_HMC_CASE(DD, LL) if (D == DD && L == LL) ci_launch_hmc_d##DD##_l##LL(&a, s->stream);
   CI_HMC_CASE(1, 1) CI_HMC_CASE(1, 2) CI_HMC_CASE(1, 4) CI_HMC_CASE(1, 8) CI_HMC_CASE(1, 16)
   CI_HMC_CASE(2, 1) CI_HMC_CASE(2, 2) CI_HMC_CASE(2, 4) CI_HMC_CASE(2, 8) CI_HMC_CASE(2, 16)
 #undef CI_HMC_CASE
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(draws, s->h_draws.p, s->h_draws.n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  // latent path + posterior-predictive trajectory of every retained draw (one workgroup per
+  // draw: C*S workgroups fill the chip), the per-chain predictor means and the float32 container
+#define CI_LAT_CASE(DD, LL)                                                                       \
+  if (D == DD && L == LL)                                                                         \
+    ci_launch_latents_d##DD##_l##LL(T, P, (int)N, s->y.p, s->mask.p, s->xt.p, s->h_draws.p, s->a1, \
+                                    s->p10, s->p11, o->seed[0], o->seed[1],                       \
+                                    (uint32_t)o->chain_offset, 0u, S, s->h_level.p, s->h_slope.p, \
+                                    s->h_loc.p, s->h_traj.p, s->stream);
+  CI_LAT_CASE(1, 1) CI_LAT_CASE(1, 2) CI_LAT_CASE(1, 4) CI_LAT_CASE(1, 8) CI_LAT_CASE(1, 16)
+  CI_LAT_CASE(2, 1) CI_LAT_CASE(2, 2) CI_LAT_CASE(2, 4) CI_LAT_CASE(2, 8) CI_LAT_CASE(2, 16)
+#undef CI_LAT_CASE
+  hipLaunchKernelGGL(ci::hmc_mean_kernel, dim3((T + 255) / 256, C), dim3(256), 0, s->stream, C, S, T,
+                     s->h_loc.p, s->h_pm.p);
+  hipLaunchKernelGGL(ci::hmc_unpack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s->stream,
+                     (int)N, P, s->h_draws.p, s->h_obs.p, s->h_lscale.p, s->h_sscale.p, s->h_w.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev2, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (kernel_ms) {
+    HIP_TRY(hipEventElapsedTime(&kernel_ms[0], s->ev0, s->ev1));
+    HIP_TRY(hipEventElapsedTime(&kernel_ms[1], s->ev1, s->ev2));
+  }
+  s->h_ran = true;
+  return 0;
+}
+
+int ci_ll_session_hmc_fetch(ci_ll_session* s, double* draws, double* accept_rate, double* step_size,
+                            ci_outputs* o) {
+  if (!s) return fail("session is NULL");
+  if (!s->h_ran) return fail("ci_ll_session_hmc_fetch needs a finished ci_ll_session_hmc_run");
+  HIP_TRY(hipSetDevice(s->device));
+  const int C = s->h_C;
+  if (draws) HIP_TRY(hipMemcpy(draws, s->h_draws.p, s->h_draws.n * sizeof(double), hipMemcpyDeviceToHost));
   if (accept_rate) HIP_TRY(hipMemcpy(accept_rate, s->h_acc.p, C * sizeof(double), hipMemcpyDeviceToHost));
   if (step_size) HIP_TRY(hipMemcpy(step_size, s->h_eps.p, C * sizeof(double), hipMemcpyDeviceToHost));
+  if (o) {
+    auto get = [&](float* dst, const DevBuf<float>& src) -> hipError_t {
+      if (!dst || src.n == 0) return hipSuccess;
+      return hipMemcpy(dst, src.p, src.n * sizeof(float), hipMemcpyDeviceToHost);
+    };
+    HIP_TRY(get(o->observation_noise_scale, s->h_obs));
+    HIP_TRY(get(o->level_scale, s->h_lscale));
+    HIP_TRY(get(o->slope_scale, s->h_sscale));
+    HIP_TRY(get(o->weights, s->h_w));
+    HIP_TRY(get(o->level, s->h_level));
+    HIP_TRY(get(o->posterior_means, s->h_pm));
+    HIP_TRY(get(o->posterior_trajectories, s->h_traj));
+    if (o->slope) {
+      if (s->D == 2) HIP_TRY(get(o->slope, s->h_slope));
+      else memset(o->slope, 0, s->h_level.n * sizeof(float));
+    }
+  }
+  return 0;
+}
+
+int ci_ll_session_kernel_name(const ci_ll_session* s, char* buf, int32_t buflen) {
+  if (!s) return fail("session is NULL");
+  char nm[64];
+  snprintf(nm, sizeof(nm), "ci::hmc_kernel<%d,%d>", s->D, s->L);
+  return copy_name(nm, buf, buflen);
+}
+
+int ci_ll_session_algorithmic_bytes(const ci_ll_session* s, double* bytes) {
+  if (!s || !bytes) return fail("NULL argument");
+  if (s->h_C < 1) return fail("no HMC fit has been configured on this session");
+  // latent / trajectory draws are produced for every HMC draw, so
+  // the per-draw figure is the Gibbs one: 4 T (d_out + 1) + 4 (P + 2 + slope); inputs once per chain.
+  const double T = s->T, P = s->P, slope = s->D == 2 ? 1.0 : 0.0;
+  const double per_draw = 4.0 * T * (1.0 + slope + 1.0) + 4.0 * (P + 2.0 + slope);
+  const double per_chain = 4.0 * T * (P + 1.0) + T;
+  *bytes = (double)s->h_C * ((double)s->h_S * per_draw + per_chain);
   return 0;
 }
 
@@ -928,7 +1085,7 @@ int ci_ll_session_draw_latents(ci_ll_session* s, int32_t num_draws, const double
 #define CI_LAT_CASE(DD, LL)                                                                       \
   if (D == DD && L == LL)                                                                         \
     ci_launch_latents_d##DD##_l##LL(T, P, E, s->y.p, s->mask.p, s->xt.p, s->theta.p, s->a1,       \
-                                    s->p10, s->p11, seed[0], seed[1], rng_chain, iter0,           \
+                                    s->p10, s->p11, seed[0], seed[1], rng_chain, iter0, 0,        \
                                     s->level.p, s->slope.p, s->loc.p, s->traj.p, 0);
   CI_LAT_CASE(1, 1) CI_LAT_CASE(1, 2) CI_LAT_CASE(1, 4) CI_LAT_CASE(1, 8) CI_LAT_CASE(1, 16)
   CI_LAT_CASE(2, 1) CI_LAT_CASE(2, 2) CI_LAT_CASE(2, 4) CI_LAT_CASE(2, 8) CI_LAT_CASE(2, 16)
@@ -950,6 +1107,13 @@ int ci_ll_session_destroy(ci_ll_session* s) {
   s->y.release(); s->xt.release(); s->mask.release(); s->theta.release(); s->ll.release();
   s->grad.release(); s->level.release(); s->slope.release(); s->loc.release(); s->traj.release();
   s->omega.release(); s->h_draws.release(); s->h_acc.release(); s->h_eps.release(); s->h_init.release();
+  s->h_level.release(); s->h_slope.release(); s->h_loc.release(); s->h_traj.release();
+  s->h_pm.release(); s->h_obs.release(); s->h_lscale.release(); s->h_sscale.release();
+  s->h_w.release();
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->ev2) (void)hipEventDestroy(s->ev2);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return 0;
 }

@@ -73,12 +73,12 @@ void CI_CAT(ci_launch_latents_d, CI_D, _l, CI_L)(int T, int P, int E, const floa
                                                 const uint8_t* mask, const float* Xt,
                                                 const double* theta, float a1, float p10,
                                                 float p11, uint32_t k0, uint32_t k1,
-                                                uint32_t rng_chain, uint32_t iter0, float* level,
-                                                float* slope, float* loc, float* traj,
+                                                uint32_t rng_chain, uint32_t iter0, int per_chain,
+                                                float* level, float* slope, float* loc, float* traj,
                                                 hipStream_t stream) {
   hipLaunchKernelGGL((ci::latents_kernel<CI_D, CI_L>), dim3(E), dim3(ci::NT), 0, stream, T, P, y,
-                     mask, Xt, theta, a1, p10, p11, k0, k1, rng_chain, iter0, level, slope, loc,
-                     traj);
+                     mask, Xt, theta, a1, p10, p11, k0, k1, rng_chain, iter0, per_chain, level, slope,
+                     loc, traj);
 }
 
 // Runs the on-device HMC fit: one workgroup per chain.

@@ -2093,6 +2093,7 @@ __global__ __launch_bounds__(NT) void latents_kernel(int T, int P, const float* 
                                                      const double* __restrict__ theta, float a1,
                                                      float p10, float p11, uint32_t k0, uint32_t k1,
                                                      uint32_t rng_chain, uint32_t iter0,
+                                                     int per_chain,
                                                      float* __restrict__ out_level,
                                                      float* __restrict__ out_slope,
                                                      float* __restrict__ out_loc,
@@ -2126,8 +2127,13 @@ __global__ __launch_bounds__(NT) void latents_kernel(int T, int P, const float* 
     md.sig.v[1] = (float)th[2];
     md.p1.v[1] = p11;
   }
-  Rng g{k0, k1, rng_chain};
-  const uint32_t iter = iter0 + blockIdx.x;
+  // per_chain > 0: rows are [chain][draw] blocks of per_chain draws (a whole HMC fit in one
+  // launch): chain id and iteration follow from the row, so the draws do not depend on how the
+  // rows are split over launches or devices
+  const uint32_t row_chain = per_chain > 0 ? blockIdx.x / (uint32_t)per_chain : 0u;
+  const uint32_t row_iter = per_chain > 0 ? blockIdx.x % (uint32_t)per_chain : blockIdx.x;
+  Rng g{k0, k1, rng_chain + row_chain};
+  const uint32_t iter = iter0 + row_iter;
   Vec<D> x[L];
   Prof prof;
   prof.start(nullptr, false);

@@ -357,6 +357,14 @@ typedef struct {
 
 /* logp(gamma) = 1/2 logdet(Omega_g) - 1/2 logdet(Omega_g + XtX_g)
  *             + sum_j log prior(gamma_j) - (a_post - 1) log(2 beta_post(g)) */
+/* Exponent of the collapsed marginal.  Scott & Varian (2013) eq. 8 -- and TFP's
+ * spike_and_slab as recalled, and bsts/BOOM -- write SS^-(N/2 - 1), i.e. (a_post - 1); integrating
+ * sigma^2 out of the model exactly gives a_post.  The difference multiplies the inclusion odds by
+ * SS_g'/SS_g = 1 + O(1/n): immaterial at the reference's sizes, visible at n = 4
+ * (tests/test_geweke.py, which therefore runs the exact exponent through
+ * CI_ORACLE_FLAG_EXACT_MARGINAL).  Default 1.0 = the reference's formula. */
+static double g_ss_exponent_offset = 1.0;
+
 static int ss_evaluate(int P, const double* xtx, const double* prior_prec, const double* xty,
                        double yty, const uint8_t* nz, double nonzero_prob, double post_conc,
                        double prior_scale, double* work /* >= 3*P*P + 2*P */, ss_eval* ev) {
@@ -391,7 +399,7 @@ static int ss_evaluate(int P, const double* xtx, const double* prior_prec, const
   }
   ev->post_scale = prior_scale + 0.5 * (yty - quad);
   ev->logp = half_logdet_prior - half_logdet_post + prior_term -
-             (post_conc - 1.0) * log(2.0 * ev->post_scale);
+             (post_conc - g_ss_exponent_offset) * log(2.0 * ev->post_scale);
   if (ev->chol_post) memcpy(ev->chol_post, lm, sizeof(double) * na * na);
   if (ev->mean) memcpy(ev->mean, mu, sizeof(double) * na);
   return 0;
@@ -448,6 +456,8 @@ int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out) {
   for (int k = 0; k < K; ++k) drift[k] = pb->drift_scale0[k];
   double* w = (double*)calloc(P > 0 ? P : 1, sizeof(double));
   double* lat = (double*)calloc((size_t)T * d, sizeof(double));
+  if (pb->weights0) memcpy(w, pb->weights0, sizeof(double) * P);
+  if (pb->latents0) memcpy(lat, pb->latents0, sizeof(double) * (size_t)T * d);
   double* resid = (double*)malloc(sizeof(double) * T);
   double* targets = (double*)malloc(sizeof(double) * T);
   double* pred_acc = (double*)calloc(T, sizeof(double));
@@ -486,6 +496,7 @@ int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out) {
       }
   }
   const double post_conc = pb->obs_conc + 0.5 * n_obs;
+  g_ss_exponent_offset = (pb->flags & CI_ORACLE_FLAG_EXACT_MARGINAL) ? 0.0 : 1.0;   /* test-only */
 
   for (int it = 0; it < W + S; ++it) {
     const uint32_t uit = (uint32_t)it;
@@ -509,6 +520,7 @@ int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out) {
       /* experimental_use_weight_adjustment=True: prior precision rescaled by the
        * previous observation-noise variance (causalimpact_lib.py:388). */
       double prev_var = obs_scale * obs_scale;
+      if (pb->flags & CI_ORACLE_FLAG_NO_WEIGHT_ADJUSTMENT) prev_var = 1.0;   /* test-only */
       for (int i = 0; i < P * P; ++i) omega_eff[i] = omega[i] * prev_var;
       ss_eval cur, prop;
       cur.chol_post = chol_post; cur.mean = mean;
@@ -655,6 +667,7 @@ int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out) {
   free(w); free(lat); free(resid); free(targets); free(pred_acc);
   free(xtx); free(omega); free(omega_eff); free(xty); free(work);
   free(chol_post); free(mean); free(zw); free(nz); free(perm_u); free(perm);
+  g_ss_exponent_offset = 1.0;
   return 0;
 }
 

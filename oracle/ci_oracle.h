@@ -79,7 +79,7 @@ typedef struct {
   int32_t num_results;  /* S */
   uint32_t seed[2];
   int32_t chain;        /* global chain id (RNG counter word 3) */
-  int32_t reserved;
+  int32_t flags;        /* CI_ORACLE_FLAG_* (0 = the reference's behaviour) */
   /* data (caller owned) */
   const double* y;               /* [T]; ignored where mask != 0 */
   const uint8_t* mask;           /* [T]; 1 = missing */
@@ -96,7 +96,20 @@ typedef struct {
   double init_seasonal_scale;                   /* N(0, sd) per effect */
   /* initial Gibbs state (causalimpact_lib.py:566-581) */
   double obs_scale0, level_scale0, slope_scale0, drift_scale0[CI_MAX_BLOCKS];
+  /* optional starting point of the chain (NULL = the reference's zeros, :575-581); lets a test
+   * apply ONE Gibbs transition to an arbitrary state (tests/test_geweke.py) */
+  const double* weights0;  /* [P] */
+  const double* latents0;  /* [T*d] */
 } ci_oracle_problem;
+
+/* Test-only: sample with the weights prior N(0, sigma^2 Omega^-1) exactly as the collapsed
+ * spike-and-slab sampler is derived (Scott & Varian 2013), i.e. WITHOUT the reference's
+ * experimental_use_weight_adjustment=True rescaling (causalimpact_lib.py:388), so that the
+ * transition has a known invariant distribution (Geweke 2004 joint-distribution test). */
+#define CI_ORACLE_FLAG_NO_WEIGHT_ADJUSTMENT 1
+/* Test-only: exponent a_post instead of the reference's (a_post - 1) in the collapsed
+ * spike-and-slab marginal (see ss_evaluate in ci_oracle.c). */
+#define CI_ORACLE_FLAG_EXACT_MARGINAL 2
 
 typedef struct {
   /* all caller-allocated; any pointer may be NULL to skip that output */

@@ -48,7 +48,7 @@ class _Problem(C.Structure):
       ("T", C.c_int32), ("P", C.c_int32), ("has_slope", C.c_int32),
       ("num_blocks", C.c_int32), ("num_seasons", C.c_int32 * _MAX_BLOCKS),
       ("num_warmup", C.c_int32), ("num_results", C.c_int32),
-      ("seed", C.c_uint32 * 2), ("chain", C.c_int32), ("reserved", C.c_int32),
+      ("seed", C.c_uint32 * 2), ("chain", C.c_int32), ("flags", C.c_int32),
       ("y", C.c_void_p), ("mask", C.c_void_p), ("X", C.c_void_p),
       ("season_change", C.c_void_p),
       ("level_conc", C.c_double), ("level_scale", C.c_double), ("level_ub", C.c_double),
@@ -60,7 +60,12 @@ class _Problem(C.Structure):
       ("init_slope_scale", C.c_double), ("init_seasonal_scale", C.c_double),
       ("obs_scale0", C.c_double), ("level_scale0", C.c_double), ("slope_scale0", C.c_double),
       ("drift_scale0", C.c_double * _MAX_BLOCKS),
+      ("weights0", C.c_void_p), ("latents0", C.c_void_p),
   ]
+
+
+FLAG_NO_WEIGHT_ADJUSTMENT = 1   # == CI_ORACLE_FLAG_NO_WEIGHT_ADJUSTMENT (test-only)
+FLAG_EXACT_MARGINAL = 2         # == CI_ORACLE_FLAG_EXACT_MARGINAL (test-only)
 
 
 class _Outputs(C.Structure):
@@ -189,8 +194,10 @@ def _u32pair(seed) -> "C.Array":
 
 def fit_gibbs(y, mask, X, spec, *, num_results, num_warmup, seed, chain=0,
               want=("obs_scale", "level_scale", "slope_scale", "drift_scales", "weights", "level",
-                    "slope", "seasonal", "pred_mean", "trajectories", "nonzeros")):
-  """Runs the float64 oracle for one chain; returns a dict of numpy arrays."""
+                    "slope", "seasonal", "pred_mean", "trajectories", "nonzeros"),
+              weights0=None, latents0=None, flags=0):
+  """Runs the float64 oracle for one chain; returns a dict of numpy arrays.  weights0 [P] /
+  latents0 [T, d] start the chain somewhere else than the reference's zeros (tests only)."""
   L = lib()
   T, P = spec["T"], spec["P"]
   K = len(spec["num_seasons"])
@@ -208,6 +215,11 @@ def fit_gibbs(y, mask, X, spec, *, num_results, num_warmup, seed, chain=0,
   s = _u32pair(seed)
   pb.seed[0], pb.seed[1] = s[0], s[1]
   pb.chain = int(chain)
+  pb.flags = int(flags)
+  w0 = None if weights0 is None else np.ascontiguousarray(weights0, dtype=np.float64)
+  l0 = None if latents0 is None else np.ascontiguousarray(latents0, dtype=np.float64)
+  pb.weights0 = None if w0 is None else w0.ctypes.data
+  pb.latents0 = None if l0 is None else l0.ctypes.data
   pb.y = y64.ctypes.data
   pb.mask = m8.ctypes.data
   pb.X = X64.ctypes.data if P > 0 else None

@@ -237,6 +237,7 @@ def main():
                                   gather_keys=("posterior_means",),
                                   device="cuda" if dist is not None else None)
   rhat = comb["split_rhat"]
+  ess = {"bulk": comb["ess_bulk"], "tail": comb["ess_tail"]}
 
   samples_per_step = world * C * CFG["num_results"]
   value = samples_per_step * args.steps / dt
@@ -264,7 +265,7 @@ def main():
                  "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
       "roofline": roof,
       "pcie_inclusive_value": C * CFG["num_results"] / dt_pcie,
-      "split_rhat": rhat,
+      "split_rhat": rhat, "ess": ess,
   }
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out["cpu_baseline"] = _cpu_baseline(args.sampler, y, mask, X)

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _fake_fit(first, count, S=40, T=7):
+  assert count > 0, "local_fit must not be called for an empty block"
   out = {"posterior_trajectories": np.zeros((count, S, T), np.float32),
          "posterior_means": np.zeros((count, T), np.float32),
          "observation_noise_scale": np.zeros((count, S), np.float32),
@@ -37,13 +38,16 @@ def _worker(rank, world, port, num_chains, q):
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
   dist.init_process_group("gloo", rank=rank, world_size=world)
   res = d.fit_sharded(_fake_fit, num_chains)
-  q.put((rank, res["posterior_trajectories"], res["posterior_means"], res["split_rhat"]))
+  q.put((rank, res["posterior_trajectories"], res["posterior_means"],
+         {k: res[k] for k in ("split_rhat", "ess_bulk", "ess_tail")}))
   dist.barrier()
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_chains", [4, 5])
+@pytest.mark.parametrize("num_chains", [4, 5, 1])
 def test_two_ranks_equal_one_process(num_chains):
+  """num_chains = 1 leaves rank 1 with an EMPTY block: it must not call the fit (a zero-chain
+  problem is invalid) and must still take part in every collective."""
   import torch.multiprocessing as mp
   sys.path[:0] = [os.path.join(ROOT, "tfp-causalimpact_amd")]
   from causalimpact import _distributed as d
@@ -60,14 +64,19 @@ def test_two_ranks_equal_one_process(num_chains):
   for p in procs:
     p.join(timeout=60)
     assert p.exitcode == 0
-  for _, traj, means, rhat in got:
+  for _, traj, means, diag in got:
     np.testing.assert_array_equal(traj, single["posterior_trajectories"])
     np.testing.assert_array_equal(means, single["posterior_means"])
-    for k, v in single["split_rhat"].items():
-      np.testing.assert_allclose(rhat[k], v, rtol=1e-9)
-  # the level_scale stand-in drifts with the chain id, so its R-hat must flag it
-  assert single["split_rhat"]["level_scale"] > 1.2
-  assert single["split_rhat"]["observation_noise_scale"] < 1.1
+    for name in ("split_rhat", "ess_bulk", "ess_tail"):
+      for k, v in single[name].items():
+        np.testing.assert_allclose(diag[name][k], v, rtol=1e-9, err_msg=f"{name}.{k}")
+  if num_chains > 1:
+    # the level_scale stand-in drifts with the chain id, so its R-hat must flag it
+    assert single["split_rhat"]["level_scale"] > 1.2
+    assert single["split_rhat"]["observation_noise_scale"] < 1.1
+    assert single["ess_bulk"]["observation_noise_scale"] > 0.5 * num_chains * 40
+    assert single["ess_tail"]["observation_noise_scale"] > 0.2 * num_chains * 40
+    assert single["ess_bulk"]["level_scale"] < 0.2 * num_chains * 40
 
 
 def test_chain_blocks_partition_exactly():

@@ -59,3 +59,36 @@ def test_effective_sample_size_on_known_processes():
   # chains stuck at different levels: R-hat large, ESS tiny
   stuck = rng.normal(size=(4, 500)) * 0.01 + np.arange(4)[:, None]
   assert lib.effective_sample_size(stuck) < 20 and lib.split_rhat(stuck) > 5
+
+
+def test_bulk_and_tail_ess_and_additivity_of_the_partial_sums():
+  """Vehtari et al. (2021) bulk / tail ESS, written as partial sums that add over ranks
+  (`_diagnostics`): iid draws give ~N for both; an AR(1) gives the textbook bulk value; a
+  heavy-tailed parameter (where the plain estimator's variance does not exist) still gets a
+  finite, sensible bulk ESS; summing the partial sums of two disjoint chain blocks reproduces
+  the all-chains value exactly (what the all-reduce in `_distributed.fit_sharded` relies on)."""
+  from causalimpact import _diagnostics as dg
+  from causalimpact import causalimpact_lib as lib
+  rng = np.random.default_rng(1)
+  iid = rng.normal(size=(4, 2000))
+  assert 0.8 * 8000 < lib.effective_sample_size(iid, "bulk") < 1.25 * 8000
+  assert 0.6 * 8000 < lib.effective_sample_size(iid, "tail") < 1.4 * 8000
+  phi = 0.9
+  ar = np.zeros((4, 4000))
+  e = rng.normal(size=ar.shape)
+  for t in range(1, ar.shape[1]):
+    ar[:, t] = phi * ar[:, t - 1] + e[:, t]
+  want = ar.size * (1 - phi) / (1 + phi)
+  assert 0.6 * want < lib.effective_sample_size(ar, "bulk") < 1.6 * want
+  assert lib.effective_sample_size(ar, "tail") < ar.size
+  cauchy = rng.standard_cauchy(size=(4, 2000))
+  assert 0.7 * 8000 < lib.effective_sample_size(cauchy, "bulk") < 1.3 * 8000
+  assert np.isnan(lib.effective_sample_size(np.zeros((2, 50)), "bulk"))
+  # additivity: chains {0,1} + chains {2,3} == chains {0..3}
+  whole = dg.bulk_partial(ar, ar)
+  a, b = dg.bulk_partial(ar[:2], ar), dg.bulk_partial(ar[2:], ar)
+  summed = dg.unpack(dg.pack(a) + dg.pack(b))
+  np.testing.assert_allclose(dg.ess_from_sums(summed), dg.ess_from_sums(whole), rtol=1e-12)
+  np.testing.assert_allclose(dg.rhat_from_sums(dg.unpack(dg.pack(dg.partial_sums(dg.split_chains(ar[:2]))) +
+                                                          dg.pack(dg.partial_sums(dg.split_chains(ar[2:]))))),
+                             lib.split_rhat(ar), rtol=1e-12)

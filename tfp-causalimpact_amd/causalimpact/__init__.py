@@ -1,9 +1,9 @@
 """MI355X-native drop-in for the hot path of google/tfp-causalimpact.
 
-Same public names as /root/reference/causalimpact/__init__.py:29-37.  `plot` is out of
-scope; `summary` renders the text report.
+Same public names as /root/reference/causalimpact/__init__.py:29-37: `fit_causalimpact`, the
+option / result types, `summary` (text report) and `plot` (Vega-Lite or matplotlib).
 """
-__version__ = "0.2.0+mi355x.r1"
+__version__ = "0.2.0+mi355x.r2"
 
 from causalimpact.causalimpact_lib import CausalImpactAnalysis
 from causalimpact.causalimpact_lib import CausalImpactPosteriorSamples
@@ -19,10 +19,4 @@ from causalimpact.batch import CausalImpactBatchAnalysis
 from causalimpact.batch import fit_causalimpact_batch
 
 
-def plot(*args, **kwargs):
-  """Not part of this build: the reference draws Altair charts
-  from `CausalImpactAnalysis.series`, which this build returns with the same schema -- the
-  reference's `causalimpact.plot` works on it unchanged."""
-  raise NotImplementedError(
-      "plot() is not provided by the MI355X build; pass the analysis to the reference's "
-      "causalimpact.plot (same CausalImpactAnalysis.series schema)")
+from causalimpact.plot import plot

@@ -4,14 +4,21 @@ The reference runs one chain in one process; chains are
 independent given the data, so ranks take contiguous blocks of chain ids with NO collective
 on the data path.  Chain c always uses RNG stream c (`chain_offset`), hence the pooled
 result is identical for any world size.  RCCL (backend "nccl" on ROCm) / gloo is used only
-after sampling: an all-gather of the per-chain draws needed for pooled summaries and an
-all-reduce of per-chain moments for split-R-hat.
+after sampling:
+  * an all-gather of the per-chain blocks needed for pooled summaries (`gather_keys`) and of
+    the scalar parameters the diagnostics rank (`rhat_keys`: [chains, draws] floats);
+  * ONE all-reduce(sum) of the diagnostics' partial sums -- per-split-chain means and
+    autocovariance sums of the rank-normalised draws and of the tail indicators
+    (`_diagnostics.partial_sums`) -- from which every rank forms split-R-hat, bulk ESS and
+    tail ESS of ALL chains.
 """
 from __future__ import annotations
 
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
+
+from causalimpact import _diagnostics as dg
 
 
 def chain_block(num_chains: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -22,22 +29,6 @@ def chain_block(num_chains: int, rank: int, world_size: int) -> Tuple[int, int]:
   return first, count
 
 
-def _moments(draws: np.ndarray) -> np.ndarray:
-  """[C_local, S] -> [C_local, 4]: split-half means and variances per chain."""
-  half = draws.shape[1] // 2
-  a, b = draws[:, :half], draws[:, half:2 * half]
-  return np.stack([a.mean(1), b.mean(1), a.var(1, ddof=1), b.var(1, ddof=1)], axis=1)
-
-
-def split_rhat_from_moments(moments: np.ndarray, half: int) -> float:
-  """moments: [C_total, 4] as produced by _moments; Gelman et al. (2013) split-R-hat."""
-  means = np.concatenate([moments[:, 0], moments[:, 1]])
-  variances = np.concatenate([moments[:, 2], moments[:, 3]])
-  within = variances.mean()
-  between = half * means.var(ddof=1)
-  return float(np.sqrt(((half - 1) / half * within + between / half) / within))
-
-
 def fit_sharded(local_fit: Callable[[int, int], Dict[str, np.ndarray]], num_chains: int,
                 gather_keys: Sequence[str] = ("posterior_trajectories", "posterior_means"),
                 rhat_keys: Sequence[str] = ("observation_noise_scale", "level_scale"),
@@ -45,8 +36,11 @@ def fit_sharded(local_fit: Callable[[int, int], Dict[str, np.ndarray]], num_chai
   """Runs `local_fit(first_chain, count)` on every rank and combines the results.
 
   local_fit returns arrays with a leading chain axis [count, ...] (e.g. the [0] slice of
-  `_native.fit_gibbs` outputs for one series).  Returns on every rank:
-    {key: [num_chains, ...] for key in gather_keys, "split_rhat": {key: float}}.
+  `_native.fit_gibbs` outputs for one series).  It is NOT called on a rank whose block is empty
+  (more ranks than chains): that rank contributes zero-length blocks to the collectives.
+  Returns on every rank:
+    {key: [num_chains, ...] for key in gather_keys,
+     "split_rhat" / "ess_bulk" / "ess_tail": {key: float for key in rhat_keys}}.
   Works without an initialised process group (world size 1).
   """
   try:
@@ -57,34 +51,73 @@ def fit_sharded(local_fit: Callable[[int, int], Dict[str, np.ndarray]], num_chai
     live = False
   rank = dist.get_rank(group) if live else 0
   world = dist.get_world_size(group) if live else 1
+  if num_chains < 1:
+    raise ValueError(f"num_chains must be >= 1, got {num_chains}")
   first, count = chain_block(num_chains, rank, world)
-  local = local_fit(first, count)
+  local = local_fit(first, count) if count > 0 else None
   out: Dict[str, object] = {}
-  half = None
+
   if not live:
     for k in gather_keys:
       out[k] = local[k]
-    mom = {k: _moments(np.asarray(local[k], np.float64)) for k in rhat_keys}
-    half = np.asarray(local[rhat_keys[0]]).shape[1] // 2 if rhat_keys else 0
+    scal = {k: np.asarray(local[k], np.float64) for k in rhat_keys}
+    sums = {k: _local_sums(scal[k], scal[k]) for k in rhat_keys}
   else:
     dev = torch.device(device) if device else torch.device("cpu")
     counts = [chain_block(num_chains, r, world)[1] for r in range(world)]
     cmax = max(counts)
-    for k in gather_keys:
-      a = np.ascontiguousarray(local[k], dtype=np.float32)
-      pad = np.zeros((cmax,) + a.shape[1:], np.float32)
-      pad[:count] = a
+
+    def gather(a: Optional[np.ndarray], tail_shape, dtype) -> np.ndarray:
+      """all-gather of [count, *tail] blocks (padded to the largest block); RCCL on GPUs."""
+      pad = np.zeros((cmax,) + tuple(tail_shape), dtype)
+      if count > 0:
+        pad[:count] = a
       mine = torch.from_numpy(pad).to(dev)
       parts = [torch.empty_like(mine) for _ in range(world)]
-      dist.all_gather(parts, mine, group=group)          # RCCL all-gather of the chain blocks
-      out[k] = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)], axis=0)
-    mom = {}
+      dist.all_gather(parts, mine, group=group)
+      return np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)], axis=0)
+
+    # tail shapes must be known on ranks with an empty block too: agree on them first
+    shapes = _agree_on_shapes(local, list(gather_keys) + list(rhat_keys), dist, group, torch, dev)
+    for k in gather_keys:
+      a = None if local is None else np.ascontiguousarray(local[k], dtype=np.float32)
+      out[k] = gather(a, shapes[k], np.float32)
+    sums = {}
     for k in rhat_keys:
-      d = np.asarray(local[k], np.float64)
-      half = d.shape[1] // 2
-      slot = torch.zeros((num_chains, 4), dtype=torch.float64, device=dev)
-      slot[first:first + count] = torch.from_numpy(_moments(d)).to(dev)
-      dist.all_reduce(slot, op=dist.ReduceOp.SUM, group=group)   # small all-reduce of moments
-      mom[k] = slot.cpu().numpy()
-  out["split_rhat"] = {k: split_rhat_from_moments(mom[k], half) for k in rhat_keys}
+      a = None if local is None else np.ascontiguousarray(local[k], dtype=np.float64)
+      pooled = gather(a, shapes[k], np.float64)                  # [num_chains, S] scalars
+      mine = pooled[first:first + count]
+      packed = np.stack([dg.pack(p) for p in _local_sums(mine, pooled)])       # [4, n + 3]
+      t = torch.from_numpy(packed).to(dev)
+      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)       # small all-reduce of the sums
+      sums[k] = [dg.unpack(v) for v in t.cpu().numpy()]
+  out["split_rhat"] = {k: dg.rhat_from_sums(sums[k][0]) for k in rhat_keys}
+  out["ess_bulk"] = {k: dg.ess_from_sums(sums[k][1]) for k in rhat_keys}
+  out["ess_tail"] = {k: float(np.nanmin([dg.ess_from_sums(sums[k][2]), dg.ess_from_sums(sums[k][3])]))
+                     for k in rhat_keys}
   return out
+
+
+def _local_sums(mine: np.ndarray, pooled: np.ndarray):
+  """The four additive statistics of this rank's chains: plain (R-hat), rank-normalised (bulk
+  ESS), and the two tail indicators."""
+  lo, hi = dg.tail_partials(mine, pooled)
+  return [dg.partial_sums(dg.split_chains(mine)), dg.bulk_partial(mine, pooled), lo, hi]
+
+
+def _agree_on_shapes(local, keys, dist, group, torch, dev):
+  """Per-key trailing shapes, taken from any rank that ran a fit (max-reduced; ranks with an
+  empty block contribute zeros)."""
+  max_nd = 4
+  t = torch.zeros((len(keys), max_nd + 1), dtype=torch.int64, device=dev)
+  if local is not None:
+    for i, k in enumerate(keys):
+      shp = np.asarray(local[k]).shape[1:]
+      if len(shp) > max_nd:
+        raise ValueError(f"{k}: at most {max_nd} trailing dimensions are supported")
+      t[i, 0] = len(shp)
+      for j, v in enumerate(shp):
+        t[i, 1 + j] = int(v)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+  t = t.cpu().numpy()
+  return {k: tuple(int(v) for v in t[i, 1:1 + int(t[i, 0])]) for i, k in enumerate(keys)}

@@ -291,6 +291,9 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
     stacked = {k: np.concatenate([r[0][k] for r in results], axis=0) for k in keys}   # [B, C, S]
     diagnostics = {
         "split_rhat": [{k: lib.split_rhat(stacked[k][b]) for k in keys} for b in range(B)],
-        "ess_bulk": [{k: lib.effective_sample_size(stacked[k][b]) for k in keys} for b in range(B)],
+        "ess_bulk": [{k: lib.effective_sample_size(stacked[k][b], "bulk") for k in keys}
+                     for b in range(B)],
+        "ess_tail": [{k: lib.effective_sample_size(stacked[k][b], "tail") for k in keys}
+                     for b in range(B)],
     }
   return CausalImpactBatchAnalysis(prep, names, alpha, means, dsum, ranks, columns, diagnostics)

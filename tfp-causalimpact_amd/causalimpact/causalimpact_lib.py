@@ -21,6 +21,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 import numpy as np
 import pandas as pd
 
+from causalimpact import _diagnostics
 from causalimpact import _model
 from causalimpact import _native
 from causalimpact import data as cid
@@ -194,48 +195,17 @@ def _sanitize_seed(seed: Optional[_SeedType]) -> Tuple[int, int]:
 
 def split_rhat(draws: np.ndarray) -> float:
   """Split-R-hat of [chains, draws] (Gelman et al. 2013); NaN for degenerate input."""
-  draws = np.asarray(draws, np.float64)
-  half = draws.shape[1] // 2
-  if half < 2:
-    return float("nan")
-  z = np.concatenate([draws[:, :half], draws[:, half:2 * half]], axis=0)
-  within = z.var(axis=1, ddof=1).mean()
-  between = half * z.mean(axis=1).var(ddof=1)
-  if within <= 0:
-    return float("nan")
-  return float(np.sqrt(((half - 1) / half * within + between / half) / within))
+  return _diagnostics.split_rhat(draws)
 
 
-def effective_sample_size(draws: np.ndarray) -> float:
-  """Bulk effective sample size of [chains, draws] scalar draws: split chains, FFT
-  autocovariances, Geyer's initial monotone positive sequence (Gelman et al. 2013, ch. 11;
-  Vehtari et al. 2021).  NaN for degenerate input.  (SURVEY.md 8(f) N3 -- absent upstream.)"""
-  x = np.asarray(draws, np.float64)
-  half = x.shape[1] // 2
-  if half < 4:
-    return float("nan")
-  z = np.concatenate([x[:, :half], x[:, half:2 * half]], axis=0)       # [2C, n]
-  m, n = z.shape
-  zc = z - z.mean(axis=1, keepdims=True)
-  size = 1 << int(np.ceil(np.log2(2 * n)))
-  f = np.fft.rfft(zc, size, axis=1)
-  acov = np.fft.irfft(f * np.conj(f), size, axis=1)[:, :n] / n          # biased, per chain
-  within = acov[:, 0].mean() * n / (n - 1.0)
-  var_plus = acov[:, 0].mean() + (z.mean(axis=1).var(ddof=1) if m > 1 else 0.0)
-  if not np.isfinite(var_plus) or var_plus <= 0:
-    return float("nan")
-  rho = 1.0 - (within - acov.mean(axis=0) * n / (n - 1.0)) / var_plus
-  rho[0] = 1.0
-  # sums of adjacent pairs must be positive and non-increasing
-  tau, prev = -1.0, np.inf
-  for k in range(0, n - 1, 2):
-    pair = rho[k] + rho[k + 1]
-    if pair < 0:
-      break
-    pair = min(pair, prev)
-    tau += 2.0 * pair
-    prev = pair
-  return float(m * n / max(tau, 1.0 / np.log10(max(m * n, 10))))
+def effective_sample_size(draws: np.ndarray, kind: str = "plain") -> float:
+  """Effective sample size of [chains, draws] scalar draws: split chains, FFT autocovariances,
+  Geyer's initial monotone positive sequence.  kind: "plain" (the draws as they are), "bulk"
+  (rank-normalised) or "tail" (min over the 5 % / 95 % indicators) -- Vehtari et al. 2021.
+  NaN for degenerate input.  (SURVEY.md 8(f) N3 -- absent upstream.)"""
+  fn = {"plain": _diagnostics.ess_plain, "bulk": _diagnostics.ess_bulk,
+        "tail": _diagnostics.ess_tail}[kind]
+  return fn(draws)
 
 
 def _train_causalimpact_sts(*,
@@ -356,11 +326,9 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
       seasonal_levels=pool(out["seasonal_levels"]))
   assert samples["weights"].shape[-1] == P and samples["seasonal_levels"].shape[-1] == K
   if num_chains > 1:
-    samples["diagnostics"] = {
-        "split_rhat": {k: split_rhat(out[k]) for k in ("observation_noise_scale", "level_scale")},
-        "ess_bulk": {k: effective_sample_size(out[k])
-                     for k in ("observation_noise_scale", "level_scale")},
-        "num_chains": num_chains}
+    samples["diagnostics"] = _diagnostics.summarize(
+        {k: out[k] for k in ("observation_noise_scale", "level_scale")})
+    samples["diagnostics"]["num_chains"] = num_chains
   posterior_means = out["posterior_means"].mean(axis=0).astype(np_dtype, copy=False)      # :627
   posterior_trajectories = (pool(out["posterior_trajectories"])                           # :631
                             if "posterior_trajectories" in out else None)

@@ -66,11 +66,21 @@ typedef struct ci_problem {
   uint32_t seed[2];             /* sanitized seed pair (int s -> (0,s)) :535-543 */
   int32_t device;               /* HIP device ordinal */
   int32_t flags;                /* CI_FLAG_* (0 = let the library choose the kernel) */
+  int32_t series_offset;        /* global id of this call's first series: series b draws from the
+                                   random streams of series id series_offset + b, so a batch split
+                                   over devices gives the same draws as one launch, and the
+                                   Monte-Carlo errors of different series are independent.  Series
+                                   id 0 (any single-series fit) uses the plain chain streams. */
+  int32_t reserved;             /* 0 */
 } ci_problem;
 
 /* Seasonal models: use the one-wavefront-per-chain sequential kernel even where the
  * time-parallel kernel (one seasonal block, state dim <= 8) applies.  Test/diagnostic knob. */
 #define CI_FLAG_SEQUENTIAL_SEASONAL 1
+/* Batches: every series consumes the random streams of series 0 (series b of the batch then
+ * reproduces a single-series fit of series b draw for draw; Monte-Carlo errors are perfectly
+ * correlated across the batch).  Off by default. */
+#define CI_FLAG_SHARED_SERIES_STREAMS 2
 
 /* Caller-allocated result buffers (float32, chain-major so per-device shards
  * are contiguous).  == GibbsSamplerState stack + (means, trajectories) returned

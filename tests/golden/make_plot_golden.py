@@ -1,4 +1,4 @@
-"""Generates tests/golden/plot_golden.json from the REAL reference (build container only; needs
+"""Generates tests/golden/plot/plot_golden.json from the REAL reference (build container only; needs
 /root/reference).  TensorFlow / TFP / altair / absl are absent, so the reference's modules are
 imported under import-only stubs (as make_golden.py does).  Only DATA is written:
 
@@ -74,9 +74,9 @@ def main():
     out["cases"][name] = {
         "series": _frame(series), "plot_df": _frame(plot_df.reset_index(drop=True)),
         "classic": getattr(ref_test, f"expected_classic_dict_{name}")}
-  with open(os.path.join(HERE, "plot_golden.json"), "w") as f:
+  with open(os.path.join(HERE, "plot", "plot_golden.json"), "w") as f:
     json.dump(out, f)
-  print("wrote plot_golden.json:", list(out["cases"]))
+  print("wrote plot/plot_golden.json:", list(out["cases"]))
 
 
 if __name__ == "__main__":

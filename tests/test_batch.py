@@ -70,7 +70,7 @@ def test_batch_fit_equals_separate_fits(p, dates):
   pre, post = (idx[0], idx[69]), (idx[72], idx[95])
   opts = ci.InferenceOptions(num_results=150, num_chains=2)
   got = ci.fit_causalimpact_batch(frames, pre, post, alpha=0.1, seed=5, inference_options=opts,
-                                  names=[f"geo{b}" for b in range(B)])
+                                  names=[f"geo{b}" for b in range(B)], shared_streams=True)
   assert len(got) == B and got.summary.shape == (2 * B, 15)
   for b, f in enumerate(frames):
     one = ci.fit_causalimpact(f, pre, post, alpha=0.1, seed=5, inference_options=opts)
@@ -82,7 +82,22 @@ def test_batch_fit_equals_separate_fits(p, dates):
     np.testing.assert_allclose(mine.series[num].to_numpy(float), one.series[num].to_numpy(float),
                                rtol=2e-5, atol=1e-6, equal_nan=True)
     assert ci.summary(mine) == ci.summary(one)
-  assert set(got.diagnostics) == {"split_rhat", "ess_bulk"}
+  assert set(got.diagnostics) == {"split_rhat", "ess_bulk", "ess_tail"}
+  # default: per-series streams.  Series 0 still equals its single fit; the others are the same
+  # posterior seen through different random numbers; identical series no longer give identical
+  # draws; and the result does not depend on how the batch is split over launches.
+  ind = ci.fit_causalimpact_batch(frames, pre, post, alpha=0.1, seed=5, inference_options=opts,
+                                  names=[f"geo{b}" for b in range(B)])
+  np.testing.assert_allclose(ind.summary.loc["geo0"].to_numpy(float),
+                             got.summary.loc["geo0"].to_numpy(float), rtol=2e-5, atol=1e-7)
+  a = ind.summary.loc["geo3"].to_numpy(float)
+  b_ = got.summary.loc["geo3"].to_numpy(float)
+  assert not np.allclose(a, b_, rtol=1e-6)
+  np.testing.assert_allclose(a[0, :2], b_[0, :2], rtol=0.05)        # actual, predicted
+  twins = ci.fit_causalimpact_batch([frames[1], frames[1]], pre, post, alpha=0.1, seed=5,
+                                    inference_options=opts)
+  assert not np.allclose(twins.summary.loc[0].to_numpy(float), twins.summary.loc[1].to_numpy(float),
+                         rtol=1e-6)
 
 
 @pytest.mark.gpu
@@ -106,7 +121,7 @@ def test_batch_with_a_weekly_seasonal_block_equals_separate_fits():
   pre, post = (idx[0], idx[97]), (idx[98], idx[-1])
   kw = dict(seed=8, inference_options=ci.InferenceOptions(num_results=120),
             model_options=ci.ModelOptions(seasons=[ci.Seasons(num_seasons=7)]))
-  got = ci.fit_causalimpact_batch(frames, pre, post, **kw)
+  got = ci.fit_causalimpact_batch(frames, pre, post, shared_streams=True, **kw)
   for b, f in enumerate(frames):
     one = ci.fit_causalimpact(f, pre, post, **kw)
     np.testing.assert_allclose(got.summary.loc[b].to_numpy(float), one.summary.to_numpy(float),

@@ -216,7 +216,10 @@ def test_baseline_cfg4_shape_matches_oracle_per_draw():
 
 def test_batch_of_series_equals_single_series_runs():
   """BASELINE cfg5 shape in miniature: B independent series in one launch (one workgroup per
-  (series, chain)) give exactly what B separate launches give."""
+  (series, chain)) give exactly what B separate launches give.  Random streams are keyed by
+  (global series id, chain): a single-series launch with series_offset = b reproduces series b
+  of the batch, i.e. the result does not depend on how a batch is split over launches / GPUs;
+  CI_FLAG_SHARED_SERIES_STREAMS keys them by chain only (series b == a plain single fit)."""
   T, p, B, C = 120, 3, 5, 2
   ys, masks, Xs, specs = [], [], [], []
   for b in range(B):
@@ -230,13 +233,27 @@ def test_batch_of_series_equals_single_series_runs():
                             _native.make_params(specs))
   for b in range(B):
     pb1 = _native.make_problem(T=T, P=P, has_slope=0, num_warmup=4, num_results=6, num_chains=C,
-                               num_series=1, seed=(8, 8))
+                               num_series=1, seed=(8, 8), series_offset=b)
     one = _native.fit_gibbs(pb1, ys[b][None], masks[b][None], Xs[b][None], None,
                             _native.make_params([specs[b]]))
     for k in ("level", "weights", "observation_noise_scale", "posterior_trajectories",
               "posterior_means"):
       np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
   assert not np.array_equal(batch["level"][0], batch["level"][1])
+  # identical series: different draws by default, identical draws with shared streams
+  twin = dict(y=np.stack([ys[1], ys[1]]), m=np.stack([masks[1], masks[1]]), X=np.stack([Xs[1], Xs[1]]))
+  for flags, same in ((0, False), (_native.FLAG_SHARED_SERIES_STREAMS, True)):
+    pb2 = _native.make_problem(T=T, P=P, has_slope=0, num_warmup=4, num_results=6, num_chains=C,
+                               num_series=2, seed=(8, 8), flags=flags)
+    tw = _native.fit_gibbs(pb2, twin["y"], twin["m"], twin["X"], None,
+                           _native.make_params([specs[1], specs[1]]))
+    assert np.array_equal(tw["level"][0], tw["level"][1]) == same
+  # shared streams: series 1 of that launch is the plain single-series fit of the same data
+  pb3 = _native.make_problem(T=T, P=P, has_slope=0, num_warmup=4, num_results=6, num_chains=C,
+                             seed=(8, 8))
+  plain = _native.fit_gibbs(pb3, ys[1][None], masks[1][None], Xs[1][None], None,
+                            _native.make_params([specs[1]]))
+  np.testing.assert_array_equal(tw["level"][1], plain["level"][0])
 
 
 def test_baseline_cfg5_full_size_batch_equals_single_series_runs_and_oracle():
@@ -256,13 +273,16 @@ def test_baseline_cfg5_full_size_batch_equals_single_series_runs_and_oracle():
                             want=("level", "weights", "observation_noise_scale"))
   assert np.isfinite(batch["level"]).all()
   for b in (0, 255, 511):
-    pb1 = _native.make_problem(T=T, P=6, has_slope=0, num_warmup=W, num_results=S, seed=(5, 12))
+    pb1 = _native.make_problem(T=T, P=6, has_slope=0, num_warmup=W, num_results=S, seed=(5, 12),
+                               series_offset=b)
     one = _native.fit_gibbs(pb1, ys[b][None], masks[b][None], Xs[b][None], None,
                             _native.make_params([specs[b]]),
                             want=("level", "weights", "observation_noise_scale"))
     for k in ("level", "weights", "observation_noise_scale"):
       np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
-    w = orc.fit_gibbs(ys[b], masks[b], Xs[b], specs[b], num_results=S, num_warmup=W, seed=(5, 12))
+    # the oracle's stream word: chain id + (series id << 16)
+    w = orc.fit_gibbs(ys[b], masks[b], Xs[b], specs[b], num_results=S, num_warmup=W, seed=(5, 12),
+                      chain=b << 16)
     np.testing.assert_allclose(batch["level"][b, 0], w["level"], atol=5e-3)
     np.testing.assert_allclose(batch["weights"][b, 0], w["weights"], atol=5e-3)
 

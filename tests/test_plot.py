@@ -16,7 +16,7 @@ import causalimpact as ci
 plot_lib = importlib.import_module("causalimpact.plot")   # `ci.plot` is the function, as upstream
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLD = json.load(open(os.path.join(HERE, "golden", "plot_golden.json")))
+GOLD = json.load(open(os.path.join(HERE, "golden", "plot", "plot_golden.json")))
 
 
 def _frame(fx):

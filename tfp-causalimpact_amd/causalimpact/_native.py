@@ -35,7 +35,8 @@ class Problem(C.Structure):
       ("num_blocks", C.c_int32), ("num_seasons", C.c_int32 * MAX_BLOCKS),
       ("num_warmup", C.c_int32), ("num_results", C.c_int32), ("num_chains", C.c_int32),
       ("chain_offset", C.c_int32), ("num_series", C.c_int32), ("seed", C.c_uint32 * 2),
-      ("device", C.c_int32), ("flags", C.c_int32)]
+      ("device", C.c_int32), ("flags", C.c_int32), ("series_offset", C.c_int32),
+      ("reserved", C.c_int32)]
 
 
 _OUT_FIELDS = ("observation_noise_scale", "level_scale", "slope_scale", "seasonal_drift_scales",
@@ -168,10 +169,12 @@ def make_params(specs: Sequence[Dict]) -> "C.Array":
 
 
 FLAG_SEQUENTIAL_SEASONAL = 1   # == CI_FLAG_SEQUENTIAL_SEASONAL
+FLAG_SHARED_SERIES_STREAMS = 2  # == CI_FLAG_SHARED_SERIES_STREAMS
 
 
 def make_problem(*, T, P, has_slope, num_seasons=(), num_warmup, num_results, num_chains=1,
-                 chain_offset=0, num_series=1, seed=(0, 0), device=0, flags=0) -> Problem:
+                 chain_offset=0, num_series=1, seed=(0, 0), device=0, flags=0,
+                 series_offset=0) -> Problem:
   pb = Problem()
   pb.abi_version = ABI_VERSION
   pb.T, pb.P, pb.has_slope = int(T), int(P), int(bool(has_slope))
@@ -184,6 +187,7 @@ def make_problem(*, T, P, has_slope, num_seasons=(), num_warmup, num_results, nu
   pb.seed[0], pb.seed[1] = s
   pb.device = int(device)
   pb.flags = int(flags)
+  pb.series_offset = int(series_offset)
   return pb
 
 

@@ -11,8 +11,9 @@ index and the pre/post periods (the same calendar for many geos / products):
     (csrc/ci_summary.h); only order statistics and per-draw totals come back;
   * the (B*2) x 15 summary table is assembled with numpy; a per-series `CausalImpactAnalysis`
     (14-column `series` frame) is built lazily on indexing.
-Series b of a batch equals `fit_causalimpact` on series b alone with the same seed (same random
-streams: they are keyed by chain, not by series).
+Random streams are keyed by (series position in the batch, chain): Monte-Carlo errors are
+independent across series; `shared_streams=True` keys them by chain only, which makes series b
+of a batch equal `fit_causalimpact` on series b alone with the same seed, draw for draw.
 """
 from __future__ import annotations
 
@@ -203,13 +204,21 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
                            model_options: Optional[lib.ModelOptions] = None,
                            inference_options: Optional[lib.InferenceOptions] = None,
                            index: Optional[pd.Index] = None,
-                           names: Optional[Sequence[Any]] = None) -> CausalImpactBatchAnalysis:
+                           names: Optional[Sequence[Any]] = None,
+                           shared_streams: bool = False) -> CausalImpactBatchAnalysis:
   """`fit_causalimpact` for B series at once.
 
   data: a sequence of DataFrames with identical index and column layout (outcome first, or
   `DataOptions.outcome_column`), or an array [B, T, 1 + covariates] (outcome first) with
   `index` (default: 0..T-1).  Other arguments as `fit_causalimpact`.  Latent-state draws are not
   downloaded (B x chains x draws x T values); the per-series frames and the summary table are.
+
+  Random streams: series b draws from streams keyed by (its position b in the batch, chain), so
+  the Monte-Carlo errors of different series are independent (pooling effects over geos averages
+  them out) and the result does not depend on how the batch is split over devices.  Series 0 of
+  a batch equals `fit_causalimpact` on that series alone with the same seed.
+  `shared_streams=True` keys the streams by chain only: EVERY series then reproduces its
+  single-series fit draw for draw, at the price of perfectly correlated Monte-Carlo errors.
   """
   data_options = data_options or lib.DataOptions()
   model_options = model_options or lib.ModelOptions()
@@ -265,7 +274,8 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
     pb = _native.make_problem(T=T, P=P, has_slope=model_options.local_linear_trend,
                               num_seasons=num_seasons, num_warmup=inference_options.num_warmup_steps,
                               num_results=S, num_chains=C, num_series=len(ids), seed=seed_pair,
-                              device=dev)
+                              device=dev, series_offset=int(ids[0]),
+                              flags=_native.FLAG_SHARED_SERIES_STREAMS if shared_streams else 0)
     sess = _native.Session(pb, y_model[ids], prep.mask[ids],
                            None if prep.design is None else prep.design[ids], season_change,
                            _native.make_params([params[b] for b in ids]))

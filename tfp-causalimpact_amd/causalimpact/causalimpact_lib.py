@@ -246,6 +246,19 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
     raise NotImplementedError("custom tfp.sts models are not supported by the HIP path")
   seed_pair = _sanitize_seed(seed)
   np_dtype = cid._as_numpy_dtype(dtype)  # pylint: disable=protected-access
+  if np_dtype == np.float64:
+    # The reference runs its whole sampler in the requested dtype (:159,
+    # causalimpact_lib_test.py:655-662).  The device kernels compute in float32 (float64 only in
+    # the regression block), so say so instead of silently downgrading; with standardised data
+    # every quantity the kernel touches is O(1) and the float32 path is accurate to ~1e-6.
+    import warnings  # pylint: disable=import-outside-toplevel
+    warnings.warn(
+        "DataOptions.dtype=float64: the MI355X kernels compute in float32 (float64 in the "
+        "regression block only); the returned arrays are float64."
+        + ("" if getattr(ci_data, "standardize_data", True) else
+           "  standardize_data=False feeds the raw outcome scale to float32 scans: "
+           "large-magnitude series lose precision -- prefer standardize_data=True."),
+        RuntimeWarning, stacklevel=3)
 
   design = None if ci_data.feature_ts is None else np.asarray(ci_data.feature_ts.values,
                                                               dtype=np.float64)    # :545-546

@@ -47,6 +47,9 @@ struct DevSeriesParams {
 
 struct KArgs {
   int T, P, W, S, C, B, chain_offset;
+  int series_stream_base;  // >= 0: series b of the launch draws from the Philox streams of series
+                           // id (series_stream_base + b) -- distinct random numbers per series;
+                           // -1: every series uses the streams of series 0 (CI_FLAG_SHARED_SERIES_STREAMS)
   uint32_t seed0, seed1;
   int x_in_lds;
   const float* y;          // [B,T]   0 where masked
@@ -65,6 +68,14 @@ struct KArgs {
   float* out_traj;         // [B,C,S,T]
   long long* prof;         // optional [16] per-phase cycle counters (block 0, thread 0)
 };
+
+// Counter word 3 of the Philox stream: the global chain id in the low 16 bits' range, the global
+// series id above it.  Series 0 (every single-series fit) keeps the plain chain id, so results of
+// one series do not depend on whether it was fitted alone or as series 0 of a batch.
+__host__ __device__ inline uint32_t stream_id(int chain_global, int series_stream_base, int series) {
+  const uint32_t sid = series_stream_base < 0 ? 0u : (uint32_t)(series_stream_base + series);
+  return (uint32_t)chain_global + (sid << 16);
+}
 
 // ------------------------------------------------------------------------------------
 // wave / block primitives
@@ -1397,7 +1408,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   Rng rng;
   rng.k0 = a.seed0;
   rng.k1 = a.seed1;
-  rng.chain = (uint32_t)(a.chain_offset + chain);
+  rng.chain = stream_id(a.chain_offset + chain, a.series_stream_base, series);
 
   // ---- stage the constants of this series
   const float* yg = a.y + (size_t)series * T;

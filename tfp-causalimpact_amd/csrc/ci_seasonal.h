@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
 
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
-  Rng rng{g.seed0, g.seed1, (uint32_t)(g.chain_offset + chain)};
+  Rng rng{g.seed0, g.seed1, stream_id(g.chain_offset + chain, g.series_stream_base, series)};
   const float* Xg = g.Xt + (size_t)series * P * T;
   const float* chol1 = a.p1_chol + (size_t)series * a.dred * a.dred;
 

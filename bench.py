@@ -140,6 +140,16 @@ class _GibbsFit:
     res = self.sess.fetch()
     return {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
 
+  def run_and_fetch(self):
+    """One fit with every result array delivered to (pinned) host memory: the copies are queued
+    chunk by chunk while the kernel is still sampling (ci_session_run_streamed)."""
+    if not hasattr(self, "_into"):
+      self.sess.run_streamed()                      # allocates the pinned result buffers once
+      self._into = self.sess._last_streamed         # pylint: disable=protected-access
+    self.sess.run_streamed(into=self._into)
+    res = self._into[1]
+    return {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
+
   def note(self, C):
     return ("one persistent workgroup per chain: %d of 256 CUs busy; the fit is bound by the "
             "(W+S)-long sequential Gibbs dependency, not by HBM (DESIGN.md)" % C)
@@ -166,6 +176,10 @@ class _HmcFit:
   def fetch(self):
     _, _, _, res = self.sess.hmc_fetch()
     return {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
+
+  def run_and_fetch(self):
+    self.run()
+    return self.fetch()
 
   def note(self, C):
     return ("one persistent workgroup per chain (%d of 256 CUs) runs (W+S) x leapfrog dependent "
@@ -227,10 +241,12 @@ def main():
     dt = float(tt.item())
 
   # ---- after the timed region: PCIe-inclusive rate, chain gather + diagnostics (RCCL)
+  fit.run_and_fetch()                 # (first call sets up the pinned result buffers)
   t1 = time.perf_counter()
-  fit.run()
-  local = fit.fetch()
-  dt_pcie = time.perf_counter() - t1
+  n_pcie = 3
+  for _ in range(n_pcie):
+    local = fit.run_and_fetch()
+  dt_pcie = (time.perf_counter() - t1) / n_pcie
   # chain gather + split-R-hat across ranks (RCCL all-gather / all-reduce; no-op at N=1)
   from causalimpact import _distributed  # pylint: disable=import-outside-toplevel
   comb = _distributed.fit_sharded(lambda first, count: local, world * C,

@@ -21,6 +21,7 @@
 #ifndef CAUSALIMPACT_AMD_H_
 #define CAUSALIMPACT_AMD_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -106,6 +107,10 @@ int ci_device_count(int* count);
 /* Device buffers of finished sessions are parked in a per-process pool (<= 2 GiB) for reuse by
  * the next fit; this returns them to the driver. */
 int ci_pool_trim(void);
+/* Pinned (page-locked) host memory for result buffers; recycled through a pool like the device
+ * buffers.  ci_host_free accepts only pointers returned by ci_host_alloc. */
+int ci_host_alloc(void** ptr, size_t bytes);
+int ci_host_free(void* ptr);
 
 /* One-shot: upload, run all W+S Gibbs iterations for B*C chains, download.
  *   y     [B,T]    float32 outcome (standardised); value ignored where mask != 0
@@ -126,6 +131,15 @@ int ci_session_create(const ci_problem* problem, const float* y, const uint8_t* 
  * receives the Gibbs kernel's duration measured with HIP events on that stream. */
 int ci_session_run(ci_session* session, float* kernel_ms);
 int ci_session_fetch(ci_session* session, ci_outputs* outputs);
+/* ci_session_run + ci_session_fetch with the copies OVERLAPPED with the fit: the persistent
+ * kernel publishes, every chunk_draws retained draws, how many rows of each chain are complete;
+ * the host then queues the device-to-host copies of those rows ([chains, chunk, T] blocks of
+ * level / slope / trajectories) on a second stream while sampling continues, and only the last
+ * chunk and the small arrays remain after the kernel ends.  Give it buffers from ci_host_alloc
+ * (pinned): the copies then run at PCIe rate; pageable buffers work but copy synchronously.
+ * Models on the seasonal kernels are copied in the same chunks after the kernel has finished. */
+int ci_session_run_streamed(ci_session* session, ci_outputs* outputs, int32_t chunk_draws,
+                            float* kernel_ms);
 /* Bytes the kernel must move per run (algorithmic bytes, DESIGN.md "Roofline"). */
 int ci_session_algorithmic_bytes(const ci_session* session, double* bytes);
 /* Name of the Gibbs kernel instantiation this session dispatches to, as a profiler shows it

@@ -93,7 +93,9 @@ def test_batch_fit_equals_separate_fits(p, dates):
   a = ind.summary.loc["geo3"].to_numpy(float)
   b_ = got.summary.loc["geo3"].to_numpy(float)
   assert not np.allclose(a, b_, rtol=1e-6)
-  np.testing.assert_allclose(a[0, :2], b_[0, :2], rtol=0.05)        # actual, predicted
+  assert a[0, 0] == b_[0, 0]                                          # actual
+  sd = float(got.summary.loc["geo3"]["predicted_sd"]["average"])
+  assert abs(a[0, 1] - b_[0, 1]) < 3.0 * sd                           # predicted: same posterior
   twins = ci.fit_causalimpact_batch([frames[1], frames[1]], pre, post, alpha=0.1, seed=5,
                                     inference_options=opts)
   assert not np.allclose(twins.summary.loc[0].to_numpy(float), twins.summary.loc[1].to_numpy(float),

@@ -88,3 +88,67 @@ def test_chain_blocks_partition_exactly():
       ids = [c for f, k in blocks for c in range(f, f + k)]
       assert ids == list(range(n))
       assert max(k for _, k in blocks) - min(k for _, k in blocks) <= 1
+
+
+def _gpu_worker(rank, world, port, num_chains, q):
+  """One rank of the real thing: its share of the chains runs on GPU 0 through the C-ABI
+  (`chain_offset` = first chain id), then the collectives of `fit_sharded` pool the results."""
+  sys.path[:0] = [ROOT, os.path.join(ROOT, "tfp-causalimpact_amd")]
+  import torch.distributed as dist
+  from causalimpact import _distributed as d, _model, _native
+  from causalimpact import _synthetic as syn
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  y, mask, X, _ = syn.make_sampler_inputs(300, 3, 5)
+  spec = _model.series_params(y, mask, X, has_slope=True)
+
+  def local_fit(first, count):
+    pb = _native.make_problem(T=300, P=4, has_slope=1, num_warmup=20, num_results=60,
+                              num_chains=count, chain_offset=first, seed=(4, 4), device=0)
+    out = _native.fit_gibbs(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+    return {k: v[0] for k, v in out.items()}
+
+  res = d.fit_sharded(local_fit, num_chains)
+  q.put((rank, res["posterior_trajectories"], res["posterior_means"],
+         {k: res[k] for k in ("split_rhat", "ess_bulk", "ess_tail")}))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_real_gpu_shares_equal_one_launch():
+  """The collective path on hardware: two processes, each running its block of chains on the
+  GPU through `_native.fit_gibbs`, pooled by `fit_sharded` (gloo here: two ranks cannot share
+  one device under RCCL; bench.py's N > 1 path uses backend "nccl", and its single-rank RCCL run
+  is logged in profiles/r02_bench_force_dist_rccl_1rank.*).  The pooled draws must be bit-equal
+  to ONE launch of all chains."""
+  import torch.multiprocessing as mp
+  sys.path[:0] = [os.path.join(ROOT, "tfp-causalimpact_amd")]
+  from causalimpact import _distributed as d, _model, _native
+  from causalimpact import _synthetic as syn
+  num_chains = 5
+  y, mask, X, _ = syn.make_sampler_inputs(300, 3, 5)
+  spec = _model.series_params(y, mask, X, has_slope=True)
+  pb = _native.make_problem(T=300, P=4, has_slope=1, num_warmup=20, num_results=60,
+                            num_chains=num_chains, seed=(4, 4), device=0)
+  one = {k: v[0] for k, v in _native.fit_gibbs(pb, y[None], mask[None], X[None], None,
+                                               _native.make_params([spec])).items()}
+  single = d.fit_sharded(lambda first, count: one, num_chains)
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, num_chains, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  got = [q.get(timeout=300) for _ in procs]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  for _, traj, means, diag in got:
+    np.testing.assert_array_equal(traj, one["posterior_trajectories"])
+    np.testing.assert_array_equal(means, one["posterior_means"])
+    for name in ("split_rhat", "ess_bulk", "ess_tail"):
+      for k, v in single[name].items():
+        np.testing.assert_allclose(diag[name][k], v, rtol=1e-9, err_msg=f"{name}.{k}")

@@ -303,3 +303,47 @@ def test_fit_causalimpact_over_several_device_shares_equals_one_launch():
   np.testing.assert_array_equal(one.posterior_samples.level, two.posterior_samples.level)
   np.testing.assert_array_equal(one.posterior_samples.weights, two.posterior_samples.weights)
   np.testing.assert_allclose(one.summary.to_numpy(float), two.summary.to_numpy(float), rtol=1e-12)
+
+
+@pytest.mark.parametrize("pinned,chunk", [(True, 7), (True, 1000), (False, 50)])
+def test_streamed_fetch_equals_run_then_fetch(pinned, chunk):
+  """ci_session_run_streamed: results are copied to the host in chunks WHILE the persistent kernel
+  is still sampling (the workgroup publishes its progress after a system-scope release).  Every
+  byte must equal what run() + fetch() return, for pinned and pageable destinations, chunk sizes
+  that do and do not divide S, several series and chains (uneven progress between workgroups)."""
+  T, p, B, C, W, S = 1000, 10, 3, 5, 20, 333
+  ys, masks, Xs, specs = [], [], [], []
+  for b in range(B):
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 40 + b)
+    ys.append(y); masks.append(mask); Xs.append(X)
+    specs.append(orc.default_spec(y, mask, X, has_slope=True))
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=1, num_warmup=W, num_results=S, num_chains=C,
+                            num_series=B, seed=(2, 9))
+  sess = _native.Session(pb, np.stack(ys), np.stack(masks), np.stack(Xs), None,
+                         _native.make_params(specs))
+  sess.run()
+  want = sess.fetch()
+  for _ in range(2):                      # the second call re-uses recycled pinned buffers
+    ms, got = sess.run_streamed(chunk_draws=chunk, pinned=pinned)
+    assert ms > 0
+    for k, v in want.items():
+      np.testing.assert_array_equal(got[k], v, err_msg=k)
+  sess.close()
+
+
+def test_streamed_fetch_of_a_seasonal_model_equals_run_then_fetch():
+  """Models on the seasonal kernels do not publish progress: same chunked copies after the
+  kernel has finished, same bytes."""
+  T, p, S = 700, 3, 40
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 3)
+  spec = orc.default_spec(y, mask, X, seasons=((7, 1),))
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_seasons=(7,), num_warmup=5,
+                            num_results=S, num_chains=2, seed=(2, 9))
+  sess = _native.Session(pb, y[None], mask[None], X[None], np.stack(spec["season_change"]),
+                         _native.make_params([spec]))
+  sess.run()
+  want = sess.fetch()
+  _, got = sess.run_streamed(chunk_draws=16)
+  for k, v in want.items():
+    np.testing.assert_array_equal(got[k], v, err_msg=k)
+  sess.close()

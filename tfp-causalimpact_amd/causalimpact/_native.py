@@ -108,6 +108,10 @@ def load():
                                         C.POINTER(Outputs)]
   L.ci_ll_session_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
   L.ci_pool_trim.argtypes = []
+  L.ci_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+  L.ci_host_free.argtypes = [C.c_void_p]
+  L.ci_session_run_streamed.argtypes = [C.c_void_p, C.POINTER(Outputs), C.c_int32,
+                                        C.POINTER(C.c_float)]
   L.ci_session_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
   L.ci_ll_session_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
   L.ci_test_rng.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
@@ -123,8 +127,9 @@ def load():
 
 def exported_symbols() -> Sequence[str]:
   """Every entry point include/causalimpact_amd.h declares."""
-  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_pool_trim", "ci_fit_gibbs",
-          "ci_session_create", "ci_session_run", "ci_session_fetch",
+  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_pool_trim", "ci_host_alloc",
+          "ci_host_free", "ci_fit_gibbs",
+          "ci_session_create", "ci_session_run", "ci_session_run_streamed", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_kernel_name", "ci_session_destroy",
           "ci_session_profile", "ci_ll_session_kernel_name",
           "ci_session_summarize", "ci_summarize_draws",
@@ -221,7 +226,36 @@ def summarize_draws(trajectories, scale, shift, observed, flags, ranks, device=0
   return dict(value_order=vo, cum_order=co, per_draw=pd_)
 
 
-def _alloc_outputs(pb: Problem, want: Optional[Sequence[str]] = None):
+class _PinnedBlock:
+  """Owner of one ci_host_alloc buffer: returned to the library's pool when the last numpy view
+  of it is collected."""
+
+  def __init__(self, nbytes: int):
+    self.ptr = C.c_void_p()
+    _check(load().ci_host_alloc(C.byref(self.ptr), max(int(nbytes), 1)))
+    self.nbytes = int(nbytes)
+
+  def __del__(self):
+    try:
+      if self.ptr:
+        load().ci_host_free(self.ptr)
+        self.ptr = C.c_void_p()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+  """An uninitialised numpy array in pinned host memory (ci_host_alloc): device-to-host copies
+  into it run at PCIe rate and overlap the fit (`Session.run_streamed`)."""
+  dtype = np.dtype(dtype)
+  n = int(np.prod(shape, dtype=np.int64))
+  block = _PinnedBlock(n * dtype.itemsize)
+  buf = (C.c_char * max(n * dtype.itemsize, 1)).from_address(block.ptr.value)
+  buf._pinned_owner = block   # keeps the allocation alive as long as any view of `buf`
+  return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def _alloc_outputs(pb: Problem, want: Optional[Sequence[str]] = None, pinned: bool = False):
   B, C_, S, T, P, K = pb.num_series, pb.num_chains, pb.num_results, pb.T, pb.P, pb.num_blocks
   shapes = dict(
       observation_noise_scale=(B, C_, S), level_scale=(B, C_, S), slope_scale=(B, C_, S),
@@ -232,7 +266,7 @@ def _alloc_outputs(pb: Problem, want: Optional[Sequence[str]] = None):
   for name, shp in shapes.items():
     if want is not None and name not in want:
       continue
-    a = np.zeros(shp, dtype=np.float32)
+    a = pinned_empty(shp) if (pinned and int(np.prod(shp)) > 0) else np.zeros(shp, dtype=np.float32)
     arrs[name] = a
     setattr(out, name, a.ctypes.data if a.size else None)
   return out, arrs
@@ -273,6 +307,16 @@ class Session:
     out, arrs = _alloc_outputs(self.pb, want)
     _check(self._lib.ci_session_fetch(self._h, C.byref(out)))
     return arrs
+
+  def run_streamed(self, want=None, chunk_draws: int = 125, pinned: bool = True, into=None):
+    """Runs the fit and copies the results to the host WHILE it runs (ci_session_run_streamed).
+    Returns (kernel_ms, arrays); the arrays live in pinned memory unless pinned=False.  `into`
+    re-uses the (Outputs, arrays) pair of an earlier call instead of allocating."""
+    out, arrs = into if into is not None else _alloc_outputs(self.pb, want, pinned=pinned)
+    ms = C.c_float(0)
+    _check(self._lib.ci_session_run_streamed(self._h, C.byref(out), int(chunk_draws), C.byref(ms)))
+    self._last_streamed = (out, arrs)
+    return float(ms.value), arrs
 
   def algorithmic_bytes(self) -> float:
     b = C.c_double(0)

@@ -40,8 +40,9 @@ CI_WIDE_DECL(2) CI_WIDE_DECL(3) CI_WIDE_DECL(4) CI_WIDE_DECL(5) CI_WIDE_DECL(6) 
                                                double*, double*, hipStream_t);                    \
   extern "C" void ci_launch_latents_d##D##_l##L(int, int, int, const float*, const uint8_t*,      \
                                                 const float*, const double*, float, float, float, \
-                                                uint32_t, uint32_t, uint32_t, uint32_t, int,      \
-                                                float*, float*, float*, float*, hipStream_t);     \
+                                                uint32_t, uint32_t, uint32_t, uint32_t, int, int, \
+                                                float*, float*, float*, float*, float*,           \
+                                                hipStream_t);                                     \
   extern "C" void ci_launch_hmc_d##D##_l##L(const ci::HmcArgs*, hipStream_t);
 CI_DECL(1, 1) CI_DECL(1, 2) CI_DECL(1, 4) CI_DECL(1, 8) CI_DECL(1, 16)
 CI_DECL(2, 1) CI_DECL(2, 2) CI_DECL(2, 4) CI_DECL(2, 8) CI_DECL(2, 16)
@@ -104,15 +105,18 @@ static __global__ void test_rng_kernel(uint32_t k0, uint32_t k1, uint32_t chain,
   }
 }
 
-// Per-chain mean over the S retained draws of the noise-free predictor (causalimpact_lib.py:627):
-// loc [C, S, T] -> pm [C, T].  One thread per (chain, t), coalesced over t.
-static __global__ void hmc_mean_kernel(int C, int S, int T, const float* __restrict__ loc,
+// Per-chain mean over the S retained draws of the noise-free predictor (causalimpact_lib.py:627)
+// from the per-group sums the latents pass leaves: part [C, NG, T] -> pm [C, T].  One thread per
+// (chain, t), coalesced over t; the order of the sums is fixed, so chain c's mean does not depend
+// on how chains are split over launches.
+static __global__ void hmc_mean_kernel(int C, int NG, int S, int T, const float* __restrict__ part,
                                        float* __restrict__ pm) {
+  // part [C, NG, T]: sums of the predictor over groups of consecutive draws (latents_kernel)
   const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
   if (t >= T || c >= C) return;
-  const float* p = loc + (size_t)c * S * T + t;
+  const float* p = part + (size_t)c * NG * T + t;
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += p[(size_t)s * T];
+  for (int g = 0; g < NG; ++g) acc += p[(size_t)g * T];
   pm[(size_t)c * T + t] = acc / (float)S;
 }
 
@@ -214,6 +218,14 @@ void pool_free(void* p, size_t bytes, int dev) {
   (void)hipFree(p);
 }
 
+// Pinned host buffers (ci_host_alloc) are recycled the same way: pinning 100 MB costs tens of
+// milliseconds, several fits' worth.
+struct HostEntry { void* p; size_t bytes; };
+std::mutex g_host_mu;
+std::vector<HostEntry> g_host_pool;       // parked (free) buffers
+std::vector<HostEntry> g_host_live;       // handed out
+size_t g_host_pool_bytes = 0;
+
 template <class T> struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
@@ -288,6 +300,10 @@ struct ci_session {
   ci_problem kpb;          // what the kernel runs (== pb except for long trend-only series)
   bool inert_block = false;
   std::string kernel_name; // the Gibbs kernel this session dispatches to (as rocprofv3 names it)
+  // streamed fetch (ci_session_run_streamed)
+  hipStream_t copy_stream = nullptr;
+  unsigned int* progress = nullptr;   // host-coherent pinned [B * C]
+  int progress_every = 0;             // != 0 only while a streamed run is in flight
 };
 
 extern "C" {
@@ -302,7 +318,58 @@ int ci_device_count(int* count) {
   return 0;
 }
 
+int ci_host_alloc(void** ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return fail("ci_host_alloc: NULL pointer or zero size");
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (size_t i = 0; i < g_host_pool.size(); ++i)
+      if (g_host_pool[i].bytes == bytes) {
+        *ptr = g_host_pool[i].p;
+        g_host_live.push_back(g_host_pool[i]);
+        g_host_pool_bytes -= bytes;
+        g_host_pool[i] = g_host_pool.back();
+        g_host_pool.pop_back();
+        return 0;
+      }
+  }
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  g_host_live.push_back({p, bytes});
+  *ptr = p;
+  return 0;
+}
+
+int ci_host_free(void* ptr) {
+  if (!ptr) return 0;
+  HostEntry e{nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (size_t i = 0; i < g_host_live.size(); ++i)
+      if (g_host_live[i].p == ptr) {
+        e = g_host_live[i];
+        g_host_live[i] = g_host_live.back();
+        g_host_live.pop_back();
+        break;
+      }
+    if (!e.p) return fail("ci_host_free: pointer was not allocated by ci_host_alloc");
+    if (g_host_pool_bytes + e.bytes <= POOL_CAP && g_host_pool.size() < 64) {
+      g_host_pool.push_back(e);
+      g_host_pool_bytes += e.bytes;
+      return 0;
+    }
+  }
+  HIP_TRY(hipHostFree(e.p));
+  return 0;
+}
+
 int ci_pool_trim(void) {
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (auto& he : g_host_pool) (void)hipHostFree(he.p);
+    g_host_pool.clear();
+    g_host_pool_bytes = 0;
+  }
   std::lock_guard<std::mutex> lk(g_pool_mu);
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -543,8 +610,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   return 0;
 }
 
-int ci_session_run(ci_session* s, float* kernel_ms) {
-  if (!s) return fail("session is NULL");
+static int session_launch(ci_session* s) {
   const ci_problem& pb = s->pb;
   HIP_TRY(hipSetDevice(pb.device));
   ci::KArgs a;
@@ -559,6 +625,8 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
   a.out_weights = s->o_w.p; a.out_level = s->o_level.p; a.out_slope = s->o_slope.p;
   a.out_pred_mean = s->o_pm.p; a.out_traj = s->o_traj.p;
   a.prof = nullptr;
+  a.progress = s->progress_every > 0 ? s->progress : nullptr;
+  a.progress_every = s->progress_every > 0 ? s->progress_every : 1;
   if (s->profile) {
     if (!s->prof.p) HIP_TRY(s->prof.alloc(32));
     HIP_TRY(hipMemsetAsync(s->prof.p, 0, 32 * sizeof(long long), s->stream));
@@ -587,9 +655,89 @@ int ci_session_run(ci_session* s, float* kernel_ms) {
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  return 0;
+}
+
+int ci_session_run(ci_session* s, float* kernel_ms) {
+  if (!s) return fail("session is NULL");
+  s->progress_every = 0;
+  if (session_launch(s)) return 1;
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s->ev0, s->ev1));
   s->ran = true;
+  return 0;
+}
+
+// The [B*C, S, T] arrays of a session, paired with the caller's buffers.
+struct BigPair { float* dst; const float* src; size_t row; };
+
+int ci_session_run_streamed(ci_session* s, ci_outputs* o, int32_t chunk_draws, float* kernel_ms) {
+  if (!s || !o) return fail("NULL argument");
+  if (chunk_draws < 1) return fail("chunk_draws must be >= 1, got %d", chunk_draws);
+  const ci_problem& pb = s->pb;
+  HIP_TRY(hipSetDevice(pb.device));
+  const int S = pb.num_results, T = pb.T, K = pb.num_blocks;
+  const size_t BC = (size_t)pb.num_series * pb.num_chains;
+  if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  // the register-resident kernel publishes its progress; the seasonal kernels do not (their
+  // results are copied in the same chunks once the kernel has finished)
+  const bool live = s->kpb.num_blocks == 0;
+  if (live) {
+    if (!s->progress)
+      HIP_TRY(hipHostMalloc((void**)&s->progress, BC * sizeof(unsigned int), hipHostMallocCoherent));
+    for (size_t i = 0; i < BC; ++i) s->progress[i] = 0u;
+    s->progress_every = chunk_draws;
+  } else {
+    s->progress_every = 0;
+  }
+  if (session_launch(s)) { s->progress_every = 0; return 1; }
+  s->progress_every = 0;
+  std::vector<BigPair> big;
+  if (o->level) big.push_back({o->level, s->o_level.p, (size_t)T});
+  if (o->slope && pb.has_slope) big.push_back({o->slope, s->o_slope.p, (size_t)T});
+  if (o->posterior_trajectories) big.push_back({o->posterior_trajectories, s->o_traj.p, (size_t)T});
+  if (o->seasonal_levels && s->o_seasonal.n) big.push_back({o->seasonal_levels, s->o_seasonal.p, (size_t)T * K});
+  int next = 0;
+  while (next < S) {
+    const int target = std::min(S, next + chunk_draws);
+    if (live) {
+      // wait until every chain has published `target` complete draws
+      for (;;) {
+        unsigned int lo = 0xFFFFFFFFu;
+        volatile unsigned int* pr = s->progress;
+        for (size_t i = 0; i < BC; ++i) lo = std::min(lo, (unsigned int)pr[i]);
+        if (lo >= (unsigned int)target) break;
+        const hipError_t q = hipStreamQuery(s->stream);
+        if (q == hipSuccess) break;                 // kernel finished: everything is in HBM
+        if (q != hipErrorNotReady) return fail("Gibbs kernel failed: %s", hipGetErrorString(q));
+        __builtin_ia32_pause();
+      }
+    } else if (next == 0) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    for (const BigPair& b : big) {
+      const size_t pitch = (size_t)S * b.row * sizeof(float);
+      HIP_TRY(hipMemcpy2DAsync(b.dst + (size_t)next * b.row, pitch, b.src + (size_t)next * b.row, pitch,
+                               (size_t)(target - next) * b.row * sizeof(float), BC,
+                               hipMemcpyDeviceToHost, s->copy_stream));
+    }
+    next = target;
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s->ev0, s->ev1));
+  s->ran = true;
+  auto small = [&](float* dst, const DevBuf<float>& src) -> hipError_t {
+    if (!dst || src.n == 0) return hipSuccess;
+    return hipMemcpyAsync(dst, src.p, src.n * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream);
+  };
+  HIP_TRY(small(o->observation_noise_scale, s->o_obs));
+  HIP_TRY(small(o->level_scale, s->o_lscale));
+  HIP_TRY(small(o->slope_scale, s->o_sscale));
+  HIP_TRY(small(o->weights, s->o_w));
+  HIP_TRY(small(o->posterior_means, s->o_pm));
+  HIP_TRY(small(o->seasonal_drift_scales, s->o_drift));
+  HIP_TRY(hipStreamSynchronize(s->copy_stream));
+  if (o->slope && !pb.has_slope) memset(o->slope, 0, s->o_level.n * sizeof(float));
   return 0;
 }
 
@@ -791,6 +939,8 @@ int ci_session_destroy(ci_session* s) {
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+  if (s->progress) (void)hipHostFree(s->progress);
   delete s;
   return 0;
 }
@@ -827,6 +977,9 @@ int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t ite
   return 0;
 }
 
+// draws per workgroup in the HMC fit's latent pass (their predictor sums stay in registers)
+constexpr int HMC_LATENT_GROUP = 8;
+
 struct ci_ll_session {
   int T = 0, P = 0, D = 1, L = 1, device = 0, max_evals = 0;
   float a1 = 0, p10 = 0, p11 = 0;
@@ -836,7 +989,7 @@ struct ci_ll_session {
   size_t draw_cap = 0;
   // on-device HMC (ci_hmc.h): the fit stays resident until ci_ll_session_hmc_fetch
   DevBuf<double> omega, h_draws, h_acc, h_eps, h_init;
-  DevBuf<float> h_level, h_slope, h_loc, h_traj, h_pm, h_obs, h_lscale, h_sscale, h_w;
+  DevBuf<float> h_level, h_slope, h_part, h_traj, h_pm, h_obs, h_lscale, h_sscale, h_w;
   int h_C = 0, h_S = 0;
   bool h_ran = false;
   hipStream_t stream = nullptr;
@@ -926,7 +1079,7 @@ int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const doubl
   const size_t N = (size_t)C * S;
   if (s->h_C != C || s->h_S != S) {
     s->h_draws.release(); s->h_acc.release(); s->h_eps.release();
-    s->h_level.release(); s->h_slope.release(); s->h_loc.release(); s->h_traj.release();
+    s->h_level.release(); s->h_slope.release(); s->h_part.release(); s->h_traj.release();
     s->h_pm.release(); s->h_obs.release(); s->h_lscale.release(); s->h_sscale.release();
     s->h_w.release();
     HIP_TRY(s->h_draws.alloc(N * (3 + P)));
@@ -934,7 +1087,7 @@ int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const doubl
     HIP_TRY(s->h_eps.alloc(C));
     HIP_TRY(s->h_level.alloc(N * T));
     HIP_TRY(s->h_slope.alloc(s->D == 2 ? N * T : 0));
-    HIP_TRY(s->h_loc.alloc(N * T));
+    HIP_TRY(s->h_part.alloc((size_t)C * ((S + HMC_LATENT_GROUP - 1) / HMC_LATENT_GROUP) * T));
     HIP_TRY(s->h_traj.alloc(N * T));
     HIP_TRY(s->h_pm.alloc((size_t)C * T));
     HIP_TRY(s->h_obs.alloc(N));
@@ -980,13 +1133,14 @@ int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const doubl
   if (D == DD && L == LL)                                                                         \
     ci_launch_latents_d##DD##_l##LL(T, P, (int)N, s->y.p, s->mask.p, s->xt.p, s->h_draws.p, s->a1, \
                                     s->p10, s->p11, o->seed[0], o->seed[1],                       \
-                                    (uint32_t)o->chain_offset, 0u, S, s->h_level.p, s->h_slope.p, \
-                                    s->h_loc.p, s->h_traj.p, s->stream);
+                                    (uint32_t)o->chain_offset, 0u, S, HMC_LATENT_GROUP,           \
+                                    s->h_level.p, s->h_slope.p, nullptr, s->h_traj.p,             \
+                                    s->h_part.p, s->stream);
   CI_LAT_CASE(1, 1) CI_LAT_CASE(1, 2) CI_LAT_CASE(1, 4) CI_LAT_CASE(1, 8) CI_LAT_CASE(1, 16)
   CI_LAT_CASE(2, 1) CI_LAT_CASE(2, 2) CI_LAT_CASE(2, 4) CI_LAT_CASE(2, 8) CI_LAT_CASE(2, 16)
 #undef CI_LAT_CASE
-  hipLaunchKernelGGL(ci::hmc_mean_kernel, dim3((T + 255) / 256, C), dim3(256), 0, s->stream, C, S, T,
-                     s->h_loc.p, s->h_pm.p);
+  hipLaunchKernelGGL(ci::hmc_mean_kernel, dim3((T + 255) / 256, C), dim3(256), 0, s->stream, C,
+                     (S + HMC_LATENT_GROUP - 1) / HMC_LATENT_GROUP, S, T, s->h_part.p, s->h_pm.p);
   hipLaunchKernelGGL(ci::hmc_unpack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s->stream,
                      (int)N, P, s->h_draws.p, s->h_obs.p, s->h_lscale.p, s->h_sscale.p, s->h_w.p);
   HIP_TRY(hipGetLastError());
@@ -1092,8 +1246,8 @@ int ci_ll_session_draw_latents(ci_ll_session* s, int32_t num_draws, const double
 #define CI_LAT_CASE(DD, LL)                                                                       \
   if (D == DD && L == LL)                                                                         \
     ci_launch_latents_d##DD##_l##LL(T, P, E, s->y.p, s->mask.p, s->xt.p, s->theta.p, s->a1,       \
-                                    s->p10, s->p11, seed[0], seed[1], rng_chain, iter0, 0,        \
-                                    s->level.p, s->slope.p, s->loc.p, s->traj.p, 0);
+                                    s->p10, s->p11, seed[0], seed[1], rng_chain, iter0, 0, 1,     \
+                                    s->level.p, s->slope.p, s->loc.p, s->traj.p, nullptr, 0);
   CI_LAT_CASE(1, 1) CI_LAT_CASE(1, 2) CI_LAT_CASE(1, 4) CI_LAT_CASE(1, 8) CI_LAT_CASE(1, 16)
   CI_LAT_CASE(2, 1) CI_LAT_CASE(2, 2) CI_LAT_CASE(2, 4) CI_LAT_CASE(2, 8) CI_LAT_CASE(2, 16)
 #undef CI_LAT_CASE
@@ -1114,7 +1268,7 @@ int ci_ll_session_destroy(ci_ll_session* s) {
   s->y.release(); s->xt.release(); s->mask.release(); s->theta.release(); s->ll.release();
   s->grad.release(); s->level.release(); s->slope.release(); s->loc.release(); s->traj.release();
   s->omega.release(); s->h_draws.release(); s->h_acc.release(); s->h_eps.release(); s->h_init.release();
-  s->h_level.release(); s->h_slope.release(); s->h_loc.release(); s->h_traj.release();
+  s->h_level.release(); s->h_slope.release(); s->h_part.release(); s->h_traj.release();
   s->h_pm.release(); s->h_obs.release(); s->h_lscale.release(); s->h_sscale.release();
   s->h_w.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);

@@ -74,11 +74,13 @@ void CI_CAT(ci_launch_latents_d, CI_D, _l, CI_L)(int T, int P, int E, const floa
                                                 const double* theta, float a1, float p10,
                                                 float p11, uint32_t k0, uint32_t k1,
                                                 uint32_t rng_chain, uint32_t iter0, int per_chain,
-                                                float* level, float* slope, float* loc, float* traj,
-                                                hipStream_t stream) {
-  hipLaunchKernelGGL((ci::latents_kernel<CI_D, CI_L>), dim3(E), dim3(ci::NT), 0, stream, T, P, y,
-                     mask, Xt, theta, a1, p10, p11, k0, k1, rng_chain, iter0, per_chain, level, slope,
-                     loc, traj);
+                                                int group, float* level, float* slope, float* loc,
+                                                float* traj, float* loc_sum, hipStream_t stream) {
+  // E rows; per_chain > 0: chains x ceil(per_chain / group) workgroups (see latents_kernel)
+  const int grid = per_chain > 0 ? (E / per_chain) * ((per_chain + group - 1) / group) : E;
+  hipLaunchKernelGGL((ci::latents_kernel<CI_D, CI_L>), dim3(grid), dim3(ci::NT), 0, stream, T, P, y,
+                     mask, Xt, theta, a1, p10, p11, k0, k1, rng_chain, iter0, per_chain, group, E,
+                     level, slope, loc, traj, loc_sum);
 }
 
 // Runs the on-device HMC fit: one workgroup per chain.

@@ -67,6 +67,12 @@ struct KArgs {
   float* out_pred_mean;    // [B,C,T]
   float* out_traj;         // [B,C,S,T]
   long long* prof;         // optional [16] per-phase cycle counters (block 0, thread 0)
+  // Streaming of results to the host while the fit runs (ci_session_run_streamed): every
+  // progress_every retained draws (and after the last one) the workgroup makes its output rows
+  // visible to the copy engines (system-scope release) and publishes the number of complete
+  // draws of its chain in progress[series * C + chain] (host-coherent pinned memory).
+  unsigned int* progress;
+  int progress_every;
 };
 
 // Counter word 3 of the Philox stream: the global chain id in the low 16 bits' range, the global
@@ -1697,6 +1703,18 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
       else if (wave == 0) emit(so_prev, nz0 + 3 * L * 64);   // waves 1-3 emitted during the serial section
     }
     prof.tick(2);
+    if (a.progress != nullptr && it > a.W) {
+      const int done = it - a.W;                  // retained draws 0 .. done-1 are in HBM
+      if (done % a.progress_every == 0 || done == a.S) {
+        __syncthreads();                          // every wave's stores of those rows have been issued and acknowledged
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: write back L2
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(a.progress + chain_lin, (unsigned int)done, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
     if (it == n_iter) break;
 
     // ---- residual and the latent-path draw of iteration it
@@ -2104,63 +2122,95 @@ __global__ __launch_bounds__(NT) void latents_kernel(int T, int P, const float* 
                                                      const double* __restrict__ theta, float a1,
                                                      float p10, float p11, uint32_t k0, uint32_t k1,
                                                      uint32_t rng_chain, uint32_t iter0,
-                                                     int per_chain,
+                                                     int per_chain, int group, int num_rows,
                                                      float* __restrict__ out_level,
                                                      float* __restrict__ out_slope,
                                                      float* __restrict__ out_loc,
-                                                     float* __restrict__ out_traj) {
+                                                     float* __restrict__ out_traj,
+                                                     float* __restrict__ out_loc_sum) {
+  // Rows (parameter draws) handled by this workgroup.  per_chain > 0: rows are [chain][draw]
+  // blocks of per_chain draws (a whole HMC fit in one launch) and the grid is
+  // chains x ceil(per_chain / group) workgroups, each running `group` consecutive draws of one
+  // chain and leaving the sum of their noise-free predictors in out_loc_sum[workgroup][T] (the
+  // per-chain posterior mean is then a short deterministic reduction, with no [draws, T] array
+  // written and re-read for it).  per_chain == 0: one row per workgroup (group = 1).
   __shared__ float slots[3 * NW * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const double* th = theta + (size_t)blockIdx.x * (3 + P);
   const int t0 = tid * L;
-  float resid[L], xw[L];
+  int row0 = blockIdx.x, row1 = blockIdx.x + 1;
+  uint32_t row_chain = 0u;
+  if (per_chain > 0) {
+    const int ng = (per_chain + group - 1) / group;
+    row_chain = blockIdx.x / (uint32_t)ng;
+    const int g = blockIdx.x % ng;
+    row0 = (int)row_chain * per_chain + g * group;
+    row1 = row0 + group;
+    const int chain_end = ((int)row_chain + 1) * per_chain;
+    if (row1 > chain_end) row1 = chain_end;
+  }
+  if (row1 > num_rows) row1 = num_rows;
   uint32_t maskbits = 0;
+  float yv[L], acc[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const int t = t0 + l;
-    float s = 0.f;
-    if (t < T)
-      for (int j = 0; j < P; ++j) s = fmaf(Xt[(size_t)j * T + t], (float)th[3 + j], s);
-    xw[l] = s;
     const bool m = (t >= T) || mask[t] != 0;
     if (m) maskbits |= 1u << l;
-    resid[l] = m ? 0.f : y[t] - s;
+    yv[l] = m ? 0.f : y[t];
+    acc[l] = 0.f;
   }
-  DkModel<D> md;
-  const float so = (float)th[0];
-  md.H = so * so;
-  md.sig.v[0] = (float)th[1];
-  md.a1 = vzero<D>();
-  md.a1.v[0] = a1;
-  md.p1.v[0] = p10;
-  if constexpr (D == 2) {
-    md.sig.v[1] = (float)th[2];
-    md.p1.v[1] = p11;
-  }
-  // per_chain > 0: rows are [chain][draw] blocks of per_chain draws (a whole HMC fit in one
-  // launch): chain id and iteration follow from the row, so the draws do not depend on how the
-  // rows are split over launches or devices
-  const uint32_t row_chain = per_chain > 0 ? blockIdx.x / (uint32_t)per_chain : 0u;
-  const uint32_t row_iter = per_chain > 0 ? blockIdx.x % (uint32_t)per_chain : blockIdx.x;
   Rng g{k0, k1, rng_chain + row_chain};
-  const uint32_t iter = iter0 + row_iter;
-  Vec<D> x[L];
-  Prof prof;
-  prof.start(nullptr, false);
-  dk_draw<D, L>(md, resid, maskbits, g, iter, tid, lane, wave, slots, x, prof);
-  float zp[L];
-  fill_normals<L>(g, iter, SITE_PRED, 0, (uint32_t)t0, zp);
-  const size_t row = (size_t)blockIdx.x * T;
+  for (int row = row0; row < row1; ++row) {
+    const double* th = theta + (size_t)row * (3 + P);
+    float resid[L], xw[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const int t = t0 + l;
-    if (t < T) {
-      const float loc = x[l].v[0] + xw[l];
-      out_level[row + t] = x[l].v[0];
-      if constexpr (D == 2) { if (out_slope) out_slope[row + t] = x[l].v[1]; }
-      out_loc[row + t] = loc;
-      out_traj[row + t] = fmaf(so, zp[l], loc);
+    for (int l = 0; l < L; ++l) {
+      const int t = t0 + l;
+      float s = 0.f;
+      if (t < T)
+        for (int j = 0; j < P; ++j) s = fmaf(Xt[(size_t)j * T + t], (float)th[3 + j], s);
+      xw[l] = s;
+      resid[l] = ((maskbits >> l) & 1u) ? 0.f : yv[l] - s;
+    }
+    DkModel<D> md;
+    const float so = (float)th[0];
+    md.H = so * so;
+    md.sig.v[0] = (float)th[1];
+    md.a1 = vzero<D>();
+    md.a1.v[0] = a1;
+    md.p1.v[0] = p10;
+    if constexpr (D == 2) {
+      md.sig.v[1] = (float)th[2];
+      md.p1.v[1] = p11;
+    }
+    const uint32_t iter = iter0 + (uint32_t)(per_chain > 0 ? row - (int)row_chain * per_chain : row);
+    Vec<D> x[L];
+    Prof prof;
+    prof.start(nullptr, false);
+    dk_draw<D, L>(md, resid, maskbits, g, iter, tid, lane, wave, slots, x, prof);
+    float zp[L];
+    fill_normals<L>(g, iter, SITE_PRED, 0, (uint32_t)t0, zp);
+    const size_t base = (size_t)row * T;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int t = t0 + l;
+      if (t < T) {
+        const float loc = x[l].v[0] + xw[l];
+        acc[l] += loc;
+        out_level[base + t] = x[l].v[0];
+        if constexpr (D == 2) { if (out_slope) out_slope[base + t] = x[l].v[1]; }
+        if (out_loc) out_loc[base + t] = loc;
+        out_traj[base + t] = fmaf(so, zp[l], loc);
+      }
+    }
+    __syncthreads();     // slots are reused by the next draw
+  }
+  if (out_loc_sum) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int t = t0 + l;
+      if (t < T) out_loc_sum[(size_t)blockIdx.x * T + t] = acc[l];
     }
   }
 }

@@ -1,47 +1,79 @@
 #!/usr/bin/env python3
-"""Summarises rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, as
-/opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes) into profiles/r01_pmc.json.
+"""Summarises rocprofv3 --pmc passes into a small JSON under profiles/.
 
-    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv>
+HBM traffic (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, as
+/opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes):
 
-Units: FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B? No: rocprofv3 reports them in
-kilobytes (x1024 bytes).  gfx950 correction from the guide: FETCH_SIZE reports exactly half of
-a wide (16 B/lane) coalesced streaming read -> doubled here; WRITE_SIZE is uncalibrated there
-and is reported as is.
+    python tools/pmc_summary.py hbm <fetch_counter_collection.csv> <write_counter_collection.csv> \
+        --kernel gibbs_kernel --out profiles/r02_pmc.json [--also latents_kernel ...]
+
+rocprofv3 reports both counters in KiB.  gfx950 correction from the guide: FETCH_SIZE reports
+exactly half of a wide (16 B/lane) coalesced streaming read -> doubled here; WRITE_SIZE is
+uncalibrated there and is reported as is.
+
+SQ issue counters (one pass):
+
+    python tools/pmc_summary.py sq <counter_collection.csv> --kernel gibbs_kernel --out profiles/...json
+
+SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves (guide,
+"rocprofv3 PMC slots").
 """
+import argparse
+import collections
 import csv
 import json
-import os
-import sys
 
 
-def per_launch(path, counter, kernel_substr="gibbs_kernel"):
-  tot, n = 0.0, 0
+def per_launch(path, kernel_substr):
+  tot = collections.defaultdict(float)
+  n = collections.defaultdict(int)
   with open(path) as f:
     for row in csv.DictReader(f):
-      if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-        tot += float(row["Counter_Value"])
-        n += 1
-  return (tot / n if n else None), n
+      if kernel_substr in row.get("Kernel_Name", ""):
+        tot[row["Counter_Name"]] += float(row["Counter_Value"])
+        n[row["Counter_Name"]] += 1
+  return {k: tot[k] / n[k] for k in tot}, (max(n.values()) if n else 0)
 
 
 def main():
-  fetch_csv, write_csv = sys.argv[1], sys.argv[2]
-  fetch_kb, nf = per_launch(fetch_csv, "FETCH_SIZE")
-  write_kb, nw = per_launch(write_csv, "WRITE_SIZE")
-  out = {
-      "kernel": "ci::gibbs_kernel<2,4,1,false>",
-      "launches": {"fetch_pass": nf, "write_pass": nw},
-      "FETCH_SIZE_kb_per_launch_raw": fetch_kb,
-      "WRITE_SIZE_kb_per_launch_raw": write_kb,
-      "fetch_bytes_per_launch_corrected": None if fetch_kb is None else 2.0 * fetch_kb * 1024.0,
-      "write_bytes_per_launch": None if write_kb is None else write_kb * 1024.0,
-  }
-  if fetch_kb is not None and write_kb is not None:
-    out["hbm_bytes_per_launch"] = (out["fetch_bytes_per_launch_corrected"] +
-                                   out["write_bytes_per_launch"])
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  with open(os.path.join(root, "profiles", "r01_pmc.json"), "w") as f:
+  ap = argparse.ArgumentParser()
+  ap.add_argument("mode", choices=("hbm", "sq"))
+  ap.add_argument("csvs", nargs="+")
+  ap.add_argument("--kernel", required=True)
+  ap.add_argument("--also", nargs="*", default=[])
+  ap.add_argument("--out", required=True)
+  ap.add_argument("--algorithmic-bytes", type=float, default=None)
+  args = ap.parse_args()
+  if args.mode == "hbm":
+    out = {"kernels": {}}
+    total = 0.0
+    for k in [args.kernel] + list(args.also):
+      fetch, nf = per_launch(args.csvs[0], k)
+      write, nw = per_launch(args.csvs[1], k)
+      f_kb, w_kb = fetch.get("FETCH_SIZE"), write.get("WRITE_SIZE")
+      ent = {"launches": {"fetch_pass": nf, "write_pass": nw},
+             "FETCH_SIZE_kb_per_launch_raw": f_kb, "WRITE_SIZE_kb_per_launch_raw": w_kb,
+             "fetch_bytes_per_launch_corrected": None if f_kb is None else 2.0 * f_kb * 1024.0,
+             "write_bytes_per_launch": None if w_kb is None else w_kb * 1024.0}
+      if f_kb is not None and w_kb is not None:
+        ent["hbm_bytes_per_launch"] = ent["fetch_bytes_per_launch_corrected"] + ent["write_bytes_per_launch"]
+        total += ent["hbm_bytes_per_launch"]
+      out["kernels"][k] = ent
+    out["kernel"] = args.kernel
+    out["hbm_bytes_per_launch"] = total
+    if args.algorithmic_bytes:
+      out["algorithmic_bytes_per_launch"] = args.algorithmic_bytes
+      out["traffic_over_algorithmic"] = total / args.algorithmic_bytes
+  else:
+    c, n = per_launch(args.csvs[0], args.kernel)
+    out = {"kernel": args.kernel, "launches": n, "per_launch": c}
+    wc = c.get("SQ_WAVE_CYCLES")
+    if wc:
+      out["fractions_of_wave_cycles"] = {k: v / wc for k, v in c.items()
+                                         if k.startswith(("SQ_WAIT", "SQ_ACTIVE"))}
+      if "SQ_INSTS_VALU" in c:
+        out["valu_instructions_per_wave_cycle_x4"] = c["SQ_INSTS_VALU"] / wc
+  with open(args.out, "w") as f:
     json.dump(out, f, indent=1)
   print(json.dumps(out))
 

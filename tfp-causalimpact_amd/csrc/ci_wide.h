@@ -30,22 +30,26 @@
 namespace ci {
 
 constexpr int WIDE_MAX_LC = 256;      // T <= 65536
-constexpr int XR = 8;               // design rows per pass of the X'targets / X w loops
+constexpr int XR = 16;              // design rows per pass of the X'targets / X w loops
 
 template <int TR, int NS> struct WDim {
   static constexpr int D = TR + NS - 1;
   static constexpr int O = TR;          // first effect of the seasonal block
   static constexpr int N1 = NS - 1;
   static constexpr int NPS = D * (D + 1) / 2;
-  // per-step private fields: y~ | a_t + x+_t | P_t (upper triangle) | K_t | v_t / F_t
-  static constexpr int F_YT = 0, F_AX = 1, F_PS = 1 + D, F_KF = 1 + D + NPS, F_VF = 1 + 2 * D + NPS;
-  static constexpr int NF = 2 + 2 * D + NPS;
+  // per-step private fields: y~ | K_t | v_t / F_t | r_{t-1}.  (The covariance P_t and the
+  // simulated path x+_t are NOT stored: the smoothed path comes from the forward recursion
+  // x^_{t+1} = T x^_t + Q_t r_t of the fast state smoother (de Jong 1989; Koopman 1993) started at
+  // the chunk's predicted moments, and x+ is re-simulated from the counter-based stream -- 16
+  // floats per step at d = 7 instead of 44.)
+  static constexpr int F_YT = 0, F_KF = 1, F_VF = 1 + D, F_RS = 2 + D;
+  static constexpr int NF = 2 + 2 * D;
 };
 
 // floats of HBM workspace per chain
 __host__ __device__ inline size_t wide_workspace_floats(int D, int Lc) {
   const size_t TP = (size_t)NT * Lc;
-  const size_t nf = 2 + 2 * D + D * (D + 1) / 2;
+  const size_t nf = 2 + 2 * D;
   return (6 + nf) * TP + TP / 2;   // 6 shared T-arrays, private fields, mask + change bytes
 }
 
@@ -411,10 +415,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
         const float zl = q == 0 ? zl4[0] : q == 1 ? zl4[1] : q == 2 ? zl4[2] : zl4[3];
         const float zk = q == 0 ? zk4[0] : q == 1 ? zk4[1] : q == 2 ? zk4[2] : zk4[3];
         const float yt = at4(r4, q) - (x.v[0] + x.v[O] + sc.so * zo);
-        float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
-        wl[W::F_YT * NT] = yt;
-#pragma unroll
-        for (int i = 0; i < D; ++i) wl[(W::F_AX + i) * NT] = x.v[i];
+        wsp[((size_t)(g4 + q) * NF + W::F_YT) * NT + tid] = yt;
         if (obs) {
           // fold observation y~_t into (A, b, C, eta, J):  x_t | x_start ~ N(A x_start + b, C)
           float za[D], cz[D];
@@ -464,37 +465,41 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
       felems_identity<D>(), fslots, lane, wave);
   prof.tick(22);
 
-  // ---- (3) local Kalman filter from the predicted moments at the start of the chunk
+  // ---- (3) local Kalman filter from the predicted moments at the start of the chunk: gains
+  // K_t and scaled innovations v_t / F_t (all the backward passes need)
+  Vec<D> a_start;
+  Mat<D> P_start;
+  if (tid == 0) { a_start = a1e; P_start = P1; } else {
+    a_start = fpre.b;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) P_start.m[i][j] = fpre.C[symidx<D>(i, j)];
+  }
   {
-    Vec<D> am;
-    Mat<D> Pm;
-    if (tid == 0) { am = a1e; Pm = P1; } else {
-      am = fpre.b;
+    Vec<D> am = a_start;
+    Mat<D> Pm = P_start;
+    float ytn[4];
 #pragma unroll
-      for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j < D; ++j) Pm.m[i][j] = fpre.C[symidx<D>(i, j)];
-    }
+    for (int q = 0; q < 4; ++q) ytn[q] = wsp[((size_t)q * NF + W::F_YT) * NT + tid];
 #pragma unroll 1
     for (int g4 = 0; g4 < Lc; g4 += 4) {
       const int t4 = t0 + g4;
       const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
       const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
+      float yt4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) yt4[q] = ytn[q];
+      if (g4 + 4 < Lc) {      // next block's rows, requested before this block's stores
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ytn[q] = wsp[((size_t)(g4 + 4 + q) * NF + W::F_YT) * NT + tid];
+      }
 #pragma unroll 1
       for (int q = 0; q < 4; ++q) {
         const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
         const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
         float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
-        const float yt = wl[W::F_YT * NT];
-#pragma unroll
-        for (int i = 0; i < D; ++i) wl[(W::F_AX + i) * NT] += am.v[i];
-        {
-          int e = 0;
-#pragma unroll
-          for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = i; j < D; ++j) wl[(W::F_PS + e++) * NT] = Pm.m[i][j];
-        }
+        const float yt = q == 0 ? yt4[0] : q == 1 ? yt4[1] : q == 2 ? yt4[2] : yt4[3];
         float vf = 0.f;
         float kf[D];
 #pragma unroll
@@ -525,7 +530,20 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
   }
   prof.tick(23);
 
-  // ---- (4) backward recursion r <- T' r ; r += Z'(v/F - K'r): chunk maps, suffix scan
+  // ---- (4) backward recursion r <- T' r ; r += Z'(v/F - K'r): chunk maps, suffix scan.
+  // (5a) below requests the workspace rows of the NEXT 4-step block before the current block is
+  // processed (one wave per SIMD: nothing else hides the L2 round trip of a dependent load;
+  // here, with the 7 x 7 map live, the extra registers cost more than the prefetch gains).
+  struct KV4 { float kf[4][D]; float vf[4]; };
+  auto load_kv = [&](int g4, KV4& b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
+#pragma unroll
+      for (int i = 0; i < D; ++i) b.kf[q][i] = wl[(W::F_KF + i) * NT];
+      b.vf[q] = wl[W::F_VF * NT];
+    }
+  };
   AElem<D> ae = aelem_identity<D>();
 #pragma unroll 1
   for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
@@ -567,7 +585,40 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
       aelem_identity<D>(), aslots, lane, wave);
   prof.tick(25);
 
-  // ---- (5) r through the chunk, x~_t = (a_t + x+_t) + P_t r_{t-1}, statistics of the draw
+  // ---- (5a) r through the chunk (backward), stored per step: rs[t] = r_{t-1}
+  {
+    Vec<D> r = asuf.c;      // the maps of all later chunks applied to r = 0
+    KV4 nxt;
+    load_kv(Lc - 4, nxt);
+#pragma unroll 1
+    for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
+      const int t4 = t0 + g4;
+      const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
+      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
+      const KV4 cur = nxt;
+      if (g4 >= 4) load_kv(g4 - 4, nxt);     // requested before this block's stores
+#pragma unroll
+      for (int q = 3; q >= 0; --q) {
+        const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
+        float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
+        w_apply_t<TR, NS>(r, ch);
+        if (obs) {
+          float kr = 0.f;
+#pragma unroll
+          for (int i = 0; i < D; ++i) kr = fmaf(cur.kf[q][i], r.v[i], kr);
+          const float add = cur.vf[q] - kr;
+          r.v[0] += add;
+          r.v[O] += add;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) wl[(W::F_RS + i) * NT] = r.v[i];
+      }
+    }
+  }
+  prof.tick(26);
+  // ---- (5b) forward: x^_{t0} = a_{t0} + P_{t0} r_{t0-1}, x^_{t+1} = T x^_t + Q_t r_t; x+ is
+  // re-simulated from the same counters as in (2); x~_t = x^_t + x+_t; statistics of the draw
   ssl = 0.f; sss = 0.f; ssd = 0.f;
   auto stats = [&](const Vec<D>& xt, const Vec<D>& xn, bool ch) {
     float dl = xn.v[0] - xt.v[0];
@@ -586,49 +637,93 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
   };
   Vec<D> xlast = vzero<D>(), xfirst = vzero<D>();
   {
-    Vec<D> r = asuf.c;      // the maps of all later chunks applied to r = 0
-    Vec<D> xn = vzero<D>();
+    Vec<D> xh = a_start;
+    {
+      Vec<D> r0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) r0.v[i] = wsp[((size_t)0 * NF + W::F_RS + i) * NT + tid];
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) xh.v[i] = fmaf(P_start.m[i][j], r0.v[j], xh.v[i]);
+    }
+    Vec<D> xp = ppre.s;
+    Vec<D> xprev = vzero<D>();
+    bool chprev = false;
+    const float ql = sc.ql, qs = sc.qs, qd = sc.qd;
+    // rn4[q] = r_t of step t = t4 + q = the stored row of step t + 1 (the later chunks' suffix at
+    // the chunk's end); the rows of the next block are requested one block ahead
+    struct R4 { float r[4][D]; };
+    auto load_r = [&](int g4, R4& b) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sidx = g4 + q + 1;
+        if (sidx < Lc) {
+#pragma unroll
+          for (int i = 0; i < D; ++i) b.r[q][i] = wsp[((size_t)sidx * NF + W::F_RS + i) * NT + tid];
+        } else {
+#pragma unroll
+          for (int i = 0; i < D; ++i) b.r[q][i] = asuf.c.v[i];
+        }
+      }
+    };
+    R4 rnx;
+    load_r(0, rnx);
 #pragma unroll 1
-    for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
+    for (int g4 = 0; g4 < Lc; g4 += 4) {
       const int t4 = t0 + g4;
-      const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
+      const R4 rcur = rnx;
+      if (g4 + 4 < Lc) load_r(g4 + 4, rnx);
+      float zl4[4], zs4[4], zk4[4];
+      normals4(site_call(rng, iter, SITE_PRIOR_LEVEL, 0, (uint32_t)(t4 >> 2)), zl4);
+      if constexpr (TR == 2) normals4(site_call(rng, iter, SITE_PRIOR_SLOPE, 0, (uint32_t)(t4 >> 2)), zs4);
+      normals4(site_call(rng, iter, SITE_PRIOR_SEAS, 0, (uint32_t)(t4 >> 2)), zk4);
       const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
-#pragma unroll 1
-      for (int q = 3; q >= 0; --q) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
         const int t = t4 + q;
-        const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
         const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
-        const float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
+        const float zl = zl4[q];
+        const float zk = zk4[q];
         Vec<D> xt;
 #pragma unroll
-        for (int i = 0; i < D; ++i) xt.v[i] = wl[(W::F_AX + i) * NT];
-        float Ps[W::NPS];
-#pragma unroll
-        for (int e = 0; e < W::NPS; ++e) Ps[e] = wl[(W::F_PS + e) * NT];
-        w_apply_t<TR, NS>(r, ch);
-        if (obs) {
-          float kr = 0.f;
-#pragma unroll
-          for (int i = 0; i < D; ++i) kr = fmaf(wl[(W::F_KF + i) * NT], r.v[i], kr);
-          const float add = wl[W::F_VF * NT] - kr;
-          r.v[0] += add;
-          r.v[O] += add;
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-          for (int j = 0; j < D; ++j) xt.v[i] = fmaf(Ps[symidx<D>(i, j)], r.v[j], xt.v[i]);
+        for (int i = 0; i < D; ++i) xt.v[i] = xh.v[i] + xp.v[i];
         if (t < T) {
           levw[t] = xt.v[0];
           if constexpr (TR == 2) slpw[t] = xt.v[1];
           seaw[t] = xt.v[O];
         }
-        if (g4 + q == Lc - 1) xlast = xt;
-        else if (t + 1 < T) stats(xt, xn, ch);
-        xn = xt;
+        if (g4 + q == 0) xfirst = xt;
+        else if (t < T) stats(xprev, xt, chprev);
+        xprev = xt;
+        chprev = ch;
+        Vec<D> rn;
+#pragma unroll
+        for (int i = 0; i < D; ++i) rn.v[i] = rcur.r[q][i];
+        // x^_{t+1} = T x^_t + Q_t r_t,  Q_t = diag(ql, qs) (+) [ch] (sdn)^2 1 1' on the block
+        w_apply<TR, NS>(xh, ch);
+        xh.v[0] = fmaf(ql, rn.v[0], xh.v[0]);
+        if constexpr (TR == 2) xh.v[1] = fmaf(qs, rn.v[1], xh.v[1]);
+        if (ch) {
+          float sr = 0.f;
+#pragma unroll
+          for (int i = 0; i < N1; ++i) sr += rn.v[O + i];
+          const float add = qd * sr;
+#pragma unroll
+          for (int i = 0; i < N1; ++i) xh.v[O + i] += add;
+        }
+        // x+_{t+1}
+        w_apply<TR, NS>(xp, ch);
+        xp.v[0] = fmaf(sc.sl, zl, xp.v[0]);
+        if constexpr (TR == 2) xp.v[1] = fmaf(sc.ss, zs4[q], xp.v[1]);
+        if (ch) {
+          const float dz = sc.sdn * zk;
+#pragma unroll
+          for (int i = 0; i < N1; ++i) xp.v[O + i] -= dz;
+        }
       }
     }
-    xfirst = xn;
+    xlast = xprev;
   }
   // increment across the chunk boundary: the next thread's first step
   if (lane == 0) {
@@ -646,7 +741,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
     const int t = t0 + Lc - 1;
     if (t + 1 < T) stats(xlast, nf, cbv[t] != 0);
   }
-  prof.tick(26);
+  prof.tick(27);
 }
 
 // ------------------------------------------------------------------------------------
@@ -765,17 +860,27 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
 #pragma unroll
         for (int q = 0; q < XR; ++q) acc[q] = 0.f;
         if (vec4) {
-          for (int c4 = tid; c4 < (T >> 2); c4 += NT) {
+          // two 4-step chunks per trip: 2 x (XR + 1) 16-byte loads in flight per thread
+          const int n4 = T >> 2;
+          for (int c4 = tid; c4 < n4; c4 += 2 * NT) {
+            const int c4b = c4 + NT;
+            const bool hb = c4b < n4;
+            const int c4s = hb ? c4b : c4;
             const float4 tg = *reinterpret_cast<const float4*>(tgw + 4 * c4);
-            float4 xv[XR];
+            float4 tgb = *reinterpret_cast<const float4*>(tgw + 4 * c4s);
+            float4 xv[XR], xb[XR];
 #pragma unroll
             for (int q = 0; q < XR; ++q) {
               const int j = j0 + q < P ? j0 + q : P - 1;
               xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
+              xb[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4s);
             }
+            if (!hb) tgb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int q = 0; q < XR; ++q)
+            for (int q = 0; q < XR; ++q) {
               acc[q] += xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
+              acc[q] += xb[q].x * tgb.x + xb[q].y * tgb.y + xb[q].z * tgb.z + xb[q].w * tgb.w;
+            }
           }
         } else {
           for (int tb = tid; tb < T; tb += 4 * NT) {
@@ -893,9 +998,35 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       const size_t o = chain_lin * g.S + s;
       const size_t row = o * T;
       const float so = scal[1];
+      // 4 steps per thread: whole 16-byte accesses when the rows are 16-byte aligned (T % 4 == 0;
+      // the shared T-arrays are padded to a multiple of 4)
+      const bool vec4e = (T & 3) == 0;
       for (int c = tid; c < (T + 3) / 4; c += NT) {
         float zp[4];
         normals4(site_call(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)c), zp);
+        if (vec4e) {
+          const float4 lv = *reinterpret_cast<const float4*>(levw + 4 * c);
+          const float4 sv = *reinterpret_cast<const float4*>(seaw + 4 * c);
+          const float4 xv = *reinterpret_cast<const float4*>(xww + 4 * c);
+          const float4 loc = make_float4(lv.x + sv.x + xv.x, lv.y + sv.y + xv.y, lv.z + sv.z + xv.z,
+                                         lv.w + sv.w + xv.w);
+          const size_t at = row + 4 * (size_t)c;
+          if (g.out_level) *reinterpret_cast<float4*>(g.out_level + at) = lv;
+          if (g.out_slope && TR == 2)
+            *reinterpret_cast<float4*>(g.out_slope + at) = *reinterpret_cast<const float4*>(slpw + 4 * c);
+          if (a.out_seasonal) *reinterpret_cast<float4*>(a.out_seasonal + at) = sv;
+          if (g.out_traj)
+            *reinterpret_cast<float4*>(g.out_traj + at) =
+                make_float4(fmaf(so, zp[0], loc.x), fmaf(so, zp[1], loc.y), fmaf(so, zp[2], loc.z),
+                            fmaf(so, zp[3], loc.w));
+          if (g.out_pred_mean) {
+            float4* pm = reinterpret_cast<float4*>(g.out_pred_mean + chain_lin * T + 4 * c);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s != 0) acc = *pm;                 // running sum, scaled at the end
+            *pm = make_float4(acc.x + loc.x, acc.y + loc.y, acc.z + loc.z, acc.w + loc.w);
+          }
+          continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int t = 4 * c + q;

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock budget of the time-parallel seasonal kernel (gibbs_wide_kernel) on
+BASELINE cfg4 (T=10000, 50 covariates, weekly block).   python tools/profile_wide.py [T] [p] [chains]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tfp-causalimpact_amd")]
+import causalimpact as ci  # noqa: E402
+from causalimpact import _model, _native  # noqa: E402
+from causalimpact import _synthetic as syn  # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+p = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+y, mask, X, _ = syn.make_sampler_inputs(T, p, 0)
+y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+spec = _model.series_params(y, mask, X, num_seasonal_blocks=1)
+counts, flg = _model.expand_seasons((ci.Seasons(num_seasons=7),), T)
+W, S = 20, 100
+pb = _native.make_problem(T=T, P=X.shape[1], has_slope=0, num_seasons=counts, num_warmup=W,
+                          num_results=S, num_chains=C, seed=(0, 1))
+sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+sess.run()
+ms = min(sess.run() for _ in range(2))
+sess.profile(True)
+sess.run()
+cyc = sess.profile(False)
+n = W + S
+names = {0: "(1) targets, X'targets, sums", 1: "(2) serial + regression block", 9: "   scale draws (wave 0)",
+         10: "   regression block (workgroup)", 2: "(3) emit", 3: "(4) X w, residual",
+         20: "dk (1) prior simulation + scan", 21: "dk (2) y~, chunk filter elements",
+         22: "dk     filter scan (256 elements)", 23: "dk (3) local filter: gains",
+         24: "dk (4) backward chunk maps", 25: "dk     backward scan", 26: "dk (5a) r through the chunk",
+         27: "dk (5b) forward reconstruction"}
+print(f"T={T} P={pb.P} chains={C}: {ms * 1e3 / n:.1f} us per iteration ({ms:.1f} ms per launch)")
+tot = 0
+for k in sorted(names):
+  print(f"  [{k:2d}] {names[k]:36s} {cyc[k] / n:10.0f} cycles / iteration")
+  if k not in (9, 10):
+    tot += cyc[k]
+print(f"  sum {tot / n:.0f} cycles / iteration")
+sess.close()

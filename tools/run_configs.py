@@ -69,5 +69,10 @@ def cfg5(B, S=1000):
 
 
 if __name__ == "__main__":
-  for line in (cfg4(1), cfg4(8), cfg5(64), cfg5(512)):
-    print(json.dumps(line))
+  which = sys.argv[1] if len(sys.argv) > 1 else "all"
+  if which == "cfg4":        # counter passes: one short cfg4 fit per chain count
+    runs = (lambda: cfg4(1, S=200), lambda: cfg4(8, S=200))
+  else:
+    runs = (lambda: cfg4(1), lambda: cfg4(8), lambda: cfg5(64), lambda: cfg5(512))
+  for run in runs:
+    print(json.dumps(run()), flush=True)

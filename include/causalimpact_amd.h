@@ -82,6 +82,11 @@ typedef struct ci_problem {
  * reproduces a single-series fit of series b draw for draw; Monte-Carlo errors are perfectly
  * correlated across the batch).  Off by default. */
 #define CI_FLAG_SHARED_SERIES_STREAMS 2
+/* Use the four-wavefront Gibbs kernel where the five-wavefront latency build (a dedicated
+ * regression wave that sweeps the next iteration's matrix during the Durbin-Koopman draw) would
+ * be chosen.  Same sampler and random stream (draws agree to float32 round-off); test /
+ * diagnostic knob. */
+#define CI_FLAG_FOUR_WAVES 4
 
 /* Caller-allocated result buffers (float32, chain-major so per-device shards
  * are contiguous).  == GibbsSamplerState stack + (means, trajectories) returned

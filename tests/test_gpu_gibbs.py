@@ -347,3 +347,47 @@ def test_streamed_fetch_of_a_seasonal_model_equals_run_then_fetch():
   for k, v in want.items():
     np.testing.assert_array_equal(got[k], v, err_msg=k)
   sess.close()
+
+
+@pytest.mark.parametrize("T,p,has_slope,B,C", [(1000, 10, 1, 1, 3), (500, 5, 0, 4, 2), (100, 1, 0, 1, 2),
+                                               (300, 15, 1, 1, 2)])
+def test_five_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, B, C):
+  """gibbs_kernel5 (a dedicated regression wavefront that sweeps the next iteration's matrix
+  during the Durbin-Koopman draw and replays the recorded multipliers on the new right-hand
+  side, csrc/ci_kernels5.h) against gibbs_kernel<D, L, 1> (CI_FLAG_FOUR_WAVES).  The regression
+  arithmetic is the same operations in the same order: on the first iterations sigma_obs and the
+  weights are IDENTICAL; the Durbin-Koopman code is shared source compiled in two contexts
+  (-ffp-contract=fast may fuse differently), so the latent paths agree to float32 round-off, and
+  since both consume the same random numbers the chains stay together: inclusion patterns equal
+  throughout, continuous outputs within float32 noise.  Covers warm-up with accepted inclusion
+  flips (fall-back route), P <= 3 (all features always in), several series and chains."""
+  ys, masks, Xs, specs = [], [], [], []
+  for b in range(B):
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 60 + b)
+    ys.append(y); masks.append(mask); Xs.append(X)
+    specs.append(orc.default_spec(y, mask, X, has_slope=bool(has_slope)))
+  out = {}
+  for flags in (0, _native.FLAG_FOUR_WAVES):
+    pb = _native.make_problem(T=T, P=p + 1, has_slope=has_slope, num_warmup=0, num_results=120,
+                              num_chains=C, num_series=B, seed=(6, 2), flags=flags)
+    sess = _native.Session(pb, np.stack(ys), np.stack(masks), np.stack(Xs), None,
+                           _native.make_params(specs))
+    out[flags] = (sess.kernel_name(), sess.run(), sess.fetch())
+    sess.close()
+  assert "gibbs_kernel5" in out[0][0] and "gibbs_kernel<" in out[_native.FLAG_FOUR_WAVES][0]
+  five, four = out[0][2], out[_native.FLAG_FOUR_WAVES][2]
+  # iterations 0 and 1: the regression draw is exact
+  for k in ("observation_noise_scale", "weights"):
+    np.testing.assert_array_equal(five[k][:, :, :2], four[k][:, :, :2], err_msg=k)
+  np.testing.assert_array_equal(five["weights"] != 0, four["weights"] != 0)
+  np.testing.assert_allclose(five["weights"], four["weights"], atol=2e-3)
+  np.testing.assert_allclose(five["observation_noise_scale"], four["observation_noise_scale"], rtol=1e-3)
+  np.testing.assert_allclose(five["level_scale"], four["level_scale"], rtol=5e-3)
+  scale = 1.0 + np.abs(four["level"]).max()
+  np.testing.assert_allclose(five["level"], four["level"], atol=1e-2 * scale)
+  np.testing.assert_allclose(five["posterior_means"], four["posterior_means"], atol=5e-3 * scale)
+  w = five["weights"]
+  assert np.isfinite(w).all() and (w != 0).any()
+  if p >= 5:   # inclusion patterns do change during the run: the fall-back route is exercised
+    incl = (w != 0)
+    assert (incl[:, :, 1:] != incl[:, :, :-1]).any()

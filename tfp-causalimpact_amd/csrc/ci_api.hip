@@ -13,6 +13,7 @@
 
 #include "../../include/causalimpact_amd.h"
 #include "ci_kernels.h"
+#include "ci_kernels5.h"
 #define CI_SEASONAL_DECL_ONLY
 #include "ci_seasonal.h"
 #include "ci_wide.h"
@@ -29,6 +30,7 @@ CI_WIDE_DECL(2) CI_WIDE_DECL(3) CI_WIDE_DECL(4) CI_WIDE_DECL(5) CI_WIDE_DECL(6) 
 // One object file per (D, L) instantiation (ci_inst.hip).
 #define CI_DECL(D, L)                                                                          \
   extern "C" void* ci_gibbs_fn_d##D##_l##L(int);                                              \
+  extern "C" void* ci_gibbs5_fn_d##D##_l##L(void);                                            \
   extern "C" void ci_launch_dk_d##D##_l##L(int, const float*, const uint8_t*, float, float,    \
                                            float, float, float, float, uint32_t, uint32_t,     \
                                            uint32_t, uint32_t, float*);                           \
@@ -138,6 +140,13 @@ static __global__ void hmc_unpack_kernel(int N, int P, const double* __restrict_
 
 namespace {
 using KernelFn = void (*)(ci::KArgs);
+KernelFn pick_kernel5(int D, int L) {
+#define CI_CASE5(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs5_fn_d##DD##_l##LL();
+  CI_CASE5(1, 1) CI_CASE5(1, 2) CI_CASE5(1, 4) CI_CASE5(1, 8) CI_CASE5(1, 16)
+  CI_CASE5(2, 1) CI_CASE5(2, 2) CI_CASE5(2, 4) CI_CASE5(2, 8) CI_CASE5(2, 16)
+#undef CI_CASE5
+  return nullptr;
+}
 KernelFn pick_kernel(int D, int L, int pm) {
 #define CI_CASE(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs_fn_d##DD##_l##LL(pm);
   CI_CASE(1, 1) CI_CASE(1, 2) CI_CASE(1, 4) CI_CASE(1, 8) CI_CASE(1, 16)
@@ -273,6 +282,7 @@ int steps_per_thread(int T) {
 struct ci_session {
   ci_problem pb;
   int L = 0, x_in_lds = 0;
+  bool five_waves = false;     // dispatching to gibbs_kernel5 (ci_kernels5.h)
   size_t lds_bytes = 0;
   KernelFn fn = nullptr, fn_prof = nullptr;
   hipStream_t stream = nullptr;
@@ -469,6 +479,19 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     char nm[96];
     snprintf(nm, sizeof(nm), "ci::gibbs_kernel<%d,%d,%d,false>", D, s->L, pm);
     s->kernel_name = nm;
+    // latency build: a fifth wavefront owns the regression section and sweeps the next
+    // iteration's matrix during the Durbin-Koopman draw (same draws, bit for bit)
+    const size_t lds5 = ci::make_layout5(P, D, ci::NT * s->L).total;
+    if (pm == 1 && !(pb->flags & CI_FLAG_FOUR_WAVES) && lds5 <= 150 * 1024) {
+      KernelFn f5 = pick_kernel5(D, s->L);
+      if (f5) {
+        s->fn = f5;
+        s->five_waves = true;
+        s->lds_bytes = lds5;
+        snprintf(nm, sizeof(nm), "ci::gibbs_kernel5<%d,%d>", D, s->L);
+        s->kernel_name = nm;
+      }
+    }
   } else {
     s->D_full = D;
     s->dred = D;
@@ -650,8 +673,15 @@ static int session_launch(ci_session* s) {
     hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(pb.num_series * pb.num_chains),
                        dim3(s->wide ? ci::NT : 64), s->lds_bytes, s->stream, sa);
   } else {
-    hipLaunchKernelGGL((s->profile && s->fn_prof) ? s->fn_prof : s->fn,
-                       dim3(pb.num_series * pb.num_chains), dim3(ci::NT), s->lds_bytes, s->stream, a);
+    if (s->profile && s->fn_prof) {
+      // the instrumented variant is the four-wave kernel (its own LDS layout)
+      const size_t lds4 = ci::make_layout(pb.P, pb.has_slope ? 2 : 1, ci::NT * s->L, s->x_in_lds).total;
+      hipLaunchKernelGGL(s->fn_prof, dim3(pb.num_series * pb.num_chains), dim3(ci::NT), lds4,
+                         s->stream, a);
+    } else {
+      hipLaunchKernelGGL(s->fn, dim3(pb.num_series * pb.num_chains),
+                         dim3(s->five_waves ? ci::NT5 : ci::NT), s->lds_bytes, s->stream, a);
+    }
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, s->stream));

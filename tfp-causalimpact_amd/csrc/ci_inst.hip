@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ci_kernels.h"
+#include "ci_kernels5.h"
 #include "ci_hmc.h"
 
 #ifndef CI_D
@@ -27,6 +28,11 @@ void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(int pm) {
   if (pm == 8) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 0, true>);
   if (pm == 9) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 1, true>);
   return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 2, true>);
+}
+
+// The five-wavefront latency build of the PM = 1 kernel (ci_kernels5.h).
+void* CI_CAT(ci_gibbs5_fn_d, CI_D, _l, CI_L)(void) {
+  return (void*)(&ci::gibbs_kernel5<CI_D, CI_L>);
 }
 
 // Launches the one-draw Durbin-Koopman test kernel on the default stream.

@@ -1706,7 +1706,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     if (a.progress != nullptr && it > a.W) {
       const int done = it - a.W;                  // retained draws 0 .. done-1 are in HBM
       if (done % a.progress_every == 0 || done == a.S) {
-        __syncthreads();                          // every wave's stores of those rows have been issued and acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows have reached L2
+        __syncthreads();                          // ... and so have every other wave's
         if (tid == 0) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: write back L2
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -30,7 +30,7 @@ CI_WIDE_DECL(2) CI_WIDE_DECL(3) CI_WIDE_DECL(4) CI_WIDE_DECL(5) CI_WIDE_DECL(6) 
 // One object file per (D, L) instantiation (ci_inst.hip).
 #define CI_DECL(D, L)                                                                          \
   extern "C" void* ci_gibbs_fn_d##D##_l##L(int);                                              \
-  extern "C" void* ci_gibbs5_fn_d##D##_l##L(void);                                            \
+  extern "C" void* ci_gibbs5_fn_d##D##_l##L(int);                                             \
   extern "C" void ci_launch_dk_d##D##_l##L(int, const float*, const uint8_t*, float, float,    \
                                            float, float, float, float, uint32_t, uint32_t,     \
                                            uint32_t, uint32_t, float*);                           \
@@ -140,8 +140,8 @@ static __global__ void hmc_unpack_kernel(int N, int P, const double* __restrict_
 
 namespace {
 using KernelFn = void (*)(ci::KArgs);
-KernelFn pick_kernel5(int D, int L) {
-#define CI_CASE5(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs5_fn_d##DD##_l##LL();
+KernelFn pick_kernel5(int D, int L, int profiled) {
+#define CI_CASE5(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs5_fn_d##DD##_l##LL(profiled);
   CI_CASE5(1, 1) CI_CASE5(1, 2) CI_CASE5(1, 4) CI_CASE5(1, 8) CI_CASE5(1, 16)
   CI_CASE5(2, 1) CI_CASE5(2, 2) CI_CASE5(2, 4) CI_CASE5(2, 8) CI_CASE5(2, 16)
 #undef CI_CASE5
@@ -284,7 +284,7 @@ struct ci_session {
   int L = 0, x_in_lds = 0;
   bool five_waves = false;     // dispatching to gibbs_kernel5 (ci_kernels5.h)
   size_t lds_bytes = 0;
-  KernelFn fn = nullptr, fn_prof = nullptr;
+  KernelFn fn = nullptr, fn_prof = nullptr, fn_prof5 = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<float> y, Xt, o_obs, o_lscale, o_sscale, o_w, o_level, o_slope, o_pm, o_traj;
@@ -483,9 +483,13 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     // iteration's matrix during the Durbin-Koopman draw (same draws, bit for bit)
     const size_t lds5 = ci::make_layout5(P, D, ci::NT * s->L).total;
     if (pm == 1 && !(pb->flags & CI_FLAG_FOUR_WAVES) && lds5 <= 150 * 1024) {
-      KernelFn f5 = pick_kernel5(D, s->L);
+      KernelFn f5 = pick_kernel5(D, s->L, 0);
       if (f5) {
         s->fn = f5;
+        s->fn_prof5 = pick_kernel5(D, s->L, 1);
+        if (s->fn_prof5)
+          HIP_TRY(hipFuncSetAttribute((const void*)s->fn_prof5,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
         s->five_waves = true;
         s->lds_bytes = lds5;
         snprintf(nm, sizeof(nm), "ci::gibbs_kernel5<%d,%d>", D, s->L);
@@ -673,7 +677,10 @@ static int session_launch(ci_session* s) {
     hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(pb.num_series * pb.num_chains),
                        dim3(s->wide ? ci::NT : 64), s->lds_bytes, s->stream, sa);
   } else {
-    if (s->profile && s->fn_prof) {
+    if (s->profile && s->five_waves && s->fn_prof5) {
+      hipLaunchKernelGGL(s->fn_prof5, dim3(pb.num_series * pb.num_chains), dim3(ci::NT5), s->lds_bytes,
+                         s->stream, a);
+    } else if (s->profile && s->fn_prof) {
       // the instrumented variant is the four-wave kernel (its own LDS layout)
       const size_t lds4 = ci::make_layout(pb.P, pb.has_slope ? 2 : 1, ci::NT * s->L, s->x_in_lds).total;
       hipLaunchKernelGGL(s->fn_prof, dim3(pb.num_series * pb.num_chains), dim3(ci::NT), lds4,

@@ -31,8 +31,12 @@ void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(int pm) {
 }
 
 // The five-wavefront latency build of the PM = 1 kernel (ci_kernels5.h).
-void* CI_CAT(ci_gibbs5_fn_d, CI_D, _l, CI_L)(void) {
-  return (void*)(&ci::gibbs_kernel5<CI_D, CI_L>);
+void* CI_CAT(ci_gibbs5_fn_d, CI_D, _l, CI_L)(int profiled) {
+#if CI_D == 2 && CI_L == 4
+  // the instrumented variant exists for the bench shape only (ci_session_profile)
+  if (profiled) return (void*)(&ci::gibbs_kernel5<CI_D, CI_L, true>);
+#endif
+  return profiled ? nullptr : (void*)(&ci::gibbs_kernel5<CI_D, CI_L, false>);
 }
 
 // Launches the one-draw Durbin-Koopman test kernel on the default stream.

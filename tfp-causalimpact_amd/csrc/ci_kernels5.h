@@ -141,12 +141,14 @@ __device__ __forceinline__ void regression_precompute(const RegLds& R, int P, do
 }
 
 // spike_slab_draw_regs with the matrix sweeps replayed from the precompute (same results).
+template <class PF>
 __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
                                                       const DevSeriesParams& sp,
                                                       double prev_obs_scale, double g_obs,
                                                       const Rng& rng, uint32_t iter, int lane,
                                                       PriorCarry& pc, const double* pre,
-                                                      const PreTables& tb, const PreState& ps) {
+                                                      const PreTables& tb, const PreState& ps,
+                                                      PF& prof) {
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
@@ -170,6 +172,7 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
     m.cb = (j == k) ? cbk * rd : m.cb - cbk * t;
     m.corner -= cbk * cbk * rd;
   }
+  prof.tick(21);
   bool dirty = false;
   if (!all_in) {
     const int rank = reinterpret_cast<const int*>(pre + 16)[j];
@@ -204,6 +207,7 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
       dirty = true;
     }
   }
+  prof.tick(22);
 #pragma unroll
   for (int r = 0; r < 4; ++r) pc.p[r] = m.p[r];
   pc.pdiag = m.pdiag;
@@ -241,16 +245,18 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
   }
   if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(mean + new_scale * umine) : 0.f;
   wave_sync();
+  prof.tick(23);
   return new_scale;
 }
 
 // Serial section of iteration `it` on the regression wave (serial_section<1> of ci_kernels.h with
 // the replayed draw).  Returns through cx / scal / R.w as there.
+template <class PF>
 static __device__ __forceinline__ void serial_section5(SerialCtx* cx, const RegLds& R,
                                                        const float* red, float* scal, int it,
                                                        int lane, PriorCarry& pc, const double* gam,
                                                        const double* pre, const PreTables& tb,
-                                                       const PreState& ps) {
+                                                       const PreState& ps, PF& prof) {
   const int P = cx->P;
   {
     const int RS = 16 + 4;
@@ -286,11 +292,12 @@ static __device__ __forceinline__ void serial_section5(SerialCtx* cx, const RegL
       if (cx->out_weights && lane < P) cx->out_weights[o * P + lane] = R.w[lane];
     }
   }
+  prof.tick(20);
   if (it < cx->n_iter) {
     NoProf np;
     if (ps.valid && ps.S == pc.S)
       obs_scale = spike_slab_draw_pre(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, pc,
-                                      pre, tb, ps);
+                                      pre, tb, ps, prof);
     else
       obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, np,
                                        pc, pre);
@@ -320,8 +327,9 @@ __host__ __device__ inline LdsLayout5 make_layout5(int P, int D, int tpad) {
 }
 
 // 0 < P <= 16, X resident in LDS (the dispatch conditions of gibbs_kernel<D, L, 1>).
-template <int D, int L>
+template <int D, int L, bool PROF = false>
 __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
+  using PF = typename std::conditional<PROF, Prof, NoProf>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -434,11 +442,17 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
     ps.valid = 0; ps.S = 0ull; ps.n_sw = 0; ps.n_un = 0; ps.diag = 1.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ps.c[r] = 0.0;
+    PF rprof;     // slots 16.. : the regression wave's own budget (lane 0 of block 0)
+    rprof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && lane == 0);
     for (int it = 0; it <= n_iter; ++it) {
       __syncthreads();      // (B1) boundary exchange of the time waves
       __syncthreads();      // (B2) partial sums complete
-      serial_section5(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1), tb, ps);
+      rprof.tick(16);
+      serial_section5(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1), tb, ps,
+                      rprof);
+      rprof.tick(17);
       __syncthreads();      // (B3) scalars and weights of iteration `it` published
+      rprof.tick(18);
       if (it == n_iter) break;
       // the time waves now run dk_draw (three barriers); meanwhile: next iteration's matrix work
       int done = 0;
@@ -458,6 +472,7 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
       const double var_next = cx->obs_scale * cx->obs_scale;
       regression_precompute(R, P, var_next, pc.S, lane, tb, ps, sync);
       while (done < 3) { __syncthreads(); ++done; }
+      rprof.tick(19);
     }
     return;
   }
@@ -469,7 +484,8 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
   float* o_level = a.out_level ? a.out_level + chain_lin * a.S * T : nullptr;
   float* o_slope = a.out_slope ? a.out_slope + chain_lin * a.S * T : nullptr;
   float* o_traj = a.out_traj ? a.out_traj + chain_lin * a.S * T : nullptr;
-  NoProf prof;
+  PF prof;
+  prof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && tid == 0);
   for (int it = 0; it <= n_iter; ++it) {
     // ---- partial sums over the owned steps (targets use the CURRENT level)
     {
@@ -525,6 +541,7 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
     }
     const float so_prev = scal[SC_OBS_DK];
     __syncthreads();                                       // (B2)
+    prof.tick(0);
 
     // ---- while the regression wave is in its serial section: next iteration's gamma variates and
     // regression randomness, emission of iteration it-1, this iteration's Durbin-Koopman normals
@@ -577,7 +594,9 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
     const bool publish = a.progress != nullptr && it > a.W &&
                          ((it - a.W) % a.progress_every == 0 || it - a.W == a.S);
     if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows are in L2
+    prof.tick(2);
     __syncthreads();                                       // (B3)
+    prof.tick(1);
     if (publish) {
       const int done = it - a.W;
       {
@@ -627,6 +646,7 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
       }
     }
     Vec<D> x[L];
+    prof.tick(3);
     dk_draw<D, L>(md, resid, maskbits, rng, (uint32_t)it, tid, lane, wave, slots, x, prof, zl, zs, zo,
                   nullptr);                                // (B4) (B5) (B6)
 #pragma unroll

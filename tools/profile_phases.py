@@ -45,6 +45,14 @@ def main():
   for i, name in enumerate(SLOTS):
     print(f"  [{i:2d}] {name:34s} {cyc[i] / n_it:9.0f} cyc/iter  {100.0 * cyc[i] / top:5.1f} %")
   print(f"  total of phases 0-7: {top / n_it:.0f} cyc/iter")
+  if "kernel5" in sess.kernel_name():
+    print("  five-wave kernel: [1] = wait at (B3) for the regression wave, [2] = overlap work "
+          "(emit, normals) before it")
+    for i, name in ((16, "regression wave: idle until (B2)"), (17, "regression wave: serial section"),
+                    (18, "regression wave: wait at (B3)"), (19, "regression wave: precompute + dk barriers"),
+                    (20, "  serial: gather, scale draws, stores"), (21, "  serial: right-hand-side replay"),
+                    (22, "  serial: flip proposals"), (23, "  serial: sigma^2, weights replay")):
+      print(f"  [{i:2d}] {name:42s} {cyc[i] / n_it:9.0f} cyc/iter")
 
 
 if __name__ == "__main__":

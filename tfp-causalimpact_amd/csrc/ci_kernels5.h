@@ -448,9 +448,13 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
       __syncthreads();      // (B1) boundary exchange of the time waves
       __syncthreads();      // (B2) partial sums complete
       rprof.tick(16);
+      // the serial section is the critical path of the iteration and shares its SIMD with one of
+      // the time waves, which has slack until (B3): win the issue arbitration while it lasts
+      __builtin_amdgcn_s_setprio(3);
       serial_section5(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1), tb, ps,
                       rprof);
       rprof.tick(17);
+      __builtin_amdgcn_s_setprio(0);
       __syncthreads();      // (B3) scalars and weights of iteration `it` published
       rprof.tick(18);
       if (it == n_iter) break;
@@ -478,6 +482,9 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
   }
 
   // ==================================== time waves =============================================
+  // above the regression wave's precompute (priority 0), below its serial section (3): the wave
+  // that shares a SIMD with it must not be held up during the Durbin-Koopman draw
+  __builtin_amdgcn_s_setprio(1);
   float lev[L], slp[L], xw[L], pm_acc[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) { lev[l] = 0.f; slp[l] = 0.f; xw[l] = 0.f; pm_acc[l] = 0.f; }  // :580-581

@@ -482,7 +482,13 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     // latency build: a fifth wavefront owns the regression section and sweeps the next
     // iteration's matrix during the Durbin-Koopman draw (same draws, bit for bit)
     const size_t lds5 = ci::make_layout5(P, D, ci::NT * s->L).total;
-    if (pm == 1 && !(pb->flags & CI_FLAG_FOUR_WAVES) && lds5 <= 150 * 1024) {
+    // ... when every chain has a compute unit to itself: five 256-register wavefronts leave room
+    // for ONE workgroup per CU, the four-wave kernel for two, so launches with more workgroups
+    // than CUs (batches of series: throughput, not latency) keep the four-wave kernel
+    int num_cus = 256;
+    (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, pb->device);
+    const bool latency_regime = (long long)B * C <= (long long)num_cus;
+    if (pm == 1 && latency_regime && !(pb->flags & CI_FLAG_FOUR_WAVES) && lds5 <= 150 * 1024) {
       KernelFn f5 = pick_kernel5(D, s->L, 0);
       if (f5) {
         s->fn = f5;

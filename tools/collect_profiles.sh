@@ -1,19 +1,38 @@
 #!/bin/bash
 # Collects the evidence committed under profiles/ for one round (run on the GPU box through
-# gpurun from the repo root):   tools/collect_profiles.sh <tag>      e.g. r01_c
-# rocprofv3 runs from /tmp with TMPDIR=/tmp; PMC counters are collected in their own passes.
+# gpurun from the repo root):   tools/collect_profiles.sh <tag>      e.g. r02_f
+# rocprofv3 runs from /tmp with TMPDIR=/tmp; PMC counters are collected in their own passes
+# (never together with trace domains).
 set -u
-TAG=${1:-r01_c}
+TAG=${1:-r02_f}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --steps 5 --warmup 1 > "$OUT/trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_write.log" 2>&1
+B="python $ROOT/bench.py"
+SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+# ---- cfg2 (bench line)
+timeout 600 $B > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $B --no-cpu-baseline --steps 5 --warmup 1 > "$OUT/trace.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $B --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $B --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_write.log" 2>&1
+timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/pmc_sq" -o bench -- $B --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_sq.log" 2>&1
+# ---- cfg3 (HMC)
+timeout 600 $B --sampler hmc > "$OUT/bench_hmc.json" 2> "$OUT/bench_hmc.err"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hmc_trace" -o hmc -- $B --no-cpu-baseline --sampler hmc --steps 2 --warmup 1 > "$OUT/hmc_trace.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/hmc_pmc_fetch" -o hmc -- $B --no-cpu-baseline --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/hmc_pmc_write" -o hmc -- $B --no-cpu-baseline --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_write.log" 2>&1
+timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/hmc_pmc_sq" -o hmc -- $B --no-cpu-baseline --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_sq.log" 2>&1
 cd "$ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_e2e" -o e2e -- python tools/time_end_to_end.py > "$OUT/e2e.log" 2>&1
-python tools/profile_phases.py > "$OUT/phase_cycles.txt" 2>&1
-python tools/run_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
-find "$OUT" -name "*.csv" | head -40
+# ---- cfg4 / cfg5
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg_trace" -o cfg -- python tools/run_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cfg_pmc_fetch" -o cfg -- python tools/run_configs.py cfg4 > "$OUT/cfg_pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cfg_pmc_write" -o cfg -- python tools/run_configs.py cfg4 > "$OUT/cfg_pmc_write.log" 2>&1
+timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/cfg_pmc_sq" -o cfg -- python tools/run_configs.py cfg4 > "$OUT/cfg_pmc_sq.log" 2>&1
+# ---- end-to-end fit_causalimpact, phase budgets, RCCL single-rank run
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_e2e" -o e2e -- python tools/time_end_to_end.py > "$OUT/e2e.log" 2>&1
+timeout 200 python tools/profile_phases.py > "$OUT/phase_cycles.txt" 2>&1
+timeout 200 python tools/profile_wide.py > "$OUT/cfg4_phase_cycles.txt" 2>&1
+CI_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --no-cpu-baseline --steps 5 > "$OUT/bench_force_dist.json" 2> "$OUT/bench_force_dist.err"
+find "$OUT" -name "*.csv" | wc -l
+tail -1 "$OUT/bench.json" | cut -c1-400

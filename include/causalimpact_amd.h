@@ -87,6 +87,10 @@ typedef struct ci_problem {
  * be chosen.  Same sampler and random stream (draws agree to float32 round-off); test /
  * diagnostic knob. */
 #define CI_FLAG_FOUR_WAVES 4
+/* Sequential seasonal kernel: keep its arrays over time in the per-chain HBM workspace even when
+ * they would fit in LDS (the library does so by itself for long series / many covariates).
+ * Test / diagnostic knob. */
+#define CI_FLAG_SEASONAL_WORKSPACE 8
 
 /* Caller-allocated result buffers (float32, chain-major so per-device shards
  * are contiguous).  == GibbsSamplerState stack + (means, trajectories) returned

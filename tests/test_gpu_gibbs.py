@@ -391,3 +391,66 @@ def test_five_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, B
   if p >= 5:   # inclusion patterns do change during the run: the fall-back route is exercised
     incl = (w != 0)
     assert (incl[:, :, 1:] != incl[:, :, :-1]).any()
+
+
+REF_SEASONS = ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))
+WS = _native.FLAG_SEASONAL_WORKSPACE
+
+
+@pytest.mark.parametrize("T,p,has_slope,seasons,flags", [
+    (300, 3, 0, REF_SEASONS, WS),            # the reference's 4+7+6 test model, arrays in HBM
+    (300, 20, 0, REF_SEASONS, 0),            # P = 21 > 16: LDS one-wavefront regression block
+    (2500, 12, 1, REF_SEASONS, 0),           # beyond the LDS bound of round 1 (T <~ 890 at D = 18)
+    (5000, 30, 0, ((12, 30),), 0),           # a 12-season block (not on the time-parallel kernel), P = 31
+])
+def test_general_seasonal_models_beyond_the_lds_bound_match_oracle_per_draw(T, p, has_slope, seasons,
+                                                                           flags):
+  """Models other than trend + one 2..7-season block: the one-wavefront sequential kernel with
+  its arrays over time in the per-chain HBM workspace (any length) and, for P > 16, the
+  LDS-resident regression block -- the reference's own 4+7+6-season model
+  (causalimpact_lib_test.py:740-752) with covariates at lengths round 1 rejected."""
+  from causalimpact import _model
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
+  rng = np.random.default_rng(0)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0) + 0.1 * rng.normal(size=T)
+  mask = mask.copy()
+  mask[[2, 3, 40, T // 2]] = True
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
+  counts, flg = _model.expand_seasons(seasons, T)
+  S, K = 3, len(seasons)
+  pb = _native.make_problem(T=T, P=spec["P"], has_slope=has_slope, num_seasons=counts,
+                            num_warmup=0, num_results=S, seed=(2, 6), flags=flags)
+  sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+  assert "gibbs_seasonal_kernel" in sess.kernel_name()
+  if flags & WS or T > 1000:
+    assert "<true>" in sess.kernel_name()
+  sess.run()
+  got = sess.fetch()
+  sess.close()
+  w = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=0, seed=(2, 6))
+  tol = 5e-3 + 2e-3 * float(np.ptp(w["level"]))
+  np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=tol)
+  np.testing.assert_allclose(got["seasonal_levels"][0, 0], w["seasonal"], atol=tol)
+  np.testing.assert_allclose(got["seasonal_drift_scales"][0, 0], w["drift_scales"], rtol=2e-2)
+  np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=5e-3)
+  np.testing.assert_allclose(got["level_scale"][0, 0], w["level_scale"], rtol=5e-3)
+  np.testing.assert_array_equal(got["weights"][0, 0] != 0, w["weights"] != 0)
+  np.testing.assert_allclose(got["weights"][0, 0], w["weights"], atol=5e-3)
+  np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=2 * tol)
+  assert got["seasonal_levels"].shape == (1, 1, S, T, K)
+
+
+def test_seasonal_kernel_with_arrays_in_hbm_equals_the_lds_variant():
+  """Same kernel source, arrays over time in LDS vs in the HBM workspace: identical draws."""
+  from causalimpact import _model
+  T, p = 200, 4
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 9)
+  spec = orc.default_spec(y, mask, X, seasons=REF_SEASONS)
+  counts, flg = _model.expand_seasons(REF_SEASONS, T)
+  out = []
+  for flags in (0, WS):
+    pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_seasons=counts, num_warmup=5,
+                              num_results=20, num_chains=2, seed=(3, 3), flags=flags)
+    out.append(_native.fit_gibbs(pb, y[None], mask[None], X[None], flg, _native.make_params([spec])))
+  for k, v in out[0].items():
+    np.testing.assert_array_equal(out[1][k], v, err_msg=k)

@@ -176,6 +176,7 @@ def make_params(specs: Sequence[Dict]) -> "C.Array":
 FLAG_SEQUENTIAL_SEASONAL = 1   # == CI_FLAG_SEQUENTIAL_SEASONAL
 FLAG_SHARED_SERIES_STREAMS = 2  # == CI_FLAG_SHARED_SERIES_STREAMS
 FLAG_FOUR_WAVES = 4             # == CI_FLAG_FOUR_WAVES
+FLAG_SEASONAL_WORKSPACE = 8     # == CI_FLAG_SEASONAL_WORKSPACE
 
 
 def make_problem(*, T, P, has_slope, num_seasons=(), num_warmup, num_results, num_chains=1,

@@ -20,7 +20,7 @@
 #include "ci_summary.h"
 #include "ci_hmc.h"
 
-extern "C" void* ci_gibbs_seasonal_fn(void);
+extern "C" void* ci_gibbs_seasonal_fn(int);
 #define CI_WIDE_DECL(NS)                                  \
   extern "C" void* ci_gibbs_wide_fn_tr1_ns##NS(void);     \
   extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);
@@ -300,6 +300,8 @@ struct ci_session {
   DevBuf<float> p1_chol, o_drift, o_seasonal;
   // time-parallel seasonal kernel
   bool wide = false;
+  bool seasonal_gws = false;           // sequential seasonal kernel with its arrays over time in HBM
+  size_t seasonal_ws_bytes = 0;
   int Lc = 0;
   DevBuf<float> ws;
   // on-device summarisation (ci_summary.h)
@@ -409,7 +411,6 @@ static int validate(const ci_problem* pb) {
         return fail("T=%d exceeds the time-parallel seasonal path (max %d)", pb->T, ci::NT * ci::WIDE_MAX_LC);
     } else {
       if (dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
-      if (pb->P > 16) return fail("this seasonal model supports P <= 16 on the device path, got %d", pb->P);
     }
   }
   if (pb->num_warmup < 0 || pb->num_results < 1) return fail("need num_warmup >= 0, num_results >= 1");
@@ -511,16 +512,24 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       s->Lc = wide_steps_per_thread(T);
       s->lds_bytes = ci::make_wlayout(P, s->dred).total;
       s->fn = (KernelFn)pick_wide_kernel(pb->has_slope, pb->num_seasons[0]);
-    } else
-      s->lds_bytes = ci::make_slayout(T, P, K, s->D_full, s->dred, pb->has_slope).total;
-    if (s->lds_bytes > 160 * 1024) {
-      return fail("seasonal model needs %zu bytes of LDS per chain (max 163840): reduce T",
-                  s->lds_bytes);
+    } else {
+      // arrays over time in LDS when the whole layout fits (fastest), else in a per-chain HBM
+      // workspace: no bound on the series length, and room in LDS for the P > 16 regression block
+      const ci::SLayout in_lds = ci::make_slayout(T, P, K, s->D_full, s->dred, pb->has_slope, 0);
+      s->seasonal_gws = in_lds.total > 150 * 1024 || (pb->flags & CI_FLAG_SEASONAL_WORKSPACE) != 0;
+      const ci::SLayout lay = ci::make_slayout(T, P, K, s->D_full, s->dred, pb->has_slope,
+                                               s->seasonal_gws ? 1 : 0);
+      s->lds_bytes = lay.total;
+      s->seasonal_ws_bytes = (lay.t_total + 255) & ~(size_t)255;
     }
-    if (!s->wide) s->fn = (KernelFn)ci_gibbs_seasonal_fn();
+    if (s->lds_bytes > 160 * 1024) {
+      return fail("seasonal model needs %zu bytes of LDS per chain (max 163840): fewer covariates "
+                  "or a narrower seasonal state", s->lds_bytes);
+    }
+    if (!s->wide) s->fn = (KernelFn)ci_gibbs_seasonal_fn(s->seasonal_gws ? 1 : 0);
     char nm[96];
     if (s->wide) snprintf(nm, sizeof(nm), "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
-    else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel");
+    else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel<%s>", s->seasonal_gws ? "true" : "false");
     s->kernel_name = nm;
   }
   HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -557,6 +566,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       HIP_TRY(s->o_seasonal.alloc(BCS * T * K));
     }
     if (s->wide) HIP_TRY(s->ws.alloc((size_t)B * C * ci::wide_workspace_floats(s->dred, s->Lc)));
+    else if (s->seasonal_gws) HIP_TRY(s->ws.alloc((size_t)B * C * (s->seasonal_ws_bytes / sizeof(float))));
     HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
     std::vector<ci::DevSeasonalParams> ssh(B);
     std::vector<float> ch((size_t)B * s->dred * s->dred, 0.f);

@@ -46,26 +46,36 @@ struct SArgs {
 };
 
 struct SLayout {
-  size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, Pa, Pb, pzv, zi, x0r, mask,
-      cbits, egg, emeta, d2, xtx, omega, bvec, w, total;
+  // arrays over time (LDS when they fit, else the per-chain HBM workspace)
+  size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, mask, cbits, t_total;
+  // always in LDS
+  size_t Pa, Pb, pzv, zi, x0r, egg, emeta, d2, xtx, omega, bvec, w,
+      aug0, pri0, chol, zv, uperm, nz, perm, idx, total;
 };
 
+// global_ws: the arrays over time live in a per-chain HBM workspace (offsets from its base,
+// t_total bytes) instead of LDS, which removes the LDS bound on the series length; the
+// LDS-resident one-wavefront regression block of P > 16 needs its buffers in LDS as well.
 __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int dred,
-                                                int has_slope) {
+                                                int has_slope, int global_ws = 0) {
   SLayout l;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
   const size_t TS = (size_t)((T + 3) & ~3);
   const size_t Tf = sizeof(float) * TS;
   const int Pp = P > 0 ? P : 1, Kp = K > 0 ? K : 1;
+  const bool big = P > 16;
   l.xtx = take(sizeof(double) * Pp * Pp);
   l.omega = take(sizeof(double) * Pp * Pp);
   l.bvec = take(sizeof(double) * (Pp + 4));
-  l.yv = take(Tf); l.lev = take(Tf); l.slp = take(has_slope ? Tf : 16); l.xw = take(Tf);
-  l.ytil = take(Tf); l.vf = take(Tf); l.zl = take(Tf); l.zs = take(has_slope ? Tf : 16);
-  l.zo = take(Tf);
-  l.seas = take(Tf * Kp); l.zk = take(Tf * Kp); l.gd = take(Tf * Kp);
-  l.kf = take(sizeof(float) * (size_t)T * D); l.rs = take(sizeof(float) * (size_t)T * D);
+  l.aug0 = take(big ? sizeof(double) * sweep_padded((size_t)(Pp + 1) * (Pp + 1)) : 16);
+  l.pri0 = take(big ? sizeof(double) * sweep_padded((size_t)Pp * Pp) : 16);
+  l.chol = take(big ? sizeof(double) * Pp * Pp : 16);
+  l.zv = take(big ? sizeof(double) * Pp : 16);
+  l.uperm = take(big ? sizeof(double) * Pp : 16);
+  l.nz = take(big ? sizeof(int) * Pp : 16);
+  l.perm = take(big ? sizeof(int) * Pp : 16);
+  l.idx = take(big ? sizeof(int) * Pp : 16);
   l.Pa = take(sizeof(float) * D * D); l.Pb = take(sizeof(float) * D * D);
   l.pzv = take(sizeof(float) * D); l.zi = take(sizeof(float) * (dred + 1));
   l.x0r = take(sizeof(float) * (dred + 1));
@@ -73,12 +83,21 @@ __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int 
   l.emeta = take(sizeof(uint32_t) * D * D);
   l.d2 = take(sizeof(float) * SMAXK);
   l.w = take(sizeof(float) * (Pp > 16 ? Pp : 16));
+  const size_t lds_fixed = o;
+  if (global_ws) o = 0;
+  l.yv = take(Tf); l.lev = take(Tf); l.slp = take(has_slope ? Tf : 16); l.xw = take(Tf);
+  l.ytil = take(Tf); l.vf = take(Tf); l.zl = take(Tf); l.zs = take(has_slope ? Tf : 16);
+  l.zo = take(Tf);
+  l.seas = take(Tf * Kp); l.zk = take(Tf * Kp); l.gd = take(Tf * Kp);
+  l.kf = take(sizeof(float) * (size_t)T * D); l.rs = take(sizeof(float) * (size_t)T * D);
   l.mask = take(TS); l.cbits = take(TS);
-  l.total = o;
+  if (global_ws) { l.t_total = o; l.total = lds_fixed; }
+  else { l.t_total = 0; l.total = o; }
   return l;
 }
 
 #ifndef CI_SEASONAL_DECL_ONLY
+template <bool GWS>
 __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -98,26 +117,35 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       if (k < K) { D += nsz[k]; rr += nsz[k] - 1; }
     }
   }
-  const SLayout L = make_slayout(T, P, K, D, a.dred, a.has_slope);
-  float* yv = (float*)(smem + L.yv); float* lev = (float*)(smem + L.lev);
-  float* slp = (float*)(smem + L.slp); float* xw = (float*)(smem + L.xw);
-  float* ytil = (float*)(smem + L.ytil); float* vf = (float*)(smem + L.vf);
-  float* zl = (float*)(smem + L.zl); float* zs = (float*)(smem + L.zs);
-  float* zo = (float*)(smem + L.zo); float* seas = (float*)(smem + L.seas);
-  float* zk = (float*)(smem + L.zk); float* gd = (float*)(smem + L.gd);
-  float* kf = (float*)(smem + L.kf);
-  float* rs = (float*)(smem + L.rs); float* Pcur = (float*)(smem + L.Pa);
+  const SLayout L = make_slayout(T, P, K, D, a.dred, a.has_slope, GWS ? 1 : 0);
+  // the arrays over time: LDS, or (GWS) this chain's slice of the HBM workspace -- every access
+  // below is either one 16-byte row per 4 steps or lane-contiguous, and a chain only ever reads
+  // what it wrote, so the slice stays in this XCD's L2
+  unsigned char* tb_ = smem;
+  if constexpr (GWS) tb_ = reinterpret_cast<unsigned char*>(a.ws) + chain_lin * ((L.t_total + 255) & ~(size_t)255);
+  float* yv = (float*)(tb_ + L.yv); float* lev = (float*)(tb_ + L.lev);
+  float* slp = (float*)(tb_ + L.slp); float* xw = (float*)(tb_ + L.xw);
+  float* ytil = (float*)(tb_ + L.ytil); float* vf = (float*)(tb_ + L.vf);
+  float* zl = (float*)(tb_ + L.zl); float* zs = (float*)(tb_ + L.zs);
+  float* zo = (float*)(tb_ + L.zo); float* seas = (float*)(tb_ + L.seas);
+  float* zk = (float*)(tb_ + L.zk); float* gd = (float*)(tb_ + L.gd);
+  float* kf = (float*)(tb_ + L.kf);
+  float* rs = (float*)(tb_ + L.rs); float* Pcur = (float*)(smem + L.Pa);
   float* Pnxt = (float*)(smem + L.Pb); float* pzv = (float*)(smem + L.pzv);
   float* zi = (float*)(smem + L.zi); float* x0r = (float*)(smem + L.x0r);
   float* egg = (float*)(smem + L.egg); float* d2 = (float*)(smem + L.d2);
   uint32_t* emeta = (uint32_t*)(smem + L.emeta);   // i | si<<6 | j<<12 | sj<<18 | bi<<24 | bj<<28
-  uint8_t* msk = smem + L.mask; uint8_t* cbv = smem + L.cbits;
+  uint8_t* msk = tb_ + L.mask; uint8_t* cbv = tb_ + L.cbits;
   const int TS = (T + 3) & ~3;       // padded length of every T-array (4-step blocks)
   RegLds R;
   R.xtx = (double*)(smem + L.xtx); R.omega = (double*)(smem + L.omega);
   R.bvec = (double*)(smem + L.bvec); R.w = (float*)(smem + L.w);
-  R.aug[0] = R.aug[1] = R.pri[0] = R.pri[1] = R.chol = R.zv = R.uperm = nullptr;
-  R.nz = R.perm = R.idx = nullptr;
+  // P > 16: the LDS-resident one-wavefront regression block (spike_slab_draw) and its buffers
+  R.aug[0] = (double*)(smem + L.aug0); R.aug[1] = R.aug[0];
+  R.pri[0] = (double*)(smem + L.pri0); R.pri[1] = R.pri[0];
+  R.chol = (double*)(smem + L.chol); R.zv = (double*)(smem + L.zv);
+  R.uperm = (double*)(smem + L.uperm);
+  R.nz = (int*)(smem + L.nz); R.perm = (int*)(smem + L.perm); R.idx = (int*)(smem + L.idx);
 
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
@@ -181,7 +209,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     emeta[e] = (uint32_t)i | ((uint32_t)si << 6) | ((uint32_t)j << 12) | ((uint32_t)sj << 18) |
                ((uint32_t)bi << 24) | ((uint32_t)bj << 28);
   }
-  if (lane < 16) R.w[lane] = 0.f;
+  for (int j = lane; j < (P > 16 ? P : 16); j += 64) R.w[j] = 0.f;
   wave_sync();
   double n_changes[SMAXK];
 #pragma unroll
@@ -339,7 +367,10 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     if (it == n_iter) break;
     if (P > 0) {
       const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
-      obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
+      if (P <= 16)
+        obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
+      else
+        obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, it == 0);
     }
     wave_sync();
     prof.tick(21);

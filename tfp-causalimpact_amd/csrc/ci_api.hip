@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/causalimpact_amd.h"
@@ -234,6 +235,14 @@ std::mutex g_host_mu;
 std::vector<HostEntry> g_host_pool;       // parked (free) buffers
 std::vector<HostEntry> g_host_live;       // handed out
 size_t g_host_pool_bytes = 0;
+
+template <class T> struct DevBuf;
+// Releases the listed buffers when an entry point leaves through any path (HIP_TRY returns early).
+template <class... B> struct BufGuard {
+  std::tuple<B*...> bufs;
+  explicit BufGuard(B*... b) : bufs(b...) {}
+  ~BufGuard() { std::apply([](auto*... b) { (b->release(), ...); }, bufs); }
+};
 
 template <class T> struct DevBuf {
   T* p = nullptr;
@@ -1016,6 +1025,7 @@ int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t ite
   HIP_TRY(hipSetDevice(device));
   DevBuf<float> du, dn;
   DevBuf<double> dg;
+  BufGuard<DevBuf<float>, DevBuf<float>, DevBuf<double>> guard(&du, &dn, &dg);
   HIP_TRY(du.alloc(n));
   HIP_TRY(dn.alloc(2 * (size_t)n));
   HIP_TRY(dg.alloc(1));
@@ -1026,7 +1036,6 @@ int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t ite
   HIP_TRY(hipMemcpy(uniforms, du.p, n * sizeof(float), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(normals, dn.p, 2 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(gamma_draw, dg.p, sizeof(double), hipMemcpyDeviceToHost));
-  du.release(); dn.release(); dg.release();
   return 0;
 }
 
@@ -1352,6 +1361,7 @@ int ci_test_dk_draw(const ci_problem* pb, const ci_series_params* params, const 
   const int T = pb->T, D = pb->has_slope ? 2 : 1, L = steps_per_thread(T);
   DevBuf<float> dres, dout;
   DevBuf<uint8_t> dmask;
+  BufGuard<DevBuf<float>, DevBuf<float>, DevBuf<uint8_t>> guard(&dres, &dout, &dmask);
   HIP_TRY(dres.alloc(T));
   HIP_TRY(dmask.alloc(T));
   HIP_TRY(dout.alloc((size_t)T * D));
@@ -1373,7 +1383,6 @@ const ci_series_params* q = params;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out_latents, dout.p, (size_t)T * D * sizeof(float), hipMemcpyDeviceToHost));
-  dres.release(); dmask.release(); dout.release();
   return 0;
 }
 

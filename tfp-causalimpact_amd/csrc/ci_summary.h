@@ -134,9 +134,47 @@ __global__ __launch_bounds__(256) void summ_select_kernel(int N, int T, int R,
     for (int i = tid; i < N; i += 256) buf[i] = x[i];
     x = buf;
   }
-  if (tid < R) { prefix[tid] = 0ull; krem[tid] = (unsigned)ranks[tid]; }
-  for (int pass = 0; pass < 8; ++pass) {
+  // The keys of one row share their leading bytes (sign, exponent, often the top mantissa bits
+  // of similar doubles): the digit sweeps start at the first byte in which the row's smallest and
+  // largest key differ -- typically 2-3 of the 8 sweeps are skipped.
+  __shared__ unsigned long long kext[2][4];
+  {
+    if (stage_row) __syncthreads();
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    for (int i = tid; i < N; i += 256) {
+      const unsigned long long key = summ_key(x[i]);
+      kmin = key < kmin ? key : kmin;
+      kmax = key > kmax ? key : kmax;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
+      kmin = a < kmin ? a : kmin;
+      kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { kext[0][wave] = kmin; kext[1][wave] = kmax; }
+    __syncthreads();
+  }
+  int first_pass = 0;
+  unsigned long long common = 0ull;
+  {
+    unsigned long long kmin = kext[0][0], kmax = kext[1][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      kmin = kext[0][w] < kmin ? kext[0][w] : kmin;
+      kmax = kext[1][w] > kmax ? kext[1][w] : kmax;
+    }
+    const unsigned long long diff = kmin ^ kmax;
+    first_pass = diff == 0ull ? 8 : (__clzll((long long)diff) >> 3);
+    common = first_pass == 0 ? 0ull : (kmin & (~0ull << (64 - 8 * first_pass)));
+  }
+  if (tid < R) { prefix[tid] = common; krem[tid] = (unsigned)ranks[tid]; }
+  __syncthreads();
+  for (int pass = first_pass; pass < 8; ++pass) {
     const int shift = 56 - 8 * pass;
+    // wave-aggregated counting pays while the digits are concentrated (the first sweeps after
+    // the common prefix); the low mantissa bytes are uniform and take plain atomics
+    const int agg_rounds = pass < first_pass + 2 ? 2 : 0;
     const unsigned long long mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
     for (int e = tid; e < R * 256; e += 256) (&hist[0][0])[e] = 0u;
     __syncthreads();
@@ -164,8 +202,7 @@ __global__ __launch_bounds__(256) void summ_select_kernel(int N, int T, int R,
         // The leading digits of similar doubles are identical (sign, exponent): almost every lane
         // hits the same bin.  Two rounds of wave-aggregated counting take the dominant bins with
         // one atomic each; whatever is left is spread out and uses plain atomics.
-#pragma unroll
-        for (int round = 0; round < 2; ++round) {
+        for (int round = 0; round < agg_rounds; ++round) {
           const unsigned long long act = __ballot(todo);
           if (act == 0ull) break;
           const int leader = __ffsll((long long)act) - 1;

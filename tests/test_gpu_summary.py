@@ -100,3 +100,43 @@ def test_host_pooled_draws_are_summarised_on_device_too():
         summarize_on_device=False, **opts))
     _assert_frames_equal(dev.series, host.series)
     _assert_frames_equal(dev.summary, host.summary)
+
+
+def _numpy_summary(traj, scale, shift, obs, flags, ranks):
+  value = traj.astype(np.float64) * scale + shift                 # [N, T]
+  point = -(value - obs[None, :])
+  base = np.where(((flags & 1) == 0)[None, :], 0.0, point)
+  holes = np.isnan(base)
+  cum = np.cumsum(np.where(holes, 0.0, base), axis=1)
+  cum[holes] = np.nan
+  return np.sort(value, axis=0)[ranks], np.sort(cum, axis=0)[ranks]
+
+
+@pytest.mark.parametrize("N", [1, 2, 615, 1024, 1025, 8000, 8192, 8193, 12345, 16384, 16385, 20000])
+def test_select_is_exact_for_every_row_length_and_awkward_rows(N):
+  """The order statistics are bit-equal to numpy's sort for every code path of the select
+  (registers with 8 / 16 keys per thread, long rows from L2) and for rows built to stress it:
+  constant rows, heavy ties, two-valued rows, one huge outlier, mixed signs and +-0, tiny spreads
+  around a large mean (keys sharing 40+ leading bits), wide dynamic range."""
+  T = 24
+  rng = np.random.default_rng(N)
+  traj = rng.normal(size=(N, T)).astype(np.float32)
+  traj[:, 1] = 3.25                                               # constant row
+  traj[:, 2] = rng.integers(0, 4, size=N)                         # heavy ties
+  traj[:, 3] = np.where(rng.random(N) < 0.5, -1.0, 1.0)           # two values, mixed sign
+  traj[:, 4] = rng.normal(size=N) * 1e-3 + 1000.0                 # tiny spread, large mean
+  traj[:, 5] = rng.normal(size=N); traj[0, 5] = 1e30              # one outlier stretches the range
+  traj[:, 6] = np.where(rng.random(N) < 0.5, -0.0, 0.0)           # +-0
+  traj[:, 7] = np.exp(rng.normal(size=N) * 8)                     # 50 binades
+  traj[:, 8] = -np.exp(rng.normal(size=N) * 8)
+  traj[:, 9] = rng.normal(size=N) * 1e-30                         # near-denormal floats
+  traj[:, 10] = np.round(rng.normal(size=N) * 3)                  # ties around zero, both signs
+  traj[:, 11] = np.where(rng.random(N) < 0.999, 5.0, rng.normal(size=N))   # almost constant
+  obs = rng.normal(size=T)
+  obs[13] = np.nan
+  flags = (np.arange(T) >= 6).astype(np.uint8) * 3
+  ranks = sorted({0, N // 40, N // 2, (N - 1) // 2, N - 1 - N // 40, N - 1, min(N - 1, 1), max(0, N - 2)})
+  got = _native.summarize_draws(traj, 1.0, 0.0, obs, flags, ranks)
+  want_value, want_cum = _numpy_summary(traj, 1.0, 0.0, obs, flags, np.asarray(ranks))
+  np.testing.assert_array_equal(got["value_order"], want_value)
+  np.testing.assert_array_equal(got["cum_order"], want_cum)

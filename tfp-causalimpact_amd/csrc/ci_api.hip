@@ -803,6 +803,30 @@ int ci_session_run_streamed(ci_session* s, ci_outputs* o, int32_t chunk_draws, f
   return 0;
 }
 
+// Order statistics of the rows of two [B*T, N] matrices in one launch.  Rows of up to 16384 values
+// (every fit_causalimpact shape: N = chains x draws) are selected from registers; longer rows by
+// the LDS / L2 digit sweeps of summ_select_kernel.
+#ifndef CI_SEL_NT
+#define CI_SEL_NT 256
+#endif
+static hipError_t launch_select(hipStream_t stream, int N, int T, int B, int R, const int* d_ranks,
+                                const double* M0, const double* M1, double* out0, double* out1) {
+  const int rows = B * T;
+  if (N <= 8192) {
+    hipLaunchKernelGGL((ci::summ_select_reg_kernel<CI_SEL_NT, 8192 / CI_SEL_NT>), dim3(2 * rows),
+                       dim3(CI_SEL_NT), 0, stream, N, T, R, rows, d_ranks, M0, M1, out0, out1);
+  } else if (N <= 16384) {
+    hipLaunchKernelGGL((ci::summ_select_reg_kernel<512, 32>), dim3(2 * rows), dim3(512), 0, stream,
+                       N, T, R, rows, d_ranks, M0, M1, out0, out1);
+  } else {
+    hipLaunchKernelGGL(ci::summ_select_kernel, dim3(rows), dim3(256), 0, stream, N, T, R, d_ranks,
+                       M0, out0);
+    hipLaunchKernelGGL(ci::summ_select_kernel, dim3(rows), dim3(256), 0, stream, N, T, R, d_ranks,
+                       M1, out1);
+  }
+  return hipGetLastError();
+}
+
 int ci_session_summarize(ci_session* s, const double* scale, const double* shift,
                          const double* observed, const uint8_t* flags, int32_t num_ranks,
                          const int32_t* ranks, double* value_order, double* cum_order,
@@ -835,19 +859,12 @@ int ci_session_summarize(ci_session* s, const double* scale, const double* shift
   HIP_TRY(hipMemcpyAsync(s->s_ranks.p, ranks, num_ranks * sizeof(int), hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(ci::summ_transpose_kernel, dim3((T + 63) / 64, (N + 63) / 64, B), dim3(64, 4), 0,
                      s->stream, N, T, s->o_traj.p, d_scale, d_shift, s->s_value.p);
-  hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s->stream, N, T,
+  hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 63) / 64, B), dim3(64), 0, s->stream, N, T,
                      s->s_value.p, s->s_obs.p, s->s_flags.p, s->s_cum.p, s->s_draw.p);
   double* ord_value = s->s_order.p;
   double* ord_cum = s->s_order.p + (size_t)B * ci::SUMM_MAX_RANKS * T;
-  const int stage = N <= ci::SUMM_STAGE_MAX_N ? 1 : 0;
-  const size_t stage_lds = stage ? (size_t)N * sizeof(double) : 0;
-  if (stage)
-    HIP_TRY(hipFuncSetAttribute((const void*)ci::summ_select_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(B * T), dim3(256), stage_lds, s->stream, N, T,
-                     num_ranks, s->s_ranks.p, s->s_value.p, ord_value, stage);
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(B * T), dim3(256), stage_lds, s->stream, N, T,
-                     num_ranks, s->s_ranks.p, s->s_cum.p, ord_cum, stage);
+  HIP_TRY(launch_select(s->stream, N, T, B, num_ranks, s->s_ranks.p, s->s_value.p, s->s_cum.p,
+                        ord_value, ord_cum));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
   const size_t ord_bytes = (size_t)B * num_ranks * T * sizeof(double);
@@ -903,19 +920,12 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
   CI_TRY_CLEAN(hipMemcpy(d_ranks.p, ranks, num_ranks * sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(ci::summ_transpose_kernel, dim3((T + 63) / 64, (N + 63) / 64, 1), dim3(64, 4), 0,
                      0, N, T, d_traj.p, d_obs.p + T, d_obs.p + T + 1, d_value.p);
-  hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, 0, N, T,
+  hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 63) / 64, 1), dim3(64), 0, 0, N, T,
                      d_value.p, d_obs.p, d_flags.p, d_cum.p, d_draw.p);
   double* ord_value = d_order.p;
   double* ord_cum = d_order.p + (size_t)ci::SUMM_MAX_RANKS * T;
-  const int stage = N <= ci::SUMM_STAGE_MAX_N ? 1 : 0;
-  const size_t stage_lds = stage ? (size_t)N * sizeof(double) : 0;
-  if (stage)
-    CI_TRY_CLEAN(hipFuncSetAttribute((const void*)ci::summ_select_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), stage_lds, 0, N, T, num_ranks,
-                     d_ranks.p, d_value.p, ord_value, stage);
-  hipLaunchKernelGGL(ci::summ_select_kernel, dim3(T), dim3(256), stage_lds, 0, N, T, num_ranks,
-                     d_ranks.p, d_cum.p, ord_cum, stage);
+  CI_TRY_CLEAN(launch_select(0, N, T, 1, num_ranks, d_ranks.p, d_value.p, d_cum.p, ord_value,
+                             ord_cum));
   CI_TRY_CLEAN(hipGetLastError());
   CI_TRY_CLEAN(hipDeviceSynchronize());
   const size_t ord_bytes = (size_t)num_ranks * T * sizeof(double);

@@ -172,18 +172,21 @@ int ci_session_destroy(ci_session* session);
  * 0-based order statistics over the N = C*S draws of a series (the caller interpolates
  * quantiles from them exactly as numpy does).  Outputs (host, caller-allocated, any may be NULL):
  *   value_order [B, num_ranks, T], cum_order [B, num_ranks, T],
- *   per_draw [B, 2, N]: sum over the window of value, and of point (NaN skipped). */
+ *   per_draw [B, 2, N]: sum over the window of value, and of point (NaN skipped),
+ *   per_draw_order [B, 2, num_ranks]: the same order statistics of those two rows of totals
+ *   (what the `summary` frame's bands interpolate: causalimpact_lib.py:1019-1075).
+ * Any output pointer may be NULL. */
 int ci_session_summarize(ci_session* session, const double* scale, const double* shift,
                          const double* observed, const uint8_t* flags, int32_t num_ranks,
                          const int32_t* ranks, double* value_order, double* cum_order,
-                         double* per_draw);
+                         double* per_draw, double* per_draw_order);
 /* The same summary for draws that are on the host (pooled from several devices / processes, or
  * produced by the HMC path): trajectories [num_draws, T] float32 are uploaded to `device`,
  * summarised there and the (one-series) results returned as above. */
 int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float* trajectories,
                        double scale, double shift, const double* observed, const uint8_t* flags,
                        int32_t num_ranks, const int32_t* ranks, double* value_order,
-                       double* cum_order, double* per_draw);
+                       double* cum_order, double* per_draw, double* per_draw_order);
 
 /* Kalman-filter log-likelihood of the trend + regression model for num_evals parameter sets
  * (the objective an HMC / VI fit would use; the reference never

@@ -128,3 +128,25 @@ def test_batch_with_a_weekly_seasonal_block_equals_separate_fits():
     one = ci.fit_causalimpact(f, pre, post, **kw)
     np.testing.assert_allclose(got.summary.loc[b].to_numpy(float), one.summary.to_numpy(float),
                                rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_batch_summary_bands_equal_the_host_quantiles_also_when_totals_straddle_zero():
+  """The batch summary interpolates device order statistics of the per-draw totals (monotone maps
+  for the mean / relative-effect bands); series whose predicted totals change sign take the
+  host sort.  Either way the frame equals the single-series one, which sorts on the host."""
+  T, B = 90, 4
+  frames = _frames(B, T, 1, seed=3)
+  frames[1]["y"] -= frames[1]["y"].iloc[:60].mean()                    # predicted totals around 0
+  frames[2] = -frames[2]                                                # negative totals
+  idx = frames[0].index
+  pre, post = (idx[0], idx[59]), (idx[60], idx[89])
+  opts = ci.InferenceOptions(num_results=200, num_chains=2)
+  got = ci.fit_causalimpact_batch(frames, pre, post, seed=11, inference_options=opts,
+                                  shared_streams=True)
+  totals = got._dsum["per_draw"][:, 0]                                 # pylint: disable=protected-access
+  assert totals[1].min() < 0 < totals[1].max() and totals[2].max() < 0 < totals[0].min()
+  for b, f in enumerate(frames):
+    one = ci.fit_causalimpact(f, pre, post, seed=11, inference_options=opts)
+    np.testing.assert_allclose(got.summary.loc[b].to_numpy(float), one.summary.to_numpy(float),
+                               rtol=2e-5, atol=1e-7)

@@ -71,6 +71,7 @@ def test_order_statistics_and_running_sums_match_numpy():
   win = (flags & 2) != 0
   np.testing.assert_array_equal(got["per_draw"][0], value.T[win].sum(axis=0))
   np.testing.assert_array_equal(got["per_draw"][1], np.nansum(point.T[win], axis=0))
+  np.testing.assert_array_equal(got["per_draw_order"], np.sort(got["per_draw"], axis=1)[:, ranks])
 
 
 def test_summarize_argument_errors():
@@ -140,3 +141,4 @@ def test_select_is_exact_for_every_row_length_and_awkward_rows(N):
   want_value, want_cum = _numpy_summary(traj, 1.0, 0.0, obs, flags, np.asarray(ranks))
   np.testing.assert_array_equal(got["value_order"], want_value)
   np.testing.assert_array_equal(got["cum_order"], want_cum)
+  np.testing.assert_array_equal(got["per_draw_order"], np.sort(got["per_draw"], axis=1)[:, ranks])

@@ -89,10 +89,11 @@ def load():
   L.ci_session_destroy.argtypes = [C.c_void_p]
   L.ci_session_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   L.ci_session_summarize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
   L.ci_summarize_draws.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
                                    C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_kalman_loglik.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
   L.ci_ll_session_create.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
@@ -222,10 +223,11 @@ def summarize_draws(trajectories, scale, shift, observed, flags, ranks, device=0
   vo = np.empty((rk.size, T), np.float64)
   co = np.empty((rk.size, T), np.float64)
   pd_ = np.empty((2, N), np.float64)
+  do = np.empty((2, rk.size), np.float64)
   _check(load().ci_summarize_draws(int(device), N, T, tr.ctypes.data, float(scale), float(shift),
                                    obs.ctypes.data, fl.ctypes.data, int(rk.size), rk.ctypes.data,
-                                   vo.ctypes.data, co.ctypes.data, pd_.ctypes.data))
-  return dict(value_order=vo, cum_order=co, per_draw=pd_)
+                                   vo.ctypes.data, co.ctypes.data, pd_.ctypes.data, do.ctypes.data))
+  return dict(value_order=vo, cum_order=co, per_draw=pd_, per_draw_order=do)
 
 
 class _PinnedBlock:
@@ -339,8 +341,8 @@ class Session:
   def summarize(self, scale, shift, observed, flags, ranks) -> Dict[str, np.ndarray]:
     """On-device order statistics / running effect sums of the pooled predictive draws of every
     series (ci_session_summarize).  scale, shift: scalars or [B]; observed, flags: [T] or [B,T].
-    Returns value_order [B,R,T], cum_order [B,R,T], per_draw [B,2,N] (leading axis dropped when
-    the session holds one series)."""
+    Returns value_order [B,R,T], cum_order [B,R,T], per_draw [B,2,N], per_draw_order [B,2,R]
+    (leading axis dropped when the session holds one series)."""
     B, T, N = self.pb.num_series, self.pb.T, self.pb.num_chains * self.pb.num_results
     sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, np.float64), (B,)))
     sh = np.ascontiguousarray(np.broadcast_to(np.asarray(shift, np.float64), (B,)))
@@ -350,12 +352,14 @@ class Session:
     vo = np.empty((B, rk.size, T), np.float64)
     co = np.empty((B, rk.size, T), np.float64)
     pd_ = np.empty((B, 2, N), np.float64)
+    do = np.empty((B, 2, rk.size), np.float64)
     _check(self._lib.ci_session_summarize(self._h, sc.ctypes.data, sh.ctypes.data, obs.ctypes.data,
                                           fl.ctypes.data, int(rk.size), rk.ctypes.data,
-                                          vo.ctypes.data, co.ctypes.data, pd_.ctypes.data))
+                                          vo.ctypes.data, co.ctypes.data, pd_.ctypes.data,
+                                          do.ctypes.data))
     if B == 1:
-      vo, co, pd_ = vo[0], co[0], pd_[0]
-    return dict(value_order=vo, cum_order=co, per_draw=pd_)
+      vo, co, pd_, do = vo[0], co[0], pd_[0], do[0]
+    return dict(value_order=vo, cum_order=co, per_draw=pd_, per_draw_order=do)
 
   def close(self):
     if self._h:

@@ -146,8 +146,36 @@ class CausalImpactBatchAnalysis:
       point_mean = np.where(n_obs[:, None] > 0, point_sum / np.maximum(n_obs, 1)[:, None], np.nan)
       rel = obs_sum[:, None] / pred_sum - 1.0
 
-      def band(x):
-        return np.quantile(x, quantiles, axis=1)
+      # The bands interpolate order statistics of the per-draw totals; the device returned
+      # those (per_draw_order), and every banded quantity is a monotone map of the totals, so
+      # its order statistics are the mapped ones -- no [B, draws] sort on the host.
+      ranks = list(self._ranks)
+      N = pred_sum.shape[1]
+      order = self._dsum.get("per_draw_order")
+      if order is None:
+        order = np.sort(self._dsum["per_draw"], axis=2)[:, :, ranks]
+      (lo_a, hi_a, g_a), (lo_b, hi_b, g_b) = lib._quantile_ranks(N, quantiles)   # pylint: disable=protected-access
+      lerp = lib._lerp_order_stats                                               # pylint: disable=protected-access
+
+      def band_of(by_rank):
+        return np.stack([lerp(by_rank, lo_a, hi_a, g_a), lerp(by_rank, lo_b, hi_b, g_b)])
+
+      pred_o = {r: order[:, 0, i] for i, r in enumerate(ranks)}
+      point_o = {r: order[:, 1, i] for i, r in enumerate(ranks)}
+      need = (lo_a, hi_a, lo_b, hi_b)
+      band_pred_sum, band_point_sum = band_of(pred_o), band_of(point_o)
+      band_pred_mean = band_of({k: pred_o[k] / n_win for k in need})
+      band_point_mean = band_of({k: np.where(n_obs > 0, point_o[k] / np.maximum(n_obs, 1), np.nan)
+                                 for k in need})
+      # rel = obs_sum / pred_sum - 1 is monotone in pred_sum on either side of zero: decreasing
+      # when obs_sum > 0 (its k-th smallest comes from the (N-1-k)-th smallest total), else
+      # increasing.  Series whose totals straddle zero take the sort.
+      down = obs_sum > 0
+      band_rel = band_of({k: np.where(down, obs_sum / pred_o[N - 1 - k], obs_sum / pred_o[k]) - 1.0
+                          for k in need})
+      straddle = ~((pred_sum.min(axis=1) > 0) | (pred_sum.max(axis=1) < 0))
+      if straddle.any():
+        band_rel[:, straddle] = np.quantile(rel[straddle], quantiles, axis=1)
 
       def sd(x):
         return np.std(x, axis=1, ddof=1)
@@ -156,16 +184,16 @@ class CausalImpactBatchAnalysis:
       cols = {
           "actual": (obs_mean, obs_sum),
           "predicted": (avg_pred, cum_pred),
-          "predicted_lower": (band(pred_mean)[0], band(pred_sum)[0]),
-          "predicted_upper": (band(pred_mean)[1], band(pred_sum)[1]),
+          "predicted_lower": (band_pred_mean[0], band_pred_sum[0]),
+          "predicted_upper": (band_pred_mean[1], band_pred_sum[1]),
           "predicted_sd": (sd(pred_mean), sd(pred_sum)),
           "abs_effect": (obs_mean - avg_pred, obs_sum - cum_pred),
-          "abs_effect_lower": (band(point_mean)[0], band(point_sum)[0]),
-          "abs_effect_upper": (band(point_mean)[1], band(point_sum)[1]),
+          "abs_effect_lower": (band_point_mean[0], band_point_sum[0]),
+          "abs_effect_upper": (band_point_mean[1], band_point_sum[1]),
           "abs_effect_sd": (sd(point_mean), sd(point_sum)),
           "rel_effect": (rel.mean(axis=1),) * 2,
-          "rel_effect_lower": (band(rel)[0],) * 2,
-          "rel_effect_upper": (band(rel)[1],) * 2,
+          "rel_effect_lower": (band_rel[0],) * 2,
+          "rel_effect_upper": (band_rel[1],) * 2,
           "rel_effect_sd": (sd(rel),) * 2,
       }
     pool_le = ((obs_sum[:, None] <= pred_sum).sum(axis=1) + 1) / (pred_sum.shape[1] + 1)

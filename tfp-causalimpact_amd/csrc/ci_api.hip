@@ -803,26 +803,28 @@ int ci_session_run_streamed(ci_session* s, ci_outputs* o, int32_t chunk_draws, f
   return 0;
 }
 
-// Order statistics of the rows of two [B*T, N] matrices in one launch.  Rows of up to 16384 values
-// (every fit_causalimpact shape: N = chains x draws) are selected from registers; longer rows by
-// the LDS / L2 digit sweeps of summ_select_kernel.
+// Order statistics of the rows of two [rows, N] matrices in one launch (M1 may be NULL: one
+// matrix); out[(row / T) * R + r][row % T].  Rows of up to 16384 values (every fit_causalimpact
+// shape: N = chains x draws) are selected from registers; longer rows by the L2 digit sweeps of
+// summ_select_kernel.
 #ifndef CI_SEL_NT
 #define CI_SEL_NT 256
 #endif
-static hipError_t launch_select(hipStream_t stream, int N, int T, int B, int R, const int* d_ranks,
+static hipError_t launch_select(hipStream_t stream, int N, int T, int rows, int R, const int* d_ranks,
                                 const double* M0, const double* M1, double* out0, double* out1) {
-  const int rows = B * T;
+  const int grid = M1 ? 2 * rows : rows;
   if (N <= 8192) {
-    hipLaunchKernelGGL((ci::summ_select_reg_kernel<CI_SEL_NT, 8192 / CI_SEL_NT>), dim3(2 * rows),
+    hipLaunchKernelGGL((ci::summ_select_reg_kernel<CI_SEL_NT, 8192 / CI_SEL_NT>), dim3(grid),
                        dim3(CI_SEL_NT), 0, stream, N, T, R, rows, d_ranks, M0, M1, out0, out1);
   } else if (N <= 16384) {
-    hipLaunchKernelGGL((ci::summ_select_reg_kernel<512, 32>), dim3(2 * rows), dim3(512), 0, stream,
+    hipLaunchKernelGGL((ci::summ_select_reg_kernel<512, 32>), dim3(grid), dim3(512), 0, stream,
                        N, T, R, rows, d_ranks, M0, M1, out0, out1);
   } else {
     hipLaunchKernelGGL(ci::summ_select_kernel, dim3(rows), dim3(256), 0, stream, N, T, R, d_ranks,
                        M0, out0);
-    hipLaunchKernelGGL(ci::summ_select_kernel, dim3(rows), dim3(256), 0, stream, N, T, R, d_ranks,
-                       M1, out1);
+    if (M1)
+      hipLaunchKernelGGL(ci::summ_select_kernel, dim3(rows), dim3(256), 0, stream, N, T, R, d_ranks,
+                         M1, out1);
   }
   return hipGetLastError();
 }
@@ -830,7 +832,7 @@ static hipError_t launch_select(hipStream_t stream, int N, int T, int B, int R, 
 int ci_session_summarize(ci_session* s, const double* scale, const double* shift,
                          const double* observed, const uint8_t* flags, int32_t num_ranks,
                          const int32_t* ranks, double* value_order, double* cum_order,
-                         double* per_draw) {
+                         double* per_draw, double* per_draw_order) {
   if (!s || !scale || !shift || !observed || !flags || !ranks) return fail("NULL argument");
   if (!s->ran) return fail("ci_session_summarize needs a finished ci_session_run");
   const ci_problem& pb = s->pb;
@@ -848,7 +850,7 @@ int ci_session_summarize(ci_session* s, const double* scale, const double* shift
     HIP_TRY(s->s_flags.alloc((size_t)B * T));
     HIP_TRY(s->s_ranks.alloc(ci::SUMM_MAX_RANKS));
     HIP_TRY(s->s_order.alloc((size_t)2 * B * ci::SUMM_MAX_RANKS * T));
-    HIP_TRY(s->s_draw.alloc((size_t)B * 2 * N));
+    HIP_TRY(s->s_draw.alloc((size_t)B * 2 * N + (size_t)B * 2 * ci::SUMM_MAX_RANKS));
   }
   double* d_scale = s->s_obs.p + (size_t)B * T;
   double* d_shift = d_scale + B;
@@ -863,8 +865,12 @@ int ci_session_summarize(ci_session* s, const double* scale, const double* shift
                      s->s_value.p, s->s_obs.p, s->s_flags.p, s->s_cum.p, s->s_draw.p);
   double* ord_value = s->s_order.p;
   double* ord_cum = s->s_order.p + (size_t)B * ci::SUMM_MAX_RANKS * T;
-  HIP_TRY(launch_select(s->stream, N, T, B, num_ranks, s->s_ranks.p, s->s_value.p, s->s_cum.p,
+  HIP_TRY(launch_select(s->stream, N, T, B * T, num_ranks, s->s_ranks.p, s->s_value.p, s->s_cum.p,
                         ord_value, ord_cum));
+  double* ord_draw = s->s_draw.p + (size_t)B * 2 * N;
+  if (per_draw_order)
+    HIP_TRY(launch_select(s->stream, N, 1, 2 * B, num_ranks, s->s_ranks.p, s->s_draw.p, nullptr,
+                          ord_draw, nullptr));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
   const size_t ord_bytes = (size_t)B * num_ranks * T * sizeof(double);
@@ -872,13 +878,16 @@ int ci_session_summarize(ci_session* s, const double* scale, const double* shift
   if (cum_order) HIP_TRY(hipMemcpy(cum_order, ord_cum, ord_bytes, hipMemcpyDeviceToHost));
   if (per_draw)
     HIP_TRY(hipMemcpy(per_draw, s->s_draw.p, (size_t)B * 2 * N * sizeof(double), hipMemcpyDeviceToHost));
+  if (per_draw_order)
+    HIP_TRY(hipMemcpy(per_draw_order, ord_draw, (size_t)B * 2 * num_ranks * sizeof(double),
+                      hipMemcpyDeviceToHost));
   return 0;
 }
 
 int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float* trajectories,
                        double scale, double shift, const double* observed, const uint8_t* flags,
                        int32_t num_ranks, const int32_t* ranks, double* value_order,
-                       double* cum_order, double* per_draw) {
+                       double* cum_order, double* per_draw, double* per_draw_order) {
   if (!trajectories || !observed || !flags || !ranks) return fail("NULL argument");
   if (num_draws < 1 || T < 1) return fail("need num_draws >= 1 and T >= 1");
   if (num_ranks < 1 || num_ranks > ci::SUMM_MAX_RANKS)
@@ -911,7 +920,7 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
   CI_TRY_CLEAN(d_flags.alloc(T));
   CI_TRY_CLEAN(d_ranks.alloc(ci::SUMM_MAX_RANKS));
   CI_TRY_CLEAN(d_order.alloc((size_t)2 * ci::SUMM_MAX_RANKS * T));
-  CI_TRY_CLEAN(d_draw.alloc((size_t)2 * N));
+  CI_TRY_CLEAN(d_draw.alloc((size_t)2 * N + 2 * ci::SUMM_MAX_RANKS));
   const double ss[2] = {scale, shift};
   CI_TRY_CLEAN(hipMemcpy(d_traj.p, trajectories, TN * sizeof(float), hipMemcpyHostToDevice));
   CI_TRY_CLEAN(hipMemcpy(d_obs.p, observed, T * sizeof(double), hipMemcpyHostToDevice));
@@ -924,8 +933,12 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
                      d_value.p, d_obs.p, d_flags.p, d_cum.p, d_draw.p);
   double* ord_value = d_order.p;
   double* ord_cum = d_order.p + (size_t)ci::SUMM_MAX_RANKS * T;
-  CI_TRY_CLEAN(launch_select(0, N, T, 1, num_ranks, d_ranks.p, d_value.p, d_cum.p, ord_value,
+  CI_TRY_CLEAN(launch_select(0, N, T, T, num_ranks, d_ranks.p, d_value.p, d_cum.p, ord_value,
                              ord_cum));
+  double* ord_draw = d_draw.p + (size_t)2 * N;
+  if (per_draw_order)
+    CI_TRY_CLEAN(launch_select(0, N, 1, 2, num_ranks, d_ranks.p, d_draw.p, nullptr, ord_draw,
+                               nullptr));
   CI_TRY_CLEAN(hipGetLastError());
   CI_TRY_CLEAN(hipDeviceSynchronize());
   const size_t ord_bytes = (size_t)num_ranks * T * sizeof(double);
@@ -933,6 +946,9 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
   if (cum_order) CI_TRY_CLEAN(hipMemcpy(cum_order, ord_cum, ord_bytes, hipMemcpyDeviceToHost));
   if (per_draw)
     CI_TRY_CLEAN(hipMemcpy(per_draw, d_draw.p, (size_t)2 * N * sizeof(double), hipMemcpyDeviceToHost));
+  if (per_draw_order)
+    CI_TRY_CLEAN(hipMemcpy(per_draw_order, ord_draw, (size_t)2 * num_ranks * sizeof(double),
+                           hipMemcpyDeviceToHost));
 #undef CI_TRY_CLEAN
   cleanup();
   return 0;

@@ -1077,7 +1077,7 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
                                                         const DevSeriesParams& sp,
                                                         double prev_obs_scale, double g_obs,
                                                         const Rng& rng, uint32_t iter, int tid,
-                                                        bool first) {
+                                                        bool first, Prof* prof = nullptr) {
   const int lane = tid & 63;
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
@@ -1106,8 +1106,10 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
     if (!all_in) R.uperm[tid] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)tid);
   }
   __syncthreads();
+  if (prof) prof->tick(4);
   for (unsigned long long todo = __ballot(nz0 != 0); todo; todo &= todo - 1ull)
     sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, first, tid, tmp);
+  if (prof) prof->tick(5);
   if (!all_in) {
     if (tid < P) {
       const double uj = R.uperm[tid];
@@ -1157,6 +1159,7 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       s_cur = s_star + 1;
     }
   }
+  if (prof) prof->tick(6);
   const double* A = R.aug[0];
   const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
   double var = beta_post / g_obs;
@@ -1173,8 +1176,12 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
     if (lane < P) R.w[lane] = 0.f;
   }
   __syncthreads();
-  // M_S = Omega_S * prev_var + XtX_S, then a left-looking Cholesky by wave 0: lane i owns row i
-  // (na <= 64), two wave barriers per column, reciprocal square roots instead of divisions
+  // M_S = Omega_S * prev_var + XtX_S, then a right-looking Cholesky by the whole workgroup, one
+  // barrier per column: the Schur-complement entries (i, j), k < j <= i, take their k-th term
+  // (the same products, in the same order, as a left-looking factorisation); column k of L goes
+  // to the UPPER triangle (row k) and its diagonal to ldiag, so that nothing a concurrent thread
+  // still reads is overwritten.  Reciprocal square roots instead of divisions.
+  double* ldiag = R.uperm;                 // (the permutation keys are no longer needed)
   for (int e = tid; e < na * na; e += NT) {
     const int i = e / na, j = e - i * na;
     const int fi = R.idx[i], fj = R.idx[j];
@@ -1182,32 +1189,38 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   }
   if (tid < na) R.zv[tid] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[tid]);
   __syncthreads();
-  if (tid < 64) {
-    for (int k = 0; k < na; ++k) {
-      double sdot = 0.0;
-      if (lane >= k && lane < na) {
-        sdot = R.chol[lane * na + k];
-        for (int j = 0; j < k; ++j) sdot -= R.chol[lane * na + j] * R.chol[k * na + j];
-      }
-      const double skk = readlane_d(sdot, k);
-      const double rs = fast_rsqrt(skk);
-      if (lane >= k && lane < na) R.chol[lane * na + k] = (lane == k) ? skk * rs : sdot * rs;
-      wave_sync();
+  for (int k = 0; k < na; ++k) {
+    const double skk = R.chol[k * na + k];
+    const double rs = fast_rsqrt(skk);
+    for (int i = k + 1 + (tid >> 4); i < na; i += NT / 16) {
+      const double lik = R.chol[i * na + k] * rs;
+      for (int j = k + 1 + (tid & 15); j <= i; j += 16)
+        R.chol[i * na + j] -= lik * (R.chol[j * na + k] * rs);
+      if ((tid & 15) == 0) R.chol[k * na + i] = lik;
     }
-    // solve L' u = z (column-oriented back substitution); u overwrites zv
+    if (tid == 0) ldiag[k] = skk * rs;
+    __syncthreads();
+  }
+  if (tid < 64) {
+    // solve L' u = z (column-oriented back substitution) in registers: lane l holds z_l
+    double z = lane < na ? R.zv[lane] : 0.0;
+    const double dl = lane < na ? ldiag[lane] : 1.0;
+    double u = 0.0;
+    double lnext = (na > 0 && lane < na - 1) ? R.chol[lane * na + (na - 1)] : 0.0;
     for (int i = na - 1; i >= 0; --i) {
-      const double ui = R.zv[i] * fast_rcp(R.chol[i * na + i]);
-      wave_sync();
-      if (lane == 0) R.zv[i] = ui;
-      if (lane < i) R.zv[lane] -= R.chol[i * na + lane] * ui;
-      wave_sync();
+      const double li = lnext;                          // L[i][lane] (stored at row lane, column i)
+      if (i > 0) lnext = lane < i - 1 ? R.chol[lane * na + (i - 1)] : 0.0;
+      const double ui = readlane_d(z, i) * fast_rcp(readlane_d(dl, i));
+      if (lane == i) u = ui;
+      if (lane < i) z -= li * ui;
     }
     if (lane < na) {
       const int f = R.idx[lane];
-      R.w[f] = (float)(A[f * n + P] + new_scale * R.zv[lane]);
+      R.w[f] = (float)(A[f * n + P] + new_scale * u);
     }
   }
   __syncthreads();
+  if (prof) prof->tick(7);
   return new_scale;
 }
 

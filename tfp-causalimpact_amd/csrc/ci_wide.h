@@ -985,7 +985,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     if (P > 16 && it < n_iter) {
       // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
       prof.tick(9);
-      obs_scale = spike_slab_draw_block(R, P, sp, st[0], st[1], rng, (uint32_t)it, tid, it == 0);
+      obs_scale = spike_slab_draw_block(R, P, sp, st[0], st[1], rng, (uint32_t)it, tid, it == 0, &prof);
       if (tid == 0) scal[0] = (float)obs_scale;
       __syncthreads();
       prof.tick(10);

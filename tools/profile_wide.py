@@ -30,7 +30,8 @@ sess.run()
 cyc = sess.profile(False)
 n = W + S
 names = {0: "(1) targets, X'targets, sums", 1: "(2) serial + regression block", 9: "   scale draws (wave 0)",
-         10: "   regression block (workgroup)", 2: "(3) emit", 3: "(4) X w, residual",
+         10: "   regression block (workgroup)", 4: "     build A", 5: "     sweeps of the active set",
+         6: "     flip proposals + sweeps", 7: "     Cholesky, solve, weights", 2: "(3) emit", 3: "(4) X w, residual",
          20: "dk (1) prior simulation + scan", 21: "dk (2) y~, chunk filter elements",
          22: "dk     filter scan (256 elements)", 23: "dk (3) local filter: gains",
          24: "dk (4) backward chunk maps", 25: "dk     backward scan", 26: "dk (5a) r through the chunk",
@@ -39,7 +40,8 @@ print(f"T={T} P={pb.P} chains={C}: {ms * 1e3 / n:.1f} us per iteration ({ms:.1f}
 tot = 0
 for k in sorted(names):
   print(f"  [{k:2d}] {names[k]:36s} {cyc[k] / n:10.0f} cycles / iteration")
-  if k not in (9, 10):
-    tot += cyc[k]
+  tot += cyc[k]
 print(f"  sum {tot / n:.0f} cycles / iteration")
+w = sess.fetch(["weights"])["weights"]
+print("  active features per draw:", float((w != 0).sum(axis=-1).mean()))
 sess.close()

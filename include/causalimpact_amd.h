@@ -91,6 +91,10 @@ typedef struct ci_problem {
  * they would fit in LDS (the library does so by itself for long series / many covariates).
  * Test / diagnostic knob. */
 #define CI_FLAG_SEASONAL_WORKSPACE 8
+/* Time-parallel seasonal kernel: one workgroup per chain even where the library would spread a
+ * chain's time-independent phases over a cluster of 2 or 4 CUs (few chains of a long series).
+ * Every cluster size gives the same bits; test / diagnostic knob. */
+#define CI_FLAG_NO_CLUSTER 16
 
 /* Caller-allocated result buffers (float32, chain-major so per-device shards
  * are contiguous).  == GibbsSamplerState stack + (means, trajectories) returned

@@ -454,3 +454,32 @@ def test_seasonal_kernel_with_arrays_in_hbm_equals_the_lds_variant():
     out.append(_native.fit_gibbs(pb, y[None], mask[None], X[None], flg, _native.make_params([spec])))
   for k, v in out[0].items():
     np.testing.assert_array_equal(out[1][k], v, err_msg=k)
+
+
+def test_clusters_of_workgroups_give_the_same_bits_as_one_workgroup_per_chain():
+  """Time-parallel seasonal kernel: a chain's X~'targets / emission / X w phases are shared by
+  4 or 2 workgroups when the launch leaves CUs idle (ci_wide.h "clusters").  The reductions run
+  over fixed segments, so every cluster size -- chosen from the number of chains -- and the
+  single-workgroup kernel produce identical draws."""
+  from causalimpact import _model
+  T, p, seasons, W, S = 4800, 20, ((7, 1),), 3, 6            # 3 segments of 2048 steps
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 5)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  mask = mask.copy()
+  mask[[5, 1000, 2047, 2048]] = True
+  spec = orc.default_spec(y, mask, X, has_slope=False, seasons=seasons)
+  counts, flg = _model.expand_seasons(seasons, T)
+
+  def fit(C, flags):
+    pb = _native.make_problem(T=T, P=spec["P"], has_slope=0, num_seasons=counts, num_warmup=W,
+                              num_results=S, num_chains=C, seed=(4, 2), flags=flags)
+    return _native.fit_gibbs(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+
+  one = fit(2, _native.FLAG_NO_CLUSTER)
+  four = fit(2, 0)                                            # 8 x 4 workgroups <= 256 CUs
+  two = fit(72, 0)                                            # 72 x 4 > 256 >= 72 x 2
+  for key in one:
+    np.testing.assert_array_equal(four[key], one[key], err_msg=key)
+    np.testing.assert_array_equal(two[key][:, :2], one[key], err_msg=key)
+  assert np.isfinite(one["posterior_trajectories"]).all()
+  assert (one["weights"] == 0).any() and (one["weights"] != 0).any()

@@ -313,6 +313,9 @@ struct ci_session {
   size_t seasonal_ws_bytes = 0;
   int Lc = 0;
   DevBuf<float> ws;
+  int cluster = 1;            // time-parallel seasonal kernel: workgroups per chain
+  DevBuf<int> csync;
+  DevBuf<float> cpart, cw;
   // on-device summarisation (ci_summary.h)
   DevBuf<double> s_value, s_cum, s_obs, s_order, s_draw;
   DevBuf<uint8_t> s_flags;
@@ -574,7 +577,24 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       HIP_TRY(s->o_drift.alloc(BCS * K));
       HIP_TRY(s->o_seasonal.alloc(BCS * T * K));
     }
-    if (s->wide) HIP_TRY(s->ws.alloc((size_t)B * C * ci::wide_workspace_floats(s->dred, s->Lc)));
+    if (s->wide) {
+      HIP_TRY(s->ws.alloc((size_t)B * C * ci::wide_workspace_floats(s->dred, s->Lc)));
+      // clusters: 4 (or 2) CUs per chain while every workgroup of the launch is resident at once
+      // (the handshakes spin); needs whole 16-byte chunks of 4 steps and a regression block
+      int num_cus = 256;
+      (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, pb->device);
+      const long long groups = ((long long)B * C + 7) / 8 * 8;
+      s->cluster = 1;
+      if (!(pb->flags & CI_FLAG_NO_CLUSTER) && P > 0 && (T & 3) == 0) {
+        if (groups * 4 <= num_cus) s->cluster = 4;
+        else if (groups * 2 <= num_cus) s->cluster = 2;
+      }
+      const size_t nseg = ((size_t)(T >> 2) + 2 * ci::NT - 1) / (2 * ci::NT);
+      const size_t RS = (size_t)(P > 16 ? P : 16) + 4;
+      HIP_TRY(s->csync.alloc((size_t)B * C * 16));
+      HIP_TRY(s->cpart.alloc((size_t)B * C * (nseg > 0 ? nseg : 1) * ci::NW * RS));
+      HIP_TRY(s->cw.alloc((size_t)B * C * 64));
+    }
     else if (s->seasonal_gws) HIP_TRY(s->ws.alloc((size_t)B * C * (s->seasonal_ws_bytes / sizeof(float))));
     HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
     std::vector<ci::DevSeasonalParams> ssh(B);
@@ -699,8 +719,15 @@ static int session_launch(ci_session* s) {
     sa.season_change = s->season_change.p; sa.ssp = s->ssp.p; sa.p1_chol = s->p1_chol.p;
     sa.out_drift = s->o_drift.p; sa.out_seasonal = s->o_seasonal.p;
     sa.ws = s->ws.p; sa.Lc = s->Lc;
-    hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(pb.num_series * pb.num_chains),
-                       dim3(s->wide ? ci::NT : 64), s->lds_bytes, s->stream, sa);
+    sa.cluster = s->wide ? s->cluster : 1;
+    sa.csync = s->csync.p; sa.cpart = s->cpart.p; sa.cw = s->cw.p;
+    int grid = pb.num_series * pb.num_chains;
+    if (s->wide && s->cluster > 1) {
+      HIP_TRY(hipMemsetAsync(s->csync.p, 0, s->csync.n * sizeof(int), s->stream));
+      grid = (grid + 7) / 8 * 8 * s->cluster;       // (chain, role) <- workgroup id: see ci_wide.h
+    }
+    hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(grid), dim3(s->wide ? ci::NT : 64),
+                       s->lds_bytes, s->stream, sa);
   } else {
     if (s->profile && s->five_waves && s->fn_prof5) {
       hipLaunchKernelGGL(s->fn_prof5, dim3(pb.num_series * pb.num_chains), dim3(ci::NT5), s->lds_bytes,
@@ -1021,7 +1048,7 @@ int ci_session_destroy(ci_session* s) {
   s->o_w.release(); s->o_level.release(); s->o_slope.release(); s->o_pm.release();
   s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->sp.release(); s->prof.release();
   s->season_change.release(); s->ssp.release(); s->p1_chol.release(); s->o_drift.release();
-  s->o_seasonal.release(); s->ws.release();
+  s->o_seasonal.release(); s->ws.release(); s->csync.release(); s->cpart.release(); s->cw.release();
   s->s_value.release(); s->s_cum.release(); s->s_obs.release(); s->s_flags.release();
   s->s_ranks.release(); s->s_order.release(); s->s_draw.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);

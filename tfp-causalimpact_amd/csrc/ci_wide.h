@@ -745,6 +745,34 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
 }
 
 // ------------------------------------------------------------------------------------
+// Clusters: several workgroups (CUs) per chain.  A few chains of a long series leave most of
+// the GPU idle while one CU streams the design matrix at its own latency-bound ~45 GB/s, so the
+// phases that are independent across time -- X~'targets, the emission of the previous draw, X w
+// -- are shared between `cluster` workgroups: workgroup 0 of a chain ("main") runs the whole
+// iteration, the others only their share of those phases.  Handshakes are per-chain counters in
+// HBM (release: every thread fences, barrier, one atomic store; acquire: one thread spins, fences,
+// barrier); the workgroups of a chain are placed on ONE XCD (dispatch is round-robin over the 8
+// XCDs), so they share its L2.  Reductions are over FIXED segments of 2 * NT chunks whatever the
+// cluster size, summed in segment order: every cluster size gives the same bits.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void cl_publish(int* flag, int value, int tid) {
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits until flags[0..n) have all reached `value`
+__device__ __forceinline__ void cl_wait(int* flags, int n, int value, int tid) {
+  if (tid == 0) {
+    for (int r = 0; r < n; ++r)
+      while (__hip_atomic_load(flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value)
+        __builtin_amdgcn_s_sleep(2);
+    __threadfence();
+  }
+  __syncthreads();
+}
+enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_PARTIAL = 4, CL_XW = 8 };   // + role
+
+// ------------------------------------------------------------------------------------
 // the persistent Gibbs kernel (same iteration structure as gibbs_kernel / the oracle's
 // ci_oracle_fit_gibbs; gibbs_sampler.fit_with_gibbs_sampling called at causalimpact_lib.py:365)
 // ------------------------------------------------------------------------------------
@@ -758,7 +786,16 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const KArgs& g = a.k;
   const int T = g.T, P = g.P, Lc = a.Lc;
   const int TP = NT * Lc;
-  const int series = blockIdx.x / g.C, chain = blockIdx.x % g.C;
+  // workgroup -> (chain, role): the workgroups of one chain share an XCD (ids equal mod 8)
+  const int G = a.cluster;
+  int chain_id = blockIdx.x, role = 0;
+  if (G > 1) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    role = slot % G;
+    chain_id = (slot / G) * 8 + xcd;
+    if (chain_id >= g.B * g.C) return;
+  }
+  const int series = chain_id / g.C, chain = chain_id % g.C;
   const size_t chain_lin = (size_t)series * g.C + chain;
   const WLayout lay = make_wlayout(P, D);
   RegLds R;
@@ -796,6 +833,175 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const float* yg = g.y + (size_t)series * T;
   const float* Xg = g.Xt + (size_t)series * P * T;
   const float* chol1 = a.p1_chol + (size_t)series * D * D;
+
+  // ---- phases shared by the workgroups of a cluster -------------------------------------------
+  const bool vec4 = (T & 3) == 0;            // (clusters need it; the host checks)
+  const int n4 = T >> 2;                     // chunks of 4 steps
+  const int nseg = (n4 + 2 * NT - 1) / (2 * NT);
+  int* csync = a.csync + chain_lin * 16;
+  float* cpart = a.cpart + chain_lin * (size_t)nseg * NW * RS;
+  float* cw = a.cw + chain_lin * 64;
+  const int clo = (int)((long long)(TP >> 2) * role / G), chi = (int)((long long)(TP >> 2) * (role + 1) / G);
+  const int n_iter = g.W + g.S;
+
+  // (1) targets y - level - seasonal of segment `seg` (2 x NT chunks of 4 steps), their squares and
+  // X~'targets: four wave partials per column, to cpart[seg][wave][.]
+  auto segment_sums = [&](int seg) {
+    const int c4 = seg * 2 * NT + tid, c4b = c4 + NT;
+    const bool ha = c4 < n4, hb = c4b < n4;
+    const int ca = ha ? c4 : 0, cb = hb ? c4b : 0;
+    float4 tg, tgb;
+    {
+      const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * ca);
+      const float4 l4 = *reinterpret_cast<const float4*>(levw + 4 * ca);
+      const float4 s4 = *reinterpret_cast<const float4*>(seaw + 4 * ca);
+      const uint32_t mk = ha ? *reinterpret_cast<const uint32_t*>(mskp + 4 * ca) : 0xFFFFFFFFu;
+      tg.x = (mk & 0xFFu) ? 0.f : y4.x - l4.x - s4.x;
+      tg.y = (mk & 0xFF00u) ? 0.f : y4.y - l4.y - s4.y;
+      tg.z = (mk & 0xFF0000u) ? 0.f : y4.z - l4.z - s4.z;
+      tg.w = (mk & 0xFF000000u) ? 0.f : y4.w - l4.w - s4.w;
+    }
+    {
+      const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * cb);
+      const float4 l4 = *reinterpret_cast<const float4*>(levw + 4 * cb);
+      const float4 s4 = *reinterpret_cast<const float4*>(seaw + 4 * cb);
+      const uint32_t mk = hb ? *reinterpret_cast<const uint32_t*>(mskp + 4 * cb) : 0xFFFFFFFFu;
+      tgb.x = (mk & 0xFFu) ? 0.f : y4.x - l4.x - s4.x;
+      tgb.y = (mk & 0xFF00u) ? 0.f : y4.y - l4.y - s4.y;
+      tgb.z = (mk & 0xFF0000u) ? 0.f : y4.z - l4.z - s4.z;
+      tgb.w = (mk & 0xFF000000u) ? 0.f : y4.w - l4.w - s4.w;
+    }
+    float yty = 0.f;
+    yty = fmaf(tg.x, tg.x, yty); yty = fmaf(tg.y, tg.y, yty);
+    yty = fmaf(tg.z, tg.z, yty); yty = fmaf(tg.w, tg.w, yty);
+    yty = fmaf(tgb.x, tgb.x, yty); yty = fmaf(tgb.y, tgb.y, yty);
+    yty = fmaf(tgb.z, tgb.z, yty); yty = fmaf(tgb.w, tgb.w, yty);
+    float* out = cpart + (size_t)seg * NW * RS;
+    // XR design rows x 2 chunks per pass: 2 x XR 16-byte loads in flight per thread (one wave per
+    // SIMD here, so memory latency is hidden by bytes in flight per thread, not by occupancy)
+    for (int j0 = 0; j0 < P; j0 += XR) {
+      float4 xv[XR], xb[XR];
+#pragma unroll
+      for (int q = 0; q < XR; ++q) {
+        const int j = j0 + q < P ? j0 + q : P - 1;
+        xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * ca);
+        xb[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * cb);
+      }
+#pragma unroll
+      for (int q = 0; q < XR; ++q) {
+        float acc = xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
+        acc += xb[q].x * tgb.x + xb[q].y * tgb.y + xb[q].z * tgb.z + xb[q].w * tgb.w;
+        const float sw = wave_sum_dpp(acc);
+        if (lane == 0 && j0 + q < P) out[wave * RS + j0 + q] = sw;
+      }
+    }
+    const float s0 = wave_sum_dpp(yty);
+    if (lane == 0) out[wave * RS + RS - 4] = s0;
+  };
+
+  // (3) latents and posterior-predictive trajectory of iteration it - 1, chunks [lo, hi)
+  auto emit_range = [&](int it, float so, int lo, int hi) {
+    const int s = it - 1 - g.W;
+    const size_t o = chain_lin * g.S + s;
+    const size_t row = o * T;
+    // 4 steps per thread: whole 16-byte accesses when the rows are 16-byte aligned (T % 4 == 0;
+    // the shared T-arrays are padded to a multiple of 4)
+    const int cend = hi < (T + 3) / 4 ? hi : (T + 3) / 4;
+    for (int c = lo + tid; c < cend; c += NT) {
+      float zp[4];
+      normals4(site_call(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)c), zp);
+      if (vec4) {
+        const float4 lv = *reinterpret_cast<const float4*>(levw + 4 * c);
+        const float4 sv = *reinterpret_cast<const float4*>(seaw + 4 * c);
+        const float4 xv = *reinterpret_cast<const float4*>(xww + 4 * c);
+        const float4 loc = make_float4(lv.x + sv.x + xv.x, lv.y + sv.y + xv.y, lv.z + sv.z + xv.z,
+                                       lv.w + sv.w + xv.w);
+        const size_t at = row + 4 * (size_t)c;
+        if (g.out_level) *reinterpret_cast<float4*>(g.out_level + at) = lv;
+        if (g.out_slope && TR == 2)
+          *reinterpret_cast<float4*>(g.out_slope + at) = *reinterpret_cast<const float4*>(slpw + 4 * c);
+        if (a.out_seasonal) *reinterpret_cast<float4*>(a.out_seasonal + at) = sv;
+        if (g.out_traj)
+          *reinterpret_cast<float4*>(g.out_traj + at) =
+              make_float4(fmaf(so, zp[0], loc.x), fmaf(so, zp[1], loc.y), fmaf(so, zp[2], loc.z),
+                          fmaf(so, zp[3], loc.w));
+        if (g.out_pred_mean) {
+          float4* pm = reinterpret_cast<float4*>(g.out_pred_mean + chain_lin * T + 4 * c);
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (s != 0) acc = *pm;                 // running sum, scaled at the end
+          *pm = make_float4(acc.x + loc.x, acc.y + loc.y, acc.z + loc.z, acc.w + loc.w);
+        }
+        continue;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = 4 * c + q;
+        if (t < T) {
+          const float lv = levw[t], sv = seaw[t];
+          const float loc = lv + sv + xww[t];
+          if (g.out_level) g.out_level[row + t] = lv;
+          if (g.out_slope && TR == 2) g.out_slope[row + t] = slpw[t];
+          if (a.out_seasonal) a.out_seasonal[row + t] = sv;
+          if (g.out_traj) g.out_traj[row + t] = fmaf(so, zp[q], loc);
+          if (g.out_pred_mean) {
+            float* pm = g.out_pred_mean + chain_lin * T + t;   // running sum, scaled at the end
+            *pm = (s == 0 ? 0.f : *pm) + loc;
+          }
+        }
+      }
+    }
+  };
+
+  // (4) X w and the residual of chunks [lo, hi) (T % 4 == 0): only the INCLUDED features' rows are
+  // streamed (a zero weight contributes an exact zero)
+  auto xw_range = [&](int lo, int hi) {
+    const unsigned long long included = __ballot(lane < P && R.w[lane < P ? lane : 0] != 0.f);
+    for (int c4 = lo + tid; c4 < hi; c4 += NT) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f), yv = s;
+      if (4 * c4 < T) {
+        for (unsigned long long todo = included; todo != 0ull;) {
+          float4 xv[XR];
+          float wj[XR];
+#pragma unroll
+          for (int q = 0; q < XR; ++q) {
+            const bool have = todo != 0ull;
+            const int j = have ? __ffsll((long long)todo) - 1 : 0;
+            todo &= todo - 1ull;
+            wj[q] = have ? R.w[j] : 0.f;
+            xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
+          }
+#pragma unroll
+          for (int q = 0; q < XR; ++q) {
+            s.x = fmaf(xv[q].x, wj[q], s.x); s.y = fmaf(xv[q].y, wj[q], s.y);
+            s.z = fmaf(xv[q].z, wj[q], s.z); s.w = fmaf(xv[q].w, wj[q], s.w);
+          }
+        }
+        const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * c4);
+        const uint32_t mk = *reinterpret_cast<const uint32_t*>(mskp + 4 * c4);
+        yv.x = (mk & 0xFFu) ? 0.f : y4.x; yv.y = (mk & 0xFF00u) ? 0.f : y4.y;
+        yv.z = (mk & 0xFF0000u) ? 0.f : y4.z; yv.w = (mk & 0xFF000000u) ? 0.f : y4.w;
+      }
+      *reinterpret_cast<float4*>(xww + 4 * c4) = s;
+      *reinterpret_cast<float4*>(residw + 4 * c4) = make_float4(yv.x - s.x, yv.y - s.y, yv.z - s.z, yv.w - s.w);
+    }
+  };
+
+  if (role > 0) {
+    // ---- helper workgroup: its share of phases (1), (3), (4), nothing else
+    for (int it = 0; it <= n_iter; ++it) {
+      cl_wait(csync + CL_LATENTS, 1, it + 1, tid);
+      for (int seg = role; seg < nseg; seg += G) segment_sums(seg);
+      cl_publish(csync + CL_PARTIAL + role, it + 1, tid);
+      cl_wait(csync + CL_WEIGHTS, 1, it + 1, tid);
+      if (tid < P) R.w[tid] = cw[tid];
+      const float so = cw[P];
+      __syncthreads();
+      if (it > g.W) emit_range(it, so, clo, chi);
+      if (it < n_iter) xw_range(clo, chi);
+      cl_publish(csync + CL_XW + role, it + 1, tid);
+    }
+    return;
+  }
 
   float nch = 0.f;
   for (int t = tid; t < TP; t += NT) {
@@ -838,11 +1044,20 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
   Prof prof;
   prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && tid == 0);
+  if (G > 1) cl_publish(csync + CL_LATENTS, 1, tid);      // masks and zeroed latents are in place
 
-  const int n_iter = g.W + g.S;
   for (int it = 0; it <= n_iter; ++it) {
     // ---- (1) targets, y'y, X~'targets (time interleaved over threads: coalesced)
-    {
+    if (vec4) {
+      for (int seg = 0; seg < nseg; seg += G) segment_sums(seg);
+      const float s1 = wave_sum_dpp(ssl), s2 = wave_sum_dpp(sss), s3 = wave_sum_dpp(ssd);
+      if (lane == 0) {
+        red[wave * RS + RS - 3] = s1;
+        red[wave * RS + RS - 2] = s2;
+        red[wave * RS + RS - 1] = s3;
+      }
+      if (G > 1) cl_wait(csync + CL_PARTIAL + 1, G - 1, it + 1, tid);
+    } else {
       float yty = 0.f;
       for (int t = tid; t < T; t += NT) {
         float tg = 0.f;
@@ -851,38 +1066,11 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         yty = fmaf(tg, tg, yty);
       }
       __syncthreads();      // tgw is read back through another thread mapping below
-      // XR design rows x 4 steps per pass, the 4 steps as one 16-byte load when rows are 16-byte
-      // aligned: one wave per SIMD here, so memory latency is hidden by bytes in flight per
-      // thread, not by occupancy
-      const bool vec4 = (T & 3) == 0;
       for (int j0 = 0; j0 < P; j0 += XR) {
         float acc[XR];
 #pragma unroll
         for (int q = 0; q < XR; ++q) acc[q] = 0.f;
-        if (vec4) {
-          // two 4-step chunks per trip: 2 x (XR + 1) 16-byte loads in flight per thread
-          const int n4 = T >> 2;
-          for (int c4 = tid; c4 < n4; c4 += 2 * NT) {
-            const int c4b = c4 + NT;
-            const bool hb = c4b < n4;
-            const int c4s = hb ? c4b : c4;
-            const float4 tg = *reinterpret_cast<const float4*>(tgw + 4 * c4);
-            float4 tgb = *reinterpret_cast<const float4*>(tgw + 4 * c4s);
-            float4 xv[XR], xb[XR];
-#pragma unroll
-            for (int q = 0; q < XR; ++q) {
-              const int j = j0 + q < P ? j0 + q : P - 1;
-              xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
-              xb[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4s);
-            }
-            if (!hb) tgb = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < XR; ++q) {
-              acc[q] += xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
-              acc[q] += xb[q].x * tgb.x + xb[q].y * tgb.y + xb[q].z * tgb.z + xb[q].w * tgb.w;
-            }
-          }
-        } else {
+        {
           for (int tb = tid; tb < T; tb += 4 * NT) {
             float tg[4];
 #pragma unroll
@@ -921,7 +1109,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         red[wave * RS + RS - 1] = s3;
       }
     }
-    __syncthreads();
+    __syncthreads();      // (G == 1: the partials are this workgroup's own stores, same CU)
     prof.tick(0);
 
     // ---- (2) serial section (wave 0): scales of iteration it-1, regression draw of iteration it
@@ -929,8 +1117,13 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       for (int j = lane; j < P + 4; j += 64) {
         const int src = j < P ? j : RS - 4 + (j - P);
         double s = 0.0;
+        if (vec4 && j <= P) {
+          // X~'targets and y'y: the segments' wave partials, in segment order
+          for (int e = 0; e < nseg * NW; ++e) s += (double)cpart[(size_t)e * RS + src];
+        } else {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) s += (double)red[w * RS + src];
+          for (int w = 0; w < NW; ++w) s += (double)red[w * RS + src];
+        }
         R.bvec[j] = s;
       }
       wave_sync();
@@ -992,95 +1185,24 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     }
     prof.tick(1);
 
-    // ---- (3) emit iteration it-1: latents and the posterior-predictive trajectory
-    if (it > g.W) {
-      const int s = it - 1 - g.W;
-      const size_t o = chain_lin * g.S + s;
-      const size_t row = o * T;
-      const float so = scal[1];
-      // 4 steps per thread: whole 16-byte accesses when the rows are 16-byte aligned (T % 4 == 0;
-      // the shared T-arrays are padded to a multiple of 4)
-      const bool vec4e = (T & 3) == 0;
-      for (int c = tid; c < (T + 3) / 4; c += NT) {
-        float zp[4];
-        normals4(site_call(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)c), zp);
-        if (vec4e) {
-          const float4 lv = *reinterpret_cast<const float4*>(levw + 4 * c);
-          const float4 sv = *reinterpret_cast<const float4*>(seaw + 4 * c);
-          const float4 xv = *reinterpret_cast<const float4*>(xww + 4 * c);
-          const float4 loc = make_float4(lv.x + sv.x + xv.x, lv.y + sv.y + xv.y, lv.z + sv.z + xv.z,
-                                         lv.w + sv.w + xv.w);
-          const size_t at = row + 4 * (size_t)c;
-          if (g.out_level) *reinterpret_cast<float4*>(g.out_level + at) = lv;
-          if (g.out_slope && TR == 2)
-            *reinterpret_cast<float4*>(g.out_slope + at) = *reinterpret_cast<const float4*>(slpw + 4 * c);
-          if (a.out_seasonal) *reinterpret_cast<float4*>(a.out_seasonal + at) = sv;
-          if (g.out_traj)
-            *reinterpret_cast<float4*>(g.out_traj + at) =
-                make_float4(fmaf(so, zp[0], loc.x), fmaf(so, zp[1], loc.y), fmaf(so, zp[2], loc.z),
-                            fmaf(so, zp[3], loc.w));
-          if (g.out_pred_mean) {
-            float4* pm = reinterpret_cast<float4*>(g.out_pred_mean + chain_lin * T + 4 * c);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s != 0) acc = *pm;                 // running sum, scaled at the end
-            *pm = make_float4(acc.x + loc.x, acc.y + loc.y, acc.z + loc.z, acc.w + loc.w);
-          }
-          continue;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int t = 4 * c + q;
-          if (t < T) {
-            const float lv = levw[t], sv = seaw[t];
-            const float loc = lv + sv + xww[t];
-            if (g.out_level) g.out_level[row + t] = lv;
-            if (g.out_slope && TR == 2) g.out_slope[row + t] = slpw[t];
-            if (a.out_seasonal) a.out_seasonal[row + t] = sv;
-            if (g.out_traj) g.out_traj[row + t] = fmaf(so, zp[q], loc);
-            if (g.out_pred_mean) {
-              float* pm = g.out_pred_mean + chain_lin * T + t;   // running sum, scaled at the end
-              *pm = (s == 0 ? 0.f : *pm) + loc;
-            }
-          }
-        }
-      }
+    // the cluster's helpers take their share of (3) and (4) from here
+    if (G > 1) {
+      if (tid < P) cw[tid] = R.w[tid];
+      if (tid == 0) cw[P] = scal[1];
+      cl_publish(csync + CL_WEIGHTS, it + 1, tid);
     }
+    // ---- (3) emit iteration it-1: latents and the posterior-predictive trajectory
+    if (it > g.W) emit_range(it, scal[1], clo, chi);
     prof.tick(2);
-    if (it == n_iter) break;
+    if (it == n_iter) {
+      if (G > 1) cl_wait(csync + CL_XW + 1, G - 1, it + 1, tid);
+      break;
+    }
     __syncthreads();     // (3) reads xww through a different thread mapping than (4) writes it
 
     // ---- (4) X w and the residual
-    // only the INCLUDED features' rows are streamed (a zero weight contributes an exact zero)
-    const unsigned long long included = __ballot(lane < P && R.w[lane < P ? lane : 0] != 0.f);
-    if ((T & 3) == 0) {
-      for (int c4 = tid; c4 < (TP >> 2); c4 += NT) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), yv = s;
-        if (4 * c4 < T) {
-          for (unsigned long long todo = included; todo != 0ull;) {
-            float4 xv[XR];
-            float wj[XR];
-#pragma unroll
-            for (int q = 0; q < XR; ++q) {
-              const bool have = todo != 0ull;
-              const int j = have ? __ffsll((long long)todo) - 1 : 0;
-              todo &= todo - 1ull;
-              wj[q] = have ? R.w[j] : 0.f;
-              xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
-            }
-#pragma unroll
-            for (int q = 0; q < XR; ++q) {
-              s.x = fmaf(xv[q].x, wj[q], s.x); s.y = fmaf(xv[q].y, wj[q], s.y);
-              s.z = fmaf(xv[q].z, wj[q], s.z); s.w = fmaf(xv[q].w, wj[q], s.w);
-            }
-          }
-          const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * c4);
-          const uint32_t mk = *reinterpret_cast<const uint32_t*>(mskp + 4 * c4);
-          yv.x = (mk & 0xFFu) ? 0.f : y4.x; yv.y = (mk & 0xFF00u) ? 0.f : y4.y;
-          yv.z = (mk & 0xFF0000u) ? 0.f : y4.z; yv.w = (mk & 0xFF000000u) ? 0.f : y4.w;
-        }
-        *reinterpret_cast<float4*>(xww + 4 * c4) = s;
-        *reinterpret_cast<float4*>(residw + 4 * c4) = make_float4(yv.x - s.x, yv.y - s.y, yv.z - s.z, yv.w - s.w);
-      }
+    if (vec4) {
+      xw_range(clo, chi);
     } else {
       for (int tb = tid; tb < TP; tb += 4 * NT) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1113,6 +1235,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         }
       }
     }
+    if (G > 1) cl_wait(csync + CL_XW + 1, G - 1, it + 1, tid);
     // x+_0 = chol(P_1) z, folded into the filter's prior mean (see dk_draw in ci_kernels.h)
     Vec<D> a1e = vzero<D>();
     a1e.v[0] = (float)sp.init_level_loc;
@@ -1143,6 +1266,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
                          (uint32_t)it, tid, lane, wave, pslots, fslots, aslots, edge, ssl, sss, ssd,
                          prof);
     __syncthreads();
+    if (G > 1) cl_publish(csync + CL_LATENTS, it + 2, tid);
   }
   __syncthreads();     // the running sums were accumulated through the emission's thread mapping
   if (g.out_pred_mean) {

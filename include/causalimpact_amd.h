@@ -92,7 +92,7 @@ typedef struct ci_problem {
  * Test / diagnostic knob. */
 #define CI_FLAG_SEASONAL_WORKSPACE 8
 /* Time-parallel seasonal kernel: one workgroup per chain even where the library would spread a
- * chain's time-independent phases over a cluster of 2 or 4 CUs (few chains of a long series).
+ * chain's time-independent phases over a cluster of 2, 4 or 8 CUs (few chains of a long series).
  * Every cluster size gives the same bits; test / diagnostic knob. */
 #define CI_FLAG_NO_CLUSTER 16
 

@@ -458,11 +458,11 @@ def test_seasonal_kernel_with_arrays_in_hbm_equals_the_lds_variant():
 
 def test_clusters_of_workgroups_give_the_same_bits_as_one_workgroup_per_chain():
   """Time-parallel seasonal kernel: a chain's X~'targets / emission / X w phases are shared by
-  4 or 2 workgroups when the launch leaves CUs idle (ci_wide.h "clusters").  The reductions run
+  8, 4 or 2 workgroups when the launch leaves CUs idle (ci_wide.h "clusters").  The reductions run
   over fixed segments, so every cluster size -- chosen from the number of chains -- and the
   single-workgroup kernel produce identical draws."""
   from causalimpact import _model
-  T, p, seasons, W, S = 4800, 20, ((7, 1),), 3, 6            # 3 segments of 2048 steps
+  T, p, seasons, W, S = 4800, 20, ((7, 1),), 3, 6            # 5 segments of 1024 steps
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 5)
   y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
   mask = mask.copy()
@@ -476,10 +476,12 @@ def test_clusters_of_workgroups_give_the_same_bits_as_one_workgroup_per_chain():
     return _native.fit_gibbs(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
 
   one = fit(2, _native.FLAG_NO_CLUSTER)
-  four = fit(2, 0)                                            # 8 x 4 workgroups <= 256 CUs
+  eight = fit(2, 0)                                           # 8 x 8 workgroups <= 256 CUs
+  four = fit(40, 0)                                           # 40 x 8 > 256 >= 40 x 4
   two = fit(72, 0)                                            # 72 x 4 > 256 >= 72 x 2
   for key in one:
-    np.testing.assert_array_equal(four[key], one[key], err_msg=key)
+    np.testing.assert_array_equal(eight[key], one[key], err_msg=key)
+    np.testing.assert_array_equal(four[key][:, :2], one[key], err_msg=key)
     np.testing.assert_array_equal(two[key][:, :2], one[key], err_msg=key)
   assert np.isfinite(one["posterior_trajectories"]).all()
   assert (one["weights"] == 0).any() and (one["weights"] != 0).any()

@@ -316,6 +316,7 @@ struct ci_session {
   int cluster = 1;            // time-parallel seasonal kernel: workgroups per chain
   DevBuf<int> csync;
   DevBuf<float> cpart, cw;
+  DevBuf<double> cv;
   // on-device summarisation (ci_summary.h)
   DevBuf<double> s_value, s_cum, s_obs, s_order, s_draw;
   DevBuf<uint8_t> s_flags;
@@ -579,21 +580,23 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     }
     if (s->wide) {
       HIP_TRY(s->ws.alloc((size_t)B * C * ci::wide_workspace_floats(s->dred, s->Lc)));
-      // clusters: 4 (or 2) CUs per chain while every workgroup of the launch is resident at once
+      // clusters: 8, 4 or 2 CUs per chain while every workgroup of the launch is resident at once
       // (the handshakes spin); needs whole 16-byte chunks of 4 steps and a regression block
       int num_cus = 256;
       (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, pb->device);
       const long long groups = ((long long)B * C + 7) / 8 * 8;
       s->cluster = 1;
       if (!(pb->flags & CI_FLAG_NO_CLUSTER) && P > 0 && (T & 3) == 0) {
-        if (groups * 4 <= num_cus) s->cluster = 4;
+        if (groups * 8 <= num_cus) s->cluster = 8;
+        else if (groups * 4 <= num_cus) s->cluster = 4;
         else if (groups * 2 <= num_cus) s->cluster = 2;
       }
-      const size_t nseg = ((size_t)(T >> 2) + 2 * ci::NT - 1) / (2 * ci::NT);
+      const size_t nseg = ((size_t)(T >> 2) + ci::NT - 1) / ci::NT;
       const size_t RS = (size_t)(P > 16 ? P : 16) + 4;
-      HIP_TRY(s->csync.alloc((size_t)B * C * 16));
+      HIP_TRY(s->csync.alloc((size_t)B * C * ci::CL_INTS));
       HIP_TRY(s->cpart.alloc((size_t)B * C * (nseg > 0 ? nseg : 1) * ci::NW * RS));
       HIP_TRY(s->cw.alloc((size_t)B * C * 64));
+      HIP_TRY(s->cv.alloc((size_t)B * C * (P + 1) * (P + 1)));
     }
     else if (s->seasonal_gws) HIP_TRY(s->ws.alloc((size_t)B * C * (s->seasonal_ws_bytes / sizeof(float))));
     HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
@@ -720,7 +723,7 @@ static int session_launch(ci_session* s) {
     sa.out_drift = s->o_drift.p; sa.out_seasonal = s->o_seasonal.p;
     sa.ws = s->ws.p; sa.Lc = s->Lc;
     sa.cluster = s->wide ? s->cluster : 1;
-    sa.csync = s->csync.p; sa.cpart = s->cpart.p; sa.cw = s->cw.p;
+    sa.csync = s->csync.p; sa.cpart = s->cpart.p; sa.cw = s->cw.p; sa.cv = s->cv.p;
     int grid = pb.num_series * pb.num_chains;
     if (s->wide && s->cluster > 1) {
       HIP_TRY(hipMemsetAsync(s->csync.p, 0, s->csync.n * sizeof(int), s->stream));
@@ -1048,7 +1051,7 @@ int ci_session_destroy(ci_session* s) {
   s->o_w.release(); s->o_level.release(); s->o_slope.release(); s->o_pm.release();
   s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->sp.release(); s->prof.release();
   s->season_change.release(); s->ssp.release(); s->p1_chol.release(); s->o_drift.release();
-  s->o_seasonal.release(); s->ws.release(); s->csync.release(); s->cpart.release(); s->cw.release();
+  s->o_seasonal.release(); s->ws.release(); s->csync.release(); s->cpart.release(); s->cw.release(); s->cv.release();
   s->s_value.release(); s->s_cum.release(); s->s_obs.release(); s->s_flags.release();
   s->s_ranks.release(); s->s_order.release(); s->s_draw.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);

@@ -1073,18 +1073,52 @@ __device__ __forceinline__ void sweep_pair_block(double* A, int n, double* Pm, i
   __syncthreads();
 }
 
+// The data-independent part of the regression block's matrix: [Omega s2 + X'X, 0; 0, 0] swept on
+// the features of `nzmask` (the border stays zero).  What is left for the iteration itself is to
+// fill the border from X~'targets (spike_slab_draw_block, split mode) -- so this half can be
+// computed ahead, by another workgroup of the chain's cluster, as soon as s2 and the active set
+// of the previous iteration are known (ci_wide.h).  Ends with a barrier.
+__device__ __forceinline__ void presweep_block(const RegLds& R, int P, double prev_var,
+                                               unsigned long long nzmask, bool with_prior, int tid) {
+  const int n = P + 1;
+  double* tmp = R.chol;
+  {
+    int i = tid / n, j = tid - (tid / n) * n;
+    const int qd = NT / n, rm = NT - qd * n;
+    for (int e = tid; e < n * n; e += NT) {
+      const int ic = i < P ? i : P - 1, jc = j < P ? j : P - 1;
+      const double inner = R.omega[ic * P + jc] * prev_var + R.xtx[ic * P + jc];
+      R.aug[0][e] = (i < P && j < P) ? inner : 0.0;
+      j += rm; i += qd;
+      if (j >= n) { j -= n; ++i; }
+    }
+  }
+  __syncthreads();
+  for (unsigned long long todo = nzmask; todo; todo &= todo - 1ull)
+    sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, with_prior, tid, tmp);
+}
+
+// split: the matrix comes from presweep_block -- computed here, or copied from `presweep`
+// ((P + 1)^2 doubles in global memory) when another workgroup prepared it -- and the border is
+// filled by a matrix-vector product instead of being carried through the sweeps (the same
+// arithmetic whoever swept).  !split: the sweeps run on the bordered matrix (ci_kernels.h kernels).
 __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
                                                         const DevSeriesParams& sp,
                                                         double prev_obs_scale, double g_obs,
                                                         const Rng& rng, uint32_t iter, int tid,
-                                                        bool first, Prof* prof = nullptr) {
+                                                        bool first, Prof* prof = nullptr,
+                                                        bool split = false,
+                                                        const double* presweep = nullptr) {
   const int lane = tid & 63;
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
   double* tmp = R.chol;            // free until the final Cholesky (P > 16 => P*P >= 256)
-  {
+  if (split) {
+    if (first)
+      for (int e = tid; e < P * P; e += NT) R.pri[0][e] = R.omega[e];
+  } else {
     int i = tid / n, j = tid - (tid / n) * n;
     const int qd = NT / n, rm = NT - qd * n;
     for (int e = tid; e < n * n; e += NT) {
@@ -1107,8 +1141,40 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   }
   __syncthreads();
   if (prof) prof->tick(4);
-  for (unsigned long long todo = __ballot(nz0 != 0); todo; todo &= todo - 1ull)
-    sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, first, tid, tmp);
+  const unsigned long long nzmask = __ballot(nz0 != 0);
+  if (!split) {
+    for (unsigned long long todo = nzmask; todo; todo &= todo - 1ull)
+      sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, first, tid, tmp);
+  } else {
+    if (presweep) {
+      for (int e = tid; e < n * n; e += NT) R.aug[0][e] = presweep[e];
+      __syncthreads();
+    } else {
+      presweep_block(R, P, prev_var, nzmask, first, tid);
+    }
+    // border: with V the swept matrix, S the swept set and b = X~'targets,
+    //   b~_j = (j in S ? 0 : b_j) - sum_{k in S} V_jk b_k ,   corner = y'y - sum_{k in S} b_k b~_k
+    if (tid < 64) {
+      double* A = R.aug[0];
+      const bool in = ((nzmask >> lane) & 1ull) != 0ull;
+      double bt = 0.0;
+      if (lane < P) {
+        double acc = 0.0;
+        for (unsigned long long todo = nzmask; todo; todo &= todo - 1ull) {
+          const int k = __ffsll((long long)todo) - 1;
+          acc += A[lane * n + k] * R.bvec[k];
+        }
+        bt = (in ? 0.0 : R.bvec[lane]) - acc;
+        A[lane * n + P] = bt;
+        A[P * n + lane] = bt;
+      }
+      double term = (lane < P && in) ? R.bvec[lane] * bt : 0.0;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) term += __shfl_xor(term, off, 64);
+      if (lane == 0) A[P * n + P] = R.bvec[P] - term;
+    }
+    __syncthreads();
+  }
   if (prof) prof->tick(5);
   if (!all_in) {
     if (tid < P) {

@@ -44,10 +44,11 @@ struct SArgs {
   float* ws;                         // time-parallel kernel (ci_wide.h): per-chain HBM workspace
   int Lc;                            //   and steps per thread
   // time-parallel kernel, several workgroups per chain (ci_wide.h "clusters"):
-  int cluster;                       //   workgroups per chain (1, 2 or 4)
-  int* csync;                        //   [B*C][16] handshake counters, zeroed before the launch
+  int cluster;                       //   workgroups per chain (1, 2, 4 or 8)
+  int* csync;                        //   [B*C][32] handshake counters, zeroed before the launch
   float* cpart;                      //   [B*C][segments][4][RS] partial sums of X~'targets, y'y
   float* cw;                         //   [B*C][64] weights + emission scale of the iteration
+  double* cv;                        //   [B*C][(P+1)^2] regression matrix swept ahead (presweep_block)
 };
 
 struct SLayout {

@@ -291,7 +291,7 @@ __device__ __forceinline__ E block_scan_excl_bwd_rolled(const E& tot, Op op, con
 
 struct WLayout {
   size_t xtx, omega, aug0, aug1, pri0, pri1, chol, bvec, zv, uperm, nz, perm, idx, w, scal, red,
-      pslots, fslots, aslots, edge, st, total;
+      pslots, fslots, aslots, edge, st, gsum, total;
 };
 __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   WLayout l;
@@ -320,6 +320,7 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   l.aslots = take(sizeof(float) * NW * (D * D + D));
   l.edge = take(sizeof(float) * (NW + 1) * D);
   l.st = take(sizeof(double) * 4);      // serial wave -> block: previous sigma_obs, gamma variate
+  l.gsum = take(sizeof(double) * NW * 64);   // quarter sums of the segment partials
   l.total = o;
   return l;
 }
@@ -749,14 +750,20 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
 // the GPU idle while one CU streams the design matrix at its own latency-bound ~45 GB/s, so the
 // phases that are independent across time -- X~'targets, the emission of the previous draw, X w
 // -- are shared between `cluster` workgroups: workgroup 0 of a chain ("main") runs the whole
-// iteration, the others only their share of those phases.  Handshakes are per-chain counters in
+// iteration, the others only their share of those phases -- and the first of them also sweeps the
+// NEXT iteration's regression matrix while main is in the Durbin-Koopman draw (presweep_block).
+// Handshakes are per-chain counters in
 // HBM (release: every thread fences, barrier, one atomic store; acquire: one thread spins, fences,
 // barrier); the workgroups of a chain are placed on ONE XCD (dispatch is round-robin over the 8
-// XCDs), so they share its L2.  Reductions are over FIXED segments of 2 * NT chunks whatever the
-// cluster size, summed in segment order: every cluster size gives the same bits.
+// XCDs), so they share its L2.  Reductions are over FIXED segments of NT chunks (1024 steps)
+// whatever the cluster size, summed in segment order: every cluster size gives the same bits.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void cl_publish(int* flag, int value, int tid) {
-  __threadfence();
+// `light`: every workgroup of the chain was found on the same XCD (cl_same_xcd), so stores only
+// have to reach the shared L2 (the vector L1 is write-through: wait for them) and the reader only
+// has to drop its L1; otherwise the release also writes the L2 back (agent scope).
+__device__ __forceinline__ void cl_publish(int* flag, int value, int tid, bool light) {
+  if (light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  else __threadfence();
   __syncthreads();
   if (tid == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -766,11 +773,42 @@ __device__ __forceinline__ void cl_wait(int* flags, int n, int value, int tid) {
     for (int r = 0; r < n; ++r)
       while (__hip_atomic_load(flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value)
         __builtin_amdgcn_s_sleep(2);
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
-enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_PARTIAL = 4, CL_XW = 8 };   // + role
+constexpr int CL_INTS = 32;              // handshake counters per chain
+enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_MODE = 2, CL_V = 3, CL_PARTIAL = 8, CL_XW = 16, CL_XCC = 24 };   // + role (< 8)
+// Are all G workgroups of this chain on one XCD?  (They are when dispatch is round-robin over the
+// XCDs, which the id -> (chain, role) map assumes; this checks instead of trusting.)  Plain
+// atomics: the counters are the message.
+__device__ __forceinline__ bool cl_same_xcd(int* csync, int role, int G, int tid) {
+  __shared__ int mode_s;
+  if (tid == 0) {
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 15) + 1;
+    int mode;
+    if (role > 0) {
+      __hip_atomic_store(csync + CL_XCC + role, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((mode = __hip_atomic_load(csync + CL_MODE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
+        __builtin_amdgcn_s_sleep(2);
+    } else {
+      bool same = true;
+      for (int r = 1; r < G; ++r) {
+        int v;
+        while ((v = __hip_atomic_load(csync + CL_XCC + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
+          __builtin_amdgcn_s_sleep(2);
+        same = same && v == xcc;
+      }
+      mode = same ? 2 : 1;
+      __hip_atomic_store(csync + CL_MODE, mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    mode_s = mode;
+  }
+  __syncthreads();
+  return mode_s == 2;
+}
 
 // ------------------------------------------------------------------------------------
 // the persistent Gibbs kernel (same iteration structure as gibbs_kernel / the oracle's
@@ -813,6 +851,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   float* aslots = (float*)(smem + lay.aslots);
   float* edge = (float*)(smem + lay.edge);
   double* st = (double*)(smem + lay.st);
+  double* gsum = (double*)(smem + lay.gsum);
   const int RS = (P > 16 ? P : 16) + 4;
 
   // per-chain HBM workspace
@@ -837,18 +876,22 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   // ---- phases shared by the workgroups of a cluster -------------------------------------------
   const bool vec4 = (T & 3) == 0;            // (clusters need it; the host checks)
   const int n4 = T >> 2;                     // chunks of 4 steps
-  const int nseg = (n4 + 2 * NT - 1) / (2 * NT);
-  int* csync = a.csync + chain_lin * 16;
+  const int nseg = (n4 + NT - 1) / NT;
+  int* csync = a.csync + chain_lin * CL_INTS;
   float* cpart = a.cpart + chain_lin * (size_t)nseg * NW * RS;
   float* cw = a.cw + chain_lin * 64;
+  double* cv = a.cv + chain_lin * (size_t)(P + 1) * (P + 1);
   const int clo = (int)((long long)(TP >> 2) * role / G), chi = (int)((long long)(TP >> 2) * (role + 1) / G);
   const int n_iter = g.W + g.S;
 
-  // (1) targets y - level - seasonal of segment `seg` (2 x NT chunks of 4 steps), their squares and
-  // X~'targets: four wave partials per column, to cpart[seg][wave][.]
-  auto segment_sums = [&](int seg) {
-    const int c4 = seg * 2 * NT + tid, c4b = c4 + NT;
-    const bool ha = c4 < n4, hb = c4b < n4;
+  // (1) targets y - level - seasonal of segments `sa` and `sb` (NT chunks of 4 steps each; sb may be
+  // >= nseg: nothing), their squares and X~'targets: four wave partials per column and segment, to
+  // cpart[seg][wave][.].  Two segments per pass keep 2 x XR 16-byte loads in flight per thread (one
+  // wave per SIMD here: memory latency is hidden by bytes in flight, not by occupancy).
+  auto segment_pair_sums = [&](int sa, int sb) {
+    const int c4 = sa * NT + tid, c4b = sb * NT + tid;
+    const bool two = sb < nseg;                                    // uniform
+    const bool ha = c4 < n4, hb = two && c4b < n4;
     const int ca = ha ? c4 : 0, cb = hb ? c4b : 0;
     float4 tg, tgb;
     {
@@ -871,14 +914,13 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       tgb.z = (mk & 0xFF0000u) ? 0.f : y4.z - l4.z - s4.z;
       tgb.w = (mk & 0xFF000000u) ? 0.f : y4.w - l4.w - s4.w;
     }
-    float yty = 0.f;
-    yty = fmaf(tg.x, tg.x, yty); yty = fmaf(tg.y, tg.y, yty);
-    yty = fmaf(tg.z, tg.z, yty); yty = fmaf(tg.w, tg.w, yty);
-    yty = fmaf(tgb.x, tgb.x, yty); yty = fmaf(tgb.y, tgb.y, yty);
-    yty = fmaf(tgb.z, tgb.z, yty); yty = fmaf(tgb.w, tgb.w, yty);
-    float* out = cpart + (size_t)seg * NW * RS;
-    // XR design rows x 2 chunks per pass: 2 x XR 16-byte loads in flight per thread (one wave per
-    // SIMD here, so memory latency is hidden by bytes in flight per thread, not by occupancy)
+    float ya = 0.f, yb = 0.f;
+    ya = fmaf(tg.x, tg.x, ya); ya = fmaf(tg.y, tg.y, ya);
+    ya = fmaf(tg.z, tg.z, ya); ya = fmaf(tg.w, tg.w, ya);
+    yb = fmaf(tgb.x, tgb.x, yb); yb = fmaf(tgb.y, tgb.y, yb);
+    yb = fmaf(tgb.z, tgb.z, yb); yb = fmaf(tgb.w, tgb.w, yb);
+    float* outa = cpart + (size_t)sa * NW * RS;
+    float* outb = cpart + (size_t)(two ? sb : sa) * NW * RS;
     for (int j0 = 0; j0 < P; j0 += XR) {
       float4 xv[XR], xb[XR];
 #pragma unroll
@@ -889,14 +931,24 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < XR; ++q) {
-        float acc = xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
-        acc += xb[q].x * tgb.x + xb[q].y * tgb.y + xb[q].z * tgb.z + xb[q].w * tgb.w;
-        const float sw = wave_sum_dpp(acc);
-        if (lane == 0 && j0 + q < P) out[wave * RS + j0 + q] = sw;
+        const float pa = xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
+        const float pb = xb[q].x * tgb.x + xb[q].y * tgb.y + xb[q].z * tgb.z + xb[q].w * tgb.w;
+        const float wa = wave_sum_dpp(pa), wb = wave_sum_dpp(pb);
+        if (lane == 0 && j0 + q < P) {
+          outa[wave * RS + j0 + q] = wa;
+          if (two) outb[wave * RS + j0 + q] = wb;
+        }
       }
     }
-    const float s0 = wave_sum_dpp(yty);
-    if (lane == 0) out[wave * RS + RS - 4] = s0;
+    const float wa = wave_sum_dpp(ya), wb = wave_sum_dpp(yb);
+    if (lane == 0) {
+      outa[wave * RS + RS - 4] = wa;
+      if (two) outb[wave * RS + RS - 4] = wb;
+    }
+  };
+  // the segments of one role: role, role + G, ... taken two at a time
+  auto role_segment_sums = [&]() {
+    for (int sa = role; sa < nseg; sa += 2 * G) segment_pair_sums(sa, sa + G);
   };
 
   // (3) latents and posterior-predictive trajectory of iteration it - 1, chunks [lo, hi)
@@ -986,19 +1038,39 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     }
   };
 
+  const bool light = G > 1 ? cl_same_xcd(csync, role, G, tid) : true;
   if (role > 0) {
-    // ---- helper workgroup: its share of phases (1), (3), (4), nothing else
+    // ---- helper workgroup: its share of phases (1), (3), (4); the first helper also prepares the
+    // next iteration's regression matrix
+    const bool sweeper = role == 1 && P > 16;
+    if (sweeper) {
+      for (int e = tid; e < P * P; e += NT) {
+        R.xtx[e] = g.xtx[(size_t)series * P * P + e];
+        R.omega[e] = g.omega[(size_t)series * P * P + e];
+      }
+      __syncthreads();
+    }
     for (int it = 0; it <= n_iter; ++it) {
       cl_wait(csync + CL_LATENTS, 1, it + 1, tid);
-      for (int seg = role; seg < nseg; seg += G) segment_sums(seg);
-      cl_publish(csync + CL_PARTIAL + role, it + 1, tid);
+      role_segment_sums();
+      cl_publish(csync + CL_PARTIAL + role, it + 1, tid, light);
       cl_wait(csync + CL_WEIGHTS, 1, it + 1, tid);
       if (tid < P) R.w[tid] = cw[tid];
       const float so = cw[P];
       __syncthreads();
       if (it > g.W) emit_range(it, so, clo, chi);
       if (it < n_iter) xw_range(clo, chi);
-      cl_publish(csync + CL_XW + role, it + 1, tid);
+      cl_publish(csync + CL_XW + role, it + 1, tid, light);
+      if (sweeper && it + 1 < n_iter) {
+        // iteration it + 1 sweeps Omega s2 + X'X on the features that are in now, s2 this
+        // iteration's observation-noise variance: both are in the message just received
+        const double so_d = *reinterpret_cast<const double*>(cw + 56);
+        const bool all_in = sp.nonzero_prob >= 1.0;
+        const unsigned long long nzmask = __ballot(lane < P && (all_in || R.w[lane < P ? lane : 0] != 0.f));
+        presweep_block(R, P, so_d * so_d, nzmask, false, tid);
+        for (int e = tid; e < (P + 1) * (P + 1); e += NT) cv[e] = R.aug[0][e];
+        cl_publish(csync + CL_V, it + 1, tid, light);
+      }
     }
     return;
   }
@@ -1044,12 +1116,12 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
   Prof prof;
   prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && tid == 0);
-  if (G > 1) cl_publish(csync + CL_LATENTS, 1, tid);      // masks and zeroed latents are in place
+  if (G > 1) cl_publish(csync + CL_LATENTS, 1, tid, light);      // masks and zeroed latents are in place
 
   for (int it = 0; it <= n_iter; ++it) {
     // ---- (1) targets, y'y, X~'targets (time interleaved over threads: coalesced)
     if (vec4) {
-      for (int seg = 0; seg < nseg; seg += G) segment_sums(seg);
+      role_segment_sums();
       const float s1 = wave_sum_dpp(ssl), s2 = wave_sum_dpp(sss), s3 = wave_sum_dpp(ssd);
       if (lane == 0) {
         red[wave * RS + RS - 3] = s1;
@@ -1110,6 +1182,18 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       }
     }
     __syncthreads();      // (G == 1: the partials are this workgroup's own stores, same CU)
+    if (vec4) {
+      // X~'targets and y'y: wave w adds its quarter of the (segment, wave) partials in order; the
+      // serial section adds the four quarters -- a fixed tree, whatever the cluster size
+      const int ne = nseg * NW, e0 = ne * wave / NW, e1 = ne * (wave + 1) / NW;
+      if (lane <= P) {
+        const int src = lane < P ? lane : RS - 4;
+        double sq = 0.0;
+        for (int e = e0; e < e1; ++e) sq += (double)cpart[(size_t)e * RS + src];
+        gsum[wave * 64 + lane] = sq;
+      }
+      __syncthreads();
+    }
     prof.tick(0);
 
     // ---- (2) serial section (wave 0): scales of iteration it-1, regression draw of iteration it
@@ -1118,8 +1202,8 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         const int src = j < P ? j : RS - 4 + (j - P);
         double s = 0.0;
         if (vec4 && j <= P) {
-          // X~'targets and y'y: the segments' wave partials, in segment order
-          for (int e = 0; e < nseg * NW; ++e) s += (double)cpart[(size_t)e * RS + src];
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s += gsum[w * 64 + j];
         } else {
 #pragma unroll
           for (int w = 0; w < NW; ++w) s += (double)red[w * RS + src];
@@ -1178,7 +1262,10 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     if (P > 16 && it < n_iter) {
       // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
       prof.tick(9);
-      obs_scale = spike_slab_draw_block(R, P, sp, st[0], st[1], rng, (uint32_t)it, tid, it == 0, &prof);
+      const bool prepared = G > 1 && it > 0;      // the cluster's first helper swept the matrix
+      if (prepared) cl_wait(csync + CL_V, 1, it, tid);
+      obs_scale = spike_slab_draw_block(R, P, sp, st[0], st[1], rng, (uint32_t)it, tid, it == 0, &prof,
+                                        true, prepared ? cv : nullptr);
       if (tid == 0) scal[0] = (float)obs_scale;
       __syncthreads();
       prof.tick(10);
@@ -1188,8 +1275,11 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     // the cluster's helpers take their share of (3) and (4) from here
     if (G > 1) {
       if (tid < P) cw[tid] = R.w[tid];
-      if (tid == 0) cw[P] = scal[1];
-      cl_publish(csync + CL_WEIGHTS, it + 1, tid);
+      if (tid == 0) {
+        cw[P] = scal[1];
+        *reinterpret_cast<double*>(cw + 56) = obs_scale;
+      }
+      cl_publish(csync + CL_WEIGHTS, it + 1, tid, light);
     }
     // ---- (3) emit iteration it-1: latents and the posterior-predictive trajectory
     if (it > g.W) emit_range(it, scal[1], clo, chi);
@@ -1266,7 +1356,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
                          (uint32_t)it, tid, lane, wave, pslots, fslots, aslots, edge, ssl, sss, ssd,
                          prof);
     __syncthreads();
-    if (G > 1) cl_publish(csync + CL_LATENTS, it + 2, tid);
+    if (G > 1) cl_publish(csync + CL_LATENTS, it + 2, tid, light);
   }
   __syncthreads();     // the running sums were accumulated through the emission's thread mapping
   if (g.out_pred_mean) {

@@ -142,6 +142,64 @@ template <class E> __device__ __forceinline__ E lds_load_e(const float* p) {
   return __builtin_bit_cast(E, a);
 }
 
+// One DPP move of every float of an element: lanes the control word gives no source keep their own
+// value (callers mask those lanes anyway).
+template <int CTRL, int ROW_MASK, class E> __device__ __forceinline__ E dpp_move_e(const E& e) {
+  Arr<E> a = __builtin_bit_cast(Arr<E>, e);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(E) / 4); ++i)
+    a.f[i] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a.f[i]), __float_as_int(a.f[i]),
+                                                        CTRL, ROW_MASK, 0xF, false));
+  return __builtin_bit_cast(E, a);
+}
+
+// Inclusive scan of one wavefront, earlier lanes first, for any associative op(earlier, later), on
+// the DPP crossbar (VALU moves, no LDS round trips): Kogge-Stone inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8), then the last lane of row 0 / 2 joins rows 1 / 3 (row_bcast:15) and lane 31
+// joins rows 2 and 3 (row_bcast:31).
+template <class E, class Op>
+__device__ __forceinline__ E wave_scan_incl_fwd(const E& v, Op op, int lane) {
+  E incl = v;
+  const int r = lane & 15;
+  { const E o = dpp_move_e<0x111, 0xF>(incl); if (r >= 1) incl = op(o, incl); }
+  { const E o = dpp_move_e<0x112, 0xF>(incl); if (r >= 2) incl = op(o, incl); }
+  { const E o = dpp_move_e<0x114, 0xF>(incl); if (r >= 4) incl = op(o, incl); }
+  { const E o = dpp_move_e<0x118, 0xF>(incl); if (r >= 8) incl = op(o, incl); }
+  { const E o = dpp_move_e<0x142, 0xA>(incl); if (lane & 16) incl = op(o, incl); }
+  { const E o = dpp_move_e<0x143, 0xC>(incl); if (lane & 32) incl = op(o, incl); }
+  return incl;
+}
+// Inclusive SUFFIX scan: lane i gets v_i o v_{i+1} o ... o v_63 with op(outer, inner).  Inside the
+// rows the same DPP pattern mirrored (row_shl); there is no backward row broadcast, so the two
+// steps across rows read the first lane of the next row / of row 2 through ds_bpermute.
+template <class E, class Op>
+__device__ __forceinline__ E wave_scan_incl_bwd(const E& v, Op op, int lane) {
+  E incl = v;
+  const int r = lane & 15;
+  { const E o = dpp_move_e<0x101, 0xF>(incl); if (r < 15) incl = op(incl, o); }
+  { const E o = dpp_move_e<0x102, 0xF>(incl); if (r < 14) incl = op(incl, o); }
+  { const E o = dpp_move_e<0x104, 0xF>(incl); if (r < 12) incl = op(incl, o); }
+  { const E o = dpp_move_e<0x108, 0xF>(incl); if (r < 8) incl = op(incl, o); }
+  {
+    // rows 0 and 2 take the suffix of row 1 / row 3 (held by that row's first lane)
+    Arr<E> a = __builtin_bit_cast(Arr<E>, incl);
+    const int src = ((lane | 15) + 1) & 63;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(E) / 4); ++i) a.f[i] = __shfl(a.f[i], src, 64);
+    const E o = __builtin_bit_cast(E, a);
+    if ((lane & 16) == 0) incl = op(incl, o);
+  }
+  {
+    // rows 0 and 1 take the suffix of rows 2-3 (lane 32)
+    Arr<E> a = __builtin_bit_cast(Arr<E>, incl);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(E) / 4); ++i) a.f[i] = __shfl(a.f[i], 32, 64);
+    const E o = __builtin_bit_cast(E, a);
+    if ((lane & 32) == 0) incl = op(incl, o);
+  }
+  return incl;
+}
+
 // Exclusive block scan over thread order (thread 0 first).  op(earlier, later).
 // Contains exactly one __syncthreads(); `slots` needs NW * sizeof(E)/4 floats and must not
 // be rewritten before another barrier has been passed.
@@ -149,15 +207,10 @@ template <class E, class Op>
 __device__ __forceinline__ E block_scan_excl_fwd(const E& tot, Op op, const E& ident, float* slots,
                                                  int lane, int wave) {
   constexpr int N = sizeof(E) / 4;
-  E incl = tot;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const E o = shfl_up_e(incl, off);
-    if (lane >= off) incl = op(o, incl);
-  }
+  const E incl = wave_scan_incl_fwd(tot, op, lane);
   if (lane == 63) lds_store_e(slots + wave * N, incl);
   __syncthreads();
-  E ex = shfl_up_e(incl, 1);
+  E ex = dpp_move_e<0x138, 0xF>(incl);        // wave_shr:1
   if (lane == 0) ex = ident;
   if (wave == 0) return ex;
   E wp = lds_load_e<E>(slots);
@@ -171,15 +224,10 @@ template <class E, class Op>
 __device__ __forceinline__ E block_scan_excl_bwd(const E& tot, Op op, const E& ident, float* slots,
                                                  int lane, int wave) {
   constexpr int N = sizeof(E) / 4;
-  E incl = tot;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const E o = shfl_down_e(incl, off);
-    if (lane + off < 64) incl = op(incl, o);
-  }
+  const E incl = wave_scan_incl_bwd(tot, op, lane);
   if (lane == 0) lds_store_e(slots + wave * N, incl);
   __syncthreads();
-  E ex = shfl_down_e(incl, 1);
+  E ex = dpp_move_e<0x130, 0xF>(incl);        // wave_shl:1
   if (lane == 63) ex = ident;
   if (wave == NW - 1) return ex;
   E ws = lds_load_e<E>(slots + (wave + 1) * N);

@@ -273,13 +273,21 @@ def test_baseline_cfg5_full_size_batch_equals_single_series_runs_and_oracle():
                             want=("level", "weights", "observation_noise_scale"))
   assert np.isfinite(batch["level"]).all()
   for b in (0, 255, 511):
+    # the 512-workgroup launch runs the four-wavefront build; a single series would get the
+    # five-wavefront latency build (same sampler, same streams, float32 round-off apart)
     pb1 = _native.make_problem(T=T, P=6, has_slope=0, num_warmup=W, num_results=S, seed=(5, 12),
-                               series_offset=b)
+                               series_offset=b, flags=_native.FLAG_FOUR_WAVES)
     one = _native.fit_gibbs(pb1, ys[b][None], masks[b][None], Xs[b][None], None,
                             _native.make_params([specs[b]]),
                             want=("level", "weights", "observation_noise_scale"))
     for k in ("level", "weights", "observation_noise_scale"):
       np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
+    pb5 = _native.make_problem(T=T, P=6, has_slope=0, num_warmup=W, num_results=S, seed=(5, 12),
+                               series_offset=b)
+    five = _native.fit_gibbs(pb5, ys[b][None], masks[b][None], Xs[b][None], None,
+                             _native.make_params([specs[b]]), want=("level", "weights"))
+    np.testing.assert_allclose(five["level"][0], batch["level"][b], atol=5e-3)
+    np.testing.assert_array_equal(five["weights"][0] != 0, batch["weights"][b] != 0)
     # the oracle's stream word: chain id + (series id << 16)
     w = orc.fit_gibbs(ys[b], masks[b], Xs[b], specs[b], num_results=S, num_warmup=W, seed=(5, 12),
                       chain=b << 16)

@@ -336,68 +336,74 @@ __device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const V
                                                    float* slots16, Vec<D> (&ap)[L],
                                                    Mat<D> (&Pp)[L], Vec<D> (&kf)[L], float (&vf)[L],
                                                    float (&fvar)[L], PF& prof) {
-  // ---- (2) Kalman filter as an associative scan over (A, b, C, eta, J)
-  const Mat<D> Tm = trans_mat<D>();
-  FElem<D> ftot = felem_identity<D>();
+  // ---- (2) Kalman filter as an associative scan over (A, b, C, eta, J), C and J packed symmetric.
+  // The chunk's element is built step by step: time update (A <- T A, b <- T b, C <- T C T' + Q),
+  // then, where y_t is observed, a rank-one fold of the observation (Z = e_0'):
+  //   S = C_00 + H ;  e = (y - b_0) / S ;  eta += A_0.' e ;  b += C_.0 e ;
+  //   J += A_0.' A_0. / S ;  A -= C_.0 A_0. / S ;  C -= C_.0 C_0. / S
+  // -- the product of the one-step elements without forming them.
+  FElemS<D> fe = felems_identity<D>();
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const bool obs = ((maskbits >> l) & 1u) == 0u;
-    FElem<D> e;
     if (tid == 0 && l == 0) {
       // prior element: A = 0, (b, C) = moments of x_0 after its own update
-      e.A = mzero<D>();
-      e.eta = vzero<D>();
-      e.J = mzero<D>();
-      e.b = a1e;
-      e.C = mzero<D>();
+      fe.A = mzero<D>();
+      fe.b = a1e;
 #pragma unroll
-      for (int i = 0; i < D; ++i) e.C.m[i][i] = md.p1.v[i];
+      for (int i = 0; i < D; ++i) fe.C[symidx<D>(i, i)] = md.p1.v[i];
       if (obs) {
         const float F = md.p1.v[0] + md.H;
         const float k0 = md.p1.v[0] / F;
-        e.b.v[0] = fmaf(k0, ytil[l] - a1e.v[0], a1e.v[0]);
-        e.C.m[0][0] = md.p1.v[0] * md.H / F;
+        fe.b.v[0] = fmaf(k0, ytil[l] - a1e.v[0], a1e.v[0]);
+        fe.C[symidx<D>(0, 0)] = md.p1.v[0] * md.H / F;
       }
-    } else if (obs) {
-      // S = Z Q Z' + H ; K = Q Z'/S ; A = (I - K Z) T ; b = K y ; C = (I - K Z) Q
-      // eta = T' Z' y / S ; J = T' Z' Z T / S          (Z = e_0')
-      const float Sv = q.v[0] + md.H;
-      const float rS = 1.0f / Sv;
-      const float hk = md.H * rS;
-      e.A = Tm;
+      continue;
+    }
+    // time update
+    if constexpr (D == 2) {
 #pragma unroll
-      for (int j = 0; j < D; ++j) e.A.m[0][j] = hk * Tm.m[0][j];
-      e.b = vzero<D>();
-      e.b.v[0] = q.v[0] * rS * ytil[l];
-      e.C = mzero<D>();
-      e.C.m[0][0] = hk * q.v[0];
-      if constexpr (D == 2) e.C.m[1][1] = q.v[1];
+      for (int j = 0; j < D; ++j) fe.A.m[0][j] += fe.A.m[1][j];
+      fe.b.v[0] += fe.b.v[1];
+      fe.C[symidx<D>(0, 0)] = fmaf(2.f, fe.C[symidx<D>(0, 1)], __fadd_rn(fe.C[symidx<D>(0, 0)], fe.C[symidx<D>(1, 1)]));
+      fe.C[symidx<D>(0, 1)] += fe.C[symidx<D>(1, 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) fe.C[symidx<D>(i, i)] += q.v[i];
+    if (obs) {
+      float za[D], cz[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) { za[j] = fe.A.m[0][j]; cz[j] = fe.C[symidx<D>(j, 0)]; }
+      const float rS = 1.0f / (cz[0] + md.H);
+      const float e = (ytil[l] - fe.b.v[0]) * rS;
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        e.eta.v[i] = Tm.m[0][i] * ytil[l] * rS;
+        fe.eta.v[i] = fmaf(za[i], e, fe.eta.v[i]);
+        fe.b.v[i] = fmaf(cz[i], e, fe.b.v[i]);
+        const float ki = cz[i] * rS, zi = za[i] * rS;
 #pragma unroll
-        for (int j = 0; j < D; ++j) e.J.m[i][j] = Tm.m[0][i] * Tm.m[0][j] * rS;
+        for (int j = 0; j < D; ++j) fe.A.m[i][j] = fmaf(-ki, za[j], fe.A.m[i][j]);
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+          fe.J[symidx<D>(i, j)] = fmaf(zi, za[j], fe.J[symidx<D>(i, j)]);
+          fe.C[symidx<D>(i, j)] = fmaf(-ki, cz[j], fe.C[symidx<D>(i, j)]);
+        }
       }
-    } else {
-      e.A = Tm;
-      e.b = vzero<D>();
-      e.C = mzero<D>();
-#pragma unroll
-      for (int i = 0; i < D; ++i) e.C.m[i][i] = q.v[i];
-      e.eta = vzero<D>();
-      e.J = mzero<D>();
     }
-    ftot = (l == 0) ? e : felem_combine(ftot, e);
   }
-  const FElem<D> fpre = block_scan_excl_fwd(
-      ftot, [](const FElem<D>& a, const FElem<D>& b) { return felem_combine(a, b); },
-      felem_identity<D>(), slots16, lane, wave);
+  const FElemS<D> fpre = block_scan_excl_fwd(
+      fe, [](const FElemS<D>& a, const FElemS<D>& b) { return felems_combine(a, b); },
+      felems_identity<D>(), slots16, lane, wave);
   prof.tick(5);
 
   // local sequential Kalman pass over the owned steps (predicted-form quantities kept)
   {
     Vec<D> mf = fpre.b;
-    Mat<D> Pf = fpre.C;
+    Mat<D> Pf;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) Pf.m[i][j] = fpre.C[symidx<D>(i, j)];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const bool obs = ((maskbits >> l) & 1u) == 0u;
@@ -427,7 +433,7 @@ __device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const V
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
-          for (int j = 0; j < D; ++j) Pf.m[i][j] = P.m[i][j] - kf[l].v[i] * P.m[0][j];
+          for (int j = 0; j < D; ++j) Pf.m[i][j] = fmaf(-kf[l].v[i], P.m[0][j], P.m[i][j]);
         symmetrize(Pf);
       } else {
         vf[l] = 0.f;
@@ -499,7 +505,7 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       xp[l] = x;
-      ytil[l] = resid[l] - (x.v[0] + so * zo[l]);
+      ytil[l] = resid[l] - fmaf(so, zo[l], x.v[0]);
       x = trans_apply(x);
       x.v[0] = fmaf(md.sig.v[0], zl[l], x.v[0]);
       if constexpr (D == 2) x.v[1] = fmaf(md.sig.v[1], zs[l], x.v[1]);

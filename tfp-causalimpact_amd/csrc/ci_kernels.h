@@ -374,7 +374,7 @@ __device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const V
       float za[D], cz[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) { za[j] = fe.A.m[0][j]; cz[j] = fe.C[symidx<D>(j, 0)]; }
-      const float rS = 1.0f / (cz[0] + md.H);
+      const float rS = __builtin_amdgcn_rcpf(cz[0] + md.H);
       const float e = (ytil[l] - fe.b.v[0]) * rS;
 #pragma unroll
       for (int i = 0; i < D; ++i) {
@@ -423,7 +423,7 @@ __device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const V
       if (obs) {
         const float v = ytil[l] - a.v[0];
         const float Fv = P.m[0][0] + md.H;
-        const float rF = 1.0f / Fv;
+        const float rF = __builtin_amdgcn_rcpf(Fv);
         fvar[l] = Fv;
         vf[l] = v * rF;
 #pragma unroll

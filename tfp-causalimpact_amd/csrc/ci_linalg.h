@@ -324,7 +324,7 @@ __device__ __forceinline__ FElemS<D> felems_combine(const FElemS<D>& e1, const F
   }
 #pragma unroll
   for (int c = 0; c < D; ++c) {
-    const float rp = 1.0f / W.m[c][c];
+    const float rp = __builtin_amdgcn_rcpf(W.m[c][c]);   // 1 ulp: ample for float32 moments
 #pragma unroll
     for (int j = c + 1; j < D; ++j) W.m[c][j] *= rp;
 #pragma unroll

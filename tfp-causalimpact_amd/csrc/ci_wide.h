@@ -426,7 +426,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
           for (int i = 0; i < D; ++i) cz[i] = fe.C[symidx<D>(i, 0)] + fe.C[symidx<D>(i, O)];
           const float zb = fe.b.v[0] + fe.b.v[O];
           const float Sv = cz[0] + cz[O] + sc.H;
-          const float rS = 1.0f / Sv;
+          const float rS = __builtin_amdgcn_rcpf(Sv);
           const float e = (yt - zb) * rS;
 #pragma unroll
           for (int i = 0; i < D; ++i) {
@@ -510,7 +510,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
 #pragma unroll
           for (int i = 0; i < D; ++i) pz[i] = Pm.m[i][0] + Pm.m[i][O];
           const float Fv = pz[0] + pz[O] + sc.H;
-          const float rF = 1.0f / Fv;
+          const float rF = __builtin_amdgcn_rcpf(Fv);
           const float v = yt - (am.v[0] + am.v[O]);
           vf = v * rF;
 #pragma unroll

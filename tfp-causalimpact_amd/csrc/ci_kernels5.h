@@ -163,14 +163,27 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
   m.cb = live ? R.bvec[col] : 0.0;
   m.corner = R.bvec[P];
   unsigned long long S = ps.S;
-  // ---- right-hand side through the recorded sweeps (sweep_q_kr: cb and corner lines)
-  for (int s = 0; s < ps.n_sw; ++s) {
-    const int k = __builtin_amdgcn_readfirstlane(tb.ksw[s]);
-    const double rd = tb.rdsw[s];
-    const double t = tb.tsw[s * 64 + lane];
-    const double cbk = readlane_d(m.cb, k);
-    m.cb = (j == k) ? cbk * rd : m.cb - cbk * t;
-    m.corner -= cbk * cbk * rd;
+  // ---- right-hand side: with V the matrix swept on S (precompute) and b = X~'targets,
+  //   b~_j = (j in S ? 0 : b_j) - sum_{k in S} V_kj b_k ,   corner = y'y - sum_{k in S} b_k b~_k
+  // (what carrying b through the recorded sweeps gives, as one matrix-vector product: lane
+  // (j, q) holds V_{4q+r, j}, r < 4; the four quadrants are added across the rows of 16 lanes)
+  {
+    double part = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * q + r;
+      const double bk = k < P ? R.bvec[k] : 0.0;
+      if ((S >> k) & 1ull) part = fma(m.c[r], bk, part);
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    const bool inj = ((S >> j) & 1ull) != 0ull;
+    const double bj = m.cb;
+    m.cb = live ? (inj ? 0.0 : bj) - part : 0.0;
+    double term = (live && inj) ? bj * m.cb : 0.0;      // (the same in every quadrant)
+    term += __shfl_xor(term, 1, 64); term += __shfl_xor(term, 2, 64);
+    term += __shfl_xor(term, 4, 64); term += __shfl_xor(term, 8, 64);
+    m.corner -= term;
   }
   prof.tick(21);
   bool dirty = false;
@@ -221,15 +234,17 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
   const double mean = m.cb;
   double mu = 0.0, umine = 0.0;
   if (!dirty) {
-    // recorded un-sweeps: feature a ~ N(mu_a, V_aa), the rest conditioned on it
+    // recorded un-sweeps (descending feature order): feature a ~ N(mu_a, V_aa), the rest
+    // conditioned on it.  The increments sqrt(V_aa) z_a do not depend on the running means, so
+    // the deviation of feature j is a plain sum over the steps -- its own increment plus
+    // t_s[j] times those of the features drawn before it -- with no chain from step to step.
+#pragma unroll 4
     for (int s = 0; s < ps.n_un; ++s) {
       const int aidx = __builtin_amdgcn_readfirstlane(tb.kun[s]);
-      const double vaa = tb.vun[s];
       const double t = tb.tun[s * 64 + lane];
-      const double mua = readlane_d(mu, aidx);
       const double za = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zf), aidx));
-      const double ua = mua + (double)__fsqrt_rn((float)vaa) * za;
-      if (j == aidx) umine = ua; else mu += t * (ua - mua);
+      const double cs = (double)__fsqrt_rn((float)tb.vun[s]) * za;
+      umine += aidx > j ? t * cs : (aidx == j ? cs : 0.0);
     }
   } else {
     for (unsigned long long mm = S; mm != 0ull;) {

@@ -95,6 +95,10 @@ typedef struct ci_problem {
  * chain's time-independent phases over a cluster of 2, 4 or 8 CUs (few chains of a long series).
  * Every cluster size gives the same bits; test / diagnostic knob. */
 #define CI_FLAG_NO_CLUSTER 16
+/* Test knob: the last workgroup of every cluster exits at once, as if it had never been
+ * scheduled -- the others must notice (time-out while assembling the cluster) and the chain's
+ * main workgroup must carry on alone with unchanged results. */
+#define CI_FLAG_TEST_DROP_HELPER 32
 
 /* Caller-allocated result buffers (float32, chain-major so per-device shards
  * are contiguous).  == GibbsSamplerState stack + (means, trajectories) returned

@@ -487,7 +487,10 @@ def test_clusters_of_workgroups_give_the_same_bits_as_one_workgroup_per_chain():
   eight = fit(2, 0)                                           # 8 x 8 workgroups <= 256 CUs
   four = fit(40, 0)                                           # 40 x 8 > 256 >= 40 x 4
   two = fit(72, 0)                                            # 72 x 4 > 256 >= 72 x 2
+  # a cluster that does not assemble (one helper "never scheduled"): main notices and runs alone
+  lonely = fit(2, _native.FLAG_TEST_DROP_HELPER)
   for key in one:
+    np.testing.assert_array_equal(lonely[key], one[key], err_msg=key)
     np.testing.assert_array_equal(eight[key], one[key], err_msg=key)
     np.testing.assert_array_equal(four[key][:, :2], one[key], err_msg=key)
     np.testing.assert_array_equal(two[key][:, :2], one[key], err_msg=key)

@@ -723,6 +723,7 @@ static int session_launch(ci_session* s) {
     sa.out_drift = s->o_drift.p; sa.out_seasonal = s->o_seasonal.p;
     sa.ws = s->ws.p; sa.Lc = s->Lc;
     sa.cluster = s->wide ? s->cluster : 1;
+    sa.cluster_drop = (pb.flags & CI_FLAG_TEST_DROP_HELPER) ? sa.cluster - 1 : 0;
     sa.csync = s->csync.p; sa.cpart = s->cpart.p; sa.cw = s->cw.p; sa.cv = s->cv.p;
     int grid = pb.num_series * pb.num_chains;
     if (s->wide && s->cluster > 1) {

@@ -779,35 +779,60 @@ __device__ __forceinline__ void cl_wait(int* flags, int n, int value, int tid) {
 }
 constexpr int CL_INTS = 32;              // handshake counters per chain
 enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_MODE = 2, CL_V = 3, CL_PARTIAL = 8, CL_XW = 16, CL_XCC = 24 };   // + role (< 8)
-// Are all G workgroups of this chain on one XCD?  (They are when dispatch is round-robin over the
-// XCDs, which the id -> (chain, role) map assumes; this checks instead of trusting.)  Plain
-// atomics: the counters are the message.
-__device__ __forceinline__ bool cl_same_xcd(int* csync, int role, int G, int tid) {
+// Assembling a cluster.  The handshakes below spin, so a cluster may only run when ALL its
+// workgroups are resident -- which the host sizes the launch for, but cannot guarantee (another
+// stream or process may hold CUs).  So the cluster is agreed on at the start, with time-outs:
+// helpers check in (their XCD id + 1); main claims them one by one (compare-and-swap) and
+// publishes the mode -- 2: all here, all on main's XCD (L2-local handshakes), 1: all here, mixed
+// XCDs (agent-scope releases), 3: someone missing, main runs alone (every cluster size gives the
+// same bits, so nothing else changes).  A helper main has not claimed after 5 ms withdraws with
+// the same compare-and-swap, so neither side ever waits for a workgroup that is not running.
+__device__ __forceinline__ int cl_assemble(int* csync, int role, int G, int tid) {
   __shared__ int mode_s;
   if (tid == 0) {
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc = (xcc & 15) + 1;
-    int mode;
+    const long long t0 = wall_clock64();                 // 100 MHz
+    int mode = 0;
     if (role > 0) {
-      __hip_atomic_store(csync + CL_XCC + role, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while ((mode = __hip_atomic_load(csync + CL_MODE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
-        __builtin_amdgcn_s_sleep(2);
-    } else {
-      bool same = true;
-      for (int r = 1; r < G; ++r) {
-        int v;
-        while ((v = __hip_atomic_load(csync + CL_XCC + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
-          __builtin_amdgcn_s_sleep(2);
-        same = same && v == xcc;
+      int* slot = csync + CL_XCC + role;
+      __hip_atomic_store(slot, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        mode = __hip_atomic_load(csync + CL_MODE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mode != 0) break;
+        if (wall_clock64() - t0 > 500000) {
+          int expect = xcc;
+          if (__hip_atomic_compare_exchange_strong(slot, &expect, -1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)) {
+            mode = 3;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(8);
       }
-      mode = same ? 2 : 1;
+    } else {
+      bool all = true, same = true;
+      for (int r = 1; r < G && all; ++r) {
+        int* slot = csync + CL_XCC + r;
+        int v;
+        while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 &&
+               wall_clock64() - t0 < 100000)
+          __builtin_amdgcn_s_sleep(8);
+        int expect = v;
+        if (v <= 0 || !__hip_atomic_compare_exchange_strong(slot, &expect, v + 64, __ATOMIC_RELAXED,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          all = false;
+        else
+          same = same && v == xcc;
+      }
+      mode = all ? (same ? 2 : 1) : 3;
       __hip_atomic_store(csync + CL_MODE, mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     mode_s = mode;
   }
   __syncthreads();
-  return mode_s == 2;
+  return mode_s;
 }
 
 // ------------------------------------------------------------------------------------
@@ -825,12 +850,12 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const int T = g.T, P = g.P, Lc = a.Lc;
   const int TP = NT * Lc;
   // workgroup -> (chain, role): the workgroups of one chain share an XCD (ids equal mod 8)
-  const int G = a.cluster;
+  const int GL = a.cluster;                   // workgroups per chain in this launch
   int chain_id = blockIdx.x, role = 0;
-  if (G > 1) {
+  if (GL > 1) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    role = slot % G;
-    chain_id = (slot / G) * 8 + xcd;
+    role = slot % GL;
+    chain_id = (slot / GL) * 8 + xcd;
     if (chain_id >= g.B * g.C) return;
   }
   const int series = chain_id / g.C, chain = chain_id % g.C;
@@ -878,6 +903,11 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const int n4 = T >> 2;                     // chunks of 4 steps
   const int nseg = (n4 + NT - 1) / NT;
   int* csync = a.csync + chain_lin * CL_INTS;
+  if (GL > 1 && role > 0 && role == a.cluster_drop) return;     // (test knob: a helper that never ran)
+  const int cmode = GL > 1 ? cl_assemble(csync, role, GL, tid) : 3;
+  if (cmode == 3 && role > 0) return;         // the cluster did not assemble: main runs alone
+  const int G = cmode == 3 ? 1 : GL;          // workgroups actually sharing this chain
+  const bool light = cmode == 2;
   float* cpart = a.cpart + chain_lin * (size_t)nseg * NW * RS;
   float* cw = a.cw + chain_lin * 64;
   double* cv = a.cv + chain_lin * (size_t)(P + 1) * (P + 1);
@@ -1038,7 +1068,6 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     }
   };
 
-  const bool light = G > 1 ? cl_same_xcd(csync, role, G, tid) : true;
   if (role > 0) {
     // ---- helper workgroup: its share of phases (1), (3), (4); the first helper also prepares the
     // next iteration's regression matrix

@@ -24,15 +24,23 @@ import csv
 import json
 
 
+LAST = 0   # --last N: only the last N dispatches of the kernel (e.g. the 8-chain launches of a sweep)
+
+
 def per_launch(path, kernel_substr):
-  tot = collections.defaultdict(float)
-  n = collections.defaultdict(int)
+  per = collections.defaultdict(lambda: collections.defaultdict(float))   # dispatch -> counter -> sum
   with open(path) as f:
     for row in csv.DictReader(f):
       if kernel_substr in row.get("Kernel_Name", ""):
-        tot[row["Counter_Name"]] += float(row["Counter_Value"])
-        n[row["Counter_Name"]] += 1
-  return {k: tot[k] / n[k] for k in tot}, (max(n.values()) if n else 0)
+        per[int(row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])
+  ids = sorted(per)
+  if LAST:
+    ids = ids[-LAST:]
+  tot = collections.defaultdict(float)
+  for d in ids:
+    for k, v in per[d].items():
+      tot[k] += v
+  return {k: tot[k] / len(ids) for k in tot}, len(ids)
 
 
 def main():
@@ -43,7 +51,10 @@ def main():
   ap.add_argument("--also", nargs="*", default=[])
   ap.add_argument("--out", required=True)
   ap.add_argument("--algorithmic-bytes", type=float, default=None)
+  ap.add_argument("--last", type=int, default=0)
   args = ap.parse_args()
+  global LAST
+  LAST = args.last
   if args.mode == "hbm":
     out = {"kernels": {}}
     total = 0.0

@@ -171,7 +171,7 @@ __device__ __forceinline__ E wave_scan_incl_fwd(const E& v, Op op, int lane) {
 }
 // Inclusive SUFFIX scan: lane i gets v_i o v_{i+1} o ... o v_63 with op(outer, inner).  Inside the
 // rows the same DPP pattern mirrored (row_shl); there is no backward row broadcast, so the two
-// steps across rows read the first lane of the next row / of row 2 through ds_bpermute.
+// steps across rows read the first lane of the next row / of row 2 through v_readlane.
 template <class E, class Op>
 __device__ __forceinline__ E wave_scan_incl_bwd(const E& v, Op op, int lane) {
   E incl = v;
@@ -181,11 +181,15 @@ __device__ __forceinline__ E wave_scan_incl_bwd(const E& v, Op op, int lane) {
   { const E o = dpp_move_e<0x104, 0xF>(incl); if (r < 12) incl = op(incl, o); }
   { const E o = dpp_move_e<0x108, 0xF>(incl); if (r < 8) incl = op(incl, o); }
   {
-    // rows 0 and 2 take the suffix of row 1 / row 3 (held by that row's first lane)
+    // rows 0 and 2 take the suffix of row 1 / row 3, held by that row's first lane: two fixed
+    // source lanes, read through v_readlane (no LDS round trip)
     Arr<E> a = __builtin_bit_cast(Arr<E>, incl);
-    const int src = ((lane | 15) + 1) & 63;
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(E) / 4); ++i) a.f[i] = __shfl(a.f[i], src, 64);
+    for (int i = 0; i < (int)(sizeof(E) / 4); ++i) {
+      const int v16 = __builtin_amdgcn_readlane(__float_as_int(a.f[i]), 16);
+      const int v48 = __builtin_amdgcn_readlane(__float_as_int(a.f[i]), 48);
+      a.f[i] = __int_as_float(lane < 32 ? v16 : v48);
+    }
     const E o = __builtin_bit_cast(E, a);
     if ((lane & 16) == 0) incl = op(incl, o);
   }
@@ -193,7 +197,8 @@ __device__ __forceinline__ E wave_scan_incl_bwd(const E& v, Op op, int lane) {
     // rows 0 and 1 take the suffix of rows 2-3 (lane 32)
     Arr<E> a = __builtin_bit_cast(Arr<E>, incl);
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(E) / 4); ++i) a.f[i] = __shfl(a.f[i], 32, 64);
+    for (int i = 0; i < (int)(sizeof(E) / 4); ++i)
+      a.f[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.f[i]), 32));
     const E o = __builtin_bit_cast(E, a);
     if ((lane & 32) == 0) incl = op(incl, o);
   }

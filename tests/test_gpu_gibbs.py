@@ -496,3 +496,26 @@ def test_clusters_of_workgroups_give_the_same_bits_as_one_workgroup_per_chain():
     np.testing.assert_array_equal(two[key][:, :2], one[key], err_msg=key)
   assert np.isfinite(one["posterior_trajectories"]).all()
   assert (one["weights"] == 0).any() and (one["weights"] != 0).any()
+
+
+def test_concurrent_cluster_launches_on_one_gpu_neither_hang_nor_change_the_draws():
+  """Two device shares of a weekly-seasonal fit run concurrently on ONE GPU (`devices=[0, 0]`):
+  together their clusters ask for more workgroups than there are CUs, so some clusters cannot
+  assemble and fall back to one workgroup per chain (ci_wide.h, cl_assemble).  Nothing may
+  hang and the pooled draws must be those of the single launch."""
+  import pandas as pd
+  import causalimpact as ci
+  T, p = 2000, 20
+  y, X = syn.make_raw_series(T, p, 3)
+  y = y + 2.0 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  df = pd.DataFrame(np.column_stack([y, X]), columns=["y"] + [f"x{j}" for j in range(p)])
+  kw = dict(seed=5, model_options=ci.ModelOptions(seasons=[ci.Seasons(num_seasons=7)]))
+  opts = dict(num_results=40, num_warmup_steps=10, num_chains=48)
+  one = ci.fit_causalimpact(df, (0, 1399), (1400, T - 1),
+                            inference_options=ci.InferenceOptions(devices=[0], **opts), **kw)
+  for _ in range(3):
+    two = ci.fit_causalimpact(df, (0, 1399), (1400, T - 1),
+                              inference_options=ci.InferenceOptions(devices=[0, 0], **opts), **kw)
+    for f in ("observation_noise_scale", "level_scale", "level", "weights", "seasonal_levels"):
+      np.testing.assert_array_equal(getattr(two.posterior_samples, f),
+                                    getattr(one.posterior_samples, f), err_msg=f)

@@ -2061,6 +2061,50 @@ __device__ __forceinline__ NElem<D> nelem_compose(const NElem<D>& o, const NElem
   return r;
 }
 
+// Both recursions at once: the r map is the transpose of the N map's L (M = L'), so one element
+// (L, c, C packed symmetric) carries  r -> L' r + c  and  N -> L' N L + C  -- one suffix scan of
+// 4 + 2 + 3 floats (d = 2) instead of two scans of 6 and 8.  outer acts after inner.
+template <int D> struct RNElem {
+  Mat<D> Lm;
+  Vec<D> c;
+  float C[D * (D + 1) / 2];
+};
+template <int D> __device__ __forceinline__ RNElem<D> rnelem_identity() {
+  RNElem<D> e;
+  e.Lm = meye<D>();
+  e.c = vzero<D>();
+#pragma unroll
+  for (int i = 0; i < D * (D + 1) / 2; ++i) e.C[i] = 0.f;
+  return e;
+}
+template <int D>
+__device__ __forceinline__ RNElem<D> rnelem_compose(const RNElem<D>& o, const RNElem<D>& i) {
+  RNElem<D> r;
+  r.Lm = mm(i.Lm, o.Lm);
+  r.c = vadd(mtv(o.Lm, i.c), o.c);
+  // Lo' Ci Lo + Co, upper triangle
+  Mat<D> t;                                   // Ci Lo
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      float sv = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) sv = fmaf(i.C[symidx<D>(a, k)], o.Lm.m[k][b], sv);
+      t.m[a][b] = sv;
+    }
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = a; b < D; ++b) {
+      float sv = o.C[symidx<D>(a, b)];
+#pragma unroll
+      for (int k = 0; k < D; ++k) sv = fmaf(o.Lm.m[k][a], t.m[k][b], sv);
+      r.C[symidx<D>(a, b)] = sv;
+    }
+  return r;
+}
+
 // Log-likelihood and score of ONE parameter set th = (sigma_obs, sigma_level, sigma_slope, beta[P])
 // by the whole 256-thread workgroup: ll -> *out_ll, d ll / d th -> out_grad[3 + P].  Contains
 // __syncthreads(); slots: 3 * NW * 16 floats, part: NW * (P + 4) floats (LDS).  The results are
@@ -2128,43 +2172,33 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
     for (int i = 0; i < D; ++i) m.m[i][0] -= kf[l].v[i];
     return m;
   };
-  auto r_map = [&](int l) {
-    AElem<D> e;
-    Mat<D> ikzt = meye<D>();
-#pragma unroll
-    for (int j = 0; j < D; ++j) ikzt.m[0][j] -= kf[l].v[j];
-    e.M = mm(ikzt, Tt);
+  auto rn_map = [&](int l) {
+    RNElem<D> e;
+    e.Lm = mm(Tm, ikz(l));                   // T (I - K Z);  the r map is its transpose
     e.c = vzero<D>();
     e.c.v[0] = vf[l];
-    return e;
-  };
-  auto n_map = [&](int l) {
-    NElem<D> e;
-    e.Lm = mm(Tm, ikz(l));
-    e.C = mzero<D>();
-    if (((maskbits >> l) & 1u) == 0u) e.C.m[0][0] = 1.0f / fvar[l];
-    return e;
-  };
-  AElem<D> atot = r_map(L - 1);
-  NElem<D> ntot = n_map(L - 1);
 #pragma unroll
-  for (int l = L - 2; l >= 0; --l) {
-    atot = aelem_compose(r_map(l), atot);
-    ntot = nelem_compose(n_map(l), ntot);
-  }
-  const AElem<D> asuf = block_scan_excl_bwd(
-      atot, [](const AElem<D>& o, const AElem<D>& i) { return aelem_compose(o, i); },
-      aelem_identity<D>(), slots + NW * 16, lane, wave);
-  const NElem<D> nsuf = block_scan_excl_bwd(
-      ntot, [](const NElem<D>& o, const NElem<D>& i) { return nelem_compose(o, i); },
-      nelem_identity<D>(), slots + 2 * NW * 16, lane, wave);
+    for (int i = 0; i < D * (D + 1) / 2; ++i) e.C[i] = 0.f;
+    if (((maskbits >> l) & 1u) == 0u) e.C[0] = __builtin_amdgcn_rcpf(fvar[l]);
+    return e;
+  };
+  RNElem<D> rntot = rn_map(L - 1);
+#pragma unroll
+  for (int l = L - 2; l >= 0; --l) rntot = rnelem_compose(rn_map(l), rntot);
+  const RNElem<D> rnsuf = block_scan_excl_bwd(
+      rntot, [](const RNElem<D>& o, const RNElem<D>& i) { return rnelem_compose(o, i); },
+      rnelem_identity<D>(), slots + NW * 16, lane, wave);
 
   float gH = 0.f, gQ[D], e_l[L];
 #pragma unroll
   for (int i = 0; i < D; ++i) gQ[i] = 0.f;
   {
-    Vec<D> r = asuf.c;       // r_t, N_t entering this thread's last step
-    Mat<D> N = nsuf.C;
+    Vec<D> r = rnsuf.c;      // r_t, N_t entering this thread's last step
+    Mat<D> N;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) N.m[i][j] = rnsuf.C[symidx<D>(i, j)];
 #pragma unroll
     for (int l = L - 1; l >= 0; --l) {
       const int t = t0 + l;

@@ -2125,15 +2125,28 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const int t = t0 + l;
-    float r = 0.f;
-    if (t < T && !mask[t]) {
-      r = y[t];
-      for (int j = 0; j < P; ++j) r = fmaf(-Xt[j * xs + t], (float)th[3 + j], r);
-    } else {
-      maskbits |= 1u << l;
-    }
-    resid[l] = r;
+    const bool obs = t < T && !mask[t];
+    resid[l] = obs ? y[t] : 0.f;
+    if (!obs) maskbits |= 1u << l;
   }
+  // the caller's zero-padded copy of the design (xstride != 0: rows of a multiple of 4 floats in
+  // LDS) is read as whole rows of the L owned steps; the matrix in HBM step by step
+  const bool rows = xstride != 0 && (xstride & 3) == 0;
+  for (int j = 0; j < P; ++j) {
+    const float bj = (float)th[3 + j];
+    float xr[L];
+    if (rows) {
+      lds_row_load<L>(Xt + j * xs + t0, xr);
+    } else {
+#pragma unroll
+      for (int l = 0; l < L; ++l) xr[l] = t0 + l < T ? Xt[j * xs + t0 + l] : 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) resid[l] = fmaf(-xr[l], bj, resid[l]);
+  }
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+    if ((maskbits >> l) & 1u) resid[l] = 0.f;
   DkModel<D> md;
   const float so = (float)th[0];
   md.H = so * so;
@@ -2238,17 +2251,30 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
     const float w = wave_prefix_dpp(v);
     if (lane == 63) part[wave * NS + slot] = w;
   };
-  put(0, ll);
-  put(1, gH);
-  put(2, gQ[0]);
-  put(3, D == 2 ? gQ[D - 1] : 0.f);
-  for (int j = 0; j < P; ++j) {
-    float s = 0.f;
+  auto xe_dot = [&](int j) {
+    float xr[L];
+    if (rows) {
+      lds_row_load<L>(Xt + j * xs + t0, xr);
+    } else {
+#pragma unroll
+      for (int l = 0; l < L; ++l) xr[l] = t0 + l < T ? Xt[j * xs + t0 + l] : 0.f;
+    }
+    float sv = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l)
-      if (t0 + l < T) s = fmaf(Xt[j * xs + t0 + l], e_l[l], s);
-    put(4 + j, s);
+      if (t0 + l < T) sv = fmaf(xr[l], e_l[l], sv);
+    return sv;
+  };
+  {
+    // the first 16 sums in one reduce-scatter (lane l < 16 ends up with the wave total of slot l)
+    float v16[16];
+    v16[0] = ll; v16[1] = gH; v16[2] = gQ[0]; v16[3] = D == 2 ? gQ[D - 1] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v16[4 + j] = j < P ? xe_dot(j) : 0.f;
+    const float tot = wave_reduce_scatter16(v16, lane);
+    if (lane < 16 && lane < NS) part[wave * NS + lane] = tot;
   }
+  for (int j = 12; j < P; ++j) put(4 + j, xe_dot(j));
   __syncthreads();
   if (tid < NS) {
     double s = 0.0;

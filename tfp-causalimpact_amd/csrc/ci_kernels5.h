@@ -265,48 +265,32 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
 }
 
 // Serial section of iteration `it` on the regression wave (serial_section<1> of ci_kernels.h with
-// the replayed draw).  Returns through cx / scal / R.w as there.
-template <class PF>
+// the replayed draw).  It starts right after (B1) -- X~'targets and y'y are complete then, and the
+// regression draw needs nothing else -- and passes the workgroup's (B2) itself (`b2`) right after
+// gathering them, about when the time waves arrive there.  The level / slope scale draws need
+// the increments the time waves sum between (B1) and (B2), and nobody needs those scales before
+// (B3): they come last.  Returns through cx / scal / R.w.
+template <class PF, class SyncFn>
 static __device__ __forceinline__ void serial_section5(SerialCtx* cx, const RegLds& R,
                                                        const float* red, float* scal, int it,
                                                        int lane, PriorCarry& pc, const double* gam,
                                                        const double* pre, const PreTables& tb,
-                                                       const PreState& ps, PF& prof) {
+                                                       const PreState& ps, PF& prof, SyncFn b2) {
   const int P = cx->P;
-  {
-    const int RS = 16 + 4;
-    for (int j = lane; j < P + 3; j += 64) {
-      const int src = j < P ? j : RS - 4 + (j - P);
-      double s = 0.0;
+  constexpr int RS = 16 + 4;
+  for (int j = lane; j < P + 1; j += 64) {
+    const int src = j < P ? j : RS - 4;
+    double s = 0.0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) s += (double)red[w * RS + src];
-      R.bvec[j] = s;
-    }
+    for (int w = 0; w < NW; ++w) s += (double)red[w * RS + src];
+    R.bvec[j] = s;
   }
+  const float wprev = lane < P ? R.w[lane] : 0.f;      // the previous draw's weights (stored below)
   wave_sync();
+  b2();                                                 // (B2)
   double obs_scale = cx->obs_scale, level_scale = cx->level_scale, slope_scale = cx->slope_scale;
-  double emit_obs = obs_scale;
+  const double emit_obs = obs_scale;
   const double g_level = gam[0], g_slope = gam[1], g_obs = gam[2];
-  auto clipped_scale = [](double scale, double ss, double g, double ub) {
-    const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
-    return s < ub ? s : ub;
-  };
-  if (it > 0) {
-    level_scale = clipped_scale(cx->sp.level_scale, R.bvec[P + 1], g_level, cx->sp.level_ub);
-    if (cx->D == 2)
-      slope_scale = clipped_scale(cx->sp.slope_scale, R.bvec[P + 2], g_slope, cx->sp.slope_ub);
-    emit_obs = obs_scale;
-    const int s = it - 1 - cx->W;
-    if (s >= 0) {
-      const size_t o = cx->chain_lin * cx->S + s;
-      if (lane == 0) {
-        if (cx->out_obs) cx->out_obs[o] = (float)obs_scale;
-        if (cx->out_level_scale) cx->out_level_scale[o] = (float)level_scale;
-        if (cx->out_slope_scale) cx->out_slope_scale[o] = (float)(cx->D == 2 ? slope_scale : 0.0);
-      }
-      if (cx->out_weights && lane < P) cx->out_weights[o * P + lane] = R.w[lane];
-    }
-  }
   prof.tick(20);
   if (it < cx->n_iter) {
     NoProf np;
@@ -316,6 +300,30 @@ static __device__ __forceinline__ void serial_section5(SerialCtx* cx, const RegL
     else
       obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, np,
                                        pc, pre);
+  }
+  auto clipped_scale = [](double scale, double ss, double g, double ub) {
+    const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
+    return s < ub ? s : ub;
+  };
+  if (it > 0) {
+    double ssl = 0.0, sss = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      ssl += (double)red[w * RS + RS - 3];
+      sss += (double)red[w * RS + RS - 2];
+    }
+    level_scale = clipped_scale(cx->sp.level_scale, ssl, g_level, cx->sp.level_ub);
+    if (cx->D == 2) slope_scale = clipped_scale(cx->sp.slope_scale, sss, g_slope, cx->sp.slope_ub);
+    const int s = it - 1 - cx->W;
+    if (s >= 0) {
+      const size_t o = cx->chain_lin * cx->S + s;
+      if (lane == 0) {
+        if (cx->out_obs) cx->out_obs[o] = (float)emit_obs;
+        if (cx->out_level_scale) cx->out_level_scale[o] = (float)level_scale;
+        if (cx->out_slope_scale) cx->out_slope_scale[o] = (float)(cx->D == 2 ? slope_scale : 0.0);
+      }
+      if (cx->out_weights && lane < P) cx->out_weights[o * P + lane] = wprev;
+    }
   }
   if (lane == 0) {
     cx->obs_scale = obs_scale;
@@ -460,14 +468,13 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
     PF rprof;     // slots 16.. : the regression wave's own budget (lane 0 of block 0)
     rprof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && lane == 0);
     for (int it = 0; it <= n_iter; ++it) {
-      __syncthreads();      // (B1) boundary exchange of the time waves
-      __syncthreads();      // (B2) partial sums complete
+      __syncthreads();      // (B1) X~'targets, y'y partials complete (and the boundary exchange)
       rprof.tick(16);
       // the serial section is the critical path of the iteration and shares its SIMD with one of
       // the time waves, which has slack until (B3): win the issue arbitration while it lasts
       __builtin_amdgcn_s_setprio(3);
       serial_section5(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1), tb, ps,
-                      rprof);
+                      rprof, []() { __syncthreads(); });      // (B2) inside, after the gather
       rprof.tick(17);
       __builtin_amdgcn_s_setprio(0);
       __syncthreads();      // (B3) scalars and weights of iteration `it` published
@@ -532,6 +539,10 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
       }
       const float tot = wave_reduce_scatter16(pj, lane);
       if (lane < 16) red[wave * RS + lane] = tot;
+      {
+        const float s0 = wave_prefix_dpp(yty);           // y'y goes with X~'targets: before (B1)
+        if (lane == 63) red[wave * RS + RS - 4] = s0;
+      }
       xlast[tid * D] = lev[L - 1];
       if constexpr (D == 2) xlast[tid * D + 1] = slp[L - 1];
       __syncthreads();                                     // (B1)
@@ -554,9 +565,8 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
         pl = lev[l];
         if constexpr (D == 2) ps_ = slp[l];
       }
-      const float s0 = wave_prefix_dpp(yty), s1 = wave_prefix_dpp(ssl), s2 = wave_prefix_dpp(sss);
+      const float s1 = wave_prefix_dpp(ssl), s2 = wave_prefix_dpp(sss);
       if (lane == 63) {
-        red[wave * RS + RS - 4] = s0;
         red[wave * RS + RS - 3] = s1;
         red[wave * RS + RS - 2] = s2;
       }

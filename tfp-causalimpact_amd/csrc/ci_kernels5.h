@@ -623,6 +623,13 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
       }
     }
     if (it < n_iter) dk_normals<D, L>(rng, (uint32_t)it, tid, zl, zs, zo);
+    if (wave == 3 && lane < D && it < n_iter) {
+      // the normals of the simulated initial state (thread 0 needs them first thing in the draw:
+      // two Philox calls on its critical path otherwise), drawn here by a wave with slack
+      float zi[1];
+      fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)lane, zi);
+      scal[12 + lane] = zi[0];
+    }
     const bool publish = a.progress != nullptr && it > a.W &&
                          ((it - a.W) % a.progress_every == 0 || it - a.W == a.S);
     if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows are in L2
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
     Vec<D> x[L];
     prof.tick(3);
     dk_draw<D, L>(md, resid, maskbits, rng, (uint32_t)it, tid, lane, wave, slots, x, prof, zl, zs, zo,
-                  nullptr);                                // (B4) (B5) (B6)
+                  scal + 12);                              // (B4) (B5) (B6)
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       lev[l] = x[l].v[0];

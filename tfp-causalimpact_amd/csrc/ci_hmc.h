@@ -75,10 +75,21 @@ __host__ __device__ inline int hmc_dim(int P, int D, int prior_mode) {
   return (prior_mode == 1 ? 3 * P + 2 : P) + (D == 2 ? 3 : 2);
 }
 
+// float64 wave total on the DPP crossbar (row_shr 1, 2, 4, 8, then row_bcast:15 / :31): lane 63
+// holds the sum, broadcast through v_readlane.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_add_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+  return v + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v = dpp_add_d<0x111, 0xF>(v);
+  v = dpp_add_d<0x112, 0xF>(v);
+  v = dpp_add_d<0x114, 0xF>(v);
+  v = dpp_add_d<0x118, 0xF>(v);
+  v = dpp_add_d<0x142, 0xA>(v);
+  v = dpp_add_d<0x143, 0xC>(v);
+  return readlane_d(v, 63);
 }
 
 __device__ __forceinline__ double clamp30(double v) { return v < -30.0 ? -30.0 : (v > 30.0 ? 30.0 : v); }
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
         if (i >= off_sc) {
           const int k = i - off_sc;
           const double lam = clamp30(th[i]);
-          const double e2 = exp(-2.0 * lam);
+          const double e2 = 1.0 / (dev[k] * dev[k]);       // exp(-2 lam): dev[k] = exp(lam)
           ci = -2.0 * a.ig_a[k] * lam - a.ig_b[k] * e2;
           gi = dev[k] * gdev[k] - 2.0 * a.ig_a[k] + 2.0 * a.ig_b[k] * e2;
         } else if (!hs) {

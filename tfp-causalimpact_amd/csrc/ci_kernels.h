@@ -2132,6 +2132,7 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
   // the caller's zero-padded copy of the design (xstride != 0: rows of a multiple of 4 floats in
   // LDS) is read as whole rows of the L owned steps; the matrix in HBM step by step
   const bool rows = xstride != 0 && (xstride & 3) == 0;
+#pragma unroll 4
   for (int j = 0; j < P; ++j) {
     const float bj = (float)th[3 + j];
     float xr[L];

@@ -30,6 +30,17 @@ def test_library_exports_every_declared_symbol():
   assert lib.ci_abi_version() == _native.ABI_VERSION
 
 
+def test_flag_constants_match_the_header():
+  """Every CI_FLAG_* of the header has a FLAG_* twin of the same value in the binding."""
+  hdr = open(os.path.join(ROOT, "include", "causalimpact_amd.h")).read()
+  flags = dict(re.findall(r"#define\s+CI_(FLAG_[A-Z_]+)\s+(\d+)", hdr))
+  assert len(flags) >= 6
+  for name, value in flags.items():
+    assert getattr(_native, name) == int(value), name
+  values = sorted(int(v) for v in flags.values())
+  assert values == [1 << i for i in range(len(values))]          # distinct single bits
+
+
 def test_struct_layouts_match_header_sizes():
   # ci_series_params: 20 doubles + 8 doubles; ci_problem: 24 int32/uint32 fields
   assert ctypes.sizeof(_native.SeriesParams) == 8 * 28

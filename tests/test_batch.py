@@ -150,3 +150,59 @@ def test_batch_summary_bands_equal_the_host_quantiles_also_when_totals_straddle_
     one = ci.fit_causalimpact(f, pre, post, seed=11, inference_options=opts)
     np.testing.assert_allclose(got.summary.loc[b].to_numpy(float), one.summary.to_numpy(float),
                                rtol=2e-5, atol=1e-7)
+
+
+def test_summary_bands_from_order_statistics_equal_numpy_quantiles():
+  """Host arithmetic of the batch summary (no GPU): bands interpolated from order statistics of
+  the per-draw totals -- mapped through the monotone transforms to means and relative effects --
+  equal numpy's quantiles of the transformed draws, for totals of either sign and for series whose
+  totals straddle zero (those take the sort).  Without device order statistics the same code
+  sorts on the host."""
+  from causalimpact import causalimpact_lib as lib
+  T, B, N, alpha = 60, 5, 401, 0.08
+  frames = _frames(B, T, 1, seed=4)
+  idx = frames[0].index
+  pre, post = (idx[0], idx[39]), (idx[42], idx[57])
+  values = np.stack([f.to_numpy(float) for f in frames])
+  prep = batch.prepare_batch(values, idx, pre, post, True)
+  rng = np.random.default_rng(0)
+  Tm = prep.y.shape[1]
+  means = rng.normal(size=(B, Tm)).astype(np.float32)
+  per_draw = rng.normal(size=(B, 2, N)) * 20.0
+  per_draw[0, 0] += 3000.0                      # positive totals
+  per_draw[1, 0] -= 3000.0                      # negative totals
+  per_draw[2, 0] += 5.0                         # straddling zero
+  per_draw[3, 0] = np.abs(per_draw[3, 0]) + 1.0
+  per_draw[4, 0] += 800.0
+  quantiles = (alpha / 2.0, 1.0 - alpha / 2.0)
+  ranks = lib._summary_ranks(N, quantiles)                          # pylint: disable=protected-access
+  order = np.sort(per_draw, axis=2)[:, :, ranks]
+  names = [f"s{b}" for b in range(B)]
+  cols = list(frames[0].columns)
+  with_order = batch.CausalImpactBatchAnalysis(prep, names, alpha, means,
+                                               dict(per_draw=per_draw, per_draw_order=order),
+                                               ranks, cols, None).summary
+  host_sort = batch.CausalImpactBatchAnalysis(prep, names, alpha, means, dict(per_draw=per_draw),
+                                              ranks, cols, None).summary
+  pd.testing.assert_frame_equal(with_order, host_sort)
+  # reference: numpy quantiles of the transformed draws
+  idxm = prep.index[prep.model_rows]
+  in_post = np.asarray((idxm >= post[0]) & (idxm <= post[1]))
+  obs = prep.values[:, prep.model_rows, 0].copy()
+  obs[:, prep.num_pre:][:, ~in_post[prep.num_pre:]] = np.nan
+  win = in_post & ~np.asarray(idxm < post[0])
+  obs_sum = np.nansum(obs[:, win], axis=1)
+  n_win, n_obs = int(win.sum()), np.sum(~np.isnan(obs[:, win]), axis=1)
+  pred_sum, point_sum = per_draw[:, 0], per_draw[:, 1]
+  rel = obs_sum[:, None] / pred_sum - 1.0
+  for b in range(B):
+    row_avg, row_cum = with_order.loc[(names[b], "average")], with_order.loc[(names[b], "cumulative")]
+    lo, hi = np.quantile(pred_sum[b], quantiles)
+    assert (row_cum["predicted_lower"], row_cum["predicted_upper"]) == (lo, hi)
+    lo, hi = np.quantile(pred_sum[b] / n_win, quantiles)
+    assert (row_avg["predicted_lower"], row_avg["predicted_upper"]) == (lo, hi)
+    lo, hi = np.quantile(point_sum[b] / n_obs[b], quantiles)
+    assert (row_avg["abs_effect_lower"], row_avg["abs_effect_upper"]) == (lo, hi)
+    lo, hi = np.quantile(rel[b], quantiles)
+    np.testing.assert_allclose([row_avg["rel_effect_lower"], row_avg["rel_effect_upper"]], [lo, hi],
+                               rtol=1e-13)

@@ -142,3 +142,36 @@ def test_select_is_exact_for_every_row_length_and_awkward_rows(N):
   np.testing.assert_array_equal(got["value_order"], want_value)
   np.testing.assert_array_equal(got["cum_order"], want_cum)
   np.testing.assert_array_equal(got["per_draw_order"], np.sort(got["per_draw"], axis=1)[:, ranks])
+
+
+def test_select_survives_infinities_and_random_shapes():
+  """Rows with +-inf (non-finite rows leave the linear-bucket path for the radix select on the
+  ordered keys), many random (N, T, ranks) shapes and value distributions: always numpy's sort."""
+  rng = np.random.default_rng(123)
+  for trial in range(24):
+    N = int(rng.choice([1, 3, 64, 257, 1000, 4097, 8192, 9000, 16384, 17000]))
+    T = int(rng.integers(1, 9))
+    kind = trial % 6
+    if kind == 0:
+      traj = rng.normal(size=(N, T))
+    elif kind == 1:
+      traj = rng.standard_cauchy(size=(N, T))                      # heavy tails: outliers stretch the range
+    elif kind == 2:
+      traj = rng.integers(-3, 4, size=(N, T)).astype(float)        # ties
+    elif kind == 3:
+      traj = rng.normal(size=(N, T))
+      traj[rng.integers(0, N, size=max(1, N // 50)), :] = np.inf   # +inf entries
+      traj[rng.integers(0, N, size=max(1, N // 70)), 0] = -np.inf
+    elif kind == 4:
+      traj = np.exp(rng.normal(size=(N, T)) * 5) * rng.choice([-1.0, 1.0], size=(N, T))
+    else:
+      traj = np.full((N, T), 2.5) + (rng.random((N, T)) < 0.01)    # almost constant
+    traj = traj.astype(np.float32)
+    R = int(rng.integers(1, 9))
+    ranks = sorted(int(r) for r in rng.integers(0, N, size=R))
+    obs = np.zeros(T)
+    flags = np.zeros(T, np.uint8)                                   # no effects: cum rows are zeros
+    got = _native.summarize_draws(traj, 1.0, 0.0, obs, flags, ranks)
+    want = np.sort(traj.astype(np.float64), axis=0)[ranks]
+    np.testing.assert_array_equal(got["value_order"], want, err_msg=f"trial {trial} N={N} kind={kind}")
+    np.testing.assert_array_equal(got["cum_order"], np.zeros_like(want))

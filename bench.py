@@ -8,11 +8,14 @@ the same series, windowed-adaptive HMC (15 leapfrog steps, 500 warm-up iteration
 draws), 8 chains per GPU = 64 chains on 8 GPUs, plus the latent-path / predictive draw of every
 retained sample.  One "step" = one complete fit (all iterations of all chains of this rank).
 Chains are independent, so ranks shard them with no data-path collective (weak scaling: 8 chains
-per GPU); RCCL is used only after the timed region, to gather per-chain moments for the
-split-R-hat diagnostic.
+per GPU); RCCL -- bound through the C-ABI (ci_comm_*), no PyTorch in this process -- is used only
+for the barrier / max-over-ranks timing and, after the timed region, to gather per-chain blocks
+from HBM and all-reduce the diagnostics' partial sums.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--sampler gibbs|hmc]
+      N > 1 without a launcher: bench.py starts its own N ranks (one process per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+      (RANK / LOCAL_RANK / WORLD_SIZE from the environment; torch itself is never imported)
 """
 import argparse
 import json
@@ -111,14 +114,16 @@ def _cpu_baseline(sampler, y, mask, X, min_seconds=10.0):
 
 def _pmc_traffic(sampler):
   """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc.json, written
-  by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
-  names = ("r02_cfg3_pmc.json",) if sampler == "hmc" else ("r02_pmc.json", "r01_pmc.json")
+  by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command; a
+  counter pass cannot run inside the timed process) and the file it came from."""
+  names = (("r03_cfg3_pmc.json", "r02_cfg3_pmc.json") if sampler == "hmc" else
+           ("r03_pmc.json", "r02_pmc.json"))
   for name in names:
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
       with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_launch")
-  return None
+        return json.load(f).get("hbm_bytes_per_launch"), "profiles/" + name
+  return None, None
 
 
 class _GibbsFit:
@@ -146,7 +151,10 @@ class _GibbsFit:
     if not hasattr(self, "_into"):
       self.sess.run_streamed()                      # allocates the pinned result buffers once
       self._into = self.sess._last_streamed         # pylint: disable=protected-access
-    self.sess.run_streamed(into=self._into)
+    ms, _ = self.sess.run_streamed(into=self._into)
+    return {"kernel": ms}
+
+  def last_small(self):
     res = self._into[1]
     return {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
 
@@ -178,8 +186,12 @@ class _HmcFit:
     return {k: res[k][0] for k in ("observation_noise_scale", "level_scale", "posterior_means")}
 
   def run_and_fetch(self):
-    self.run()
-    return self.fetch()
+    ms = self.run()
+    self._last = self.fetch()
+    return ms
+
+  def last_small(self):
+    return self._last
 
   def note(self, C):
     return ("one persistent workgroup per chain (%d of 256 CUs) runs (W+S) x leapfrog dependent "
@@ -201,67 +213,81 @@ def main():
   if args.warmup is None:
     args.warmup = 3 if args.sampler == "gibbs" else 1
 
+  # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one
+  # process per GPU); rank 0 prints the JSON line.  Under torch.distributed.run (or any launcher
+  # that exports RANK / LOCAL_RANK / WORLD_SIZE) this process IS a rank.
+  from causalimpact import _comm  # pylint: disable=import-outside-toplevel
+  launched = "WORLD_SIZE" in os.environ
+  if not launched:
+    rc = _comm.self_launch(args.gpus)
+    if rc is not None:
+      raise SystemExit(rc)
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-  dist = None
-  # CI_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU smoke test)
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+  # RCCL through the C-ABI (ci_comm_*): no PyTorch in this process.  CI_BENCH_FORCE_DIST=1
+  # exercises the same path with a single rank (1-GPU box).
+  comm = None
   if world > 1 or os.environ.get("CI_BENCH_FORCE_DIST") == "1":
-    import torch  # pylint: disable=import-outside-toplevel
-    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    comm = _comm.Comm.from_env()
 
   C = args.chains_per_gpu
   y, mask, X, _ = syn.make_sampler_inputs(CFG["T"], CFG["covariates"], CFG["data_seed"])
   fit = (_HmcFit if args.sampler == "hmc" else _GibbsFit)(y, mask, X, C, rank, local_rank)
 
   def sync():
-    if dist is not None:
-      import torch  # pylint: disable=import-outside-toplevel
-      dist.barrier()
-      torch.cuda.synchronize()
+    if comm is not None:
+      comm.barrier()
+    _native.device_synchronize(local_rank)
 
+  # One step = one complete fit with every result array DELIVERED to (pinned) host memory: the
+  # metric of SURVEY.md section 8(d) includes the device-to-host copy of the results; inputs are
+  # resident in HBM.  The copies run in the shadow of the persistent kernel (run_streamed).
   for _ in range(args.warmup):
-    fit.run()
+    fit.run_and_fetch()
   sync()
   t0 = time.perf_counter()
   kernel_ms = []
   for _ in range(args.steps):
-    kernel_ms.append(fit.run())      # run() waits for the fit's stream
+    kernel_ms.append(fit.run_and_fetch())
   sync()
   dt = time.perf_counter() - t0
-  if dist is not None:
-    import torch  # pylint: disable=import-outside-toplevel
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+  if comm is not None:
+    dt = float(comm.all_reduce([dt], _comm.MAX)[0])
 
-  # ---- after the timed region: PCIe-inclusive rate, chain gather + diagnostics (RCCL)
-  fit.run_and_fetch()                 # (first call sets up the pinned result buffers)
+  # ---- after the timed region: kernel-only rate, chain gather + diagnostics
   t1 = time.perf_counter()
-  n_pcie = 3
-  for _ in range(n_pcie):
-    local = fit.run_and_fetch()
-  dt_pcie = (time.perf_counter() - t1) / n_pcie
-  # chain gather + split-R-hat across ranks (RCCL all-gather / all-reduce; no-op at N=1)
+  n_k = 3
+  for _ in range(n_k):
+    fit.run()
+  dt_kernel = (time.perf_counter() - t1) / n_k
+  local = fit.last_small()
+  # chain gather + split-R-hat / ESS across ranks: all-gather of the blocks still resident in HBM
+  # (ncclAllGather on the sessions' device buffers) + ONE all-reduce of the partial sums
   from causalimpact import _distributed  # pylint: disable=import-outside-toplevel
+
+  def resident(key):
+    if comm is None:
+      return None
+    g = comm.session_all_gather(fit.sess, key)             # [world, 1, C, ...]
+    return g.reshape((world * C,) + g.shape[3:])
+
   comb = _distributed.fit_sharded(lambda first, count: local, world * C,
-                                  gather_keys=("posterior_means",),
-                                  device="cuda" if dist is not None else None)
+                                  gather_keys=("posterior_means",), comm=comm, resident=resident)
   rhat = comb["split_rhat"]
   ess = {"bulk": comb["ess_bulk"], "tail": comb["ess_tail"]}
+  assert comb["posterior_means"].shape == (world * C, CFG["T"])
 
   samples_per_step = world * C * CFG["num_results"]
   value = samples_per_step * args.steps / dt
   k_ms = float(np.mean([sum(k.values()) for k in kernel_ms]))
   alg_bytes = fit.sess.algorithmic_bytes()
   achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+  traffic, traffic_src = _pmc_traffic(args.sampler)
   roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-          "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(args.sampler),
+          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
           "kernel": fit.sess.kernel_name(),
           "kernel_ms": float(np.mean([k["kernel"] for k in kernel_ms])),
           "algorithmic_bytes_per_launch": alg_bytes, "note": fit.note(C)}
@@ -278,21 +304,31 @@ def main():
       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
       "config": {"workload": fit.workload, "sampler": args.sampler,
                  "chains_per_gpu": C, "chains_total": world * C,
-                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
+                 "timed_region": "fit + delivery of every result array to pinned host memory",
+                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
+                 "launcher": ("external (RANK/WORLD_SIZE in the environment)" if launched else
+                              ("bench.py spawned its own ranks" if world > 1 else "single process")),
+                 "collectives": (f"{comm.transport} via ci_comm_* (C-ABI), ranks_seen="
+                                 f"{comm.ranks_seen}" if comm is not None else "none")},
       "roofline": roof,
-      "pcie_inclusive_value": C * CFG["num_results"] / dt_pcie,
+      "kernel_only_value": C * CFG["num_results"] / dt_kernel,
       "split_rhat": rhat, "ess": ess,
   }
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out["cpu_baseline"] = _cpu_baseline(args.sampler, y, mask, X)
   elif rank == 0:
     out["cpu_baseline"] = None
+  if comm is not None:
+    comm.barrier()
   fit.sess.close()
+  if comm is not None:
+    comm.close()
+  # librccl prints a version banner through C stdio (buffered when stdout is a pipe): flush it now
+  # so that the JSON line is the LAST line of this job's output
+  import ctypes  # pylint: disable=import-outside-toplevel
+  ctypes.CDLL(None).fflush(None)
   if rank == 0:
-    print(json.dumps(out))
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

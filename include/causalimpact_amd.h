@@ -121,6 +121,8 @@ typedef struct ci_session ci_session;  /* device-resident fit: inputs + outputs 
 const char* ci_last_error(void);
 int ci_abi_version(void);
 int ci_device_count(int* count);
+/* Waits for all work queued on `device` (bench.py brackets its timed region with it). */
+int ci_device_synchronize(int device);
 /* Device buffers of finished sessions are parked in a per-process pool (<= 2 GiB) for reuse by
  * the next fit; this returns them to the driver. */
 int ci_pool_trim(void);
@@ -266,6 +268,50 @@ int ci_ll_session_kernel_name(const ci_ll_session* session, char* buf, int32_t b
 /* Algorithmic bytes of the last configured HMC fit (DESIGN.md "Roofline", cfg3). */
 int ci_ll_session_algorithmic_bytes(const ci_ll_session* session, double* bytes);
 int ci_ll_session_destroy(ci_ll_session* session);
+
+/* ---- chain gather / diagnostics across the GPUs of one node ----
+ * The reference runs one chain in one process and has no communication;
+ * BASELINE.json shards independent chains over the GPUs of a node, "RCCL over xGMI only for chain
+ * gather/diagnostics".  The fit itself never communicates.  One ci_comm per rank (one rank per
+ * GPU); transports:
+ *   CI_COMM_RCCL  librccl, loaded on first use: ncclAllGather / ncclAllReduce on device buffers.
+ *   CI_COMM_HOST  a POSIX shared-memory segment on one node, for ranks that share a device (RCCL
+ *                 refuses two ranks on one GPU) and GPU-less tests; same results, staged via host.
+ * ci_comm_unique_id is called by ONE rank; the 128 bytes reach the others out of band (the host
+ * package passes them through a file, causalimpact/_comm.py).  ci_comm_create is collective.
+ * ranks_seen = ncclCommCount of the live communicator (host transport: attached ranks). */
+#define CI_COMM_ID_BYTES 128
+#define CI_COMM_RCCL 0
+#define CI_COMM_HOST 1
+#define CI_COMM_SUM 0
+#define CI_COMM_MAX 1
+typedef struct ci_comm ci_comm;
+int ci_comm_unique_id(int32_t transport, uint8_t* id /* [CI_COMM_ID_BYTES] */);
+int ci_comm_create(int32_t transport, const uint8_t* id, int32_t rank, int32_t world,
+                   int32_t device, ci_comm** comm);
+int ci_comm_info(const ci_comm* comm, int32_t* rank, int32_t* world, int32_t* ranks_seen);
+int ci_comm_barrier(ci_comm* comm);
+/* values [n] float64 on the host, reduced in place over all ranks (every rank gets the same bits). */
+int ci_comm_all_reduce(ci_comm* comm, double* values, int64_t n, int32_t op);
+/* send [bytes] -> recv [world, bytes], host buffers, rank order. */
+int ci_comm_all_gather(ci_comm* comm, const void* send, void* recv, int64_t bytes);
+/* One result array of a finished fit, gathered STRAIGHT FROM HBM (no host round trip on the RCCL
+ * transport): every rank's device-resident [B, C, ...] block -> recv [world, B, C, ...] on the
+ * host of every rank.  All ranks must hold sessions of the same shape.  field = CI_FIELD_*, the
+ * members of ci_outputs in order. */
+#define CI_FIELD_OBSERVATION_NOISE_SCALE 0
+#define CI_FIELD_LEVEL_SCALE 1
+#define CI_FIELD_SLOPE_SCALE 2
+#define CI_FIELD_SEASONAL_DRIFT_SCALES 3
+#define CI_FIELD_WEIGHTS 4
+#define CI_FIELD_LEVEL 5
+#define CI_FIELD_SLOPE 6
+#define CI_FIELD_SEASONAL_LEVELS 7
+#define CI_FIELD_POSTERIOR_MEANS 8
+#define CI_FIELD_POSTERIOR_TRAJECTORIES 9
+int ci_comm_session_all_gather(ci_comm* comm, ci_session* session, int32_t field, float* recv);
+int ci_comm_ll_session_all_gather(ci_comm* comm, ci_ll_session* session, int32_t field, float* recv);
+int ci_comm_destroy(ci_comm* comm);
 
 /* ---- component entry points used by the parity tests (tests/test_gpu_*.py) ---- */
 /* normals/uniforms/gammas of the specified Philox stream, computed on device. */

@@ -1,0 +1,156 @@
+"""Multi-rank runs through the C-ABI collectives (`ci_comm_*`) on hardware -- no PyTorch.
+
+A one-GPU box cannot host two RCCL ranks (RCCL refuses two ranks on one device: "Duplicate GPU
+detected"), so:
+  * RCCL is exercised with one rank (communicator creation from the file rendezvous, barrier,
+    all-reduce, all-gather of the session's DEVICE-RESIDENT arrays == ci_session_fetch);
+  * two ranks SHARING GPU 0 run real fits of their chain blocks and pool them over the host
+    transport (same entry points, staged through shared memory): bit-equal to ONE launch of all
+    chains; they are started by `_comm.spawn_ranks`, the launcher behind `bench.py --gpus N`;
+  * asking RCCL for two ranks on one device must fail with a clean error, not hang.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "tfp-causalimpact_amd")
+pytestmark = pytest.mark.gpu
+
+_RANK = r"""
+import json, os, sys
+sys.path[:0] = [%(root)r, %(pkg)r]
+import numpy as np
+from causalimpact import _comm, _distributed as d, _model, _native
+from causalimpact import _synthetic as syn
+comm = _comm.Comm.from_env()
+num_chains = %(num_chains)d
+y, mask, X, _ = syn.make_sampler_inputs(300, 3, 5)
+spec = _model.series_params(y, mask, X, has_slope=True)
+holder = {}
+
+def local_fit(first, count):
+  pb = _native.make_problem(T=300, P=4, has_slope=1, num_warmup=20, num_results=60,
+                            num_chains=count, chain_offset=first, seed=(4, 4), device=comm.device)
+  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  sess.run()
+  holder["sess"] = sess
+  return {k: v[0] for k, v in sess.fetch().items()}
+
+def resident(key):
+  g = comm.session_all_gather(holder["sess"], key)       # [world, 1, C, ...] from HBM
+  return g.reshape((-1,) + g.shape[3:])
+
+res = d.fit_sharded(local_fit, num_chains, comm=comm, resident=resident if %(even)d else None)
+np.savez(os.path.join(%(out)r, "rank%%d.npz" %% comm.rank), traj=res["posterior_trajectories"],
+         means=res["posterior_means"], rhat=res["split_rhat"]["level_scale"],
+         ess=res["ess_bulk"]["observation_noise_scale"], seen=comm.ranks_seen)
+comm.barrier()
+comm.close()
+assert "torch" not in sys.modules
+"""
+
+
+def _one_launch(num_chains):
+  sys.path[:0] = [PKG]
+  from causalimpact import _distributed as d, _model, _native
+  from causalimpact import _synthetic as syn
+  y, mask, X, _ = syn.make_sampler_inputs(300, 3, 5)
+  spec = _model.series_params(y, mask, X, has_slope=True)
+  pb = _native.make_problem(T=300, P=4, has_slope=1, num_warmup=20, num_results=60,
+                            num_chains=num_chains, seed=(4, 4), device=0)
+  one = {k: v[0] for k, v in _native.fit_gibbs(pb, y[None], mask[None], X[None], None,
+                                               _native.make_params([spec])).items()}
+  return one, d.fit_sharded(lambda first, count: one, num_chains)
+
+
+@pytest.mark.parametrize("num_chains", [4, 5])
+def test_two_ranks_sharing_gpu0_equal_one_launch(tmp_path, num_chains):
+  """Even blocks gather straight from the sessions' device buffers (`ci_comm_session_all_gather`),
+  uneven ones pad and gather the host copies; both must reproduce the single launch bit for bit."""
+  from causalimpact import _comm
+  one, single = _one_launch(num_chains)
+  script = tmp_path / "rank.py"
+  script.write_text(_RANK % dict(root=ROOT, pkg=PKG, num_chains=num_chains, out=str(tmp_path),
+                                 even=int(num_chains % 2 == 0)))
+  codes = _comm.spawn_ranks(2, [sys.executable, str(script)], transport="host", devices=[0, 0],
+                            timeout=300)
+  assert codes == [0, 0]
+  for r in range(2):
+    got = np.load(tmp_path / f"rank{r}.npz")
+    assert int(got["seen"]) == 2
+    np.testing.assert_array_equal(got["traj"], one["posterior_trajectories"])
+    np.testing.assert_array_equal(got["means"], one["posterior_means"])
+    np.testing.assert_allclose(got["rhat"], single["split_rhat"]["level_scale"], rtol=1e-9)
+    np.testing.assert_allclose(got["ess"], single["ess_bulk"]["observation_noise_scale"], rtol=1e-9)
+
+
+def test_rccl_single_rank_gathers_device_resident_arrays(tmp_path):
+  sys.path[:0] = [PKG]
+  from causalimpact import _comm, _model, _native
+  from causalimpact import _synthetic as syn
+  y, mask, X, _ = syn.make_sampler_inputs(200, 2, 1)
+  spec = _model.series_params(y, mask, X, has_slope=False)
+  pb = _native.make_problem(T=200, P=3, has_slope=0, num_warmup=5, num_results=30, num_chains=3,
+                            seed=(1, 2), device=0)
+  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  sess.run()
+  want = sess.fetch()
+  comm = _comm.Comm(0, 1, device=0, transport="rccl", path=str(tmp_path / "rdzv"))
+  assert comm.ranks_seen == 1 and comm.world == 1
+  comm.barrier()
+  np.testing.assert_array_equal(comm.all_reduce([1.5, -2.0]), [1.5, -2.0])
+  np.testing.assert_array_equal(comm.all_reduce([1.5, -2.0], _comm.MAX), [1.5, -2.0])
+  a = np.arange(12, dtype=np.float64).reshape(3, 4)
+  np.testing.assert_array_equal(comm.all_gather(a), a[None])
+  for key in ("posterior_trajectories", "level", "weights", "posterior_means",
+              "observation_noise_scale"):
+    np.testing.assert_array_equal(comm.session_all_gather(sess, key), want[key][None], err_msg=key)
+  comm.close()
+  sess.close()
+  assert "torch" not in sys.modules
+
+
+_DUP = r"""
+import sys
+sys.path[:0] = [%(root)r, %(pkg)r]
+from causalimpact import _comm, _native
+try:
+  _comm.Comm.from_env()
+except _native.NativeError as e:
+  print("NativeError:", e)
+  raise SystemExit(3)
+raise SystemExit(0)
+"""
+
+
+def test_rccl_refuses_two_ranks_on_one_device_with_an_error(tmp_path):
+  from causalimpact import _comm
+  script = tmp_path / "dup.py"
+  script.write_text(_DUP % dict(root=ROOT, pkg=PKG))
+  env = dict(os.environ, NCCL_DEBUG="WARN")
+  codes = _comm.spawn_ranks(2, [sys.executable, str(script)], env=env, transport="rccl",
+                            devices=[0, 0], timeout=240)
+  assert all(c != 0 for c in codes), codes           # an error on every rank, no hang
+
+
+def test_bench_single_rank_through_the_rccl_path_matches_plain_bench():
+  """bench.py with CI_BENCH_FORCE_DIST=1: the N > 1 code path (C-ABI communicator, barrier,
+  max-reduce of the time, gather from HBM, diagnostics all-reduce) with one rank."""
+  env = dict(os.environ, CI_BENCH_FORCE_DIST="1")
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+         "--no-cpu-baseline"]
+  # the JSON line must be the LAST line of the output (librccl's banner is flushed before it)
+  forced = json.loads(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600,
+                                     check=True).stdout.strip().splitlines()[-1])
+  plain = json.loads(subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                                    check=True).stdout.strip().splitlines()[-1])
+  assert "ranks_seen=1" in forced["config"]["collectives"] and "rccl" in forced["config"]["collectives"]
+  assert plain["config"]["collectives"] == "none"
+  assert forced["n_gpus"] == plain["n_gpus"] == 1
+  assert forced["split_rhat"] == plain["split_rhat"] and forced["ess"] == plain["ess"]
+  assert abs(forced["value"] / plain["value"] - 1.0) < 0.1

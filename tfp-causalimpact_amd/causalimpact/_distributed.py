@@ -1,10 +1,11 @@
-"""Chain sharding over the GPUs of one node (one process per GPU, torch.distributed).
+"""Chain sharding over the GPUs of one node (one process per GPU).
 
 The reference runs one chain in one process; chains are
 independent given the data, so ranks take contiguous blocks of chain ids with NO collective
 on the data path.  Chain c always uses RNG stream c (`chain_offset`), hence the pooled
-result is identical for any world size.  RCCL (backend "nccl" on ROCm) / gloo is used only
-after sampling:
+result is identical for any world size.  Collectives run only after sampling -- through
+`_comm.Comm` (librccl or a shared-memory host transport behind the C-ABI; no PyTorch), or through
+an initialised torch.distributed group (gloo in the CPU tests):
   * an all-gather of the per-chain blocks needed for pooled summaries (`gather_keys`) and of
     the scalar parameters the diagnostics rank (`rhat_keys`: [chains, draws] floats);
   * ONE all-reduce(sum) of the diagnostics' partial sums -- per-split-chain means and
@@ -14,6 +15,7 @@ after sampling:
 """
 from __future__ import annotations
 
+import sys
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -29,68 +31,107 @@ def chain_block(num_chains: int, rank: int, world_size: int) -> Tuple[int, int]:
   return first, count
 
 
+class _TorchComm:
+  """`torch.distributed` (gloo in the CPU tests) behind the interface of `_comm.Comm`."""
+
+  def __init__(self, dist, torch, group, device):
+    self._dist, self._torch, self._group = dist, torch, group
+    self._dev = torch.device(device) if device else torch.device("cpu")
+    self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+  def all_gather(self, a: np.ndarray) -> np.ndarray:
+    mine = self._torch.from_numpy(np.ascontiguousarray(a)).to(self._dev)
+    parts = [self._torch.empty_like(mine) for _ in range(self.world)]
+    self._dist.all_gather(parts, mine, group=self._group)
+    return np.stack([p.cpu().numpy() for p in parts])
+
+  def all_reduce(self, values, op: int = 0) -> np.ndarray:
+    t = self._torch.from_numpy(np.array(values, dtype=np.float64, copy=True)).to(self._dev)
+    red = self._dist.ReduceOp.MAX if op == 1 else self._dist.ReduceOp.SUM
+    self._dist.all_reduce(t, op=red, group=self._group)
+    return t.cpu().numpy()
+
+
+def _resolve_comm(comm, group, device):
+  """The communicator to use: an explicit `_comm.Comm` (RCCL / host transport through the C-ABI,
+  no PyTorch), else an initialised torch.distributed process group, else None (one process)."""
+  if comm is not None:
+    return comm
+  if "torch" not in sys.modules and group is None:
+    return None         # nobody initialised a process group: do not import torch for nothing
+  try:
+    import torch
+    import torch.distributed as dist
+  except ImportError:
+    return None
+  if dist.is_available() and dist.is_initialized():
+    return _TorchComm(dist, torch, group, device)
+  return None
+
+
 def fit_sharded(local_fit: Callable[[int, int], Dict[str, np.ndarray]], num_chains: int,
                 gather_keys: Sequence[str] = ("posterior_trajectories", "posterior_means"),
                 rhat_keys: Sequence[str] = ("observation_noise_scale", "level_scale"),
-                group=None, device: Optional[str] = None) -> Dict[str, object]:
+                group=None, device: Optional[str] = None, comm=None,
+                resident: Optional[Callable[[str], Optional[np.ndarray]]] = None
+                ) -> Dict[str, object]:
   """Runs `local_fit(first_chain, count)` on every rank and combines the results.
 
   local_fit returns arrays with a leading chain axis [count, ...] (e.g. the [0] slice of
   `_native.fit_gibbs` outputs for one series).  It is NOT called on a rank whose block is empty
   (more ranks than chains): that rank contributes zero-length blocks to the collectives.
+  `comm`: a `_comm.Comm` (RCCL over xGMI or the host transport, through the C-ABI -- the product
+  path, no PyTorch); without one an initialised `torch.distributed` group is used (gloo in the CPU
+  tests), and without either the call is a single process.
+  `resident(key)` (optional, equal blocks only): returns the gathered [world, count, ...] array
+  of `key` straight from the ranks' device-resident sessions (`Comm.session_all_gather`), or
+  None to fall back to gathering the host copy in `local_fit`'s result.
   Returns on every rank:
     {key: [num_chains, ...] for key in gather_keys,
      "split_rhat" / "ess_bulk" / "ess_tail": {key: float for key in rhat_keys}}.
-  Works without an initialised process group (world size 1).
   """
-  try:
-    import torch
-    import torch.distributed as dist
-    live = dist.is_available() and dist.is_initialized()
-  except ImportError:   # torch is plumbing only; a single process needs none of it
-    live = False
-  rank = dist.get_rank(group) if live else 0
-  world = dist.get_world_size(group) if live else 1
+  comm = _resolve_comm(comm, group, device)
+  rank = comm.rank if comm is not None else 0
+  world = comm.world if comm is not None else 1
   if num_chains < 1:
     raise ValueError(f"num_chains must be >= 1, got {num_chains}")
   first, count = chain_block(num_chains, rank, world)
   local = local_fit(first, count) if count > 0 else None
   out: Dict[str, object] = {}
 
-  if not live:
+  if comm is None:
     for k in gather_keys:
       out[k] = local[k]
     scal = {k: np.asarray(local[k], np.float64) for k in rhat_keys}
     sums = {k: _local_sums(scal[k], scal[k]) for k in rhat_keys}
   else:
-    dev = torch.device(device) if device else torch.device("cpu")
     counts = [chain_block(num_chains, r, world)[1] for r in range(world)]
     cmax = max(counts)
+    even = min(counts) == cmax
 
-    def gather(a: Optional[np.ndarray], tail_shape, dtype) -> np.ndarray:
-      """all-gather of [count, *tail] blocks (padded to the largest block); RCCL on GPUs."""
+    def gather(key: str, tail_shape, dtype) -> np.ndarray:
+      """all-gather of [count, *tail] blocks (padded to the largest block)."""
+      if even and resident is not None:
+        got = resident(key)
+        if got is not None:
+          return np.asarray(got, dtype).reshape((num_chains,) + tuple(tail_shape))
       pad = np.zeros((cmax,) + tuple(tail_shape), dtype)
       if count > 0:
-        pad[:count] = a
-      mine = torch.from_numpy(pad).to(dev)
-      parts = [torch.empty_like(mine) for _ in range(world)]
-      dist.all_gather(parts, mine, group=group)
-      return np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)], axis=0)
+        pad[:count] = np.asarray(local[key], dtype)
+      parts = comm.all_gather(pad)
+      return np.concatenate([parts[r][:c] for r, c in enumerate(counts)], axis=0)
 
     # tail shapes must be known on ranks with an empty block too: agree on them first
-    shapes = _agree_on_shapes(local, list(gather_keys) + list(rhat_keys), dist, group, torch, dev)
+    shapes = _agree_on_shapes(local, list(gather_keys) + list(rhat_keys), comm)
     for k in gather_keys:
-      a = None if local is None else np.ascontiguousarray(local[k], dtype=np.float32)
-      out[k] = gather(a, shapes[k], np.float32)
+      out[k] = gather(k, shapes[k], np.float32)
     sums = {}
     for k in rhat_keys:
-      a = None if local is None else np.ascontiguousarray(local[k], dtype=np.float64)
-      pooled = gather(a, shapes[k], np.float64)                  # [num_chains, S] scalars
+      pooled = gather(k, shapes[k], np.float64)                  # [num_chains, S] scalars
       mine = pooled[first:first + count]
       packed = np.stack([dg.pack(p) for p in _local_sums(mine, pooled)])       # [4, n + 3]
-      t = torch.from_numpy(packed).to(dev)
-      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)       # small all-reduce of the sums
-      sums[k] = [dg.unpack(v) for v in t.cpu().numpy()]
+      red = comm.all_reduce(packed).reshape(packed.shape)         # small all-reduce of the sums
+      sums[k] = [dg.unpack(v) for v in red]
   out["split_rhat"] = {k: dg.rhat_from_sums(sums[k][0]) for k in rhat_keys}
   out["ess_bulk"] = {k: dg.ess_from_sums(sums[k][1]) for k in rhat_keys}
   out["ess_tail"] = {k: float(np.nanmin([dg.ess_from_sums(sums[k][2]), dg.ess_from_sums(sums[k][3])]))
@@ -105,11 +146,11 @@ def _local_sums(mine: np.ndarray, pooled: np.ndarray):
   return [dg.partial_sums(dg.split_chains(mine)), dg.bulk_partial(mine, pooled), lo, hi]
 
 
-def _agree_on_shapes(local, keys, dist, group, torch, dev):
+def _agree_on_shapes(local, keys, comm):
   """Per-key trailing shapes, taken from any rank that ran a fit (max-reduced; ranks with an
   empty block contribute zeros)."""
   max_nd = 4
-  t = torch.zeros((len(keys), max_nd + 1), dtype=torch.int64, device=dev)
+  t = np.zeros((len(keys), max_nd + 1), np.float64)
   if local is not None:
     for i, k in enumerate(keys):
       shp = np.asarray(local[k]).shape[1:]
@@ -118,6 +159,5 @@ def _agree_on_shapes(local, keys, dist, group, torch, dev):
       t[i, 0] = len(shp)
       for j, v in enumerate(shp):
         t[i, 1 + j] = int(v)
-  dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-  t = t.cpu().numpy()
+  t = comm.all_reduce(t, 1).reshape(t.shape)       # MAX (exact: small integers in float64)
   return {k: tuple(int(v) for v in t[i, 1:1 + int(t[i, 0])]) for i, k in enumerate(keys)}

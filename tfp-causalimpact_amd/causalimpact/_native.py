@@ -79,6 +79,7 @@ def load():
   L.ci_last_error.restype = C.c_char_p
   L.ci_abi_version.restype = C.c_int
   L.ci_device_count.argtypes = [C.POINTER(C.c_int)]
+  L.ci_device_synchronize.argtypes = [C.c_int]
   L.ci_fit_gibbs.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.POINTER(SeriesParams), C.POINTER(Outputs)]
   L.ci_session_create.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -128,7 +129,7 @@ def load():
 
 def exported_symbols() -> Sequence[str]:
   """Every entry point include/causalimpact_amd.h declares."""
-  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_pool_trim", "ci_host_alloc",
+  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_device_synchronize", "ci_pool_trim", "ci_host_alloc",
           "ci_host_free", "ci_fit_gibbs",
           "ci_session_create", "ci_session_run", "ci_session_run_streamed", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_kernel_name", "ci_session_destroy",
@@ -136,7 +137,10 @@ def exported_symbols() -> Sequence[str]:
           "ci_session_summarize", "ci_summarize_draws",
           "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_eval",
           "ci_ll_session_draw_latents", "ci_ll_session_hmc_run", "ci_ll_session_hmc_fetch",
-          "ci_ll_session_algorithmic_bytes", "ci_ll_session_destroy", "ci_test_rng",
+          "ci_ll_session_algorithmic_bytes", "ci_ll_session_destroy",
+          "ci_comm_unique_id", "ci_comm_create", "ci_comm_info", "ci_comm_barrier",
+          "ci_comm_all_reduce", "ci_comm_all_gather", "ci_comm_session_all_gather",
+          "ci_comm_ll_session_all_gather", "ci_comm_destroy", "ci_test_rng",
           "ci_test_dk_draw")
 
 
@@ -149,6 +153,11 @@ def device_count() -> int:
   n = C.c_int(0)
   _check(load().ci_device_count(C.byref(n)))
   return n.value
+
+
+def device_synchronize(device: int = 0):
+  """Waits for all work queued on `device` (ci_device_synchronize)."""
+  _check(load().ci_device_synchronize(int(device)))
 
 
 def pool_trim():
@@ -261,13 +270,18 @@ def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
   return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
 
-def _alloc_outputs(pb: Problem, want: Optional[Sequence[str]] = None, pinned: bool = False):
+def output_shapes(pb: Problem) -> Dict[str, tuple]:
+  """Shapes of the members of ci_outputs for this problem (chain-major, per device)."""
   B, C_, S, T, P, K = pb.num_series, pb.num_chains, pb.num_results, pb.T, pb.P, pb.num_blocks
-  shapes = dict(
+  return dict(
       observation_noise_scale=(B, C_, S), level_scale=(B, C_, S), slope_scale=(B, C_, S),
       seasonal_drift_scales=(B, C_, S, K), weights=(B, C_, S, P), level=(B, C_, S, T),
       slope=(B, C_, S, T), seasonal_levels=(B, C_, S, T, K), posterior_means=(B, C_, T),
       posterior_trajectories=(B, C_, S, T))
+
+
+def _alloc_outputs(pb: Problem, want: Optional[Sequence[str]] = None, pinned: bool = False):
+  shapes = output_shapes(pb)
   out, arrs = Outputs(), {}
   for name, shp in shapes.items():
     if want is not None and name not in want:

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -340,6 +341,12 @@ int ci_abi_version(void) { return CI_ABI_VERSION; }
 int ci_device_count(int* count) {
   if (!count) return fail("count is NULL");
   HIP_TRY(hipGetDeviceCount(count));
+  return 0;
+}
+
+int ci_device_synchronize(int device) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipDeviceSynchronize());
   return 0;
 }
 
@@ -1444,3 +1451,5 @@ const ci_series_params* q = params;
 }
 
 }  // extern "C"
+
+#include "ci_comm.h"

@@ -363,7 +363,7 @@ typedef struct {
  * SS_g'/SS_g = 1 + O(1/n): immaterial at the reference's sizes, visible at n = 4
  * (tests/test_geweke.py, which therefore runs the exact exponent through
  * CI_ORACLE_FLAG_EXACT_MARGINAL).  Default 1.0 = the reference's formula. */
-static double g_ss_exponent_offset = 1.0;
+static _Thread_local double g_ss_exponent_offset = 1.0;   /* per thread: fits are re-entrant */
 
 static int ss_evaluate(int P, const double* xtx, const double* prior_prec, const double* xty,
                        double yty, const uint8_t* nz, double nonzero_prob, double post_conc,

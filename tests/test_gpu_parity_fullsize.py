@@ -82,33 +82,41 @@ def _compare(tag, dev_chains, orc_chains, scale_floor):
 
 
 def test_cfg2_long_run_posterior_matches_oracle_within_one_percent_or_mc_error():
-  """BASELINE cfg2: T=1000, P=11, LocalLinearTrend + spike-and-slab, W=112, S=1000; 8 device
-  chains vs 32 float64 oracle chains (ids 0..31; ~0.2 s each, run on the host cores)."""
-  T, p, W, S, C, CO = 1000, 10, 112, 1000, 8, 32
+  """BASELINE cfg2: T=1000, P=11, LocalLinearTrend + spike-and-slab, W=112, S=1000.  64 device
+  chains (ids 0..63, one launch) and 32 float64 oracle chains (ids 0..31; ~0.2 s each, on the
+  host cores).  Two comparisons:
+    * INDEPENDENT replicates -- device chains 32..63 against oracle chains 0..31 (disjoint random
+      streams): 32 chains a side bring the Monte-Carlo error of the headline quantities below the
+      1 % mark, so the `allowed = max(1 %, 4 s.e.)` band is the 1 % band for them;
+    * the SAME chain ids 0..7 on both sides: float32 kernel vs float64 oracle on one random
+      stream, i.e. pure arithmetic drift over 1112 iterations."""
+  T, p, W, S, C, CO = 1000, 10, 112, 1000, 64, 32
   seed = (0, 20240927)
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 2024)
   spec = orc.default_spec(y, mask, X, has_slope=True)
   post = slice(int(0.7 * T), T)
   pb = _native.make_problem(T=T, P=p + 1, has_slope=1, num_warmup=W, num_results=S, num_chains=C,
                             seed=seed)
-  g = _native.fit_gibbs(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  g = _native.fit_gibbs(pb, y[None], mask[None], X[None], None, _native.make_params([spec]),
+                        want=("observation_noise_scale", "level_scale", "slope_scale", "weights",
+                              "posterior_trajectories", "posterior_means"))
   dev = [_chain_summaries(g["observation_noise_scale"][0, c], g["level_scale"][0, c],
                           g["slope_scale"][0, c], g["weights"][0, c],
                           g["posterior_trajectories"][0, c][:, post].mean(axis=1),
                           g["posterior_means"][0, c][post].mean()) for c in range(C)]
   with concurrent.futures.ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
     ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
-  rows = _compare("cfg2", dev, ora, scale_floor=0.05)
+  rows = _compare("cfg2", dev[CO:], ora, scale_floor=0.05)
   # float32 drift over 1112 iterations: the SAME chains (ids 0..7) on both sides
-  same = _compare("cfg2_same_chains", dev, ora[:C], scale_floor=0.05)
-  assert abs(same["sigma_obs.mean"]["rel"]) < 0.01 or abs(same["sigma_obs.mean"]["diff"]) < 4 * same["sigma_obs.mean"]["mc_se"]
+  same = _compare("cfg2_same_chains", dev[:8], ora[:8], scale_floor=0.05)
+  assert abs(same["sigma_obs.mean"]["rel"]) < 1e-3
   assert rows["sigma_obs.mean"]["oracle"] > 0
 
 
 def test_cfg4_long_run_posterior_matches_oracle_within_one_percent_or_mc_error():
   """BASELINE cfg4: T=10000, 50 covariates (P=51) + Seasonal(num_seasons=7), time-parallel
   kernel over its HBM workspace; 4 device chains vs 4 oracle chains (ids 0..3), W=112, S=400
-  (the oracle costs ~45 ms per iteration: ~25 s per chain, run in parallel on the host)."""
+  (the oracle costs ~8 ms per iteration: ~4 s per chain, run in parallel on the host)."""
   T, p, W, S, C = 10000, 50, 112, 400, 4
   seed = (3, 1)
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)

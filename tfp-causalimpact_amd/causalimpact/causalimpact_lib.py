@@ -109,6 +109,10 @@ class InferenceOptions:
   # holds them (csrc/ci_summary.h) instead of pandas on the host.  Single-device Gibbs fits only;
   # `False` keeps the reference's host arithmetic (and downloads the trajectories).
   summarize_on_device: bool = True
+  # CI_FLAG_* bits handed to the C-ABI (include/causalimpact_amd.h), e.g. `_native.FLAG_NO_CLUSTER`
+  # on a GPU shared with other jobs: the time-parallel seasonal kernel then runs one workgroup per
+  # chain instead of spin-synchronised clusters of CUs (same draws, bit for bit).
+  kernel_flags: int = 0
 
   def __post_init__(self):
     if self.num_warmup_steps is None:
@@ -152,7 +156,8 @@ def fit_causalimpact(data: pd.DataFrame,
       seasons=model_options.seasons, num_chains=inference_options.num_chains,
       devices=inference_options.devices, local_linear_trend=model_options.local_linear_trend,
       sampler=inference_options.sampler, summary_request=request,
-      hmc_init=inference_options.hmc_init, hmc_prior=inference_options.hmc_prior)
+      hmc_init=inference_options.hmc_init, hmc_prior=inference_options.hmc_prior,
+      kernel_flags=inference_options.kernel_flags)
   if request is not None and device_summary is None:
     # draws pooled on the host (several devices, or the HMC path): summarise them on one device
     request["ranks"] = _summary_ranks(posterior_trajectories.shape[0], request["quantiles"])
@@ -238,7 +243,7 @@ def _train_causalimpact_sts(*,
 def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps, model=None,
                  dtype=np.float32, seasons=(), num_chains=1, devices=None,
                  local_linear_trend=False, sampler="gibbs", summary_request=None,
-                 hmc_init="gibbs", hmc_prior="slab"):
+                 hmc_init="gibbs", hmc_prior="slab", kernel_flags=0):
   """_train_causalimpact_sts plus, when `summary_request` is given (single device, Gibbs), the
   on-device summary of the predictive draws; the [draws, T] trajectories then stay in HBM and
   are returned as None."""
@@ -298,7 +303,7 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
     pb = _native.make_problem(T=T, P=P, has_slope=local_linear_trend, num_seasons=num_seasons,
                               num_warmup=num_warmup_steps, num_results=num_results,
                               num_chains=len(chain_ids), chain_offset=int(chain_ids[0]),
-                              seed=seed_pair, device=dev)
+                              seed=seed_pair, device=dev, flags=int(kernel_flags))
     if summary_request is not None and len(devs) == 1:
       sess = _native.Session(pb, y[None], mask[None], None if design is None else design[None],
                              season_change, _native.make_params([params]))

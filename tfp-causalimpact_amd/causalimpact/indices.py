@@ -1,3 +1,7 @@
+# Attribution: this module restates the interface, validation rules and error messages of
+# google/tfp-causalimpact causalimpact/indices.py (Copyright 2019-2023 The TFP CausalImpact Authors,
+# Copyright 2014 Google Inc.; Apache License 2.0, http://www.apache.org/licenses/LICENSE-2.0) so that
+# this package is a drop-in for it; the implementation is TensorFlow-free and written for this build.
 """Period parsing/alignment (host side, pandas only).
 
 Behavioural mirror of /root/reference/causalimpact/indices.py:30-149: same accepted

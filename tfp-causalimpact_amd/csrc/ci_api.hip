@@ -501,7 +501,9 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     snprintf(nm, sizeof(nm), "ci::gibbs_kernel<%d,%d,%d,false>", D, s->L, pm);
     s->kernel_name = nm;
     // latency build: a fifth wavefront owns the regression section and sweeps the next
-    // iteration's matrix during the Durbin-Koopman draw (same draws, bit for bit)
+    // iteration's matrix during the Durbin-Koopman draw.  Same draws, bit for bit (the library is
+    // built with -ffp-contract=on: shared source rounds the same in both kernels; tested across
+    // the CU-count boundary), so choosing by launch size never changes a result.
     const size_t lds5 = ci::make_layout5(P, D, ci::NT * s->L).total;
     // ... when every chain has a compute unit to itself: five 256-register wavefronts leave room
     // for ONE workgroup per CU, the four-wave kernel for two, so launches with more workgroups
@@ -554,9 +556,12 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   }
   HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)s->lds_bytes));
-  if (s->fn_prof)
+  if (s->fn_prof) {
+    // the instrumented variant is always the four-wave kernel: its own LDS layout
+    const size_t lds_prof = K == 0 ? ci::make_layout(P, D, ci::NT * s->L, s->x_in_lds).total : s->lds_bytes;
     HIP_TRY(hipFuncSetAttribute((const void*)s->fn_prof, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)s->lds_bytes));
+                                (int)lds_prof));
+  }
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
@@ -1208,6 +1213,7 @@ int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const doubl
     s->h_level.release(); s->h_slope.release(); s->h_part.release(); s->h_traj.release();
     s->h_pm.release(); s->h_obs.release(); s->h_lscale.release(); s->h_sscale.release();
     s->h_w.release();
+    s->h_C = 0; s->h_S = 0;          // an allocation failing below must not leave a stale shape
     HIP_TRY(s->h_draws.alloc(N * (3 + P)));
     HIP_TRY(s->h_acc.alloc(C));
     HIP_TRY(s->h_eps.alloc(C));

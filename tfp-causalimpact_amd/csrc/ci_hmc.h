@@ -2,7 +2,7 @@
 // EXTENSION (BASELINE config "64 HMC chains sharded across 8 GPUs"):
 // the reference is Gibbs-only; upstream analogues tfp.sts.fit_with_hmc and
 // tfp.experimental.mcmc.windowed_adaptive_hmc.  Parity with TFP: unpinned; the float64 CPU
-// restatement of exactly this sampler is oracle/ci_oracle_hmc.c (same random stream, so the two
+// restatement of exactly this sampler is oracle/ci_oracle.c::ci_oracle_fit_hmc (same random stream, so the two
 // agree draw for draw until float32 round-off in the score separates the trajectories).
 //
 // One 256-thread workgroup per chain runs ALL warm-up and sampling iterations: every leapfrog

@@ -1,9 +1,11 @@
 // ci_kernels5.h -- the latency build of the register-resident Gibbs kernel: FIVE wavefronts per
-// chain.  Same sampler, same random stream and the same regression arithmetic in the same order
-// as gibbs_kernel<D, L, 1> (ci_kernels.h): sigma_obs and the weights of the first iterations are
-// bit-identical, the shared Durbin-Koopman source differs only by how -ffp-contract=fast fuses
-// it in the two compilation contexts (float32 round-off), and the chains stay together
-// (tests/test_gpu_gibbs.py compares the two).  What changes is WHO computes WHAT WHEN.
+// chain.  Same sampler, same random stream, the same arithmetic in the same order as
+// gibbs_kernel<D, L, 1> (ci_kernels.h), and -- the library is built with -ffp-contract=on, under
+// which a multiply-add is fused iff it is ONE source expression, whatever it is inlined into --
+// the same roundings: every draw of the two kernels is bit-identical
+// (tests/test_gpu_gibbs.py::test_five_wave_latency_kernel_equals_the_four_wave_kernel), so the
+// dispatch by launch size in ci_api.hip never changes a result.  What changes is WHO computes
+// WHAT WHEN.
 //
 // In gibbs_kernel the serial regression section of wave 0 is half of every iteration
 // (profiles/r02_a_phase_cycles.txt: 13.6k of 27k cycles), and most of it is a chain of

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CI_ABI_VERSION 2
+#define CI_ABI_VERSION 3
 #define CI_MAX_BLOCKS 8
 
 /* Per-series priors and initial Gibbs state.  One per series because every
@@ -47,6 +47,12 @@ typedef struct ci_series_params {
   double init_seasonal_scale;                 /* N(0, sd)                            :489     */
   double obs_scale0, level_scale0, slope_scale0;  /* initial state                   :566-572 */
   double drift_scale0[CI_MAX_BLOCKS];             /*                                 :573-574 */
+  /* Multiplier of the weights-prior precision Omega = 0.01 (X'X/2 + diag(X'X)/2) / T (:451-453,
+   * built on the device from X); 1 = the reference's prior.  The host package conditions a raw-
+   * scale outcome as y -> (y - mu) / s before the float32 kernels see it and passes s^2 here:
+   * Omega is then in the conditioned units and the chain is the reference's chain, mapped
+   * (causalimpact_lib._internal_conditioning).  Must be positive. */
+  double weights_prior_scale;
 } ci_series_params;
 
 /* The sampler's static configuration == the non-tensor arguments of

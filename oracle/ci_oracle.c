@@ -492,7 +492,8 @@ int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out) {
     for (int i = 0; i < P; ++i)
       for (int j = 0; j < P; ++j) {
         double full = omega[i * P + j];
-        omega[i * P + j] = 0.01 * (i == j ? full : 0.5 * full) / (double)T;
+        omega[i * P + j] = 0.01 * (i == j ? full : 0.5 * full) / (double)T *
+                           (pb->weights_prior_scale > 0.0 ? pb->weights_prior_scale : 1.0);
       }
   }
   const double post_conc = pb->obs_conc + 0.5 * n_obs;

@@ -100,6 +100,10 @@ typedef struct {
    * apply ONE Gibbs transition to an arbitrary state (tests/test_geweke.py) */
   const double* weights0;  /* [P] */
   const double* latents0;  /* [T*d] */
+  /* multiplier of the weights-prior precision Omega = 0.01 (X'X/2 + diag(X'X)/2) / T
+   * (causalimpact_lib.py:451-453); 0 is read as 1.  The product's internal conditioning of a raw-
+   * scale outcome, y -> (y - mu) / s, needs Omega in the conditioned units: s^2 Omega. */
+  double weights_prior_scale;
 } ci_oracle_problem;
 
 /* Test-only: sample with the weights prior N(0, sigma^2 Omega^-1) exactly as the collapsed

@@ -61,6 +61,7 @@ class _Problem(C.Structure):
       ("obs_scale0", C.c_double), ("level_scale0", C.c_double), ("slope_scale0", C.c_double),
       ("drift_scale0", C.c_double * _MAX_BLOCKS),
       ("weights0", C.c_void_p), ("latents0", C.c_void_p),
+      ("weights_prior_scale", C.c_double),
   ]
 
 
@@ -229,6 +230,7 @@ def fit_gibbs(y, mask, X, spec, *, num_results, num_warmup, seed, chain=0,
             "nonzero_prob", "init_level_loc", "init_level_scale", "init_slope_scale",
             "init_seasonal_scale", "obs_scale0", "level_scale0", "slope_scale0"):
     setattr(pb, f, float(spec[f]))
+  pb.weights_prior_scale = float(spec.get("weights_prior_scale", 1.0))
   S = int(num_results)
   shapes = dict(obs_scale=(S,), level_scale=(S,), slope_scale=(S,), drift_scales=(S, K),
                 weights=(S, P), level=(S, T), slope=(S, T), seasonal=(S, T, K),
@@ -377,7 +379,8 @@ def _hmc_problem(y, mask, X, spec, *, num_results, num_warmup, num_leapfrog, pri
       X=np.ascontiguousarray(np.asarray(X, np.float64)) if P > 0 else np.zeros((T, 0)),
       sc=(np.ascontiguousarray(np.stack(spec["season_change"]).astype(np.uint8))
           if K > 0 else np.zeros((0, T), np.uint8)))
-  keep["omega"] = np.ascontiguousarray(slab_precision(keep["X"])) if P > 0 else np.zeros((0, 0))
+  keep["omega"] = (np.ascontiguousarray(slab_precision(keep["X"]) * float(spec.get("weights_prior_scale", 1.0)))
+                   if P > 0 else np.zeros((0, 0)))
   pb = _HmcProblem()
   pb.T, pb.P, pb.has_slope, pb.num_blocks = T, P, int(spec["has_slope"]), K
   for k in range(K):

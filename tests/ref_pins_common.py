@@ -15,12 +15,12 @@ from oracle import ci_oracle as orc
 
 
 def fit(backend, data, pre, post, *, seed, num_results, num_warmup=None, prior_level_sd=0.01,
-        seasons=(), alpha=0.05, standardize=True):
+        seasons=(), alpha=0.05, standardize=True, dtype=np.float32):
   inf = lib.InferenceOptions(num_results=num_results, num_warmup_steps=num_warmup)
   if backend == "gpu":
     return lib.fit_causalimpact(
         data, pre, post, alpha=alpha, seed=seed, inference_options=inf,
-        data_options=lib.DataOptions(standardize_data=standardize),
+        data_options=lib.DataOptions(standardize_data=standardize, dtype=dtype),
         model_options=lib.ModelOptions(prior_level_sd=prior_level_sd, seasons=list(seasons)))
   ci = cid.CausalImpactData(data, pre, post, standardize_data=standardize, dtype=np.float64)
   design = None if ci.feature_ts is None else ci.feature_ts.values.astype(np.float64)

@@ -42,8 +42,8 @@ def test_flag_constants_match_the_header():
 
 
 def test_struct_layouts_match_header_sizes():
-  # ci_series_params: 20 doubles + 8 doubles; ci_problem: 24 int32/uint32 fields
-  assert ctypes.sizeof(_native.SeriesParams) == 8 * 28
+  # ci_series_params: 20 doubles + 8 doubles + 1; ci_problem: 24 int32/uint32 fields
+  assert ctypes.sizeof(_native.SeriesParams) == 8 * 29
   assert ctypes.sizeof(_native.Problem) == 4 * (5 + 8 + 5 + 2 + 2 + 2)
   assert ctypes.sizeof(_native.Outputs) == 8 * 10
 

@@ -78,19 +78,48 @@ def test_evaluate_is_deterministic(backend, seed):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_numeric_impact_values(backend):
-  # :655-702: effect (5, 250) to 1e-3 and relative interval widths <= 1 %
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_numeric_impact_values(backend, dtype):
+  # :655-702 (float32 AND float64): effect (5, 250) to 1e-3, relative interval widths <= 1 %
   rng = np.random.default_rng(11)
   n, start, effect = 100, 50, 5.0
   y = rng.normal(size=n, scale=0.0001)
   y[start:] += effect
   df = pd.DataFrame({"y": y}, index=pd.date_range("2018-01-01", periods=n, freq="D"))
   res = rp.fit(backend, df, (df.index[0], df.index[start - 1]), (df.index[start], df.index[-1]),
-               seed=5, num_results=1000)
+               seed=5, num_results=1000, dtype=dtype)
   s = res.summary
   np.testing.assert_allclose(s["abs_effect"], (effect, effect * (n - start)), rtol=1e-3, atol=1e-3)
   width = (s["abs_effect_upper"] - s["abs_effect_lower"]) / s["abs_effect"]
   assert width["average"] <= 0.01 and width["cumulative"] <= 0.01
+  if backend == "gpu":
+    assert res.posterior_samples.level.dtype == np.dtype(dtype)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_numeric_impact_values_without_standardisation_and_a_large_offset(backend, dtype):
+  """The reference's TODO (causalimpact_lib_test.py:679-682): no standardisation, y + 100 with
+  noise 1e-4 -- `series.posterior_lower[0] < y[0] < series.posterior_upper[0]`.  float32 resolves
+  100.0001 with a dozen levels; the product conditions the outcome internally (exact map,
+  tests/test_conditioning.py), so the band is as sharp as for standardised data."""
+  rng = np.random.default_rng(12)
+  n, start, effect = 100, 50, 5.0
+  y = 100.0 + rng.normal(size=n, scale=0.0001)
+  y[start:] += effect
+  df = pd.DataFrame({"y": y}, index=pd.date_range("2018-01-01", periods=n, freq="D"))
+  res = rp.fit(backend, df, (df.index[0], df.index[start - 1]), (df.index[start], df.index[-1]),
+               seed=5, num_results=1000, standardize=False, dtype=dtype)
+  first = res.series.iloc[0]
+  assert first["posterior_lower"] < y[0] < first["posterior_upper"]
+  # the band has the width of the observation noise (1e-4), not of float32 at 100 (8e-6 steps)
+  assert 1e-4 < first["posterior_upper"] - first["posterior_lower"] < 2e-3
+  s = res.summary
+  np.testing.assert_allclose(s["abs_effect"], (effect, effect * (n - start)), rtol=1e-3, atol=1e-3)
+  if dtype == np.float64:
+    # float64 back-transform: the posterior mean follows the data to better than float32 at 100
+    pm = res.series["posterior_mean"].to_numpy()[:start]
+    assert np.abs(pm - y[:start]).max() < 5e-4
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

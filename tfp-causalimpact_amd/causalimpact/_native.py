@@ -13,7 +13,7 @@ from typing import Dict, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_BLOCKS = 8
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libcausalimpact_amd.so")
@@ -26,7 +26,8 @@ _PARAM_FIELDS = (
 
 
 class SeriesParams(C.Structure):
-  _fields_ = [(f, C.c_double) for f in _PARAM_FIELDS] + [("drift_scale0", C.c_double * MAX_BLOCKS)]
+  _fields_ = ([(f, C.c_double) for f in _PARAM_FIELDS] + [("drift_scale0", C.c_double * MAX_BLOCKS)]
+              + [("weights_prior_scale", C.c_double)])
 
 
 class Problem(C.Structure):
@@ -180,6 +181,7 @@ def make_params(specs: Sequence[Dict]) -> "C.Array":
       setattr(arr[i], f, float(sp[f]))
     for k, v in enumerate(sp.get("drift_scale0", ())):
       arr[i].drift_scale0[k] = float(v)
+    arr[i].weights_prior_scale = float(sp.get("weights_prior_scale", 1.0))
   return arr
 
 

@@ -240,6 +240,41 @@ def _train_causalimpact_sts(*,
                       local_linear_trend=local_linear_trend, sampler=sampler)[:3]
 
 
+def _outcome_float64(ci_data) -> np.ndarray:
+  """The pre-period outcome the sampler models, in float64 from the source frame
+  (`outcome_ts.time_series` has already been rounded to DataOptions.dtype, data.py:125-126)."""
+  src = getattr(ci_data, "model_pre_data", None)
+  if src is None:
+    return np.asarray(ci_data.outcome_ts.time_series, np.float64)
+  return np.asarray(src[ci_data.outcome_column], np.float64)
+
+
+def _internal_conditioning(ci_data) -> Tuple[float, float]:
+  """(mu, s) of the affine map y -> (y - mu) / s applied to the outcome before it reaches the
+  float32 kernels when the caller did NOT standardise (`standardize_data=False`); (0, 1) else.
+
+  The default model is exactly equivariant under it: every prior and every initial value the
+  reference builds is expressed in units of outcome_sd (:424-443, :467-474, :566-574), the level
+  prior is centred on the first observation (:467-469), and the weights prior is conjugate (its
+  covariance carries sigma^2_obs).  So with y' = (y - mu) / s the Markov chain on
+  (level' = (level - mu) / s, slope / s, seasonal / s, weights / s, scales / s) driven by the SAME
+  random numbers is the same chain; the draws are mapped back in float64.  What this buys: the
+  float32 scans never see a large offset or a tiny scale (the reference's own TODO case,
+  causalimpact_lib_test.py:679-682: no standardisation, y + 100 with noise 1e-4, where float32
+  would resolve the noise with a dozen levels).  tests/test_conditioning.py checks the
+  equivariance on the float64 oracle (1e-9) and the GPU tests run that TODO case."""
+  if getattr(ci_data, "standardize_data", True):
+    return 0.0, 1.0
+  pre = _outcome_float64(ci_data)
+  pre = pre[~np.isnan(pre)]
+  if pre.size < 2:
+    return 0.0, 1.0
+  mu, sd = float(np.mean(pre)), float(np.std(pre, ddof=1))
+  if not np.isfinite(sd) or sd <= 0.0:
+    sd = 1.0
+  return mu, sd
+
+
 def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps, model=None,
                  dtype=np.float32, seasons=(), num_chains=1, devices=None,
                  local_linear_trend=False, sampler="gibbs", summary_request=None,
@@ -251,35 +286,35 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
     raise NotImplementedError("custom tfp.sts models are not supported by the HIP path")
   seed_pair = _sanitize_seed(seed)
   np_dtype = cid._as_numpy_dtype(dtype)  # pylint: disable=protected-access
-  if np_dtype == np.float64:
-    # The reference runs its whole sampler in the requested dtype (:159,
-    # causalimpact_lib_test.py:655-662).  The device kernels compute in float32 (float64 only in
-    # the regression block), so say so instead of silently downgrading; with standardised data
-    # every quantity the kernel touches is O(1) and the float32 path is accurate to ~1e-6.
-    import warnings  # pylint: disable=import-outside-toplevel
-    warnings.warn(
-        "DataOptions.dtype=float64: the MI355X kernels compute in float32 (float64 in the "
-        "regression block only); the returned arrays are float64."
-        + ("" if getattr(ci_data, "standardize_data", True) else
-           "  standardize_data=False feeds the raw outcome scale to float32 scans: "
-           "large-magnitude series lose precision -- prefer standardize_data=True."),
-        RuntimeWarning, stacklevel=3)
-
+  # dtype (reference :159: the sampler runs in DataOptions.dtype).  The device kernels compute in
+  # float32 (float64 in the regression block) on an INTERNALLY CONDITIONED copy of the outcome --
+  # see `_internal_conditioning` below: an exact reparametrisation of the model that keeps every
+  # quantity the float32 scans touch O(1) whatever the scale / offset of the raw series, mapped
+  # back in float64.  dtype=float64 therefore returns float64 arrays whose data-scale arithmetic
+  # (offsets, scales, summaries) is float64; the chain itself has float32 round-off (same-chain
+  # drift vs the float64 oracle < 1e-5 relative over a full fit).
   design = None if ci_data.feature_ts is None else np.asarray(ci_data.feature_ts.values,
                                                               dtype=np.float64)    # :545-546
   # Post-period handled as missing observations: forecasting == sampling (:548-562).
   n_after = ci_data.model_after_pre_data.shape[0]
-  y = np.concatenate([np.asarray(ci_data.outcome_ts.time_series, np.float64),
-                      np.full(n_after, np.nan)])
+  y = np.concatenate([_outcome_float64(ci_data), np.full(n_after, np.nan)])
   mask = np.concatenate([np.asarray(ci_data.outcome_ts.is_missing, bool),
                          np.ones(n_after, bool)])
   T = y.shape[0]
-  outcome_sd = float(np.nanstd(np.asarray(ci_data.outcome_ts.time_series, np.float64), ddof=1))
+  cond_mu, cond_s = _internal_conditioning(ci_data)
+  if (cond_mu, cond_s) != (0.0, 1.0):
+    y = (y - cond_mu) / cond_s
+  outcome_sd = float(np.nanstd(y[:T - n_after], ddof=1))
   num_seasons, season_change = _model.expand_seasons(seasons, T)
   params = _model.series_params(y, mask, design, prior_level_sd=prior_level_sd,
                                 num_seasonal_blocks=len(num_seasons),
                                 has_slope=local_linear_trend, outcome_sd=outcome_sd)
+  params["weights_prior_scale"] = cond_s * cond_s     # Omega in the conditioned units (exact map)
   P = 0 if design is None else design.shape[1]
+  if P > 0:
+    # the spike-and-slab branch clips the VARIANCE at upper_bound = 1.2 sd, a scale (:442-443 as
+    # the sampler reads it): var <= 1.2 sd  <=>  var' <= 1.2 sd / s^2 in the conditioned units
+    params["obs_ub"] = params["obs_ub"] / cond_s
   K = len(num_seasons)
 
   if sampler not in ("gibbs", "hmc"):
@@ -298,7 +333,8 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
       res = _hmc.fit_hmc(y, mask, design, params, has_slope=local_linear_trend,
                          num_results=num_results, num_warmup=num_warmup_steps,
                          num_chains=len(chain_ids), seed=seed_pair, device=dev,
-                         chain_offset=int(chain_ids[0]), init=hmc_init, prior=hmc_prior)
+                         chain_offset=int(chain_ids[0]), init=hmc_init, prior=hmc_prior,
+                         horseshoe_scale=0.1 / cond_s)
       return {k: v for k, v in res.items() if not k.startswith("hmc_")}
     pb = _native.make_problem(T=T, P=P, has_slope=local_linear_trend, num_seasons=num_seasons,
                               num_warmup=num_warmup_steps, num_results=num_results,
@@ -313,8 +349,12 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
                            if k != "posterior_trajectories"])
         summary_request["ranks"] = _summary_ranks(len(chain_ids) * num_results,
                                                   summary_request["quantiles"])
+        # value = trajectory * scale + shift, the trajectory being in the internal units
         device_summary = sess.summarize(
-            **{k: summary_request[k] for k in ("scale", "shift", "observed", "flags", "ranks")})
+            scale=np.asarray(summary_request["scale"], np.float64) * cond_s,
+            shift=(np.asarray(summary_request["shift"], np.float64)
+                   + cond_mu * np.asarray(summary_request["scale"], np.float64)),
+            **{k: summary_request[k] for k in ("observed", "flags", "ranks")})
       finally:
         sess.close()
       return part
@@ -332,6 +372,13 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
       parts = list(pool_.map(lambda a: run_on(*a), work))
   out = ({k: v[0] for k, v in parts[0].items()} if len(parts) == 1 else              # [C, ...]
          {k: np.concatenate([p[k][0] for p in parts], axis=0) for k in parts[0]})
+
+  if (cond_mu, cond_s) != (0.0, 1.0):
+    # back to the caller's scale, in float64: locations get the offset, everything else the scale
+    out = {k: np.asarray(v, np.float64) * cond_s for k, v in out.items()}
+    for k in ("level", "posterior_means", "posterior_trajectories"):
+      if k in out:
+        out[k] += cond_mu
 
   def pool(a):   # [C, S, ...] -> [C*S, ...]
     return a.reshape((a.shape[0] * a.shape[1],) + a.shape[2:]).astype(np_dtype, copy=False)

@@ -60,7 +60,8 @@ namespace ci {
 // feature-major copy).
 // ------------------------------------------------------------------------------------
 static __global__ void setup_regression_kernel(int T, int P, const float* Xt, const uint8_t* mask,
-                                        double* xtx, double* omega) {
+                                        const double* __restrict__ prior_scale, double* xtx,
+                                        double* omega) {
   // one wavefront per (series, i, j): lanes stride over time (both rows coalesced), float64 sums
   const int e = blockIdx.x % (P * P), series = blockIdx.x / (P * P);
   const int i = e / P, j = e % P, lane = threadIdx.x;
@@ -80,7 +81,8 @@ static __global__ void setup_regression_kernel(int T, int P, const float* Xt, co
   }
   if (lane == 0) {
     xtx[(size_t)series * P * P + e] = so;
-    omega[(size_t)series * P * P + e] = 0.01 * (i == j ? sa : 0.5 * sa) / (double)T;
+    omega[(size_t)series * P * P + e] =
+        0.01 * (i == j ? sa : 0.5 * sa) / (double)T * prior_scale[series];
   }
 }
 
@@ -299,7 +301,7 @@ struct ci_session {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<float> y, Xt, o_obs, o_lscale, o_sscale, o_w, o_level, o_slope, o_pm, o_traj;
   DevBuf<uint8_t> mask;
-  DevBuf<double> xtx, omega;
+  DevBuf<double> xtx, omega, wps;      // wps [B]: ci_series_params.weights_prior_scale
   DevBuf<ci::DevSeriesParams> sp;
   DevBuf<long long> prof;
   bool profile = false;
@@ -572,6 +574,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   HIP_TRY(s->Xt.alloc((size_t)B * P * T));
   HIP_TRY(s->xtx.alloc((size_t)B * P * P));
   HIP_TRY(s->omega.alloc((size_t)B * P * P));
+  HIP_TRY(s->wps.alloc(B));
   HIP_TRY(s->sp.alloc(B));
   HIP_TRY(s->o_obs.alloc(BCS));
   HIP_TRY(s->o_lscale.alloc(BCS));
@@ -684,6 +687,15 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   HIP_TRY(hipMemcpy(s->y.p, yh.data(), BT * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->mask.p, mask, BT, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->sp.p, sph.data(), B * sizeof(ci::DevSeriesParams), hipMemcpyHostToDevice));
+  {
+    std::vector<double> wps(B);
+    for (int b = 0; b < B; ++b) {
+      if (!(params[b].weights_prior_scale > 0.0) || !std::isfinite(params[b].weights_prior_scale))
+        return fail("params[%d].weights_prior_scale must be positive and finite (1 = the reference's prior)", b);
+      wps[b] = params[b].weights_prior_scale;
+    }
+    HIP_TRY(hipMemcpy(s->wps.p, wps.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  }
   if (P > 0) {
     std::vector<float> xt((size_t)B * P * T);
     for (int b = 0; b < B; ++b)
@@ -721,7 +733,7 @@ static int session_launch(ci_session* s) {
   }
   if (pb.P > 0) {
     hipLaunchKernelGGL(ci::setup_regression_kernel, dim3(pb.num_series * pb.P * pb.P), dim3(64), 0,
-                       s->stream, pb.T, pb.P, s->Xt.p, s->mask.p, s->xtx.p, s->omega.p);
+                       s->stream, pb.T, pb.P, s->Xt.p, s->mask.p, s->wps.p, s->xtx.p, s->omega.p);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -1062,7 +1074,7 @@ int ci_session_destroy(ci_session* s) {
   (void)hipSetDevice(s->pb.device);
   s->y.release(); s->Xt.release(); s->o_obs.release(); s->o_lscale.release(); s->o_sscale.release();
   s->o_w.release(); s->o_level.release(); s->o_slope.release(); s->o_pm.release();
-  s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->sp.release(); s->prof.release();
+  s->o_traj.release(); s->mask.release(); s->xtx.release(); s->omega.release(); s->wps.release(); s->sp.release(); s->prof.release();
   s->season_change.release(); s->ssp.release(); s->p1_chol.release(); s->o_drift.release();
   s->o_seasonal.release(); s->ws.release(); s->csync.release(); s->cpart.release(); s->cw.release(); s->cv.release();
   s->s_value.release(); s->s_cum.release(); s->s_obs.release(); s->s_flags.release();
@@ -1143,6 +1155,8 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
     return fail("log-likelihood path: T=%d exceeds the register-resident scans (max %d)", pb->T,
                 ci::NT * 16);
   if (!params || !y || !mask || !out || max_evals < 1) return fail("bad argument");
+  if (!(params->weights_prior_scale > 0.0) || !std::isfinite(params->weights_prior_scale))
+    return fail("params->weights_prior_scale must be positive and finite (1 = the reference's prior)");
   if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
   HIP_TRY(hipSetDevice(pb->device));
   ci_ll_session* s = new ci_ll_session();
@@ -1185,7 +1199,8 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
           om[(size_t)i * P + j] += (double)X[(size_t)t * P + i] * (double)X[(size_t)t * P + j];
     for (int i = 0; i < P; ++i)
       for (int j = 0; j < P; ++j)
-        om[(size_t)i * P + j] = 0.01 * (i == j ? om[(size_t)i * P + j] : 0.5 * om[(size_t)i * P + j]) / T;
+        om[(size_t)i * P + j] = 0.01 * (i == j ? om[(size_t)i * P + j] : 0.5 * om[(size_t)i * P + j]) / T *
+                                params->weights_prior_scale;
     HIP_TRY(s->omega.alloc((size_t)P * P));
     HIP_TRY(hipMemcpy(s->omega.p, om.data(), om.size() * sizeof(double), hipMemcpyHostToDevice));
   }

@@ -7,6 +7,11 @@ Where `tensorflow_probability` AND the reference package import (e.g. a machine 
 `pip install tfp-causalimpact`; neither exists in the build container or on the GPU box):
 
     python tests/golden/make_tfp_fixtures.py [--out tests/golden/tfp] [--seeds 8]
+                                             [--substrate tensorflow|numpy|jax]
+
+(`--substrate numpy` / `jax` alias TFP's TensorFlow-free substrates under the names the reference
+imports, so a machine with `pip install tfp-nightly tfp-causalimpact` and NO TensorFlow can
+produce the fixtures; best effort, reports what is missing otherwise.)
 
 it runs the REFERENCE's own hot path -- `causalimpact.causalimpact_lib._train_causalimpact_sts`,
 i.e. `gibbs_sampler.fit_with_gibbs_sampling(...)` exactly as called at
@@ -39,8 +44,42 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 
-def _import_reference():
+def _alias_substrate(substrate: str):
+  """Runs the reference on a TensorFlow-FREE substrate of TFP (`pip install tfp-nightly[jax]` or
+  just `tfp-nightly` + numpy): `tensorflow_probability.substrates.{numpy,jax}` re-exports the whole
+  library -- including `experimental.sts_gibbs.gibbs_sampler` and `sts` -- over a backend that
+  mimics the `tf` API (`tensorflow_probability.python.internal.backend.{numpy,jax}`).  The
+  reference imports the plain names `tensorflow` / `tensorflow_probability` (and four
+  `tensorflow_probability.python...` sub-modules, causalimpact_lib.py:31-35), so those names are
+  aliased in sys.modules BEFORE it is imported.  Best effort: returns an error string when the
+  installed TFP lacks a piece (nothing is written then)."""
+  import importlib  # pylint: disable=import-outside-toplevel
+  try:
+    sub = importlib.import_module(f"tensorflow_probability.substrates.{substrate}")
+    backend = importlib.import_module(f"tensorflow_probability.python.internal.backend.{substrate}")
+  except ImportError as e:
+    return f"tensorflow_probability.substrates.{substrate} is not importable here ({e})"
+  tf_like = getattr(backend, "v2", backend)
+  sys.modules["tensorflow"] = tf_like
+  sys.modules["tensorflow_probability"] = sub
+  base = f"tensorflow_probability.substrates.{substrate}"
+  for tail in ("experimental.distributions", "experimental.sts_gibbs.gibbs_sampler",
+               "experimental.sts_gibbs", "internal.prefer_static", "sts", "distributions",
+               "bijectors"):
+    try:
+      mod = importlib.import_module(base + "." + tail)
+    except ImportError as e:
+      return f"the {substrate} substrate lacks {tail} ({e})"
+    sys.modules["tensorflow_probability.python." + tail] = mod
+  return None
+
+
+def _import_reference(substrate: str = "tensorflow"):
   """The pip-installed reference, never this repository's drop-in package of the same name."""
+  if substrate != "tensorflow":
+    why = _alias_substrate(substrate)
+    if why:
+      return None, why
   try:
     import tensorflow_probability  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
   except ImportError:
@@ -53,6 +92,8 @@ def _import_reference():
     from causalimpact import causalimpact_lib  # pylint: disable=import-outside-toplevel
   except ImportError as e:
     return None, f"the reference package is not importable here ({e})"
+  except Exception as e:  # pylint: disable=broad-except
+    return None, f"importing the reference on the {substrate} substrate failed ({type(e).__name__}: {e})"
   if os.path.abspath(causalimpact.__file__).startswith(ROOT):
     return None, "`import causalimpact` resolved to this repository's drop-in, not the reference"
   if not hasattr(causalimpact_lib, "_train_causalimpact_sts"):
@@ -106,8 +147,10 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--out", default=os.path.join(HERE, "tfp"))
   ap.add_argument("--seeds", type=int, default=8)
+  ap.add_argument("--substrate", choices=("tensorflow", "numpy", "jax"), default="tensorflow",
+                  help="run TFP on this substrate; numpy / jax need no TensorFlow install")
   args = ap.parse_args()
-  ci, why = _import_reference()
+  ci, why = _import_reference(args.substrate)
   if ci is None:
     print(f"make_tfp_fixtures: nothing written -- {why}.  Parity with TFP stays unpinned.")
     return 2
@@ -134,7 +177,9 @@ def main():
       per_seed.append(_summaries(packed, np.asarray(trajectories), post_rows))
     fixture = dict(
         recipe=name, generator="tests/golden/make_tfp_fixtures.py",
-        versions=dict(tensorflow=tf.__version__, tensorflow_probability=tfp.__version__,
+        substrate=args.substrate,
+        versions=dict(tensorflow=getattr(tf, "__version__", "substrate backend"),
+                      tensorflow_probability=getattr(tfp, "__version__", "?"),
                       causalimpact=getattr(ci, "__version__", "?")),
         call="causalimpact_lib._train_causalimpact_sts (gibbs_sampler.fit_with_gibbs_sampling, "
              "causalimpact_lib.py:365-388)",

@@ -112,7 +112,6 @@ def test_rccl_single_rank_gathers_device_resident_arrays(tmp_path):
     np.testing.assert_array_equal(comm.session_all_gather(sess, key), want[key][None], err_msg=key)
   comm.close()
   sess.close()
-  assert "torch" not in sys.modules
 
 
 _DUP = r"""

@@ -2,6 +2,9 @@
 Validated against this build's own Gibbs posterior on the same data: for P <= 3 the
 spike-and-slab prior includes every feature, so both samplers target (nearly) the same
 posterior -- the Gibbs one adds the hard upper bounds and the sigma^2-coupled slab."""
+import concurrent.futures
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -81,8 +84,10 @@ def test_device_hmc_agrees_with_host_driven_hmc_and_splits_like_gibbs():
                              host["weights"].mean(axis=(0, 1, 2))[:p], atol=0.03)
   sd_d, sd_h = dev["weights"][0, :, :, 0].std(), host["weights"][0, :, :, 0].std()
   assert 0.7 < sd_d / sd_h < 1.4
+  # two independent Monte-Carlo estimates (6 chains x 300 draws each) of the same predictor mean;
+  # the masked post-period's forecast uncertainty makes its last steps the noisiest
   np.testing.assert_allclose(dev["posterior_means"].mean(axis=1), host["posterior_means"].mean(axis=1),
-                             atol=0.1)
+                             atol=0.15)
   # chains {0..5} in one launch == chains {0,1,2} and {3,4,5} in two launches
   a = _hmc.fit_hmc(y, mask, X, spec, num_chains=3, chain_offset=0, **kw)
   b = _hmc.fit_hmc(y, mask, X, spec, num_chains=3, chain_offset=3, **kw)
@@ -115,8 +120,9 @@ def test_surrogate_posterior_tracks_the_hmc_posterior_and_can_initialise_it():
   assert (hmc_vi["hmc_accept_rate"] > 0.5).all()
 
 
+@pytest.mark.parametrize("T,p", [(300, 3), (1000, 10)])
 @pytest.mark.parametrize("prior,has_slope", [("slab", True), ("horseshoe", False)])
-def test_device_hmc_tracks_the_float64_oracle_draw_for_draw(prior, has_slope):
+def test_device_hmc_tracks_the_float64_oracle_draw_for_draw(prior, has_slope, T, p):
   """csrc/ci_hmc.h against oracle/ci_oracle.c::ci_oracle_fit_hmc: same sampler, same Philox
   stream, float32 scans on the device vs float64 recursions in the oracle.  The first
   iterations (windowed warm-up included) must agree draw for draw; later ones separate as
@@ -124,7 +130,6 @@ def test_device_hmc_tracks_the_float64_oracle_draw_for_draw(prior, has_slope):
   from causalimpact import _model, _native
   from causalimpact import _synthetic as syn
   from oracle import ci_oracle as orc
-  T, p = 300, 3
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 12)
   spec = _model.series_params(y, mask, X, has_slope=has_slope)
   ospec = orc.default_spec(y, mask, X, has_slope=has_slope)
@@ -149,6 +154,46 @@ def test_device_hmc_tracks_the_float64_oracle_draw_for_draw(prior, has_slope):
     np.testing.assert_allclose(arrs["posterior_means"][0, c], want["loc"].mean(axis=0), atol=3e-2)
     np.testing.assert_allclose(arrs["observation_noise_scale"][0, c], draws[c, :, 0], rtol=1e-6)
     np.testing.assert_allclose(arrs["weights"][0, c], draws[c, :, 3:], rtol=1e-6, atol=1e-7)
+
+
+def test_full_warmup_schedule_adapts_like_the_oracle():
+  """The whole 75 / slow windows / 25 schedule at BASELINE cfg3's size (T=1000, P=11, 15
+  leapfrogs).  Draw-for-draw agreement cannot survive it: float32-vs-float64 round-off in the
+  score is amplified exponentially by the leapfrog dynamics (tools/exp_hmc_parity.py: the retained
+  draws of device and oracle chains with the same seed are unrelated after 150 iterations, whatever
+  the trajectory length) -- that is chaos, not a bug, and it is why the draw-for-draw test above
+  stops at 20 iterations.  What CAN be pinned over the full schedule is what the schedule is for:
+  the adapted step size and acceptance rate, as distributions over chains."""
+  from causalimpact import _model, _native
+  from causalimpact import _synthetic as syn
+  from oracle import ci_oracle as orc
+  T, p, W, S, NL, C = 1000, 10, 200, 20, 15, 8
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 2024)
+  spec = _model.series_params(y, mask, X, has_slope=True)
+  ospec = orc.default_spec(y, mask, X, has_slope=True)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=1, num_warmup=0, num_results=1, seed=(3, 4))
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8)
+  sess.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=NL, seed=(3, 4))
+  draws, acc, eps, _ = sess.hmc_fetch()
+  sess.close()
+  with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+    want = list(ex.map(_oracle_hmc_chain, [(y, mask, X, ospec, S, W, NL, c) for c in range(C)]))
+  o_eps = np.array([w["step_size"] for w in want])
+  o_acc = np.array([w["accept_rate"] for w in want])
+  # chain-to-chain spread of the adapted step size is ~5 %; the means must agree within 10 %
+  np.testing.assert_allclose(eps.mean(), o_eps.mean(), rtol=0.10)
+  assert abs(acc.mean() - o_acc.mean()) < 0.15
+  assert (eps > 0.3 * o_eps.mean()).all() and (eps < 3.0 * o_eps.mean()).all()
+  # and the chains have reached the same posterior
+  np.testing.assert_allclose(draws[:, :, 0].mean(), np.mean([w["draws"][:, 0].mean() for w in want]),
+                             rtol=0.05)
+
+
+def _oracle_hmc_chain(args):
+  from oracle import ci_oracle as orc
+  y, mask, X, ospec, S, W, NL, c = args
+  return orc.fit_hmc(y, mask, X, ospec, num_results=S, num_warmup=W, num_leapfrog=NL, seed=(3, 4),
+                     chain=c, latents=False)
 
 
 def _pooled_stats(x):

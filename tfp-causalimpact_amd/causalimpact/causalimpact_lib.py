@@ -241,10 +241,12 @@ def _train_causalimpact_sts(*,
 
 
 def _outcome_float64(ci_data) -> np.ndarray:
-  """The pre-period outcome the sampler models, in float64 from the source frame
-  (`outcome_ts.time_series` has already been rounded to DataOptions.dtype, data.py:125-126)."""
+  """The pre-period outcome the sampler models.  Standardised data: `outcome_ts.time_series`, i.e.
+  the values rounded to DataOptions.dtype exactly as the reference hands them to its sampler
+  (data.py:125-126).  Raw-scale data (`standardize_data=False`): the float64 source column -- the
+  rounding to float32 must come AFTER the internal conditioning, not before it."""
   src = getattr(ci_data, "model_pre_data", None)
-  if src is None:
+  if getattr(ci_data, "standardize_data", True) or src is None:
     return np.asarray(ci_data.outcome_ts.time_series, np.float64)
   return np.asarray(src[ci_data.outcome_column], np.float64)
 
@@ -394,9 +396,15 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
     samples["diagnostics"] = _diagnostics.summarize(
         {k: out[k] for k in ("observation_noise_scale", "level_scale")})
     samples["diagnostics"]["num_chains"] = num_chains
-  posterior_means = out["posterior_means"].mean(axis=0).astype(np_dtype, copy=False)      # :627
-  posterior_trajectories = (pool(out["posterior_trajectories"])                           # :631
-                            if "posterior_trajectories" in out else None)
+  # the predictive arrays feed the data-scale summaries: with internal conditioning they carry the
+  # offset again and stay float64 (float32 would round 100.0001 to 8e-6 steps)
+  pred_dtype = np.float64 if (cond_mu, cond_s) != (0.0, 1.0) else np_dtype
+  posterior_means = out["posterior_means"].mean(axis=0).astype(pred_dtype, copy=False)    # :627
+  posterior_trajectories = None
+  if "posterior_trajectories" in out:                                                     # :631
+    tr = out["posterior_trajectories"]
+    posterior_trajectories = tr.reshape((tr.shape[0] * tr.shape[1],) + tr.shape[2:]).astype(
+        pred_dtype, copy=False)
   return samples, posterior_means, posterior_trajectories, device_summary
 
 

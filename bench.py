@@ -37,7 +37,7 @@ from causalimpact import _synthetic as syn  # noqa: E402
 
 CFG = dict(T=1000, covariates=10, has_slope=1, num_results=1000, num_warmup=112,
            chains_per_gpu=8, data_seed=2024, seed=(0, 20240927),
-           hmc_warmup=500, hmc_leapfrog=15)
+           hmc_warmup=500, hmc_leapfrog=15, chunk_draws=32)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -151,7 +151,7 @@ class _GibbsFit:
     if not hasattr(self, "_into"):
       self.sess.run_streamed()                      # allocates the pinned result buffers once
       self._into = self.sess._last_streamed         # pylint: disable=protected-access
-    ms, _ = self.sess.run_streamed(into=self._into)
+    ms, _ = self.sess.run_streamed(into=self._into, chunk_draws=getattr(self, "chunk_draws", 125))
     return {"kernel": ms}
 
   def last_small(self):
@@ -207,6 +207,8 @@ def main():
   ap.add_argument("--sampler", choices=("gibbs", "hmc"), default="gibbs")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--chains-per-gpu", type=int, default=CFG["chains_per_gpu"])
+  ap.add_argument("--chunk-draws", type=int, default=CFG["chunk_draws"],
+                  help="retained draws per device-to-host copy of the streamed fetch")
   args = ap.parse_args()
   if args.steps is None:
     args.steps = 20 if args.sampler == "gibbs" else 5
@@ -236,6 +238,7 @@ def main():
   C = args.chains_per_gpu
   y, mask, X, _ = syn.make_sampler_inputs(CFG["T"], CFG["covariates"], CFG["data_seed"])
   fit = (_HmcFit if args.sampler == "hmc" else _GibbsFit)(y, mask, X, C, rank, local_rank)
+  fit.chunk_draws = args.chunk_draws
 
   def sync():
     if comm is not None:

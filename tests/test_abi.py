@@ -71,7 +71,7 @@ def test_argument_validation_happens_before_any_device_call():
 
   for kw, msg in [
       (dict(T=2), "T must be >= 3"),
-      (dict(P=500), "P must be in"),
+      (dict(P=5000), "P must be in"),
       (dict(num_results=0), "num_results >= 1"),
       (dict(num_chains=0), "num_chains >= 1"),
       (dict(num_seasons=(1,)), r"num_seasons\[0\] must be >= 2"),

@@ -275,7 +275,7 @@ void* pick_wide_kernel(int has_slope, int num_seasons) {
   return nullptr;
 }
 bool use_wide(const ci_problem* pb) {
-  return pb->num_blocks == 1 && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
+  return pb->num_blocks == 1 && pb->P <= ci::MAXP && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
          pick_wide_kernel(pb->has_slope, pb->num_seasons[0]) != nullptr;
 }
 int wide_steps_per_thread(int T) {
@@ -419,7 +419,8 @@ static int validate(const ci_problem* pb) {
   if (pb->abi_version != CI_ABI_VERSION)
     return fail("ABI mismatch: caller %d, library %d", pb->abi_version, CI_ABI_VERSION);
   if (pb->T < 3) return fail("T must be >= 3, got %d", pb->T);
-  if (pb->P < 0 || pb->P > ci::MAXP) return fail("P must be in [0, %d], got %d", ci::MAXP, pb->P);
+  if (pb->P < 0 || pb->P > ci::MAXP_BIG)
+    return fail("P must be in [0, %d], got %d", ci::MAXP_BIG, pb->P);
   if (pb->num_blocks < 0 || pb->num_blocks > CI_MAX_BLOCKS)
     return fail("num_blocks must be in [0, %d], got %d", CI_MAX_BLOCKS, pb->num_blocks);
   if (pb->num_blocks > 0) {
@@ -475,7 +476,10 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   // number of the trend / regression draws are unchanged (the block's own drift-scale draw uses
   // its own Philox site).
   s->kpb = *pb;
-  const bool long_trend = pb->num_blocks == 0 && steps_per_thread(pb->T) == 0;
+  // More than MAXP design columns: every model runs on the sequential one-wavefront kernel, whose
+  // regression block then keeps its O(P^2) arrays in a per-chain HBM workspace (any T as well).
+  const bool bigp = pb->P > ci::MAXP;
+  const bool long_trend = pb->num_blocks == 0 && steps_per_thread(pb->T) == 0 && !bigp;
   std::vector<uint8_t> no_changes;
   if (long_trend) {
     s->kpb.num_blocks = 1;
@@ -489,7 +493,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   const int D = pb->has_slope ? 2 : 1;
   const int K = pb->num_blocks;
   (void)caller_pb;
-  if (K == 0) {
+  if (K == 0 && !bigp) {
     s->L = steps_per_thread(T);
     // X lives in LDS when the whole layout fits in 160 KiB (leave room for a second block).
     const ci::LdsLayout with_x = ci::make_layout(P, D, ci::NT * s->L, 1);
@@ -544,16 +548,17 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       const ci::SLayout lay = ci::make_slayout(T, P, K, s->D_full, s->dred, pb->has_slope,
                                                s->seasonal_gws ? 1 : 0);
       s->lds_bytes = lay.total;
-      s->seasonal_ws_bytes = (lay.t_total + 255) & ~(size_t)255;
+      s->seasonal_ws_bytes = ((lay.t_total + 255) & ~(size_t)255) + (bigp ? ci::bigp_workspace_bytes(P) : 0);
     }
     if (s->lds_bytes > 160 * 1024) {
       return fail("seasonal model needs %zu bytes of LDS per chain (max 163840): fewer covariates "
                   "or a narrower seasonal state", s->lds_bytes);
     }
-    if (!s->wide) s->fn = (KernelFn)ci_gibbs_seasonal_fn(s->seasonal_gws ? 1 : 0);
+    if (!s->wide) s->fn = (KernelFn)ci_gibbs_seasonal_fn((s->seasonal_gws ? 1 : 0) | (bigp ? 2 : 0));
     char nm[96];
     if (s->wide) snprintf(nm, sizeof(nm), "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
-    else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel<%s>", s->seasonal_gws ? "true" : "false");
+    else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel<%s,%s>", s->seasonal_gws ? "true" : "false",
+                  bigp ? "true" : "false");
     s->kernel_name = nm;
   }
   HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -584,7 +589,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   HIP_TRY(s->o_slope.alloc(pb->has_slope ? BCS * T : 0));
   HIP_TRY(s->o_pm.alloc((size_t)B * C * T));
   HIP_TRY(s->o_traj.alloc(BCS * T));
-  if (K > 0) {
+  if (K > 0 || bigp) {
     HIP_TRY(s->season_change.alloc((size_t)K * T));
     HIP_TRY(s->ssp.alloc(B));
     HIP_TRY(s->p1_chol.alloc((size_t)B * s->dred * s->dred));
@@ -613,8 +618,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       HIP_TRY(s->cw.alloc((size_t)B * C * 64));
       HIP_TRY(s->cv.alloc((size_t)B * C * (P + 1) * (P + 1)));
     }
-    else if (s->seasonal_gws) HIP_TRY(s->ws.alloc((size_t)B * C * (s->seasonal_ws_bytes / sizeof(float))));
-    HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
+    else if (s->seasonal_ws_bytes > 0) HIP_TRY(s->ws.alloc((size_t)B * C * (s->seasonal_ws_bytes / sizeof(float))));
+    if (K > 0) HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
     std::vector<ci::DevSeasonalParams> ssh(B);
     std::vector<float> ch((size_t)B * s->dred * s->dred, 0.f);
     for (int b = 0; b < B; ++b) {
@@ -738,7 +743,7 @@ static int session_launch(ci_session* s) {
   }
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
   const ci_problem& kpb = s->kpb;
-  if (kpb.num_blocks > 0) {
+  if (kpb.num_blocks > 0 || kpb.P > ci::MAXP) {
     ci::SArgs sa;
     sa.k = a;
     sa.K = kpb.num_blocks; sa.has_slope = kpb.has_slope; sa.dred = s->dred;
@@ -746,6 +751,7 @@ static int session_launch(ci_session* s) {
     sa.season_change = s->season_change.p; sa.ssp = s->ssp.p; sa.p1_chol = s->p1_chol.p;
     sa.out_drift = s->o_drift.p; sa.out_seasonal = s->o_seasonal.p;
     sa.ws = s->ws.p; sa.Lc = s->Lc;
+    sa.ws_stride = s->wide ? 0 : s->seasonal_ws_bytes;
     sa.cluster = s->wide ? s->cluster : 1;
     sa.cluster_drop = (pb.flags & CI_FLAG_TEST_DROP_HELPER) ? sa.cluster - 1 : 0;
     sa.csync = s->csync.p; sa.cpart = s->cpart.p; sa.cw = s->cw.p; sa.cv = s->cv.p;
@@ -798,7 +804,7 @@ int ci_session_run_streamed(ci_session* s, ci_outputs* o, int32_t chunk_draws, f
   if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
   // the register-resident kernel publishes its progress; the seasonal kernels do not (their
   // results are copied in the same chunks once the kernel has finished)
-  const bool live = s->kpb.num_blocks == 0;
+  const bool live = s->kpb.num_blocks == 0 && s->kpb.P <= ci::MAXP;
   if (live) {
     if (!s->progress)
       HIP_TRY(hipHostMalloc((void**)&s->progress, BC * sizeof(unsigned int), hipHostMallocCoherent));
@@ -1151,6 +1157,7 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
                          ci_ll_session** out) {
   if (validate(pb)) return 1;
   if (pb->num_blocks != 0) return fail("log-likelihood path: seasonal blocks not supported yet");
+  if (pb->P > ci::MAXP) return fail("log-likelihood path: P must be <= %d, got %d", ci::MAXP, pb->P);
   if (steps_per_thread(pb->T) == 0)
     return fail("log-likelihood path: T=%d exceeds the register-resident scans (max %d)", pb->T,
                 ci::NT * 16);

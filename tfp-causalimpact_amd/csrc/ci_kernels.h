@@ -1074,6 +1074,192 @@ __device__ __forceinline__ double spike_slab_draw(const RegLds& R, int P,
 }
 
 // ------------------------------------------------------------------------------------
+// Any number of design columns (MAXP < P <= MAXP_BIG): the same draw, one wavefront, with every
+// O(P^2) array in a per-chain HBM workspace instead of LDS (a chain only reads what it wrote, and
+// a workgroup's accesses go through its own L1: program order + wave_sync suffice) and every
+// per-feature step looped over the lanes.  The reference has no cap on the number of covariates
+// (causalimpact_lib.py:445-453); this is the capability route, not a fast one: a sweep costs
+// (P+1)^2 / 64 L2 round trips per lane.  R.xtx / R.omega point at the setup kernel's output,
+// R.aug[0] [(P+1)^2], R.pri[0] [P^2], R.chol [P^2 + 2 (P + 1)], R.zv / R.uperm [P], R.nz / R.perm /
+// R.idx [P] at the workspace; R.bvec [P + 4] and R.w [P] stay in LDS.
+// ------------------------------------------------------------------------------------
+constexpr int MAXP_BIG = 512;
+
+__device__ __forceinline__ void sweep_big(double* M, int m, const double* t, int k, double sgn,
+                                          int lane) {
+  const double rd = 1.0 / t[k];
+  for (int e = lane; e < m * m; e += 64) {
+    const int i = e / m, j = e - i * m;
+    M[e] -= (t[i] * rd) * t[j];
+  }
+  wave_sync();
+  for (int j = lane; j < m; j += 64) {
+    const double pv = (j == k) ? -rd : sgn * t[j] * rd;
+    M[k * m + j] = pv;
+    M[j * m + k] = pv;
+  }
+  wave_sync();
+}
+
+// workspace doubles / ints the big-P regression block needs per chain
+__host__ __device__ inline size_t bigp_workspace_bytes(int P) {
+  const size_t n = (size_t)P + 1;
+  const size_t dbl = n * n + (size_t)P * P + (size_t)P * P + 2 * n + 2 * (size_t)P;
+  return (dbl * sizeof(double) + 3 * (size_t)P * sizeof(int) + 255) & ~(size_t)255;
+}
+__device__ __forceinline__ void bigp_point(RegLds& R, unsigned char* ws, int P) {
+  const size_t n = (size_t)P + 1;
+  double* d = reinterpret_cast<double*>(ws);
+  R.aug[0] = d; R.aug[1] = d; d += n * n;
+  R.pri[0] = d; R.pri[1] = d; d += (size_t)P * P;
+  R.chol = d; d += (size_t)P * P + 2 * n;        // Cholesky block, then the two saved pivot rows
+  R.zv = d; d += P;
+  R.uperm = d; d += P;
+  int* q = reinterpret_cast<int*>(d);
+  R.nz = q; R.perm = q + P; R.idx = q + 2 * P;
+}
+
+__device__ __noinline__ double spike_slab_draw_big(const RegLds& R, int P, const DevSeriesParams& sp,
+                                                   double prev_obs_scale, double g_obs,
+                                                   const Rng& rng, uint32_t iter, int lane,
+                                                   bool first) {
+  const int n = P + 1;
+  const double prev_var = prev_obs_scale * prev_obs_scale;
+  const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
+  const bool all_in = sp.nonzero_prob >= 1.0;
+  double* A = R.aug[0];
+  double* Pm = R.pri[0];
+  double* ta = R.chol + (size_t)P * P;      // saved pivot row of A   [n]
+  double* tp = ta + n;                      // saved pivot row of Pm  [n]
+  for (int e = lane; e < n * n; e += 64) {
+    const int i = e / n, j = e - i * n;
+    double v;
+    if (i < P && j < P) v = R.omega[i * P + j] * prev_var + R.xtx[i * P + j];
+    else v = R.bvec[(i == P && j == P) ? P : (i < j ? i : j)];
+    A[e] = v;
+  }
+  // the prior precision is kept swept on the current model at unit scale from iteration to
+  // iteration (see spike_slab_draw)
+  if (first)
+    for (int e = lane; e < P * P; e += 64) Pm[e] = R.omega[e];
+  for (int j = lane; j < P; j += 64) {
+    R.nz[j] = all_in ? 1 : (R.w[j] != 0.f ? 1 : 0);
+    if (!all_in) R.uperm[j] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j);
+  }
+  wave_sync();
+  auto sweep_both = [&](int k, bool reverse, bool with_prior) {
+    const double sgn = reverse ? -1.0 : 1.0;
+    for (int j = lane; j < n; j += 64) ta[j] = A[k * n + j];
+    if (with_prior)
+      for (int j = lane; j < P; j += 64) tp[j] = Pm[k * P + j];
+    wave_sync();
+    sweep_big(A, n, ta, k, sgn, lane);
+    if (with_prior) sweep_big(Pm, P, tp, k, sgn, lane);
+  };
+  // sweep in the currently included features (the prior matrix only when it is being built)
+  for (int k = 0; k < P; ++k)
+    if (R.nz[k]) sweep_both(k, false, first);
+  if (!all_in) {
+    // visiting order = stable argsort of P uniforms
+    for (int j = lane; j < P; j += 64) {
+      const double uj = R.uperm[j];
+      int rank = 0;
+      for (int k = 0; k < P; ++k) {
+        const double uk = R.uperm[k];
+        rank += (uk < uj || (uk == uj && k < j)) ? 1 : 0;
+      }
+      R.perm[rank] = j;
+    }
+    wave_sync();
+    const double logit_pi = log(sp.nonzero_prob) - log1p(-sp.nonzero_prob);
+    // lanes evaluate the proposals of 64 consecutive visiting positions on the CURRENT model; the
+    // first position (>= the scan position) that flips is applied and the later ones re-evaluated
+    int s_cur = 0;
+    while (s_cur < P) {
+      const int base = s_cur & ~63;
+      const int pos = base + lane;
+      bool flip = false;
+      if (pos < P && pos >= s_cur) {
+        const int j = R.perm[pos];
+        const bool in = R.nz[j] != 0;
+        const double ajj = A[j * n + j], ajb = A[j * n + P], corner = A[P * n + P];
+        const double pju = Pm[j * P + j];
+        const double beta_old = sp.obs_scale + 0.5 * corner;
+        double delta;
+        if (!in) {
+          const double beta_new = sp.obs_scale + 0.5 * (corner - ajb * ajb / ajj);
+          delta = 0.5 * log(pju * prev_var) - 0.5 * log(ajj) + logit_pi -
+                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
+        } else {
+          const double V = -ajj, Vp = -pju / prev_var;
+          const double beta_new = sp.obs_scale + 0.5 * (corner + ajb * ajb / V);
+          delta = 0.5 * log(Vp) - 0.5 * log(V) - logit_pi -
+                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
+        }
+        const double u = uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)pos);
+        flip = u < 1.0 / (1.0 + exp(-delta));
+      }
+      const unsigned long long bal = __ballot(flip);
+      if (bal == 0ull) { s_cur = base + 64; continue; }
+      const int s_star = base + __ffsll((long long)bal) - 1;
+      const int j = R.perm[s_star];
+      const bool in = R.nz[j] != 0;
+      wave_sync();
+      sweep_both(j, in, true);
+      if (lane == 0) R.nz[j] = in ? 0 : 1;
+      wave_sync();
+      s_cur = s_star + 1;
+    }
+  }
+  const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
+  double var = beta_post / g_obs;
+  if (var > sp.obs_ub) var = sp.obs_ub;   // the variance is clipped at upper_bound (see spike_slab_draw)
+  const double new_scale = sqrt(var);
+  // active set in increasing feature order
+  int na = 0;
+  for (int j0 = 0; j0 < P; j0 += 64) {
+    const int j = j0 + lane;
+    const int mynz = j < P ? R.nz[j] : 0;
+    const unsigned long long bal = __ballot(mynz != 0);
+    if (mynz) R.idx[na + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+    na += __popcll(bal);
+  }
+  for (int j = lane; j < P; j += 64) R.w[j] = 0.f;
+  wave_sync();
+  // Cholesky of M_S = Omega_S * prev_var + XtX_S (right-looking), z ~ N(0, I), L' u = z
+  for (int i = lane >> 4; i < na; i += 4)
+    for (int j = lane & 15; j < na; j += 16) {
+      const int fi = R.idx[i], fj = R.idx[j];
+      R.chol[i * na + j] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
+    }
+  for (int i = lane; i < na; i += 64) R.zv[i] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[i]);
+  wave_sync();
+  for (int k = 0; k < na; ++k) {
+    const double dkk = sqrt(R.chol[k * na + k]);
+    wave_sync();
+    for (int i = k + lane; i < na; i += 64) R.chol[i * na + k] = (i == k) ? dkk : R.chol[i * na + k] / dkk;
+    wave_sync();
+    for (int i = k + 1 + (lane >> 4); i < na; i += 4)
+      for (int j = k + 1 + (lane & 15); j <= i; j += 16)
+        R.chol[i * na + j] -= R.chol[i * na + k] * R.chol[j * na + k];
+    wave_sync();
+  }
+  for (int i = na - 1; i >= 0; --i) {
+    const double ui = R.zv[i] / R.chol[i * na + i];
+    wave_sync();
+    if (lane == 0) R.zv[i] = ui;
+    for (int k = lane; k < i; k += 64) R.zv[k] -= R.chol[i * na + k] * ui;
+    wave_sync();
+  }
+  for (int i = lane; i < na; i += 64) {
+    const int f = R.idx[i];
+    R.w[f] = (float)(A[f * n + P] + new_scale * R.zv[i]);
+  }
+  wave_sync();
+  return new_scale;
+}
+
+// ------------------------------------------------------------------------------------
 // The same regression draw executed by the WHOLE workgroup (P > 16 in the time-parallel kernel,
 // where the serial section would otherwise idle three waves for ~0.3M cycles at P = 51).
 // Control flow is uniform without any broadcast: every wave evaluates the (cheap) proposals and

@@ -50,6 +50,8 @@ struct SArgs {
   float* cpart;                      //   [B*C][segments][4][RS] partial sums of X~'targets, y'y
   float* cw;                         //   [B*C][64] weights + emission scale of the iteration
   double* cv;                        //   [B*C][(P+1)^2] regression matrix swept ahead (presweep_block)
+  size_t ws_stride;                  // sequential kernel: bytes of `ws` per chain (arrays over time when
+                                     //   they are not in LDS, then the P > MAXP regression block)
 };
 
 struct SLayout {
@@ -71,9 +73,10 @@ __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int 
   const size_t TS = (size_t)((T + 3) & ~3);
   const size_t Tf = sizeof(float) * TS;
   const int Pp = P > 0 ? P : 1, Kp = K > 0 ? K : 1;
-  const bool big = P > 16;
-  l.xtx = take(sizeof(double) * Pp * Pp);
-  l.omega = take(sizeof(double) * Pp * Pp);
+  const bool bigp = P > MAXP;          // every O(P^2) array lives in the HBM workspace (spike_slab_draw_big)
+  const bool big = P > 16 && !bigp;
+  l.xtx = take(bigp ? 16 : sizeof(double) * Pp * Pp);
+  l.omega = take(bigp ? 16 : sizeof(double) * Pp * Pp);
   l.bvec = take(sizeof(double) * (Pp + 4));
   l.aug0 = take(big ? sizeof(double) * sweep_padded((size_t)(Pp + 1) * (Pp + 1)) : 16);
   l.pri0 = take(big ? sizeof(double) * sweep_padded((size_t)Pp * Pp) : 16);
@@ -104,7 +107,9 @@ __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int 
 }
 
 #ifndef CI_SEASONAL_DECL_ONLY
-template <bool GWS>
+// BIGP: the P > MAXP build (regression block in the HBM workspace, spike_slab_draw_big); its own
+// instantiation so that the call does not cost the P <= MAXP builds a stack frame.
+template <bool GWS, bool BIGP = false>
 __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -129,7 +134,8 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   // below is either one 16-byte row per 4 steps or lane-contiguous, and a chain only ever reads
   // what it wrote, so the slice stays in this XCD's L2
   unsigned char* tb_ = smem;
-  if constexpr (GWS) tb_ = reinterpret_cast<unsigned char*>(a.ws) + chain_lin * ((L.t_total + 255) & ~(size_t)255);
+  unsigned char* wsc = reinterpret_cast<unsigned char*>(a.ws) + chain_lin * a.ws_stride;   // this chain's slice
+  if constexpr (GWS) tb_ = wsc;
   float* yv = (float*)(tb_ + L.yv); float* lev = (float*)(tb_ + L.lev);
   float* slp = (float*)(tb_ + L.slp); float* xw = (float*)(tb_ + L.xw);
   float* ytil = (float*)(tb_ + L.ytil); float* vf = (float*)(tb_ + L.vf);
@@ -153,6 +159,14 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   R.chol = (double*)(smem + L.chol); R.zv = (double*)(smem + L.zv);
   R.uperm = (double*)(smem + L.uperm);
   R.nz = (int*)(smem + L.nz); R.perm = (int*)(smem + L.perm); R.idx = (int*)(smem + L.idx);
+  constexpr bool bigp = BIGP;
+  if constexpr (BIGP) {
+    // any number of covariates: the O(P^2) arrays in this chain's workspace, X'X and Omega read
+    // where the setup kernel left them
+    R.xtx = const_cast<double*>(g.xtx) + (size_t)series * P * P;
+    R.omega = const_cast<double*>(g.omega) + (size_t)series * P * P;
+    bigp_point(R, wsc + (GWS ? ((L.t_total + 255) & ~(size_t)255) : 0), P);
+  }
 
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
@@ -191,10 +205,11 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       }
     cbv[t] = (uint8_t)bits;
   }
-  for (int e = lane; e < P * P; e += 64) {
-    R.xtx[e] = g.xtx[(size_t)series * P * P + e];
-    R.omega[e] = g.omega[(size_t)series * P * P + e];
-  }
+  if (!bigp)
+    for (int e = lane; e < P * P; e += 64) {
+      R.xtx[e] = g.xtx[(size_t)series * P * P + e];
+      R.omega[e] = g.omega[(size_t)series * P * P + e];
+    }
   // per-entry tables of the covariance time update P <- T P T' + Q
   for (int e = lane; e < D * D; e += 64) {
     const int i = e / D, j = e - i * D;
@@ -340,7 +355,8 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
           for (int k = 0; k < SMAXK; ++k)
             if (k < K && lane == k) a.out_drift[o * K + k] = (float)drift[k];
         }
-        if (g.out_weights && lane < P) g.out_weights[o * P + lane] = R.w[lane];
+        if (g.out_weights)
+          for (int j = lane; j < P; j += 64) g.out_weights[o * P + j] = R.w[j];
         // level / seasonal contributions / posterior-predictive trajectory of iteration it-1
         const float so = (float)emit_obs;
         const size_t row = o * T;
@@ -376,8 +392,10 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
       if (P <= 16)
         obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
-      else
+      else if constexpr (!BIGP)
         obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, it == 0);
+      else
+        obs_scale = spike_slab_draw_big(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, it == 0);
     }
     wave_sync();
     prof.tick(21);

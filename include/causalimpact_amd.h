@@ -225,6 +225,12 @@ typedef struct ci_ll_session ci_ll_session;
 int ci_ll_session_create(const ci_problem* problem, const ci_series_params* params, const float* y,
                          const uint8_t* mask, const float* X, int32_t max_evals,
                          ci_ll_session** session);
+/* The same for ANY model and length: seasonal blocks (season_change [K,T] as in ci_fit_gibbs) and
+ * T > 4096 run on the sequential one-wavefront route (csrc/ci_score_seq.h).  theta / grad rows
+ * are then [3 + K + P]: (sigma_obs, sigma_level, sigma_slope, sigma_drift[K], weights[P]). */
+int ci_ll_session_create2(const ci_problem* problem, const ci_series_params* params, const float* y,
+                          const uint8_t* mask, const float* X, const uint8_t* season_change,
+                          int32_t max_evals, ci_ll_session** session);
 int ci_ll_session_eval(ci_ll_session* session, int32_t num_evals, const double* theta,
                        double* loglik, double* grad);
 int ci_ll_session_draw_latents(ci_ll_session* session, int32_t num_draws, const double* theta,

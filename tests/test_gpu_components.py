@@ -172,3 +172,56 @@ def test_latent_draws_for_given_parameters_match_oracle():
     zp = np.array([orc.normal((4, 2), 7, 10 + e, orc.SITES["PRED"], 0, t) for t in range(T)])
     np.testing.assert_allclose(out["traj"][e], loc + th[0] * zp, atol=5e-3)
   sess.close()
+
+
+@pytest.mark.parametrize("T,p,has_slope,seasons", [
+    (120, 2, 0, ((7, 1),)),                      # weekly block
+    (200, 3, 1, ((4, 3), (7, 1))),               # trend + two blocks
+    (90, 0, 0, ((2, 5),)),                       # n = 2, no regression
+    (300, 1, 0, ((6, (1, 1, 2, 1, 1, 3)),)),     # per-season lengths
+    (5000, 2, 1, ()),                            # no block, T > 4096: the sequential route too
+    (6000, 1, 0, ((7, 1),)),
+])
+def test_sequential_loglik_and_score_match_the_oracle(T, p, has_slope, seasons):
+  """Row H for seasonal models and long series (csrc/ci_score_seq.h, one wavefront per
+  evaluation) against the oracle's ANALYTIC log-likelihood and score (ci_oracle_loglik_score,
+  itself pinned to central differences in tests/test_oracle_hmc.py): l, dl/d(sigma_obs,
+  sigma_level, sigma_slope, sigma_drift[K]) and dl/d beta = X'e."""
+  from causalimpact import _model
+  from causalimpact import _synthetic as syn
+  y, mask, X, _ = syn.make_sampler_inputs(T, max(p, 1), 21)
+  X = X if p > 0 else None
+  y = y + 0.6 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  mask = mask.copy()
+  mask[[3, 9, T // 3]] = True
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
+  counts, flg = _model.expand_seasons(seasons, T)
+  P, K = spec["P"], len(seasons)
+  rng = np.random.default_rng(1)
+  E = 4
+  theta = np.zeros((E, 3 + K + P))
+  theta[:, 0] = rng.uniform(0.3, 0.9, E)
+  theta[:, 1] = rng.uniform(0.02, 0.2, E)
+  theta[:, 2] = rng.uniform(0.005, 0.03, E) if has_slope else 0.0
+  theta[:, 3:3 + K] = rng.uniform(0.01, 0.1, (E, K))
+  theta[:, 3 + K:] = 0.3 * rng.normal(size=(E, P))
+  pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_seasons=counts, num_warmup=0,
+                            num_results=1)
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8,
+                               season_change=flg)
+  ll, grad = sess.evaluate(theta)
+  ll_only, _ = sess.evaluate(theta, want_grad=False)
+  np.testing.assert_array_equal(ll, ll_only)
+  sess.close()
+  for e in range(E):
+    th = theta[e]
+    ssm = orc.make_ssm(spec, mask, obs_scale=th[0], level_scale=th[1], slope_scale=th[2],
+                       drift_scale=th[3:3 + K])
+    resid = np.where(mask, 0.0, y) - (X @ th[3 + K:] if P else 0.0)
+    want_ll, ee, gs = orc.loglik_score(ssm, resid)
+    np.testing.assert_allclose(ll[e], want_ll, rtol=3e-5, atol=3e-3)
+    want = np.concatenate([gs[:3], gs[3:3 + K], (X.T @ ee) if P else np.zeros(0)])
+    if not has_slope:
+      want[2] = 0.0
+    scale = np.maximum(np.abs(want), 1e-2 * np.abs(want).max())
+    assert (np.abs(grad[e] - want) <= 2e-2 * scale + 1e-2).all(), (grad[e], want)

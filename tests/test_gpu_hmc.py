@@ -247,3 +247,83 @@ def test_cfg3_full_size_64_chains_as_8_launches_and_against_oracle_and_gibbs():
   sd_g = g["posterior_trajectories"][0][:, :, post].mean(axis=2).std()
   assert abs(cf_g - cf_h) < 0.25 * sd_g + 0.01, (cf_g, cf_h, sd_g)
   np.testing.assert_allclose(np.mean(oloc[:, :, post]), cf_h, atol=0.25 * sd_g + 0.01)
+
+
+@pytest.mark.parametrize("T,p,has_slope,seasons,prior", [
+    (140, 2, 0, ((7, 1),), "slab"),
+    (160, 3, 1, ((4, 3), (7, 1)), "horseshoe"),
+    (4500, 1, 0, (), "slab"),                     # no block, T > 4096: the sequential route too
+])
+def test_sequential_route_hmc_tracks_the_oracle_draw_for_draw(T, p, has_slope, seasons, prior):
+  """Row H for seasonal models / long series: hmc_seq_kernel (csrc/ci_score_seq.h: hmc_kernel's
+  driver over the one-wavefront score) against ci_oracle_fit_hmc -- same target, adaptation and
+  random stream, so the first iterations agree draw for draw; then the latent pass (the sequential
+  Gibbs kernel in its latents-only mode, a wavefront per retained draw) against
+  ci_oracle_hmc_latents on the SAME parameter draws."""
+  from causalimpact import _model, _native
+  from causalimpact import _synthetic as syn
+  from oracle import ci_oracle as orc
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 12)
+  y = y + 0.5 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
+  counts, flg = _model.expand_seasons(seasons, T)
+  K = len(seasons)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=has_slope, num_seasons=counts, num_warmup=0,
+                            num_results=1, seed=(3, 4))
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=4,
+                               season_change=flg)
+  assert sess.kernel_name() == "ci::hmc_seq_kernel"
+  W, S, C, NL = 20, 2, 2, 3
+  sess.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=NL, seed=(3, 4),
+               chain_offset=5, prior=prior)
+  draws, acc, eps, arrs = sess.hmc_fetch()
+  sess.close()
+  assert draws.shape == (C, S, 3 + K + p + 1)
+  for c in range(C):
+    want = orc.fit_hmc(y, mask, X, spec, num_results=S, num_warmup=W, num_leapfrog=NL, seed=(3, 4),
+                       chain=5 + c, prior=prior, latents=False)
+    np.testing.assert_allclose(eps[c], want["step_size"], rtol=3e-2)
+    np.testing.assert_allclose(draws[c], want["draws"], rtol=2e-2, atol=5e-3)
+    np.testing.assert_allclose(arrs["observation_noise_scale"][0, c], draws[c, :, 0], rtol=1e-6)
+    np.testing.assert_allclose(arrs["weights"][0, c], draws[c, :, 3 + K:], rtol=1e-6, atol=1e-7)
+    if K:
+      np.testing.assert_allclose(arrs["seasonal_drift_scales"][0, c], draws[c, :, 3:3 + K], rtol=1e-6)
+    # the latent pass on the DEVICE's own draws (float32 Durbin-Koopman vs the float64 oracle's)
+    for s in range(S):
+      th = draws[c, s]
+      ssm = orc.make_ssm(spec, mask, obs_scale=th[0], level_scale=th[1], slope_scale=th[2],
+                         drift_scale=th[3:3 + K])
+      resid = np.where(mask, 0.0, y) - X @ th[3 + K:]
+      lat = orc.dk_draw(ssm, resid, (3, 4), chain=5 + c, it=s)
+      tol = 5e-3 + 2e-3 * float(np.ptp(lat[:, 0]))
+      np.testing.assert_allclose(arrs["level"][0, c, s], lat[:, 0], atol=tol)
+      o = 1 + int(has_slope)
+      for k, n in enumerate(counts):
+        np.testing.assert_allclose(arrs["seasonal_levels"][0, c, s, :, k], lat[:, o], atol=5e-3)
+        o += n - 1
+
+
+def test_fit_causalimpact_hmc_with_weekly_seasonality_agrees_with_gibbs():
+  """`fit_causalimpact(..., sampler="hmc", seasons=[Seasons(7)])` used to raise."""
+  rng = np.random.default_rng(2)
+  n = 140
+  x = rng.normal(size=n).cumsum() * 0.2 + rng.normal(size=n)
+  season = np.tile([1.0, 0.4, -0.3, -0.9, -0.5, 0.1, 0.2], n // 7)
+  y = 1.2 * x + season + 0.3 * rng.normal(size=n)
+  y[98:] += 2.0
+  df = pd.DataFrame({"y": y, "x": x}, index=pd.date_range("2021-01-04", periods=n, freq="D"))
+  pre, post = (df.index[0], df.index[97]), (df.index[98], df.index[-1])
+  mo = lib.ModelOptions(seasons=[lib.Seasons(num_seasons=7)])
+  gibbs = lib.fit_causalimpact(df, pre, post, seed=(1, 2), model_options=mo,
+                               inference_options=lib.InferenceOptions(num_results=400, num_chains=4))
+  hmc = lib.fit_causalimpact(df, pre, post, seed=(1, 2), model_options=mo,
+                             inference_options=lib.InferenceOptions(
+                                 num_results=150, num_warmup_steps=150, num_chains=4, sampler="hmc"))
+  assert hmc.posterior_samples.seasonal_levels.shape == (600, n, 1)
+  np.testing.assert_allclose(hmc.summary.loc["average", "abs_effect"], 2.0, atol=0.5)
+  np.testing.assert_allclose(hmc.summary.loc["average", "abs_effect"],
+                             gibbs.summary.loc["average", "abs_effect"], atol=0.35)
+  # the weekly pattern is recovered by both samplers
+  sg = gibbs.posterior_samples.seasonal_levels[:, :98, 0].mean(axis=0)
+  sh = hmc.posterior_samples.seasonal_levels[:, :98, 0].mean(axis=0)
+  assert np.corrcoef(sg, sh)[0, 1] > 0.95

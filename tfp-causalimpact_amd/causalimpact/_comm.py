@@ -147,7 +147,8 @@ class Comm:
       fn = self._lib.ci_comm_session_all_gather
     else:
       Cn, S = session._hmc_shape       # pylint: disable=protected-access
-      hp = _native.make_problem(T=session.T, P=session.P, has_slope=session.D == 2, num_warmup=0,
+      hp = _native.make_problem(T=session.T, P=session.P, has_slope=session.D == 2,
+                                num_seasons=getattr(session, "num_seasons", ()), num_warmup=0,
                                 num_results=S, num_chains=Cn)
       shp = _native.output_shapes(hp)[field]
       fn = self._lib.ci_comm_ll_session_all_gather

@@ -111,12 +111,14 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
             num_chains: int, seed, device: int = 0, chain_offset: int = 0, num_leapfrog: int = 15,
             target_accept: float = 0.75, initial_step_size: float = 0.05,
             init: str = "gibbs", prior: str = "slab",
-            horseshoe_scale: float = 0.1) -> Dict[str, np.ndarray]:
+            horseshoe_scale: float = 0.1, num_seasons=(), season_change=None) -> Dict[str, np.ndarray]:
   """HMC with the whole fit on the device (csrc/ci_hmc.h: one workgroup per chain runs the
   windowed warm-up and all sampling iterations; one more launch draws the latent path and the
   predictive trajectory of every retained draw).  Returns the arrays of `_native.fit_gibbs`
   (leading series axis of 1) plus `hmc_accept_rate`, `hmc_step_size` [C], `hmc_target_calls`
-  and `hmc_kernel_ms`.
+  and `hmc_kernel_ms`.  Models with seasonal blocks (`num_seasons`, `season_change` [K, T] as in
+  `_native.fit_gibbs`) and series longer than 4096 steps run on the sequential route
+  (csrc/ci_score_seq.h: same target, same adaptation, one wavefront evaluates the score).
 
   prior: "slab" (the Gaussian slab of the reference's spike-and-slab prior) or "horseshoe" (the
   prior of `tfp.sts.SparseLinearRegression`, weights_prior_scale = horseshoe_scale).
@@ -128,14 +130,17 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
   T = y.shape[0]
   P = 0 if X is None else int(np.asarray(X).shape[1])
   C, S, W = int(num_chains), int(num_results), int(num_warmup)
-  pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_warmup=0, num_results=1,
-                            seed=seed, device=device)
-  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=64)
+  K = len(num_seasons)
+  pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_seasons=num_seasons, num_warmup=0,
+                            num_results=1, seed=seed, device=device)
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=64,
+                               season_change=season_change)
   try:
     init_theta = None
     if init == "vi":
-      if prior != "slab":
-        raise NotImplementedError("the surrogate posterior is built for the slab prior only")
+      if prior != "slab" or K > 0:
+        raise NotImplementedError("the surrogate posterior is built for the slab prior and "
+                                  "trend + regression models only")
       from causalimpact import _vi  # pylint: disable=import-outside-toplevel
       vi = _vi.fit_surrogate_posterior(y, mask, X, spec, has_slope=has_slope, seed=seed,
                                        device=device, sess=sess,
@@ -151,8 +156,9 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
     _, acc, eps, out = sess.hmc_fetch()
   finally:
     sess.close()
-  out["seasonal_drift_scales"] = np.zeros((1, C, S, 0), np.float32)
-  out["seasonal_levels"] = np.zeros((1, C, S, T, 0), np.float32)
+  if K == 0:
+    out["seasonal_drift_scales"] = np.zeros((1, C, S, 0), np.float32)
+    out["seasonal_levels"] = np.zeros((1, C, S, T, 0), np.float32)
   out.update(hmc_accept_rate=acc, hmc_step_size=eps, hmc_kernel_ms=np.asarray(ms),
              hmc_target_calls=np.int64((W + S) * num_leapfrog + 1))
   return out

@@ -100,6 +100,9 @@ def load():
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
   L.ci_ll_session_create.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+  L.ci_ll_session_create2.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.POINTER(C.c_void_p)]
   L.ci_ll_session_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_ll_session_draw_latents.argtypes = [C.c_void_p, C.c_int32, C.c_void_p,
                                            C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
@@ -136,7 +139,7 @@ def exported_symbols() -> Sequence[str]:
           "ci_session_algorithmic_bytes", "ci_session_kernel_name", "ci_session_destroy",
           "ci_session_profile", "ci_ll_session_kernel_name",
           "ci_session_summarize", "ci_summarize_draws",
-          "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_eval",
+          "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_create2", "ci_ll_session_eval",
           "ci_ll_session_draw_latents", "ci_ll_session_hmc_run", "ci_ll_session_hmc_fetch",
           "ci_ll_session_algorithmic_bytes", "ci_ll_session_destroy",
           "ci_comm_unique_id", "ci_comm_create", "ci_comm_info", "ci_comm_barrier",
@@ -409,20 +412,27 @@ def kalman_loglik(pb: Problem, params, y, mask, X, theta) -> np.ndarray:
 class LogLikSession:
   """Device-resident log-likelihood / score evaluator and latent-path drawer for one series."""
 
-  def __init__(self, pb: Problem, params, y, mask, X, max_evals: int):
+  def __init__(self, pb: Problem, params, y, mask, X, max_evals: int, season_change=None):
+    """season_change [K, T] uint8 for models with seasonal blocks (pb.num_blocks = K): those, and
+    series longer than 4096 steps, run on the sequential route (csrc/ci_score_seq.h); parameter
+    rows are then (sigma_obs, sigma_level, sigma_slope, sigma_drift[K], weights[P])."""
     self._lib = load()
-    self.T, self.P, self.D = pb.T, pb.P, 2 if pb.has_slope else 1
+    self.T, self.P, self.D, self.K = pb.T, pb.P, 2 if pb.has_slope else 1, pb.num_blocks
+    self.num_seasons = [int(pb.num_seasons[k]) for k in range(pb.num_blocks)]
     self.max_evals = int(max_evals)
     m8 = np.ascontiguousarray(np.asarray(mask, bool).astype(np.uint8))
     y32 = np.ascontiguousarray(np.where(m8 != 0, np.float32(0), np.asarray(y, np.float32)))
     X32 = (np.ascontiguousarray(np.asarray(X, np.float32).reshape(self.T, self.P))
            if self.P > 0 else None)
+    sc = None
+    if self.K > 0:
+      sc = np.ascontiguousarray(np.asarray(season_change, dtype=np.uint8).reshape(self.K, self.T))
     self._h = C.c_void_p()
-    _check(self._lib.ci_ll_session_create(C.byref(pb), params, y32.ctypes.data, m8.ctypes.data,
-                                          _ptr(X32), self.max_evals, C.byref(self._h)))
+    _check(self._lib.ci_ll_session_create2(C.byref(pb), params, y32.ctypes.data, m8.ctypes.data,
+                                           _ptr(X32), _ptr(sc), self.max_evals, C.byref(self._h)))
 
   def evaluate(self, theta, want_grad=True):
-    th = np.ascontiguousarray(np.asarray(theta, np.float64).reshape(-1, 3 + self.P))
+    th = np.ascontiguousarray(np.asarray(theta, np.float64).reshape(-1, 3 + self.K + self.P))
     ll = np.zeros(th.shape[0], np.float64)
     grad = np.zeros_like(th) if want_grad else None
     _check(self._lib.ci_ll_session_eval(self._h, th.shape[0], th.ctypes.data, ll.ctypes.data,
@@ -455,7 +465,7 @@ class LogLikSession:
     o.seed[0], o.seed[1] = seed_pair(seed)
     init = None if init_theta is None else np.ascontiguousarray(init_theta, dtype=np.float64)
     if init is not None:
-      dim = (3 * self.P + 2 if prior == "horseshoe" else self.P) + self.D + 1
+      dim = (3 * self.P + 2 if prior == "horseshoe" else self.P) + self.D + 1 + self.K
       if init.shape != (int(num_chains), dim):
         raise ValueError(f"init_theta must be [{int(num_chains)}, {dim}], got {init.shape}")
     ms = (C.c_float * 2)()
@@ -464,15 +474,17 @@ class LogLikSession:
     return float(ms[0]), float(ms[1])
 
   def hmc_fetch(self, want=None):
-    """Host copies of the finished fit: draws [C, S, 3+P] float64, accept_rate, step_size [C] and
-    the float32 sample container of `fit_gibbs` (leading series axis of 1)."""
+    """Host copies of the finished fit: draws [C, S, 3+K+P] float64 (sigma_obs, sigma_level,
+    sigma_slope, sigma_drift[K], weights), accept_rate, step_size [C] and the float32 sample
+    container of `fit_gibbs` (leading series axis of 1)."""
     Cn, S = self._hmc_shape
-    pb = make_problem(T=self.T, P=self.P, has_slope=self.D == 2, num_warmup=0, num_results=S,
-                      num_chains=Cn)
+    pb = make_problem(T=self.T, P=self.P, has_slope=self.D == 2, num_seasons=self.num_seasons,
+                      num_warmup=0, num_results=S, num_chains=Cn)
     if want is None:
-      want = [f for f in _OUT_FIELDS if f not in ("seasonal_drift_scales", "seasonal_levels")]
+      want = [f for f in _OUT_FIELDS
+              if self.K > 0 or f not in ("seasonal_drift_scales", "seasonal_levels")]
     out, arrs = _alloc_outputs(pb, want)
-    draws = np.zeros((Cn, S, 3 + self.P), np.float64)
+    draws = np.zeros((Cn, S, 3 + self.K + self.P), np.float64)
     acc = np.zeros(Cn, np.float64)
     eps = np.zeros(Cn, np.float64)
     _check(self._lib.ci_ll_session_hmc_fetch(self._h, draws.ctypes.data, acc.ctypes.data,
@@ -483,7 +495,7 @@ class LogLikSession:
     """hmc_run + the parameter draws only: draws [C, S, 3+P], accept_rate, step_size [C]."""
     self.hmc_run(**kw)
     Cn, S = self._hmc_shape
-    draws = np.zeros((Cn, S, 3 + self.P), np.float64)
+    draws = np.zeros((Cn, S, 3 + self.K + self.P), np.float64)
     acc = np.zeros(Cn, np.float64)
     eps = np.zeros(Cn, np.float64)
     _check(self._lib.ci_ll_session_hmc_fetch(self._h, draws.ctypes.data, acc.ctypes.data,

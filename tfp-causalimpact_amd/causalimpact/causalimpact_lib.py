@@ -321,8 +321,6 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
 
   if sampler not in ("gibbs", "hmc"):
     raise ValueError(f"sampler must be 'gibbs' or 'hmc', got {sampler!r}")
-  if sampler == "hmc" and K > 0:
-    raise NotImplementedError("the HMC extension does not support seasonal effects yet")
   devs = list(devices) if devices else [0]
   shares = np.array_split(np.arange(num_chains), len(devs))
   parts = []
@@ -336,7 +334,8 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
                          num_results=num_results, num_warmup=num_warmup_steps,
                          num_chains=len(chain_ids), seed=seed_pair, device=dev,
                          chain_offset=int(chain_ids[0]), init=hmc_init, prior=hmc_prior,
-                         horseshoe_scale=0.1 / cond_s)
+                         horseshoe_scale=0.1 / cond_s, num_seasons=num_seasons,
+                         season_change=season_change)
       return {k: v for k, v in res.items() if not k.startswith("hmc_")}
     pb = _native.make_problem(T=T, P=P, has_slope=local_linear_trend, num_seasons=num_seasons,
                               num_warmup=num_warmup_steps, num_results=num_results,

@@ -21,8 +21,11 @@
 #include "ci_wide.h"
 #include "ci_summary.h"
 #include "ci_hmc.h"
+#include "ci_score_seq.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(int);
+extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs*, int, hipStream_t);
+extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs*, int, hipStream_t);
 #define CI_WIDE_DECL(NS)                                  \
   extern "C" void* ci_gibbs_wide_fn_tr1_ns##NS(void);     \
   extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);
@@ -289,6 +292,55 @@ int steps_per_thread(int T) {
   return 0;
 }
 
+}  // namespace
+
+namespace {
+// Lower Cholesky factor of the prior covariance of x_0 in the (n-1)-effect coordinates:
+// diag(level, [slope]) (+) sd^2 (I - 11'/n) per block   (SURVEY.md Appendix F); row-major [dr, dr].
+std::vector<float> prior_chol_reduced(const ci_problem* pb, const ci_series_params& q, int dr,
+                                      bool inert_blocks) {
+  const int K = pb->num_blocks;
+  std::vector<double> A((size_t)dr * dr, 0.0);
+  A[0] = q.init_level_scale * q.init_level_scale;
+  int o = 1;
+  if (pb->has_slope) { A[(size_t)1 * dr + 1] = q.init_slope_scale * q.init_slope_scale; o = 2; }
+  for (int k = 0; k < K; ++k) {
+    const int n = pb->num_seasons[k];
+    const double v = inert_blocks ? 0.0 : q.init_seasonal_scale * q.init_seasonal_scale;
+    for (int i = 0; i < n - 1; ++i)
+      for (int j = 0; j < n - 1; ++j)
+        A[(size_t)(o + i) * dr + o + j] = v * ((i == j ? 1.0 : 0.0) - 1.0 / n);
+    o += n - 1;
+  }
+  for (int j = 0; j < dr; ++j) {
+    double sdiag = A[(size_t)j * dr + j];
+    for (int k2 = 0; k2 < j; ++k2) sdiag -= A[(size_t)j * dr + k2] * A[(size_t)j * dr + k2];
+    const double ljj = sdiag > 0.0 ? std::sqrt(sdiag) : 0.0;
+    A[(size_t)j * dr + j] = ljj;
+    for (int i = j + 1; i < dr; ++i) {
+      double t2 = A[(size_t)i * dr + j];
+      for (int k2 = 0; k2 < j; ++k2) t2 -= A[(size_t)i * dr + k2] * A[(size_t)j * dr + k2];
+      A[(size_t)i * dr + j] = ljj > 0.0 ? t2 / ljj : 0.0;
+    }
+    for (int i = 0; i < j; ++i) A[(size_t)i * dr + j] = 0.0;
+  }
+  std::vector<float> out(A.size());
+  for (size_t e = 0; e < A.size(); ++e) out[e] = (float)A[e];
+  return out;
+}
+
+ci::DevSeriesParams dev_series_params(const ci_series_params& q, double n_obs) {
+  ci::DevSeriesParams d;
+  d.level_conc = q.level_conc; d.level_scale = q.level_scale; d.level_ub = q.level_ub;
+  d.slope_conc = q.slope_conc; d.slope_scale = q.slope_scale; d.slope_ub = q.slope_ub;
+  d.obs_conc = q.obs_conc; d.obs_scale = q.obs_scale; d.obs_ub = q.obs_ub;
+  d.nonzero_prob = q.nonzero_prob;
+  d.init_level_loc = q.init_level_loc; d.init_level_scale = q.init_level_scale;
+  d.init_slope_scale = q.init_slope_scale;
+  d.obs_scale0 = q.obs_scale0; d.level_scale0 = q.level_scale0; d.slope_scale0 = q.slope_scale0;
+  d.n_obs = n_obs;
+  return d;
+}
 }  // namespace
 
 struct ci_session {
@@ -631,34 +683,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
         ssh[b].drift_conc = 1.0; ssh[b].drift_scale = 1.0; ssh[b].drift_ub = 1.0;
         for (int k = 0; k < CI_MAX_BLOCKS; ++k) ssh[b].drift_scale0[k] = 0.0;
       }
-      // lower Cholesky factor of the prior covariance of x_0 in the (n-1)-effect coordinates:
-      // diag(level, [slope]) (+) sd^2 (I - 11'/n) per block   
-      const int dr = s->dred;
-      std::vector<double> A((size_t)dr * dr, 0.0);
-      A[0] = q.init_level_scale * q.init_level_scale;
-      int o = 1;
-      if (pb->has_slope) { A[(size_t)1 * dr + 1] = q.init_slope_scale * q.init_slope_scale; o = 2; }
-      for (int k = 0; k < K; ++k) {
-        const int n = pb->num_seasons[k];
-        const double v = long_trend ? 0.0 : q.init_seasonal_scale * q.init_seasonal_scale;
-        for (int i = 0; i < n - 1; ++i)
-          for (int j = 0; j < n - 1; ++j)
-            A[(size_t)(o + i) * dr + o + j] = v * ((i == j ? 1.0 : 0.0) - 1.0 / n);
-        o += n - 1;
-      }
-      for (int j = 0; j < dr; ++j) {
-        double sdiag = A[(size_t)j * dr + j];
-        for (int k2 = 0; k2 < j; ++k2) sdiag -= A[(size_t)j * dr + k2] * A[(size_t)j * dr + k2];
-        const double ljj = sdiag > 0.0 ? std::sqrt(sdiag) : 0.0;
-        A[(size_t)j * dr + j] = ljj;
-        for (int i = j + 1; i < dr; ++i) {
-          double t2 = A[(size_t)i * dr + j];
-          for (int k2 = 0; k2 < j; ++k2) t2 -= A[(size_t)i * dr + k2] * A[(size_t)j * dr + k2];
-          A[(size_t)i * dr + j] = ljj > 0.0 ? t2 / ljj : 0.0;
-        }
-        for (int i = 0; i < j; ++i) A[(size_t)i * dr + j] = 0.0;
-      }
-      for (size_t e = 0; e < A.size(); ++e) ch[(size_t)b * dr * dr + e] = (float)A[e];
+      const std::vector<float> cf = prior_chol_reduced(pb, q, s->dred, long_trend);
+      std::copy(cf.begin(), cf.end(), ch.begin() + (size_t)b * s->dred * s->dred);
     }
     HIP_TRY(hipMemcpy(s->ssp.p, ssh.data(), B * sizeof(ci::DevSeasonalParams), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->p1_chol.p, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -678,16 +704,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
         if (!std::isfinite(y[i])) return fail("y[%d,%d] is not finite but unmasked", b, t);
       }
     }
-    const ci_series_params& q = params[b];
-    ci::DevSeriesParams& d = sph[b];
-    d.level_conc = q.level_conc; d.level_scale = q.level_scale; d.level_ub = q.level_ub;
-    d.slope_conc = q.slope_conc; d.slope_scale = q.slope_scale; d.slope_ub = q.slope_ub;
-    d.obs_conc = q.obs_conc; d.obs_scale = q.obs_scale; d.obs_ub = q.obs_ub;
-    d.nonzero_prob = q.nonzero_prob;
-    d.init_level_loc = q.init_level_loc; d.init_level_scale = q.init_level_scale;
-    d.init_slope_scale = q.init_slope_scale;
-    d.obs_scale0 = q.obs_scale0; d.level_scale0 = q.level_scale0; d.slope_scale0 = q.slope_scale0;
-    d.n_obs = nobs;
+    sph[b] = dev_series_params(params[b], nobs);
   }
   HIP_TRY(hipMemcpy(s->y.p, yh.data(), BT * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->mask.p, mask, BT, hipMemcpyHostToDevice));
@@ -1131,7 +1148,18 @@ constexpr int HMC_LATENT_GROUP = 8;
 
 struct ci_ll_session {
   int T = 0, P = 0, D = 1, L = 1, device = 0, max_evals = 0;
-  float a1 = 0, p10 = 0, p11 = 0;
+  float a1 = 0, p10 = 0, p11 = 0, p1e = 0;
+  // seasonal blocks and / or T > 4096: the sequential one-wavefront route (ci_score_seq.h)
+  bool seq = false;
+  int K = 0, D_full = 1, nseas[CI_MAX_BLOCKS] = {0};
+  DevBuf<uint8_t> season_change;
+  DevBuf<float> seq_ws;
+  size_t seq_ws_evals = 0;          // evaluations seq_ws has room for
+  int dred = 1;
+  ci_problem spb;                   // the problem (geometry) for the latent pass
+  DevBuf<ci::DevSeriesParams> d_sp;
+  DevBuf<ci::DevSeasonalParams> d_ssp;
+  DevBuf<float> p1_chol, lat_ws, h_seasonal, h_drift, h_loc;
   DevBuf<float> y, xt, level, slope, loc, traj;
   DevBuf<uint8_t> mask;
   DevBuf<double> theta, ll, grad;
@@ -1152,24 +1180,40 @@ struct LlSessionGuard {
   ~LlSessionGuard() { if (s) ci_ll_session_destroy(s); }
 };
 
+int ci_ll_session_create2(const ci_problem* pb, const ci_series_params* params, const float* y,
+                          const uint8_t* mask, const float* X, const uint8_t* season_change,
+                          int32_t max_evals, ci_ll_session** out);
+
 int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, const float* y,
                          const uint8_t* mask, const float* X, int32_t max_evals,
                          ci_ll_session** out) {
+  if (pb && pb->num_blocks != 0)
+    return fail("ci_ll_session_create: seasonal blocks need ci_ll_session_create2 (season_change)");
+  return ci_ll_session_create2(pb, params, y, mask, X, nullptr, max_evals, out);
+}
+
+int ci_ll_session_create2(const ci_problem* pb, const ci_series_params* params, const float* y,
+                          const uint8_t* mask, const float* X, const uint8_t* season_change,
+                          int32_t max_evals, ci_ll_session** out) {
   if (validate(pb)) return 1;
-  if (pb->num_blocks != 0) return fail("log-likelihood path: seasonal blocks not supported yet");
+  if (pb->num_blocks > 0 && !season_change) return fail("season_change is NULL but num_blocks > 0");
   if (pb->P > ci::MAXP) return fail("log-likelihood path: P must be <= %d, got %d", ci::MAXP, pb->P);
-  if (steps_per_thread(pb->T) == 0)
-    return fail("log-likelihood path: T=%d exceeds the register-resident scans (max %d)", pb->T,
-                ci::NT * 16);
   if (!params || !y || !mask || !out || max_evals < 1) return fail("bad argument");
   if (!(params->weights_prior_scale > 0.0) || !std::isfinite(params->weights_prior_scale))
     return fail("params->weights_prior_scale must be positive and finite (1 = the reference's prior)");
   if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
+  const bool seq = pb->num_blocks > 0 || steps_per_thread(pb->T) == 0;
+  int dfull = pb->has_slope ? 2 : 1;
+  for (int k = 0; k < pb->num_blocks; ++k) dfull += pb->num_seasons[k];
+  if (seq && dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
   HIP_TRY(hipSetDevice(pb->device));
   ci_ll_session* s = new ci_ll_session();
   LlSessionGuard guard{s};
-  s->T = pb->T; s->P = pb->P; s->D = pb->has_slope ? 2 : 1; s->L = steps_per_thread(pb->T);
+  s->T = pb->T; s->P = pb->P; s->D = pb->has_slope ? 2 : 1; s->L = seq ? 0 : steps_per_thread(pb->T);
   s->device = pb->device; s->max_evals = max_evals;
+  s->seq = seq; s->K = pb->num_blocks; s->D_full = dfull;
+  for (int k = 0; k < pb->num_blocks; ++k) s->nseas[k] = pb->num_seasons[k];
+  s->p1e = (float)(params->init_seasonal_scale * params->init_seasonal_scale);
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
@@ -1181,9 +1225,34 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
   HIP_TRY(s->y.alloc(T));
   HIP_TRY(s->mask.alloc(T));
   HIP_TRY(s->xt.alloc((size_t)P * T));
-  HIP_TRY(s->theta.alloc((size_t)max_evals * (3 + P)));
+  const int K = pb->num_blocks;
+  HIP_TRY(s->theta.alloc((size_t)max_evals * (3 + K + P)));
   HIP_TRY(s->ll.alloc(max_evals));
-  HIP_TRY(s->grad.alloc((size_t)max_evals * (3 + P)));
+  HIP_TRY(s->grad.alloc((size_t)max_evals * (3 + K + P)));
+  if (seq) {
+    HIP_TRY(s->seq_ws.alloc((size_t)max_evals * ci::seq_score_ws_floats(T, dfull)));
+    s->seq_ws_evals = (size_t)max_evals;
+    s->spb = *pb;
+    s->dred = dfull - K;
+    double nobs = 0;
+    for (int t = 0; t < T; ++t) nobs += mask[t] ? 0 : 1;
+    const ci::DevSeriesParams dsp = dev_series_params(*params, nobs);
+    ci::DevSeasonalParams dss;
+    dss.drift_conc = params->drift_conc; dss.drift_scale = params->drift_scale;
+    dss.drift_ub = params->drift_ub; dss.init_seasonal_scale = params->init_seasonal_scale;
+    for (int k = 0; k < CI_MAX_BLOCKS; ++k) dss.drift_scale0[k] = params->drift_scale0[k];
+    const std::vector<float> cf = prior_chol_reduced(pb, *params, s->dred, false);
+    HIP_TRY(s->d_sp.alloc(1));
+    HIP_TRY(s->d_ssp.alloc(1));
+    HIP_TRY(s->p1_chol.alloc(cf.size()));
+    HIP_TRY(hipMemcpy(s->d_sp.p, &dsp, sizeof(dsp), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_ssp.p, &dss, sizeof(dss), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->p1_chol.p, cf.data(), cf.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (K > 0) {
+      HIP_TRY(s->season_change.alloc((size_t)K * T));
+      HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
+    }
+  }
   std::vector<float> yh(T);
   for (int t = 0; t < T; ++t) {
     yh[t] = mask[t] ? 0.f : y[t];
@@ -1216,6 +1285,99 @@ int ci_ll_session_create(const ci_problem* pb, const ci_series_params* params, c
   return 0;
 }
 
+// The HMC fit of a session on the sequential route (seasonal blocks and / or T > 4096): the chain
+// (hmc_seq_kernel, one workgroup per chain), then ONE launch of the sequential Gibbs kernel in its
+// latents-only mode: a workgroup (one wavefront) per retained draw.
+static int hmc_run_sequential(ci_ll_session* s, const ci_hmc_options* o, const double* init_theta,
+                              float* kernel_ms) {
+  const int P = s->P, C = o->num_chains, S = o->num_results, T = s->T, K = s->K;
+  const size_t N = (size_t)C * S;
+  const int has_slope = s->D == 2 ? 1 : 0;
+  const int nsc = 2 + has_slope + K;
+  const int dim = (o->prior == CI_HMC_PRIOR_HORSESHOE ? 3 * P + 2 : P) + nsc;
+  if ((size_t)C > s->seq_ws_evals) {
+    s->seq_ws.release();
+    HIP_TRY(s->seq_ws.alloc((size_t)C * ci::seq_score_ws_floats(T, s->D_full)));
+    s->seq_ws_evals = (size_t)C;
+  }
+  if (init_theta) {
+    if (s->h_init.n != (size_t)C * dim) { s->h_init.release(); HIP_TRY(s->h_init.alloc((size_t)C * dim)); }
+    HIP_TRY(hipMemcpyAsync(s->h_init.p, init_theta, (size_t)C * dim * sizeof(double),
+                           hipMemcpyHostToDevice, s->stream));
+  }
+  ci::HmcSeqArgs a;
+  a.q.T = T; a.q.P = P; a.q.K = K; a.q.has_slope = has_slope; a.q.E = C;
+  for (int k = 0; k < ci::SMAXK; ++k) a.q.nseas[k] = k < K ? s->nseas[k] : 0;
+  a.q.y = s->y.p; a.q.mask = s->mask.p; a.q.Xt = s->xt.p; a.q.season_change = s->season_change.p;
+  a.q.theta = nullptr; a.q.a1 = s->a1; a.q.p10 = s->p10; a.q.p11 = s->p11; a.q.p1e = s->p1e;
+  a.q.out_ll = nullptr; a.q.out_grad = nullptr; a.q.ws = s->seq_ws.p;
+  a.C = C; a.W = o->num_warmup; a.S = S; a.n_leap = o->num_leapfrog; a.chain_offset = o->chain_offset;
+  a.prior_mode = o->prior; a.seed0 = o->seed[0]; a.seed1 = o->seed[1];
+  a.omega = s->omega.p;
+  const ci_series_params& q = s->prm;
+  {
+    int n = 0;
+    a.ig_a[n] = q.obs_conc; a.ig_b[n] = q.obs_scale; a.init_log[n++] = std::log(q.obs_scale0);
+    a.ig_a[n] = q.level_conc; a.ig_b[n] = q.level_scale; a.init_log[n++] = std::log(std::max(q.level_scale0, 1e-4));
+    if (has_slope) {
+      a.ig_a[n] = q.slope_conc; a.ig_b[n] = q.slope_scale; a.init_log[n++] = std::log(std::max(q.slope_scale0, 1e-4));
+    }
+    for (int k = 0; k < K; ++k) {
+      a.ig_a[n] = q.drift_conc; a.ig_b[n] = q.drift_scale;
+      a.init_log[n++] = std::log(std::max(q.drift_scale0[k], 1e-4));
+    }
+  }
+  a.hs_scale0 = o->horseshoe_scale; a.target_accept = o->target_accept; a.eps0 = o->initial_step_size;
+  a.init = init_theta ? s->h_init.p : nullptr;
+  a.draws = s->h_draws.p; a.accept_rate = s->h_acc.p; a.step_size = s->h_eps.p;
+  HIP_TRY(hipEventRecord(s->ev0, s->stream));
+  ci_launch_hmc_seq(&a, s->D_full, s->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  // ---- latent path + predictive trajectory of every retained draw
+  const ci::SLayout in_lds = ci::make_slayout(T, P, K, s->D_full, s->dred, has_slope, 0);
+  const bool gws = in_lds.total > 150 * 1024;
+  const ci::SLayout lay = ci::make_slayout(T, P, K, s->D_full, s->dred, has_slope, gws ? 1 : 0);
+  if (lay.total > 160 * 1024) return fail("latent pass needs %zu bytes of LDS (max 163840)", lay.total);
+  const size_t ws_stride = (lay.t_total + 255) & ~(size_t)255;
+  if (gws && s->lat_ws.n < N * (ws_stride / sizeof(float))) {
+    s->lat_ws.release();
+    HIP_TRY(s->lat_ws.alloc(N * (ws_stride / sizeof(float))));
+  }
+  ci::SArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  ci::KArgs& k = sa.k;
+  k.T = T; k.P = P; k.W = 0; k.S = 1; k.C = (int)N; k.B = 1; k.chain_offset = o->chain_offset;
+  k.series_stream_base = -1; k.seed0 = o->seed[0]; k.seed1 = o->seed[1]; k.x_in_lds = 0;
+  k.y = s->y.p; k.mask = s->mask.p; k.Xt = s->xt.p; k.xtx = nullptr; k.omega = nullptr; k.sp = s->d_sp.p;
+  k.out_obs = s->h_obs.p; k.out_level_scale = s->h_lscale.p; k.out_slope_scale = s->h_sscale.p;
+  k.out_weights = s->h_w.p; k.out_level = s->h_level.p; k.out_slope = s->h_slope.p;
+  k.out_pred_mean = s->h_loc.p; k.out_traj = s->h_traj.p; k.prof = nullptr; k.progress = nullptr;
+  k.progress_every = 1;
+  sa.K = K; sa.has_slope = has_slope; sa.dred = s->dred;
+  for (int kk = 0; kk < ci::SMAXK; ++kk) sa.nseas[kk] = kk < K ? s->nseas[kk] : 0;
+  sa.season_change = s->season_change.p; sa.ssp = s->d_ssp.p; sa.p1_chol = s->p1_chol.p;
+  sa.out_drift = s->h_drift.p; sa.out_seasonal = s->h_seasonal.p;
+  sa.ws = s->lat_ws.p; sa.Lc = 0; sa.cluster = 1; sa.ws_stride = gws ? ws_stride : 0;
+  sa.lat_theta = s->h_draws.p; sa.lat_S = S;
+  void* fn = ci_gibbs_seasonal_fn(gws ? 1 : 0);
+  HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+  hipLaunchKernelGGL((void (*)(ci::SArgs))fn, dim3((unsigned)N), dim3(64), lay.total, s->stream, sa);
+  HIP_TRY(hipGetLastError());
+  // per-chain mean of the noise-free predictor over the S draws (hmc_mean_kernel: groups of 1)
+  hipLaunchKernelGGL(ci::hmc_mean_kernel, dim3((T + 255) / 256, C), dim3(256), 0, s->stream, C, S, S, T,
+                     s->h_loc.p, s->h_pm.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev2, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (kernel_ms) {
+    HIP_TRY(hipEventElapsedTime(&kernel_ms[0], s->ev0, s->ev1));
+    HIP_TRY(hipEventElapsedTime(&kernel_ms[1], s->ev1, s->ev2));
+  }
+  s->h_ran = true;
+  return 0;
+}
+
 int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const double* init_theta,
                           float* kernel_ms) {
   if (!s || !o) return fail("NULL argument");
@@ -1236,7 +1398,13 @@ int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const doubl
     s->h_pm.release(); s->h_obs.release(); s->h_lscale.release(); s->h_sscale.release();
     s->h_w.release();
     s->h_C = 0; s->h_S = 0;          // an allocation failing below must not leave a stale shape
-    HIP_TRY(s->h_draws.alloc(N * (3 + P)));
+    HIP_TRY(s->h_draws.alloc(N * (3 + s->K + P)));
+    if (s->seq) {
+      s->h_seasonal.release(); s->h_drift.release(); s->h_loc.release();
+      HIP_TRY(s->h_seasonal.alloc(N * T * s->K));
+      HIP_TRY(s->h_drift.alloc(N * s->K));
+      HIP_TRY(s->h_loc.alloc(N * T));
+    }
     HIP_TRY(s->h_acc.alloc(C));
     HIP_TRY(s->h_eps.alloc(C));
     HIP_TRY(s->h_level.alloc(N * T));
@@ -1251,6 +1419,7 @@ int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const doubl
     s->h_C = C; s->h_S = S;
   }
   s->h_ran = false;
+  if (s->seq) return hmc_run_sequential(s, o, init_theta, kernel_ms);
   const int dim = ci::hmc_dim(P, s->D, o->prior);
   if (init_theta) {
     if (s->h_init.n != (size_t)C * dim) { s->h_init.release(); HIP_TRY(s->h_init.alloc((size_t)C * dim)); }
@@ -1329,6 +1498,8 @@ int ci_ll_session_hmc_fetch(ci_ll_session* s, double* draws, double* accept_rate
     HIP_TRY(get(o->level, s->h_level));
     HIP_TRY(get(o->posterior_means, s->h_pm));
     HIP_TRY(get(o->posterior_trajectories, s->h_traj));
+    HIP_TRY(get(o->seasonal_drift_scales, s->h_drift));
+    HIP_TRY(get(o->seasonal_levels, s->h_seasonal));
     if (o->slope) {
       if (s->D == 2) HIP_TRY(get(o->slope, s->h_slope));
       else memset(o->slope, 0, s->h_level.n * sizeof(float));
@@ -1340,7 +1511,8 @@ int ci_ll_session_hmc_fetch(ci_ll_session* s, double* draws, double* accept_rate
 int ci_ll_session_kernel_name(const ci_ll_session* s, char* buf, int32_t buflen) {
   if (!s) return fail("session is NULL");
   char nm[64];
-  snprintf(nm, sizeof(nm), "ci::hmc_kernel<%d,%d>", s->D, s->L);
+  if (s->seq) snprintf(nm, sizeof(nm), "ci::hmc_seq_kernel");
+  else snprintf(nm, sizeof(nm), "ci::hmc_kernel<%d,%d>", s->D, s->L);
   return copy_name(nm, buf, buflen);
 }
 
@@ -1349,8 +1521,8 @@ int ci_ll_session_algorithmic_bytes(const ci_ll_session* s, double* bytes) {
   if (s->h_C < 1) return fail("no HMC fit has been configured on this session");
   // latent / trajectory draws are produced for every HMC draw, so
   // the per-draw figure is the Gibbs one: 4 T (d_out + 1) + 4 (P + 2 + slope); inputs once per chain.
-  const double T = s->T, P = s->P, slope = s->D == 2 ? 1.0 : 0.0;
-  const double per_draw = 4.0 * T * (1.0 + slope + 1.0) + 4.0 * (P + 2.0 + slope);
+  const double T = s->T, P = s->P, slope = s->D == 2 ? 1.0 : 0.0, K = s->K;
+  const double per_draw = 4.0 * T * (1.0 + slope + K + 1.0) + 4.0 * (P + 2.0 + slope + K);
   const double per_chain = 4.0 * T * (P + 1.0) + T;
   *bytes = (double)s->h_C * ((double)s->h_S * per_draw + per_chain);
   return 0;
@@ -1362,7 +1534,21 @@ int ci_ll_session_eval(ci_ll_session* s, int32_t num_evals, const double* theta,
   if (num_evals < 1 || num_evals > s->max_evals) return fail("num_evals out of range");
   HIP_TRY(hipSetDevice(s->device));
   const int T = s->T, P = s->P, D = s->D, L = s->L, E = num_evals;
-  HIP_TRY(hipMemcpy(s->theta.p, theta, (size_t)E * (3 + P) * sizeof(double), hipMemcpyHostToDevice));
+  const int dimt = 3 + s->K + P;
+  HIP_TRY(hipMemcpy(s->theta.p, theta, (size_t)E * dimt * sizeof(double), hipMemcpyHostToDevice));
+  if (s->seq) {
+    ci::SeqScoreArgs qa;
+    qa.T = T; qa.P = P; qa.K = s->K; qa.has_slope = D == 2 ? 1 : 0; qa.E = E;
+    for (int k = 0; k < ci::SMAXK; ++k) qa.nseas[k] = k < s->K ? s->nseas[k] : 0;
+    qa.y = s->y.p; qa.mask = s->mask.p; qa.Xt = s->xt.p; qa.season_change = s->season_change.p;
+    qa.theta = s->theta.p; qa.a1 = s->a1; qa.p10 = s->p10; qa.p11 = s->p11; qa.p1e = s->p1e;
+    qa.out_ll = s->ll.p; qa.out_grad = grad ? s->grad.p : nullptr; qa.ws = s->seq_ws.p;
+    ci_launch_seq_score(&qa, s->D_full, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(loglik, s->ll.p, E * sizeof(double), hipMemcpyDeviceToHost));
+    if (grad) HIP_TRY(hipMemcpy(grad, s->grad.p, (size_t)E * dimt * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+  }
 #define CI_LL_CASE(DD, LL)                                                                        \
   if (D == DD && L == LL) {                                                                       \
     if (grad)                                                                                     \
@@ -1386,6 +1572,7 @@ int ci_ll_session_draw_latents(ci_ll_session* s, int32_t num_draws, const double
                                const uint32_t seed[2], uint32_t rng_chain, uint32_t iter0,
                                float* level, float* slope, float* loc, float* traj) {
   if (!s || !theta || !seed || !level || !loc || !traj) return fail("NULL argument");
+  if (s->seq) return fail("ci_ll_session_draw_latents: trend models with T <= 4096 only");
   if (num_draws < 1 || num_draws > s->max_evals) return fail("num_draws out of range");
   HIP_TRY(hipSetDevice(s->device));
   const int T = s->T, P = s->P, D = s->D, L = s->L, E = num_draws;
@@ -1420,7 +1607,7 @@ int ci_ll_session_destroy(ci_ll_session* s) {
   if (!s) return 0;
   (void)hipSetDevice(s->device);
   s->y.release(); s->xt.release(); s->mask.release(); s->theta.release(); s->ll.release();
-  s->grad.release(); s->level.release(); s->slope.release(); s->loc.release(); s->traj.release();
+  s->grad.release(); s->season_change.release(); s->seq_ws.release(); s->d_sp.release(); s->d_ssp.release(); s->p1_chol.release(); s->lat_ws.release(); s->h_seasonal.release(); s->h_drift.release(); s->h_loc.release(); s->level.release(); s->slope.release(); s->loc.release(); s->traj.release();
   s->omega.release(); s->h_draws.release(); s->h_acc.release(); s->h_eps.release(); s->h_init.release();
   s->h_level.release(); s->h_slope.release(); s->h_part.release(); s->h_traj.release();
   s->h_pm.release(); s->h_obs.release(); s->h_lscale.release(); s->h_sscale.release();

@@ -52,6 +52,14 @@ struct SArgs {
   double* cv;                        //   [B*C][(P+1)^2] regression matrix swept ahead (presweep_block)
   size_t ws_stride;                  // sequential kernel: bytes of `ws` per chain (arrays over time when
                                      //   they are not in LDS, then the P > MAXP regression block)
+  // Sequential kernel, LATENTS-ONLY mode (the pass after an HMC fit, ci_ll_session_hmc_run): block n
+  // takes its parameters from lat_theta[n] = (sigma_obs, sigma_level, sigma_slope, drift[K],
+  // beta[P]) instead of sampling them, draws ONE latent path (Durbin-Koopman, random stream of
+  // chain chain_offset + n / lat_S, iteration n % lat_S) and emits it with its posterior-
+  // predictive trajectory: what one_step_predictive does with each retained draw
+  // (causalimpact_lib.py:609-632).  Launch with W = 0, S = 1, C = number of draws.
+  const double* lat_theta;           //   NULL = the Gibbs sampler
+  int lat_S;
 };
 
 struct SLayout {
@@ -171,6 +179,14 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
   Rng rng{g.seed0, g.seed1, stream_id(g.chain_offset + chain, g.series_stream_base, series)};
+  const bool lat = a.lat_theta != nullptr;
+  uint32_t itb = 0u;                          // iteration offset of the random stream
+  const double* lth = nullptr;
+  if (lat) {
+    rng.chain = (uint32_t)(g.chain_offset + chain / a.lat_S);
+    itb = (uint32_t)(chain % a.lat_S);
+    lth = a.lat_theta + (size_t)chain * (3 + K + P);
+  }
   const float* Xg = g.Xt + (size_t)series * P * T;
   const float* chol1 = a.p1_chol + (size_t)series * a.dred * a.dred;
 
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       }
     cbv[t] = (uint8_t)bits;
   }
-  if (!bigp)
+  if (!bigp && !lat)
     for (int e = lane; e < P * P; e += 64) {
       R.xtx[e] = g.xtx[(size_t)series * P * P + e];
       R.omega[e] = g.omega[(size_t)series * P * P + e];
@@ -290,9 +306,16 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   auto at4 = [](const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
 
   const int n_iter = g.W + g.S;
+  if (lat) {
+    obs_scale = lth[0]; level_scale = lth[1]; slope_scale = lth[2];
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k) if (k < K) drift[k] = lth[3 + k];
+    for (int j = lane; j < P; j += 64) R.w[j] = (float)lth[3 + K + j];
+    wave_sync();
+  }
   for (int it = 0; it <= n_iter; ++it) {
     // ---- (1) X~'targets, y'y from the current latents
-    {
+    if (!lat) {
       float yty = 0.f;
       for (int t = lane; t < T; t += 64) {
         float tg = 0.f;
@@ -320,7 +343,8 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     // ---- (2) scale draws of iteration it-1, regression draw of iteration it
     double emit_obs = obs_scale;
     if (it > 0) {
-      const uint32_t pit = (uint32_t)(it - 1);
+      const uint32_t pit = (uint32_t)(it - 1) + itb;
+      if (!lat) {
       const double v_l = (double)readlane_f(ssl, 0);
       level_scale = scale_draw(sp.level_conc, sp.level_scale, sp.level_ub, (double)(T - 1), v_l,
                                rng, pit, SITE_LEVEL_SCALE, lane);
@@ -341,6 +365,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       if (P == 0)
         obs_scale = scale_draw(sp.obs_conc, sp.obs_scale, sp.obs_ub, sp.n_obs, R.bvec[P], rng, pit,
                                SITE_OBS_SCALE, lane);
+      }
       emit_obs = obs_scale;
       const int s = it - 1 - g.W;
       if (s >= 0) {
@@ -388,7 +413,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       }
     }
     if (it == n_iter) break;
-    if (P > 0) {
+    if (P > 0 && !lat) {
       const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
       if (P <= 16)
         obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
@@ -408,24 +433,24 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     }
     for (int c = lane; c < (T + 3) / 4; c += 64) {
       float z4[4];
-      normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_LEVEL, 0, (uint32_t)c), z4);
+      normals4(site_call(rng, (uint32_t)it + itb, SITE_PRIOR_LEVEL, 0, (uint32_t)c), z4);
       *reinterpret_cast<float4*>(zl + 4 * c) = make_float4(z4[0], z4[1], z4[2], z4[3]);
-      normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_OBS, 0, (uint32_t)c), z4);
+      normals4(site_call(rng, (uint32_t)it + itb, SITE_PRIOR_OBS, 0, (uint32_t)c), z4);
       *reinterpret_cast<float4*>(zo + 4 * c) = make_float4(z4[0], z4[1], z4[2], z4[3]);
       if (a.has_slope) {
-        normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SLOPE, 0, (uint32_t)c), z4);
+        normals4(site_call(rng, (uint32_t)it + itb, SITE_PRIOR_SLOPE, 0, (uint32_t)c), z4);
         *reinterpret_cast<float4*>(zs + 4 * c) = make_float4(z4[0], z4[1], z4[2], z4[3]);
       }
 #pragma unroll
       for (int k = 0; k < SMAXK; ++k)
         if (k < K) {
-          normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SEAS, (uint32_t)k, (uint32_t)c), z4);
+          normals4(site_call(rng, (uint32_t)it + itb, SITE_PRIOR_SEAS, (uint32_t)k, (uint32_t)c), z4);
           *reinterpret_cast<float4*>(zk + k * TS + 4 * c) = make_float4(z4[0], z4[1], z4[2], z4[3]);
         }
     }
     if (lane < a.dred) {
       float z1[1];
-      fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)lane, z1);
+      fill_normals<1>(rng, (uint32_t)it + itb, SITE_PRIOR_INIT, 0, (uint32_t)lane, z1);
       zi[lane] = z1[0];
     }
     float mydrift = 0.f;

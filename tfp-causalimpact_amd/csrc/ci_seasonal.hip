@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ci_seasonal.h"
+#include "ci_score_seq.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(int which) {
   switch (which) {
@@ -12,4 +13,20 @@ extern "C" void* ci_gibbs_seasonal_fn(int which) {
     case 2: return (void*)(&ci::gibbs_seasonal_kernel<false, true>);
     default: return (void*)(&ci::gibbs_seasonal_kernel<true, true>);
   }
+}
+
+// E sequential log-likelihood / score evaluations (ci_score_seq.h), one wavefront each.
+extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs* args, int D, hipStream_t stream) {
+  const size_t lds = ci::seq_score_lds_bytes(D, args->K);
+  (void)hipFuncSetAttribute((const void*)(&ci::seq_score_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ci::seq_score_kernel, dim3(args->E), dim3(64), lds, stream, *args);
+}
+
+// The HMC fit over the sequential score (ci_score_seq.h): one workgroup per chain.
+extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs* args, int D, hipStream_t stream) {
+  const size_t lds = ci::hmc_seq_lds_bytes(D, args->q.K);
+  (void)hipFuncSetAttribute((const void*)(&ci::hmc_seq_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ci::hmc_seq_kernel, dim3(args->C), dim3(ci::NT), lds, stream, *args);
 }

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
   hdr = open(os.path.join(ROOT, "include", "causalimpact_amd.h")).read()
   hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-  return sorted(set(re.findall(r"\b(ci_[a-z_]+)\s*\(", hdr)))
+  return sorted(set(re.findall(r"\b(ci_[a-z_0-9]+)\s*\(", hdr)))
 
 
 def test_header_and_binding_agree():

@@ -48,7 +48,7 @@ def _worker(rank, world, port, num_chains, q):
 def test_two_ranks_equal_one_process(num_chains):
   """num_chains = 1 leaves rank 1 with an EMPTY block: it must not call the fit (a zero-chain
   problem is invalid) and must still take part in every collective."""
-  import torch.multiprocessing as mp
+  import multiprocessing as mp
   sys.path[:0] = [os.path.join(ROOT, "tfp-causalimpact_amd")]
   from causalimpact import _distributed as d
   single = d.fit_sharded(_fake_fit, num_chains)
@@ -122,7 +122,7 @@ def test_two_ranks_with_real_gpu_shares_equal_one_launch():
   one device under RCCL; bench.py's N > 1 path uses backend "nccl", and its single-rank RCCL run
   is logged in profiles/r02_bench_force_dist_rccl_1rank.*).  The pooled draws must be bit-equal
   to ONE launch of all chains."""
-  import torch.multiprocessing as mp
+  import multiprocessing as mp        # (not torch.multiprocessing: keep torch out of THIS process)
   sys.path[:0] = [os.path.join(ROOT, "tfp-causalimpact_amd")]
   from causalimpact import _distributed as d, _model, _native
   from causalimpact import _synthetic as syn

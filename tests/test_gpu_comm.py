@@ -89,29 +89,45 @@ def test_two_ranks_sharing_gpu0_equal_one_launch(tmp_path, num_chains):
     np.testing.assert_allclose(got["ess"], single["ess_bulk"]["observation_noise_scale"], rtol=1e-9)
 
 
+_RCCL1 = r"""
+import sys
+sys.path[:0] = [%(root)r, %(pkg)r]
+import numpy as np
+from causalimpact import _comm, _model, _native
+from causalimpact import _synthetic as syn
+y, mask, X, _ = syn.make_sampler_inputs(200, 2, 1)
+spec = _model.series_params(y, mask, X, has_slope=False)
+pb = _native.make_problem(T=200, P=3, has_slope=0, num_warmup=5, num_results=30, num_chains=3,
+                          seed=(1, 2), device=0)
+sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+sess.run()
+want = sess.fetch()
+comm = _comm.Comm(0, 1, device=0, transport="rccl", path=%(rdzv)r)
+assert comm.ranks_seen == 1 and comm.world == 1
+comm.barrier()
+np.testing.assert_array_equal(comm.all_reduce([1.5, -2.0]), [1.5, -2.0])
+np.testing.assert_array_equal(comm.all_reduce([1.5, -2.0], _comm.MAX), [1.5, -2.0])
+a = np.arange(12, dtype=np.float64).reshape(3, 4)
+np.testing.assert_array_equal(comm.all_gather(a), a[None])
+for key in ("posterior_trajectories", "level", "weights", "posterior_means",
+            "observation_noise_scale"):
+  np.testing.assert_array_equal(comm.session_all_gather(sess, key), want[key][None], err_msg=key)
+comm.close()
+sess.close()
+assert "torch" not in sys.modules
+print("rccl single rank ok")
+"""
+
+
 def test_rccl_single_rank_gathers_device_resident_arrays(tmp_path):
-  sys.path[:0] = [PKG]
-  from causalimpact import _comm, _model, _native
-  from causalimpact import _synthetic as syn
-  y, mask, X, _ = syn.make_sampler_inputs(200, 2, 1)
-  spec = _model.series_params(y, mask, X, has_slope=False)
-  pb = _native.make_problem(T=200, P=3, has_slope=0, num_warmup=5, num_results=30, num_chains=3,
-                            seed=(1, 2), device=0)
-  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
-  sess.run()
-  want = sess.fetch()
-  comm = _comm.Comm(0, 1, device=0, transport="rccl", path=str(tmp_path / "rdzv"))
-  assert comm.ranks_seen == 1 and comm.world == 1
-  comm.barrier()
-  np.testing.assert_array_equal(comm.all_reduce([1.5, -2.0]), [1.5, -2.0])
-  np.testing.assert_array_equal(comm.all_reduce([1.5, -2.0], _comm.MAX), [1.5, -2.0])
-  a = np.arange(12, dtype=np.float64).reshape(3, 4)
-  np.testing.assert_array_equal(comm.all_gather(a), a[None])
-  for key in ("posterior_trajectories", "level", "weights", "posterior_means",
-              "observation_noise_scale"):
-    np.testing.assert_array_equal(comm.session_all_gather(sess, key), want[key][None], err_msg=key)
-  comm.close()
-  sess.close()
+  """In its own process, as in production: a process that has imported PyTorch carries the ROCm
+  runtime bundled with the torch wheel, and librccl resolved there does not see the devices of
+  the runtime libcausalimpact_amd.so is linked to -- the product path never imports torch."""
+  script = tmp_path / "rccl1.py"
+  script.write_text(_RCCL1 % dict(root=ROOT, pkg=PKG, rdzv=str(tmp_path / "rdzv")))
+  out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+  assert out.returncode == 0, out.stderr[-2000:]
+  assert "rccl single rank ok" in out.stdout
 
 
 _DUP = r"""

@@ -49,21 +49,28 @@ def test_hmc_matches_gibbs_on_quickstart_shape():
   assert hmc.diagnostics["split_rhat"]["observation_noise_scale"] < 1.3
 
 
-def test_hmc_rejects_unsupported_options():
+def test_hmc_options_round_3_supports_and_what_it_still_rejects():
+  """Seasonal models and series longer than 4096 steps used to raise; they now run on the
+  sequential route (csrc/ci_score_seq.h).  Still rejected: a surrogate-posterior start for a
+  seasonal model, and more than 52 design columns on the log-likelihood path."""
   df = rp.create_test_data(5.0, 50, seed=1)
   with pytest.raises(NotImplementedError):
     lib.fit_causalimpact(df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
                          model_options=lib.ModelOptions(seasons=[lib.Seasons(7)]),
-                         inference_options=lib.InferenceOptions(num_results=10, sampler="hmc"))
-  from causalimpact import _native
+                         inference_options=lib.InferenceOptions(num_results=10, sampler="hmc",
+                                                                hmc_init="vi"))
   big = rp.create_test_data(5.0, 4000, num_timesteps=5000, seed=1)
-  with pytest.raises(_native.NativeError, match="exceeds the register-resident scans"):
-    lib.fit_causalimpact(big, (big.index[0], big.index[3999]), (big.index[4000], big.index[-1]),
+  res = lib.fit_causalimpact(big, (big.index[0], big.index[3999]), (big.index[4000], big.index[-1]),
+                             inference_options=lib.InferenceOptions(num_results=8, num_warmup_steps=8,
+                                                                    sampler="hmc"))
+  assert res.posterior_samples.level.shape == (8, 5000)
+  assert np.isfinite(res.summary.to_numpy(float)).all()
+  from causalimpact import _native
+  rng = np.random.default_rng(0)
+  wide = pd.DataFrame(rng.normal(size=(120, 61)), columns=["y"] + [f"x{j}" for j in range(60)])
+  with pytest.raises(_native.NativeError, match="P must be <= 52"):
+    lib.fit_causalimpact(wide, (0, 79), (80, 119),
                          inference_options=lib.InferenceOptions(num_results=10, sampler="hmc"))
-  with pytest.raises(ValueError, match="sampler must be"):
-    lib.fit_causalimpact(df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
-                         inference_options=lib.InferenceOptions(num_results=10, sampler="nuts"))
-
 
 def test_device_hmc_agrees_with_host_driven_hmc_and_splits_like_gibbs():
   """The on-device chain (csrc/ci_hmc.h) against the numpy-driven sampler it replaced (same

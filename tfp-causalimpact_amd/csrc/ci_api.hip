@@ -762,6 +762,7 @@ static int session_launch(ci_session* s) {
   const ci_problem& kpb = s->kpb;
   if (kpb.num_blocks > 0 || kpb.P > ci::MAXP) {
     ci::SArgs sa;
+    memset(&sa, 0, sizeof(sa));       // (lat_theta = NULL: the Gibbs sampler, not the latents-only mode)
     sa.k = a;
     sa.K = kpb.num_blocks; sa.has_slope = kpb.has_slope; sa.dred = s->dred;
     for (int k = 0; k < ci::SMAXK; ++k) sa.nseas[k] = k < kpb.num_blocks ? kpb.num_seasons[k] : 0;

@@ -148,6 +148,28 @@ int ci_fit_gibbs(const ci_problem* problem, const float* y, const uint8_t* mask,
                  const uint8_t* season_change, const ci_series_params* params,
                  ci_outputs* outputs);
 
+/* The same fit computed in FLOAT64 throughout (DataOptions.dtype = float64: the reference runs its
+ * sampler in the requested dtype, causalimpact_lib.py:159; its numeric pin covers float32 and
+ * float64, causalimpact_lib_test.py:655-662).  y, X and every result array are float64; any model
+ * the float32 entry point takes (seasonal blocks, P up to 512, any T).  Runs on the sequential
+ * one-wavefront kernel (csrc/ci_gibbs64.h): the precision option, not the fast one.  Same random
+ * stream as ci_fit_gibbs: the two agree draw for draw to float32 round-off. */
+typedef struct ci_outputs_f64 {
+  double* observation_noise_scale;  /* [B,C,S]   */
+  double* level_scale;              /* [B,C,S]   */
+  double* slope_scale;              /* [B,C,S]   */
+  double* seasonal_drift_scales;    /* [B,C,S,K] */
+  double* weights;                  /* [B,C,S,P] */
+  double* level;                    /* [B,C,S,T] */
+  double* slope;                    /* [B,C,S,T] */
+  double* seasonal_levels;          /* [B,C,S,T,K] */
+  double* posterior_means;          /* [B,C,T]   */
+  double* posterior_trajectories;   /* [B,C,S,T] */
+} ci_outputs_f64;
+int ci_fit_gibbs_f64(const ci_problem* problem, const double* y, const uint8_t* mask,
+                     const double* X, const uint8_t* season_change,
+                     const ci_series_params* params, ci_outputs_f64* outputs);
+
 /* Device-resident variant (what bench.py times: inputs already in HBM). */
 int ci_session_create(const ci_problem* problem, const float* y, const uint8_t* mask,
                       const float* X, const uint8_t* season_change,

@@ -83,6 +83,8 @@ def load():
   L.ci_device_synchronize.argtypes = [C.c_int]
   L.ci_fit_gibbs.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.POINTER(SeriesParams), C.POINTER(Outputs)]
+  L.ci_fit_gibbs_f64.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(SeriesParams), C.POINTER(Outputs)]
   L.ci_session_create.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(SeriesParams), C.POINTER(C.c_void_p)]
   L.ci_session_run.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -134,7 +136,7 @@ def load():
 def exported_symbols() -> Sequence[str]:
   """Every entry point include/causalimpact_amd.h declares."""
   return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_device_synchronize", "ci_pool_trim", "ci_host_alloc",
-          "ci_host_free", "ci_fit_gibbs",
+          "ci_host_free", "ci_fit_gibbs", "ci_fit_gibbs_f64",
           "ci_session_create", "ci_session_run", "ci_session_run_streamed", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_kernel_name", "ci_session_destroy",
           "ci_session_profile", "ci_ll_session_kernel_name",
@@ -308,6 +310,27 @@ def fit_gibbs(pb: Problem, y, mask, X, season_change, params, want=None) -> Dict
   out, arrs = _alloc_outputs(pb, want)
   _check(L.ci_fit_gibbs(C.byref(pb), _ptr(y32), _ptr(mask8), _ptr(X32), _ptr(sc), params,
                         C.byref(out)))
+  return arrs
+
+
+def fit_gibbs_f64(pb: Problem, y, mask, X, season_change, params, want=None) -> Dict[str, np.ndarray]:
+  """The float64 fit (ci_fit_gibbs_f64): every input and result array float64, any model."""
+  L = load()
+  B, T, P, K = pb.num_series, pb.T, pb.P, pb.num_blocks
+  mask8 = np.ascontiguousarray(np.asarray(mask, dtype=bool).reshape(B, T).astype(np.uint8))
+  y64 = np.ascontiguousarray(np.where(mask8 != 0, 0.0, np.asarray(y, np.float64).reshape(B, T)))
+  X64 = np.ascontiguousarray(np.asarray(X, np.float64).reshape(B, T, P)) if P > 0 else None
+  sc = (np.ascontiguousarray(np.asarray(season_change, dtype=np.uint8).reshape(K, T))
+        if K > 0 else None)
+  out, arrs = Outputs(), {}
+  for name, shp in output_shapes(pb).items():
+    if want is not None and name not in want:
+      continue
+    a = np.zeros(shp, dtype=np.float64)
+    arrs[name] = a
+    setattr(out, name, a.ctypes.data if a.size else None)
+  _check(L.ci_fit_gibbs_f64(C.byref(pb), _ptr(y64), _ptr(mask8), _ptr(X64), _ptr(sc), params,
+                            C.byref(out)))
   return arrs
 
 

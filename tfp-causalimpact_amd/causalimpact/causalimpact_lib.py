@@ -288,13 +288,13 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
     raise NotImplementedError("custom tfp.sts models are not supported by the HIP path")
   seed_pair = _sanitize_seed(seed)
   np_dtype = cid._as_numpy_dtype(dtype)  # pylint: disable=protected-access
-  # dtype (reference :159: the sampler runs in DataOptions.dtype).  The device kernels compute in
-  # float32 (float64 in the regression block) on an INTERNALLY CONDITIONED copy of the outcome --
-  # see `_internal_conditioning` below: an exact reparametrisation of the model that keeps every
-  # quantity the float32 scans touch O(1) whatever the scale / offset of the raw series, mapped
-  # back in float64.  dtype=float64 therefore returns float64 arrays whose data-scale arithmetic
-  # (offsets, scales, summaries) is float64; the chain itself has float32 round-off (same-chain
-  # drift vs the float64 oracle < 1e-5 relative over a full fit).
+  # dtype (reference :159: the sampler runs in DataOptions.dtype).  float32 (the default): the
+  # latency / time-parallel kernels, on an INTERNALLY CONDITIONED copy of a raw-scale outcome (see
+  # `_internal_conditioning`: an exact reparametrisation that keeps every quantity the float32
+  # scans touch O(1), mapped back in float64).  float64: the Gibbs sampler runs in float64 on the
+  # sequential one-wavefront kernel (csrc/ci_gibbs64.h; draw for draw equal to the float64 oracle
+  # to ~1e-9, tests/test_gpu_float64.py); slower -- it is the precision option.  The HMC
+  # extension computes in float32 for either dtype.
   design = None if ci_data.feature_ts is None else np.asarray(ci_data.feature_ts.values,
                                                               dtype=np.float64)    # :545-546
   # Post-period handled as missing observations: forecasting == sampling (:548-562).
@@ -341,6 +341,10 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
                               num_warmup=num_warmup_steps, num_results=num_results,
                               num_chains=len(chain_ids), chain_offset=int(chain_ids[0]),
                               seed=seed_pair, device=dev, flags=int(kernel_flags))
+    if np_dtype == np.float64:
+      # float64 compute (csrc/ci_gibbs64.h): the sequential kernel, every buffer float64
+      return _native.fit_gibbs_f64(pb, y[None], mask[None], None if design is None else design[None],
+                                   season_change, _native.make_params([params]))
     if summary_request is not None and len(devs) == 1:
       sess = _native.Session(pb, y[None], mask[None], None if design is None else design[None],
                              season_change, _native.make_params([params]))

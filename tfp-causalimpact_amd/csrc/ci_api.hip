@@ -22,10 +22,12 @@
 #include "ci_summary.h"
 #include "ci_hmc.h"
 #include "ci_score_seq.h"
+#include "ci_gibbs64.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(int);
 extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs*, int, hipStream_t);
 extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs*, int, hipStream_t);
+extern "C" void ci_launch_gibbs64(const ci::G64Args*, int, size_t, hipStream_t);
 #define CI_WIDE_DECL(NS)                                  \
   extern "C" void* ci_gibbs_wide_fn_tr1_ns##NS(void);     \
   extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);
@@ -62,14 +64,15 @@ namespace ci {
 // One workgroup per series; thread (i, j) streams over T (coalesced over the
 // feature-major copy).
 // ------------------------------------------------------------------------------------
-static __global__ void setup_regression_kernel(int T, int P, const float* Xt, const uint8_t* mask,
+template <class XT>
+static __global__ void setup_regression_kernel(int T, int P, const XT* Xt, const uint8_t* mask,
                                         const double* __restrict__ prior_scale, double* xtx,
                                         double* omega) {
   // one wavefront per (series, i, j): lanes stride over time (both rows coalesced), float64 sums
   const int e = blockIdx.x % (P * P), series = blockIdx.x / (P * P);
   const int i = e / P, j = e % P, lane = threadIdx.x;
-  const float* xi = Xt + ((size_t)series * P + i) * T;
-  const float* xj = Xt + ((size_t)series * P + j) * T;
+  const XT* xi = Xt + ((size_t)series * P + i) * T;
+  const XT* xj = Xt + ((size_t)series * P + j) * T;
   const uint8_t* m = mask + (size_t)series * T;
   double so = 0.0, sa = 0.0;
   for (int t = lane; t < T; t += 64) {
@@ -297,8 +300,8 @@ int steps_per_thread(int T) {
 namespace {
 // Lower Cholesky factor of the prior covariance of x_0 in the (n-1)-effect coordinates:
 // diag(level, [slope]) (+) sd^2 (I - 11'/n) per block   (SURVEY.md Appendix F); row-major [dr, dr].
-std::vector<float> prior_chol_reduced(const ci_problem* pb, const ci_series_params& q, int dr,
-                                      bool inert_blocks) {
+std::vector<double> prior_chol_reduced_d(const ci_problem* pb, const ci_series_params& q, int dr,
+                                         bool inert_blocks) {
   const int K = pb->num_blocks;
   std::vector<double> A((size_t)dr * dr, 0.0);
   A[0] = q.init_level_scale * q.init_level_scale;
@@ -324,6 +327,11 @@ std::vector<float> prior_chol_reduced(const ci_problem* pb, const ci_series_para
     }
     for (int i = 0; i < j; ++i) A[(size_t)i * dr + j] = 0.0;
   }
+  return A;
+}
+std::vector<float> prior_chol_reduced(const ci_problem* pb, const ci_series_params& q, int dr,
+                                      bool inert_blocks) {
+  const std::vector<double> A = prior_chol_reduced_d(pb, q, dr, inert_blocks);
   std::vector<float> out(A.size());
   for (size_t e = 0; e < A.size(); ++e) out[e] = (float)A[e];
   return out;
@@ -754,7 +762,7 @@ static int session_launch(ci_session* s) {
     a.prof = s->prof.p;
   }
   if (pb.P > 0) {
-    hipLaunchKernelGGL(ci::setup_regression_kernel, dim3(pb.num_series * pb.P * pb.P), dim3(64), 0,
+    hipLaunchKernelGGL(ci::setup_regression_kernel<float>, dim3(pb.num_series * pb.P * pb.P), dim3(64), 0,
                        s->stream, pb.T, pb.P, s->Xt.p, s->mask.p, s->wps.p, s->xtx.p, s->omega.p);
     HIP_TRY(hipGetLastError());
   }
@@ -1121,6 +1129,136 @@ int ci_fit_gibbs(const ci_problem* pb, const float* y, const uint8_t* mask, cons
   if (!rc) rc = ci_session_fetch(s, outputs);
   ci_session_destroy(s);
   return rc;
+}
+
+// ---- the float64 fit (ci_gibbs64.h): standalone, every buffer float64 -------------------------
+int ci_fit_gibbs_f64(const ci_problem* pb, const double* y, const uint8_t* mask, const double* X,
+                     const uint8_t* season_change, const ci_series_params* params,
+                     ci_outputs_f64* o) {
+  if (validate(pb)) return 1;
+  if (!y || !mask || !params || !o) return fail("NULL argument");
+  if (pb->num_blocks > 0 && !season_change) return fail("season_change is NULL but num_blocks > 0");
+  if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
+  const int T = pb->T, P = pb->P, B = pb->num_series, C = pb->num_chains, S = pb->num_results;
+  const int K = pb->num_blocks, has_slope = pb->has_slope ? 1 : 0;
+  int dfull = has_slope ? 2 : 1, dred = dfull;
+  for (int k = 0; k < K; ++k) { dfull += pb->num_seasons[k]; dred += pb->num_seasons[k] - 1; }
+  if (dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
+  HIP_TRY(hipSetDevice(pb->device));
+  const ci::Layout64 lay = ci::make_layout64(T, P, K, dfull, dred, has_slope);
+  if (lay.total > 160 * 1024) return fail("float64 fit needs %zu bytes of LDS (max 163840)", lay.total);
+  const size_t ws_stride = ci::gibbs64_ws_bytes(T, P, K, dfull, dred, has_slope);
+  const size_t BT = (size_t)B * T, BCS = (size_t)B * C * S;
+  DevBuf<double> d_y, d_xt, d_xtx, d_om, d_wps, d_chol, o_obs, o_ls, o_ss, o_dr, o_w, o_lev, o_slp, o_sea,
+      o_pm, o_tr;
+  DevBuf<uint8_t> d_mask, d_sc, d_ws;
+  DevBuf<ci::DevSeriesParams> d_sp;
+  DevBuf<ci::DevSeasonalParams> d_ssp;
+  auto cleanup = [&]() {
+    d_y.release(); d_xt.release(); d_xtx.release(); d_om.release(); d_wps.release(); d_chol.release();
+    o_obs.release(); o_ls.release(); o_ss.release(); o_dr.release(); o_w.release(); o_lev.release();
+    o_slp.release(); o_sea.release(); o_pm.release(); o_tr.release(); d_mask.release(); d_sc.release();
+    d_ws.release(); d_sp.release(); d_ssp.release();
+  };
+#define CI_TRY64(expr)                                                                       \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      cleanup();                                                                             \
+      return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                        \
+  } while (0)
+  CI_TRY64(d_y.alloc(BT)); CI_TRY64(d_mask.alloc(BT)); CI_TRY64(d_xt.alloc((size_t)B * P * T));
+  CI_TRY64(d_xtx.alloc((size_t)B * P * P)); CI_TRY64(d_om.alloc((size_t)B * P * P));
+  CI_TRY64(d_wps.alloc(B)); CI_TRY64(d_sp.alloc(B)); CI_TRY64(d_ssp.alloc(B));
+  CI_TRY64(d_chol.alloc((size_t)B * dred * dred)); CI_TRY64(d_sc.alloc((size_t)K * T));
+  CI_TRY64(d_ws.alloc((size_t)B * C * ws_stride));
+  CI_TRY64(o_obs.alloc(BCS)); CI_TRY64(o_ls.alloc(BCS)); CI_TRY64(o_ss.alloc(BCS));
+  CI_TRY64(o_dr.alloc(BCS * K)); CI_TRY64(o_w.alloc(BCS * P)); CI_TRY64(o_lev.alloc(BCS * T));
+  CI_TRY64(o_slp.alloc(has_slope ? BCS * T : 0)); CI_TRY64(o_sea.alloc(BCS * T * K));
+  CI_TRY64(o_pm.alloc((size_t)B * C * T)); CI_TRY64(o_tr.alloc(BCS * T));
+  {
+    std::vector<double> yh(BT), wps(B), ch((size_t)B * dred * dred);
+    std::vector<ci::DevSeriesParams> sph(B);
+    std::vector<ci::DevSeasonalParams> ssh(B);
+    for (int b = 0; b < B; ++b) {
+      double nobs = 0;
+      for (int t = 0; t < T; ++t) {
+        const size_t i = (size_t)b * T + t;
+        const bool m = mask[i] != 0;
+        yh[i] = m ? 0.0 : y[i];
+        if (!m) {
+          nobs += 1;
+          if (!std::isfinite(y[i])) { cleanup(); return fail("y[%d,%d] is not finite but unmasked", b, t); }
+        }
+      }
+      const ci_series_params& q = params[b];
+      if (!(q.weights_prior_scale > 0.0) || !std::isfinite(q.weights_prior_scale)) {
+        cleanup();
+        return fail("params[%d].weights_prior_scale must be positive and finite", b);
+      }
+      wps[b] = q.weights_prior_scale;
+      sph[b] = dev_series_params(q, nobs);
+      ssh[b].drift_conc = q.drift_conc; ssh[b].drift_scale = q.drift_scale; ssh[b].drift_ub = q.drift_ub;
+      ssh[b].init_seasonal_scale = q.init_seasonal_scale;
+      for (int k = 0; k < CI_MAX_BLOCKS; ++k) ssh[b].drift_scale0[k] = q.drift_scale0[k];
+      const std::vector<double> cf = prior_chol_reduced_d(pb, q, dred, false);
+      std::copy(cf.begin(), cf.end(), ch.begin() + (size_t)b * dred * dred);
+    }
+    CI_TRY64(hipMemcpy(d_y.p, yh.data(), BT * sizeof(double), hipMemcpyHostToDevice));
+    CI_TRY64(hipMemcpy(d_mask.p, mask, BT, hipMemcpyHostToDevice));
+    CI_TRY64(hipMemcpy(d_wps.p, wps.data(), B * sizeof(double), hipMemcpyHostToDevice));
+    CI_TRY64(hipMemcpy(d_sp.p, sph.data(), B * sizeof(ci::DevSeriesParams), hipMemcpyHostToDevice));
+    CI_TRY64(hipMemcpy(d_ssp.p, ssh.data(), B * sizeof(ci::DevSeasonalParams), hipMemcpyHostToDevice));
+    CI_TRY64(hipMemcpy(d_chol.p, ch.data(), ch.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (K > 0) CI_TRY64(hipMemcpy(d_sc.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
+    if (P > 0) {
+      std::vector<double> xt((size_t)B * P * T);
+      for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t)
+          for (int j = 0; j < P; ++j)
+            xt[((size_t)b * P + j) * T + t] = X[((size_t)b * T + t) * P + j];
+      CI_TRY64(hipMemcpy(d_xt.p, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(ci::setup_regression_kernel<double>, dim3(B * P * P), dim3(64), 0, 0, T, P,
+                         d_xt.p, d_mask.p, d_wps.p, d_xtx.p, d_om.p);
+      CI_TRY64(hipGetLastError());
+    }
+  }
+  ci::G64Args a;
+  memset(&a, 0, sizeof(a));
+  a.k.T = T; a.k.P = P; a.k.W = pb->num_warmup; a.k.S = S; a.k.C = C; a.k.B = B;
+  a.k.chain_offset = pb->chain_offset;
+  a.k.series_stream_base = (pb->flags & CI_FLAG_SHARED_SERIES_STREAMS) ? -1 : pb->series_offset;
+  a.k.seed0 = pb->seed[0]; a.k.seed1 = pb->seed[1];
+  a.k.y = d_y.p; a.k.mask = d_mask.p; a.k.Xt = d_xt.p; a.k.xtx = d_xtx.p; a.k.omega = d_om.p;
+  a.k.sp = d_sp.p;
+  a.k.out_obs = o_obs.p; a.k.out_level_scale = o_ls.p; a.k.out_slope_scale = o_ss.p;
+  a.k.out_weights = o_w.p; a.k.out_level = o_lev.p; a.k.out_slope = o_slp.p;
+  a.k.out_pred_mean = o_pm.p; a.k.out_traj = o_tr.p; a.k.prof = nullptr;
+  a.K = K; a.has_slope = has_slope; a.dred = dred;
+  for (int k = 0; k < ci::SMAXK; ++k) a.nseas[k] = k < K ? pb->num_seasons[k] : 0;
+  a.season_change = d_sc.p; a.ssp = d_ssp.p; a.p1_chol = d_chol.p;
+  a.out_drift = o_dr.p; a.out_seasonal = o_sea.p;
+  a.ws = d_ws.p; a.ws_stride = ws_stride; a.lat_theta = nullptr; a.lat_S = 1;
+  ci_launch_gibbs64(&a, B * C, lay.total, 0);
+  CI_TRY64(hipGetLastError());
+  CI_TRY64(hipDeviceSynchronize());
+  auto get = [&](double* dst, const DevBuf<double>& src) -> hipError_t {
+    if (!dst || src.n == 0) return hipSuccess;
+    return hipMemcpy(dst, src.p, src.n * sizeof(double), hipMemcpyDeviceToHost);
+  };
+  CI_TRY64(get(o->observation_noise_scale, o_obs)); CI_TRY64(get(o->level_scale, o_ls));
+  CI_TRY64(get(o->slope_scale, o_ss)); CI_TRY64(get(o->seasonal_drift_scales, o_dr));
+  CI_TRY64(get(o->weights, o_w)); CI_TRY64(get(o->level, o_lev));
+  CI_TRY64(get(o->seasonal_levels, o_sea)); CI_TRY64(get(o->posterior_means, o_pm));
+  CI_TRY64(get(o->posterior_trajectories, o_tr));
+  if (o->slope) {
+    if (has_slope) CI_TRY64(get(o->slope, o_slp));
+    else memset(o->slope, 0, BCS * T * sizeof(double));
+  }
+#undef CI_TRY64
+  cleanup();
+  return 0;
 }
 
 int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t iter, uint32_t site,

@@ -1,0 +1,731 @@
+// ci_gibbs64.h -- the Gibbs sampler computed in FLOAT64 (DataOptions.dtype = float64).
+//
+// The reference runs its whole sampler in the requested dtype (causalimpact_lib.py:159) and its
+// numeric pin runs float32 AND float64 (causalimpact_lib_test.py:655-662).  The register-resident
+// and time-parallel kernels are float32 designs; this is the float64 build of the SEQUENTIAL
+// one-wavefront kernel (ci_seasonal.h -- same passes, same lane layout, same random stream, any
+// model: trend, optional slope, any list of seasonal blocks, any number of covariates, any length),
+// with every quantity float64:
+//   * arrays over time and the regression block's O(P^2) arrays in a per-chain HBM workspace;
+//   * Box-Muller normals, Marsaglia-Tsang gammas, logs and square roots in float64 (the float32
+//     kernels use hardware float32 transcendentals in places where 1e-7 does not matter);
+//   * the regression draw of spike_slab_draw_big (dense float64 sweeps) for every P.
+// Consequence: the device and the float64 oracle (oracle/ci_oracle.c) run the same arithmetic up
+// to summation order, so they agree draw for draw to ~1e-9 over whole fits
+// (tests/test_gpu_float64.py) -- a far tighter pin of the device algorithm than the float32
+// kernels' 5e-3.  It is the precision option, not the fast one (sequential in time).
+#pragma once
+#include "ci_seasonal.h"
+#include "ci_hmc.h"       // wave_sum_d
+
+namespace ci {
+
+struct K64 {
+  int T, P, W, S, C, B, chain_offset, series_stream_base;
+  uint32_t seed0, seed1;
+  const double* y;          // [B,T]   0 where masked
+  const uint8_t* mask;      // [B,T]
+  const double* Xt;         // [B,P,T] feature-major
+  const double* xtx;        // [B,P,P]
+  const double* omega;      // [B,P,P]
+  const DevSeriesParams* sp;
+  double *out_obs, *out_level_scale, *out_slope_scale, *out_weights, *out_level, *out_slope,
+      *out_pred_mean, *out_traj;
+  long long* prof;
+};
+struct G64Args {
+  K64 k;
+  int K, has_slope, dred;
+  int nseas[SMAXK];
+  const uint8_t* season_change;      // [K,T]
+  const DevSeasonalParams* ssp;      // [B]
+  const double* p1_chol;             // [B,dred,dred]
+  double* out_drift;                 // [B,C,S,K]
+  double* out_seasonal;              // [B,C,S,T,K]
+  unsigned char* ws;                 // [B*C, ws_stride] bytes
+  size_t ws_stride;
+  const double* lat_theta;           // latents-only mode (see SArgs); NULL = sample
+  int lat_S;
+};
+
+struct Layout64 {
+  // per-chain HBM workspace (arrays over time), bytes
+  size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, mask, cbits, t_total;
+  // LDS
+  size_t Pa, Pb, pzv, zi, x0r, egg, emeta, d2, bvec, w, total;
+};
+__host__ __device__ inline Layout64 make_layout64(int T, int P, int K, int D, int dred, int has_slope) {
+  Layout64 l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 31) & ~(size_t)31; return r; };
+  const size_t TS = (size_t)((T + 3) & ~3);
+  const size_t Td = sizeof(double) * TS;
+  const int Pp = P > 0 ? P : 1, Kp = K > 0 ? K : 1;
+  l.Pa = take(sizeof(double) * D * D); l.Pb = take(sizeof(double) * D * D);
+  l.pzv = take(sizeof(double) * D); l.zi = take(sizeof(double) * (dred + 1));
+  l.x0r = take(sizeof(double) * (dred + 1));
+  l.egg = take(sizeof(double) * D * D);
+  l.emeta = take(sizeof(uint32_t) * D * D);
+  l.d2 = take(sizeof(double) * SMAXK);
+  l.bvec = take(sizeof(double) * (Pp + 4));
+  l.w = take(sizeof(double) * (Pp > 16 ? Pp : 16));
+  l.total = o;
+  o = 0;
+  l.yv = take(Td); l.lev = take(Td); l.slp = take(has_slope ? Td : 32); l.xw = take(Td);
+  l.ytil = take(Td); l.vf = take(Td); l.zl = take(Td); l.zs = take(has_slope ? Td : 32);
+  l.zo = take(Td);
+  l.seas = take(Td * Kp); l.zk = take(Td * Kp); l.gd = take(Td * Kp);
+  l.kf = take(sizeof(double) * (size_t)T * D); l.rs = take(sizeof(double) * (size_t)T * D);
+  l.mask = take(TS); l.cbits = take(TS);
+  l.t_total = o;
+  return l;
+}
+__host__ __device__ inline size_t gibbs64_ws_bytes(int T, int P, int K, int D, int dred, int has_slope) {
+  const Layout64 l = make_layout64(T, P, K, D, dred, has_slope);
+  return ((l.t_total + 255) & ~(size_t)255) + bigp_workspace_bytes(P > 0 ? P : 1);
+}
+
+// ---- float64 random variates of the specified stream (the oracle's formulas)
+__device__ __forceinline__ void normals4(const U4& r, double z[4]) {
+  box_muller_d(r.x, r.y, z[0], z[1]);
+  box_muller_d(r.z, r.w, z[2], z[3]);
+}
+// Gamma(alpha, 1), Marsaglia-Tsang, attempt k = Philox call k of the site (ci_oracle_gamma): the 64
+// lanes evaluate attempts 0..63 at once, the first accepted one wins.
+static __device__ __noinline__ double gamma_wave_d(double alpha, const Rng& g, uint32_t iter,
+                                                   uint32_t site, uint32_t sub, int lane) {
+  const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
+  const double d = a - 1.0 / 3.0;
+  const double c = 1.0 / sqrt(9.0 * d);
+  const U4 r = site_call(g, iter, site, sub, (uint32_t)lane);
+  double x, unused;
+  box_muller_d(r.x, r.y, x, unused);
+  const double t = 1.0 + c * x;
+  const double v = t * t * t;
+  bool ok = false;
+  double gval = d;
+  if (v > 0.0) {
+    ok = log(u01d(r.z)) < 0.5 * x * x + d - d * v + d * log(v);
+    gval = d * v;
+    if (alpha < 1.0) gval *= pow(u01d(r.w), 1.0 / alpha);
+  }
+  const unsigned long long m = __ballot(ok);
+  if (m == 0ull) return d;
+  return readlane_d(gval, __ffsll((long long)m) - 1);
+}
+__device__ __forceinline__ double scale_draw_d(double conc, double scale, double ub, double n,
+                                               double ss, const Rng& rng, uint32_t iter,
+                                               uint32_t site, int lane) {
+  const double g = gamma_wave_d(conc + 0.5 * n, rng, iter, site, 0, lane);
+  const double s = sqrt((scale + 0.5 * ss) / g);
+  return s < ub ? s : ub;
+}
+
+#ifndef CI_SEASONAL_DECL_ONLY
+__global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
+  extern __shared__ __attribute__((aligned(32))) unsigned char smem64[];
+  unsigned char* smem = smem64;
+  const int lane = threadIdx.x;
+  const K64& g = a.k;
+  const int T = g.T, P = g.P, K = a.K;
+  const int series = blockIdx.x / g.C, chain = blockIdx.x % g.C;
+  const size_t chain_lin = (size_t)series * g.C + chain;
+  const int trend = a.has_slope ? 2 : 1;
+  // block geometry in registers: every loop over blocks is fully unrolled with static indices
+  int off[SMAXK], nsz[SMAXK], roff[SMAXK];
+  int D = trend;
+  {
+    int rr = trend;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k) {
+      off[k] = D; roff[k] = rr; nsz[k] = (k < K) ? a.nseas[k] : 0;
+      if (k < K) { D += nsz[k]; rr += nsz[k] - 1; }
+    }
+  }
+  const Layout64 L = make_layout64(T, P, K, D, a.dred, a.has_slope);
+  // the arrays over time: LDS, or (GWS) this chain's slice of the HBM workspace -- every access
+  // below is either one 16-byte row per 4 steps or lane-contiguous, and a chain only ever reads
+  // what it wrote, so the slice stays in this XCD's L2
+  unsigned char* wsc = a.ws + chain_lin * a.ws_stride;        // this chain's slice of the workspace
+  unsigned char* tb_ = wsc;                                    // arrays over time: always in HBM
+  double* yv = (double*)(tb_ + L.yv); double* lev = (double*)(tb_ + L.lev);
+  double* slp = (double*)(tb_ + L.slp); double* xw = (double*)(tb_ + L.xw);
+  double* ytil = (double*)(tb_ + L.ytil); double* vf = (double*)(tb_ + L.vf);
+  double* zl = (double*)(tb_ + L.zl); double* zs = (double*)(tb_ + L.zs);
+  double* zo = (double*)(tb_ + L.zo); double* seas = (double*)(tb_ + L.seas);
+  double* zk = (double*)(tb_ + L.zk); double* gd = (double*)(tb_ + L.gd);
+  double* kf = (double*)(tb_ + L.kf);
+  double* rs = (double*)(tb_ + L.rs); double* Pcur = (double*)(smem + L.Pa);
+  double* Pnxt = (double*)(smem + L.Pb); double* pzv = (double*)(smem + L.pzv);
+  double* zi = (double*)(smem + L.zi); double* x0r = (double*)(smem + L.x0r);
+  double* egg = (double*)(smem + L.egg); double* d2 = (double*)(smem + L.d2);
+  uint32_t* emeta = (uint32_t*)(smem + L.emeta);   // i | si<<6 | j<<12 | sj<<18 | bi<<24 | bj<<28
+  uint8_t* msk = tb_ + L.mask; uint8_t* cbv = tb_ + L.cbits;
+  const int TS = (T + 3) & ~3;       // padded length of every T-array (4-step blocks)
+  RegLds R;
+  R.bvec = (double*)(smem + L.bvec);
+  R.w = nullptr;                        // (float weights of the float32 kernels: unused here)
+  double* wv = (double*)(smem + L.w);   // the weights, float64
+  R.xtx = const_cast<double*>(g.xtx) + (size_t)series * P * P;
+  R.omega = const_cast<double*>(g.omega) + (size_t)series * P * P;
+  bigp_point(R, wsc + ((L.t_total + 255) & ~(size_t)255), P > 0 ? P : 1);
+
+  const DevSeriesParams sp = g.sp[series];
+  const DevSeasonalParams ss = a.ssp[series];
+  Rng rng{g.seed0, g.seed1, stream_id(g.chain_offset + chain, g.series_stream_base, series)};
+  const bool lat = a.lat_theta != nullptr;
+  uint32_t itb = 0u;                          // iteration offset of the random stream
+  const double* lth = nullptr;
+  if (lat) {
+    rng.chain = (uint32_t)(g.chain_offset + chain / a.lat_S);
+    itb = (uint32_t)(chain % a.lat_S);
+    lth = a.lat_theta + (size_t)chain * (3 + K + P);
+  }
+  const double* Xg = g.Xt + (size_t)series * P * T;
+  const double* chol1 = a.p1_chol + (size_t)series * a.dred * a.dred;
+
+  // ---- lane roles: component `lane` of the state, block membership, shift partners
+  int blk = -1, pos = 0, nb = 1, boff = 0, rbase = 0;
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k)
+    if (k < K && lane >= off[k] && lane < off[k] + nsz[k]) {
+      blk = k; pos = lane - off[k]; nb = nsz[k]; boff = off[k]; rbase = roff[k];
+    }
+  const bool comp = lane < D;
+  const bool isz = comp && (lane == 0 || (blk >= 0 && pos == 0));   // rows of Z
+  const int fwd_src = blk >= 0 ? boff + (pos + 1 == nb ? 0 : pos + 1) : lane;   // x'_p = x_{p+1}
+  const int bwd_src = blk >= 0 ? boff + (pos == 0 ? nb - 1 : pos - 1) : lane;   // (T'r)_p = r_{p-1}
+  const double gpos = blk >= 0 ? ((pos == nb - 1) ? 1.f - 1.f / (double)nb : -1.f / (double)nb) : 0.f;
+  const int blk0 = blk >= 0 ? blk : 0;
+
+  // ---- stage constants
+  for (int t = lane; t < TS; t += 64) {
+    const bool in = t < T;
+    const bool m = in ? g.mask[(size_t)series * T + t] != 0 : true;
+    msk[t] = m ? 1 : 0;
+    yv[t] = m ? 0.f : g.y[(size_t)series * T + t];
+    lev[t] = 0.f; xw[t] = 0.f; ytil[t] = 0.f; vf[t] = 0.f; zl[t] = 0.f; zo[t] = 0.f;
+    if (a.has_slope) { slp[t] = 0.f; zs[t] = 0.f; }
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        seas[k * TS + t] = 0.f; zk[k * TS + t] = 0.f; gd[k * TS + t] = 0.f;
+        if (in && a.season_change[(size_t)k * T + t]) bits |= 1u << k;
+      }
+    cbv[t] = (uint8_t)bits;
+  }
+  // per-entry tables of the covariance time update P <- T P T' + Q
+  for (int e = lane; e < D * D; e += 64) {
+    const int i = e / D, j = e - i * D;
+    int bi = 15, bj = 15, si = i, sj = j;
+    double gi = 0.f, gj = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        if (i >= off[k] && i < off[k] + nsz[k]) {
+          bi = k; const int p = i - off[k]; si = off[k] + (p + 1 == nsz[k] ? 0 : p + 1);
+          gi = (p == nsz[k] - 1) ? 1.f - 1.f / (double)nsz[k] : -1.f / (double)nsz[k];
+        }
+        if (j >= off[k] && j < off[k] + nsz[k]) {
+          bj = k; const int p = j - off[k]; sj = off[k] + (p + 1 == nsz[k] ? 0 : p + 1);
+          gj = (p == nsz[k] - 1) ? 1.f - 1.f / (double)nsz[k] : -1.f / (double)nsz[k];
+        }
+      }
+    egg[e] = (bi == bj && bi != 15) ? gi * gj : 0.f;
+    emeta[e] = (uint32_t)i | ((uint32_t)si << 6) | ((uint32_t)j << 12) | ((uint32_t)sj << 18) |
+               ((uint32_t)bi << 24) | ((uint32_t)bj << 28);
+  }
+  for (int j = lane; j < (P > 16 ? P : 16); j += 64) wv[j] = 0.f;
+  wave_sync();
+  double n_changes[SMAXK];
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k) {
+    n_changes[k] = 0.0;
+    if (k < K) {
+      double c = 0.f;
+      for (int t = lane; t + 1 < T; t += 64) c += ((cbv[t] >> k) & 1) ? 1.f : 0.f;
+      n_changes[k] = (double)wave_sum_d(c);
+    }
+  }
+
+  double obs_scale = sp.obs_scale0, level_scale = sp.level_scale0, slope_scale = sp.slope_scale0;
+  double drift[SMAXK];
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k) drift[k] = (k < K) ? ss.drift_scale0[k] : 0.0;
+  double ssl = 0.f, sss = 0.f, ssd = 0.f;   // lane 0 / lane 1 / lane off[k] accumulate
+  const double p1l = (double)(sp.init_level_scale * sp.init_level_scale);
+  const double p1s = (double)(sp.init_slope_scale * sp.init_slope_scale);
+  const double p1e = (double)(ss.init_seasonal_scale * ss.init_seasonal_scale);
+  Prof prof;
+  prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && lane == 0);
+
+  auto zsum = [&](double x) -> double {   // Z x for a lane-distributed vector
+    double s = readlane_d(x, 0);
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) s += readlane_d(x, off[k]);
+    return s;
+  };
+  // x <- T_t x : cyclic shift of the blocks that change season at t (+ level += slope)
+  auto transition = [&](double x, unsigned cb) -> double {
+    const double sh = __shfl(x, fwd_src, 64);
+    double r = (blk >= 0 && ((cb >> blk) & 1u)) ? sh : x;
+    if (a.has_slope) {
+      const double s1 = readlane_d(x, 1);
+      if (lane == 0) r += s1;
+    }
+    return r;
+  };
+  auto transition_T = [&](double x, unsigned cb) -> double {   // x <- T_t' x
+    const double sh = __shfl(x, bwd_src, 64);
+    double r = (blk >= 0 && ((cb >> blk) & 1u)) ? sh : x;
+    if (a.has_slope) {
+      const double r0 = readlane_d(x, 0);
+      if (lane == 1) r += r0;
+    }
+    return r;
+  };
+  auto ld4 = [](const double* p) { return *reinterpret_cast<const double4*>(p); };
+  auto ldb4 = [](const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); };
+  auto at4 = [](const double4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
+
+  const int n_iter = g.W + g.S;
+  if (lat) {
+    obs_scale = lth[0]; level_scale = lth[1]; slope_scale = lth[2];
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k) if (k < K) drift[k] = lth[3 + k];
+    for (int j = lane; j < P; j += 64) wv[j] = (double)lth[3 + K + j];
+    wave_sync();
+  }
+  for (int it = 0; it <= n_iter; ++it) {
+    // ---- (1) X~'targets, y'y from the current latents
+    if (!lat) {
+      double yty = 0.f;
+      for (int t = lane; t < T; t += 64) {
+        double tg = 0.f;
+        if (!msk[t]) {
+          tg = yv[t] - lev[t];
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k)
+            if (k < K) tg -= seas[k * TS + t];
+        }
+        ytil[t] = tg;            // reused as the targets buffer here
+        yty = fma(tg, tg, yty);
+      }
+      wave_sync();
+      for (int j = 0; j < P; ++j) {
+        double pj = 0.f;
+        for (int t = lane; t < T; t += 64) pj = fma(Xg[(size_t)j * T + t], ytil[t], pj);
+        const double s = wave_sum_d(pj);
+        if (lane == 0) R.bvec[j] = (double)s;
+      }
+      const double s0 = wave_sum_d(yty);
+      if (lane == 0) R.bvec[P] = (double)s0;
+      wave_sync();
+    }
+    prof.tick(20);
+    // ---- (2) scale draws of iteration it-1, regression draw of iteration it
+    double emit_obs = obs_scale;
+    if (it > 0) {
+      const uint32_t pit = (uint32_t)(it - 1) + itb;
+      if (!lat) {
+      const double v_l = (double)readlane_d(ssl, 0);
+      level_scale = scale_draw_d(sp.level_conc, sp.level_scale, sp.level_ub, (double)(T - 1), v_l,
+                               rng, pit, SITE_LEVEL_SCALE, lane);
+      if (a.has_slope) {
+        const double v_s = (double)readlane_d(sss, 1);
+        slope_scale = scale_draw_d(sp.slope_conc, sp.slope_scale, sp.slope_ub, (double)(T - 1), v_s,
+                                 rng, pit, SITE_SLOPE_SCALE, lane);
+      }
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K) {
+          const double v_d = (double)readlane_d(ssd, off[k]);
+          const double gk = gamma_wave_d(ss.drift_conc + 0.5 * n_changes[k], rng, pit,
+                                       SITE_DRIFT_SCALE, (uint32_t)k, lane);
+          const double sd = (double)sqrt(((ss.drift_scale + 0.5 * v_d) * (1.0 / gk)));
+          drift[k] = sd < ss.drift_ub ? sd : ss.drift_ub;
+        }
+      if (P == 0)
+        obs_scale = scale_draw_d(sp.obs_conc, sp.obs_scale, sp.obs_ub, sp.n_obs, R.bvec[P], rng, pit,
+                               SITE_OBS_SCALE, lane);
+      }
+      emit_obs = obs_scale;
+      const int s = it - 1 - g.W;
+      if (s >= 0) {
+        const size_t o = chain_lin * g.S + s;
+        if (lane == 0) {
+          if (g.out_obs) g.out_obs[o] = (double)obs_scale;
+          if (g.out_level_scale) g.out_level_scale[o] = (double)level_scale;
+          if (g.out_slope_scale) g.out_slope_scale[o] = (double)(a.has_slope ? slope_scale : 0.0);
+        }
+        if (a.out_drift) {
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k)
+            if (k < K && lane == k) a.out_drift[o * K + k] = (double)drift[k];
+        }
+        if (g.out_weights)
+          for (int j = lane; j < P; j += 64) g.out_weights[o * P + j] = wv[j];
+        // level / seasonal contributions / posterior-predictive trajectory of iteration it-1
+        const double so = (double)emit_obs;
+        const size_t row = o * T;
+        for (int c = lane; c < (T + 3) / 4; c += 64) {
+          double zp[4];
+          normals4(site_call(rng, pit, SITE_PRED, 0, (uint32_t)c), zp);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t = 4 * c + q;
+            if (t < T) {
+              double loc = lev[t] + xw[t];
+#pragma unroll
+              for (int k = 0; k < SMAXK; ++k)
+                if (k < K) {
+                  const double sv = seas[k * TS + t];
+                  loc += sv;
+                  if (a.out_seasonal) a.out_seasonal[(row + t) * K + k] = sv;
+                }
+              if (g.out_level) g.out_level[row + t] = lev[t];
+              if (g.out_slope && a.has_slope) g.out_slope[row + t] = slp[t];
+              if (g.out_traj) g.out_traj[row + t] = fma(so, zp[q], loc);
+              if (g.out_pred_mean) {
+                double* pm = g.out_pred_mean + chain_lin * T + t;   // running sum, scaled at the end
+                *pm = (s == 0 ? 0.f : *pm) + loc;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (it == n_iter) break;
+    if (P > 0 && !lat) {
+      const double g_obs = gamma_wave_d(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
+      obs_scale = spike_slab_draw_big(R, wv, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, it == 0);
+    }
+    wave_sync();
+    prof.tick(21);
+
+    // ---- (3) residual, normals of this iteration
+    for (int t = lane; t < T; t += 64) {
+      double s = 0.f;
+      for (int j = 0; j < P; ++j) s = fma(Xg[(size_t)j * T + t], wv[j], s);
+      xw[t] = s;
+    }
+    for (int c = lane; c < (T + 3) / 4; c += 64) {
+      double z4[4];
+      normals4(site_call(rng, (uint32_t)it + itb, SITE_PRIOR_LEVEL, 0, (uint32_t)c), z4);
+      *reinterpret_cast<double4*>(zl + 4 * c) = make_double4(z4[0], z4[1], z4[2], z4[3]);
+      normals4(site_call(rng, (uint32_t)it + itb, SITE_PRIOR_OBS, 0, (uint32_t)c), z4);
+      *reinterpret_cast<double4*>(zo + 4 * c) = make_double4(z4[0], z4[1], z4[2], z4[3]);
+      if (a.has_slope) {
+        normals4(site_call(rng, (uint32_t)it + itb, SITE_PRIOR_SLOPE, 0, (uint32_t)c), z4);
+        *reinterpret_cast<double4*>(zs + 4 * c) = make_double4(z4[0], z4[1], z4[2], z4[3]);
+      }
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K) {
+          normals4(site_call(rng, (uint32_t)it + itb, SITE_PRIOR_SEAS, (uint32_t)k, (uint32_t)c), z4);
+          *reinterpret_cast<double4*>(zk + k * TS + 4 * c) = make_double4(z4[0], z4[1], z4[2], z4[3]);
+        }
+    }
+    if (lane < a.dred) {
+      zi[lane] = normal_d(rng, (uint32_t)it + itb, SITE_PRIOR_INIT, 0, (uint32_t)lane);
+    }
+    double mydrift = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        if (blk == k) mydrift = (double)drift[k];
+        if (lane == 0) d2[k] = (double)(drift[k] * drift[k]);
+      }
+    wave_sync();
+    // x+_0 = chol(P_1) z in the oracle's reduced coordinates, folded into the prior mean
+    if (lane < a.dred) {
+      double s = 0.f;
+      for (int j = 0; j <= lane; ++j) s = fma(chol1[lane * a.dred + j], zi[j], s);
+      x0r[lane] = s;
+    }
+    wave_sync();
+    double a1e = 0.f;
+    if (lane == 0) a1e = (double)sp.init_level_loc + x0r[0];
+    if (a.has_slope && lane == 1) a1e = x0r[1];
+    if (blk >= 0) {
+      if (pos < nb - 1) a1e = x0r[rbase + pos];
+      else { double s = 0.f; for (int q = 0; q < nb - 1; ++q) s += x0r[rbase + q]; a1e = -s; }
+    }
+    const double so = (double)obs_scale, sl = (double)level_scale, ssc = (double)slope_scale;
+    const double H = so * so, ql = sl * sl, qs = ssc * ssc;
+    const double* zkb = zk + blk0 * TS;
+    const double dg = mydrift * gpos;            // this lane's share of a unit drift shock
+    prof.tick(22);
+
+    // ---- (4) pass 0: simulate x+ (zero initial state) and form y~ = resid - y+.
+    // Every pass walks time in blocks of 4 steps so that the per-step scalars arrive as one
+    // batch of 16-byte LDS loads instead of one exposed round trip each.
+    {
+      double xp = 0.f;
+      for (int t4 = 0; t4 < T; t4 += 4) {
+        const double4 zo4 = ld4(zo + t4), zl4 = ld4(zl + t4), zk4 = ld4(zkb + t4);
+        const double4 yv4 = ld4(yv + t4), xw4 = ld4(xw + t4);
+        double4 zs4 = make_double4(0.f, 0.f, 0.f, 0.f);
+        if (a.has_slope) zs4 = ld4(zs + t4);
+        const uint32_t cb4 = ldb4(cbv + t4);
+        double yt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t4 + q;
+          const double zx = zsum(xp);
+          yt[q] = (at4(yv4, q) - at4(xw4, q)) - (zx + so * at4(zo4, q));
+          if (t + 1 < T) {
+            const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
+            double r = transition(xp, cb);
+            if (lane == 0) r = fma(sl, at4(zl4, q), r);
+            if (a.has_slope && lane == 1) r = fma(ssc, at4(zs4, q), r);
+            if (blk >= 0 && ((cb >> blk) & 1u)) r = fma(dg, at4(zk4, q), r);
+            xp = r;
+          }
+        }
+        if (lane == 0) *reinterpret_cast<double4*>(ytil + t4) = make_double4(yt[0], yt[1], yt[2], yt[3]);
+      }
+    }
+    prof.tick(23);
+    // prior covariance of x_0 in full-effect form: sd^2 (I - 11'/n) per block
+    for (int e = lane; e < D * D; e += 64) {
+      const uint32_t mt = emeta[e];
+      const int i = mt & 63u, j = (mt >> 12) & 63u;
+      const unsigned bi = (mt >> 24) & 15u, bj = mt >> 28;
+      double v = 0.f;
+      if (e == 0) v = p1l;
+      else if (a.has_slope && i == 1 && j == 1) v = p1s;
+      else if (bi != 15u && bi == bj) {
+        int nn = 1;
+#pragma unroll
+        for (int k = 0; k < SMAXK; ++k) if (k < K && bi == (unsigned)k) nn = nsz[k];
+        v = p1e * ((i == j ? 1.f : 0.f) - 1.f / (double)nn);
+      }
+      Pcur[e] = v;
+    }
+    wave_sync();
+    prof.tick(24);
+
+    // ---- (5) pass 1: Kalman filter, storing K_t and v_t / F_t.  The measurement update and the
+    // time update of the covariance are ONE sweep over the D x D entries:
+    //   P'[i][j] = P[si][sj] - pz[si] pz[sj] / F + Q[i][j]      (si, sj: sources under the shifts)
+    // with the per-entry table lookups issued before the dependent loads.
+    {
+      double am = a1e;
+      const int DD = D * D;
+      uint32_t mt0[4];          // the first 256 entries' tables stay in registers
+      double gq0[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = lane + 64 * u;
+        mt0[u] = (e < DD) ? emeta[e] : 0u;
+        gq0[u] = (e < DD) ? egg[e] : 0.f;
+      }
+      for (int t4 = 0; t4 < T; t4 += 4) {
+        const double4 yt4 = ld4(ytil + t4);
+        const uint32_t cb4 = ldb4(cbv + t4), mk4 = ldb4(msk + t4);
+        double vfq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t4 + q;
+          vfq[q] = 0.f;
+          if (t >= T) continue;
+          const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+          const unsigned cb = (t + 1 < T) ? ((cb4 >> (8 * q)) & 0xFFu) : 0u;
+          double kfi = 0.f, rF = 0.f;
+          if (obs) {
+            double pz = 0.f;
+            if (comp) {
+              pz = Pcur[lane * D];
+#pragma unroll
+              for (int k = 0; k < SMAXK; ++k)
+                if (k < K) pz += Pcur[lane * D + off[k]];
+              pzv[lane] = pz;
+            }
+            const double F = zsum(pz) + H;
+            rF = 1.0 / F;
+            const double v = at4(yt4, q) - zsum(am);
+            kfi = pz * rF;
+            vfq[q] = v * rF;
+            am = fma(kfi, v, am);
+          } else if (comp) {
+            pzv[lane] = 0.f;
+          }
+          if (comp) kf[(size_t)t * D + lane] = kfi;
+          if (t + 1 == T) continue;
+          am = transition(am, cb);
+          wave_sync();
+          if (!obs && cb == 0u && !a.has_slope) {
+            if (lane == 0) Pcur[0] += ql;
+            wave_sync();
+            continue;
+          }
+          for (int e0 = lane; e0 < DD; e0 += 64 * 4) {
+            uint32_t mt[4];
+            double gq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int e = e0 + 64 * u;
+              if (e0 == lane) { mt[u] = mt0[u]; gq[u] = gq0[u]; }
+              else {
+                mt[u] = (e < DD) ? emeta[e] : 0u;
+                gq[u] = (e < DD) ? egg[e] : 0.f;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int e = e0 + 64 * u;
+              if (e < DD) {
+                const unsigned bi = (mt[u] >> 24) & 15u, bj = mt[u] >> 28;
+                const bool ci = bi != 15u && ((cb >> bi) & 1u), cj = bj != 15u && ((cb >> bj) & 1u);
+                const int i = mt[u] & 63u, j = (mt[u] >> 12) & 63u;
+                const int si = ci ? (int)((mt[u] >> 6) & 63u) : i;
+                const int sj = cj ? (int)((mt[u] >> 18) & 63u) : j;
+                double v = Pcur[__mul24(si, D) + sj] - pzv[si] * pzv[sj] * rF;
+                if (a.has_slope) {       // level <- level + slope
+                  if (i == 0) v += Pcur[D + sj] - pzv[1] * pzv[sj] * rF;
+                  if (j == 0) v += Pcur[__mul24(si, D) + 1] - pzv[si] * pzv[1] * rF;
+                  if (i == 0 && j == 0) v += Pcur[D + 1] - pzv[1] * pzv[1] * rF;
+                  if (i == 1 && j == 1) v += qs;
+                }
+                if (e == 0) v += ql;
+                if (ci && bi == bj) v = fma(d2[bi], gq[u], v);
+                Pnxt[e] = v;
+              }
+            }
+          }
+          wave_sync();
+          double* tmp = Pcur; Pcur = Pnxt; Pnxt = tmp;
+        }
+        if (lane == 0) *reinterpret_cast<double4*>(vf + t4) = make_double4(vfq[0], vfq[1], vfq[2], vfq[3]);
+      }
+    }
+    wave_sync();
+    prof.tick(25);
+    // ---- (6) pass 2: backward recursion, rs[t] = r_{t-1}; then gd[k][t] = g . r_{t-1} per block
+    // (the projection the forward reconstruction needs at season changes)
+    {
+      double r = 0.f;
+      for (int t4 = ((T - 1) & ~3); t4 >= 0; t4 -= 4) {
+        const double4 vf4 = ld4(vf + t4);
+        const uint32_t cb4 = ldb4(cbv + t4), mk4 = ldb4(msk + t4);
+        double kfq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kfq[q] = (comp && t4 + q < T) ? kf[(size_t)(t4 + q) * D + lane] : 0.f;
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
+          const int t = t4 + q;
+          if (t >= T) continue;
+          r = (t + 1 < T) ? transition_T(r, (cb4 >> (8 * q)) & 0xFFu) : 0.f;
+          if (((mk4 >> (8 * q)) & 0xFFu) == 0u) {
+            const double kr = wave_sum_d(kfq[q] * r);
+            if (isz) r += at4(vf4, q) - kr;
+          }
+          if (comp) rs[(size_t)t * D + lane] = r;
+        }
+      }
+    }
+    wave_sync();
+    // g . r_{t-1} per block, time-parallel: g = e_last - 1/n
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        const double rn = 1.0 / (double)nsz[k];
+        for (int t = lane; t < T; t += 64) {
+          const double* rr = rs + (size_t)t * D + off[k];
+          double sb = 0.f;
+          for (int q = 0; q < nsz[k]; ++q) sb += rr[q];
+          gd[k * TS + t] = rr[nsz[k] - 1] - sb * rn;
+        }
+      }
+    wave_sync();
+    prof.tick(26);
+    // ---- (7) pass 3: reconstruct x^ forward, re-simulate x+, write the draw, gather statistics
+    {
+      double xh = a1e;
+      {   // x^_0 = a_1 + P_1 r_{-1}
+        const double r0 = comp ? rs[lane] : 0.f;
+        if (lane == 0) xh += p1l * r0;
+        if (a.has_slope && lane == 1) xh += p1s * r0;
+        if (blk >= 0) {
+          double sb = 0.f;
+          for (int q = 0; q < nb; ++q) sb += rs[boff + q];
+          xh += p1e * (r0 - sb / (double)nb);
+        }
+      }
+      double xp = 0.f, prev = 0.f, prev_next = 0.f;
+      ssl = 0.f; sss = 0.f; ssd = 0.f;
+      unsigned cb_prev = 0u;
+      const double* gdb = gd + blk0 * TS;
+      const double dgd = mydrift * dg;            // sigma_d^2 g_i
+      for (int t4 = 0; t4 < T; t4 += 4) {
+        const double4 zl4 = ld4(zl + t4), zk4 = ld4(zkb + t4);
+        double4 zs4 = make_double4(0.f, 0.f, 0.f, 0.f);
+        if (a.has_slope) zs4 = ld4(zs + t4);
+        const uint32_t cb4 = ldb4(cbv + t4);
+        double rnq[4], gdq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {       // r_t = rs[t + 1] and g . r_t of this lane's block
+          const int t1 = t4 + q + 1;
+          rnq[q] = (comp && t1 < T) ? rs[(size_t)t1 * D + lane] : 0.f;
+          gdq[q] = (t1 < T) ? gdb[t1] : 0.f;
+        }
+        double xo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t4 + q;
+          xo[q] = 0.f;
+          if (t >= T) continue;
+          const double xt = xh + xp;
+          xo[q] = xt;
+          if (t > 0) {
+            if (lane == 0) {
+              double dl = xt - prev;
+              if (a.has_slope) dl -= prev_next;       // slope_{t-1} is lane 1 = "next" of lane 0
+              ssl = fma(dl, dl, ssl);
+            }
+            if (a.has_slope && lane == 1) { const double ds = xt - prev; sss = fma(ds, ds, sss); }
+            if (blk >= 0 && pos == 0 && ((cb_prev >> blk) & 1u)) {
+              const double w = (double)nb * (prev_next - xt);   // n (e_{t-1,1} - e_{t,0})
+              ssd = fma(w, w, ssd);
+            }
+          }
+          prev = xt;
+          prev_next = __shfl_down(xt, 1, 64);
+          if (t + 1 < T) {
+            const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
+            const bool mych = blk >= 0 && ((cb >> blk) & 1u);
+            double h = transition(xh, cb);
+            if (lane == 0) h = fma(ql, rnq[q], h);
+            if (a.has_slope && lane == 1) h = fma(qs, rnq[q], h);
+            if (mych) h = fma(dgd, gdq[q], h);
+            xh = h;
+            double r = transition(xp, cb);
+            if (lane == 0) r = fma(sl, at4(zl4, q), r);
+            if (a.has_slope && lane == 1) r = fma(ssc, at4(zs4, q), r);
+            if (mych) r = fma(dg, at4(zk4, q), r);
+            xp = r;
+            cb_prev = cb;
+          }
+        }
+        // the observed components of the draw, 4 steps at a time
+        if (lane == 0) *reinterpret_cast<double4*>(lev + t4) = make_double4(xo[0], xo[1], xo[2], xo[3]);
+        if (a.has_slope && lane == 1)
+          *reinterpret_cast<double4*>(slp + t4) = make_double4(xo[0], xo[1], xo[2], xo[3]);
+        if (blk >= 0 && pos == 0)
+          *reinterpret_cast<double4*>(seas + blk * TS + t4) = make_double4(xo[0], xo[1], xo[2], xo[3]);
+      }
+    }
+    wave_sync();
+    prof.tick(27);
+  }
+  if (g.out_pred_mean) {
+    const double inv = 1.0 / (double)(g.S > 0 ? g.S : 1);
+    for (int t = lane; t < T; t += 64) g.out_pred_mean[chain_lin * T + t] *= inv;
+  }
+}
+#endif  // CI_SEASONAL_DECL_ONLY
+
+}  // namespace ci

@@ -1119,10 +1119,12 @@ __device__ __forceinline__ void bigp_point(RegLds& R, unsigned char* ws, int P) 
   R.nz = q; R.perm = q + P; R.idx = q + 2 * P;
 }
 
-__device__ __noinline__ double spike_slab_draw_big(const RegLds& R, int P, const DevSeriesParams& sp,
-                                                   double prev_obs_scale, double g_obs,
-                                                   const Rng& rng, uint32_t iter, int lane,
-                                                   bool first) {
+// `w`: the weights vector (float in the float32 kernels, double in the float64 one, ci_gibbs64.h).
+template <class WT>
+__device__ __noinline__ double spike_slab_draw_big(const RegLds& R, WT* w, int P,
+                                                   const DevSeriesParams& sp, double prev_obs_scale,
+                                                   double g_obs, const Rng& rng, uint32_t iter,
+                                                   int lane, bool first) {
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
@@ -1143,7 +1145,7 @@ __device__ __noinline__ double spike_slab_draw_big(const RegLds& R, int P, const
   if (first)
     for (int e = lane; e < P * P; e += 64) Pm[e] = R.omega[e];
   for (int j = lane; j < P; j += 64) {
-    R.nz[j] = all_in ? 1 : (R.w[j] != 0.f ? 1 : 0);
+    R.nz[j] = all_in ? 1 : (w[j] != (WT)0 ? 1 : 0);
     if (!all_in) R.uperm[j] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j);
   }
   wave_sync();
@@ -1224,7 +1226,7 @@ __device__ __noinline__ double spike_slab_draw_big(const RegLds& R, int P, const
     if (mynz) R.idx[na + __popcll(bal & ((1ull << lane) - 1ull))] = j;
     na += __popcll(bal);
   }
-  for (int j = lane; j < P; j += 64) R.w[j] = 0.f;
+  for (int j = lane; j < P; j += 64) w[j] = (WT)0;
   wave_sync();
   // Cholesky of M_S = Omega_S * prev_var + XtX_S (right-looking), z ~ N(0, I), L' u = z
   for (int i = lane >> 4; i < na; i += 4)
@@ -1253,7 +1255,7 @@ __device__ __noinline__ double spike_slab_draw_big(const RegLds& R, int P, const
   }
   for (int i = lane; i < na; i += 64) {
     const int f = R.idx[i];
-    R.w[f] = (float)(A[f * n + P] + new_scale * R.zv[i]);
+    w[f] = (WT)(A[f * n + P] + new_scale * R.zv[i]);
   }
   wave_sync();
   return new_scale;

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       else if constexpr (!BIGP)
         obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, it == 0);
       else
-        obs_scale = spike_slab_draw_big(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, it == 0);
+        obs_scale = spike_slab_draw_big(R, R.w, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, it == 0);
     }
     wave_sync();
     prof.tick(21);

@@ -5,6 +5,7 @@
 
 #include "ci_seasonal.h"
 #include "ci_score_seq.h"
+#include "ci_gibbs64.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(int which) {
   switch (which) {
@@ -29,4 +30,11 @@ extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs* args, int D, hipStream_t
   (void)hipFuncSetAttribute((const void*)(&ci::hmc_seq_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(ci::hmc_seq_kernel, dim3(args->C), dim3(ci::NT), lds, stream, *args);
+}
+
+// The float64 Gibbs sampler (ci_gibbs64.h): one wavefront per chain.
+extern "C" void ci_launch_gibbs64(const ci::G64Args* args, int grid, size_t lds, hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)(&ci::gibbs64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL(ci::gibbs64_kernel, dim3(grid), dim3(64), lds, stream, *args);
 }

@@ -1069,10 +1069,12 @@ int ci_session_algorithmic_bytes(const ci_session* s, double* bytes) {
   const ci_problem& pb = s->pb;
   const double T = pb.T, P = pb.P, S = pb.num_results;
   const double chains = (double)pb.num_series * pb.num_chains;
-  const double d_out = 1.0 + (pb.has_slope ? 1.0 : 0.0);
-  // per retained draw 4 T (d_out + 1) + 4 (P + 2 + slope); inputs once
-  // per chain: 4 T (P + 1) + T.
-  const double per_draw = 4.0 * T * (d_out + 1.0) + 4.0 * (P + 2.0 + (pb.has_slope ? 1.0 : 0.0));
+  // per retained draw 4 T (d_out + 1) + 4 (P + 2 + slope + K), d_out = level
+  // + slope + the seasonal latents the fit materialises (one per block: ci_outputs.seasonal_levels);
+  // inputs once per chain: 4 T (P + 1) + T.
+  const double K = pb.num_blocks;
+  const double d_out = 1.0 + (pb.has_slope ? 1.0 : 0.0) + K;
+  const double per_draw = 4.0 * T * (d_out + 1.0) + 4.0 * (P + 2.0 + (pb.has_slope ? 1.0 : 0.0) + K);
   const double per_chain = 4.0 * T * (P + 1.0) + T;
   *bytes = chains * (S * per_draw + per_chain);
   return 0;

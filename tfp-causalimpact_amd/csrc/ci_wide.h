@@ -479,7 +479,13 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
   }
   {
     Vec<D> am = a_start;
-    Mat<D> Pm = P_start;
+    // the covariance stays a PACKED upper triangle through the pass (28 entries at d = 7 instead of
+    // 49): the pass is VALU-issue bound at one wave per SIMD
+    float Ps[W::NPS];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) Ps[symidx<D>(i, j)] = P_start.m[i][j];
     float ytn[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) ytn[q] = wsp[((size_t)q * NF + W::F_YT) * NT + tid];
@@ -508,7 +514,7 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
         if (obs) {
           float pz[D];
 #pragma unroll
-          for (int i = 0; i < D; ++i) pz[i] = Pm.m[i][0] + Pm.m[i][O];
+          for (int i = 0; i < D; ++i) pz[i] = Ps[symidx<D>(i, 0)] + Ps[symidx<D>(i, O)];
           const float Fv = pz[0] + pz[O] + sc.H;
           const float rF = __builtin_amdgcn_rcpf(Fv);
           const float v = yt - (am.v[0] + am.v[O]);
@@ -518,14 +524,15 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
             kf[i] = pz[i] * rF;
             am.v[i] = fmaf(kf[i], v, am.v[i]);
 #pragma unroll
-            for (int j = 0; j < D; ++j) Pm.m[i][j] = fmaf(-(pz[i] * pz[j]), rF, Pm.m[i][j]);
+            for (int j = i; j < D; ++j)
+              Ps[symidx<D>(i, j)] = fmaf(-(pz[i] * pz[j]), rF, Ps[symidx<D>(i, j)]);
           }
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) wl[(W::F_KF + i) * NT] = kf[i];
         wl[W::F_VF * NT] = vf;
         w_apply<TR, NS>(am, ch);
-        w_cov_predict<TR, NS>(Pm, ch, sc);
+        w_cov_predict_sym<TR, NS>(Ps, ch, sc);
       }
     }
   }

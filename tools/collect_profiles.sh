@@ -4,7 +4,7 @@
 # rocprofv3 runs from /tmp with TMPDIR=/tmp; PMC counters are collected in their own passes
 # (never together with trace domains).
 set -u
-TAG=${1:-r02_f}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -33,6 +33,10 @@ timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/cfg_pmc_sq" -o cfg 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_e2e" -o e2e -- python tools/time_end_to_end.py > "$OUT/e2e.log" 2>&1
 timeout 200 python tools/profile_phases.py > "$OUT/phase_cycles.txt" 2>&1
 timeout 200 python tools/profile_wide.py > "$OUT/cfg4_phase_cycles.txt" 2>&1
-CI_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --no-cpu-baseline --steps 5 > "$OUT/bench_force_dist.json" 2> "$OUT/bench_force_dist.err"
+# the N > 1 code path with one rank: C-ABI communicator (librccl), barrier, max-reduce, gather from HBM
+CI_BENCH_FORCE_DIST=1 NCCL_DEBUG=VERSION timeout 300 python bench.py --no-cpu-baseline --steps 5 > "$OUT/bench_force_dist.json" 2> "$OUT/bench_force_dist.err"
+# two ranks sharing GPU 0 through the self-launcher (host transport: RCCL refuses two ranks on one device)
+timeout 300 python -m pytest tests/test_gpu_comm.py -q > "$OUT/comm_tests.txt" 2>&1
+timeout 600 python tools/run_configs.py extras > "$OUT/extras.jsonl" 2> "$OUT/extras.err"
 find "$OUT" -name "*.csv" | wc -l
 tail -1 "$OUT/bench.json" | cut -c1-400

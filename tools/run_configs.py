@@ -68,8 +68,58 @@ def cfg5(B, S=1000):
           "mean_abs_effect": float(res.summary.xs("average", level=1)["abs_effect"].mean())}
 
 
+def extras():
+  """Round-3 capability routes, timed once each (wall time of the C-ABI call)."""
+  out = []
+  # float64 compute at cfg2's size (sequential kernel, csrc/ci_gibbs64.h)
+  T, p, W, S, C = 1000, 10, 112, 1000, 8
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 2024)
+  spec = _model.series_params(y, mask, X, has_slope=True)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=1, num_warmup=W, num_results=S, num_chains=C,
+                            seed=(0, 1))
+  prm = _native.make_params([spec])
+  _native.fit_gibbs_f64(_native.make_problem(T=T, P=p + 1, has_slope=1, num_warmup=1, num_results=2,
+                                             seed=(0, 1)), y[None], mask[None], X[None], None, prm)
+  t0 = time.time()
+  _native.fit_gibbs_f64(pb, y[None], mask[None], X[None], None, prm,
+                        want=("observation_noise_scale", "posterior_means"))
+  dt = time.time() - t0
+  out.append({"config": "cfg2 in float64", "kernel": "ci::gibbs64_kernel", "chains": C, "wall_s": dt,
+              "us_per_iteration": dt / (W + S) * 1e6, "samples_per_s": C * S / dt})
+  # 100 covariates (regression block in the HBM workspace)
+  T, p, W, S, C = 1000, 100, 50, 200, 8
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
+  spec = _model.series_params(y, mask, X)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_warmup=W, num_results=S, num_chains=C,
+                            seed=(0, 1))
+  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  sess.run()
+  ms = sess.run()
+  out.append({"config": "T=1000, 100 covariates (P=101)", "kernel": sess.kernel_name(), "chains": C,
+              "kernel_ms": ms, "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": C * S / ms * 1e3})
+  sess.close()
+  # HMC with a weekly block (sequential score, csrc/ci_score_seq.h)
+  T, p, W, S, C, NL = 1000, 10, 100, 100, 8, 15
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 2024)
+  spec = _model.series_params(y, mask, X, num_seasonal_blocks=1)
+  counts, flg = _model.expand_seasons((ci.Seasons(num_seasons=7),), T)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_seasons=counts, num_warmup=0, num_results=1,
+                            seed=(0, 1))
+  ll = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8, season_change=flg)
+  hmc_ms, lat_ms = ll.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=NL, seed=(0, 1))
+  out.append({"config": "T=1000, 10 covariates + Seasonal(7), HMC", "kernel": ll.kernel_name(), "chains": C,
+              "kernel_ms": hmc_ms, "latents_ms": lat_ms, "us_per_leapfrog": hmc_ms * 1e3 / ((W + S) * NL),
+              "samples_per_s": C * S / (hmc_ms + lat_ms) * 1e3})
+  ll.close()
+  return out
+
+
 if __name__ == "__main__":
   which = sys.argv[1] if len(sys.argv) > 1 else "all"
+  if which == "extras":
+    for row in extras():
+      print(json.dumps(row), flush=True)
+    sys.exit(0)
   if which == "cfg4":        # counter passes: one short cfg4 fit per chain count
     runs = (lambda: cfg4(1, S=200), lambda: cfg4(8, S=200))
   else:

@@ -27,7 +27,7 @@
 extern "C" void* ci_gibbs_seasonal_fn(int);
 extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs*, int, hipStream_t);
 extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs*, int, hipStream_t);
-extern "C" void ci_launch_gibbs64(const ci::G64Args*, int, size_t, hipStream_t);
+extern "C" void ci_launch_gibbs64(const ci::G64Args*, int, size_t, int, hipStream_t);
 #define CI_WIDE_DECL(NS)                                  \
   extern "C" void* ci_gibbs_wide_fn_tr1_ns##NS(void);     \
   extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);
@@ -1147,9 +1147,11 @@ int ci_fit_gibbs_f64(const ci_problem* pb, const double* y, const uint8_t* mask,
   for (int k = 0; k < K; ++k) { dfull += pb->num_seasons[k]; dred += pb->num_seasons[k] - 1; }
   if (dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
   HIP_TRY(hipSetDevice(pb->device));
-  const ci::Layout64 lay = ci::make_layout64(T, P, K, dfull, dred, has_slope);
+  // arrays over time in LDS when the whole layout fits (short series), else in the HBM workspace
+  const int gws = ci::make_layout64(T, P, K, dfull, dred, has_slope, 0).total > 150 * 1024 ? 1 : 0;
+  const ci::Layout64 lay = ci::make_layout64(T, P, K, dfull, dred, has_slope, gws);
   if (lay.total > 160 * 1024) return fail("float64 fit needs %zu bytes of LDS (max 163840)", lay.total);
-  const size_t ws_stride = ci::gibbs64_ws_bytes(T, P, K, dfull, dred, has_slope);
+  const size_t ws_stride = ci::gibbs64_ws_bytes(T, P, K, dfull, dred, has_slope, gws);
   const size_t BT = (size_t)B * T, BCS = (size_t)B * C * S;
   DevBuf<double> d_y, d_xt, d_xtx, d_om, d_wps, d_chol, o_obs, o_ls, o_ss, o_dr, o_w, o_lev, o_slp, o_sea,
       o_pm, o_tr;
@@ -1242,7 +1244,7 @@ int ci_fit_gibbs_f64(const ci_problem* pb, const double* y, const uint8_t* mask,
   a.season_change = d_sc.p; a.ssp = d_ssp.p; a.p1_chol = d_chol.p;
   a.out_drift = o_dr.p; a.out_seasonal = o_sea.p;
   a.ws = d_ws.p; a.ws_stride = ws_stride; a.lat_theta = nullptr; a.lat_S = 1;
-  ci_launch_gibbs64(&a, B * C, lay.total, 0);
+  ci_launch_gibbs64(&a, B * C, lay.total, gws, 0);
   CI_TRY64(hipGetLastError());
   CI_TRY64(hipDeviceSynchronize());
   auto get = [&](double* dst, const DevBuf<double>& src) -> hipError_t {

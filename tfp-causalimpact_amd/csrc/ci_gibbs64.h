@@ -54,7 +54,10 @@ struct Layout64 {
   // LDS
   size_t Pa, Pb, pzv, zi, x0r, egg, emeta, d2, bvec, w, total;
 };
-__host__ __device__ inline Layout64 make_layout64(int T, int P, int K, int D, int dred, int has_slope) {
+// global_ws = 1: the arrays over time in the per-chain HBM workspace (any T); 0: in LDS behind the
+// fixed part (short series: every per-step access then is an LDS access instead of an L2 round trip)
+__host__ __device__ inline Layout64 make_layout64(int T, int P, int K, int D, int dred, int has_slope,
+                                                  int global_ws = 1) {
   Layout64 l;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 31) & ~(size_t)31; return r; };
@@ -69,19 +72,21 @@ __host__ __device__ inline Layout64 make_layout64(int T, int P, int K, int D, in
   l.d2 = take(sizeof(double) * SMAXK);
   l.bvec = take(sizeof(double) * (Pp + 4));
   l.w = take(sizeof(double) * (Pp > 16 ? Pp : 16));
-  l.total = o;
-  o = 0;
+  const size_t lds_fixed = o;
+  if (global_ws) o = 0;
   l.yv = take(Td); l.lev = take(Td); l.slp = take(has_slope ? Td : 32); l.xw = take(Td);
   l.ytil = take(Td); l.vf = take(Td); l.zl = take(Td); l.zs = take(has_slope ? Td : 32);
   l.zo = take(Td);
   l.seas = take(Td * Kp); l.zk = take(Td * Kp); l.gd = take(Td * Kp);
   l.kf = take(sizeof(double) * (size_t)T * D); l.rs = take(sizeof(double) * (size_t)T * D);
   l.mask = take(TS); l.cbits = take(TS);
-  l.t_total = o;
+  if (global_ws) { l.t_total = o; l.total = lds_fixed; }
+  else { l.t_total = 0; l.total = o; }
   return l;
 }
-__host__ __device__ inline size_t gibbs64_ws_bytes(int T, int P, int K, int D, int dred, int has_slope) {
-  const Layout64 l = make_layout64(T, P, K, D, dred, has_slope);
+__host__ __device__ inline size_t gibbs64_ws_bytes(int T, int P, int K, int D, int dred, int has_slope,
+                                                  int global_ws) {
+  const Layout64 l = make_layout64(T, P, K, D, dred, has_slope, global_ws);
   return ((l.t_total + 255) & ~(size_t)255) + bigp_workspace_bytes(P > 0 ? P : 1);
 }
 
@@ -122,6 +127,7 @@ __device__ __forceinline__ double scale_draw_d(double conc, double scale, double
 }
 
 #ifndef CI_SEASONAL_DECL_ONLY
+template <bool GWS>
 __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smem64[];
   unsigned char* smem = smem64;
@@ -142,12 +148,12 @@ __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
       if (k < K) { D += nsz[k]; rr += nsz[k] - 1; }
     }
   }
-  const Layout64 L = make_layout64(T, P, K, D, a.dred, a.has_slope);
+  const Layout64 L = make_layout64(T, P, K, D, a.dred, a.has_slope, GWS ? 1 : 0);
   // the arrays over time: LDS, or (GWS) this chain's slice of the HBM workspace -- every access
   // below is either one 16-byte row per 4 steps or lane-contiguous, and a chain only ever reads
   // what it wrote, so the slice stays in this XCD's L2
   unsigned char* wsc = a.ws + chain_lin * a.ws_stride;        // this chain's slice of the workspace
-  unsigned char* tb_ = wsc;                                    // arrays over time: always in HBM
+  unsigned char* tb_ = GWS ? wsc : smem;                       // arrays over time: workspace or LDS
   double* yv = (double*)(tb_ + L.yv); double* lev = (double*)(tb_ + L.lev);
   double* slp = (double*)(tb_ + L.slp); double* xw = (double*)(tb_ + L.xw);
   double* ytil = (double*)(tb_ + L.ytil); double* vf = (double*)(tb_ + L.vf);

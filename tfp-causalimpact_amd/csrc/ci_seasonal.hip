@@ -32,9 +32,12 @@ extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs* args, int D, hipStream_t
   hipLaunchKernelGGL(ci::hmc_seq_kernel, dim3(args->C), dim3(ci::NT), lds, stream, *args);
 }
 
-// The float64 Gibbs sampler (ci_gibbs64.h): one wavefront per chain.
-extern "C" void ci_launch_gibbs64(const ci::G64Args* args, int grid, size_t lds, hipStream_t stream) {
-  (void)hipFuncSetAttribute((const void*)(&ci::gibbs64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  hipLaunchKernelGGL(ci::gibbs64_kernel, dim3(grid), dim3(64), lds, stream, *args);
+// The float64 Gibbs sampler (ci_gibbs64.h): one wavefront per chain; arrays over time in the HBM
+// workspace (global_ws) or in LDS.
+extern "C" void ci_launch_gibbs64(const ci::G64Args* args, int grid, size_t lds, int global_ws,
+                                  hipStream_t stream) {
+  const void* fn = global_ws ? (const void*)(&ci::gibbs64_kernel<true>) : (const void*)(&ci::gibbs64_kernel<false>);
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (global_ws) hipLaunchKernelGGL(ci::gibbs64_kernel<true>, dim3(grid), dim3(64), lds, stream, *args);
+  else hipLaunchKernelGGL(ci::gibbs64_kernel<false>, dim3(grid), dim3(64), lds, stream, *args);
 }

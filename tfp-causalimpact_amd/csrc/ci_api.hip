@@ -1147,11 +1147,19 @@ int ci_fit_gibbs_f64(const ci_problem* pb, const double* y, const uint8_t* mask,
   for (int k = 0; k < K; ++k) { dfull += pb->num_seasons[k]; dred += pb->num_seasons[k] - 1; }
   if (dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
   HIP_TRY(hipSetDevice(pb->device));
-  // arrays over time in LDS when the whole layout fits (short series), else in the HBM workspace
-  const int gws = ci::make_layout64(T, P, K, dfull, dred, has_slope, 0).total > 150 * 1024 ? 1 : 0;
-  const ci::Layout64 lay = ci::make_layout64(T, P, K, dfull, dred, has_slope, gws);
+  // LDS first: arrays over time AND the regression block (P <= 32) when both fit, then the arrays
+  // over time alone; else the HBM workspace for the arrays (regression still in LDS if small)
+  int gws = 0, reg_lds = P <= 32 ? 1 : 0;
+  if (ci::make_layout64(T, P, K, dfull, dred, has_slope, 0, reg_lds).total > 150 * 1024) {
+    reg_lds = 0;
+    if (ci::make_layout64(T, P, K, dfull, dred, has_slope, 0, 0).total > 150 * 1024) {
+      gws = 1;
+      reg_lds = P <= 32 ? 1 : 0;
+    }
+  }
+  const ci::Layout64 lay = ci::make_layout64(T, P, K, dfull, dred, has_slope, gws, reg_lds);
   if (lay.total > 160 * 1024) return fail("float64 fit needs %zu bytes of LDS (max 163840)", lay.total);
-  const size_t ws_stride = ci::gibbs64_ws_bytes(T, P, K, dfull, dred, has_slope, gws);
+  const size_t ws_stride = ci::gibbs64_ws_bytes(T, P, K, dfull, dred, has_slope, gws, reg_lds);
   const size_t BT = (size_t)B * T, BCS = (size_t)B * C * S;
   DevBuf<double> d_y, d_xt, d_xtx, d_om, d_wps, d_chol, o_obs, o_ls, o_ss, o_dr, o_w, o_lev, o_slp, o_sea,
       o_pm, o_tr;
@@ -1243,7 +1251,7 @@ int ci_fit_gibbs_f64(const ci_problem* pb, const double* y, const uint8_t* mask,
   for (int k = 0; k < ci::SMAXK; ++k) a.nseas[k] = k < K ? pb->num_seasons[k] : 0;
   a.season_change = d_sc.p; a.ssp = d_ssp.p; a.p1_chol = d_chol.p;
   a.out_drift = o_dr.p; a.out_seasonal = o_sea.p;
-  a.ws = d_ws.p; a.ws_stride = ws_stride; a.lat_theta = nullptr; a.lat_S = 1;
+  a.ws = d_ws.p; a.ws_stride = ws_stride; a.lat_theta = nullptr; a.lat_S = 1; a.reg_lds = reg_lds;
   ci_launch_gibbs64(&a, B * C, lay.total, gws, 0);
   CI_TRY64(hipGetLastError());
   CI_TRY64(hipDeviceSynchronize());

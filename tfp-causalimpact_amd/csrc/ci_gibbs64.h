@@ -46,18 +46,21 @@ struct G64Args {
   size_t ws_stride;
   const double* lat_theta;           // latents-only mode (see SArgs); NULL = sample
   int lat_S;
+  int reg_lds;                       // regression block in LDS (small P)
 };
 
 struct Layout64 {
   // per-chain HBM workspace (arrays over time), bytes
   size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, mask, cbits, t_total;
   // LDS
-  size_t Pa, Pb, pzv, zi, x0r, egg, emeta, d2, bvec, w, total;
+  size_t Pa, Pb, pzv, zi, x0r, egg, emeta, d2, bvec, w, reg, total;
 };
 // global_ws = 1: the arrays over time in the per-chain HBM workspace (any T); 0: in LDS behind the
 // fixed part (short series: every per-step access then is an LDS access instead of an L2 round trip)
+// reg_lds = 1: the regression block's O(P^2) arrays in LDS too (small P): LDS latency instead of
+// L2 round trips in every sweep.
 __host__ __device__ inline Layout64 make_layout64(int T, int P, int K, int D, int dred, int has_slope,
-                                                  int global_ws = 1) {
+                                                  int global_ws = 1, int reg_lds = 0) {
   Layout64 l;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 31) & ~(size_t)31; return r; };
@@ -72,12 +75,14 @@ __host__ __device__ inline Layout64 make_layout64(int T, int P, int K, int D, in
   l.d2 = take(sizeof(double) * SMAXK);
   l.bvec = take(sizeof(double) * (Pp + 4));
   l.w = take(sizeof(double) * (Pp > 16 ? Pp : 16));
+  l.reg = take(reg_lds ? bigp_workspace_bytes(Pp) : 32);
   const size_t lds_fixed = o;
   if (global_ws) o = 0;
   l.yv = take(Td); l.lev = take(Td); l.slp = take(has_slope ? Td : 32); l.xw = take(Td);
   l.ytil = take(Td); l.vf = take(Td); l.zl = take(Td); l.zs = take(has_slope ? Td : 32);
   l.zo = take(Td);
-  l.seas = take(Td * Kp); l.zk = take(Td * Kp); l.gd = take(Td * Kp);
+  const size_t Tk = K > 0 ? Td * Kp : 32;          // (no seasonal arrays without blocks)
+  l.seas = take(Tk); l.zk = take(Tk); l.gd = take(Tk);
   l.kf = take(sizeof(double) * (size_t)T * D); l.rs = take(sizeof(double) * (size_t)T * D);
   l.mask = take(TS); l.cbits = take(TS);
   if (global_ws) { l.t_total = o; l.total = lds_fixed; }
@@ -85,9 +90,9 @@ __host__ __device__ inline Layout64 make_layout64(int T, int P, int K, int D, in
   return l;
 }
 __host__ __device__ inline size_t gibbs64_ws_bytes(int T, int P, int K, int D, int dred, int has_slope,
-                                                  int global_ws) {
-  const Layout64 l = make_layout64(T, P, K, D, dred, has_slope, global_ws);
-  return ((l.t_total + 255) & ~(size_t)255) + bigp_workspace_bytes(P > 0 ? P : 1);
+                                                  int global_ws, int reg_lds) {
+  const Layout64 l = make_layout64(T, P, K, D, dred, has_slope, global_ws, reg_lds);
+  return ((l.t_total + 255) & ~(size_t)255) + (reg_lds ? 256 : bigp_workspace_bytes(P > 0 ? P : 1));
 }
 
 // ---- float64 random variates of the specified stream (the oracle's formulas)
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
       if (k < K) { D += nsz[k]; rr += nsz[k] - 1; }
     }
   }
-  const Layout64 L = make_layout64(T, P, K, D, a.dred, a.has_slope, GWS ? 1 : 0);
+  const Layout64 L = make_layout64(T, P, K, D, a.dred, a.has_slope, GWS ? 1 : 0, a.reg_lds);
   // the arrays over time: LDS, or (GWS) this chain's slice of the HBM workspace -- every access
   // below is either one 16-byte row per 4 steps or lane-contiguous, and a chain only ever reads
   // what it wrote, so the slice stays in this XCD's L2
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
   double* wv = (double*)(smem + L.w);   // the weights, float64
   R.xtx = const_cast<double*>(g.xtx) + (size_t)series * P * P;
   R.omega = const_cast<double*>(g.omega) + (size_t)series * P * P;
-  bigp_point(R, wsc + ((L.t_total + 255) & ~(size_t)255), P > 0 ? P : 1);
+  bigp_point(R, a.reg_lds ? smem + L.reg : wsc + ((L.t_total + 255) & ~(size_t)255), P > 0 ? P : 1);
 
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
@@ -464,6 +469,139 @@ __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
     const double* zkb = zk + blk0 * TS;
     const double dg = mydrift * gpos;            // this lane's share of a unit drift shock
     prof.tick(22);
+
+    if (K == 0) {
+      // ---- trend-only models (the reference's default: LocalLevel, D = 1; LocalLinearTrend, D = 2):
+      // the four passes as wave-uniform SCALAR recursions -- every lane carries the same 1 x 1 or
+      // 2 x 2 quantities, lane 0 stores; no LDS matrix, no table, no barrier inside the loops.
+      const bool s2 = a.has_slope != 0;
+      const double a0 = readlane_d(a1e, 0), a1s = s2 ? readlane_d(a1e, 1) : 0.0;
+      {   // pass 0: x+ and y~ = resid - y+
+        double x0 = 0.0, x1 = 0.0;
+        for (int t4 = 0; t4 < T; t4 += 4) {
+          const double4 zo4 = ld4(zo + t4), zl4 = ld4(zl + t4), yv4 = ld4(yv + t4), xw4 = ld4(xw + t4);
+          double4 zs4 = make_double4(0.0, 0.0, 0.0, 0.0);
+          if (s2) zs4 = ld4(zs + t4);
+          double yt[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            yt[q] = (at4(yv4, q) - at4(xw4, q)) - (x0 + so * at4(zo4, q));
+            if (t4 + q + 1 < T) {
+              if (s2) x0 += x1;
+              x0 = fma(sl, at4(zl4, q), x0);
+              if (s2) x1 = fma(ssc, at4(zs4, q), x1);
+            }
+          }
+          if (lane == 0) *reinterpret_cast<double4*>(ytil + t4) = make_double4(yt[0], yt[1], yt[2], yt[3]);
+        }
+      }
+      wave_sync();
+      {   // pass 1: Kalman filter, gains and scaled innovations
+        double m0 = a0, m1 = a1s, p00 = p1l, p01 = 0.0, p11 = s2 ? p1s : 0.0;
+        for (int t4 = 0; t4 < T; t4 += 4) {
+          const double4 yt4 = ld4(ytil + t4);
+          const uint32_t mk4 = ldb4(msk + t4);
+          double vfq[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t = t4 + q;
+            vfq[q] = 0.0;
+            if (t >= T) continue;
+            double k0 = 0.0, k1 = 0.0;
+            if (((mk4 >> (8 * q)) & 0xFFu) == 0u) {
+              const double rF = 1.0 / (p00 + H);
+              const double v = at4(yt4, q) - m0;
+              k0 = p00 * rF; k1 = p01 * rF;
+              vfq[q] = v * rF;
+              m0 = fma(k0, v, m0); m1 = fma(k1, v, m1);
+              const double q00 = p00, q01 = p01;
+              p00 -= q00 * q00 * rF; p01 -= q00 * q01 * rF; p11 -= q01 * q01 * rF;
+            }
+            if (lane == 0) { kf[(size_t)t * D] = k0; if (s2) kf[(size_t)t * D + 1] = k1; }
+            if (t + 1 < T) {
+              if (s2) {
+                m0 += m1;
+                p00 = p00 + 2.0 * p01 + p11 + ql;
+                p01 = p01 + p11;
+                p11 = p11 + qs;
+              } else {
+                p00 += ql;
+              }
+            }
+          }
+          if (lane == 0) *reinterpret_cast<double4*>(vf + t4) = make_double4(vfq[0], vfq[1], vfq[2], vfq[3]);
+        }
+      }
+      wave_sync();
+      {   // pass 2: backward recursion, rs[t] = r_{t-1}  (4 steps per batch of loads)
+        double r0 = 0.0, r1 = 0.0;
+        for (int t4 = ((T - 1) & ~3); t4 >= 0; t4 -= 4) {
+          const double4 vf4 = ld4(vf + t4);
+          const uint32_t mk4 = ldb4(msk + t4);
+          double k0q[4], k1q[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool in = t4 + q < T;
+            k0q[q] = in ? kf[(size_t)(t4 + q) * D] : 0.0;
+            k1q[q] = (in && s2) ? kf[(size_t)(t4 + q) * D + 1] : 0.0;
+          }
+#pragma unroll
+          for (int q = 3; q >= 0; --q) {
+            const int t = t4 + q;
+            if (t >= T) continue;
+            if (t + 1 < T) { if (s2) r1 += r0; } else { r0 = 0.0; r1 = 0.0; }
+            if (((mk4 >> (8 * q)) & 0xFFu) == 0u) r0 += at4(vf4, q) - (k0q[q] * r0 + k1q[q] * r1);
+            if (lane == 0) { rs[(size_t)t * D] = r0; if (s2) rs[(size_t)t * D + 1] = r1; }
+          }
+        }
+      }
+      wave_sync();
+      {   // pass 3: x^ forward, x+ again, the draw and its increment statistics
+        double h0 = a0 + p1l * rs[0], h1 = s2 ? a1s + p1s * rs[1] : 0.0;
+        double x0 = 0.0, x1 = 0.0, pv0 = 0.0, pv1 = 0.0, al = 0.0, as = 0.0;
+        for (int t4 = 0; t4 < T; t4 += 4) {
+          const double4 zl4 = ld4(zl + t4);
+          double4 zs4 = make_double4(0.0, 0.0, 0.0, 0.0);
+          if (s2) zs4 = ld4(zs + t4);
+          double l4[4], g4[4], rn0q[4], rn1q[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {       // r_t = rs[t + 1]
+            const int t1 = t4 + q + 1;
+            rn0q[q] = t1 < T ? rs[(size_t)t1 * D] : 0.0;
+            rn1q[q] = (t1 < T && s2) ? rs[(size_t)t1 * D + 1] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t = t4 + q;
+            l4[q] = 0.0; g4[q] = 0.0;
+            if (t >= T) continue;
+            const double xt0 = h0 + x0, xt1 = h1 + x1;
+            l4[q] = xt0; g4[q] = xt1;
+            if (t > 0) {
+              double dl = xt0 - pv0;
+              if (s2) { dl -= pv1; const double ds = xt1 - pv1; as = fma(ds, ds, as); }
+              al = fma(dl, dl, al);
+            }
+            pv0 = xt0; pv1 = xt1;
+            if (t + 1 < T) {
+              const double rn0 = rn0q[q], rn1 = rn1q[q];
+              if (s2) { h0 += h1; x0 += x1; }
+              h0 = fma(ql, rn0, h0);
+              x0 = fma(sl, at4(zl4, q), x0);
+              if (s2) { h1 = fma(qs, rn1, h1); x1 = fma(ssc, at4(zs4, q), x1); }
+            }
+          }
+          if (lane == 0) {
+            *reinterpret_cast<double4*>(lev + t4) = make_double4(l4[0], l4[1], l4[2], l4[3]);
+            if (s2) *reinterpret_cast<double4*>(slp + t4) = make_double4(g4[0], g4[1], g4[2], g4[3]);
+          }
+        }
+        ssl = al; sss = as; ssd = 0.0;
+      }
+      wave_sync();
+      prof.tick(27);
+      continue;
+    }
 
     // ---- (4) pass 0: simulate x+ (zero initial state) and form y~ = resid - y+.
     // Every pass walks time in blocks of 4 steps so that the per-step scalars arrive as one

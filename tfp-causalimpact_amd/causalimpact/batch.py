@@ -100,12 +100,38 @@ class CausalImpactBatchAnalysis:
   when more than one chain was run."""
 
   def __init__(self, prepared, names, alpha, posterior_means, device_summary, ranks, columns,
-               diagnostics):
+               diagnostic_draws):
     self._prep, self._names, self.alpha = prepared, list(names), alpha
     self._means, self._dsum, self._ranks, self._columns = posterior_means, device_summary, ranks, columns
-    self.diagnostics = diagnostics
+    # {key: [B, chains, draws]} of the scalars the diagnostics rank, or None for one chain.  The
+    # diagnostics themselves (three rank / FFT passes per key per series) are computed on access:
+    # for thousands of series they would otherwise cost more host time than the device fit.
+    self._diag_draws = diagnostic_draws
+    self._diag: Dict[int, Dict] = {}
     self._cache: Dict[int, lib.CausalImpactAnalysis] = {}
     self.summary = self._build_summary()
+
+  def diagnostics_of(self, b: int):
+    """{"split_rhat" | "ess_bulk" | "ess_tail": {key: value}} of series b (None for one chain)."""
+    if self._diag_draws is None:
+      return None
+    b = range(len(self))[b]
+    if b not in self._diag:
+      d = {k: v[b] for k, v in self._diag_draws.items()}
+      self._diag[b] = {
+          "split_rhat": {k: lib.split_rhat(v) for k, v in d.items()},
+          "ess_bulk": {k: lib.effective_sample_size(v, "bulk") for k, v in d.items()},
+          "ess_tail": {k: lib.effective_sample_size(v, "tail") for k, v in d.items()}}
+    return self._diag[b]
+
+  @property
+  def diagnostics(self):
+    """{"split_rhat" | "ess_bulk" | "ess_tail": [per-series {key: value}]} for ALL series (computed
+    now, O(B) host work); None when a single chain was run."""
+    if self._diag_draws is None:
+      return None
+    per = [self.diagnostics_of(b) for b in range(len(self))]
+    return {name: [p[name] for p in per] for name in ("split_rhat", "ess_bulk", "ess_tail")}
 
   def __len__(self):
     return len(self._names)
@@ -217,9 +243,7 @@ class CausalImpactBatchAnalysis:
       rq["ranks"] = self._ranks
       series, summary = lib._compute_impact_device(            # pylint: disable=protected-access
           self._means[b], dsum, rq, ci_data, self.alpha)
-      self._cache[b] = lib.CausalImpactAnalysis(series, summary, None,
-                                                None if self.diagnostics is None else
-                                                {k: v[b] for k, v in self.diagnostics.items()})
+      self._cache[b] = lib.CausalImpactAnalysis(series, summary, None, self.diagnostics_of(b))
     return self._cache[b]
 
   def __iter__(self):
@@ -295,6 +319,9 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
   flags = (~np.asarray(idx < prep.post_period[0])).astype(np.uint8) | (in_post.astype(np.uint8) << 1)
   observed = values[:, prep.model_rows, 0].copy()
   observed[:, prep.num_pre:][:, ~in_post[prep.num_pre:]] = np.nan
+  if not shared_streams and (B > 65536 or C > 65536):
+    raise ValueError("per-series random streams pack (series id, chain id) into 16 bits each: "
+                     "batches beyond 65,536 series or chains need shared_streams=True")
   devs = list(inference_options.devices) if inference_options.devices else [0]
   shards = [s for s in np.array_split(np.arange(B), len(devs)) if len(s)]
 
@@ -323,15 +350,8 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
     results = list(pool.map(lambda a: run(*a), zip(devs, shards)))
   means = np.concatenate([r[0]["posterior_means"].mean(axis=1) for r in results], axis=0)   # [B, T]
   dsum = {k: np.concatenate([r[1][k] for r in results], axis=0) for k in results[0][1]}
-  diagnostics = None
+  diag_draws = None
   if C > 1:
     keys = ("observation_noise_scale", "level_scale")
-    stacked = {k: np.concatenate([r[0][k] for r in results], axis=0) for k in keys}   # [B, C, S]
-    diagnostics = {
-        "split_rhat": [{k: lib.split_rhat(stacked[k][b]) for k in keys} for b in range(B)],
-        "ess_bulk": [{k: lib.effective_sample_size(stacked[k][b], "bulk") for k in keys}
-                     for b in range(B)],
-        "ess_tail": [{k: lib.effective_sample_size(stacked[k][b], "tail") for k in keys}
-                     for b in range(B)],
-    }
-  return CausalImpactBatchAnalysis(prep, names, alpha, means, dsum, ranks, columns, diagnostics)
+    diag_draws = {k: np.concatenate([r[0][k] for r in results], axis=0) for k in keys}   # [B, C, S]
+  return CausalImpactBatchAnalysis(prep, names, alpha, means, dsum, ranks, columns, diag_draws)

@@ -94,3 +94,49 @@ def test_argument_validation_happens_before_any_device_call():
   rc = _native.load().ci_session_create(C.byref(pb), y.ctypes.data, m.ctypes.data, None, None, prm,
                                         C.byref(h))
   assert rc != 0 and b"X is NULL" in _native.load().ci_last_error()
+
+
+def test_round_3_entry_points_validate_before_any_device_call():
+  """ci_fit_gibbs_f64, ci_ll_session_create2 and ci_series_params.weights_prior_scale: argument
+  errors are reported without touching a GPU."""
+  import ctypes as C
+  import numpy as np
+  L = _native.load()
+  T = 30
+  y64 = np.zeros((1, T), np.float64)
+  y32 = np.zeros((1, T), np.float32)
+  m = np.zeros((1, T), np.uint8)
+  spec = dict.fromkeys(_native._PARAM_FIELDS, 1.0)   # pylint: disable=protected-access
+  prm = _native.make_params([spec])
+  assert prm[0].weights_prior_scale == 1.0                       # the reference's prior by default
+  out = _native.Outputs()
+  pb = _native.make_problem(T=T, P=2, has_slope=0, num_warmup=1, num_results=2)
+  assert L.ci_fit_gibbs_f64(C.byref(pb), y64.ctypes.data, m.ctypes.data, None, None, prm, C.byref(out)) != 0
+  assert b"X is NULL" in L.ci_last_error()
+  pb = _native.make_problem(T=T, P=0, has_slope=0, num_seasons=(7,), num_warmup=1, num_results=2)
+  assert L.ci_fit_gibbs_f64(C.byref(pb), y64.ctypes.data, m.ctypes.data, None, None, prm, C.byref(out)) != 0
+  assert b"season_change is NULL" in L.ci_last_error()
+  pb = _native.make_problem(T=T, P=0, has_slope=0, num_seasons=(40, 40), num_warmup=1, num_results=2)
+  sc = np.zeros((2, T), np.uint8)
+  assert L.ci_fit_gibbs_f64(C.byref(pb), y64.ctypes.data, m.ctypes.data, None, sc.ctypes.data, prm,
+                            C.byref(out)) != 0
+  assert b"too wide" in L.ci_last_error()
+  # log-likelihood sessions: blocks need create2's season_change; P is capped at 52 there
+  h = C.c_void_p()
+  pb = _native.make_problem(T=T, P=0, has_slope=0, num_seasons=(7,), num_warmup=0, num_results=1)
+  assert L.ci_ll_session_create(C.byref(pb), prm, y32.ctypes.data, m.ctypes.data, None, 4, C.byref(h)) != 0
+  assert b"ci_ll_session_create2" in L.ci_last_error()
+  assert L.ci_ll_session_create2(C.byref(pb), prm, y32.ctypes.data, m.ctypes.data, None, None, 4,
+                                 C.byref(h)) != 0
+  assert b"season_change is NULL" in L.ci_last_error()
+  pb = _native.make_problem(T=T, P=60, has_slope=0, num_warmup=0, num_results=1)
+  X = np.zeros((T, 60), np.float32)
+  assert L.ci_ll_session_create2(C.byref(pb), prm, y32.ctypes.data, m.ctypes.data, X.ctypes.data, None,
+                                 4, C.byref(h)) != 0
+  assert b"P must be <= 52" in L.ci_last_error()
+  # a non-positive multiplier of the weights-prior precision is rejected
+  bad = _native.make_params([dict(spec, weights_prior_scale=0.0)])
+  pb = _native.make_problem(T=T, P=0, has_slope=0, num_warmup=0, num_results=1)
+  assert L.ci_ll_session_create2(C.byref(pb), bad, y32.ctypes.data, m.ctypes.data, None, None, 4,
+                                 C.byref(h)) != 0
+  assert b"weights_prior_scale" in L.ci_last_error()

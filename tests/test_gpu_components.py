@@ -182,11 +182,14 @@ def test_latent_draws_for_given_parameters_match_oracle():
     (5000, 2, 1, ()),                            # no block, T > 4096: the sequential route too
     (6000, 1, 0, ((7, 1),)),
 ])
-def test_sequential_loglik_and_score_match_the_oracle(T, p, has_slope, seasons):
-  """Row H for seasonal models and long series (csrc/ci_score_seq.h, one wavefront per
-  evaluation) against the oracle's ANALYTIC log-likelihood and score (ci_oracle_loglik_score,
-  itself pinned to central differences in tests/test_oracle_hmc.py): l, dl/d(sigma_obs,
-  sigma_level, sigma_slope, sigma_drift[K]) and dl/d beta = X'e."""
+@pytest.mark.parametrize("route", ["auto", "sequential"])
+def test_sequential_loglik_and_score_match_the_oracle(T, p, has_slope, seasons, route):
+  """Row H for seasonal models and long series against the oracle's ANALYTIC log-likelihood and
+  score (ci_oracle_loglik_score, itself pinned to central differences in
+  tests/test_oracle_hmc.py): l, dl/d(sigma_obs, sigma_level, sigma_slope, sigma_drift[K]) and
+  dl/d beta = X'e.  route "auto": trend + one block of 2-7 seasons and long trend-only series take
+  the TIME-PARALLEL scans (csrc/ci_wide_score.h: filter scan + one merged (r, N) suffix scan), the
+  rest the sequential one-wavefront route (csrc/ci_score_seq.h); "sequential" forces the latter."""
   from causalimpact import _model
   from causalimpact import _synthetic as syn
   y, mask, X, _ = syn.make_sampler_inputs(T, max(p, 1), 21)
@@ -206,9 +209,12 @@ def test_sequential_loglik_and_score_match_the_oracle(T, p, has_slope, seasons):
   theta[:, 3:3 + K] = rng.uniform(0.01, 0.1, (E, K))
   theta[:, 3 + K:] = 0.3 * rng.normal(size=(E, P))
   pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_seasons=counts, num_warmup=0,
-                            num_results=1)
+                            num_results=1,
+                            flags=_native.FLAG_SEQUENTIAL_SEASONAL if route == "sequential" else 0)
   sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8,
                                season_change=flg)
+  wide = route == "auto" and K <= 1
+  assert ("hmc_wide_kernel" in sess.kernel_name()) == wide, sess.kernel_name()
   ll, grad = sess.evaluate(theta)
   ll_only, _ = sess.evaluate(theta, want_grad=False)
   np.testing.assert_array_equal(ll, ll_only)

@@ -261,7 +261,8 @@ def test_cfg3_full_size_64_chains_as_8_launches_and_against_oracle_and_gibbs():
     (160, 3, 1, ((4, 3), (7, 1)), "horseshoe"),
     (4500, 1, 0, (), "slab"),                     # no block, T > 4096: the sequential route too
 ])
-def test_sequential_route_hmc_tracks_the_oracle_draw_for_draw(T, p, has_slope, seasons, prior):
+@pytest.mark.parametrize("route", ["auto", "sequential"])
+def test_sequential_route_hmc_tracks_the_oracle_draw_for_draw(T, p, has_slope, seasons, prior, route):
   """Row H for seasonal models / long series: hmc_seq_kernel (csrc/ci_score_seq.h: hmc_kernel's
   driver over the one-wavefront score) against ci_oracle_fit_hmc -- same target, adaptation and
   random stream, so the first iterations agree draw for draw; then the latent pass (the sequential
@@ -275,11 +276,18 @@ def test_sequential_route_hmc_tracks_the_oracle_draw_for_draw(T, p, has_slope, s
   spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
   counts, flg = _model.expand_seasons(seasons, T)
   K = len(seasons)
+  if route == "sequential" and K > 1:
+    pytest.skip("two blocks: the same route as 'auto'")
   pb = _native.make_problem(T=T, P=p + 1, has_slope=has_slope, num_seasons=counts, num_warmup=0,
-                            num_results=1, seed=(3, 4))
+                            num_results=1, seed=(3, 4),
+                            flags=_native.FLAG_SEQUENTIAL_SEASONAL if route == "sequential" else 0)
   sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=4,
                                season_change=flg)
-  assert sess.kernel_name() == "ci::hmc_seq_kernel"
+  # "auto": one block of 2-7 seasons / a long trend-only series -> the time-parallel scans
+  # (hmc_wide_kernel, csrc/ci_wide_score.h); two blocks -> the sequential route either way
+  want_kernel = ("ci::hmc_wide_kernel<%d,%d>" % (1 + has_slope, counts[0] if K == 1 else 2)
+                 if route == "auto" and K <= 1 else "ci::hmc_seq_kernel")
+  assert sess.kernel_name() == want_kernel
   W, S, C, NL = 20, 2, 2, 3
   sess.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=NL, seed=(3, 4),
                chain_offset=5, prior=prior)

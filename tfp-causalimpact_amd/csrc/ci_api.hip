@@ -23,6 +23,7 @@
 #include "ci_hmc.h"
 #include "ci_score_seq.h"
 #include "ci_gibbs64.h"
+#include "ci_wide_score.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(int);
 extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs*, int, hipStream_t);
@@ -30,7 +31,11 @@ extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs*, int, hipStream_t);
 extern "C" void ci_launch_gibbs64(const ci::G64Args*, int, size_t, int, hipStream_t);
 #define CI_WIDE_DECL(NS)                                  \
   extern "C" void* ci_gibbs_wide_fn_tr1_ns##NS(void);     \
-  extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);
+  extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);     \
+  extern "C" void ci_launch_wide_score_tr1_ns##NS(const ci::WideScoreArgs*, hipStream_t);  \
+  extern "C" void ci_launch_wide_score_tr2_ns##NS(const ci::WideScoreArgs*, hipStream_t);  \
+  extern "C" void ci_launch_hmc_wide_tr1_ns##NS(const ci::HmcWideArgs*, hipStream_t);      \
+  extern "C" void ci_launch_hmc_wide_tr2_ns##NS(const ci::HmcWideArgs*, hipStream_t);
 CI_WIDE_DECL(2) CI_WIDE_DECL(3) CI_WIDE_DECL(4) CI_WIDE_DECL(5) CI_WIDE_DECL(6) CI_WIDE_DECL(7)
 #undef CI_WIDE_DECL
 
@@ -1297,6 +1302,19 @@ int ci_test_rng(int device, const uint32_t seed[2], uint32_t chain, uint32_t ite
 // draws per workgroup in the HMC fit's latent pass (their predictor sums stay in registers)
 constexpr int HMC_LATENT_GROUP = 8;
 
+namespace {
+void launch_wide_score(int D, int ns, const ci::WideScoreArgs* a, hipStream_t st) {
+#define CI_WS_CASE(NS) if (ns == NS) { if (D == 2) ci_launch_wide_score_tr2_ns##NS(a, st); else ci_launch_wide_score_tr1_ns##NS(a, st); return; }
+  CI_WS_CASE(2) CI_WS_CASE(3) CI_WS_CASE(4) CI_WS_CASE(5) CI_WS_CASE(6) CI_WS_CASE(7)
+#undef CI_WS_CASE
+}
+void launch_hmc_wide(int D, int ns, const ci::HmcWideArgs* a, hipStream_t st) {
+#define CI_WH_CASE(NS) if (ns == NS) { if (D == 2) ci_launch_hmc_wide_tr2_ns##NS(a, st); else ci_launch_hmc_wide_tr1_ns##NS(a, st); return; }
+  CI_WH_CASE(2) CI_WH_CASE(3) CI_WH_CASE(4) CI_WH_CASE(5) CI_WH_CASE(6) CI_WH_CASE(7)
+#undef CI_WH_CASE
+}
+}  // namespace
+
 struct ci_ll_session {
   int T = 0, P = 0, D = 1, L = 1, device = 0, max_evals = 0;
   float a1 = 0, p10 = 0, p11 = 0, p1e = 0;
@@ -1306,6 +1324,8 @@ struct ci_ll_session {
   DevBuf<uint8_t> season_change;
   DevBuf<float> seq_ws;
   size_t seq_ws_evals = 0;          // evaluations seq_ws has room for
+  bool wide = false;                // ... on the time-parallel scans (ci_wide_score.h): d <= 8
+  int wide_ns = 2, Lc = 0;
   int dred = 1;
   ci_problem spb;                   // the problem (geometry) for the latent pass
   DevBuf<ci::DevSeriesParams> d_sp;
@@ -1356,7 +1376,13 @@ int ci_ll_session_create2(const ci_problem* pb, const ci_series_params* params, 
   const bool seq = pb->num_blocks > 0 || steps_per_thread(pb->T) == 0;
   int dfull = pb->has_slope ? 2 : 1;
   for (int k = 0; k < pb->num_blocks; ++k) dfull += pb->num_seasons[k];
-  if (seq && dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
+  // trend + one block of 2-7 seasons (or a long trend-only series: an inert 2-season block) run on
+  // the time-parallel scans of ci_wide_score.h; everything else sequentially (ci_score_seq.h)
+  const bool wide_ll = seq && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
+                       wide_steps_per_thread(pb->T) <= ci::WIDE_MAX_LC &&
+                       (pb->num_blocks == 0 ||
+                        (pb->num_blocks == 1 && pb->num_seasons[0] >= 2 && pb->num_seasons[0] <= 7));
+  if (seq && !wide_ll && dfull > 64) return fail("seasonal state too wide for one wavefront: %d > 64", dfull);
   HIP_TRY(hipSetDevice(pb->device));
   ci_ll_session* s = new ci_ll_session();
   LlSessionGuard guard{s};
@@ -1380,8 +1406,13 @@ int ci_ll_session_create2(const ci_problem* pb, const ci_series_params* params, 
   HIP_TRY(s->theta.alloc((size_t)max_evals * (3 + K + P)));
   HIP_TRY(s->ll.alloc(max_evals));
   HIP_TRY(s->grad.alloc((size_t)max_evals * (3 + K + P)));
+  s->wide = wide_ll;
+  s->wide_ns = pb->num_blocks == 1 ? pb->num_seasons[0] : 2;
+  s->Lc = wide_ll ? wide_steps_per_thread(T) : 0;
   if (seq) {
-    HIP_TRY(s->seq_ws.alloc((size_t)max_evals * ci::seq_score_ws_floats(T, dfull)));
+    const size_t per_eval = wide_ll ? ci::wide_score_ws_floats(s->D + s->wide_ns - 1, s->Lc)
+                                    : ci::seq_score_ws_floats(T, dfull);
+    HIP_TRY(s->seq_ws.alloc((size_t)max_evals * per_eval));
     s->seq_ws_evals = (size_t)max_evals;
     s->spb = *pb;
     s->dred = dfull - K;
@@ -1448,7 +1479,9 @@ static int hmc_run_sequential(ci_ll_session* s, const ci_hmc_options* o, const d
   const int dim = (o->prior == CI_HMC_PRIOR_HORSESHOE ? 3 * P + 2 : P) + nsc;
   if ((size_t)C > s->seq_ws_evals) {
     s->seq_ws.release();
-    HIP_TRY(s->seq_ws.alloc((size_t)C * ci::seq_score_ws_floats(T, s->D_full)));
+    const size_t per_eval = s->wide ? ci::wide_score_ws_floats(s->D + s->wide_ns - 1, s->Lc)
+                                    : ci::seq_score_ws_floats(T, s->D_full);
+    HIP_TRY(s->seq_ws.alloc((size_t)C * per_eval));
     s->seq_ws_evals = (size_t)C;
   }
   if (init_theta) {
@@ -1482,7 +1515,13 @@ static int hmc_run_sequential(ci_ll_session* s, const ci_hmc_options* o, const d
   a.init = init_theta ? s->h_init.p : nullptr;
   a.draws = s->h_draws.p; a.accept_rate = s->h_acc.p; a.step_size = s->h_eps.p;
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
-  ci_launch_hmc_seq(&a, s->D_full, s->stream);
+  if (s->wide) {
+    ci::HmcWideArgs wa;
+    wa.h = a; wa.Lc = s->Lc; wa.ws = s->seq_ws.p;
+    launch_hmc_wide(s->D, s->wide_ns, &wa, s->stream);
+  } else {
+    ci_launch_hmc_seq(&a, s->D_full, s->stream);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, s->stream));
   // ---- latent path + predictive trajectory of every retained draw
@@ -1662,7 +1701,8 @@ int ci_ll_session_hmc_fetch(ci_ll_session* s, double* draws, double* accept_rate
 int ci_ll_session_kernel_name(const ci_ll_session* s, char* buf, int32_t buflen) {
   if (!s) return fail("session is NULL");
   char nm[64];
-  if (s->seq) snprintf(nm, sizeof(nm), "ci::hmc_seq_kernel");
+  if (s->wide) snprintf(nm, sizeof(nm), "ci::hmc_wide_kernel<%d,%d>", s->D, s->wide_ns);
+  else if (s->seq) snprintf(nm, sizeof(nm), "ci::hmc_seq_kernel");
   else snprintf(nm, sizeof(nm), "ci::hmc_kernel<%d,%d>", s->D, s->L);
   return copy_name(nm, buf, buflen);
 }
@@ -1694,7 +1734,13 @@ int ci_ll_session_eval(ci_ll_session* s, int32_t num_evals, const double* theta,
     qa.y = s->y.p; qa.mask = s->mask.p; qa.Xt = s->xt.p; qa.season_change = s->season_change.p;
     qa.theta = s->theta.p; qa.a1 = s->a1; qa.p10 = s->p10; qa.p11 = s->p11; qa.p1e = s->p1e;
     qa.out_ll = s->ll.p; qa.out_grad = grad ? s->grad.p : nullptr; qa.ws = s->seq_ws.p;
-    ci_launch_seq_score(&qa, s->D_full, 0);
+    if (s->wide) {
+      ci::WideScoreArgs wa;
+      wa.q = qa; wa.Lc = s->Lc; wa.ws = s->seq_ws.p;
+      launch_wide_score(D, s->wide_ns, &wa, 0);
+    } else {
+      ci_launch_seq_score(&qa, s->D_full, 0);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(loglik, s->ll.p, E * sizeof(double), hipMemcpyDeviceToHost));
     if (grad) HIP_TRY(hipMemcpy(grad, s->grad.p, (size_t)E * dimt * sizeof(double), hipMemcpyDeviceToHost));

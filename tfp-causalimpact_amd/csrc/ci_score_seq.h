@@ -402,9 +402,11 @@ __host__ __device__ inline size_t hmc_seq_lds_bytes(int D, int K) {
   return sizeof(double) * hmc_seq_dbl_count() + ((seq_score_lds_bytes(D, K) + 15) & ~(size_t)15);
 }
 
-#ifndef CI_SEASONAL_DECL_ONLY
-__global__ __launch_bounds__(NT) void hmc_seq_kernel(HmcSeqArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+// The driver.  `score(dev, gdev, ll_out)` is called by ALL threads of the workgroup with uniform
+// control flow; it evaluates l and its gradient at the device-layout parameters `dev` into
+// *ll_out / `gdev` (same layout) and ends with a barrier.  smem_s: hmc_seq_dbl_count() doubles.
+template <class Score>
+__device__ __forceinline__ void hmc_drive(const HmcSeqArgs& a, unsigned char* smem_s, Score& score) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int P = a.q.P, K = a.q.K;
@@ -425,11 +427,8 @@ __global__ __launch_bounds__(NT) void hmc_seq_kernel(HmcSeqArgs a) {
   double* gdev = dev + (MAXP + 3 + SMAXK);
   double* hsc = gdev + (MAXP + 3 + SMAXK);
   double* sc = hsc + MAXP;
-  unsigned char* smem_score = (unsigned char*)(sc + 8);
   const int chain = blockIdx.x;
   Rng rng{a.seed0, a.seed1, (uint32_t)(a.chain_offset + chain)};
-  const SeqGeom geo = seq_geometry(K, a.q.has_slope, a.q.nseas, lane);
-  float* ws = a.q.ws + (size_t)chain * seq_score_ws_floats(a.q.T, geo.D);
   // theta's scale k -> slot of the device layout
   auto slot = [&](int k) { return k < ntr ? k : 3 + (k - ntr); };
 
@@ -451,11 +450,7 @@ __global__ __launch_bounds__(NT) void hmc_seq_kernel(HmcSeqArgs a) {
     if (tid >= 64 && tid < 64 + nsc) dev[slot(tid - 64)] = exp(clamp30(th[off_sc + tid - 64]));
     if (!a.q.has_slope && tid == 128) dev[2] = 0.0;
     __syncthreads();
-    if (wave == 0) {
-      const double ll = seq_loglik_score(a.q, geo, dev, gdev, ws, smem_score, lane);
-      if (lane == 0) sc[0] = ll;
-    }
-    __syncthreads();
+    score(dev, gdev, &sc[0]);
     if (wave == 0) {
       double sgb = 0.0;
       if (hs) {
@@ -624,6 +619,36 @@ __global__ __launch_bounds__(NT) void hmc_seq_kernel(HmcSeqArgs a) {
     a.accept_rate[chain] = accepted / (double)(a.S > 0 ? a.S : 1);
     a.step_size[chain] = eps;
   }
+}
+
+#ifndef CI_SEASONAL_DECL_ONLY
+// The sequential route: wave 0 evaluates the score (seq_loglik_score), the others wait.
+struct SeqScoreFn {
+  const SeqScoreArgs* q;
+  SeqGeom geo;
+  float* ws;
+  unsigned char* smem;
+  int lane, wave;
+  __device__ __forceinline__ void operator()(const double* dev, double* gdev, double* ll_out) {
+    if (wave == 0) {
+      const double ll = seq_loglik_score(*q, geo, dev, gdev, ws, smem, lane);
+      if (lane == 0) *ll_out = ll;
+    }
+    __syncthreads();
+  }
+};
+
+__global__ __launch_bounds__(NT) void hmc_seq_kernel(HmcSeqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  SeqScoreFn fn;
+  fn.q = &a.q;
+  fn.geo = seq_geometry(a.q.K, a.q.has_slope, a.q.nseas, lane);
+  fn.ws = a.q.ws + (size_t)blockIdx.x * seq_score_ws_floats(a.q.T, fn.geo.D);
+  fn.smem = smem_s + sizeof(double) * hmc_seq_dbl_count();
+  fn.lane = lane;
+  fn.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  hmc_drive(a, smem_s, fn);
 }
 #endif
 

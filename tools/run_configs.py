@@ -98,19 +98,29 @@ def extras():
   out.append({"config": "T=1000, 100 covariates (P=101)", "kernel": sess.kernel_name(), "chains": C,
               "kernel_ms": ms, "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": C * S / ms * 1e3})
   sess.close()
-  # HMC with a weekly block (sequential score, csrc/ci_score_seq.h)
-  T, p, W, S, C, NL = 1000, 10, 100, 100, 8, 15
-  y, mask, X, _ = syn.make_sampler_inputs(T, p, 2024)
-  spec = _model.series_params(y, mask, X, num_seasonal_blocks=1)
-  counts, flg = _model.expand_seasons((ci.Seasons(num_seasons=7),), T)
-  pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_seasons=counts, num_warmup=0, num_results=1,
-                            seed=(0, 1))
-  ll = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8, season_change=flg)
-  hmc_ms, lat_ms = ll.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=NL, seed=(0, 1))
-  out.append({"config": "T=1000, 10 covariates + Seasonal(7), HMC", "kernel": ll.kernel_name(), "chains": C,
-              "kernel_ms": hmc_ms, "latents_ms": lat_ms, "us_per_leapfrog": hmc_ms * 1e3 / ((W + S) * NL),
-              "samples_per_s": C * S / (hmc_ms + lat_ms) * 1e3})
-  ll.close()
+  # HMC with a weekly block: the time-parallel scans (csrc/ci_wide_score.h) and, forced, the
+  # sequential one-wavefront route (csrc/ci_score_seq.h); and a long trend-only series
+  for label, T, seasons, slope, flags in (
+      ("T=1000, 10 covariates + Seasonal(7), HMC", 1000, (ci.Seasons(num_seasons=7),), 0, 0),
+      ("T=1000, 10 covariates + Seasonal(7), HMC, sequential route forced", 1000,
+       (ci.Seasons(num_seasons=7),), 0, _native.FLAG_SEQUENTIAL_SEASONAL),
+      ("T=8000, 10 covariates, local linear trend, HMC", 8000, (), 1, 0),
+      ("T=8000, 10 covariates, local linear trend, HMC, sequential route forced", 8000, (), 1,
+       _native.FLAG_SEQUENTIAL_SEASONAL)):
+    p, W, S, C, NL = 10, 100, 100, 8, 15
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 2024)
+    spec = _model.series_params(y, mask, X, has_slope=bool(slope), num_seasonal_blocks=len(seasons))
+    counts, flg = _model.expand_seasons(seasons, T)
+    pb = _native.make_problem(T=T, P=p + 1, has_slope=slope, num_seasons=counts, num_warmup=0,
+                              num_results=1, seed=(0, 1), flags=flags)
+    ll = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8,
+                               season_change=flg if seasons else None)
+    hmc_ms, lat_ms = ll.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=NL, seed=(0, 1))
+    out.append({"config": label, "kernel": ll.kernel_name(), "chains": C,
+                "kernel_ms": hmc_ms, "latents_ms": lat_ms,
+                "us_per_leapfrog": hmc_ms * 1e3 / ((W + S) * NL),
+                "samples_per_s": C * S / (hmc_ms + lat_ms) * 1e3})
+    ll.close()
   return out
 
 

@@ -14,6 +14,7 @@ names, argument meaning, result frames and error behaviour.  What changed undern
 Host-side post-processing (reference :635-1093) is re-implemented on numpy arrays and pinned
 against the reference's own output by tests/test_golden_postprocessing.py.
 """
+import collections.abc
 import dataclasses
 import math
 from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
@@ -43,6 +44,32 @@ class Tensor(np.ndarray):
 
 def _tensor(a) -> Tensor:
   return np.asarray(a).view(Tensor)
+
+
+class _LazyMapping(collections.abc.Mapping):
+  """A read-only dict whose content is computed on first use (the convergence diagnostics cost
+  as much host time as a third of the fit; most callers never read them)."""
+
+  def __init__(self, make):
+    self._make, self._value = make, None
+
+  def _get(self):
+    if self._value is None:
+      self._value = dict(self._make())
+      self._make = None
+    return self._value
+
+  def __getitem__(self, key):
+    return self._get()[key]
+
+  def __iter__(self):
+    return iter(self._get())
+
+  def __len__(self):
+    return len(self._get())
+
+  def __repr__(self):
+    return repr(self._get())
 
 
 @dataclasses.dataclass
@@ -349,9 +376,12 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
       sess = _native.Session(pb, y[None], mask[None], None if design is None else design[None],
                              season_change, _native.make_params([params]))
       try:
-        sess.run()
-        part = sess.fetch([k for k in _native._OUT_FIELDS  # pylint: disable=protected-access
-                           if k != "posterior_trajectories"])
+        # the draws travel to (pinned) host memory while the sampler runs; the trajectories stay
+        # on the device for the summary kernels
+        _, part = sess.run_streamed(
+            want=[k for k in _native._OUT_FIELDS  # pylint: disable=protected-access
+                  if k != "posterior_trajectories" and (k != "slope" or local_linear_trend)],
+            chunk_draws=32)
         summary_request["ranks"] = _summary_ranks(len(chain_ids) * num_results,
                                                   summary_request["quantiles"])
         # value = trajectory * scale + shift, the trajectory being in the internal units
@@ -391,14 +421,15 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
   samples = dict(
       observation_noise_scale=pool(out["observation_noise_scale"]),
       level_scale=pool(out["level_scale"]), slope_scale=pool(out["slope_scale"]),
-      weights=pool(out["weights"]), level=pool(out["level"]), slope=pool(out["slope"]),
+      weights=pool(out["weights"]), level=pool(out["level"]),
+      slope=pool(out["slope"]) if "slope" in out else None,
       seasonal_drift_scales=pool(out["seasonal_drift_scales"]),
       seasonal_levels=pool(out["seasonal_levels"]))
   assert samples["weights"].shape[-1] == P and samples["seasonal_levels"].shape[-1] == K
   if num_chains > 1:
-    samples["diagnostics"] = _diagnostics.summarize(
-        {k: out[k] for k in ("observation_noise_scale", "level_scale")})
-    samples["diagnostics"]["num_chains"] = num_chains
+    scalars = {k: out[k] for k in ("observation_noise_scale", "level_scale")}
+    samples["diagnostics"] = _LazyMapping(
+        lambda: dict(_diagnostics.summarize(scalars), num_chains=num_chains))
   # the predictive arrays feed the data-scale summaries: with internal conditioning they carry the
   # offset again and stay float64 (float32 would round 100.0001 to 8e-6 steps)
   pred_dtype = np.float64 if (cond_mu, cond_s) != (0.0, 1.0) else np_dtype

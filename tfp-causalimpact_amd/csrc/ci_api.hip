@@ -242,6 +242,66 @@ void pool_free(void* p, size_t bytes, int dev) {
   (void)hipFree(p);
 }
 
+// Streams and events are recycled too: hipStreamCreate / hipStreamDestroy cost about a
+// millisecond each on this runtime, four of them per fit.  A parked stream is idle (it is
+// synchronised before it is parked) and carries no state of the session that used it.
+struct StreamEntry { hipStream_t s; int device; };
+struct EventEntry { hipEvent_t e; int device; };
+std::vector<StreamEntry> g_stream_pool;
+std::vector<EventEntry> g_event_pool;
+
+hipError_t pool_stream_get(hipStream_t* out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); ++i)
+      if (g_stream_pool[i].device == dev) {
+        *out = g_stream_pool[i].s;
+        g_stream_pool[i] = g_stream_pool.back();
+        g_stream_pool.pop_back();
+        return hipSuccess;
+      }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void pool_stream_put(hipStream_t st, int dev) {
+  if (!st) return;
+  if (hipStreamSynchronize(st) == hipSuccess) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_stream_pool.size() < 64) { g_stream_pool.push_back({st, dev}); return; }
+  }
+  (void)hipStreamDestroy(st);
+}
+
+hipError_t pool_event_get(hipEvent_t* out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_event_pool.size(); ++i)
+      if (g_event_pool[i].device == dev) {
+        *out = g_event_pool[i].e;
+        g_event_pool[i] = g_event_pool.back();
+        g_event_pool.pop_back();
+        return hipSuccess;
+      }
+  }
+  return hipEventCreate(out);
+}
+
+void pool_event_put(hipEvent_t ev, int dev) {
+  if (!ev) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_event_pool.size() < 128) { g_event_pool.push_back({ev, dev}); return; }
+  }
+  (void)hipEventDestroy(ev);
+}
+
 // Pinned host buffers (ci_host_alloc) are recycled the same way: pinning 100 MB costs tens of
 // milliseconds, several fits' worth.
 struct HostEntry { void* p; size_t bytes; };
@@ -475,6 +535,10 @@ int ci_pool_trim(void) {
   for (auto& pe : g_pool) { (void)hipSetDevice(pe.device); (void)hipFree(pe.p); }
   g_pool.clear();
   g_pool_bytes = 0;
+  for (auto& se : g_stream_pool) { (void)hipSetDevice(se.device); (void)hipStreamDestroy(se.s); }
+  g_stream_pool.clear();
+  for (auto& ee : g_event_pool) { (void)hipSetDevice(ee.device); (void)hipEventDestroy(ee.e); }
+  g_event_pool.clear();
   (void)hipSetDevice(dev);
   return 0;
 }
@@ -634,9 +698,9 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     HIP_TRY(hipFuncSetAttribute((const void*)s->fn_prof, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_prof));
   }
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&s->ev0));
-  HIP_TRY(hipEventCreate(&s->ev1));
+  HIP_TRY(pool_stream_get(&s->stream));
+  HIP_TRY(pool_event_get(&s->ev0));
+  HIP_TRY(pool_event_get(&s->ev1));
 
   const size_t BT = (size_t)B * T, BCS = (size_t)B * C * S;
   HIP_TRY(s->y.alloc(BT));
@@ -832,7 +896,7 @@ int ci_session_run_streamed(ci_session* s, ci_outputs* o, int32_t chunk_draws, f
   HIP_TRY(hipSetDevice(pb.device));
   const int S = pb.num_results, T = pb.T, K = pb.num_blocks;
   const size_t BC = (size_t)pb.num_series * pb.num_chains;
-  if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  if (!s->copy_stream) HIP_TRY(pool_stream_get(&s->copy_stream));
   // the register-resident kernel publishes its progress; the seasonal kernels do not (their
   // results are copied in the same chunks once the kernel has finished)
   const bool live = s->kpb.num_blocks == 0 && s->kpb.P <= ci::MAXP;
@@ -1118,10 +1182,10 @@ int ci_session_destroy(ci_session* s) {
   s->o_seasonal.release(); s->ws.release(); s->csync.release(); s->cpart.release(); s->cw.release(); s->cv.release();
   s->s_value.release(); s->s_cum.release(); s->s_obs.release(); s->s_flags.release();
   s->s_ranks.release(); s->s_order.release(); s->s_draw.release();
-  if (s->ev0) (void)hipEventDestroy(s->ev0);
-  if (s->ev1) (void)hipEventDestroy(s->ev1);
-  if (s->stream) (void)hipStreamDestroy(s->stream);
-  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+  pool_event_put(s->ev0, s->pb.device);
+  pool_event_put(s->ev1, s->pb.device);
+  pool_stream_put(s->stream, s->pb.device);
+  pool_stream_put(s->copy_stream, s->pb.device);
   if (s->progress) (void)hipHostFree(s->progress);
   delete s;
   return 0;
@@ -1391,10 +1455,10 @@ int ci_ll_session_create2(const ci_problem* pb, const ci_series_params* params, 
   s->seq = seq; s->K = pb->num_blocks; s->D_full = dfull;
   for (int k = 0; k < pb->num_blocks; ++k) s->nseas[k] = pb->num_seasons[k];
   s->p1e = (float)(params->init_seasonal_scale * params->init_seasonal_scale);
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&s->ev0));
-  HIP_TRY(hipEventCreate(&s->ev1));
-  HIP_TRY(hipEventCreate(&s->ev2));
+  HIP_TRY(pool_stream_get(&s->stream));
+  HIP_TRY(pool_event_get(&s->ev0));
+  HIP_TRY(pool_event_get(&s->ev1));
+  HIP_TRY(pool_event_get(&s->ev2));
   s->a1 = (float)params->init_level_loc;
   s->p10 = (float)(params->init_level_scale * params->init_level_scale);
   s->p11 = (float)(params->init_slope_scale * params->init_slope_scale);
@@ -1809,10 +1873,10 @@ int ci_ll_session_destroy(ci_ll_session* s) {
   s->h_level.release(); s->h_slope.release(); s->h_part.release(); s->h_traj.release();
   s->h_pm.release(); s->h_obs.release(); s->h_lscale.release(); s->h_sscale.release();
   s->h_w.release();
-  if (s->ev0) (void)hipEventDestroy(s->ev0);
-  if (s->ev1) (void)hipEventDestroy(s->ev1);
-  if (s->ev2) (void)hipEventDestroy(s->ev2);
-  if (s->stream) (void)hipStreamDestroy(s->stream);
+  pool_event_put(s->ev0, s->device);
+  pool_event_put(s->ev1, s->device);
+  pool_event_put(s->ev2, s->device);
+  pool_stream_put(s->stream, s->device);
   delete s;
   return 0;
 }

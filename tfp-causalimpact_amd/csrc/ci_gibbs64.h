@@ -13,7 +13,9 @@
 // Consequence: the device and the float64 oracle (oracle/ci_oracle.c) run the same arithmetic up
 // to summation order, so they agree draw for draw to ~1e-9 over whole fits
 // (tests/test_gpu_float64.py) -- a far tighter pin of the device algorithm than the float32
-// kernels' 5e-3.  It is the precision option, not the fast one (sequential in time).
+// kernels' 5e-3.  It is the precision option, not the fast one: sequential in time for models
+// with seasonal blocks; trend-only models (the reference's default) are time-parallel over the
+// 64 lanes of the chain's wavefront (Drift2 / Kf2 / Aff2 below).
 #pragma once
 #include "ci_seasonal.h"
 #include "ci_hmc.h"       // wave_sum_d
@@ -132,6 +134,124 @@ __device__ __forceinline__ double scale_draw_d(double conc, double scale, double
 }
 
 #ifndef CI_SEASONAL_DECL_ONLY
+// ---- time-parallel pieces of the trend-only path (one wavefront, lane j owns Lc consecutive
+// steps): every pass over time is  (i) summarise the own chunk as an element of a semigroup,
+// (ii) scan the 64 elements across the lanes, (iii) replay the own chunk from the true incoming
+// state.  Float64 throughout; the elements are those of ci_kernels.h's float32 scans for d = 2.
+__device__ __forceinline__ double shfl_up_d(double v, int off) { return __shfl_up(v, (unsigned)off, 64); }
+__device__ __forceinline__ double shfl_down_d(double v, int off) { return __shfl_down(v, (unsigned)off, 64); }
+
+// x -> T^n x + c with T = [[1, 1], [0, 1]] (level += slope): the prior simulation and the
+// reconstruction recursions.  then(a, b) = b after a.
+struct Drift2 { double n, c0, c1; };
+__device__ __forceinline__ Drift2 drift2_then(const Drift2& a, const Drift2& b) {
+  Drift2 r;
+  r.n = a.n + b.n;
+  r.c0 = fma(b.n, a.c1, a.c0) + b.c0;
+  r.c1 = a.c1 + b.c1;
+  return r;
+}
+// exclusive forward scan: lane j receives e_0 then ... then e_{j-1} (lane 0: the identity)
+__device__ __forceinline__ Drift2 drift2_scan_excl(Drift2 e, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    Drift2 o;
+    o.n = shfl_up_d(e.n, off); o.c0 = shfl_up_d(e.c0, off); o.c1 = shfl_up_d(e.c1, off);
+    if (lane >= off) e = drift2_then(o, e);
+  }
+  Drift2 x;
+  x.n = shfl_up_d(e.n, 1); x.c0 = shfl_up_d(e.c0, 1); x.c1 = shfl_up_d(e.c1, 1);
+  if (lane == 0) { x.n = 0.0; x.c0 = 0.0; x.c1 = 0.0; }
+  return x;
+}
+
+// x -> M x + c, general 2 x 2 (the backward recursion r_{t-1} = L_t' r_t + z v_t / F_t)
+struct Aff2 { double m00, m01, m10, m11, c0, c1; };
+__device__ __forceinline__ Aff2 aff2_then(const Aff2& a, const Aff2& b) {
+  Aff2 r;
+  r.m00 = fma(b.m00, a.m00, b.m01 * a.m10); r.m01 = fma(b.m00, a.m01, b.m01 * a.m11);
+  r.m10 = fma(b.m10, a.m00, b.m11 * a.m10); r.m11 = fma(b.m10, a.m01, b.m11 * a.m11);
+  r.c0 = fma(b.m00, a.c0, fma(b.m01, a.c1, b.c0));
+  r.c1 = fma(b.m10, a.c0, fma(b.m11, a.c1, b.c1));
+  return r;
+}
+// exclusive BACKWARD scan: lane j receives e_63 then ... then e_{j+1} (lane 63: the identity)
+__device__ __forceinline__ Aff2 aff2_scan_excl_bwd(Aff2 e, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    Aff2 o;
+    o.m00 = shfl_down_d(e.m00, off); o.m01 = shfl_down_d(e.m01, off);
+    o.m10 = shfl_down_d(e.m10, off); o.m11 = shfl_down_d(e.m11, off);
+    o.c0 = shfl_down_d(e.c0, off); o.c1 = shfl_down_d(e.c1, off);
+    if (lane + off < 64) e = aff2_then(o, e);
+  }
+  Aff2 x;
+  x.m00 = shfl_down_d(e.m00, 1); x.m01 = shfl_down_d(e.m01, 1);
+  x.m10 = shfl_down_d(e.m10, 1); x.m11 = shfl_down_d(e.m11, 1);
+  x.c0 = shfl_down_d(e.c0, 1); x.c1 = shfl_down_d(e.c1, 1);
+  if (lane == 63) { x.m00 = 1.0; x.m01 = 0.0; x.m10 = 0.0; x.m11 = 1.0; x.c0 = 0.0; x.c1 = 0.0; }
+  return x;
+}
+
+// The Kalman filter over a stretch of steps as a map of the predicted moments (a, P):
+//   a -> A (I + P J)^-1 (a + P eta) + b,   P -> A (I + P J)^-1 P A' + C      (C, J symmetric)
+// (Sarkka & Garcia-Fernandez 2021, the element of ci_kernels.h's filter scan), d = 2.
+struct Kf2 { double a00, a01, a10, a11, b0, b1, c00, c01, c11, e0, e1, j00, j01, j11; };
+__device__ __forceinline__ Kf2 kf2_then(const Kf2& x, const Kf2& y) {
+  // G = I + C1 J2,  W = G^-1
+  const double g00 = 1.0 + fma(x.c00, y.j00, x.c01 * y.j01), g01 = fma(x.c00, y.j01, x.c01 * y.j11);
+  const double g10 = fma(x.c01, y.j00, x.c11 * y.j01), g11 = 1.0 + fma(x.c01, y.j01, x.c11 * y.j11);
+  const double rdet = 1.0 / fma(g00, g11, -(g01 * g10));
+  const double w00 = g11 * rdet, w01 = -g01 * rdet, w10 = -g10 * rdet, w11 = g00 * rdet;
+  // U = A2 W
+  const double u00 = fma(y.a00, w00, y.a01 * w10), u01 = fma(y.a00, w01, y.a01 * w11);
+  const double u10 = fma(y.a10, w00, y.a11 * w10), u11 = fma(y.a10, w01, y.a11 * w11);
+  Kf2 r;
+  r.a00 = fma(u00, x.a00, u01 * x.a10); r.a01 = fma(u00, x.a01, u01 * x.a11);
+  r.a10 = fma(u10, x.a00, u11 * x.a10); r.a11 = fma(u10, x.a01, u11 * x.a11);
+  // b = U (b1 + C1 eta2) + b2
+  const double t0 = x.b0 + fma(x.c00, y.e0, x.c01 * y.e1), t1 = x.b1 + fma(x.c01, y.e0, x.c11 * y.e1);
+  r.b0 = fma(u00, t0, fma(u01, t1, y.b0));
+  r.b1 = fma(u10, t0, fma(u11, t1, y.b1));
+  // S = W C1 (symmetric), C = A2 S A2' + C2
+  const double s00 = fma(w00, x.c00, w01 * x.c01), s01 = fma(w00, x.c01, w01 * x.c11);
+  const double s11 = fma(w10, x.c01, w11 * x.c11);
+  const double q00 = fma(y.a00, s00, y.a01 * s01), q01 = fma(y.a00, s01, y.a01 * s11);   // A2 S
+  const double q10 = fma(y.a10, s00, y.a11 * s01), q11 = fma(y.a10, s01, y.a11 * s11);
+  r.c00 = fma(q00, y.a00, fma(q01, y.a01, y.c00));
+  r.c01 = fma(q00, y.a10, fma(q01, y.a11, y.c01));
+  r.c11 = fma(q10, y.a10, fma(q11, y.a11, y.c11));
+  // eta = A1' W' (eta2 - J2 b1) + eta1
+  const double d0 = y.e0 - fma(y.j00, x.b0, y.j01 * x.b1), d1 = y.e1 - fma(y.j01, x.b0, y.j11 * x.b1);
+  const double v0 = fma(w00, d0, w10 * d1), v1 = fma(w01, d0, w11 * d1);                 // W' d
+  r.e0 = fma(x.a00, v0, fma(x.a10, v1, x.e0));
+  r.e1 = fma(x.a01, v0, fma(x.a11, v1, x.e1));
+  // R = W' J2 (symmetric), J = A1' R A1 + J1
+  const double r00 = fma(w00, y.j00, w10 * y.j01), r01 = fma(w00, y.j01, w10 * y.j11);
+  const double r11 = fma(w01, y.j01, w11 * y.j11);
+  const double p00 = fma(r00, x.a00, r01 * x.a10), p01 = fma(r00, x.a01, r01 * x.a11);   // R A1
+  const double p10 = fma(r01, x.a00, r11 * x.a10), p11 = fma(r01, x.a01, r11 * x.a11);
+  r.j00 = fma(x.a00, p00, fma(x.a10, p10, x.j00));
+  r.j01 = fma(x.a00, p01, fma(x.a10, p11, x.j01));
+  r.j11 = fma(x.a01, p01, fma(x.a11, p11, x.j11));
+  return r;
+}
+// inclusive forward scan of the filter elements; only (b, C) of the result is used (lane 0's
+// element starts from the prior, so every prefix has A = 0 and (b, C) = the predicted moments)
+__device__ __forceinline__ Kf2 kf2_scan_incl(Kf2 e, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    Kf2 o;
+    o.a00 = shfl_up_d(e.a00, off); o.a01 = shfl_up_d(e.a01, off); o.a10 = shfl_up_d(e.a10, off);
+    o.a11 = shfl_up_d(e.a11, off); o.b0 = shfl_up_d(e.b0, off); o.b1 = shfl_up_d(e.b1, off);
+    o.c00 = shfl_up_d(e.c00, off); o.c01 = shfl_up_d(e.c01, off); o.c11 = shfl_up_d(e.c11, off);
+    o.e0 = shfl_up_d(e.e0, off); o.e1 = shfl_up_d(e.e1, off);
+    o.j00 = shfl_up_d(e.j00, off); o.j01 = shfl_up_d(e.j01, off); o.j11 = shfl_up_d(e.j11, off);
+    if (lane >= off) e = kf2_then(o, e);
+  }
+  return e;
+}
+
 template <bool GWS>
 __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smem64[];
@@ -471,132 +591,149 @@ __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
     prof.tick(22);
 
     if (K == 0) {
-      // ---- trend-only models (the reference's default: LocalLevel, D = 1; LocalLinearTrend, D = 2):
-      // the four passes as wave-uniform SCALAR recursions -- every lane carries the same 1 x 1 or
-      // 2 x 2 quantities, lane 0 stores; no LDS matrix, no table, no barrier inside the loops.
+      // ---- trend-only models (the reference's default: LocalLevel, D = 1; LocalLinearTrend, D = 2),
+      // TIME-PARALLEL within the wavefront: lane j owns the steps [t0, t1) (an ODD number of
+      // steps per lane, so that the lanes' strided accesses spread over the LDS banks) and every
+      // pass is chunk summary -> scan across lanes -> replay (helpers above).  LocalLevel runs
+      // the same 2 x 2 code with an identically-zero slope (0 variance, 0 noise: exact).
       const bool s2 = a.has_slope != 0;
       const double a0 = readlane_d(a1e, 0), a1s = s2 ? readlane_d(a1e, 1) : 0.0;
+      const double qs2 = s2 ? qs : 0.0, ss2 = s2 ? ssc : 0.0, p1s2 = s2 ? p1s : 0.0;
+      const int Lc = ((T + 63) / 64) | 1;
+      const int t0 = lane * Lc < T ? lane * Lc : T;
+      const int t1 = t0 + Lc < T ? t0 + Lc : T;
+      double xin0, xin1;                       // x+ at t0 (kept for pass 3)
       {   // pass 0: x+ and y~ = resid - y+
-        double x0 = 0.0, x1 = 0.0;
-        for (int t4 = 0; t4 < T; t4 += 4) {
-          const double4 zo4 = ld4(zo + t4), zl4 = ld4(zl + t4), yv4 = ld4(yv + t4), xw4 = ld4(xw + t4);
-          double4 zs4 = make_double4(0.0, 0.0, 0.0, 0.0);
-          if (s2) zs4 = ld4(zs + t4);
-          double yt[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            yt[q] = (at4(yv4, q) - at4(xw4, q)) - (x0 + so * at4(zo4, q));
-            if (t4 + q + 1 < T) {
-              if (s2) x0 += x1;
-              x0 = fma(sl, at4(zl4, q), x0);
-              if (s2) x1 = fma(ssc, at4(zs4, q), x1);
-            }
+        Drift2 e; e.n = 0.0; e.c0 = 0.0; e.c1 = 0.0;
+        for (int t = t0; t < t1; ++t)
+          if (t + 1 < T) {
+            e.n += 1.0;
+            e.c0 = fma(sl, zl[t], e.c0 + e.c1);
+            if (s2) e.c1 = fma(ss2, zs[t], e.c1);
           }
-          if (lane == 0) *reinterpret_cast<double4*>(ytil + t4) = make_double4(yt[0], yt[1], yt[2], yt[3]);
+        const Drift2 in = drift2_scan_excl(e, lane);
+        xin0 = in.c0; xin1 = in.c1;            // x+_0 = 0
+        double x0 = xin0, x1 = xin1;
+        for (int t = t0; t < t1; ++t) {
+          ytil[t] = (yv[t] - xw[t]) - fma(so, zo[t], x0);
+          if (t + 1 < T) {
+            x0 = fma(sl, zl[t], x0 + x1);
+            if (s2) x1 = fma(ss2, zs[t], x1);
+          }
         }
       }
-      wave_sync();
       {   // pass 1: Kalman filter, gains and scaled innovations
-        double m0 = a0, m1 = a1s, p00 = p1l, p01 = 0.0, p11 = s2 ? p1s : 0.0;
-        for (int t4 = 0; t4 < T; t4 += 4) {
-          const double4 yt4 = ld4(ytil + t4);
-          const uint32_t mk4 = ldb4(msk + t4);
-          double vfq[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int t = t4 + q;
-            vfq[q] = 0.0;
-            if (t >= T) continue;
-            double k0 = 0.0, k1 = 0.0;
-            if (((mk4 >> (8 * q)) & 0xFFu) == 0u) {
-              const double rF = 1.0 / (p00 + H);
-              const double v = at4(yt4, q) - m0;
-              k0 = p00 * rF; k1 = p01 * rF;
-              vfq[q] = v * rF;
-              m0 = fma(k0, v, m0); m1 = fma(k1, v, m1);
-              const double q00 = p00, q01 = p01;
-              p00 -= q00 * q00 * rF; p01 -= q00 * q01 * rF; p11 -= q01 * q01 * rF;
-            }
-            if (lane == 0) { kf[(size_t)t * D] = k0; if (s2) kf[(size_t)t * D + 1] = k1; }
-            if (t + 1 < T) {
-              if (s2) {
-                m0 += m1;
-                p00 = p00 + 2.0 * p01 + p11 + ql;
-                p01 = p01 + p11;
-                p11 = p11 + qs;
-              } else {
-                p00 += ql;
-              }
-            }
+        Kf2 e;
+        e.a00 = 1.0; e.a01 = 0.0; e.a10 = 0.0; e.a11 = 1.0; e.b0 = 0.0; e.b1 = 0.0;
+        e.c00 = 0.0; e.c01 = 0.0; e.c11 = 0.0; e.e0 = 0.0; e.e1 = 0.0; e.j00 = 0.0; e.j01 = 0.0; e.j11 = 0.0;
+        if (lane == 0) { e.a00 = 0.0; e.a11 = 0.0; e.b0 = a0; e.b1 = a1s; e.c00 = p1l; e.c11 = p1s2; }
+        // the own chunk: a Kalman sweep on (b, C) that also carries A, eta, J -- appending one
+        // step (J2 = z z'/H, eta2 = z y/H, A2 = T, C2 = Q) is a rank-one update of each
+        for (int t = t0; t < t1; ++t) {
+          if (msk[t] == 0) {
+            const double rf = 1.0 / (e.c00 + H);
+            const double v = ytil[t] - e.b0;
+            const double k0 = e.c00 * rf, k1 = e.c01 * rf;
+            const double vr = v * rf;
+            e.e0 = fma(e.a00, vr, e.e0); e.e1 = fma(e.a01, vr, e.e1);          // eta += A'z v / f
+            e.j00 = fma(e.a00 * rf, e.a00, e.j00); e.j01 = fma(e.a00 * rf, e.a01, e.j01);
+            e.j11 = fma(e.a01 * rf, e.a01, e.j11);                              // J += A'z z'A / f
+            e.b0 = fma(k0, v, e.b0); e.b1 = fma(k1, v, e.b1);
+            const double r00 = e.a00, r01 = e.a01;                              // A -= k (z'A)
+            e.a10 = fma(-k1, r00, e.a10); e.a11 = fma(-k1, r01, e.a11);
+            e.a00 = fma(-k0, r00, e.a00); e.a01 = fma(-k0, r01, e.a01);
+            const double c00 = e.c00, c01 = e.c01;
+            e.c00 -= c00 * c00 * rf; e.c01 -= c00 * c01 * rf; e.c11 -= c01 * c01 * rf;
           }
-          if (lane == 0) *reinterpret_cast<double4*>(vf + t4) = make_double4(vfq[0], vfq[1], vfq[2], vfq[3]);
+          // time update with T = [[1, 1], [0, 1]], Q = diag(ql, qs)
+          e.a00 += e.a10; e.a01 += e.a11;
+          e.b0 += e.b1;
+          e.c00 = e.c00 + 2.0 * e.c01 + e.c11 + ql;
+          e.c01 = e.c01 + e.c11;
+          e.c11 = e.c11 + qs2;
+        }
+        const Kf2 pre = kf2_scan_incl(e, lane);
+        double m0 = shfl_up_d(pre.b0, 1), m1 = shfl_up_d(pre.b1, 1);
+        double p00 = shfl_up_d(pre.c00, 1), p01 = shfl_up_d(pre.c01, 1), p11 = shfl_up_d(pre.c11, 1);
+        if (lane == 0) { m0 = a0; m1 = a1s; p00 = p1l; p01 = 0.0; p11 = p1s2; }
+        for (int t = t0; t < t1; ++t) {
+          double k0 = 0.0, k1 = 0.0, vfq = 0.0;
+          if (msk[t] == 0) {
+            const double rF = 1.0 / (p00 + H);
+            const double v = ytil[t] - m0;
+            k0 = p00 * rF; k1 = p01 * rF;
+            vfq = v * rF;
+            m0 = fma(k0, v, m0); m1 = fma(k1, v, m1);
+            const double q00 = p00, q01 = p01;
+            p00 -= q00 * q00 * rF; p01 -= q00 * q01 * rF; p11 -= q01 * q01 * rF;
+          }
+          kf[(size_t)t * D] = k0;
+          if (s2) kf[(size_t)t * D + 1] = k1;
+          vf[t] = vfq;
+          if (t + 1 < T) {
+            m0 += m1;
+            p00 = p00 + 2.0 * p01 + p11 + ql;
+            p01 = p01 + p11;
+            p11 = p11 + qs2;
+          }
         }
       }
-      wave_sync();
-      {   // pass 2: backward recursion, rs[t] = r_{t-1}  (4 steps per batch of loads)
-        double r0 = 0.0, r1 = 0.0;
-        for (int t4 = ((T - 1) & ~3); t4 >= 0; t4 -= 4) {
-          const double4 vf4 = ld4(vf + t4);
-          const uint32_t mk4 = ldb4(msk + t4);
-          double k0q[4], k1q[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool in = t4 + q < T;
-            k0q[q] = in ? kf[(size_t)(t4 + q) * D] : 0.0;
-            k1q[q] = (in && s2) ? kf[(size_t)(t4 + q) * D + 1] : 0.0;
-          }
-#pragma unroll
-          for (int q = 3; q >= 0; --q) {
-            const int t = t4 + q;
-            if (t >= T) continue;
-            if (t + 1 < T) { if (s2) r1 += r0; } else { r0 = 0.0; r1 = 0.0; }
-            if (((mk4 >> (8 * q)) & 0xFFu) == 0u) r0 += at4(vf4, q) - (k0q[q] * r0 + k1q[q] * r1);
-            if (lane == 0) { rs[(size_t)t * D] = r0; if (s2) rs[(size_t)t * D + 1] = r1; }
-          }
+      {   // pass 2: backward recursion, rs[t] = r_{t-1}
+        auto step = [&](int t, double& r0, double& r1, double k0, double k1, double vft, bool obs) {
+          if (t + 1 < T) r1 += r0;                      // r <- T' r
+          if (obs) r0 += vft - fma(k0, r0, k1 * r1);    // + z (v/F - K'r)
+        };
+        Aff2 e; e.m00 = 1.0; e.m01 = 0.0; e.m10 = 0.0; e.m11 = 1.0; e.c0 = 0.0; e.c1 = 0.0;
+        for (int t = t1 - 1; t >= t0; --t) {
+          const bool obs = msk[t] == 0;
+          const double k0 = kf[(size_t)t * D], k1 = s2 ? kf[(size_t)t * D + 1] : 0.0, vft = vf[t];
+          // the step applied to the three columns (M e_0, M e_1, c) of the element so far
+          double c0 = e.c0, c1 = e.c1, x0 = e.m00, x1 = e.m10, y0 = e.m01, y1 = e.m11;
+          step(t, c0, c1, k0, k1, vft, obs);
+          step(t, x0, x1, k0, k1, 0.0, obs);
+          step(t, y0, y1, k0, k1, 0.0, obs);
+          e.c0 = c0; e.c1 = c1; e.m00 = x0; e.m10 = x1; e.m01 = y0; e.m11 = y1;
+        }
+        const Aff2 in = aff2_scan_excl_bwd(e, lane);
+        double r0 = in.c0, r1 = in.c1;                  // r_{T-1} = 0 at the right end
+        for (int t = t1 - 1; t >= t0; --t) {
+          const double k0 = kf[(size_t)t * D], k1 = s2 ? kf[(size_t)t * D + 1] : 0.0;
+          step(t, r0, r1, k0, k1, vf[t], msk[t] == 0);
+          rs[(size_t)t * D] = r0;
+          if (s2) rs[(size_t)t * D + 1] = r1;
         }
       }
       wave_sync();
       {   // pass 3: x^ forward, x+ again, the draw and its increment statistics
-        double h0 = a0 + p1l * rs[0], h1 = s2 ? a1s + p1s * rs[1] : 0.0;
-        double x0 = 0.0, x1 = 0.0, pv0 = 0.0, pv1 = 0.0, al = 0.0, as = 0.0;
-        for (int t4 = 0; t4 < T; t4 += 4) {
-          const double4 zl4 = ld4(zl + t4);
-          double4 zs4 = make_double4(0.0, 0.0, 0.0, 0.0);
-          if (s2) zs4 = ld4(zs + t4);
-          double l4[4], g4[4], rn0q[4], rn1q[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {       // r_t = rs[t + 1]
-            const int t1 = t4 + q + 1;
-            rn0q[q] = t1 < T ? rs[(size_t)t1 * D] : 0.0;
-            rn1q[q] = (t1 < T && s2) ? rs[(size_t)t1 * D + 1] : 0.0;
+        const double hi0 = fma(p1l, rs[0], a0), hi1 = s2 ? fma(p1s2, rs[1], a1s) : 0.0;
+        Drift2 e; e.n = 0.0; e.c0 = 0.0; e.c1 = 0.0;
+        for (int t = t0; t < t1; ++t)
+          if (t + 1 < T) {
+            e.n += 1.0;
+            e.c0 = fma(ql, rs[(size_t)(t + 1) * D], e.c0 + e.c1);
+            if (s2) e.c1 = fma(qs2, rs[(size_t)(t + 1) * D + 1], e.c1);
           }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int t = t4 + q;
-            l4[q] = 0.0; g4[q] = 0.0;
-            if (t >= T) continue;
-            const double xt0 = h0 + x0, xt1 = h1 + x1;
-            l4[q] = xt0; g4[q] = xt1;
-            if (t > 0) {
-              double dl = xt0 - pv0;
-              if (s2) { dl -= pv1; const double ds = xt1 - pv1; as = fma(ds, ds, as); }
-              al = fma(dl, dl, al);
+        const Drift2 in = drift2_scan_excl(e, lane);
+        double h0 = fma(in.n, hi1, hi0) + in.c0, h1 = hi1 + in.c1;
+        double x0 = xin0, x1 = xin1, al = 0.0, as = 0.0;
+        for (int t = t0; t < t1; ++t) {
+          const double xt0 = h0 + x0, xt1 = h1 + x1;
+          lev[t] = xt0;
+          if (s2) slp[t] = xt1;
+          if (t + 1 < T) {
+            h0 = fma(ql, rs[(size_t)(t + 1) * D], h0 + h1);
+            x0 = fma(sl, zl[t], x0 + x1);
+            if (s2) {
+              h1 = fma(qs2, rs[(size_t)(t + 1) * D + 1], h1);
+              x1 = fma(ss2, zs[t], x1);
             }
-            pv0 = xt0; pv1 = xt1;
-            if (t + 1 < T) {
-              const double rn0 = rn0q[q], rn1 = rn1q[q];
-              if (s2) { h0 += h1; x0 += x1; }
-              h0 = fma(ql, rn0, h0);
-              x0 = fma(sl, at4(zl4, q), x0);
-              if (s2) { h1 = fma(qs, rn1, h1); x1 = fma(ssc, at4(zs4, q), x1); }
-            }
-          }
-          if (lane == 0) {
-            *reinterpret_cast<double4*>(lev + t4) = make_double4(l4[0], l4[1], l4[2], l4[3]);
-            if (s2) *reinterpret_cast<double4*>(slp + t4) = make_double4(g4[0], g4[1], g4[2], g4[3]);
+            const double nx0 = h0 + x0, nx1 = h1 + x1;       // the increment t -> t + 1
+            const double dl = (nx0 - xt0) - xt1;
+            al = fma(dl, dl, al);
+            if (s2) { const double ds = nx1 - xt1; as = fma(ds, ds, as); }
           }
         }
-        ssl = al; sss = as; ssd = 0.0;
+        ssl = wave_sum_d(al); sss = wave_sum_d(as); ssd = 0.0;
       }
       wave_sync();
       prof.tick(27);

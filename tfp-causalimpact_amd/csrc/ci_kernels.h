@@ -208,19 +208,34 @@ __device__ __forceinline__ E wave_scan_incl_bwd(const E& v, Op op, int lane) {
 // Exclusive block scan over thread order (thread 0 first).  op(earlier, later).
 // Contains exactly one __syncthreads(); `slots` needs NW * sizeof(E)/4 floats and must not
 // be rewritten before another barrier has been passed.
+// The scan in two halves around its barrier, for callers that own the barrier (ci_kernels5.h runs
+// the first half while the regression wave is still in its serial section and lets the
+// workgroup's (B3) separate the halves): begin = the in-wave inclusive scan + the wave total to
+// `slots`; finish = the exclusive prefix from the earlier waves' totals.
 template <class E, class Op>
-__device__ __forceinline__ E block_scan_excl_fwd(const E& tot, Op op, const E& ident, float* slots,
-                                                 int lane, int wave) {
+__device__ __forceinline__ E block_scan_fwd_begin(const E& tot, Op op, float* slots, int lane, int wave) {
   constexpr int N = sizeof(E) / 4;
   const E incl = wave_scan_incl_fwd(tot, op, lane);
   if (lane == 63) lds_store_e(slots + wave * N, incl);
-  __syncthreads();
+  return incl;
+}
+template <class E, class Op>
+__device__ __forceinline__ E block_scan_fwd_finish(const E& incl, Op op, const E& ident, const float* slots,
+                                                   int lane, int wave) {
+  constexpr int N = sizeof(E) / 4;
   E ex = dpp_move_e<0x138, 0xF>(incl);        // wave_shr:1
   if (lane == 0) ex = ident;
   if (wave == 0) return ex;
   E wp = lds_load_e<E>(slots);
   for (int ww = 1; ww < wave; ++ww) wp = op(wp, lds_load_e<E>(slots + ww * N));
   return op(wp, ex);
+}
+template <class E, class Op>
+__device__ __forceinline__ E block_scan_excl_fwd(const E& tot, Op op, const E& ident, float* slots,
+                                                 int lane, int wave) {
+  const E incl = block_scan_fwd_begin(tot, op, slots, lane, wave);
+  __syncthreads();
+  return block_scan_fwd_finish(incl, op, ident, slots, lane, wave);
 }
 
 // Exclusive suffix scan: result for thread i = e_{i+1} o e_{i+2} o ... o e_last, with
@@ -464,12 +479,40 @@ __device__ __forceinline__ void dk_normals(const Rng& rng, uint32_t iter, int ow
   fill_normals<L>(rng, iter, SITE_PRIOR_OBS, 0, t0, zo);
 }
 
+// Step (1) of dk_draw, the scan of the prior simulation x <- T x + n_t, in two halves around a
+// workgroup barrier: it needs the disturbance scales and the normals only, not the regression
+// draw, so the five-wave kernel runs the first half before its (B3).
+template <int D, int L>
+__device__ __forceinline__ PElem<D> dk_prior_begin(const Vec<D>& sig, const float (&zl)[L],
+                                                   const float (&zs)[L], float* slots, int lane,
+                                                   int wave) {
+  PElem<D> ptot = pelem_identity<D>();
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    PElem<D> e;
+    e.k = 1.f;
+    e.s.v[0] = sig.v[0] * zl[l];
+    if constexpr (D == 2) e.s.v[1] = sig.v[1] * zs[l];
+    ptot = pelem_combine(ptot, e);
+  }
+  return block_scan_fwd_begin(
+      ptot, [](const PElem<D>& a, const PElem<D>& b) { return pelem_combine(a, b); }, slots, lane, wave);
+}
+template <int D>
+__device__ __forceinline__ PElem<D> dk_prior_finish(const PElem<D>& incl, const float* slots, int lane,
+                                                    int wave) {
+  return block_scan_fwd_finish(
+      incl, [](const PElem<D>& a, const PElem<D>& b) { return pelem_combine(a, b); },
+      pelem_identity<D>(), slots, lane, wave);
+}
+
 template <int D, int L, class PF>
 __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
                                         uint32_t maskbits, const Rng& rng, uint32_t iter, int tid,
                                         int lane, int wave, float* slots, Vec<D> (&xout)[L],
                                         PF& prof, const float (&zl)[L], const float (&zs)[L],
-                                        const float (&zo)[L], const float* zinit = nullptr) {
+                                        const float (&zo)[L], const float* zinit = nullptr,
+                                        const PElem<D>* ppre_in = nullptr) {
   Vec<D> q;
 #pragma unroll
   for (int i = 0; i < D; ++i) q.v[i] = md.sig.v[i] * md.sig.v[i];
@@ -480,7 +523,6 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
   // it is folded into the filter's prior mean instead:
   //   x~ = x+_noise + E[x | y - y+_noise ; prior mean a_1 + x+_0]
   // which is the same draw as the oracle's x+ + E[x | y - y+ ; prior mean a_1].
-  PElem<D> ptot = pelem_identity<D>();
   Vec<D> a1e = md.a1;
   if (tid == 0) {
 #pragma unroll
@@ -491,17 +533,14 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
       a1e.v[i] = fmaf(__fsqrt_rn(md.p1.v[i]), zi[0], md.a1.v[i]);
     }
   }
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    PElem<D> e;
-    e.k = 1.f;
-    e.s.v[0] = md.sig.v[0] * zl[l];
-    if constexpr (D == 2) e.s.v[1] = md.sig.v[1] * zs[l];
-    ptot = pelem_combine(ptot, e);
+  PElem<D> ppre;
+  if (ppre_in) {
+    ppre = *ppre_in;                     // scanned by the caller (dk_prior_begin / dk_prior_finish)
+  } else {
+    const PElem<D> incl = dk_prior_begin<D, L>(md.sig, zl, zs, slots, lane, wave);
+    __syncthreads();
+    ppre = dk_prior_finish<D>(incl, slots, lane, wave);
   }
-  const PElem<D> ppre = block_scan_excl_fwd(
-      ptot, [](const PElem<D>& a, const PElem<D>& b) { return pelem_combine(a, b); },
-      pelem_identity<D>(), slots, lane, wave);
   Vec<D> xp[L];
   float ytil[L];
   {

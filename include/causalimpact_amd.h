@@ -130,7 +130,8 @@ int ci_device_count(int* count);
 /* Waits for all work queued on `device` (bench.py brackets its timed region with it). */
 int ci_device_synchronize(int device);
 /* Device buffers of finished sessions are parked in a per-process pool (<= 2 GiB) for reuse by
- * the next fit; this returns them to the driver. */
+ * the next fit, and so are their streams and events (creating and destroying a stream costs about
+ * a millisecond on this runtime); this returns all of them to the driver. */
 int ci_pool_trim(void);
 /* Pinned (page-locked) host memory for result buffers; recycled through a pool like the device
  * buffers.  ci_host_free accepts only pointers returned by ci_host_alloc. */

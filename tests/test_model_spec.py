@@ -92,3 +92,25 @@ def test_bulk_and_tail_ess_and_additivity_of_the_partial_sums():
   np.testing.assert_allclose(dg.rhat_from_sums(dg.unpack(dg.pack(dg.partial_sums(dg.split_chains(ar[:2]))) +
                                                           dg.pack(dg.partial_sums(dg.split_chains(ar[2:]))))),
                              lib.split_rhat(ar), rtol=1e-12)
+
+
+def test_diagnostics_mapping_is_computed_on_first_use_and_behaves_like_a_dict():
+  """CausalImpactAnalysis.diagnostics (num_chains > 1) is a read-only mapping filled in when it is
+  first read: the convergence statistics cost a third of a fit's host time and most callers never
+  look at them."""
+  from causalimpact import causalimpact_lib as lib
+  calls = []
+
+  def make():
+    calls.append(1)
+    return {"split_rhat": {"observation_noise_scale": 1.01}, "num_chains": 4}
+
+  d = lib._LazyMapping(make)      # pylint: disable=protected-access
+  assert not calls
+  assert d["num_chains"] == 4 and calls == [1]
+  assert set(d) == {"split_rhat", "num_chains"} and len(d) == 2 and "split_rhat" in d
+  assert dict(d)["split_rhat"]["observation_noise_scale"] == 1.01
+  assert "split_rhat" in repr(d)
+  assert calls == [1]                                  # computed once
+  with pytest.raises(TypeError):
+    d["x"] = 1                                         # read-only

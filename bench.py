@@ -309,8 +309,10 @@ def main():
                  "chains_per_gpu": C, "chains_total": world * C,
                  "timed_region": "fit + delivery of every result array to pinned host memory",
                  "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
-                 "launcher": ("external (RANK/WORLD_SIZE in the environment)" if launched else
-                              ("bench.py spawned its own ranks" if world > 1 else "single process")),
+                 "launcher": ("bench.py spawned its own ranks (one process per GPU)"
+                              if os.environ.get("CI_COMM_SPAWNED") == "1" else
+                              ("external (RANK/WORLD_SIZE in the environment)" if launched else
+                               "single process")),
                  "collectives": (f"{comm.transport} via ci_comm_* (C-ABI), ranks_seen="
                                  f"{comm.ranks_seen}" if comm is not None else "none")},
       "roofline": roof,

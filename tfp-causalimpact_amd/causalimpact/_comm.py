@@ -182,7 +182,7 @@ def spawn_ranks(world: int, argv: Sequence[str], env: Optional[Dict[str, str]] =
   for r in range(world):
     e = dict(os.environ if env is None else env)
     e.update(RANK=str(r), WORLD_SIZE=str(world), CI_COMM_RDZV=path, CI_COMM_TRANSPORT=transport,
-             LOCAL_RANK=str(r if devices is None else devices[r]))
+             LOCAL_RANK=str(r if devices is None else devices[r]), CI_COMM_SPAWNED="1")
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs.append(subprocess.Popen(list(argv), env=e))
   # wait for all ranks; when one dies the others would wait for it in a collective: give them a

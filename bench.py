@@ -21,6 +21,7 @@ import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -113,17 +114,78 @@ def _cpu_baseline(sampler, y, mask, X, min_seconds=10.0):
 
 
 def _pmc_traffic(sampler):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc.json, written
-  by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command; a
-  counter pass cannot run inside the timed process) and the file it came from."""
+  """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (profiles/*pmc.json, written by
+  tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command) and the
+  file it came from -- the fallback of _measure_traffic."""
   names = (("r03_cfg3_pmc.json", "r02_cfg3_pmc.json") if sampler == "hmc" else
            ("r03_pmc.json", "r02_pmc.json"))
   for name in names:
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
       with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_launch"), "profiles/" + name
+        return json.load(f).get("hbm_bytes_per_launch"), "profiles/" + name + " (committed; not measured in this run)"
   return None, None
+
+
+def _measure_traffic(sampler, timeout_s=150):
+  """HBM bytes per launch MEASURED NOW: two rocprofv3 counter passes over this very command with
+  a short step count -- FETCH_SIZE and WRITE_SIZE in their own runs, no trace domain next to
+  them, summed over the kernels of one fit and corrected as /opt/skills/guides/MI355X_MICROARCH.md
+  prescribes (both counters in KiB; on gfx950 FETCH_SIZE reports half of a wide streaming read).
+  A counter pass cannot run inside the timed process, so it runs after the timed region as a
+  child.  Returns (bytes, source) or (None, why) -- the caller then falls back to the committed
+  figure."""
+  import csv  # pylint: disable=import-outside-toplevel
+  import glob  # pylint: disable=import-outside-toplevel
+  import shutil  # pylint: disable=import-outside-toplevel
+  import signal  # pylint: disable=import-outside-toplevel
+  import tempfile  # pylint: disable=import-outside-toplevel
+  prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+  if not os.path.exists(prof):
+    return None, "rocprofv3 not found"
+  kernels = (("hmc_kernel", "latents_kernel", "hmc_mean_kernel", "hmc_unpack_kernel")
+             if sampler == "hmc" else ("gibbs_kernel",))
+  steps = 1 if sampler == "hmc" else 3
+  tmp = tempfile.mkdtemp(prefix="ci_bench_pmc_", dir="/tmp")
+  env = dict(os.environ, TMPDIR="/tmp", CI_BENCH_INNER="1")
+  per_launch = {}
+  try:
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+      out_dir = os.path.join(tmp, counter)
+      cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "bench", "--",
+             sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-pmc",
+             "--sampler", sampler, "--steps", str(steps), "--warmup", "1"]
+      p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           start_new_session=True)
+      try:
+        p.wait(timeout=timeout_s)
+      except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        p.wait()
+        return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"
+      files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+      if p.returncode != 0 or not files:
+        return None, f"rocprofv3 --pmc {counter} pass failed (rc {p.returncode})"
+      # KiB per dispatch, summed over the kernels of one fit, averaged over the gibbs/hmc launches
+      per = {}
+      main_ids = set()
+      with open(files[0]) as f:
+        for row in csv.DictReader(f):
+          name = row.get("Kernel_Name", "")
+          if row.get("Counter_Name") != counter or not any(k in name for k in kernels):
+            continue
+          per[name] = per.get(name, 0.0) + float(row["Counter_Value"])
+          if kernels[0] in name:
+            main_ids.add(row["Dispatch_Id"])
+      if not main_ids:
+        return None, f"no {kernels[0]} dispatch in the {counter} pass"
+      per_launch[counter] = sum(per.values()) / len(main_ids)
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+  total = 2.0 * per_launch["FETCH_SIZE"] * 1024.0 + per_launch["WRITE_SIZE"] * 1024.0
+  return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate "
+                 f"passes of {steps + 1} fits each, KiB -> bytes, FETCH_SIZE x2 (gfx950 wide reads)")
 
 
 class _GibbsFit:
@@ -206,6 +268,8 @@ def main():
   ap.add_argument("--warmup", type=int, default=None)
   ap.add_argument("--sampler", choices=("gibbs", "hmc"), default="gibbs")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-pmc", action="store_true",
+                  help="skip the two rocprofv3 counter passes that measure roofline.traffic")
   ap.add_argument("--chains-per-gpu", type=int, default=CFG["chains_per_gpu"])
   ap.add_argument("--chunk-draws", type=int, default=CFG["chunk_draws"],
                   help="retained draws per device-to-host copy of the streamed fetch")
@@ -288,7 +352,15 @@ def main():
   k_ms = float(np.mean([sum(k.values()) for k in kernel_ms]))
   alg_bytes = fit.sess.algorithmic_bytes()
   achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-  traffic, traffic_src = _pmc_traffic(args.sampler)
+  traffic, traffic_src = None, None
+  if rank == 0 and world == 1 and not args.no_pmc and os.environ.get("CI_BENCH_INNER") != "1":
+    traffic, why = _measure_traffic(args.sampler)
+    traffic_src = why
+    if traffic is None:
+      traffic, src = _pmc_traffic(args.sampler)
+      traffic_src = f"{src}; in-run measurement unavailable: {why}"
+  else:
+    traffic, traffic_src = _pmc_traffic(args.sampler)
   roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
           "kernel": fit.sess.kernel_name(),

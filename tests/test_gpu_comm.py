@@ -158,7 +158,7 @@ def test_bench_single_rank_through_the_rccl_path_matches_plain_bench():
   max-reduce of the time, gather from HBM, diagnostics all-reduce) with one rank."""
   env = dict(os.environ, CI_BENCH_FORCE_DIST="1")
   cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "3",
-         "--no-cpu-baseline"]
+         "--no-cpu-baseline", "--no-pmc"]
   # the JSON line must be the LAST line of the output (librccl's banner is flushed before it)
   forced = json.loads(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600,
                                      check=True).stdout.strip().splitlines()[-1])

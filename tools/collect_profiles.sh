@@ -13,16 +13,16 @@ B="python $ROOT/bench.py"
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 # ---- cfg2 (bench line)
 timeout 600 $B > "$OUT/bench.json" 2> "$OUT/bench.err"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $B --no-cpu-baseline --steps 5 --warmup 1 > "$OUT/trace.log" 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $B --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $B --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_write.log" 2>&1
-timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/pmc_sq" -o bench -- $B --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_sq.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $B --no-cpu-baseline --no-pmc --steps 5 --warmup 1 > "$OUT/trace.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $B --no-cpu-baseline --no-pmc --steps 3 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $B --no-cpu-baseline --no-pmc --steps 3 --warmup 1 > "$OUT/pmc_write.log" 2>&1
+timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/pmc_sq" -o bench -- $B --no-cpu-baseline --no-pmc --steps 3 --warmup 1 > "$OUT/pmc_sq.log" 2>&1
 # ---- cfg3 (HMC)
 timeout 600 $B --sampler hmc > "$OUT/bench_hmc.json" 2> "$OUT/bench_hmc.err"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hmc_trace" -o hmc -- $B --no-cpu-baseline --sampler hmc --steps 2 --warmup 1 > "$OUT/hmc_trace.log" 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/hmc_pmc_fetch" -o hmc -- $B --no-cpu-baseline --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_fetch.log" 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/hmc_pmc_write" -o hmc -- $B --no-cpu-baseline --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_write.log" 2>&1
-timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/hmc_pmc_sq" -o hmc -- $B --no-cpu-baseline --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_sq.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hmc_trace" -o hmc -- $B --no-cpu-baseline --no-pmc --sampler hmc --steps 2 --warmup 1 > "$OUT/hmc_trace.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/hmc_pmc_fetch" -o hmc -- $B --no-cpu-baseline --no-pmc --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/hmc_pmc_write" -o hmc -- $B --no-cpu-baseline --no-pmc --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_write.log" 2>&1
+timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/hmc_pmc_sq" -o hmc -- $B --no-cpu-baseline --no-pmc --sampler hmc --steps 1 --warmup 1 > "$OUT/hmc_pmc_sq.log" 2>&1
 cd "$ROOT"
 # ---- cfg4 / cfg5
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg_trace" -o cfg -- python tools/run_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
@@ -34,7 +34,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_
 timeout 200 python tools/profile_phases.py > "$OUT/phase_cycles.txt" 2>&1
 timeout 200 python tools/profile_wide.py > "$OUT/cfg4_phase_cycles.txt" 2>&1
 # the N > 1 code path with one rank: C-ABI communicator (librccl), barrier, max-reduce, gather from HBM
-CI_BENCH_FORCE_DIST=1 NCCL_DEBUG=VERSION timeout 300 python bench.py --no-cpu-baseline --steps 5 > "$OUT/bench_force_dist.json" 2> "$OUT/bench_force_dist.err"
+CI_BENCH_FORCE_DIST=1 NCCL_DEBUG=VERSION timeout 300 python bench.py --no-cpu-baseline --no-pmc --steps 5 > "$OUT/bench_force_dist.json" 2> "$OUT/bench_force_dist.err"
 # two ranks sharing GPU 0 through the self-launcher (host transport: RCCL refuses two ranks on one device)
 timeout 300 python -m pytest tests/test_gpu_comm.py -q > "$OUT/comm_tests.txt" 2>&1
 timeout 600 python tools/run_configs.py extras > "$OUT/extras.jsonl" 2> "$OUT/extras.err"

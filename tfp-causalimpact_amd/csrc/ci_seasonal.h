@@ -3,14 +3,18 @@
 // causalimpact/causalimpact_lib.py:471-489).
 //
 // State dimension is 1 (+1 slope) + sum_k num_seasons_k, too wide for the register-resident
-// scan elements of ci_kernels.h, so this first device version is ONE WAVEFRONT PER CHAIN and
-// sequential in time (DESIGN.md "Seasonal models"):
-//   * lane i holds component i of every state-sized vector; the covariance lives in LDS;
+// scan elements of ci_kernels.h, so this kernel is ONE WAVEFRONT PER CHAIN and sequential in time
+// (DESIGN.md 3.3):
+//   * lane i holds component i of every state-sized vector and ROW i of the covariance (LDS);
 //   * every seasonal block is carried in its FULL n-effect form (the n-th effect is minus the
-//     sum of the others).  The constrained dynamics then are a pure cyclic shift of the block's
-//     lanes plus rank-1 noise, so no per-step block sums are needed; the covariance is
-//     singular but F = Z P Z' + H > 0.  This is the same Gaussian as the oracle's
-//     (n-1)-dimensional form, so draws agree per random number;
+//     sum of the others), in SLOT coordinates: the effect of season s stays in lane off[k] + s and
+//     the index c_k(t) of the observed slot moves (+1 mod n at each season change).  The
+//     constrained dynamics then are the identity on the block plus rank-1 noise
+//     sigma eta (e_{slot just observed} - 1/n), the observation row is e_0 + sum_k e_{off[k]+c_k(t)};
+//     the covariance is singular but F = Z P Z' + H > 0.  Same Gaussian as the oracle's
+//     (n-1)-dimensional form in permuted coordinates, so draws agree per random number.
+//     (ci_gibbs64.h and ci_score_seq.h keep the rotated form of rounds 1-2: observed effect first,
+//     cyclic lane shift at each change);
 //   * de Jong / Koopman fast state smoother: forward filter (store K_t, v_t/F_t), backward
 //     r-recursion (store r_t), forward reconstruction x^_{t+1} = T x^_t + Q_t r_t -- no
 //     per-step covariance storage;

@@ -129,7 +129,7 @@ int ci_abi_version(void);
 int ci_device_count(int* count);
 /* Waits for all work queued on `device` (bench.py brackets its timed region with it). */
 int ci_device_synchronize(int device);
-/* Device buffers of finished sessions are parked in a per-process pool (<= 2 GiB) for reuse by
+/* Device buffers of finished sessions are parked in a per-process pool (<= 32 GiB of the 288) for reuse by
  * the next fit, and so are their streams and events (creating and destroying a stream costs about
  * a millisecond on this runtime); this returns all of them to the driver. */
 int ci_pool_trim(void);

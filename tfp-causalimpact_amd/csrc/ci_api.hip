@@ -193,14 +193,17 @@ int fail(const char* fmt, ...) {
   } while (0)
 
 // Device allocations are recycled through a small per-process pool (exact-size match per
-// device, at most POOL_CAP bytes parked): a fit allocates ~10 buffers, 100+ MB of them outputs, and
+// device, at most POOL_CAP bytes parked; ci_pool_trim returns them): a fit allocates ~10 buffers, 100+ MB of them outputs, and
 // hipMalloc / hipFree of those cost several milliseconds per fit_causalimpact() call -- comparable
 // to the 12 ms the sampler itself takes.  The pool holds no caller data and no pointers escape.
 struct PoolEntry { void* p; size_t bytes; int device; };
 std::mutex g_pool_mu;
 std::vector<PoolEntry> g_pool;
 size_t g_pool_bytes = 0;
-constexpr size_t POOL_CAP = (size_t)2 << 30;
+// 32 GiB of 288: a 512-series batch parks 6 GB (1 GB each of level / trajectories, 2 GB each of the
+// float64 summary matrices); with the 2 GiB cap of rounds 1-2 every batch call re-allocated them.
+constexpr size_t POOL_CAP = (size_t)32 << 30;
+constexpr size_t HOST_POOL_CAP = (size_t)2 << 30;   // pinned host memory is the scarcer resource
 
 hipError_t pool_alloc(void** out, size_t bytes) {
   int dev = 0;
@@ -512,7 +515,7 @@ int ci_host_free(void* ptr) {
         break;
       }
     if (!e.p) return fail("ci_host_free: pointer was not allocated by ci_host_alloc");
-    if (g_host_pool_bytes + e.bytes <= POOL_CAP && g_host_pool.size() < 64) {
+    if (g_host_pool_bytes + e.bytes <= HOST_POOL_CAP && g_host_pool.size() < 64) {
       g_host_pool.push_back(e);
       g_host_pool_bytes += e.bytes;
       return 0;

@@ -1,4 +1,8 @@
+"""Wall time and host profile of fit_causalimpact_batch on BASELINE cfg5 (512 series, T = 500, 5
+covariates).  The device worker normally runs in a thread; here it runs inline so that cProfile
+sees it."""
 import sys, time, cProfile, pstats, io
+import concurrent.futures
 import numpy as np
 sys.path.insert(0, "tfp-causalimpact_amd"); sys.path.insert(0, ".")
 import causalimpact as ci
@@ -7,8 +11,22 @@ B, T, p = 512, 500, 5
 values = np.stack([np.column_stack(syn.make_raw_series(T, p, b)) for b in range(B)])
 opts = ci.InferenceOptions(num_results=1000)
 ci.fit_causalimpact_batch(values[:2], (0, 349), (350, 499), seed=1, inference_options=opts)
-t0 = time.time(); res = ci.fit_causalimpact_batch(values, (0, 349), (350, 499), seed=1, inference_options=opts); print("wall", time.time() - t0)
+ci.fit_causalimpact_batch(values, (0, 349), (350, 499), seed=1, inference_options=opts)
+ts = []
+for _ in range(3):
+  t0 = time.time(); res = ci.fit_causalimpact_batch(values, (0, 349), (350, 499), seed=1, inference_options=opts); ts.append(time.time() - t0)
+print("wall", min(ts))
+
+
+class _Inline:
+  def __init__(self, **kw): pass
+  def __enter__(self): return self
+  def __exit__(self, *a): return False
+  def map(self, fn, it): return [fn(x) for x in it]
+
+
+concurrent.futures.ThreadPoolExecutor = _Inline
 pr = cProfile.Profile(); pr.enable()
 res = ci.fit_causalimpact_batch(values, (0, 349), (350, 499), seed=1, inference_options=opts)
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(25); print(s.getvalue()[:5000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22); print(s.getvalue()[:5000])

@@ -141,7 +141,9 @@ struct SeasFilterArgs {
 #define CI_GLB __attribute__((address_space(1)))
 typedef float ci_f4v __attribute__((ext_vector_type(4)));
 typedef int ci_i4v __attribute__((ext_vector_type(4)));
-template <bool GWS>
+// NCH: the own covariance row lives in REGISTERS (8 NCH floats, D <= 8 NCH); LDS holds a mirror for
+// the accesses with a run-time column (P z) and for lane 0's view of row 1.
+template <bool GWS, int NCH>
 static __device__ __noinline__ void seasonal_filter_pass(const SeasFilterArgs& p) {
   const int T = p.T, D = p.D, DS = p.DS, lane = p.lane, blk = p.blk, pos = p.pos, nb = p.nb;
   const bool slope = p.has_slope != 0;
@@ -179,6 +181,14 @@ static __device__ __noinline__ void seasonal_filter_pass(const SeasFilterArgs& p
   lds_sync();
   if (blk >= 0 && pos == 0) zcol[blk] = p.boff;
   lds_sync();
+  float prow[8 * NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    ci_f4v a0 = ci_f4v{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (8 * c < D) { a0 = ld4(Prow + 8 * c); a1 = ld4(Prow + 8 * c + 4); }
+    prow[8 * c] = a0.x; prow[8 * c + 1] = a0.y; prow[8 * c + 2] = a0.z; prow[8 * c + 3] = a0.w;
+    prow[8 * c + 4] = a1.x; prow[8 * c + 5] = a1.y; prow[8 * c + 6] = a1.z; prow[8 * c + 7] = a1.w;
+  }
   float am = p.a1e;
   for (int t4 = 0; t4 < T; t4 += 4) {
     const ci_f4v yt4 = ldt4(ytil + t4);
@@ -198,7 +208,7 @@ static __device__ __noinline__ void seasonal_filter_pass(const SeasFilterArgs& p
       if (obs) {
         if (comp) {
           const ci_i4v z0 = *(CI_LDS const ci_i4v*)zcol, z1 = *(CI_LDS const ci_i4v*)(zcol + 4);
-          pz = Prow[0];
+          pz = prow[0];
           pz += Prow[z0.x]; pz += Prow[z0.y]; pz += Prow[z0.z]; pz += Prow[z0.w];
           pz += Prow[z1.x]; pz += Prow[z1.y]; pz += Prow[z1.z]; pz += Prow[z1.w];
         }
@@ -223,46 +233,52 @@ static __device__ __noinline__ void seasonal_filter_pass(const SeasFilterArgs& p
         if (lane == 0) am += m1;
       }
       if (!obs && cb == 0u && !slope) {
-        if (lane == 0) Prow[0] += ql;
+        if (lane == 0) { prow[0] += ql; Prow[0] = prow[0]; }
         continue;
       }
       lds_sync();
       if (comp) {
-        // One sweep of the own row, 8 columns per batch of loads:
+        // One sweep of the own row (registers), every load of the step's vectors issued first:
         //   P'[i][j] = P[i][j] - (Pz)_i (Pz)_j / F  + sigma_k^2 g_i g_j   (g: own block's shock)
         // and, with a slope, level <- level + slope on rows (lane 0 adds row 1) and columns.
         const float pz1 = slope ? pzv[1] : 0.f;
-        for (int j0 = 0; j0 < D; j0 += 8) {
-          float pr[8], pj[8], gj[8];
-          {
-            const ci_f4v a0 = ld4(Prow + j0), a1 = ld4(Prow + j0 + 4);
-            const ci_f4v b0 = ld4(pzv + j0), b1 = ld4(pzv + j0 + 4);
-            const ci_f4v c0 = ld4(gmine + j0), c1 = ld4(gmine + j0 + 4);
-            pr[0] = a0.x; pr[1] = a0.y; pr[2] = a0.z; pr[3] = a0.w; pr[4] = a1.x; pr[5] = a1.y; pr[6] = a1.z; pr[7] = a1.w;
-            pj[0] = b0.x; pj[1] = b0.y; pj[2] = b0.z; pj[3] = b0.w; pj[4] = b1.x; pj[5] = b1.y; pj[6] = b1.z; pj[7] = b1.w;
-            gj[0] = c0.x; gj[1] = c0.y; gj[2] = c0.z; gj[3] = c0.w; gj[4] = c1.x; gj[5] = c1.y; gj[6] = c1.z; gj[7] = c1.w;
-          }
-          if (slope) {
-            const ci_f4v d0 = ld4(Pm + DS + j0), d1 = ld4(Pm + DS + j0 + 4);
-            const float p1[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        ci_f4v pj4[2 * NCH], gj4[2 * NCH], p14[2 * NCH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              float r = fmaf(-(pz * pj[u]), rF, pr[u]);
-              if (lane == 0) r += fmaf(-(pz1 * pj[u]), rF, p1[u]);
-              pr[u] = fmaf(myd2, gi * gj[u], r);
-            }
-            if (j0 == 0) {
-              pr[0] += pr[1];
-              if (lane == 1) pr[1] += qs;
-            }
-          } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pr[u] = fmaf(myd2, gi * gj[u], fmaf(-(pz * pj[u]), rF, pr[u]));
+        for (int c = 0; c < NCH; ++c)
+          if (8 * c < D) {
+            pj4[2 * c] = ld4(pzv + 8 * c); pj4[2 * c + 1] = ld4(pzv + 8 * c + 4);
+            gj4[2 * c] = ld4(gmine + 8 * c); gj4[2 * c + 1] = ld4(gmine + 8 * c + 4);
+            if (slope) { p14[2 * c] = ld4(Pm + DS + 8 * c); p14[2 * c + 1] = ld4(Pm + DS + 8 * c + 4); }
           }
-          if (j0 == 0 && lane == 0) pr[0] += ql;
-          *(CI_LDS ci_f4v*)(Prow + j0) = ci_f4v{pr[0], pr[1], pr[2], pr[3]};
-          *(CI_LDS ci_f4v*)(Prow + j0 + 4) = ci_f4v{pr[4], pr[5], pr[6], pr[7]};
-        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if (8 * c < D) {
+            const float pj[8] = {pj4[2 * c].x, pj4[2 * c].y, pj4[2 * c].z, pj4[2 * c].w,
+                                 pj4[2 * c + 1].x, pj4[2 * c + 1].y, pj4[2 * c + 1].z, pj4[2 * c + 1].w};
+            const float gj[8] = {gj4[2 * c].x, gj4[2 * c].y, gj4[2 * c].z, gj4[2 * c].w,
+                                 gj4[2 * c + 1].x, gj4[2 * c + 1].y, gj4[2 * c + 1].z, gj4[2 * c + 1].w};
+            if (slope) {
+              const float p1[8] = {p14[2 * c].x, p14[2 * c].y, p14[2 * c].z, p14[2 * c].w,
+                                   p14[2 * c + 1].x, p14[2 * c + 1].y, p14[2 * c + 1].z, p14[2 * c + 1].w};
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                float r = fmaf(-(pz * pj[u]), rF, prow[8 * c + u]);
+                if (lane == 0) r += fmaf(-(pz1 * pj[u]), rF, p1[u]);
+                prow[8 * c + u] = fmaf(myd2, gi * gj[u], r);
+              }
+              if (c == 0) {
+                prow[0] += prow[1];
+                if (lane == 1) prow[1] += qs;
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                prow[8 * c + u] = fmaf(myd2, gi * gj[u], fmaf(-(pz * pj[u]), rF, prow[8 * c + u]));
+            }
+            if (c == 0 && lane == 0) prow[0] += ql;
+            *(CI_LDS ci_f4v*)(Prow + 8 * c) = ci_f4v{prow[8 * c], prow[8 * c + 1], prow[8 * c + 2], prow[8 * c + 3]};
+            *(CI_LDS ci_f4v*)(Prow + 8 * c + 4) = ci_f4v{prow[8 * c + 4], prow[8 * c + 5], prow[8 * c + 6], prow[8 * c + 7]};
+          }
       }
       // the changing blocks observe their next slot from t + 1 on
       if (mych && pos == 0) zcol[blk] = p.boff + ((mycur + 1 == nb) ? 0 : mycur + 1);
@@ -676,7 +692,10 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
       fa.has_slope = a.has_slope;
       fa.a1e = a1e; fa.H = H; fa.ql = ql; fa.qs = qs; fa.myd2 = d2[blk0]; fa.rnb = rnb;
       fa.Pm = Pm; fa.pzv = pzv; fa.kf = kf; fa.vf = vf; fa.ytil = ytil; fa.cbv = cbv; fa.msk = msk; fa.cidb = cidb;
-      seasonal_filter_pass<GWS>(fa);
+      if (D <= 16) seasonal_filter_pass<GWS, 2>(fa);
+      else if (D <= 24) seasonal_filter_pass<GWS, 3>(fa);
+      else if (D <= 32) seasonal_filter_pass<GWS, 4>(fa);
+      else seasonal_filter_pass<GWS, 8>(fa);
     }
     wave_sync();
     prof.tick(25);

@@ -2456,7 +2456,8 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
         for (int i = 0; i < D; ++i) kr = fmaf(kf[l].v[i], rT.v[i], kr);
         const float e = vf[l] - kr;
         const Vec<D> nk = mv(NT, kf[l]);
-        float dt = 1.0f / fvar[l];
+        const float rfv = __builtin_amdgcn_rcpf(fvar[l]);      // the same 1 / F_t the scan's element used
+        float dt = rfv;
 #pragma unroll
         for (int i = 0; i < D; ++i) dt = fmaf(kf[l].v[i], nk.v[i], dt);
         gH += 0.5f * (e * e - dt);
@@ -2465,7 +2466,7 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
         r = mtv(m, rT);
         r.v[0] += vf[l];
         N = mtm(m, mm(NT, m));
-        N.m[0][0] += 1.0f / fvar[l];
+        N.m[0][0] += rfv;
         symmetrize(N);
       } else {
         r = rT;

@@ -255,6 +255,35 @@ __device__ __forceinline__ E block_scan_excl_bwd(const E& tot, Op op, const E& i
   return op(ex, ws);
 }
 
+// L consecutive floats row[t0 .. t0 + L) of a length-T row in global memory, 0 beyond the end --
+// straight-line code (clamped addresses, zeroed by selects): the callers hoist every wave-uniform
+// choice (LDS copy / wide / scalar) OUT of their loops over rows, because a branch around a load
+// makes the compiler wait for it at the join, which serialises the rows of a batch (one L2 round
+// trip per row instead of one per batch).  Wide: T % 4 == 0 and a 16-byte aligned row.
+template <int L>
+__device__ __forceinline__ void global_row_load_wide(const float* __restrict__ row, int t0, int T,
+                                                     float (&v)[L]) {
+  static_assert(L % 4 == 0, "wide rows need L % 4 == 0");
+#pragma unroll
+  for (int q = 0; q < L / 4; ++q) {
+    const int t = t0 + 4 * q;
+    const float4 x = *reinterpret_cast<const float4*>(row + (t < T ? t : T - 4));
+    const bool in = t < T;
+    v[4 * q] = in ? x.x : 0.f; v[4 * q + 1] = in ? x.y : 0.f;
+    v[4 * q + 2] = in ? x.z : 0.f; v[4 * q + 3] = in ? x.w : 0.f;
+  }
+}
+template <int L>
+__device__ __forceinline__ void global_row_load_scalar(const float* __restrict__ row, int t0, int T,
+                                                       float (&v)[L]) {
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    const float x = row[t < T ? t : T - 1];
+    v[l] = t < T ? x : 0.f;
+  }
+}
+
 // L consecutive floats of an LDS row starting at a 4*L-byte aligned index, as wide loads.
 template <int L>
 __device__ __forceinline__ void lds_row_load(const float* p, float (&v)[L]) {
@@ -1785,6 +1814,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   const float* yg = a.y + (size_t)series * T;
   const uint8_t* mg = a.mask + (size_t)series * T;
   const float* Xg = a.Xt + (size_t)series * P * T;
+  // rows of the streamed design can be read as float4: T % 4 == 0 keeps every row 16-byte aligned
+  const bool xwide = L % 4 == 0 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(Xg) & 15) == 0;
   const int t0 = tid * L;
   RegLds R;
   {
@@ -1953,18 +1984,36 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         const float tot = wave_reduce_scatter16(pj, lane);
         if (lane < 16) red[wave * RS + lane] = tot;
       } else if constexpr (PM == 2) {
-        for (int j = 0; j < P; ++j) {
-          float pj = 0.f;
-          if (a.x_in_lds) {
+        // 16 features per round: their rows are independent loads (one L2 round trip per batch of
+        // 8 when X streams from L2, instead of one per feature) and their wave sums ONE
+        // reduce-scatter.  The row source is chosen outside the loop (see global_row_load_wide).
+        auto xt_rounds = [&](auto load_row) {
+          for (int j0 = 0; j0 < P; j0 += 16) {
+            float pj[16];
 #pragma unroll
-            for (int l = 0; l < L; ++l) pj = fmaf(Xs[j * TPAD + t0 + l], tg[l], pj);
-          } else {
+            for (int h = 0; h < 2; ++h) {
+              float xr[8][L];
 #pragma unroll
-            for (int l = 0; l < L; ++l)
-              if (t0 + l < T) pj = fmaf(Xg[(size_t)j * T + t0 + l], tg[l], pj);
+              for (int u = 0; u < 8; ++u) load_row(j0 + 8 * h + u < P ? j0 + 8 * h + u : P - 1, xr[u]);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                float sv = 0.f;
+#pragma unroll
+                for (int l = 0; l < L; ++l) sv = fmaf(xr[u][l], tg[l], sv);
+                pj[8 * h + u] = sv;
+              }
+            }
+            const float tot = wave_reduce_scatter16(pj, lane);
+            if (lane < 16 && j0 + lane < P) red[wave * RS + j0 + lane] = tot;
           }
-          const float s = wave_sum_dpp(pj);
-          if (lane == 0) red[wave * RS + j] = s;
+        };
+        if (a.x_in_lds) {
+          xt_rounds([&](int j, float (&xr)[L]) { lds_row_load<L>(Xs + j * TPAD + t0, xr); });
+        } else if (xwide) {
+          if constexpr (L % 4 == 0)
+            xt_rounds([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xg + (size_t)j * T, t0, T, xr); });
+        } else {
+          xt_rounds([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); });
         }
       }
       prof.tick(13);
@@ -2100,16 +2149,29 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
       }
     } else if constexpr (PM == 2) {
-      for (int j = 0; j < P; ++j) {
-        const float wj = wls[j];
-        if (a.x_in_lds) {
+      // 8 features per round (independent row loads, see the X~'targets loop)
+      auto xw_rounds = [&](auto load_row) {
+        for (int j0 = 0; j0 < P; j0 += 8) {
+          float xr[8][L], wj[8];
 #pragma unroll
-          for (int l = 0; l < L; ++l) xw[l] = fmaf(Xs[j * TPAD + t0 + l], wj, xw[l]);
-        } else {
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u < P ? j0 + u : P - 1;
+            wj[u] = j0 + u < P ? wls[j] : 0.f;
+            load_row(j, xr[u]);
+          }
 #pragma unroll
-          for (int l = 0; l < L; ++l)
-            if (t0 + l < T) xw[l] = fmaf(Xg[(size_t)j * T + t0 + l], wj, xw[l]);
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[u][l], wj[u], xw[l]);
         }
+      };
+      if (a.x_in_lds) {
+        xw_rounds([&](int j, float (&xr)[L]) { lds_row_load<L>(Xs + j * TPAD + t0, xr); });
+      } else if (xwide) {
+        if constexpr (L % 4 == 0)
+          xw_rounds([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xg + (size_t)j * T, t0, T, xr); });
+      } else {
+        xw_rounds([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); });
       }
     }
 #pragma unroll

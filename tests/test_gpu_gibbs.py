@@ -36,6 +36,8 @@ def _fit_both(T, p, has_slope, W, S, C=1, seed=(5, 9), data_seed=0, chain_offset
     (1000, 10, 1),  # BASELINE cfg2 shape
     (700, 10, 0),   # L=4 with padding, local level
     (500, 24, 0),   # P=25 > 16: LDS-resident regression block (in-place sweeps)
+    (1000, 34, 1),  # P=35: the design no longer fits LDS and streams from L2, float4 rows
+    (998, 33, 0),   # P=34, T % 4 != 0: the streamed design read row-scalar, ragged last chunk
     (5000, 3, 0),   # T > 4096: trend-only series on the time-parallel kernel (inert seasonal block)
     (9000, 2, 1),   # same with a local linear trend
     (40000, 1, 0),  # 157 steps per thread (the kernel's own limit is 65536 steps)

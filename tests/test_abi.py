@@ -140,3 +140,21 @@ def test_round_3_entry_points_validate_before_any_device_call():
   assert L.ci_ll_session_create2(C.byref(pb), bad, y32.ctypes.data, m.ctypes.data, None, None, 4,
                                  C.byref(h)) != 0
   assert b"weights_prior_scale" in L.ci_last_error()
+
+
+def test_make_params_fills_every_member_by_name():
+  """make_params writes the ci_series_params table as one float64 block: every named member, the
+  drift-scale array and the weights-prior multiplier must land where the struct declares them."""
+  specs = []
+  for b in range(3):
+    sp = {f: 100.0 * b + i for i, f in enumerate(_native._PARAM_FIELDS)}   # pylint: disable=protected-access
+    sp["drift_scale0"] = (0.5 + b, 0.25)
+    if b == 1:
+      sp["weights_prior_scale"] = 9.0
+    specs.append(sp)
+  arr = _native.make_params(specs)
+  for b, sp in enumerate(specs):
+    for f in _native._PARAM_FIELDS:                                        # pylint: disable=protected-access
+      assert getattr(arr[b], f) == sp[f], (b, f)
+    assert list(arr[b].drift_scale0)[:3] == [0.5 + b, 0.25, 0.0]
+    assert arr[b].weights_prior_scale == (9.0 if b == 1 else 1.0)

@@ -576,3 +576,23 @@ def test_fit_causalimpact_with_more_than_52_covariates():
   incl = (w != 0).mean(axis=0)
   assert incl[[3, 40, 77]].min() > 0.9 and np.delete(incl, [3, 40, 77, p]).mean() < 0.15
   np.testing.assert_allclose(res.summary.loc["average", "abs_effect"], 4.0, atol=0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,p,has_slope", [(3, 0, 0), (4, 1, 0), (5, 0, 1), (9, 2, 1), (6, 0, 0)])
+def test_shortest_series_match_the_oracle(T, p, has_slope):
+  """The C-ABI's lower bound T = 3 and its neighbours: one step per thread, most threads idle, the
+  last step missing (the forecast)."""
+  y, mask, X, _ = syn.make_sampler_inputs(12, max(p, 1), 3)
+  y, mask = y[:T].copy(), np.zeros(T, bool)
+  mask[-1] = True
+  X = X[:T, :p + 1] if p else None
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope))
+  pb = _native.make_problem(T=T, P=spec["P"], has_slope=has_slope, num_warmup=0, num_results=4,
+                            seed=(1, 2))
+  got = _native.fit_gibbs(pb, y[None], mask[None], None if X is None else X[None], None,
+                          _native.make_params([spec]))
+  w = orc.fit_gibbs(y, mask, X, spec, num_results=4, num_warmup=0, seed=(1, 2))
+  np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=1e-4)
+  np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=1e-4)
+  np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-4)

@@ -348,7 +348,7 @@ void ci_oracle_dk_draw(const ci_oracle_ssm* m, const double* data,
 /* ------------------------------------------------------------------ */
 typedef struct {
   int na;
-  int idx[256];
+  int idx[512];
   double logp;
   double post_scale;       /* b0 + (yty - b'M^{-1}b)/2 */
   double* chol_post;       /* na*na */
@@ -433,7 +433,7 @@ static double draw_scale(double conc, double scale, double ub, double n, double 
 int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out) {
   const int T = pb->T, P = pb->P, K = pb->num_blocks;
   const int W = pb->num_warmup, S = pb->num_results;
-  if (T < 1 || P < 0 || P > 255 || K < 0 || K > CI_MAX_BLOCKS) return -1;
+  if (T < 1 || P < 0 || P > 512 || K < 0 || K > CI_MAX_BLOCKS) return -1;
   ci_oracle_ssm m;
   memset(&m, 0, sizeof(m));
   m.T = T; m.has_slope = pb->has_slope; m.num_blocks = K;

@@ -44,6 +44,7 @@ def _fit_both(T, p, has_slope, W, S, C=1, seed=(5, 9), data_seed=0, chain_offset
     (400, 60, 0),   # P = 61 > 52: sequential kernel, regression block in the HBM workspace
     (300, 130, 1),  # P = 131: three rounds of 64 visiting positions, local linear trend
     (6000, 70, 0),  # big P and T > 4096 together (arrays over time in the workspace too)
+    (700, 511, 0),  # P = 512: the largest design the C-ABI accepts (eight rounds of positions)
 ])
 def test_first_iterations_match_oracle_per_draw(T, p, has_slope):
   S = 4

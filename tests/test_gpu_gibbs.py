@@ -41,6 +41,7 @@ def _fit_both(T, p, has_slope, W, S, C=1, seed=(5, 9), data_seed=0, chain_offset
     (5000, 3, 0),   # T > 4096: trend-only series on the time-parallel kernel (inert seasonal block)
     (9000, 2, 1),   # same with a local linear trend
     (40000, 1, 0),  # 157 steps per thread (the kernel's own limit is 65536 steps)
+    (65536, 1, 0),  # ... and that limit: 256 steps per thread
     (400, 60, 0),   # P = 61 > 52: sequential kernel, regression block in the HBM workspace
     (300, 130, 1),  # P = 131: three rounds of 64 visiting positions, local linear trend
     (6000, 70, 0),  # big P and T > 4096 together (arrays over time in the workspace too)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define CI_MAX_D 40        /* max state dimension handled by the oracle */
+#define CI_MAX_D 64        /* max state dimension handled by the oracle (the device: 64 full-effect lanes) */
 #define CI_MAX_BLOCKS 8    /* max seasonal blocks */
 
 /* RNG sites (shared with the HIP kernels: csrc/ci_rng.h). */

@@ -138,6 +138,12 @@ SEQ = _native.FLAG_SEQUENTIAL_SEASONAL
     (150, 0, 0, ((2, 1),), 0),                          # n = 2: a single free effect
     (330, 5, 0, ((5, 1),), 0), (96, 1, 1, ((3, 2),), 0), (240, 3, 0, ((6, (1, 1, 2, 1, 1, 3)),), 0),
     (350, 66, 0, ((7, 1),), 0),                         # P = 67 > 52 with a weekly block
+    # the sequential kernel's wider covariance rows (8, 16, 32 registers more per lane)
+    (200, 2, 0, ((12, 1),), 0),                         # monthly-type block: D = 13
+    (260, 0, 1, ((24, 1),), 0),                         # hour-of-day block + trend: D = 26
+    (300, 3, 0, ((52, 1),), 0),                         # week-of-year block: D = 53
+    (250, 0, 1, ((62, 1),), 0),                         # D = 64: the widest state the kernel holds
+    (280, 1, 0, ((24, 1), (7, 24)), 0),                 # hour-of-day and day-of-week: D = 32
     (280, 90, 1, ((4, 2), (7, 1)), 0),                  # P = 91, trend + two blocks
 ])
 def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, seasons, flags):

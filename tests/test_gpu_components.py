@@ -181,6 +181,8 @@ def test_latent_draws_for_given_parameters_match_oracle():
     (300, 1, 0, ((6, (1, 1, 2, 1, 1, 3)),)),     # per-season lengths
     (5000, 2, 1, ()),                            # no block, T > 4096: the sequential route too
     (6000, 1, 0, ((7, 1),)),
+    (37, 1, 1, ((3, 1),)),                       # shorter than the workgroup: most chunks empty
+    (30000, 1, 1, ((7, 2),)),                    # 118 steps per thread, trend + block (d = 8)
 ])
 @pytest.mark.parametrize("route", ["auto", "sequential"])
 def test_sequential_loglik_and_score_match_the_oracle(T, p, has_slope, seasons, route):

@@ -70,7 +70,7 @@ struct SLayout {
   // arrays over time (LDS when they fit, else the per-chain HBM workspace)
   size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, mask, cbits, cidx, t_total;
   // always in LDS
-  size_t Pa, Pb, pzv, zi, x0r, d2, xtx, omega, bvec, w,
+  size_t Pa, pzv, zi, x0r, d2, xtx, omega, bvec, w,
       aug0, pri0, chol, zv, uperm, nz, perm, idx, total;
 };
 
@@ -98,8 +98,8 @@ __host__ __device__ inline SLayout make_slayout(int T, int P, int K, int D, int 
   l.nz = take(big ? sizeof(int) * Pp : 16);
   l.perm = take(big ? sizeof(int) * Pp : 16);
   l.idx = take(big ? sizeof(int) * Pp : 16);
-  // the covariance: D rows of stride ((D + 7) & ~7) + 4 floats (Pa and Pb are one buffer)
-  l.Pa = take(sizeof(float) * D * ((((size_t)D + 7) & ~(size_t)7) + 4)); l.Pb = take(16);
+  // the covariance (mirror of the lanes' register rows): D rows of stride ((D + 7) & ~7) + 4 floats
+  l.Pa = take(sizeof(float) * D * ((((size_t)D + 7) & ~(size_t)7) + 4));
   // P z [72], the blocks' shock vectors [SMAXK][72], the observed columns [16]
   l.pzv = take(sizeof(float) * (72 + SMAXK * 72 + 16)); l.zi = take(sizeof(float) * (dred + 1));
   l.x0r = take(sizeof(float) * (dred + 1));
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
   float* zo = (float*)(tb_ + L.zo); float* seas = (float*)(tb_ + L.seas);
   float* zk = (float*)(tb_ + L.zk); float* gd = (float*)(tb_ + L.gd);
   float* kf = (float*)(tb_ + L.kf);
-  float* rs = (float*)(tb_ + L.rs); float* Pcur = (float*)(smem + L.Pa);
-  float* Pnxt = (float*)(smem + L.Pb); float* pzv = (float*)(smem + L.pzv);
+  float* rs = (float*)(tb_ + L.rs); float* Pm = (float*)(smem + L.Pa);   // covariance rows, stride DS
+  float* pzv = (float*)(smem + L.pzv);
   float* zi = (float*)(smem + L.zi); float* x0r = (float*)(smem + L.x0r);
   float* d2 = (float*)(smem + L.d2);
   uint8_t* msk = tb_ + L.mask; uint8_t* cbv = tb_ + L.cbits;
@@ -613,7 +613,6 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
     // change is sigma_k eta (e_{slot that was observed} - 1/n): rank one.  Lane i owns ROW i of the
     // covariance in LDS (odd row stride: column reads are conflict-free), so the measurement and
     // time updates are one in-place sweep of the own row -- no tables, no second buffer.
-    float* Pm = Pcur < Pnxt ? Pcur : Pnxt;       // 2 D^2 + 32 floats: D rows of stride DS
     const int DS = ((D + 7) & ~7) + 4;           // 16-byte rows, 8-column batches, stride = 4 mod 8
     float* Prow = Pm + (comp ? lane : 0) * DS;
     const float rnb = 1.0f / (float)nb;

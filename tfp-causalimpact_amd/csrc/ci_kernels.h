@@ -2421,19 +2421,37 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
   // the caller's zero-padded copy of the design (xstride != 0: rows of a multiple of 4 floats in
   // LDS) is read as whole rows of the L owned steps; the matrix in HBM step by step
   const bool rows = xstride != 0 && (xstride & 3) == 0;
-#pragma unroll 4
-  for (int j = 0; j < P; ++j) {
-    const float bj = (float)th[3 + j];
-    float xr[L];
+  // the design streamed from HBM / L2 (xstride == 0): float4 rows when every row is 16-byte aligned.
+  // The row source is chosen OUTSIDE the loops over features (see global_row_load_wide) and the
+  // rows travel in batches of 4 independent loads: with the choice inside the loop every row
+  // cost a full L2 round trip (26 us per leapfrog at P = 36 against 12 at P = 31).
+  const bool gwide = xstride == 0 && L % 4 == 0 && (T & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(Xt) & 15) == 0;
+  auto with_rows = [&](auto body) {
     if (rows) {
-      lds_row_load<L>(Xt + j * xs + t0, xr);
+      body([&](int j, float (&xr)[L]) { lds_row_load<L>(Xt + j * xs + t0, xr); });
+    } else if (gwide) {
+      if constexpr (L % 4 == 0)
+        body([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xt + j * xs, t0, T, xr); });
     } else {
-#pragma unroll
-      for (int l = 0; l < L; ++l) xr[l] = t0 + l < T ? Xt[j * xs + t0 + l] : 0.f;
+      body([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xt + j * xs, t0, T, xr); });
     }
+  };
+  with_rows([&](auto load_row) {
+    for (int j0 = 0; j0 < P; j0 += 4) {
+      float xr[4][L], bj[4];
 #pragma unroll
-    for (int l = 0; l < L; ++l) resid[l] = fmaf(-xr[l], bj, resid[l]);
-  }
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u < P ? j0 + u : P - 1;
+        bj[u] = j0 + u < P ? (float)th[3 + j] : 0.f;
+        load_row(j, xr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int l = 0; l < L; ++l) resid[l] = fmaf(-xr[u][l], bj[u], resid[l]);
+    }
+  });
 #pragma unroll
   for (int l = 0; l < L; ++l)
     if ((maskbits >> l) & 1u) resid[l] = 0.f;
@@ -2538,34 +2556,46 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
   }
   // block sums: ll, dH, dQ[0], dQ[1], then dbeta_j
   const int NS = P + 4;
-  auto put = [&](int slot, float v) {
-    const float w = wave_prefix_dpp(v);
-    if (lane == 63) part[wave * NS + slot] = w;
-  };
-  auto xe_dot = [&](int j) {
-    float xr[L];
-    if (rows) {
-      lds_row_load<L>(Xt + j * xs + t0, xr);
-    } else {
+  // d l / d beta_j = sum_t x_jt e_t: rows in batches of 4 independent loads, 16 wave sums per
+  // reduce-scatter (lane l < 16 ends up with the wave total of slot l)
+  with_rows([&](auto load_row) {
+    auto dots4 = [&](int j0, float* out) {            // out[u] = this thread's share of feature j0 + u
+      if (j0 >= P) {                                  // (no design at all, or fewer than j0 columns)
 #pragma unroll
-      for (int l = 0; l < L; ++l) xr[l] = t0 + l < T ? Xt[j * xs + t0 + l] : 0.f;
+        for (int u = 0; u < 4; ++u) out[u] = 0.f;
+        return;
+      }
+      float xr[4][L];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load_row(j0 + u < P ? j0 + u : P - 1, xr[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float sv = 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) sv = fmaf(xr[u][l], e_l[l], sv);
+        out[u] = j0 + u < P ? sv : 0.f;
+      }
+    };
+    {
+      // slots 0..3: ll, dH, dQ[0], dQ[1]; slots 4..15: the first 12 features
+      float v16[16];
+      v16[0] = ll; v16[1] = gH; v16[2] = gQ[0]; v16[3] = D == 2 ? gQ[D - 1] : 0.f;
+      dots4(0, v16 + 4);
+      dots4(4, v16 + 8);
+      dots4(8, v16 + 12);
+      const float tot = wave_reduce_scatter16(v16, lane);
+      if (lane < 16 && lane < NS) part[wave * NS + lane] = tot;
     }
-    float sv = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-      if (t0 + l < T) sv = fmaf(xr[l], e_l[l], sv);
-    return sv;
-  };
-  {
-    // the first 16 sums in one reduce-scatter (lane l < 16 ends up with the wave total of slot l)
-    float v16[16];
-    v16[0] = ll; v16[1] = gH; v16[2] = gQ[0]; v16[3] = D == 2 ? gQ[D - 1] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 12; ++j) v16[4 + j] = j < P ? xe_dot(j) : 0.f;
-    const float tot = wave_reduce_scatter16(v16, lane);
-    if (lane < 16 && lane < NS) part[wave * NS + lane] = tot;
-  }
-  for (int j = 12; j < P; ++j) put(4 + j, xe_dot(j));
+    for (int j0 = 12; j0 < P; j0 += 16) {
+      float d16[16];
+      dots4(j0, d16);
+      dots4(j0 + 4, d16 + 4);
+      dots4(j0 + 8, d16 + 8);
+      dots4(j0 + 12, d16 + 12);
+      const float tot = wave_reduce_scatter16(d16, lane);
+      if (lane < 16 && j0 + lane < P) part[wave * NS + 4 + j0 + lane] = tot;
+    }
+  });
   __syncthreads();
   if (tid < NS) {
     double s = 0.0;

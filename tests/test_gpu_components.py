@@ -134,7 +134,11 @@ def _oracle_ll(spec, y, mask, X, th):
   return orc.kalman_loglik(ssm, resid)
 
 
-@pytest.mark.parametrize("T,p,has_slope", [(80, 2, 1), (300, 0, 0), (1000, 10, 1)])
+@pytest.mark.parametrize("T,p,has_slope", [
+    (80, 2, 1), (300, 0, 0), (1000, 10, 1),
+    (1000, 40, 1),     # more than 12 covariates: further rounds of 16 sums, float4 rows of the design
+    (998, 37, 0),      # T % 4 != 0: the design read row-scalar, ragged last chunk
+])
 def test_loglik_score_matches_finite_differences_of_oracle(T, p, has_slope):
   """Row H: device score (two suffix scans) vs central differences of the float64 oracle
   log-likelihood.  float32 recursions: 2 % relative on each component's scale."""

@@ -445,27 +445,59 @@ template <int TR, int NS> struct WideScoreFn {
   __device__ __forceinline__ void eval(const double* dev, double* gdev, double* ll_out, bool want_grad) {
     const int T = q->T, P = q->P, K = q->K, TP = NT * Lc, ob = 3 + K;
     const int n4 = TP >> 2;
-    // ---- residual (time interleaved over threads: coalesced 16-byte accesses)
-    for (int c4 = tid; c4 < n4; c4 += NT) {
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int t = 4 * c4;
-      if (t < T) {
-        float yv[4], xs[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- residual (time interleaved over threads: coalesced 16-byte accesses).  The rows of the
+    // design are read UNCONDITIONALLY (a load inside a lane-predicated branch is waited for at the
+    // end of the branch: one L2 round trip per load), four features per batch; `wide` (T % 4 == 0,
+    // 16-byte aligned rows) is chosen outside the loops.
+    const bool wide = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(q->Xt) & 15) == 0;
+    auto row4_wide = [&](int j, int t) { return *reinterpret_cast<const float4*>(q->Xt + (size_t)j * T + t); };
+    auto row4_scalar = [&](int j, int t) {            // t < T; entries beyond the end read as 0
+      const float* r = q->Xt + (size_t)j * T;
+      float4 x;
+      x.x = r[t];
+      const float x1 = r[t + 1 < T ? t + 1 : T - 1], x2 = r[t + 2 < T ? t + 2 : T - 1],
+                  x3 = r[t + 3 < T ? t + 3 : T - 1];
+      x.y = t + 1 < T ? x1 : 0.f; x.z = t + 2 < T ? x2 : 0.f; x.w = t + 3 < T ? x3 : 0.f;
+      return x;
+    };
+    auto residual_pass = [&](auto row4) {
+      for (int c4 = tid; c4 < n4; c4 += NT) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int t = 4 * c4;
+        if (t < T) {
+          float xs[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int j0 = 0; j0 < P; j0 += 4) {
+            float4 xr[4];
+            float bj[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) yv[u] = (t + u < T && !mskp[t + u]) ? q->y[t + u] : 0.f;
-        for (int j = 0; j < P; ++j) {
-          const float bj = (float)dev[ob + j];
+            for (int u = 0; u < 4; ++u) {
+              const int j = j0 + u < P ? j0 + u : P - 1;
+              bj[u] = j0 + u < P ? (float)dev[ob + j] : 0.f;
+              xr[u] = row4(j, t);
+            }
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (t + u < T) xs[u] = fmaf(q->Xt[(size_t)j * T + t + u], bj, xs[u]);
+            for (int u = 0; u < 4; ++u) {
+              xs[0] = fmaf(xr[u].x, bj[u], xs[0]); xs[1] = fmaf(xr[u].y, bj[u], xs[1]);
+              xs[2] = fmaf(xr[u].z, bj[u], xs[2]); xs[3] = fmaf(xr[u].w, bj[u], xs[3]);
+            }
+          }
+          float yv[4];
+          bool ok[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {               // clamped, unconditional (see above)
+            const int tu = t + u < T ? t + u : T - 1;
+            yv[u] = q->y[tu];
+            ok[u] = t + u < T && mskp[tu] == 0;
+          }
+          s.x = ok[0] ? yv[0] - xs[0] : 0.f;
+          s.y = ok[1] ? yv[1] - xs[1] : 0.f;
+          s.z = ok[2] ? yv[2] - xs[2] : 0.f;
+          s.w = ok[3] ? yv[3] - xs[3] : 0.f;
         }
-        s.x = mskp[t] ? 0.f : yv[0] - xs[0];
-        s.y = (t + 1 < T && !mskp[t + 1]) ? yv[1] - xs[1] : 0.f;
-        s.z = (t + 2 < T && !mskp[t + 2]) ? yv[2] - xs[2] : 0.f;
-        s.w = (t + 3 < T && !mskp[t + 3]) ? yv[3] - xs[3] : 0.f;
+        *reinterpret_cast<float4*>(residw + 4 * c4) = s;
       }
-      *reinterpret_cast<float4*>(residw + 4 * c4) = s;
-    }
+    };
+    if (wide) residual_pass(row4_wide); else residual_pass(row4_scalar);
     WideScal sc;
     sc.so = (float)dev[0]; sc.H = sc.so * sc.so;
     sc.sl = (float)dev[1]; sc.ql = sc.sl * sc.sl;
@@ -487,21 +519,31 @@ template <int TR, int NS> struct WideScoreFn {
     }
     __syncthreads();                 // e_t of every step is in the workspace
     if (want_grad) {
-      for (int j = 0; j < P; ++j) {
-        float acc = 0.f;
-        for (int c4 = tid; c4 < n4; c4 += NT) {
-          const int t = 4 * c4;
-          if (t < T) {
-            const float4 e4 = *reinterpret_cast<const float4*>(ew + t);
-            acc = fmaf(q->Xt[(size_t)j * T + t], e4.x, acc);
-            if (t + 1 < T) acc = fmaf(q->Xt[(size_t)j * T + t + 1], e4.y, acc);
-            if (t + 2 < T) acc = fmaf(q->Xt[(size_t)j * T + t + 2], e4.z, acc);
-            if (t + 3 < T) acc = fmaf(q->Xt[(size_t)j * T + t + 3], e4.w, acc);
+      // d l / d beta_j = sum_t x_jt e_t, four features per pass over time (e_t = 0 beyond T and
+      // where y is missing)
+      auto gradient_pass = [&](auto row4) {
+        for (int j0 = 0; j0 < P; j0 += 4) {
+          float acc[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int c4 = tid; c4 < n4; c4 += NT) {
+            const int t = 4 * c4;
+            if (t < T) {
+              const float4 e4 = *reinterpret_cast<const float4*>(ew + t);
+              float4 xr[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) xr[u] = row4(j0 + u < P ? j0 + u : P - 1, t);
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                acc[u] = fmaf(xr[u].w, e4.w, fmaf(xr[u].z, e4.z, fmaf(xr[u].y, e4.y, fmaf(xr[u].x, e4.x, acc[u]))));
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float w = wave_sum_dpp(acc[u]);
+            if (lane == 0 && j0 + u < P) red[wave * RSN + 8 + j0 + u] = w;
           }
         }
-        const float w = wave_sum_dpp(acc);
-        if (lane == 0) red[wave * RSN + 8 + j] = w;
-      }
+      };
+      if (wide) gradient_pass(row4_wide); else gradient_pass(row4_scalar);
     }
     __syncthreads();
     if (tid < RSN) {

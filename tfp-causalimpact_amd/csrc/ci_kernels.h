@@ -1965,17 +1965,50 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
       if constexpr (PM == 1) {
         // register-resident path: 16 independent accumulators, DPP reductions interleave
         float pj[16];
-        // branch-free: rows >= P re-read row P-1 and are masked out, so all 16 wide LDS loads
-        // are in flight before the first FMA (per-feature branches exposed the LDS latency)
+        if (a.x_in_lds) {
+          // branch-free: rows >= P re-read row P-1 and are masked out, so all 16 wide LDS loads
+          // are in flight before the first FMA (per-feature branches exposed the LDS latency)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int jj = j < P ? j : P - 1;
-          float xr[L];
-          lds_row_load<L>(Xs + jj * TPAD + t0, xr);
-          float s = 0.f;
+          for (int j = 0; j < 16; ++j) {
+            const int jj = j < P ? j : P - 1;
+            float xr[L];
+            lds_row_load<L>(Xs + jj * TPAD + t0, xr);
+            float s = 0.f;
 #pragma unroll
-          for (int l = 0; l < L; ++l) s = fmaf(xr[l], tg[l], s);
-          pj[j] = s;
+            for (int l = 0; l < L; ++l) s = fmaf(xr[l], tg[l], s);
+            pj[j] = s;
+          }
+        } else {
+          // long series: T x P floats no longer fit LDS and the design streams from L2 -- the
+          // regression block stays in registers all the same.  Rows in batches of independent
+          // loads (as many as 32 registers hold), unused batches skipped.
+          constexpr int RB = L >= 16 ? 2 : (L >= 8 ? 4 : 8);
+          auto stream = [&](auto load_row) {
+#pragma unroll
+            for (int h = 0; h < 16 / RB; ++h) {
+              if (h * RB >= P) {
+#pragma unroll
+                for (int u = 0; u < RB; ++u) pj[h * RB + u] = 0.f;
+                continue;
+              }
+              float xr[RB][L];
+#pragma unroll
+              for (int u = 0; u < RB; ++u) load_row(h * RB + u < P ? h * RB + u : P - 1, xr[u]);
+#pragma unroll
+              for (int u = 0; u < RB; ++u) {
+                float sv = 0.f;
+#pragma unroll
+                for (int l = 0; l < L; ++l) sv = fmaf(xr[u][l], tg[l], sv);
+                pj[h * RB + u] = sv;
+              }
+            }
+          };
+          if (xwide) {
+            if constexpr (L % 4 == 0)
+              stream([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xg + (size_t)j * T, t0, T, xr); });
+          } else {
+            stream([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); });
+          }
         }
         prof.tick(16);
         // 16 wave sums as ONE reduce-scatter: lane l ends up with the total of feature l & 15
@@ -2139,14 +2172,40 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     if constexpr (PM == 1) {
       float wv[16];
       lds_row_load<16>(wls, wv);           // the weights vector is padded to 16 floats
+      if (a.x_in_lds) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int jj = j < P ? j : P - 1;
-        const float wj = j < P ? wv[j] : 0.f;
-        float xr[L];
-        lds_row_load<L>(Xs + jj * TPAD + t0, xr);
+        for (int j = 0; j < 16; ++j) {
+          const int jj = j < P ? j : P - 1;
+          const float wj = j < P ? wv[j] : 0.f;
+          float xr[L];
+          lds_row_load<L>(Xs + jj * TPAD + t0, xr);
 #pragma unroll
-        for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
+          for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
+        }
+      } else {
+        // the streamed design (see the X~'targets loop)
+        constexpr int RB = L >= 16 ? 2 : (L >= 8 ? 4 : 8);
+        auto stream = [&](auto load_row) {
+#pragma unroll
+          for (int h = 0; h < 16 / RB; ++h) {
+            if (h * RB >= P) continue;
+            float xr[RB][L];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) load_row(h * RB + u < P ? h * RB + u : P - 1, xr[u]);
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+              const float wj = h * RB + u < P ? wv[h * RB + u] : 0.f;
+#pragma unroll
+              for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[u][l], wj, xw[l]);
+            }
+          }
+        };
+        if (xwide) {
+          if constexpr (L % 4 == 0)
+            stream([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xg + (size_t)j * T, t0, T, xr); });
+        } else {
+          stream([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); });
+        }
       }
     } else if constexpr (PM == 2) {
       // 8 features per round (independent row loads, see the X~'targets loop)

@@ -152,9 +152,10 @@ int ci_fit_gibbs(const ci_problem* problem, const float* y, const uint8_t* mask,
 /* The same fit computed in FLOAT64 throughout (DataOptions.dtype = float64: the reference runs its
  * sampler in the requested dtype, causalimpact_lib.py:159; its numeric pin covers float32 and
  * float64, causalimpact_lib_test.py:655-662).  y, X and every result array are float64; any model
- * the float32 entry point takes (seasonal blocks, P up to 512, any T).  Runs on the sequential
- * one-wavefront kernel (csrc/ci_gibbs64.h): the precision option, not the fast one.  Same random
- * stream as ci_fit_gibbs: the two agree draw for draw to float32 round-off. */
+ * the float32 entry point takes (seasonal blocks, P up to 512, any T).  One wavefront per chain
+ * (csrc/ci_gibbs64.h): trend models time-parallel over its 64 lanes, models with seasonal blocks
+ * sequential in time -- the precision option, not the fast one.  Same random stream as
+ * ci_fit_gibbs: the two agree draw for draw to float32 round-off. */
 typedef struct ci_outputs_f64 {
   double* observation_noise_scale;  /* [B,C,S]   */
   double* level_scale;              /* [B,C,S]   */
@@ -248,9 +249,11 @@ typedef struct ci_ll_session ci_ll_session;
 int ci_ll_session_create(const ci_problem* problem, const ci_series_params* params, const float* y,
                          const uint8_t* mask, const float* X, int32_t max_evals,
                          ci_ll_session** session);
-/* The same for ANY model and length: seasonal blocks (season_change [K,T] as in ci_fit_gibbs) and
- * T > 4096 run on the sequential one-wavefront route (csrc/ci_score_seq.h).  theta / grad rows
- * are then [3 + K + P]: (sigma_obs, sigma_level, sigma_slope, sigma_drift[K], weights[P]). */
+/* The same for ANY model and length (season_change [K,T] as in ci_fit_gibbs): trend + one block
+ * of 2-7 seasons and trend-only series of more than 4096 steps are time-parallel
+ * (csrc/ci_wide_score.h), other block lists -- or CI_FLAG_SEQUENTIAL_SEASONAL -- take the
+ * sequential one-wavefront route (csrc/ci_score_seq.h).  theta / grad rows are then
+ * [3 + K + P]: (sigma_obs, sigma_level, sigma_slope, sigma_drift[K], weights[P]). */
 int ci_ll_session_create2(const ci_problem* problem, const ci_series_params* params, const float* y,
                           const uint8_t* mask, const float* X, const uint8_t* season_change,
                           int32_t max_evals, ci_ll_session** session);

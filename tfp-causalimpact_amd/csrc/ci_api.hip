@@ -633,7 +633,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     s->lds_bytes = ci::make_layout(P, D, ci::NT * s->L, s->x_in_lds).total;
     // P <= 16: the register-resident regression block, with the design in LDS or -- long series --
     // streamed from L2; beyond 16 columns the LDS block drawn by the whole workgroup
-    const int pm = (P == 0) ? 0 : (P <= 16 ? 1 : 2);
+    const int pm = (P == 0) ? 0 : (P <= 16 ? (s->x_in_lds ? 1 : 3) : 2);
     s->fn = pick_kernel(D, s->L, pm);
     s->fn_prof = pick_kernel(D, s->L, pm + 8);       // instrumented variant (ci_session_profile)
     if (!s->fn || !s->fn_prof) return fail("no kernel for L=%d", s->L);

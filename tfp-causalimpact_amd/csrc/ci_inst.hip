@@ -27,7 +27,14 @@ void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(int pm) {
   if (pm == 2) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 2, false>);
   if (pm == 8) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 0, true>);
   if (pm == 9) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 1, true>);
-  return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 2, true>);
+  if (pm == 10) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 2, true>);
+#if CI_L >= 8
+  // pm = 3: register-resident regression block, design streamed from L2 -- only series long enough
+  // that <= 16 columns of T floats overflow LDS reach it (L >= 8 steps per thread)
+  if (pm == 3) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 3, false>);
+  if (pm == 11) return (void*)(&ci::gibbs_kernel<CI_D, CI_L, 3, true>);
+#endif
+  return nullptr;
 }
 
 // The five-wavefront latency build of the PM = 1 kernel (ci_kernels5.h).

@@ -1787,12 +1787,17 @@ template <int D, int L, int PM, bool PROF = false>
 #define CI_MIN_WAVES 2
 #endif
 __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
+  // PM = 3: the register-resident regression block (PM = 1) with the design STREAMED from L2 --
+  // its own instantiation, so that the loops of the LDS-resident build stay what they were (one
+  // function holding both cost the 512-series batch 7 %)
+  constexpr int RPM = (PM == 3) ? 1 : PM;
+  constexpr bool STREAM = PM == 3;
   using PF = typename std::conditional<PROF, Prof, NoProf>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int series = blockIdx.x / a.C, chain = blockIdx.x % a.C;
-  const int T = a.T, P = (PM == 0) ? 0 : a.P;
+  const int T = a.T, P = (RPM == 0) ? 0 : a.P;
   constexpr int TPAD = NT * L;
   const LdsLayout lay = make_layout(P, D, TPAD, a.x_in_lds);
   SerialCtx* cx = (SerialCtx*)(smem + lay.off_ctx);
@@ -1881,8 +1886,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   __syncthreads();
   double* gam = (double*)(smem + lay.off_gam);
   float* nz0 = (float*)(smem + lay.off_nz0);
-  if (wave == 1) serial_gammas<PM>(cx, 0, lane, gam);     // (no draw is active at it = 0 but P > 0's)
-  if constexpr (PM == 1) {
+  if (wave == 1) serial_gammas<RPM>(cx, 0, lane, gam);     // (no draw is active at it = 0 but P > 0's)
+  if constexpr (RPM == 1) {
     if (wave == 2) spike_slab_randoms(rng, 0u, P, lane, gam + 8);
   }
   const float init_loc = scal[8], init_var = scal[9], init_svar = scal[10];
@@ -1962,10 +1967,10 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         yty = fmaf(tg[l], tg[l], yty);
       }
       prof.tick(15);
-      if constexpr (PM == 1) {
+      if constexpr (RPM == 1) {
         // register-resident path: 16 independent accumulators, DPP reductions interleave
         float pj[16];
-        if (a.x_in_lds) {
+        if constexpr (!STREAM) {
           // branch-free: rows >= P re-read row P-1 and are masked out, so all 16 wide LDS loads
           // are in flight before the first FMA (per-feature branches exposed the LDS latency)
 #pragma unroll
@@ -2016,7 +2021,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         // stored by lanes 0..15 in a single instruction
         const float tot = wave_reduce_scatter16(pj, lane);
         if (lane < 16) red[wave * RS + lane] = tot;
-      } else if constexpr (PM == 2) {
+      } else if constexpr (RPM == 2) {
         // 16 features per round: their rows are independent loads (one L2 round trip per batch of
         // 8 when X streams from L2, instead of one per feature) and their wave sums ONE
         // reduce-scatter.  The row source is chosen outside the loop (see global_row_load_wide).
@@ -2095,15 +2100,15 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) zs[l] = 0.f;
     if (wave == 0) {
-      serial_section<PM, PF>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1),
+      serial_section<RPM, PF>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1),
                          gam + 72);
     } else {
-      if (wave == 1 && it < n_iter) serial_gammas<PM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));
-      if constexpr (PM == 1) {
+      if (wave == 1 && it < n_iter) serial_gammas<RPM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));
+      if constexpr (RPM == 1) {
         if (wave == 2 && it + 1 < n_iter)
           spike_slab_randoms(rng, (uint32_t)(it + 1), P, lane, gam + 8 + 32 * ((it + 1) & 1));
       }
-      if constexpr (PM != 0) {
+      if constexpr (RPM != 0) {
         if (it > a.W) {
           emit(so_prev, nullptr);
           if (wave == 3) {      // wave 0's predictive normals of iteration it-1
@@ -2131,7 +2136,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
       }
     }
     __syncthreads();
-    if constexpr (PM == 2) {
+    if constexpr (RPM == 2) {
       if (P > 16 && it < n_iter) {
         // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
         const double ns = spike_slab_draw_block(R, P, cx->sp, gam[72], gam[73], rng, (uint32_t)it, tid,
@@ -2146,7 +2151,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     prof.tick(1);
 
     if (it > a.W) {
-      if constexpr (PM == 0) emit(scal[SC_OBS_EMIT], nullptr);
+      if constexpr (RPM == 0) emit(scal[SC_OBS_EMIT], nullptr);
       else if (wave == 0) emit(so_prev, nz0 + 3 * L * 64);   // waves 1-3 emitted during the serial section
     }
     prof.tick(2);
@@ -2169,10 +2174,10 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     float resid[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) xw[l] = 0.f;
-    if constexpr (PM == 1) {
+    if constexpr (RPM == 1) {
       float wv[16];
       lds_row_load<16>(wls, wv);           // the weights vector is padded to 16 floats
-      if (a.x_in_lds) {
+      if constexpr (!STREAM) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int jj = j < P ? j : P - 1;
@@ -2207,7 +2212,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
           stream([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); });
         }
       }
-    } else if constexpr (PM == 2) {
+    } else if constexpr (RPM == 2) {
       // 8 features per round (independent row loads, see the X~'targets loop)
       auto xw_rounds = [&](auto load_row) {
         for (int j0 = 0; j0 < P; j0 += 8) {

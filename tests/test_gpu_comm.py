@@ -170,3 +170,22 @@ def test_bench_single_rank_through_the_rccl_path_matches_plain_bench():
   assert forced["split_rhat"] == plain["split_rhat"] and forced["ess"] == plain["ess"]
   # same work per step either way; a loose band: 8 steps of 9 ms on a box that is not ours alone
   assert abs(forced["value"] / plain["value"] - 1.0) < 0.3
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_reports_the_whole_job():
+  """`python bench.py --gpus 2` with no launcher around it (the form the driver uses): bench.py
+  spawns its two ranks, they meet through the C-ABI communicator, rank 0 prints one JSON line for
+  the whole job.  On this one-GPU box both ranks share GPU 0 over the host transport
+  (CI_COMM_TRANSPORT / CI_COMM_DEVICES); on a node with 2+ GPUs the same command uses RCCL."""
+  env = dict(os.environ, CI_COMM_TRANSPORT="host", CI_COMM_DEVICES="0,0")
+  env.pop("WORLD_SIZE", None)
+  env.pop("RANK", None)
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+  out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, check=True).stdout
+  line = json.loads(out.strip().splitlines()[-1])
+  assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+  assert line["config"]["chains_total"] == 2 * line["config"]["chains_per_gpu"]
+  assert "ranks_seen=2" in line["config"]["collectives"]
+  assert "spawned its own ranks" in line["config"]["launcher"]
+  assert line["value"] > 0 and set(line["split_rhat"]) == {"observation_noise_scale", "level_scale"}
+  assert "cpu_baseline" not in line or line.get("cpu_baseline") is None or line["n_gpus"] == 2

@@ -213,5 +213,12 @@ def self_launch(world: int) -> Optional[int]:
   (WORLD_SIZE already set) or when world == 1, i.e. when the caller should just carry on."""
   if world <= 1 or "WORLD_SIZE" in os.environ:
     return None
-  codes = spawn_ranks(world, [sys.executable] + sys.argv)
+  # CI_COMM_TRANSPORT / CI_COMM_DEVICES (e.g. "host" and "0,0": two ranks sharing GPU 0) let a
+  # one-GPU box run the N-rank path; the defaults are RCCL and rank r on device r
+  transport = os.environ.get("CI_COMM_TRANSPORT", "rccl")
+  devices = os.environ.get("CI_COMM_DEVICES")
+  devs = [int(d) for d in devices.split(",")] if devices else None
+  if devs is not None and len(devs) != world:
+    raise ValueError(f"CI_COMM_DEVICES names {len(devs)} devices for {world} ranks")
+  codes = spawn_ranks(world, [sys.executable] + sys.argv, transport=transport, devices=devs)
   return max((abs(c) for c in codes), default=0)

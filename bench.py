@@ -70,15 +70,44 @@ def _cpu_worker(sampler, y, mask, X, spec, S, W, first_chain, go, seconds, done)
 def _cpu_baseline(sampler, y, mask, X, min_seconds=10.0):
   """Times the float64 CPU restatement (oracle/, kind="port") on the host's cores.
 
-  1 core: whole chains of the bench workload, repeated until >= min_seconds of CPU work.
-  All cores: one process per core (os.cpu_count() of them), each running whole chains until the
-  same deadline (bounded: ~min_seconds plus one chain).  The oracle is the checker here, never
-  the product path."""
+  Gibbs (the headline): the build BASELINE.md section 2 names -- `-O3 -march=native`, one thread
+  per chain, OpenMP across chains -- compiled on THIS host (oracle/Makefile `native`; the flags
+  are echoed in `sample`).  1 core: whole chains of the bench workload until >= min_seconds of CPU
+  work; all cores: rounds of os.cpu_count() chains (one per core) until the same budget.
+  HMC (--sampler hmc): the checker build, one process per core.
+  The oracle is the checker here, never the product path."""
   import multiprocessing as mp  # pylint: disable=import-outside-toplevel
   from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
   spec = orc.default_spec(y, mask, X, has_slope=bool(CFG["has_slope"]))
   S = CFG["num_results"]
   W = CFG["hmc_warmup"] if sampler == "hmc" else CFG["num_warmup"]
+  ncpu = os.cpu_count() or 1
+  if sampler == "gibbs":
+    _, flags = orc.native_lib()
+    kw = dict(num_results=S, num_warmup=W, seed=CFG["seed"])
+    orc.fit_gibbs_chains_native(y, mask, X, spec, first_chain=0, n_chains=1, threads=1, **kw)  # warm
+    t0 = time.perf_counter()
+    chains = 0
+    while time.perf_counter() - t0 < min_seconds:
+      orc.fit_gibbs_chains_native(y, mask, X, spec, first_chain=chains, n_chains=1, threads=1, **kw)
+      chains += 1
+    dt1 = time.perf_counter() - t0
+    what = f"({W}+{S}) Gibbs iterations"
+    res = {"value": chains * S / dt1, "unit": "posterior samples/sec", "cores": 1, "kind": "port",
+           "sample": f"{chains} chains x {what} of the bench series, float64 C restatement "
+                     f"(oracle/ci_oracle.c built on this host with `{flags}`), {dt1:.1f} s"}
+    if ncpu > 1:
+      t0 = time.perf_counter()
+      n_tot, used = 0, ncpu
+      while time.perf_counter() - t0 < min_seconds:
+        used = orc.fit_gibbs_chains_native(y, mask, X, spec, first_chain=1000 + n_tot,
+                                           n_chains=ncpu, threads=ncpu, **kw)
+        n_tot += ncpu
+      dtn = time.perf_counter() - t0
+      res["all_cores"] = {"value": n_tot * S / dtn, "cores": used,
+                          "sample": f"{n_tot} chains, OpenMP over chains on {used} threads "
+                                    f"(one chain per thread), same build, {dtn:.1f} s"}
+    return res
   orc.lib()
   t0 = time.perf_counter()
   chains = 0
@@ -87,12 +116,10 @@ def _cpu_baseline(sampler, y, mask, X, min_seconds=10.0):
     chains += 1
   dt1 = time.perf_counter() - t0
   one = chains * S / dt1
-  what = (f"({W}+{S}) x {CFG['hmc_leapfrog']}-leapfrog HMC iterations + latent draws"
-          if sampler == "hmc" else f"({W}+{S}) Gibbs iterations")
+  what = f"({W}+{S}) x {CFG['hmc_leapfrog']}-leapfrog HMC iterations + latent draws"
   res = {"value": one, "unit": "posterior samples/sec", "cores": 1, "kind": "port",
          "sample": f"{chains} chains x {what} of the bench series, float64 C restatement "
-                   f"(oracle/ci_oracle.c), {dt1:.1f} s"}
-  ncpu = os.cpu_count() or 1
+                   f"(oracle/ci_oracle.c, checker build -O2 -fno-fast-math), {dt1:.1f} s"}
   if ncpu > 1:
     ctx = mp.get_context("fork")
     go, done = ctx.Event(), ctx.Queue()
@@ -295,9 +322,14 @@ def main():
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
   # RCCL through the C-ABI (ci_comm_*): no PyTorch in this process.  CI_BENCH_FORCE_DIST=1
   # exercises the same path with a single rank (1-GPU box).
+  # connect(): the host transport comes up first, RCCL is joined under a deadline and proven with
+  # one all-reduce; if any rank cannot join, ALL ranks carry on over the host transport and the
+  # reason lands in config.collectives -- an N-GPU run cannot hang or fail silently in set-up.
   comm = None
   if world > 1 or os.environ.get("CI_BENCH_FORCE_DIST") == "1":
-    comm = _comm.Comm.from_env()
+    comm = _comm.connect(rank, world, local_rank)
+    if comm.ranks_seen != world:
+      raise SystemExit(f"rank {rank}: communicator sees {comm.ranks_seen} of {world} ranks")
 
   C = args.chains_per_gpu
   y, mask, X, _ = syn.make_sampler_inputs(CFG["T"], CFG["covariates"], CFG["data_seed"])
@@ -386,7 +418,8 @@ def main():
                               ("external (RANK/WORLD_SIZE in the environment)" if launched else
                                "single process")),
                  "collectives": (f"{comm.transport} via ci_comm_* (C-ABI), ranks_seen="
-                                 f"{comm.ranks_seen}" if comm is not None else "none")},
+                                 f"{comm.ranks_seen}" if comm is not None else "none"),
+                 "ranks_seen": comm.ranks_seen if comm is not None else 1},
       "roofline": roof,
       "kernel_only_value": C * CFG["num_results"] / dt_kernel,
       "split_rhat": rhat, "ess": ess,
@@ -395,8 +428,13 @@ def main():
     out["cpu_baseline"] = _cpu_baseline(args.sampler, y, mask, X)
   elif rank == 0:
     out["cpu_baseline"] = None
+    out["config"]["n_gt_1_note"] = ("cpu_baseline is timed at N=1 only; roofline.traffic on this "
+                                    "line is the committed single-GPU counter figure (per GPU), not "
+                                    "measured in this run")
+  hard_exit = False
   if comm is not None:
     comm.barrier()
+    hard_exit = comm.hard_exit
   fit.sess.close()
   if comm is not None:
     comm.close()
@@ -406,6 +444,12 @@ def main():
   ctypes.CDLL(None).fflush(None)
   if rank == 0:
     print(json.dumps(out), flush=True)
+  if hard_exit:
+    # an abandoned RCCL attempt may still be blocked inside librccl on a helper thread: do not let
+    # interpreter shutdown wait for it
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -1089,3 +1089,54 @@ int ci_oracle_hmc_latents(const ci_oracle_hmc_problem* pb, const double* draws, 
   free(resid); free(xw); free(lat);
   return 0;
 }
+
+
+/* ---- cpu_baseline: whole chains, OpenMP over chains ---- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int ci_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+void ci_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+int ci_oracle_fit_gibbs_chains(const ci_oracle_problem* pb, int first_chain, int n_chains) {
+  int failed = 0;
+  const size_t T = (size_t)pb->T, S = (size_t)pb->num_results;
+  const size_t P = (size_t)(pb->P > 0 ? pb->P : 1), K = (size_t)(pb->num_blocks > 0 ? pb->num_blocks : 1);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : failed)
+#endif
+  for (int c = 0; c < n_chains; ++c) {
+    ci_oracle_problem q = *pb;
+    q.chain = first_chain + c;
+    ci_oracle_outputs o;
+    memset(&o, 0, sizeof(o));
+    o.obs_scale = (double*)malloc(sizeof(double) * S);
+    o.level_scale = (double*)malloc(sizeof(double) * S);
+    o.slope_scale = (double*)malloc(sizeof(double) * S);
+    o.drift_scales = (double*)malloc(sizeof(double) * S * K);
+    o.weights = (double*)malloc(sizeof(double) * S * P);
+    o.level = (double*)malloc(sizeof(double) * S * T);
+    o.slope = (double*)malloc(sizeof(double) * S * T);
+    o.seasonal = pb->num_blocks > 0 ? (double*)malloc(sizeof(double) * S * T * K) : NULL;
+    o.pred_mean = (double*)malloc(sizeof(double) * T);
+    o.trajectories = (double*)malloc(sizeof(double) * S * T);
+    if (ci_oracle_fit_gibbs(&q, &o) != 0) failed += 1;
+    free(o.obs_scale); free(o.level_scale); free(o.slope_scale); free(o.drift_scales);
+    free(o.weights); free(o.level); free(o.slope); free(o.seasonal); free(o.pred_mean);
+    free(o.trajectories);
+  }
+  return failed;
+}

@@ -133,6 +133,15 @@ typedef struct {
 /* Full Gibbs fit for one chain.  Returns 0 on success. */
 int ci_oracle_fit_gibbs(const ci_oracle_problem* pb, ci_oracle_outputs* out);
 
+/* cpu_baseline leg of bench.py only: n_chains whole fits (chain ids first_chain ...), each
+ * producing every output array of ci_oracle_outputs into buffers of its own, OpenMP-parallel over
+ * chains when built with -fopenmp (the `native` target: -O3 -march=native -fopenmp, BASELINE.md
+ * section 2), serial otherwise.  Returns the number of chains that failed. */
+int ci_oracle_fit_gibbs_chains(const ci_oracle_problem* pb, int first_chain, int n_chains);
+/* Threads the call above uses (1 without OpenMP) / sets them. */
+int ci_oracle_max_threads(void);
+void ci_oracle_set_threads(int n);
+
 /* ---- building blocks exposed for the unit tests ---- */
 void ci_oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double ci_oracle_uniform(const uint32_t seed[2], uint32_t chain, uint32_t iter,

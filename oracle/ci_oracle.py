@@ -200,6 +200,29 @@ def fit_gibbs(y, mask, X, spec, *, num_results, num_warmup, seed, chain=0,
   """Runs the float64 oracle for one chain; returns a dict of numpy arrays.  weights0 [P] /
   latents0 [T, d] start the chain somewhere else than the reference's zeros (tests only)."""
   L = lib()
+  pb, keep = _make_problem(y, mask, X, spec, num_results=num_results, num_warmup=num_warmup,
+                           seed=seed, chain=chain, weights0=weights0, latents0=latents0, flags=flags)
+  T, P, K = spec["T"], spec["P"], len(spec["num_seasons"])
+  S = int(num_results)
+  shapes = dict(obs_scale=(S,), level_scale=(S,), slope_scale=(S,), drift_scales=(S, K),
+                weights=(S, P), level=(S, T), slope=(S, T), seasonal=(S, T, K),
+                pred_mean=(T,), trajectories=(S, T), nonzeros=(S, P))
+  res, out = {}, _Outputs()
+  for name, shp in shapes.items():
+    if name in want:
+      arr = np.zeros(shp, dtype=np.int32 if name == "nonzeros" else np.float64)
+      res[name] = arr
+      setattr(out, name, arr.ctypes.data if arr.size else None)
+  rc = L.ci_oracle_fit_gibbs(C.byref(pb), C.byref(out))
+  del keep
+  if rc != 0:
+    raise RuntimeError(f"ci_oracle_fit_gibbs failed rc={rc}")
+  return res
+
+
+def _make_problem(y, mask, X, spec, *, num_results, num_warmup, seed, chain=0, weights0=None,
+                  latents0=None, flags=0):
+  """(_Problem, the arrays it points into)."""
   T, P = spec["T"], spec["P"]
   K = len(spec["num_seasons"])
   y64 = np.ascontiguousarray(np.where(np.asarray(mask, bool), 0.0, np.asarray(y, np.float64)))
@@ -231,20 +254,46 @@ def fit_gibbs(y, mask, X, spec, *, num_results, num_warmup, seed, chain=0,
             "init_seasonal_scale", "obs_scale0", "level_scale0", "slope_scale0"):
     setattr(pb, f, float(spec[f]))
   pb.weights_prior_scale = float(spec.get("weights_prior_scale", 1.0))
-  S = int(num_results)
-  shapes = dict(obs_scale=(S,), level_scale=(S,), slope_scale=(S,), drift_scales=(S, K),
-                weights=(S, P), level=(S, T), slope=(S, T), seasonal=(S, T, K),
-                pred_mean=(T,), trajectories=(S, T), nonzeros=(S, P))
-  res, out = {}, _Outputs()
-  for name, shp in shapes.items():
-    if name in want:
-      arr = np.zeros(shp, dtype=np.int32 if name == "nonzeros" else np.float64)
-      res[name] = arr
-      setattr(out, name, arr.ctypes.data if arr.size else None)
-  rc = L.ci_oracle_fit_gibbs(C.byref(pb), C.byref(out))
-  if rc != 0:
-    raise RuntimeError(f"ci_oracle_fit_gibbs failed rc={rc}")
-  return res
+  return pb, (y64, m8, X64, sc, w0, l0)
+
+
+# ----------------------------------------------------------------------------
+# cpu_baseline leg of bench.py: the build of BASELINE.md section 2 (-O3 -march=native, OpenMP over
+# chains), compiled on the host that times it
+# ----------------------------------------------------------------------------
+_native = None
+
+
+def native_lib():
+  """(CDLL, compiler + flags) of `make native`, built into a fresh temporary directory ON THIS
+  HOST (a -march=native binary must not travel between machines)."""
+  global _native
+  if _native is None:
+    import tempfile  # pylint: disable=import-outside-toplevel
+    out = tempfile.mkdtemp(prefix="ci_oracle_native_")
+    subprocess.check_call(["make", "-s", "-C", _HERE, "native", f"OUT={out}"])
+    flags = subprocess.check_output(["make", "-s", "-C", _HERE, "print-native-flags"], text=True).strip()
+    L = C.CDLL(os.path.join(out, "libci_oracle_native.so"))
+    L.ci_oracle_fit_gibbs_chains.restype = C.c_int
+    L.ci_oracle_fit_gibbs_chains.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int]
+    L.ci_oracle_max_threads.restype = C.c_int
+    _native = (L, flags)
+  return _native
+
+
+def fit_gibbs_chains_native(y, mask, X, spec, *, num_results, num_warmup, seed, first_chain,
+                            n_chains, threads=None) -> int:
+  """n_chains whole Gibbs fits (every output array produced and dropped) on the native build,
+  OpenMP-parallel over chains on `threads` cores (default: all).  Returns the threads used."""
+  L, _ = native_lib()
+  if threads:
+    L.ci_oracle_set_threads(int(threads))
+  pb, keep = _make_problem(y, mask, X, spec, num_results=num_results, num_warmup=num_warmup, seed=seed)
+  failed = L.ci_oracle_fit_gibbs_chains(C.byref(pb), int(first_chain), int(n_chains))
+  del keep
+  if failed:
+    raise RuntimeError(f"{failed} oracle chains failed")
+  return int(L.ci_oracle_max_threads())
 
 
 def make_ssm(spec, mask, *, obs_scale, level_scale, slope_scale=0.0, drift_scale=()):

@@ -131,3 +131,48 @@ def test_create_rejects_bad_ranks_before_any_transport_work():
   assert b"rank" in L.ci_last_error()
   assert L.ci_comm_create(7, buf, 0, 1, 0, C.byref(h)) != 0
   assert b"transport" in L.ci_last_error()
+
+
+_CONNECT = r"""
+import os, sys
+sys.path[:0] = [%(root)r, %(pkg)r]
+import numpy as np
+from causalimpact import _comm
+c = _comm.connect()
+assert c.ranks_seen == c.world == 2
+s = c.all_reduce([1.0 + c.rank])
+g = c.all_gather(np.array([c.rank], np.float32))
+assert float(s[0]) == 3.0 and g.ravel().tolist() == [0.0, 1.0]
+with open(os.path.join(%(out)r, "rank%%d.txt" %% c.rank), "w") as f:
+  f.write(c.kind + "|" + c.transport)
+c.barrier()
+hard = c.hard_exit
+c.close()
+if hard:
+  os._exit(0)
+"""
+
+
+def test_connect_falls_back_to_host_when_rccl_cannot_start(tmp_path):
+  """No GPU here: librccl cannot even draw a unique id.  `_comm.connect` (bench.py's entry) must
+  neither raise nor hang: all ranks agree to carry on over the host transport and say why."""
+  sys.path[:0] = [PKG]
+  from causalimpact import _comm
+  script = tmp_path / "connect.py"
+  script.write_text(_CONNECT % dict(root=ROOT, pkg=PKG, out=str(tmp_path)))
+  env = dict(os.environ, CI_COMM_INIT_TIMEOUT_S="60")
+  codes = _comm.spawn_ranks(2, [sys.executable, str(script)], env=env, transport="rccl", timeout=300)
+  assert codes == [0, 0]
+  for r in range(2):
+    kind, transport = (tmp_path / f"rank{r}.txt").read_text().split("|", 1)
+    assert kind == "host" and transport.startswith("host (rccl failed:"), transport
+
+
+def test_second_communicator_of_a_process_uses_its_own_rendezvous_file(monkeypatch):
+  sys.path[:0] = [PKG]
+  from causalimpact import _comm
+  monkeypatch.setenv("CI_COMM_RDZV", "/tmp/ci_rdzv_x")
+  monkeypatch.setattr(_comm, "_SEQ", [0])
+  assert _comm.rendezvous_path() == "/tmp/ci_rdzv_x"
+  assert _comm.rendezvous_path() == "/tmp/ci_rdzv_x.1"
+  assert _comm.rendezvous_path() == "/tmp/ci_rdzv_x.2"

@@ -7,7 +7,10 @@ detected"), so:
   * two ranks SHARING GPU 0 run real fits of their chain blocks and pool them over the host
     transport (same entry points, staged through shared memory): bit-equal to ONE launch of all
     chains; they are started by `_comm.spawn_ranks`, the launcher behind `bench.py --gpus N`;
-  * asking RCCL for two ranks on one device must fail with a clean error, not hang.
+  * asking RCCL for two ranks on one device must fail with a clean error, not hang -- and through
+    `_comm.connect` (what bench.py uses) it must FALL BACK to the host transport, labelled;
+  * on a box with >= 2 GPUs (the driver's round-end box may be one) two tests run REAL RCCL with
+    two ranks: pooled results bit-equal to one launch, and `bench.py --gpus 2` end to end.
 """
 import json
 import os
@@ -27,7 +30,7 @@ sys.path[:0] = [%(root)r, %(pkg)r]
 import numpy as np
 from causalimpact import _comm, _distributed as d, _model, _native
 from causalimpact import _synthetic as syn
-comm = _comm.Comm.from_env()
+comm = _comm.connect()          # host control plane first, RCCL under a deadline, agreed fallback
 num_chains = %(num_chains)d
 y, mask, X, _ = syn.make_sampler_inputs(300, 3, 5)
 spec = _model.series_params(y, mask, X, has_slope=True)
@@ -48,10 +51,15 @@ def resident(key):
 res = d.fit_sharded(local_fit, num_chains, comm=comm, resident=resident if %(even)d else None)
 np.savez(os.path.join(%(out)r, "rank%%d.npz" %% comm.rank), traj=res["posterior_trajectories"],
          means=res["posterior_means"], rhat=res["split_rhat"]["level_scale"],
-         ess=res["ess_bulk"]["observation_noise_scale"], seen=comm.ranks_seen)
+         ess=res["ess_bulk"]["observation_noise_scale"], seen=comm.ranks_seen,
+         transport=comm.transport, kind=comm.kind)
 comm.barrier()
+hard = comm.hard_exit
 comm.close()
 assert "torch" not in sys.modules
+if hard:
+  sys.stdout.flush()
+  os._exit(0)
 """
 
 
@@ -80,13 +88,80 @@ def test_two_ranks_sharing_gpu0_equal_one_launch(tmp_path, num_chains):
   codes = _comm.spawn_ranks(2, [sys.executable, str(script)], transport="host", devices=[0, 0],
                             timeout=300)
   assert codes == [0, 0]
-  for r in range(2):
+  for transport, kind in _check_ranks(tmp_path, one, single):
+    assert transport == "host" and kind == "host"
+
+
+def _check_ranks(tmp_path, one, single, world=2):
+  out = []
+  for r in range(world):
     got = np.load(tmp_path / f"rank{r}.npz")
-    assert int(got["seen"]) == 2
+    assert int(got["seen"]) == world
     np.testing.assert_array_equal(got["traj"], one["posterior_trajectories"])
     np.testing.assert_array_equal(got["means"], one["posterior_means"])
     np.testing.assert_allclose(got["rhat"], single["split_rhat"]["level_scale"], rtol=1e-9)
     np.testing.assert_allclose(got["ess"], single["ess_bulk"]["observation_noise_scale"], rtol=1e-9)
+    out.append((str(got["transport"]), str(got["kind"])))
+  return out
+
+
+def _device_count():
+  sys.path[:0] = [PKG]
+  from causalimpact import _native
+  return _native.device_count()
+
+
+@pytest.mark.parametrize("num_chains", [4, 5])
+def test_rccl_with_real_ranks_on_two_gpus_equals_one_launch(tmp_path, num_chains):
+  """Armed for any box with >= 2 GPUs (skips on one): two ranks, one per GPU, over REAL RCCL --
+  even blocks gathered straight from HBM with ncclAllGather, uneven ones padded -- bit-equal to ONE
+  launch of all chains on GPU 0, and the transport must really be RCCL (no silent fallback)."""
+  if _device_count() < 2:
+    pytest.skip("needs two GPUs")
+  from causalimpact import _comm
+  one, single = _one_launch(num_chains)
+  script = tmp_path / "rank.py"
+  script.write_text(_RANK % dict(root=ROOT, pkg=PKG, num_chains=num_chains, out=str(tmp_path),
+                                 even=int(num_chains % 2 == 0)))
+  codes = _comm.spawn_ranks(2, [sys.executable, str(script)], transport="rccl", devices=[0, 1],
+                            timeout=600)
+  assert codes == [0, 0]
+  for transport, kind in _check_ranks(tmp_path, one, single):
+    assert transport == "rccl" and kind == "rccl", transport
+
+
+def test_bench_gpus_2_over_rccl_on_two_gpus():
+  """`python bench.py --gpus 2` as the driver runs it, on a box that has the GPUs: RCCL must carry
+  the collectives, both ranks must be seen, the whole-job value must be about twice one GPU's."""
+  if _device_count() < 2:
+    pytest.skip("needs two GPUs")
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK",
+                                                          "CI_COMM_TRANSPORT", "CI_COMM_DEVICES")}
+  base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2",
+          "--no-cpu-baseline", "--no-pmc"]
+  two = json.loads(subprocess.run(base + ["--gpus", "2"], env=env, capture_output=True, text=True,
+                                  timeout=900, check=True).stdout.strip().splitlines()[-1])
+  one = json.loads(subprocess.run(base, env=env, capture_output=True, text=True, timeout=900,
+                                  check=True).stdout.strip().splitlines()[-1])
+  assert two["n_gpus"] == 2 and two["config"]["ranks_seen"] == 2
+  assert two["config"]["collectives"].startswith("rccl"), two["config"]["collectives"]
+  assert 1.5 < two["value"] / one["value"] < 2.3
+
+
+def test_connect_falls_back_to_the_host_transport_when_rccl_refuses(tmp_path):
+  """Two ranks asked to use RCCL on ONE device: RCCL refuses ("Duplicate GPU detected").  `connect`
+  must not hang and must not fail: every rank drops the attempt, the collectives run over the
+  host transport, the reason is in `transport`, and the pooled result still equals one launch."""
+  from causalimpact import _comm
+  one, single = _one_launch(4)
+  script = tmp_path / "rank.py"
+  script.write_text(_RANK % dict(root=ROOT, pkg=PKG, num_chains=4, out=str(tmp_path), even=1))
+  env = dict(os.environ, CI_COMM_INIT_TIMEOUT_S="60")
+  codes = _comm.spawn_ranks(2, [sys.executable, str(script)], env=env, transport="rccl",
+                            devices=[0, 0], timeout=600)
+  assert codes == [0, 0]
+  for transport, kind in _check_ranks(tmp_path, one, single):
+    assert kind == "host" and transport.startswith("host (rccl failed:"), transport
 
 
 _RCCL1 = r"""
@@ -164,7 +239,8 @@ def test_bench_single_rank_through_the_rccl_path_matches_plain_bench():
                                      check=True).stdout.strip().splitlines()[-1])
   plain = json.loads(subprocess.run(cmd, capture_output=True, text=True, timeout=600,
                                     check=True).stdout.strip().splitlines()[-1])
-  assert "ranks_seen=1" in forced["config"]["collectives"] and "rccl" in forced["config"]["collectives"]
+  assert "ranks_seen=1" in forced["config"]["collectives"]
+  assert forced["config"]["collectives"].startswith("rccl"), forced["config"]["collectives"]
   assert plain["config"]["collectives"] == "none"
   assert forced["n_gpus"] == plain["n_gpus"] == 1
   assert forced["split_rhat"] == plain["split_rhat"] and forced["ess"] == plain["ess"]

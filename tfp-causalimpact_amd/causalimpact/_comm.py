@@ -12,7 +12,15 @@ in HBM and one small all-reduce of the diagnostics' partial sums (SURVEY.md sect
 Rendezvous: rank 0 asks the library for the 128-byte unique id and publishes it in a file (atomic
 rename); the other ranks poll for it.  The path is `$CI_COMM_RDZV` (set by `spawn_ranks`) or is
 derived from MASTER_PORT and the launcher's pid, so ranks started by `torch.distributed.run` (which
-this module does not import) find each other too.
+this module does not import) find each other too; the n-th communicator a process builds uses
+`<path>.<n>`, rank 0 clears a leftover before publishing and readers ignore files older than an
+hour, so neither a second communicator nor a crashed earlier run can hand out a stale id.
+
+`connect()` is what multi-GPU callers (bench.py) use: it ALWAYS builds the host transport first
+(the control plane), then tries RCCL under a deadline, lets the ranks agree on the outcome and --
+if any rank could not join the RCCL communicator -- carries on over the host transport with the
+reason in `Comm.transport` ("host (rccl failed: ...)").  An N-GPU run can therefore not fail
+silently or hang in communicator set-up.
 """
 from __future__ import annotations
 
@@ -21,6 +29,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 from typing import Dict, List, Optional, Sequence
 
@@ -52,14 +61,25 @@ def _bind(L):
   return L
 
 
+_SEQ = [0]                                # communicators this process has built from the default path
+STALE_SECONDS = 3600.0                    # a rendezvous file older than this belongs to an earlier run
+
+
 def rendezvous_path() -> str:
-  """Where rank 0 publishes the unique id."""
+  """Where rank 0 publishes the unique id of the NEXT communicator this process builds.  Every rank
+  builds its communicators in the same order, so the running number keeps a second communicator
+  off the first one's file (rank 0 unlinks a file only after a barrier; a faster rank could
+  otherwise read the previous id)."""
   p = os.environ.get("CI_COMM_RDZV")
-  if p:
-    return p
-  port = os.environ.get("MASTER_PORT", "0")
-  run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-  return os.path.join(tempfile.gettempdir(), f"ci_comm_{os.getuid()}_{port}_{run}_{os.getppid()}")
+  if not p:
+    port = os.environ.get("MASTER_PORT", "0")
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    p = os.path.join(tempfile.gettempdir(),
+                     f"ci_comm_{os.getuid()}_{port}_{run}_{restart}_{os.getppid()}")
+  seq = _SEQ[0]
+  _SEQ[0] += 1
+  return p if seq == 0 else f"{p}.{seq}"
 
 
 def _exchange_id(rank: int, transport: int, path: str, timeout: float = 300.0) -> bytes:
@@ -70,14 +90,15 @@ def _exchange_id(rank: int, transport: int, path: str, timeout: float = 300.0) -
     tmp = f"{path}.tmp{os.getpid()}"
     with open(tmp, "wb") as f:
       f.write(bytes(buf))
-    os.replace(tmp, path)
+    os.replace(tmp, path)                 # atomically replaces a leftover of a crashed run, too
     return bytes(buf)
   t0 = time.monotonic()
   while True:
     try:
       with open(path, "rb") as f:
         b = f.read()
-      if len(b) == ID_BYTES:
+        fresh = time.time() - os.fstat(f.fileno()).st_mtime < STALE_SECONDS
+      if len(b) == ID_BYTES and fresh:
         return b
     except FileNotFoundError:
       pass
@@ -90,13 +111,18 @@ class Comm:
   """One rank of a communicator (`ci_comm`).  All methods are collective."""
 
   def __init__(self, rank: int, world: int, device: int = 0, transport: str = "rccl",
-               path: Optional[str] = None):
+               path: Optional[str] = None, uid: Optional[bytes] = None):
+    """`uid`: the 128-byte id when the caller has already distributed it (`connect` sends the
+    RCCL id over the host communicator); otherwise rank 0 publishes it in the file `path`."""
     if transport not in TRANSPORTS:
       raise ValueError(f"transport must be one of {sorted(TRANSPORTS)}, got {transport!r}")
     self._lib = _bind(_native.load())
     self.rank, self.world, self.device, self.transport = int(rank), int(world), int(device), transport
-    self._path = path or rendezvous_path()
-    uid = _exchange_id(self.rank, TRANSPORTS[transport], self._path)
+    self.kind = transport               # "rccl" | "host": what actually carries the collectives
+    self._path = None
+    if uid is None:
+      self._path = path or rendezvous_path()
+      uid = _exchange_id(self.rank, TRANSPORTS[transport], self._path)
     self._h = C.c_void_p()
     buf = (C.c_uint8 * ID_BYTES).from_buffer_copy(uid)
     _native._check(self._lib.ci_comm_create(TRANSPORTS[transport], buf, self.rank, self.world,
@@ -104,12 +130,16 @@ class Comm:
     seen = C.c_int32(0)
     _native._check(self._lib.ci_comm_info(self._h, None, None, C.byref(seen)))
     self.ranks_seen = int(seen.value)
-    self.barrier()                      # every rank has read the id: rank 0 may remove the file
-    if self.rank == 0:
-      try:
-        os.unlink(self._path)
-      except OSError:
-        pass
+    if self.ranks_seen != self.world:
+      raise _native.NativeError(f"rank {self.rank}: communicator sees {self.ranks_seen} ranks, "
+                                f"world size is {self.world}")
+    if self._path is not None:
+      self.barrier()                    # every rank has read the id: rank 0 may remove the file
+      if self.rank == 0:
+        try:
+          os.unlink(self._path)
+        except OSError:
+          pass
 
   @classmethod
   def from_env(cls, transport: Optional[str] = None) -> "Comm":
@@ -119,6 +149,12 @@ class Comm:
     device = int(os.environ.get("LOCAL_RANK", str(rank)))
     transport = transport or os.environ.get("CI_COMM_TRANSPORT", "rccl")
     return cls(rank, world, device, transport)
+
+  @property
+  def hard_exit(self) -> bool:
+    """True when an abandoned RCCL attempt may still be blocked inside the library on a helper
+    thread: the process should leave through os._exit after flushing its output."""
+    return getattr(self, "_hard_exit", False)
 
   def barrier(self):
     _native._check(self._lib.ci_comm_barrier(self._h))
@@ -152,7 +188,9 @@ class Comm:
                                 num_results=S, num_chains=Cn)
       shp = _native.output_shapes(hp)[field]
       fn = self._lib.ci_comm_ll_session_all_gather
-    out = np.empty((self.world,) + tuple(shp), np.float32)
+    # zeros: a field the model does not have (the slope of a local-level fit) has no device buffer
+    # and reads as zeros, as `Session.fetch` returns it
+    out = np.zeros((self.world,) + tuple(shp), np.float32)
     _native._check(fn(self._h, session._h, FIELDS[field], out.ctypes.data if out.size else None))
     return out
 
@@ -160,12 +198,108 @@ class Comm:
     if getattr(self, "_h", None):
       self._lib.ci_comm_destroy(self._h)
       self._h = C.c_void_p()
+    ctl = getattr(self, "ctl", None)      # the control plane `connect` built next to an RCCL comm
+    if ctl is not None:
+      self.ctl = None
+      ctl.close()
 
   def __del__(self):
     try:
       self.close()
     except Exception:  # pylint: disable=broad-except
       pass
+
+
+def _with_deadline(fn, seconds: float):
+  """Runs fn() on a helper thread (ctypes releases the GIL inside the library).  Returns
+  (result, error text or None, finished): a call still blocked after `seconds` is abandoned
+  (daemon thread) and reported as not finished."""
+  box = {}
+
+  def run():
+    try:
+      box["res"] = fn()
+    except BaseException as e:  # pylint: disable=broad-except
+      box["err"] = f"{type(e).__name__}: {e}"
+
+  t = threading.Thread(target=run, daemon=True)
+  t.start()
+  t.join(seconds)
+  if t.is_alive():
+    return None, f"no answer within {seconds:.0f} s", False
+  return box.get("res"), box.get("err"), True
+
+
+def connect(rank: Optional[int] = None, world: Optional[int] = None, device: Optional[int] = None,
+            transport: Optional[str] = None, path: Optional[str] = None,
+            init_timeout: Optional[float] = None) -> Comm:
+  """The communicator of a multi-GPU run, built so that set-up can neither hang nor fail silently.
+
+  1. the HOST transport (shared memory, always available on one node) comes up first;
+  2. for transport "rccl": rank 0 draws the RCCL id and sends it over (1); every rank joins the
+     RCCL communicator under a deadline ($CI_COMM_INIT_TIMEOUT_S, default 90 s) and proves it with
+     one all-reduce; the ranks agree on the outcome over (1);
+  3. everybody in -> the RCCL communicator is returned (`transport == "rccl"`); anybody out ->
+     every rank drops its RCCL attempt and the host communicator is returned with
+     `transport == "host (rccl failed: <first reason>)"`.
+  rank / world / device default to RANK / WORLD_SIZE / LOCAL_RANK."""
+  rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+  world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+  device = int(os.environ.get("LOCAL_RANK", str(rank))) if device is None else int(device)
+  transport = transport or os.environ.get("CI_COMM_TRANSPORT", "rccl")
+  if transport not in TRANSPORTS:
+    raise ValueError(f"transport must be one of {sorted(TRANSPORTS)}, got {transport!r}")
+  if init_timeout is None:
+    init_timeout = float(os.environ.get("CI_COMM_INIT_TIMEOUT_S", "90"))
+  ctl = Comm(rank, world, device, "host", path)
+  if transport == "host":
+    return ctl
+  L = _bind(_native.load())
+  # ---- the id, from rank 0 over the control plane
+  uid, why = bytes(ID_BYTES), ""
+  if rank == 0:
+    buf = (C.c_uint8 * ID_BYTES)()
+    # (_check on the helper thread: the library's error string is thread-local)
+    _, err, _ = _with_deadline(lambda: _native._check(L.ci_comm_unique_id(TRANSPORTS["rccl"], buf)),
+                               init_timeout)
+    if err is None:
+      uid = bytes(buf)
+    else:
+      why = err
+  msg = np.zeros(ID_BYTES + 1, np.uint8)
+  if rank == 0:
+    msg[:ID_BYTES] = np.frombuffer(uid, np.uint8)
+    msg[ID_BYTES] = 0 if why else 1
+  got = ctl.all_gather(msg)[0]
+  have_id = bool(got[ID_BYTES])
+  uid = got[:ID_BYTES].tobytes()
+  # ---- join + one proving all-reduce, under the deadline
+  data, finished = None, True
+  if have_id:
+    def join():
+      c = Comm(rank, world, device, "rccl", uid=uid)
+      s = c.all_reduce([1.0])
+      if int(round(float(s[0]))) != world:
+        raise _native.NativeError(f"proving all-reduce returned {float(s[0])}, expected {world}")
+      return c
+    data, err, finished = _with_deadline(join, init_timeout)
+    if err is not None:
+      why, data = err, None
+  # ---- agree: everybody in, or nobody
+  text = np.zeros(200, np.uint8)
+  b = (f"rank {rank}: {why}" if why else "").encode()[:200]
+  text[:len(b)] = np.frombuffer(b, np.uint8)
+  verdict = ctl.all_gather(np.concatenate([[np.uint8(0 if data is not None else 1)], text]))
+  if not verdict[:, 0].any():
+    data.ctl = ctl                      # keeps the control plane alive next to the data plane
+    return data
+  first = int(np.argmax(verdict[:, 0] != 0))
+  reason = bytes(verdict[first, 1:]).rstrip(b"\0").decode(errors="replace") or f"rank {first} could not join"
+  if data is not None:
+    data.close()
+  ctl.transport = f"host (rccl failed: {reason})"
+  ctl._hard_exit = not finished         # pylint: disable=protected-access
+  return ctl
 
 
 def spawn_ranks(world: int, argv: Sequence[str], env: Optional[Dict[str, str]] = None,

@@ -80,6 +80,35 @@ int rccl_load() {
     }                                                                                   \
   } while (0)
 
+// Every collective is bounded: a rank that died (or an RCCL ring that never forms) must surface as
+// an error on the survivors, never as a hang.  $CI_COMM_TIMEOUT_S (default 300 s) bounds one
+// collective on either transport.
+double comm_timeout_s() {
+  const char* e = getenv("CI_COMM_TIMEOUT_S");
+  const double v = e ? atof(e) : 0.0;
+  return v > 0.0 ? v : 300.0;
+}
+double mono_seconds() {
+  timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+// hipStreamSynchronize with a deadline (hipStreamQuery polling): an RCCL collective whose peers
+// never arrive leaves its kernel spinning on the stream for ever.
+int stream_wait(hipStream_t st, const char* what) {
+  const double t0 = mono_seconds(), limit = comm_timeout_s();
+  for (unsigned spin = 0;; ++spin) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return fail("%s: %s", what, hipGetErrorString(q));
+    if (spin < 2000) { sched_yield(); continue; }
+    if (mono_seconds() - t0 > limit)
+      return fail("ci_comm (rccl transport): %s did not complete within %.0f s (a rank died or the "
+                  "ring never formed)", what, limit);
+    usleep(100);
+  }
+}
+
 // ---- host transport: one shared-memory segment per communicator ------------------------------
 constexpr size_t HOST_SLOT_BYTES = (size_t)4 << 20;       // staging area per rank
 struct HostHeader {
@@ -149,8 +178,9 @@ int host_barrier(ci_comm* c) {
     if ((spin & 63) == 63) {
       timespec t1;
       clock_gettime(CLOCK_MONOTONIC, &t1);
-      if ((double)(t1.tv_sec - t0.tv_sec) > 600.0)
-        return fail("ci_comm (host transport): barrier timed out (a rank died?)");
+      if ((double)(t1.tv_sec - t0.tv_sec) > comm_timeout_s())
+        return fail("ci_comm (host transport): barrier timed out after %.0f s (a rank died?)",
+                    comm_timeout_s());
       usleep(50);
     } else {
       sched_yield();
@@ -257,7 +287,7 @@ int comm_scratch(ci_comm* c, size_t send_bytes, size_t recv_bytes) {
 // All-gather of a device-resident block of `count` floats from every rank into host `recv`
 // [world, count].
 int gather_device_floats(ci_comm* c, const float* dev, size_t count, float* recv, int device) {
-  if (count == 0) return 0;
+  if (count == 0) return 0;      // (the host side hands in a zero-initialised array)
   if (!dev || !recv) return fail("ci_comm: nothing resident to gather / recv is NULL");
   HIP_TRY(hipSetDevice(device));
   const size_t bytes = count * sizeof(float);
@@ -266,8 +296,7 @@ int gather_device_floats(ci_comm* c, const float* dev, size_t count, float* recv
     if (comm_scratch(c, 0, bytes * c->world)) return 1;
     RCCL_TRY(c->nc, g_rccl.AllGather(dev, c->recv.p, count, RCCL_FLOAT32, c->nc, c->stream));
     HIP_TRY(hipMemcpyAsync(recv, c->recv.p, bytes * c->world, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return stream_wait(c->stream, "ncclAllGather of a resident result array");
   }
   std::vector<unsigned char> mine(bytes);
   HIP_TRY(hipMemcpy(mine.data(), dev, bytes, hipMemcpyDeviceToHost));
@@ -357,8 +386,7 @@ int ci_comm_all_reduce(ci_comm* c, double* values, int64_t n, int32_t op) {
   RCCL_TRY(c->nc, g_rccl.AllReduce(c->send.p, c->recv.p, (size_t)n, RCCL_FLOAT64,
                                    op == CI_COMM_MAX ? RCCL_MAX : RCCL_SUM, c->nc, c->stream));
   HIP_TRY(hipMemcpyAsync(values, c->recv.p, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return 0;
+  return stream_wait(c->stream, "ncclAllReduce");
 }
 
 int ci_comm_barrier(ci_comm* c) {
@@ -379,8 +407,7 @@ int ci_comm_all_gather(ci_comm* c, const void* send, void* recv, int64_t bytes) 
   HIP_TRY(hipMemcpyAsync(c->send.p, send, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
   RCCL_TRY(c->nc, g_rccl.AllGather(c->send.p, c->recv.p, (size_t)bytes, RCCL_INT8, c->nc, c->stream));
   HIP_TRY(hipMemcpyAsync(recv, c->recv.p, (size_t)bytes * c->world, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return 0;
+  return stream_wait(c->stream, "ncclAllGather");
 }
 
 int ci_comm_session_all_gather(ci_comm* c, ci_session* s, int32_t field, float* recv) {
@@ -411,6 +438,8 @@ int ci_comm_ll_session_all_gather(ci_comm* c, ci_ll_session* s, int32_t field, f
     case CI_FIELD_OBSERVATION_NOISE_SCALE: b = &s->h_obs; break;
     case CI_FIELD_LEVEL_SCALE: b = &s->h_lscale; break;
     case CI_FIELD_SLOPE_SCALE: b = &s->h_sscale; break;
+    case CI_FIELD_SEASONAL_DRIFT_SCALES: b = &s->h_drift; break;
+    case CI_FIELD_SEASONAL_LEVELS: b = &s->h_seasonal; break;
     case CI_FIELD_WEIGHTS: b = &s->h_w; break;
     case CI_FIELD_LEVEL: b = &s->h_level; break;
     case CI_FIELD_SLOPE: b = &s->h_slope; break;

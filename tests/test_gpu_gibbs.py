@@ -290,14 +290,14 @@ def test_baseline_cfg5_full_size_batch_equals_single_series_runs_and_oracle():
                             want=("level", "weights", "observation_noise_scale"))
   assert np.isfinite(batch["level"]).all()
   for b in (0, 255, 511):
-    # the 512-workgroup launch runs the four-wavefront build, a single series the five-wavefront
+    # the 512-workgroup launch runs the four-wavefront build, a single series the eight-wavefront
     # latency build: the SAME bits (the library is compiled with -ffp-contract=on, so shared
     # source rounds identically in both kernels)
     pb1 = _native.make_problem(T=T, P=6, has_slope=0, num_warmup=W, num_results=S, seed=(5, 12),
                                series_offset=b)
     s1 = _native.Session(pb1, ys[b][None], masks[b][None], Xs[b][None], None,
                          _native.make_params([specs[b]]))
-    assert "gibbs_kernel5" in s1.kernel_name()
+    assert "gibbs_kernel8" in s1.kernel_name()
     s1.run()
     one = s1.fetch(want=("level", "weights", "observation_noise_scale"))
     s1.close()
@@ -374,10 +374,10 @@ def test_streamed_fetch_of_a_seasonal_model_equals_run_then_fetch():
 
 @pytest.mark.parametrize("T,p,has_slope,B,C", [(1000, 10, 1, 1, 3), (500, 5, 0, 4, 2), (100, 1, 0, 1, 2),
                                                (300, 15, 1, 1, 2)])
-def test_five_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, B, C):
-  """gibbs_kernel5 (a dedicated regression wavefront that sweeps the next iteration's matrix
+def test_eight_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, B, C):
+  """gibbs_kernel8 (a dedicated regression wavefront that sweeps the next iteration's matrix
   during the Durbin-Koopman draw and replays the recorded multipliers on the new right-hand
-  side, csrc/ci_kernels5.h) against gibbs_kernel<D, L, 1> (CI_FLAG_FOUR_WAVES).  Same operations in
+  side, csrc/ci_kernels8.h; three more wavefronts produce every random number one iteration ahead) against gibbs_kernel<D, L, 1> (CI_FLAG_FOUR_WAVES).  Same operations in
   the same order on the same random numbers, and -- the library being compiled with
   -ffp-contract=on, where fusion is a property of the source expression, not of the inlining
   context -- the same roundings: EVERY output of every draw is bit-identical.  Covers warm-up with
@@ -396,7 +396,7 @@ def test_five_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, B
                            _native.make_params(specs))
     out[flags] = (sess.kernel_name(), sess.run(), sess.fetch())
     sess.close()
-  assert "gibbs_kernel5" in out[0][0] and "gibbs_kernel<" in out[_native.FLAG_FOUR_WAVES][0]
+  assert "gibbs_kernel8" in out[0][0] and "gibbs_kernel<" in out[_native.FLAG_FOUR_WAVES][0]
   five, four = out[0][2], out[_native.FLAG_FOUR_WAVES][2]
   for k, v in four.items():
     np.testing.assert_array_equal(five[k], v, err_msg=k)
@@ -410,7 +410,7 @@ def test_five_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, B
 def test_a_batch_split_over_launches_of_any_size_gives_the_bits_of_one_launch():
   """identical outputs regardless of the number of GPUs.  512 series in ONE
   launch (more workgroups than CUs: the four-wavefront throughput build) against the same batch as
-  8 launches of 64 series (`series_offset`; every chain has a CU: the five-wavefront latency
+  8 launches of 64 series (`series_offset`; every chain has a CU: the eight-wavefront latency
   build) -- what 8 GPUs would run -- and against an uneven 300 + 212 split that straddles the
   CU count: all draws bit-equal."""
   T, p, B, W, S = 200, 5, 512, 4, 6
@@ -444,7 +444,7 @@ def test_a_batch_split_over_launches_of_any_size_gives_the_bits_of_one_launch():
       for k in want_keys:
         np.testing.assert_array_equal(part[k], whole[k][first:first + count],
                                       err_msg=f"{k} series {first}..{first + count}")
-  assert names == {"ci::gibbs_kernel5", "ci::gibbs_kernel"}       # both builds took part
+  assert names == {"ci::gibbs_kernel8", "ci::gibbs_kernel"}       # both builds took part
 
 
 REF_SEASONS = ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))

@@ -15,7 +15,7 @@
 
 #include "../../include/causalimpact_amd.h"
 #include "ci_kernels.h"
-#include "ci_kernels5.h"
+#include "ci_kernels8.h"
 #define CI_SEASONAL_DECL_ONLY
 #include "ci_seasonal.h"
 #include "ci_wide.h"
@@ -42,7 +42,7 @@ CI_WIDE_DECL(2) CI_WIDE_DECL(3) CI_WIDE_DECL(4) CI_WIDE_DECL(5) CI_WIDE_DECL(6) 
 // One object file per (D, L) instantiation (ci_inst.hip).
 #define CI_DECL(D, L)                                                                          \
   extern "C" void* ci_gibbs_fn_d##D##_l##L(int);                                              \
-  extern "C" void* ci_gibbs5_fn_d##D##_l##L(int);                                             \
+  extern "C" void* ci_gibbs8_fn_d##D##_l##L(int, size_t*);                                    \
   extern "C" void ci_launch_dk_d##D##_l##L(int, const float*, const uint8_t*, float, float,    \
                                            float, float, float, float, uint32_t, uint32_t,     \
                                            uint32_t, uint32_t, float*);                           \
@@ -155,8 +155,8 @@ static __global__ void hmc_unpack_kernel(int N, int P, const double* __restrict_
 
 namespace {
 using KernelFn = void (*)(ci::KArgs);
-KernelFn pick_kernel5(int D, int L, int profiled) {
-#define CI_CASE5(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs5_fn_d##DD##_l##LL(profiled);
+KernelFn pick_kernel8(int D, int L, int profiled, size_t* lds_base) {
+#define CI_CASE5(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs8_fn_d##DD##_l##LL(profiled, lds_base);
   CI_CASE5(1, 1) CI_CASE5(1, 2) CI_CASE5(1, 4) CI_CASE5(1, 8) CI_CASE5(1, 16)
   CI_CASE5(2, 1) CI_CASE5(2, 2) CI_CASE5(2, 4) CI_CASE5(2, 8) CI_CASE5(2, 16)
 #undef CI_CASE5
@@ -422,7 +422,7 @@ ci::DevSeriesParams dev_series_params(const ci_series_params& q, double n_obs) {
 struct ci_session {
   ci_problem pb;
   int L = 0, x_in_lds = 0;
-  bool five_waves = false;     // dispatching to gibbs_kernel5 (ci_kernels5.h)
+  bool five_waves = false;     // dispatching to the eight-wave latency kernel (ci_kernels8.h)
   size_t lds_bytes = 0;
   KernelFn fn = nullptr, fn_prof = nullptr, fn_prof5 = nullptr;
   hipStream_t stream = nullptr;
@@ -640,28 +640,30 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     char nm[96];
     snprintf(nm, sizeof(nm), "ci::gibbs_kernel<%d,%d,%d,false>", D, s->L, pm);
     s->kernel_name = nm;
-    // latency build: a fifth wavefront owns the regression section and sweeps the next
-    // iteration's matrix during the Durbin-Koopman draw.  Same draws, bit for bit (the library is
-    // built with -ffp-contract=on: shared source rounds the same in both kernels; tested across
-    // the CU-count boundary), so choosing by launch size never changes a result.
-    const size_t lds5 = ci::make_layout5(P, D, ci::NT * s->L).total;
-    // ... when every chain has a compute unit to itself: five 256-register wavefronts leave room
-    // for ONE workgroup per CU, the four-wave kernel for two, so launches with more workgroups
-    // than CUs (batches of series: throughput, not latency) keep the four-wave kernel
+    // latency build (ci_kernels8.h): eight wavefronts per chain -- four time waves, a regression
+    // wave that owns the serial section and sweeps the next iteration's matrix during the draw,
+    // three randomness waves.  Same draws, bit for bit (shared functions for everything that
+    // rounds, -ffp-contract=on; tested across the CU-count boundary), so choosing by launch size
+    // never changes a result.
+    // ... when every chain has a compute unit to itself: eight 256-register wavefronts fill a CU,
+    // the four-wave kernel leaves room for two workgroups, so launches with more workgroups than
+    // CUs (batches of series: throughput, not latency) keep the four-wave kernel
     int num_cus = 256;
     (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, pb->device);
     const bool latency_regime = (long long)B * C <= (long long)num_cus;
-    if (pm == 1 && latency_regime && !(pb->flags & CI_FLAG_FOUR_WAVES) && lds5 <= 150 * 1024) {
-      KernelFn f5 = pick_kernel5(D, s->L, 0);
-      if (f5) {
-        s->fn = f5;
-        s->fn_prof5 = pick_kernel5(D, s->L, 1);
+    if (pm == 1 && latency_regime && !(pb->flags & CI_FLAG_FOUR_WAVES)) {
+      size_t base8 = 0;
+      KernelFn f8 = pick_kernel8(D, s->L, 0, &base8);
+      const size_t lds8 = base8 + (size_t)P * ci::NT * s->L * sizeof(float);
+      if (f8 && lds8 <= 160 * 1024) {
+        s->fn = f8;
+        s->fn_prof5 = pick_kernel8(D, s->L, 1, nullptr);
         if (s->fn_prof5)
           HIP_TRY(hipFuncSetAttribute((const void*)s->fn_prof5,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
         s->five_waves = true;
-        s->lds_bytes = lds5;
-        snprintf(nm, sizeof(nm), "ci::gibbs_kernel5<%d,%d>", D, s->L);
+        s->lds_bytes = lds8;
+        snprintf(nm, sizeof(nm), "ci::gibbs_kernel8<%d,%d>", D, s->L);
         s->kernel_name = nm;
       }
     }
@@ -864,7 +866,7 @@ static int session_launch(ci_session* s) {
                        s->lds_bytes, s->stream, sa);
   } else {
     if (s->profile && s->five_waves && s->fn_prof5) {
-      hipLaunchKernelGGL(s->fn_prof5, dim3(pb.num_series * pb.num_chains), dim3(ci::NT5), s->lds_bytes,
+      hipLaunchKernelGGL(s->fn_prof5, dim3(pb.num_series * pb.num_chains), dim3(ci::NT8), s->lds_bytes,
                          s->stream, a);
     } else if (s->profile && s->fn_prof) {
       // the instrumented variant is the four-wave kernel (its own LDS layout)
@@ -873,7 +875,7 @@ static int session_launch(ci_session* s) {
                          s->stream, a);
     } else {
       hipLaunchKernelGGL(s->fn, dim3(pb.num_series * pb.num_chains),
-                         dim3(s->five_waves ? ci::NT5 : ci::NT), s->lds_bytes, s->stream, a);
+                         dim3(s->five_waves ? ci::NT8 : ci::NT), s->lds_bytes, s->stream, a);
     }
   }
   HIP_TRY(hipGetLastError());

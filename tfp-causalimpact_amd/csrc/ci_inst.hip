@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ci_kernels.h"
-#include "ci_kernels5.h"
+#include "ci_kernels8.h"
 #include "ci_hmc.h"
 
 #ifndef CI_D
@@ -37,13 +37,20 @@ void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(int pm) {
   return nullptr;
 }
 
-// The five-wavefront latency build of the PM = 1 kernel (ci_kernels5.h).
-void* CI_CAT(ci_gibbs5_fn_d, CI_D, _l, CI_L)(int profiled) {
+// The eight-wavefront latency build of the PM = 1 kernel (ci_kernels8.h); *lds_base = its LDS
+// bytes without the design (+ P * 256 * L * 4 for the design).
+void* CI_CAT(ci_gibbs8_fn_d, CI_D, _l, CI_L)(int profiled, size_t* lds_base) {
+#if CI_L <= 8
+  if (lds_base) *lds_base = ci::Lay8<CI_D, CI_L>::off_x;
 #if CI_D == 2 && CI_L == 4
   // the instrumented variant exists for the bench shape only (ci_session_profile)
-  if (profiled) return (void*)(&ci::gibbs_kernel5<CI_D, CI_L, true>);
+  if (profiled) return (void*)(&ci::gibbs_kernel8<CI_D, CI_L, true>);
 #endif
-  return profiled ? nullptr : (void*)(&ci::gibbs_kernel5<CI_D, CI_L, false>);
+  return profiled ? nullptr : (void*)(&ci::gibbs_kernel8<CI_D, CI_L, false>);
+#else
+  (void)profiled; (void)lds_base;
+  return nullptr;      // T > 2048: the design does not fit LDS beside the randomness buffers
+#endif
 }
 
 // Launches the one-draw Durbin-Koopman test kernel on the default stream.

@@ -360,6 +360,76 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 
 // ------------------------------------------------------------------------------------
+// X~'targets and y'y with a summation order that does not depend on WHO sums WHAT: feature j's
+// sum is  lane l: its float4 chunks l, l + 64, ... of the series in that order, four fused
+// multiply-adds per chunk in time order;  then the 64 lane sums through the fixed DPP tree of
+// wave_prefix_dpp (lane 63 stores).  Any wavefront can take any feature -- the four-wave kernel
+// gives each of its waves 4 features, the eight-wave latency kernel 2 (its regression and
+// randomness waves join in) -- and the bits are the same.  No cross-wave reduction, no gather.
+// tg: tpad floats in LDS (0 where missing / beyond T); Xs: rows of tpad floats; sums[0..15] the
+// features, sums[16] = y'y (from the wave called with with_yty).
+// ------------------------------------------------------------------------------------
+constexpr int RED_YTY = 16;        // slot of y'y in the new layout of `red`
+constexpr int RED_INC = 20;        // then (ss_level, ss_slope) per time wave
+template <int L, int NF>
+__device__ __forceinline__ void xt_sums_wave(const float* tg, const float* Xs, int tpad, int P, int j0,
+                                             bool with_yty, float* sums, int lane) {
+  float4 tq[L];
+#pragma unroll
+  for (int c = 0; c < L; ++c) tq[c] = *reinterpret_cast<const float4*>(tg + 4 * (lane + 64 * c));
+  float acc[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int j = j0 + f;
+    const float* row = Xs + (size_t)(j < P ? j : P - 1) * tpad;
+    float4 xq[L];
+#pragma unroll
+    for (int c = 0; c < L; ++c) xq[c] = *reinterpret_cast<const float4*>(row + 4 * (lane + 64 * c));
+    float sv = 0.f;
+#pragma unroll
+    for (int c = 0; c < L; ++c) {
+      sv = fmaf(xq[c].x, tq[c].x, sv);
+      sv = fmaf(xq[c].y, tq[c].y, sv);
+      sv = fmaf(xq[c].z, tq[c].z, sv);
+      sv = fmaf(xq[c].w, tq[c].w, sv);
+    }
+    acc[f] = sv;
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f) acc[f] = wave_prefix_dpp(acc[f]);
+  if (lane == 63) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+      if (j0 + f < P) sums[j0 + f] = acc[f];
+  }
+  if (with_yty) {
+    float yy = 0.f;
+#pragma unroll
+    for (int c = 0; c < L; ++c) {
+      yy = fmaf(tq[c].x, tq[c].x, yy);
+      yy = fmaf(tq[c].y, tq[c].y, yy);
+      yy = fmaf(tq[c].z, tq[c].z, yy);
+      yy = fmaf(tq[c].w, tq[c].w, yy);
+    }
+    yy = wave_prefix_dpp(yy);
+    if (lane == 63) sums[RED_YTY] = yy;
+  }
+}
+// The owned steps' targets (0 where missing) to the shared vector.
+template <int L>
+__device__ __forceinline__ void store_targets(float* tgv, int t0, const float (&tg)[L]) {
+  if constexpr (L % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < L / 4; ++q)
+      *reinterpret_cast<float4*>(tgv + t0 + 4 * q) = make_float4(tg[4 * q], tg[4 * q + 1], tg[4 * q + 2], tg[4 * q + 3]);
+  } else if constexpr (L == 2) {
+    *reinterpret_cast<float2*>(tgv + t0) = make_float2(tg[0], tg[1]);
+  } else {
+    tgv[t0] = tg[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Durbin-Koopman simulation smoother for the trend block, time-parallel.
 // (LinearGaussianStateSpaceModel.posterior_sample reached from
 //  gibbs_sampler._resample_latents; oracle: ci_oracle_dk_draw.)
@@ -495,7 +565,6 @@ __device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const V
   }
 }
 
-// slots: 3 regions of NW * 16 floats.  Contains 3 __syncthreads().
 // The 3 L normals thread `owner` consumes in dk_draw (level, slope, observation disturbances of
 // its L steps).  They depend on (seed, chain, iteration) only, so the Gibbs kernel draws them
 // while wave 0 is in the serial section.
@@ -535,6 +604,416 @@ __device__ __forceinline__ PElem<D> dk_prior_finish(const PElem<D>& incl, const 
       pelem_identity<D>(), slots, lane, wave);
 }
 
+// ------------------------------------------------------------------------------------
+// The Durbin-Koopman draw in two phases.
+//   MATRIX phase -- needs the variances (sigma^2_obs, the disturbance scales) and the
+//   missing-data pattern, NOT the data: scan of the (A, C, J) part of the filtering elements
+//   (FMElem), then a local pass that leaves for every owned step the predicted covariance P_t,
+//   the gain k_t = P_t Z'/F_t, 1/F_t, and the two 2 x 2 products the data phase scans with:
+//     Mf = G_{L-1} ... G_0,   G_t = (I - k_t Z) T      filtered mean:  m_t = G_t m_{t-1} + k_t y_t
+//     Mb = N_0 ... N_{L-1},   N_t = (I - Z' k_t') T'   adjoint:  r_{t-1} = N_t r_t + Z' v_t / F_t
+//   DATA phase -- two scans of affine maps of d-vectors (forward: the filtered means, backward:
+//   the smoothing adjoint r) whose matrix parts are Mf / Mb, each followed by a local pass.
+// The five-/eight-wave Gibbs kernels run the matrix phase while the regression wave is still
+// drawing the weights (the data of the filter); every kernel calls the same functions, so all of
+// them produce the same bits (-ffp-contract=on).
+// ------------------------------------------------------------------------------------
+template <int D, int L> struct DkMats {
+  Mat<D> Pp[L];     // predicted covariance P_t
+  Vec<D> kf[L];     // filter gain P_t Z' / F_t (0 where missing)
+  float rF[L];      // 1 / F_t (0 where missing)
+  Mat<D> Mf, Mb;
+};
+
+// The chunk's (A, C, J): time update, then -- where y_t is observed -- the rank-one fold of the
+// observation (kalman_filter_pass (2) without its vector parts).
+template <int D, int L>
+__device__ __forceinline__ FMElem<D> dk_matrix_chunk(const DkModel<D>& md, const Vec<D>& q,
+                                                     uint32_t maskbits, int tid) {
+  FMElem<D> fe = fmelem_identity<D>();
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const bool obs = ((maskbits >> l) & 1u) == 0u;
+    if (tid == 0 && l == 0) {
+      // prior element: A = 0, C = covariance of x_0 after its own update
+      fe.A = mzero<D>();
+#pragma unroll
+      for (int i = 0; i < D; ++i) fe.C[symidx<D>(i, i)] = md.p1.v[i];
+      if (obs) {
+        const float F = md.p1.v[0] + md.H;
+        fe.C[symidx<D>(0, 0)] = md.p1.v[0] * md.H / F;
+      }
+      continue;
+    }
+    if constexpr (D == 2) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) fe.A.m[0][j] += fe.A.m[1][j];
+      fe.C[symidx<D>(0, 0)] = fmaf(2.f, fe.C[symidx<D>(0, 1)], __fadd_rn(fe.C[symidx<D>(0, 0)], fe.C[symidx<D>(1, 1)]));
+      fe.C[symidx<D>(0, 1)] += fe.C[symidx<D>(1, 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) fe.C[symidx<D>(i, i)] += q.v[i];
+    if (obs) {
+      float za[D], cz[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) { za[j] = fe.A.m[0][j]; cz[j] = fe.C[symidx<D>(j, 0)]; }
+      const float rS = __builtin_amdgcn_rcpf(cz[0] + md.H);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const float ki = cz[i] * rS, zi = za[i] * rS;
+#pragma unroll
+        for (int j = 0; j < D; ++j) fe.A.m[i][j] = fmaf(-ki, za[j], fe.A.m[i][j]);
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+          fe.J[symidx<D>(i, j)] = fmaf(zi, za[j], fe.J[symidx<D>(i, j)]);
+          fe.C[symidx<D>(i, j)] = fmaf(-ki, cz[j], fe.C[symidx<D>(i, j)]);
+        }
+      }
+    }
+  }
+  return fe;
+}
+
+// The three block scans of the draw, each in two halves around a workgroup barrier that the CALLER
+// places (the eight-wave kernel shares its barriers with the regression and randomness waves).
+// begin = the in-wave inclusive scan + the wave total to LDS; finish = what the thread needs from
+// everything before (after) its chunk.  Across waves nothing is COMPOSED any more: the earlier
+// waves' totals are APPLIED one after the other to the quantity that is carried -- a covariance
+// (34 instead of 62 operations per wave), a mean, an adjoint (4 instead of 12) -- which is all the
+// local passes start from.  Wave 0 holds x_0, whose element has A = 0 (no predecessor): its total
+// maps every incoming state to the same (mean, covariance), so the chain starts from that total.
+// slots: NW * 16 floats per scan.
+template <int D>
+__device__ __forceinline__ void fm_apply_cov(float (&P)[D * (D + 1) / 2], const FMElem<D>& e) {
+  // P <- A (I + P J)^-1 P A' + C
+  Mat<D> W, RC;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = (i == j) ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fmaf(P[symidx<D>(i, k)], e.J[symidx<D>(k, j)], s);
+      W.m[i][j] = s;
+      RC.m[i][j] = P[symidx<D>(i, j)];
+    }
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    const float rp = __builtin_amdgcn_rcpf(W.m[c][c]);
+#pragma unroll
+    for (int j = c + 1; j < D; ++j) W.m[c][j] *= rp;
+#pragma unroll
+    for (int j = 0; j < D; ++j) RC.m[c][j] *= rp;
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      if (r == c) continue;
+      const float f = W.m[r][c];
+#pragma unroll
+      for (int j = c + 1; j < D; ++j) W.m[r][j] = fmaf(-f, W.m[c][j], W.m[r][j]);
+#pragma unroll
+      for (int j = 0; j < D; ++j) RC.m[r][j] = fmaf(-f, RC.m[c][j], RC.m[r][j]);
+    }
+  }
+  const Mat<D> T1 = mm(e.A, RC);
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      float s = e.C[symidx<D>(i, j)];
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fmaf(T1.m[i][k], e.A.m[j][k], s);
+      P[symidx<D>(i, j)] = s;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ FMElem<D> dk_matrix_scan_begin(const FMElem<D>& fe, float* slots_m, int lane,
+                                                          int wave) {
+  const FMElem<D> incl = wave_scan_incl_fwd(
+      fe, [](const FMElem<D>& a, const FMElem<D>& b) { return fmelem_combine(a, b); }, lane);
+  if (lane == 63) lds_store_e(slots_m + wave * 16, incl);
+  return incl;
+}
+// -> the filtered covariance of the step before this thread's chunk (packed upper triangle)
+template <int D>
+__device__ __forceinline__ void dk_matrix_scan_finish(const FMElem<D>& incl, const float* slots_m,
+                                                      int lane, int wave,
+                                                      float (&Pin)[D * (D + 1) / 2]) {
+  FMElem<D> ex = dpp_move_e<0x138, 0xF>(incl);        // wave_shr:1
+  if (lane == 0) ex = fmelem_identity<D>();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < D * (D + 1) / 2; ++i) Pin[i] = ex.C[i];
+    return;
+  }
+  FMElem<D> tot[NW - 1];
+#pragma unroll
+  for (int u = 0; u < NW - 1; ++u) tot[u] = lds_load_e<FMElem<D>>(slots_m + u * 16);
+#pragma unroll
+  for (int i = 0; i < D * (D + 1) / 2; ++i) Pin[i] = tot[0].C[i];
+#pragma unroll
+  for (int u = 1; u < NW - 1; ++u)
+    if (wave > u) fm_apply_cov<D>(Pin, tot[u]);
+  fm_apply_cov<D>(Pin, ex);
+}
+
+template <int D>
+__device__ __forceinline__ AElem<D> aff_fwd_begin(const AElem<D>& fe, float* slots_f, int lane, int wave) {
+  // op(earlier, later) = later after earlier
+  const AElem<D> incl = wave_scan_incl_fwd(
+      fe, [](const AElem<D>& a, const AElem<D>& b) { return aelem_compose(b, a); }, lane);
+  if (lane == 63) lds_store_e(slots_f + wave * 16, incl);
+  return incl;
+}
+// -> the filtered mean of the step before this thread's chunk
+template <int D>
+__device__ __forceinline__ Vec<D> aff_fwd_finish(const AElem<D>& incl, const float* slots_f, int lane,
+                                                 int wave) {
+  AElem<D> ex = dpp_move_e<0x138, 0xF>(incl);
+  if (lane == 0) ex = aelem_identity<D>();
+  if (wave == 0) return ex.c;
+  AElem<D> tot[NW - 1];
+#pragma unroll
+  for (int u = 0; u < NW - 1; ++u) tot[u] = lds_load_e<AElem<D>>(slots_f + u * 16);
+  Vec<D> m = tot[0].c;
+#pragma unroll
+  for (int u = 1; u < NW - 1; ++u)
+    if (wave > u) m = vadd(mv(tot[u].M, m), tot[u].c);
+  return vadd(mv(ex.M, m), ex.c);
+}
+
+template <int D>
+__device__ __forceinline__ AElem<D> aff_bwd_begin(const AElem<D>& be, float* slots_b, int lane, int wave) {
+  const AElem<D> incl = wave_scan_incl_bwd(
+      be, [](const AElem<D>& o, const AElem<D>& i) { return aelem_compose(o, i); }, lane);
+  if (lane == 0) lds_store_e(slots_b + wave * 16, incl);
+  return incl;
+}
+// -> the adjoint r of this thread's last step (r = 0 beyond the end of the series)
+template <int D>
+__device__ __forceinline__ Vec<D> aff_bwd_finish(const AElem<D>& incl, const float* slots_b, int lane,
+                                                 int wave) {
+  AElem<D> ex = dpp_move_e<0x130, 0xF>(incl);        // wave_shl:1
+  if (lane == 63) ex = aelem_identity<D>();
+  if (wave == NW - 1) return ex.c;
+  AElem<D> tot[NW];
+#pragma unroll
+  for (int u = 1; u < NW; ++u) tot[u] = lds_load_e<AElem<D>>(slots_b + u * 16);
+  Vec<D> r = tot[NW - 1].c;
+#pragma unroll
+  for (int u = NW - 2; u >= 1; --u)
+    if (wave < u) r = vadd(mv(tot[u].M, r), tot[u].c);
+  return vadd(mv(ex.M, r), ex.c);
+}
+
+// Local covariance pass from the filtered covariance `Pin` of the step before the chunk: P_t,
+// gains, 1/F_t and the chunk's two mean maps.
+template <int D, int L>
+__device__ __forceinline__ void dk_matrix_local(const DkModel<D>& md, const Vec<D>& q,
+                                                uint32_t maskbits, int tid,
+                                                const float (&Pin)[D * (D + 1) / 2],
+                                                DkMats<D, L>& km) {
+  Mat<D> Pf;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) Pf.m[i][j] = Pin[symidx<D>(i, j)];
+  // thread 0: x_0 has no predecessor -- its first step wipes any dependence on an incoming mean
+  Mat<D> Mf = (tid == 0) ? mzero<D>() : meye<D>();
+  Mat<D> Mb = meye<D>();
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const bool obs = ((maskbits >> l) & 1u) == 0u;
+    Mat<D> P;
+    if (tid == 0 && l == 0) {
+      P = mzero<D>();
+#pragma unroll
+      for (int i = 0; i < D; ++i) P.m[i][i] = md.p1.v[i];
+    } else {
+      P = trans_cov(Pf, q);
+      Mf = trans_left(Mf);
+    }
+    km.Pp[l] = P;
+    Vec<D> k = vzero<D>();
+    float rF = 0.f;
+    if (obs) {
+      rF = __builtin_amdgcn_rcpf(P.m[0][0] + md.H);
+#pragma unroll
+      for (int i = 0; i < D; ++i) k.v[i] = P.m[i][0] * rF;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Pf.m[i][j] = fmaf(-k.v[i], P.m[0][j], P.m[i][j]);
+      symmetrize(Pf);
+    } else {
+      Pf = P;
+    }
+    km.kf[l] = k;
+    km.rF[l] = rF;
+    // Mf <- (I - k Z) Mf   (row i loses k_i times row 0; k = 0 where missing)
+    {
+      float r0[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) r0[j] = Mf.m[0][j];
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Mf.m[i][j] = fmaf(-k.v[i], r0[j], Mf.m[i][j]);
+    }
+    // Mb <- Mb (I - Z' k') T'   (column j loses k_j times column 0, then T' from the right)
+    {
+      Mat<D> X;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) X.m[i][j] = fmaf(-Mb.m[i][0], k.v[j], Mb.m[i][j]);
+      Mb = trans_right_t(X);
+    }
+  }
+  km.Mf = Mf;
+  km.Mb = Mb;
+}
+
+// One step of the adjoint recursion r_{t-1} = (I - Z' k_t')(T' r_t) + Z' v_t / F_t.
+template <int D, int L>
+__device__ __forceinline__ Vec<D> dk_adjoint_step(const DkMats<D, L>& km, int l, const Vec<D>& r,
+                                                  float vfl) {
+  Vec<D> u = trans_t_apply(r);
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) dot = fmaf(km.kf[l].v[i], u.v[i], dot);
+  u.v[0] = (u.v[0] - dot) + vfl;
+  return u;
+}
+
+// Forward chunk map of the filtered mean (matrix part from the matrix phase, vector part here).
+template <int D, int L>
+__device__ __forceinline__ AElem<D> dk_fwd_chunk(const DkMats<D, L>& km, const Vec<D>& a1e,
+                                                 const float (&ytil)[L], uint32_t maskbits, int tid) {
+  Vec<D> c = vzero<D>();
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const bool obs = ((maskbits >> l) & 1u) == 0u;
+    const Vec<D> a = (tid == 0 && l == 0) ? a1e : trans_apply(c);
+    c = a;
+    if (obs) {
+      const float v = ytil[l] - a.v[0];
+#pragma unroll
+      for (int i = 0; i < D; ++i) c.v[i] = fmaf(km.kf[l].v[i], v, a.v[i]);
+    }
+  }
+  AElem<D> e;
+  e.M = km.Mf;
+  e.c = c;
+  return e;
+}
+
+// Local pass of the means from the filtered mean `mf` of the step before the chunk: predicted
+// means a_t and v_t / F_t (0 where missing); then the chunk's adjoint map.
+template <int D, int L>
+__device__ __forceinline__ AElem<D> dk_fwd_local_bwd_chunk(const DkMats<D, L>& km, const Vec<D>& a1e,
+                                                           const float (&ytil)[L], uint32_t maskbits,
+                                                           int tid, Vec<D> mf, Vec<D> (&ap)[L],
+                                                           float (&vf)[L]) {
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const bool obs = ((maskbits >> l) & 1u) == 0u;
+    const Vec<D> a = (tid == 0 && l == 0) ? a1e : trans_apply(mf);
+    ap[l] = a;
+    mf = a;
+    vf[l] = 0.f;
+    if (obs) {
+      const float v = ytil[l] - a.v[0];
+      vf[l] = v * km.rF[l];
+#pragma unroll
+      for (int i = 0; i < D; ++i) mf.v[i] = fmaf(km.kf[l].v[i], v, a.v[i]);
+    }
+  }
+  Vec<D> d = vzero<D>();
+#pragma unroll
+  for (int l = L - 1; l >= 0; --l) d = dk_adjoint_step<D, L>(km, l, d, vf[l]);
+  AElem<D> e;
+  e.M = km.Mb;
+  e.c = d;
+  return e;
+}
+
+// Fix-up: r of the chunk's last step in, the draw x~_t = a_t + P_t r_{t-1} + x+_t out.
+template <int D, int L>
+__device__ __forceinline__ void dk_bwd_fixup(const DkMats<D, L>& km, Vec<D> r, const Vec<D> (&ap)[L],
+                                             const float (&vf)[L], const Vec<D> (&xp)[L],
+                                             Vec<D> (&xout)[L]) {
+#pragma unroll
+  for (int l = L - 1; l >= 0; --l) {
+    r = dk_adjoint_step<D, L>(km, l, r, vf[l]);
+    const Vec<D> sm = vadd(ap[l], mv(km.Pp[l], r));
+    xout[l] = vadd(sm, xp[l]);
+  }
+}
+
+// The simulated path of the prior (zero initial state) from the scanned prefix, and the data of
+// the filter y~ = resid - y+.
+template <int D, int L>
+__device__ __forceinline__ void dk_prior_path(const DkModel<D>& md, const PElem<D>& ppre,
+                                              const float (&resid)[L], const float (&zl)[L],
+                                              const float (&zs)[L], const float (&zo)[L],
+                                              Vec<D> (&xp)[L], float (&ytil)[L]) {
+  Vec<D> x = ppre.s;
+  const float so = __fsqrt_rn(md.H);
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    xp[l] = x;
+    ytil[l] = resid[l] - fmaf(so, zo[l], x.v[0]);
+    x = trans_apply(x);
+    x.v[0] = fmaf(md.sig.v[0], zl[l], x.v[0]);
+    if constexpr (D == 2) x.v[1] = fmaf(md.sig.v[1], zs[l], x.v[1]);
+  }
+}
+
+// The prior mean of x_0 with the simulated initial state folded in (see dk_draw).
+template <int D>
+__device__ __forceinline__ Vec<D> dk_initial_mean(const DkModel<D>& md, const Rng& rng, uint32_t iter,
+                                                  int tid, const float* zinit) {
+  Vec<D> a1e = md.a1;
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float zi[1];
+      if (zinit) zi[0] = zinit[i];       // drawn ahead by an idle wave (same site, same index)
+      else fill_normals<1>(rng, iter, SITE_PRIOR_INIT, 0, (uint32_t)i, zi);
+      a1e.v[i] = fmaf(__fsqrt_rn(md.p1.v[i]), zi[0], md.a1.v[i]);
+    }
+  }
+  return a1e;
+}
+
+// The data phase: contains two __syncthreads().  slots_f / slots_b: NW * 16 floats each.
+template <int D, int L, class PF>
+__device__ __forceinline__ void dk_data_phase(const DkMats<D, L>& km, const Vec<D>& a1e,
+                                              const float (&ytil)[L], const Vec<D> (&xp)[L],
+                                              uint32_t maskbits, int tid, int lane, int wave,
+                                              float* slots_f, float* slots_b, Vec<D> (&xout)[L],
+                                              PF& prof) {
+  const AElem<D> fe = dk_fwd_chunk<D, L>(km, a1e, ytil, maskbits, tid);
+  prof.tick(27);
+  const AElem<D> fincl = aff_fwd_begin<D>(fe, slots_f, lane, wave);
+  __syncthreads();
+  const Vec<D> mf = aff_fwd_finish<D>(fincl, slots_f, lane, wave);
+  prof.tick(5);
+  Vec<D> ap[L];
+  float vf[L];
+  const AElem<D> be = dk_fwd_local_bwd_chunk<D, L>(km, a1e, ytil, maskbits, tid, mf, ap, vf);
+  prof.tick(6);
+  const AElem<D> bincl = aff_bwd_begin<D>(be, slots_b, lane, wave);
+  __syncthreads();
+  const Vec<D> r = aff_bwd_finish<D>(bincl, slots_b, lane, wave);
+  prof.tick(28);
+  dk_bwd_fixup<D, L>(km, r, ap, vf, xp, xout);
+  prof.tick(7);
+}
+
+// slots: 3 regions of NW * 16 floats.  Contains 4 __syncthreads() (3 with the prior simulation
+// scanned by the caller).
 template <int D, int L, class PF>
 __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resid)[L],
                                         uint32_t maskbits, const Rng& rng, uint32_t iter, int tid,
@@ -552,16 +1031,7 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
   // it is folded into the filter's prior mean instead:
   //   x~ = x+_noise + E[x | y - y+_noise ; prior mean a_1 + x+_0]
   // which is the same draw as the oracle's x+ + E[x | y - y+ ; prior mean a_1].
-  Vec<D> a1e = md.a1;
-  if (tid == 0) {
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      float zi[1];
-      if (zinit) zi[0] = zinit[i];       // drawn ahead by an idle wave (same site, same index)
-      else fill_normals<1>(rng, iter, SITE_PRIOR_INIT, 0, (uint32_t)i, zi);
-      a1e.v[i] = fmaf(__fsqrt_rn(md.p1.v[i]), zi[0], md.a1.v[i]);
-    }
-  }
+  const Vec<D> a1e = dk_initial_mean<D>(md, rng, iter, tid, zinit);
   PElem<D> ppre;
   if (ppre_in) {
     ppre = *ppre_in;                     // scanned by the caller (dk_prior_begin / dk_prior_finish)
@@ -572,61 +1042,26 @@ __device__ __forceinline__ void dk_draw(const DkModel<D>& md, const float (&resi
   }
   Vec<D> xp[L];
   float ytil[L];
-  {
-    Vec<D> x = ppre.s;
-    const float so = __fsqrt_rn(md.H);
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      xp[l] = x;
-      ytil[l] = resid[l] - fmaf(so, zo[l], x.v[0]);
-      x = trans_apply(x);
-      x.v[0] = fmaf(md.sig.v[0], zl[l], x.v[0]);
-      if constexpr (D == 2) x.v[1] = fmaf(md.sig.v[1], zs[l], x.v[1]);
-    }
-  }
-
+  dk_prior_path<D, L>(md, ppre, resid, zl, zs, zo, xp, ytil);
   prof.tick(4);
-  // ---- (2) Kalman filter (associative scan + local pass)
-  Vec<D> ap[L];
-  Mat<D> Pp[L];
-  Vec<D> kf[L];
-  float vf[L], fvar[L];
-  kalman_filter_pass<D, L>(md, a1e, q, ytil, maskbits, tid, lane, wave, slots + NW * 16, ap, Pp,
-                           kf, vf, fvar, prof);
 
-  prof.tick(6);
-  // ---- (3) backward recursion r_{t-1} = (I - K_t Z)' T' r_t + Z' v_t / F_t as a suffix scan
-  auto step_map = [&](int l) {
-    AElem<D> e;
-    // (I - kf Z)' : identity with row 0 reduced by kf'
-    Mat<D> ikzt = meye<D>();
-#pragma unroll
-    for (int j = 0; j < D; ++j) ikzt.m[0][j] -= kf[l].v[j];
-    // T' = transpose of trans_mat
-    Mat<D> Tt = meye<D>();
-    if constexpr (D == 2) Tt.m[1][0] = 1.f;
-    e.M = mm(ikzt, Tt);
-    e.c = vzero<D>();
-    e.c.v[0] = vf[l];
-    return e;
-  };
-  AElem<D> atot = step_map(L - 1);
-#pragma unroll
-  for (int l = L - 2; l >= 0; --l) atot = aelem_compose(step_map(l), atot);
-  const AElem<D> asuf = block_scan_excl_bwd(
-      atot, [](const AElem<D>& o, const AElem<D>& i) { return aelem_compose(o, i); },
-      aelem_identity<D>(), slots + 2 * NW * 16, lane, wave);
-  {
-    Vec<D> r = asuf.c;  // the map of everything after this chunk applied to r = 0
-#pragma unroll
-    for (int l = L - 1; l >= 0; --l) {
-      const AElem<D> e = step_map(l);
-      r = vadd(mv(e.M, r), e.c);
-      const Vec<D> sm = vadd(ap[l], mv(Pp[l], r));
-      xout[l] = vadd(sm, xp[l]);
-    }
-  }
-  prof.tick(7);
+  // ---- (2) matrix phase: covariances, gains, the chunk's mean maps
+  const FMElem<D> fe = dk_matrix_chunk<D, L>(md, q, maskbits, tid);
+  prof.tick(24);
+  const FMElem<D> mincl = dk_matrix_scan_begin<D>(fe, slots + NW * 16, lane, wave);
+  __syncthreads();
+  float Pin[D * (D + 1) / 2];
+  dk_matrix_scan_finish<D>(mincl, slots + NW * 16, lane, wave, Pin);
+  prof.tick(25);
+  DkMats<D, L> km;
+  dk_matrix_local<D, L>(md, q, maskbits, tid, Pin, km);
+  prof.tick(26);
+
+  // ---- (3) data phase: filtered means forward, adjoint backward, fix-up
+  // (region 0 of `slots` is free again: the prior scan's totals were read before the barrier of
+  //  the matrix scan)
+  dk_data_phase<D, L>(km, a1e, ytil, xp, maskbits, tid, lane, wave, slots, slots + 2 * NW * 16, xout,
+                      prof);
 }
 
 template <int D, int L, class PF>
@@ -847,13 +1282,19 @@ __device__ __forceinline__ void spike_slab_randoms(const Rng& rng, uint32_t iter
   }
 }
 
-template <class PF>
+// `publish(new_scale)` is called as soon as sigma_obs is drawn, before the weights (the eight-wave
+// kernel hands it to the time waves there).
+struct NoPublish {
+  __device__ __forceinline__ void operator()(double) const {}
+};
+template <class PF, class Pub = NoPublish>
 __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
                                                        const DevSeriesParams& sp,
                                                        double prev_obs_scale, double g_obs,
                                                        const Rng& rng, uint32_t iter, int lane,
                                                        PF& prof, PriorCarry& pc,
-                                                       const double* pre = nullptr) {
+                                                       const double* pre = nullptr,
+                                                       Pub publish = Pub()) {
   // pre (optional, LDS): this iteration's data-independent randomness, drawn one iteration
   // ahead by an idle wave (spike_slab_randoms): [0,16) flip uniforms by feature, [16,24) visiting
   // ranks (int), [24,32) weight normals (float)
@@ -952,6 +1393,7 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
   double var = beta_post * fast_rcp(g_obs);
   if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
   const double new_scale = (double)__fsqrt_rn((float)var);
+  publish(new_scale);
   prof.tick(11);
 
   // weights_S ~ N(mean, var * V), V = M_S^{-1} = -(swept block).  Un-sweep the included
@@ -1639,7 +2081,7 @@ struct SerialCtx {
 struct LdsLayout {
   size_t off_ctx, off_xtx, off_omega, off_aug0, off_aug1, off_pri0, off_pri1, off_chol, off_bvec,
       off_zv, off_uperm, off_nz, off_perm, off_idx, off_w, off_scal, off_red, off_slots, off_xlast,
-      off_tg, off_gam, off_nz0, off_x, total;
+      off_tg, off_gam, off_nz0, off_tgv, off_x, total;
 };
 
 __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_in_lds) {
@@ -1670,6 +2112,8 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_gam = take(sizeof(double) * (8 + 64 + 4));   // gamma draws (wave 1) and regression-block randomness
                                                  // (wave 2) handed to the serial wave, double-buffered
   l.off_nz0 = take(sizeof(float) * (4 * 64 * (tpad / NT) + 4));   // wave 0's normals, drawn by waves 1-3
+  // targets y - level over time, handed to the waves that sum X~'targets (P <= 16, X in LDS)
+  l.off_tgv = take((x_in_lds && P > 0 && P <= 16) ? sizeof(float) * (size_t)tpad : 16);
   l.off_x = take(x_in_lds ? sizeof(float) * (size_t)Pp * tpad : 16);
   l.total = o;
   return l;
@@ -1706,7 +2150,7 @@ static __device__ __forceinline__ void serial_gammas(const SerialCtx* cx, int it
   if (lane == 0) { out[0] = g_level; out[1] = g_slope; out[2] = g_obs; }
 }
 
-template <int PM, class PF>
+template <int PM, class PF, bool NR = false>
 static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLds& R,
                                                       const float* red, float* scal, int it,
                                                       int lane, PriorCarry& pc,
@@ -1717,7 +2161,16 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
   const int P = (PM == 0) ? 0 : cx->P, T = cx->T;
   PF prof;
   prof.start(cx->prof, cx->prof != nullptr && lane == 0);
-  {
+  if constexpr (NR) {
+    // xt_sums_wave left the finished sums (one float each); the increments come per time wave
+    if (lane < P + 1) R.bvec[lane] = (double)red[lane < P ? lane : RED_YTY];
+    if (lane >= 62) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += (double)red[RED_INC + 2 * w + (lane - 62)];
+      R.bvec[P + 1 + (lane - 62)] = s;
+    }
+  } else {
     const int RS = (P > 16 ? P : 16) + 4;
     for (int j = lane; j < P + 3; j += 64) {
       const int src = j < P ? j : RS - 4 + (j - P);
@@ -1792,6 +2245,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   // function holding both cost the 512-series batch 7 %)
   constexpr int RPM = (PM == 3) ? 1 : PM;
   constexpr bool STREAM = PM == 3;
+  constexpr bool NEWRED = PM == 1;        // xt_sums_wave's layout of `red` (shared with the eight-wave kernel)
   using PF = typename std::conditional<PROF, Prof, NoProf>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1807,6 +2261,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   float* xlast = (float*)(smem + lay.off_xlast);
   float* wls = (float*)(smem + lay.off_w);
   const float* Xs = (const float*)(smem + lay.off_x);
+  float* tgv = (float*)(smem + lay.off_tgv);
   const size_t chain_lin = (size_t)series * a.C + chain;
   const int RS = (P > 16 ? P : 16) + 4;   // stride of the per-wave partial-sum rows
 
@@ -1971,18 +2426,9 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         // register-resident path: 16 independent accumulators, DPP reductions interleave
         float pj[16];
         if constexpr (!STREAM) {
-          // branch-free: rows >= P re-read row P-1 and are masked out, so all 16 wide LDS loads
-          // are in flight before the first FMA (per-feature branches exposed the LDS latency)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int jj = j < P ? j : P - 1;
-            float xr[L];
-            lds_row_load<L>(Xs + jj * TPAD + t0, xr);
-            float s = 0.f;
-#pragma unroll
-            for (int l = 0; l < L; ++l) s = fmaf(xr[l], tg[l], s);
-            pj[j] = s;
-          }
+          // X in LDS: the targets go to the shared vector; after (B1) every wave sums four
+          // features over the WHOLE series (xt_sums_wave: no cross-wave reduction, no gather)
+          store_targets<L>(tgv, t0, tg);
         } else {
           // long series: T x P floats no longer fit LDS and the design streams from L2 -- the
           // regression block stays in registers all the same.  Rows in batches of independent
@@ -2016,11 +2462,13 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
           }
         }
         prof.tick(16);
-        // 16 wave sums as ONE reduce-scatter: lane l ends up with the total of feature l & 15
-        // (15 DPP exchange-adds + two cross-row shuffles instead of 16 six-step prefix chains),
-        // stored by lanes 0..15 in a single instruction
-        const float tot = wave_reduce_scatter16(pj, lane);
-        if (lane < 16) red[wave * RS + lane] = tot;
+        if constexpr (STREAM) {
+          // 16 wave sums as ONE reduce-scatter: lane l ends up with the total of feature l & 15
+          // (15 DPP exchange-adds + two cross-row shuffles instead of 16 six-step prefix chains),
+          // stored by lanes 0..15 in a single instruction
+          const float tot = wave_reduce_scatter16(pj, lane);
+          if (lane < 16) red[wave * RS + lane] = tot;
+        }
       } else if constexpr (RPM == 2) {
         // 16 features per round: their rows are independent loads (one L2 round trip per batch of
         // 8 when X streams from L2, instead of one per feature) and their wave sums ONE
@@ -2059,6 +2507,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
       xlast[tid * D] = lev[L - 1];
       if constexpr (D == 2) xlast[tid * D + 1] = slp[L - 1];
       __syncthreads();
+      if constexpr (NEWRED) xt_sums_wave<L, 4>(tgv, Xs, TPAD, P, 4 * wave, wave == NW - 1, red, lane);
       float ssl = 0.f, sss = 0.f;
       float pl = (tid > 0) ? xlast[(tid - 1) * D] : 0.f;
       float ps = 0.f;
@@ -2079,11 +2528,19 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         if constexpr (D == 2) ps = slp[l];
       }
       prof.tick(14);
-      const float s0 = wave_prefix_dpp(yty), s1 = wave_prefix_dpp(ssl), s2 = wave_prefix_dpp(sss);
-      if (lane == 63) {
-        red[wave * RS + RS - 4] = s0;
-        red[wave * RS + RS - 3] = s1;
-        red[wave * RS + RS - 2] = s2;
+      if constexpr (NEWRED) {
+        const float s1 = wave_prefix_dpp(ssl), s2 = wave_prefix_dpp(sss);
+        if (lane == 63) {
+          red[RED_INC + 2 * wave] = s1;
+          red[RED_INC + 2 * wave + 1] = s2;
+        }
+      } else {
+        const float s0 = wave_prefix_dpp(yty), s1 = wave_prefix_dpp(ssl), s2 = wave_prefix_dpp(sss);
+        if (lane == 63) {
+          red[wave * RS + RS - 4] = s0;
+          red[wave * RS + RS - 3] = s1;
+          red[wave * RS + RS - 2] = s2;
+        }
       }
     }
     // sigma_obs of iteration it-1's regression draw: the noise scale of its predictive trajectory
@@ -2100,8 +2557,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) zs[l] = 0.f;
     if (wave == 0) {
-      serial_section<RPM, PF>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1), gam + 8 + 32 * (it & 1),
-                         gam + 72);
+      serial_section<RPM, PF, NEWRED>(cx, R, red, scal, it, lane, pc, gam + 4 * (it & 1),
+                                      gam + 8 + 32 * (it & 1), gam + 72);
     } else {
       if (wave == 1 && it < n_iter) serial_gammas<RPM>(cx, it + 1, lane, gam + 4 * ((it + 1) & 1));
       if constexpr (RPM == 1) {

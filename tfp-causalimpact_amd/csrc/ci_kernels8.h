@@ -1,0 +1,847 @@
+// ci_kernels8.h -- the latency build of the register-resident Gibbs kernel: EIGHT wavefronts per
+// chain, one chain per compute unit (dispatched when every chain has a CU to itself, 0 < P <= 16,
+// X resident in LDS).  Same sampler, same random stream, the same arithmetic in the same order as
+// gibbs_kernel<D, L, 1> (ci_kernels.h) -- both call the same functions for everything that
+// rounds, and the library is built with -ffp-contract=on -- so every draw of the two kernels is
+// bit-identical (tests/test_gpu_gibbs.py) and the dispatch by launch size in ci_api.hip never
+// changes a result.  What changes is WHO computes WHAT WHEN.
+//
+//   waves 0-3  TIME waves: thread i owns the L consecutive steps [iL, (i+1)L) -- targets, the
+//              Durbin-Koopman draw, emission of the finished draw;
+//   wave 4     REGRESSION wave: owns the serial section (sigma^2_obs, weights) and, during the
+//              draw, already sweeps the NEXT iteration's posterior block (record / replay, as in
+//              rounds 2-3);
+//   waves 5-7  RANDOMNESS waves: every normal the time waves consume (3 L per thread for the
+//              draw, L for the predictive trajectory), the gamma variates and the regression
+//              block's permutation / uniforms, one iteration ahead, through LDS.  Philox + Box-Muller
+//              were 40 % of what the time waves executed between two barriers.
+//
+// One Gibbs iteration, barriers (B1) ... (B5) + (Bs) shared by all eight waves:
+//
+//   time waves                         regression wave                 randomness waves
+//   targets -> LDS                     .                               .
+//   (B1) ------------------------------------------------------------------------------------
+//   X~'targets: 2 features per wave over the WHOLE series (xt_sums_wave; all 8 waves), no
+//   cross-wave reduction; time waves also sum the level / slope increments
+//   (B2) ------------------------------------------------------------------------------------
+//   normals from LDS, emission of    right-hand side replay, flips,   gammas / permutation /
+//   draw it-1, disturbance scales,   sigma^2_obs(it) -> LDS           x_0 normals of it+1
+//   prior-simulation scan (1st half)
+//   (Bs) sigma^2_obs published --------------------------------------------------------------
+//   MATRIX phase of the draw         weights(it) replay, scale        normals of it+1 ...
+//   ((A, C, J) chunk + in-wave scan) draws of it-1, scalar outputs
+//   (B3) weights published = barrier of the matrix scan -------------------------------------
+//   covariances / gains, X w,        precompute for it+1 ...          ...
+//   forward scan of the means
+//   (B4) ------------------------------------------------------------------------------------
+//   local means, adjoint scan        ...                              ...
+//   (B5) ------------------------------------------------------------------------------------
+//   fix-up -> level, slope           ...                              ...
+//
+// The point of the split: the covariance side of the Kalman filter needs
+// sigma^2_obs but not the weights, so it runs WHILE the regression wave draws the weights, and
+// the time waves no longer generate random numbers in the window before it.
+#pragma once
+#include "ci_kernels.h"
+
+namespace ci {
+
+constexpr int NT8 = 512;              // 4 time waves + regression wave + 3 randomness waves
+constexpr int NW8 = 8;
+constexpr int PRE_MAXS = 16;          // recorded sweeps / un-sweeps (P <= 16)
+
+// LDS tables written by the regression wave's precompute, read by its next serial section.
+struct PreTables {
+  double* tsw;      // [PRE_MAXS][64]  sweep s: t_j of lane j (1 at the pivot)
+  double* tun;      // [PRE_MAXS][64]  un-sweep s: t_j
+  double* rdsw;     // [PRE_MAXS]      sweep s: 1 / pivot
+  double* vun;      // [PRE_MAXS]      un-sweep s: V_aa
+  int* ksw;         // [PRE_MAXS]      sweep s: pivot feature
+  int* kun;         // [PRE_MAXS]      un-sweep s: feature
+};
+__host__ __device__ constexpr size_t pre_tables_bytes() {
+  return sizeof(double) * (2 * PRE_MAXS * 64 + 2 * PRE_MAXS) + sizeof(int) * 2 * PRE_MAXS + 16;
+}
+
+// What the precompute leaves in the regression wave's registers for the next serial section.
+struct PreState {
+  double c[4];      // swept posterior block (quadrant layout of QCols)
+  double diag;
+  unsigned long long S;   // the set it is swept on
+  int n_sw, n_un;
+  int valid;
+};
+
+// sweep_q_kr<KR, false> that also returns its multipliers (t of this lane, 1 / pivot).
+template <int KR>
+__device__ __forceinline__ void sweep_rec_kr(QCols& m, int k, int lane, double& t_out, double& rd_out) {
+  const int kq = k >> 2, j = lane & 15, q = lane >> 4;
+  const double ckr = m.c[KR];
+  const double rd = fast_rcp(readlane_d(ckr, k + 16 * kq));
+  const double rowk = bperm_d(ckr, j + 16 * kq);      // A[k][j]
+  const bool isk = j == k;
+  const double t = isk ? 1.0 : rowk * rd;
+  double colk[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) colk[r] = bperm_d(m.c[r], k + 16 * q);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m.c[r] = isk ? colk[r] * rd : m.c[r] - colk[r] * t;
+  m.c[KR] = (q == kq) ? (isk ? -rd : t) : m.c[KR];
+  m.diag = isk ? -rd : m.diag - rowk * rowk * rd;
+  t_out = t;
+  rd_out = rd;
+}
+__device__ __forceinline__ void sweep_rec(QCols& m, int k, int lane, double& t_out, double& rd_out) {
+  switch (k & 3) {
+    case 0: sweep_rec_kr<0>(m, k, lane, t_out, rd_out); break;
+    case 1: sweep_rec_kr<1>(m, k, lane, t_out, rd_out); break;
+    case 2: sweep_rec_kr<2>(m, k, lane, t_out, rd_out); break;
+    default: sweep_rec_kr<3>(m, k, lane, t_out, rd_out); break;
+  }
+}
+
+// The matrix work of the NEXT serial section: posterior block for sigma^2 = var_next swept on S,
+// multipliers recorded; then (on a copy) the descending un-sweeps of the weights draw, recorded.
+// `sync` is called after every step; the caller uses it to place the workgroup barriers of the
+// phase the time waves are in.
+template <class Sync>
+__device__ __forceinline__ void regression_precompute(const RegLds& R, int P, double var_next,
+                                                      unsigned long long S, int lane,
+                                                      const PreTables& tb, PreState& ps, Sync sync) {
+  const int j = lane & 15, q = lane >> 4;
+  const bool live = j < P;
+  const int col = live ? j : 0;
+  QCols m;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * q + r;
+    double om = 0.0, xx = 0.0;
+    if (live && i < P) {
+      om = R.omega[i * P + col];
+      xx = R.xtx[i * P + col];
+    }
+    m.c[r] = om * var_next + xx;
+    m.p[r] = 0.0;
+  }
+  m.diag = live ? R.omega[col * P + col] * var_next + R.xtx[col * P + col] : 1.0;
+  m.cb = 0.0; m.corner = 0.0; m.pdiag = 0.0;
+  int n = 0;
+  for (unsigned long long pending = S; pending != 0ull; pending &= pending - 1ull) {
+    const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+    double t, rd;
+    sweep_rec(m, k, lane, t, rd);
+    tb.tsw[n * 64 + lane] = t;
+    if (lane == 0) { tb.rdsw[n] = rd; tb.ksw[n] = k; }
+    ++n;
+    sync();
+  }
+  ps.n_sw = n;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ps.c[r] = m.c[r];
+  ps.diag = m.diag;
+  ps.S = S;
+  int nu = 0;
+  for (unsigned long long mm = S; mm != 0ull;) {
+    const int aidx = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mm));   // descending
+    mm &= ~(1ull << aidx);
+    const double vaa = -readlane_d(m.diag, aidx);
+    const double t = unsweep_q(m, aidx, lane);
+    tb.tun[nu * 64 + lane] = t;
+    if (lane == 0) { tb.vun[nu] = vaa; tb.kun[nu] = aidx; }
+    ++nu;
+    sync();
+  }
+  ps.n_un = nu;
+  ps.valid = 1;
+}
+
+// spike_slab_draw_regs with the matrix sweeps replayed from the precompute (same results).
+// `publish(new_scale)` is called as soon as sigma_obs is drawn -- before the weights.
+template <class PF, class Pub>
+__device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
+                                                      const DevSeriesParams& sp,
+                                                      double prev_obs_scale, double g_obs,
+                                                      int lane, PriorCarry& pc, const double* pre,
+                                                      const PreTables& tb, const PreState& ps,
+                                                      PF& prof, Pub publish) {
+  const double prev_var = prev_obs_scale * prev_obs_scale;
+  const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
+  const bool all_in = sp.nonzero_prob >= 1.0;
+  const int j = lane & 15, q = lane >> 4;
+  const bool live = j < P;
+  const int col = live ? j : 0;
+  QCols m;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m.c[r] = ps.c[r]; m.p[r] = pc.p[r]; }
+  m.diag = ps.diag;
+  m.pdiag = pc.pdiag;
+  m.cb = live ? R.bvec[col] : 0.0;
+  m.corner = R.bvec[P];
+  unsigned long long S = ps.S;
+  // ---- right-hand side: with V the matrix swept on S (precompute) and b = X~'targets,
+  //   b~_j = (j in S ? 0 : b_j) - sum_{k in S} V_kj b_k ,   corner = y'y - sum_{k in S} b_k b~_k
+  // (what carrying b through the recorded sweeps gives, as one matrix-vector product: lane
+  // (j, q) holds V_{4q+r, j}, r < 4; the four quadrants are added across the rows of 16 lanes)
+  {
+    double part = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * q + r;
+      const double bk = k < P ? R.bvec[k] : 0.0;
+      if ((S >> k) & 1ull) part = fma(m.c[r], bk, part);
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    const bool inj = ((S >> j) & 1ull) != 0ull;
+    const double bj = m.cb;
+    m.cb = live ? (inj ? 0.0 : bj) - part : 0.0;
+    double term = (live && inj) ? bj * m.cb : 0.0;      // (the same in every quadrant)
+    term += __shfl_xor(term, 1, 64); term += __shfl_xor(term, 2, 64);
+    term += __shfl_xor(term, 4, 64); term += __shfl_xor(term, 8, 64);
+    m.corner -= term;
+  }
+  prof.tick(21);
+  bool dirty = false;
+  if (!all_in) {
+    const int rank = reinterpret_cast<const int*>(pre + 16)[j];
+    const double uflip = pre[j];
+    const double logit_pi =
+        (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
+    int s_cur = 0;
+    const double inv_prev_var = fast_rcp(prev_var);
+    for (;;) {
+      const bool in = ((S >> j) & 1ull) != 0ull;
+      const double sg = in ? -1.0 : 1.0;
+      const double rap = fast_rcp(sg * m.diag);
+      const double beta_old = sp.obs_scale + 0.5 * m.corner;
+      const double x = -0.5 * sg * m.cb * m.cb * rap * fast_rcp(beta_old);
+      const double pscale = in ? inv_prev_var : prev_var;
+      const double delta = 0.5 * (double)__logf((float)(sg * m.pdiag * pscale * rap)) +
+                           sg * logit_pi - (a_post - 1.0) * fast_log1p(x);
+      const float prob = 1.0f / (1.0f + __expf(-(float)delta));
+      const bool acc = live && q == 0 && rank >= s_cur && uflip < (double)prob;
+      unsigned long long cand = __ballot(acc);
+      if (cand == 0ull) break;
+      int best = -1, best_rank = 1 << 20;
+      for (; cand != 0ull; cand &= cand - 1ull) {
+        const int jj = __ffsll((long long)cand) - 1;
+        const int rj = __builtin_amdgcn_readlane(rank, jj);
+        if (rj < best_rank) { best_rank = rj; best = jj; }
+      }
+      best = __builtin_amdgcn_readfirstlane(best);
+      sweep_q<true>(m, best, ((S >> best) & 1ull) != 0ull, lane);
+      S ^= 1ull << best;
+      s_cur = best_rank + 1;
+      dirty = true;
+    }
+  }
+  prof.tick(22);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pc.p[r] = m.p[r];
+  pc.pdiag = m.pdiag;
+  pc.S = S;
+  pc.valid = 1;
+  const double beta_post = sp.obs_scale + 0.5 * m.corner;
+  double var = beta_post * fast_rcp(g_obs);
+  if (var > sp.obs_ub) var = sp.obs_ub;
+  const double new_scale = (double)__fsqrt_rn((float)var);
+  publish(new_scale);
+  const float zf = reinterpret_cast<const float*>(pre + 24)[col];
+  const double mean = m.cb;
+  double mu = 0.0, umine = 0.0;
+  if (!dirty) {
+    // recorded un-sweeps (descending feature order): feature a ~ N(mu_a, V_aa), the rest
+    // conditioned on it.  The increments sqrt(V_aa) z_a do not depend on the running means, so
+    // the deviation of feature j is a plain sum over the steps -- its own increment plus
+    // t_s[j] times those of the features drawn before it -- with no chain from step to step.
+#pragma unroll 4
+    for (int s = 0; s < ps.n_un; ++s) {
+      const int aidx = __builtin_amdgcn_readfirstlane(tb.kun[s]);
+      const double t = tb.tun[s * 64 + lane];
+      const double za = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zf), aidx));
+      const double cs = (double)__fsqrt_rn((float)tb.vun[s]) * za;
+      umine += aidx > j ? t * cs : (aidx == j ? cs : 0.0);
+    }
+  } else {
+    for (unsigned long long mm = S; mm != 0ull;) {
+      const int aidx = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mm));
+      mm &= ~(1ull << aidx);
+      const double vaa = -readlane_d(m.diag, aidx);
+      const double mua = readlane_d(mu, aidx);
+      const double za = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zf), aidx));
+      const double ua = mua + (double)__fsqrt_rn((float)vaa) * za;
+      const double t = unsweep_q(m, aidx, lane);
+      if (j == aidx) umine = ua; else mu += t * (ua - mua);
+    }
+  }
+  if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(mean + new_scale * umine) : 0.f;
+  wave_sync();
+  prof.tick(23);
+  return new_scale;
+}
+
+// ---- LDS layout: every offset but the design's size is a compile-time constant (P <= 16 is
+// provisioned as 16), so LDS addresses are immediates instead of live scalar registers.
+template <int D, int L> struct Lay8 {
+  static constexpr size_t TP = (size_t)NT * L;
+  static constexpr size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
+  static constexpr size_t off_ctx = 0;
+  static constexpr size_t off_xtx = a16(sizeof(SerialCtx));
+  static constexpr size_t off_omega = off_xtx + 16 * 16 * sizeof(double);
+  static constexpr size_t off_bvec = off_omega + 16 * 16 * sizeof(double);
+  static constexpr size_t off_w = off_bvec + a16(20 * sizeof(double));
+  static constexpr size_t off_scal = off_w + 16 * sizeof(float);
+  static constexpr size_t off_red = off_scal + 32 * sizeof(float);
+  static constexpr size_t off_slots = off_red + 32 * sizeof(float);
+  static constexpr size_t off_xlast = off_slots + 3 * NW * 16 * sizeof(float);
+  static constexpr size_t off_gam = off_xlast + a16((size_t)NT * D * sizeof(float));
+  static constexpr size_t off_pre = off_gam + a16((8 + 64 + 4) * sizeof(double));
+  static constexpr size_t off_tgv = off_pre + a16(pre_tables_bytes());
+  static constexpr size_t off_z = off_tgv + TP * sizeof(float);          // zl, zs, zo, zp
+  static constexpr size_t off_x = off_z + 4 * TP * sizeof(float);
+  static __host__ __device__ constexpr size_t total(int P) { return off_x + (size_t)P * TP * sizeof(float); }
+};
+// indices into `scal` beyond enum Scal: prior moments, then the x_0 normals of even / odd iterations
+enum Scal8 { SC8_INIT_LOC = 8, SC8_INIT_VAR = 9, SC8_INIT_SVAR = 10, SC8_ZINIT = 12 };
+
+// Profile slots of the instrumented build (ci_session_profile; 32 int64):
+//   time thread 0:      0 = targets .. (B2)   2 = window work   1 = wait at (Bs)   24 = matrix chunk +
+//                       in-wave scan   25 = wait (B3) + cross-wave + local   3 = X w + prior path
+//                       27 = forward chunk + in-wave scan   5 = (B4) + finish   6 = local means +
+//                       adjoint in-wave scan   28 = (B5) + finish   7 = fix-up
+//   regression lane 0:  16 = until (B2) done   20 = gather   21 = rhs   22 = flips + sigma^2
+//                       18 = wait at (Bs)   23 = weights + scale draws   17 = wait at (B3)
+//                       19 = precompute steps (pure)   29 = its waits at (B4) (B5)
+//   randomness wave 5:  30 = work   31 = waits at barriers
+template <int D, int L, bool PROF = false>
+__global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
+  using PF = typename std::conditional<PROF, Prof, NoProf>::type;
+  using LY = Lay8<D, L>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int series = blockIdx.x / a.C, chain = blockIdx.x % a.C;
+  const int T = a.T, P = a.P;
+  constexpr int TPAD = NT * L;
+  SerialCtx* cx = (SerialCtx*)(smem + LY::off_ctx);
+  float* scal = (float*)(smem + LY::off_scal);
+  float* red = (float*)(smem + LY::off_red);
+  float* slots = (float*)(smem + LY::off_slots);
+  float* xlast = (float*)(smem + LY::off_xlast);
+  float* wls = (float*)(smem + LY::off_w);
+  float* tgv = (float*)(smem + LY::off_tgv);
+  float* zb = (float*)(smem + LY::off_z);
+  double* gam = (double*)(smem + LY::off_gam);
+  const float* Xs = (const float*)(smem + LY::off_x);
+  const size_t chain_lin = (size_t)series * a.C + chain;
+  const int n_iter = a.W + a.S;
+
+  Rng rng;
+  rng.k0 = a.seed0;
+  rng.k1 = a.seed1;
+  rng.chain = stream_id(a.chain_offset + chain, a.series_stream_base, series);
+
+  const float* yg = a.y + (size_t)series * T;
+  const uint8_t* mg = a.mask + (size_t)series * T;
+  const float* Xg = a.Xt + (size_t)series * P * T;
+  RegLds R;
+  R.xtx = (double*)(smem + LY::off_xtx);
+  R.omega = (double*)(smem + LY::off_omega);
+  R.aug[0] = R.aug[1] = R.pri[0] = R.pri[1] = R.chol = R.zv = R.uperm = nullptr;   // (LDS block: unused)
+  R.nz = R.perm = R.idx = nullptr;
+  R.bvec = (double*)(smem + LY::off_bvec);
+  R.w = wls;
+  if (tid == 0) {
+    cx->sp = a.sp[series];
+    cx->obs_scale = cx->sp.obs_scale0;           // causalimpact_lib.py:566-572
+    cx->level_scale = cx->sp.level_scale0;
+    cx->slope_scale = cx->sp.slope_scale0;
+    cx->R = R;
+    cx->scal = scal;
+    cx->red = red;
+    cx->out_obs = a.out_obs;
+    cx->out_level_scale = a.out_level_scale;
+    cx->out_slope_scale = a.out_slope_scale;
+    cx->out_weights = a.out_weights;
+    cx->chain_lin = chain_lin;
+    cx->rng = rng;
+    cx->P = P; cx->T = T; cx->D = D; cx->W = a.W; cx->S = a.S; cx->n_iter = n_iter;
+    cx->prof = nullptr;
+    scal[SC_OBS_DK] = (float)cx->sp.obs_scale0;
+    scal[SC8_INIT_LOC] = (float)cx->sp.init_level_loc;
+    scal[SC8_INIT_VAR] = (float)(cx->sp.init_level_scale * cx->sp.init_level_scale);
+    scal[SC8_INIT_SVAR] = (float)(cx->sp.init_slope_scale * cx->sp.init_slope_scale);
+  }
+  {
+    for (int e = tid; e < P * P; e += NT8) {
+      R.xtx[e] = a.xtx[(size_t)series * P * P + e];
+      R.omega[e] = a.omega[(size_t)series * P * P + e];
+    }
+    float* xw_ = (float*)(smem + LY::off_x);
+    for (int j = 0; j < P; ++j)
+      for (int t = tid; t < TPAD; t += NT8) xw_[j * TPAD + t] = (t < T) ? Xg[(size_t)j * T + t] : 0.f;
+    if (tid < 16) wls[tid] = 0.f;                   // weights = 0            :575-578
+  }
+  __syncthreads();
+  PreTables tb;
+  {
+    double* d = (double*)(smem + LY::off_pre);
+    tb.tsw = d; d += PRE_MAXS * 64;
+    tb.tun = d; d += PRE_MAXS * 64;
+    tb.rdsw = d; d += PRE_MAXS;
+    tb.vun = d; d += PRE_MAXS;
+    tb.ksw = (int*)d;
+    tb.kun = tb.ksw + PRE_MAXS;
+  }
+
+  if (wave > NW) {
+    // ================================ randomness waves =========================================
+    // Everything random the other waves consume, one iteration ahead, into LDS:
+    //   zb[0..3][TPAD]  level / slope / observation disturbances of the draw of iteration `it`
+    //                   and the predictive normals of the draw of `it - 1`, chunk c (= Philox call
+    //                   c: 4 normals) at floats 4c .. 4c + 3;
+    //   gam / pre       gamma variates (wave 5) and the regression block's permutation ranks,
+    //                   flip uniforms and weight normals (wave 6), double-buffered by parity;
+    //   scal[SC8_ZINIT] the x_0 normals (wave 7), double-buffered by parity.
+    const int e = wave - NW - 1;                       // 0, 1, 2
+    constexpr int NTASK = (D == 2) ? 4 : 3;            // zl, [zs,] zo, zp
+    constexpr int ROUNDS = NTASK * L;                  // wave-rounds of 64 chunks
+    PF eprof;
+    eprof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && wave == NW + 1 && lane == 0);
+    auto normals_round = [&](int k, uint32_t it_draw) {
+      // task-major: all chunks of a kind, then the next kind
+      const int task = k / L, blk = k - task * L;
+      const int slot = (D == 2) ? task : (task == 0 ? 0 : task + 1);     // D = 1 has no slope row
+      const uint32_t site = slot == 0 ? SITE_PRIOR_LEVEL
+                            : (slot == 1 ? SITE_PRIOR_SLOPE : (slot == 2 ? SITE_PRIOR_OBS : SITE_PRED));
+      // the predictive normals belong to the draw that is being made now, the disturbances to
+      // the next one
+      const uint32_t iter = slot == 3 ? it_draw : it_draw + 1u;
+      const int c = 64 * blk + lane;
+      const U4 r = site_call(rng, iter, site, 0, (uint32_t)c);
+      float z[4];
+      normals4(r, z);
+      *reinterpret_cast<float4*>(zb + (size_t)slot * TPAD + 4 * c) = make_float4(z[0], z[1], z[2], z[3]);
+    };
+    auto role_work = [&](int it_next) {
+      if (it_next > n_iter) return;
+      if (e == 0) {
+        serial_gammas<1>(cx, it_next, lane, gam + 4 * (it_next & 1));
+      } else if (e == 1) {
+        if (it_next < n_iter) spike_slab_randoms(rng, (uint32_t)it_next, P, lane, gam + 8 + 32 * (it_next & 1));
+      } else if (lane < D && it_next < n_iter) {
+        float zi[1];
+        fill_normals<1>(rng, (uint32_t)it_next, SITE_PRIOR_INIT, 0, (uint32_t)lane, zi);
+        scal[SC8_ZINIT + 2 * (it_next & 1) + lane] = zi[0];
+      }
+    };
+    // iteration 0's randomness (the disturbances of draw 0: it_draw = -1 + 1; no predictive row yet)
+    role_work(0);
+    for (int k = e; k < ROUNDS; k += 3)
+      if (k / L != NTASK - 1) normals_round(k, 0xFFFFFFFFu);
+    eprof.tick(30);
+    for (int it = 0; it <= n_iter; ++it) {
+      __syncthreads();                                   // (B1)
+      eprof.tick(31);
+      xt_sums_wave<L, 2>(tgv, Xs, TPAD, P, 2 * wave, wave == NW8 - 1, red, lane);
+      eprof.tick(30);
+      __syncthreads();                                   // (B2)
+      eprof.tick(31);
+      role_work(it + 1);
+      eprof.tick(30);
+      __syncthreads();                                   // (Bs)
+      eprof.tick(31);
+      if (it == n_iter) {
+        __syncthreads();                                 // (B3)
+        break;
+      }
+      // the normals of iteration it + 1 (and the predictive normals of draw it), with the three
+      // barriers of the draw placed after about 1/3, 2/3 and 5/6 of this wave's rounds
+      const int n_my = (ROUNDS - e + 2) / 3;
+      const int m3 = (n_my + 2) / 3, m4 = (2 * n_my + 2) / 3, m5 = (5 * n_my + 5) / 6;
+      int done = 0, r = 0;
+      auto sync_to = [&](int upto) {
+        while (done < upto) {
+          eprof.tick(30);
+          __syncthreads();
+          eprof.tick(31);
+          ++done;
+        }
+      };
+      for (int k = e; k < ROUNDS; k += 3, ++r) {
+        if (r == m3) sync_to(1);
+        if (r == m4) sync_to(2);
+        if (r == m5) sync_to(3);
+        normals_round(k, (uint32_t)it);
+      }
+      sync_to(3);                                        // (B3) (B4) (B5) all passed
+      eprof.tick(30);
+    }
+    return;
+  }
+
+  if (wave == NW) {
+    // ================================ regression wave ==========================================
+    PriorCarry pc;
+    pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
+    PreState ps;
+    ps.valid = 0; ps.S = 0ull; ps.n_sw = 0; ps.n_un = 0; ps.diag = 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps.c[r] = 0.0;
+    PF rprof;
+    rprof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && lane == 0);
+    double obs_scale = cx->sp.obs_scale0, level_scale = cx->sp.level_scale0, slope_scale = cx->sp.slope_scale0;
+    const DevSeriesParams sp = cx->sp;
+    float* o_obs = a.out_obs;
+    float* o_ls = a.out_level_scale;
+    float* o_ss = a.out_slope_scale;
+    float* o_w = a.out_weights;
+    for (int it = 0; it <= n_iter; ++it) {
+      __syncthreads();                                   // (B1) targets in LDS
+      xt_sums_wave<L, 2>(tgv, Xs, TPAD, P, 2 * wave, false, red, lane);
+      __syncthreads();                                   // (B2) all sums complete
+      rprof.tick(16);
+      // the serial section is the critical path of the iteration and shares its SIMD with time
+      // wave 0, which has slack until (Bs): win the issue arbitration while it lasts
+      __builtin_amdgcn_s_setprio(3);
+      if (lane < P + 1) R.bvec[lane] = (double)red[lane < P ? lane : RED_YTY];
+      const float wprev = lane < P ? wls[lane] : 0.f;    // the previous draw's weights (stored below)
+      const double* gm = gam + 4 * (it & 1);
+      const double g_level = gm[0], g_slope = gm[1], g_obs = gm[2];
+      const double emit_obs = obs_scale;
+      wave_sync();
+      rprof.tick(20);
+      auto publish = [&](double ns) {
+        if (lane == 0) scal[SC_OBS_DK] = (float)ns;
+        rprof.tick(22);
+        __syncthreads();                                 // (Bs) sigma^2_obs(it) published
+        rprof.tick(18);
+      };
+      if (it < n_iter) {
+        if (ps.valid && ps.S == pc.S) {
+          obs_scale = spike_slab_draw_pre(R, P, sp, obs_scale, g_obs, lane, pc, gam + 8 + 32 * (it & 1), tb,
+                                          ps, rprof, publish);
+        } else {
+          NoProf np;
+          obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, np, pc,
+                                           gam + 8 + 32 * (it & 1), publish);
+        }
+      } else {
+        publish(obs_scale);
+      }
+      // level / slope scales of iteration it - 1 (the time waves formed the same values for their
+      // draw already) and its scalar outputs
+      if (it > 0) {
+        auto clipped_scale = [](double scale, double ss, double g, double ub) {
+          const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
+          return s < ub ? s : ub;
+        };
+        double ssl = 0.0, sss = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          ssl += (double)red[RED_INC + 2 * w];
+          sss += (double)red[RED_INC + 2 * w + 1];
+        }
+        level_scale = clipped_scale(sp.level_scale, ssl, g_level, sp.level_ub);
+        if (D == 2) slope_scale = clipped_scale(sp.slope_scale, sss, g_slope, sp.slope_ub);
+        const int s = it - 1 - a.W;
+        if (s >= 0) {
+          const size_t o = chain_lin * a.S + s;
+          if (lane == 0) {
+            if (o_obs) o_obs[o] = (float)emit_obs;
+            if (o_ls) o_ls[o] = (float)level_scale;
+            if (o_ss) o_ss[o] = (float)(D == 2 ? slope_scale : 0.0);
+          }
+          if (o_w && lane < P) o_w[o * P + lane] = wprev;
+        }
+      }
+      rprof.tick(23);
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();                                   // (B3) weights of iteration `it` published
+      rprof.tick(17);
+      if (it == n_iter) break;
+      // the time waves now finish the draw ((B4) (B5)); meanwhile: next iteration's matrix work
+      int done = 0, step = 0;
+      const int n_steps = 2 * __popcll(pc.S);
+      const int mark4 = (n_steps * 9 + 10) / 20 > 0 ? (n_steps * 9 + 10) / 20 : 1;     // ~ 45 %
+      const int mark5 = (n_steps * 7 + 5) / 10 > mark4 ? (n_steps * 7 + 5) / 10 : mark4 + 1;   // ~ 70 %
+      auto sync = [&]() {
+        ++step;
+        for (;;) {
+          const int mark = done == 0 ? mark4 : mark5;
+          if (done >= 2 || step < mark) break;
+          rprof.tick(19);
+          __syncthreads();
+          rprof.tick(29);
+          ++done;
+        }
+      };
+      regression_precompute(R, P, obs_scale * obs_scale, pc.S, lane, tb, ps, sync);
+      rprof.tick(19);
+      while (done < 2) { __syncthreads(); ++done; }
+      rprof.tick(29);
+    }
+    return;
+  }
+
+  // ==================================== time waves =============================================
+  // above the regression wave's precompute and the randomness waves (priority 0), below the
+  // serial section (3)
+  __builtin_amdgcn_s_setprio(1);
+  const int t0 = tid * L;
+  float yv[L];
+  uint32_t maskbits = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    const bool in = t < T;
+    yv[l] = in ? yg[t] : 0.f;
+    const bool m = in ? (mg[t] != 0) : true;
+    if (m) { maskbits |= (1u << l); yv[l] = 0.f; }
+  }
+  const float init_loc = scal[SC8_INIT_LOC], init_var = scal[SC8_INIT_VAR], init_svar = scal[SC8_INIT_SVAR];
+  const DevSeriesParams* spp = &cx->sp;
+  const double sp_level_scale0 = spp->level_scale0, sp_slope_scale0 = spp->slope_scale0;
+  const double sp_level_scale = spp->level_scale, sp_slope_scale = spp->slope_scale;
+  const double sp_level_ub = spp->level_ub, sp_slope_ub = spp->slope_ub;
+  float lev[L], slp[L], xw[L], pm_acc[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { lev[l] = 0.f; slp[l] = 0.f; xw[l] = 0.f; pm_acc[l] = 0.f; }  // :580-581
+  float* o_level = a.out_level ? a.out_level + chain_lin * a.S * T : nullptr;
+  float* o_slope = a.out_slope ? a.out_slope + chain_lin * a.S * T : nullptr;
+  float* o_traj = a.out_traj ? a.out_traj + chain_lin * a.S * T : nullptr;
+  PF prof;
+  prof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && tid == 0);
+  for (int it = 0; it <= n_iter; ++it) {
+    // ---- targets (they use the CURRENT level) to LDS; the last owned state for the neighbour
+    {
+      float tg[L];
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const bool obs = ((maskbits >> l) & 1u) == 0u;
+        tg[l] = obs ? (yv[l] - lev[l]) : 0.f;
+      }
+      store_targets<L>(tgv, t0, tg);
+      xlast[tid * D] = lev[L - 1];
+      if constexpr (D == 2) xlast[tid * D + 1] = slp[L - 1];
+    }
+    __syncthreads();                                       // (B1)
+    xt_sums_wave<L, 2>(tgv, Xs, TPAD, P, 2 * wave, false, red, lane);
+    {
+      float ssl = 0.f, sss = 0.f;
+      float pl = (tid > 0) ? xlast[(tid - 1) * D] : 0.f;
+      float ps_ = 0.f;
+      if constexpr (D == 2) ps_ = (tid > 0) ? xlast[(tid - 1) * D + 1] : 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const int t = t0 + l;
+        if (t >= 1 && t < T) {
+          float dl = lev[l] - pl;
+          if constexpr (D == 2) {
+            dl -= ps_;
+            const float ds = slp[l] - ps_;
+            sss = fmaf(ds, ds, sss);
+          }
+          ssl = fmaf(dl, dl, ssl);
+        }
+        pl = lev[l];
+        if constexpr (D == 2) ps_ = slp[l];
+      }
+      const float s1 = wave_prefix_dpp(ssl), s2 = wave_prefix_dpp(sss);
+      if (lane == 63) {
+        red[RED_INC + 2 * wave] = s1;
+        red[RED_INC + 2 * wave + 1] = s2;
+      }
+    }
+    // sigma_obs of iteration it-1's regression draw: the noise scale of its predictive trajectory
+    // (read before the regression wave publishes this iteration's, which happens after (B2))
+    const float so_prev = scal[SC_OBS_DK];
+    __syncthreads();                                       // (B2)
+    prof.tick(0);
+
+    // ---- window: the normals of this iteration from LDS, emission of draw it-1, this iteration's
+    // disturbance scales, first half of the prior-simulation scan
+    float zl[L], zs[L], zo[L];
+    lds_row_load<L>(zb + t0, zl);
+    if constexpr (D == 2) {
+      lds_row_load<L>(zb + TPAD + t0, zs);
+    } else {
+#pragma unroll
+      for (int l = 0; l < L; ++l) zs[l] = 0.f;
+    }
+    lds_row_load<L>(zb + 2 * TPAD + t0, zo);
+    if (it > a.W) {
+      const int s = it - 1 - a.W;
+      float zp[L];
+      lds_row_load<L>(zb + 3 * TPAD + t0, zp);
+      float tr[L];
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const float loc = lev[l] + xw[l];
+        pm_acc[l] += loc;
+        tr[l] = fmaf(so_prev, zp[l], loc);
+      }
+      const size_t row = (size_t)s * T;
+      bool vec_done = false;
+      if constexpr (L % 4 == 0) {
+        if ((T & 3) == 0) {
+          vec_done = true;
+#pragma unroll
+          for (int q = 0; q < L / 4; ++q) {
+            const int t = t0 + 4 * q;
+            if (t < T) {
+              if (o_level) *(float4*)(o_level + row + t) = make_float4(lev[4 * q], lev[4 * q + 1], lev[4 * q + 2], lev[4 * q + 3]);
+              if (o_slope) *(float4*)(o_slope + row + t) = make_float4(slp[4 * q], slp[4 * q + 1], slp[4 * q + 2], slp[4 * q + 3]);
+              if (o_traj) *(float4*)(o_traj + row + t) = make_float4(tr[4 * q], tr[4 * q + 1], tr[4 * q + 2], tr[4 * q + 3]);
+            }
+          }
+        }
+      }
+      if (!vec_done) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const int t = t0 + l;
+          if (t < T) {
+            if (o_level) o_level[row + t] = lev[l];
+            if (o_slope) o_slope[row + t] = slp[l];
+            if (o_traj) o_traj[row + t] = tr[l];
+          }
+        }
+      }
+    }
+    // The level / slope disturbance scales of this iteration -- the draw the regression wave makes
+    // too (same expression, same inputs: the increments' sums in `red`, complete since (B2), and
+    // the gamma variates of the randomness wave)
+    Vec<D> sig;
+    PElem<D> pincl = pelem_identity<D>();
+    {
+      auto clipped_scale = [](double scale, double ss, double g, double ub) {
+        const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
+        return s < ub ? s : ub;
+      };
+      double level_scale = sp_level_scale0, slope_scale = sp_slope_scale0;
+      if (it > 0) {
+        const double* gm = gam + 4 * (it & 1);
+        double ssl = 0.0, sss = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          ssl += (double)red[RED_INC + 2 * w];
+          sss += (double)red[RED_INC + 2 * w + 1];
+        }
+        level_scale = clipped_scale(sp_level_scale, ssl, gm[0], sp_level_ub);
+        if constexpr (D == 2) slope_scale = clipped_scale(sp_slope_scale, sss, gm[1], sp_slope_ub);
+      }
+      sig.v[0] = (float)level_scale;
+      if constexpr (D == 2) sig.v[1] = (float)slope_scale;
+      if (it < n_iter) pincl = dk_prior_begin<D, L>(sig, zl, zs, slots, lane, wave);
+    }
+    const bool publish = a.progress != nullptr && it > a.W &&
+                         ((it - a.W) % a.progress_every == 0 || it - a.W == a.S);
+    if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows are in L2
+    prof.tick(2);
+    __syncthreads();                                       // (Bs) sigma^2_obs(it) in LDS
+    prof.tick(1);
+    if (publish) {
+      // the time waves' stores of the first `done` rows were issued before (Bs); make them visible
+      // to the copy engines and publish (the scalars / weights of these draws are copied after
+      // the kernel has ended)
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.progress + chain_lin, (unsigned int)(it - a.W), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    if (it == n_iter) {
+      __syncthreads();                                     // (B3)
+      break;
+    }
+
+    // ---- matrix phase of the draw of iteration it: needs sigma^2_obs, not the weights
+    DkModel<D> md;
+    {
+      const float so = scal[SC_OBS_DK];
+      md.H = so * so;
+      md.sig = sig;
+      md.a1 = vzero<D>();
+      md.a1.v[0] = init_loc;
+      md.p1.v[0] = init_var;
+      if constexpr (D == 2) md.p1.v[1] = init_svar;
+    }
+    Vec<D> q;
+#pragma unroll
+    for (int i = 0; i < D; ++i) q.v[i] = md.sig.v[i] * md.sig.v[i];
+    const PElem<D> ppre = dk_prior_finish<D>(pincl, slots, lane, wave);   // ((Bs) was its barrier)
+    const FMElem<D> fme = dk_matrix_chunk<D, L>(md, q, maskbits, tid);
+    const FMElem<D> mincl = dk_matrix_scan_begin<D>(fme, slots + NW * 16, lane, wave);
+    prof.tick(24);
+    __syncthreads();                                       // (B3) weights(it) in LDS; matrix scan
+    float Pin[D * (D + 1) / 2];
+    dk_matrix_scan_finish<D>(mincl, slots + NW * 16, lane, wave, Pin);
+    DkMats<D, L> km;
+    dk_matrix_local<D, L>(md, q, maskbits, tid, Pin, km);
+    prof.tick(25);
+
+    // ---- residual, data phase
+    float resid[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) xw[l] = 0.f;
+    {
+      float wv[16];
+      lds_row_load<16>(wls, wv);           // the weights vector is padded to 16 floats
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int jj = j < P ? j : P - 1;
+        const float wj = j < P ? wv[j] : 0.f;
+        float xr[L];
+        lds_row_load<L>(Xs + jj * TPAD + t0, xr);
+#pragma unroll
+        for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) resid[l] = yv[l] - xw[l];
+    const Vec<D> a1e = dk_initial_mean<D>(md, rng, (uint32_t)it, tid, scal + SC8_ZINIT + 2 * (it & 1));
+    Vec<D> xp[L];
+    float ytil[L];
+    dk_prior_path<D, L>(md, ppre, resid, zl, zs, zo, xp, ytil);
+    prof.tick(3);
+    const AElem<D> fe = dk_fwd_chunk<D, L>(km, a1e, ytil, maskbits, tid);
+    const AElem<D> fincl = aff_fwd_begin<D>(fe, slots, lane, wave);
+    prof.tick(27);
+    __syncthreads();                                       // (B4)
+    const Vec<D> mf = aff_fwd_finish<D>(fincl, slots, lane, wave);
+    prof.tick(5);
+    Vec<D> ap[L];
+    float vf[L];
+    const AElem<D> be = dk_fwd_local_bwd_chunk<D, L>(km, a1e, ytil, maskbits, tid, mf, ap, vf);
+    const AElem<D> bincl = aff_bwd_begin<D>(be, slots + 2 * NW * 16, lane, wave);
+    prof.tick(6);
+    __syncthreads();                                       // (B5)
+    const Vec<D> rr = aff_bwd_finish<D>(bincl, slots + 2 * NW * 16, lane, wave);
+    prof.tick(28);
+    Vec<D> x[L];
+    dk_bwd_fixup<D, L>(km, rr, ap, vf, xp, x);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      lev[l] = x[l].v[0];
+      if constexpr (D == 2) slp[l] = x[l].v[1];
+    }
+    prof.tick(7);
+  }
+
+  if (a.out_pred_mean) {
+    const float inv = 1.0f / (float)(a.S > 0 ? a.S : 1);
+    float* pm = a.out_pred_mean + chain_lin * T;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int t = t0 + l;
+      if (t < T) pm[t] = pm_acc[l] * inv;
+    }
+  }
+}
+
+}  // namespace ci

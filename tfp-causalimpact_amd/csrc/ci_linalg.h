@@ -377,6 +377,125 @@ __device__ __forceinline__ FElemS<D> felems_combine(const FElemS<D>& e1, const F
   return r;
 }
 
+
+// ---- the MATRIX part (A, C, J) of the filtering element on its own.  The combine of
+// (A, b, C, eta, J) never feeds (b, eta) back into (A, C, J): the matrix part is closed under
+// composition and depends on the model's variances and the missing-data pattern only -- not on
+// the data.  The Gibbs kernels exploit that twice: the covariance side of the Kalman filter
+// (P_t, gains, 1/F_t) is scanned as soon as sigma^2_obs is known, while the regression weights
+// -- hence the data of the filter -- are still being drawn; and the data side shrinks to two
+// scans of affine maps of the MEAN (forward: filtered means, backward: the smoothing adjoint)
+// whose matrices come out of the matrix pass.
+template <int D> struct FMElem {
+  Mat<D> A;
+  float C[D * (D + 1) / 2];
+  float J[D * (D + 1) / 2];
+};
+template <int D> __device__ __forceinline__ FMElem<D> fmelem_identity() {
+  FMElem<D> r;
+  r.A = meye<D>();
+#pragma unroll
+  for (int i = 0; i < D * (D + 1) / 2; ++i) { r.C[i] = 0.f; r.J[i] = 0.f; }
+  return r;
+}
+// e1 covers the earlier steps, e2 the later ones (felems_combine without its vector parts).
+template <int D>
+__device__ __forceinline__ FMElem<D> fmelem_combine(const FMElem<D>& e1, const FMElem<D>& e2) {
+  Mat<D> W, RA = e1.A, RC;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = (i == j) ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fmaf(e1.C[symidx<D>(i, k)], e2.J[symidx<D>(k, j)], s);
+      W.m[i][j] = s;
+      RC.m[i][j] = e1.C[symidx<D>(i, j)];
+    }
+  }
+  Mat<D> T2;                                         // J2 A1
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float sj = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) sj = fmaf(e2.J[symidx<D>(i, k)], e1.A.m[k][j], sj);
+      T2.m[i][j] = sj;
+    }
+  }
+  // W^-1 [A1 | C1] by unpivoted Gauss-Jordan (W = I + C1 J2, C1 and J2 positive semi-definite:
+  // eigenvalues >= 1)
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    const float rp = __builtin_amdgcn_rcpf(W.m[c][c]);
+#pragma unroll
+    for (int j = c + 1; j < D; ++j) W.m[c][j] *= rp;
+#pragma unroll
+    for (int j = 0; j < D; ++j) { RA.m[c][j] *= rp; RC.m[c][j] *= rp; }
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      if (r == c) continue;
+      const float f = W.m[r][c];
+#pragma unroll
+      for (int j = c + 1; j < D; ++j) W.m[r][j] = fmaf(-f, W.m[c][j], W.m[r][j]);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        RA.m[r][j] = fmaf(-f, RA.m[c][j], RA.m[r][j]);
+        RC.m[r][j] = fmaf(-f, RC.m[c][j], RC.m[r][j]);
+      }
+    }
+  }
+  FMElem<D> r;
+  r.A = mm(e2.A, RA);
+  {
+    const Mat<D> T1 = mm(e2.A, RC);                 // A2 W^-1 C1
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) {
+        float s = e2.C[symidx<D>(i, j)];
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = fmaf(T1.m[i][k], e2.A.m[j][k], s);
+        r.C[symidx<D>(i, j)] = s;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      float t = e1.J[symidx<D>(i, j)];
+#pragma unroll
+      for (int k = 0; k < D; ++k) t = fmaf(RA.m[k][i], T2.m[k][j], t);
+      r.J[symidx<D>(i, j)] = t;
+    }
+  return r;
+}
+
+// T M and M T' for the trend transition (D = 1: identity)
+template <int D> __device__ __forceinline__ Mat<D> trans_left(const Mat<D>& m) {
+  Mat<D> r = m;
+  if constexpr (D == 2) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) r.m[0][j] = m.m[0][j] + m.m[1][j];
+  }
+  return r;
+}
+template <int D> __device__ __forceinline__ Mat<D> trans_right_t(const Mat<D>& m) {
+  Mat<D> r = m;
+  if constexpr (D == 2) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) r.m[i][0] = m.m[i][0] + m.m[i][1];
+  }
+  return r;
+}
+// T' r
+template <int D> __device__ __forceinline__ Vec<D> trans_t_apply(const Vec<D>& r) {
+  Vec<D> u = r;
+  if constexpr (D == 2) u.v[1] = r.v[0] + r.v[1];
+  return u;
+}
+
 // Affine map r_out = M r_in + c (backward smoothing recursion).
 template <int D> struct AElem {
   Mat<D> M;

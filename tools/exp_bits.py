@@ -1,4 +1,4 @@
-"""Experiment: are gibbs_kernel5 and gibbs_kernel<.,.,1> bit-identical? (prints per shape)"""
+"""Experiment: are gibbs_kernel8 and gibbs_kernel<.,.,1> bit-identical? (prints per shape)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tfp-causalimpact_amd")]

@@ -407,6 +407,31 @@ def test_eight_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, 
     assert (incl[:, :, 1:] != incl[:, :, :-1]).any()
 
 
+@pytest.mark.parametrize("T,p,has_slope", [(1000, 10, 1), (500, 5, 0), (180, 2, 1)])
+def test_eight_wave_kernel_does_not_depend_on_the_schedule_of_its_helper_waves(T, p, has_slope, monkeypatch):
+  """The regression wave's precompute and the randomness waves' rounds are background work placed
+  between the workgroup barriers by a schedule word (csrc/ci_kernels8.h SCHED_DEFAULT).  Whatever
+  the schedule -- everything as early as possible ($CI_DBG=1), everything after the last barrier
+  (2), or other quotas -- every output of every draw must be bit-identical: a difference would mean
+  a buffer is read before it is complete or overwritten while still in use."""
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 11)
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope))
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=has_slope, num_warmup=10, num_results=150,
+                            num_chains=2, seed=(8, 1))
+  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  assert "gibbs_kernel8" in sess.kernel_name()
+  out = {}
+  for word in ("0", "1", "2", str((3 << 4) | (3 << 6) | (1 << 8) | (3 << 10) | (1 << 12) | (1 << 14)),
+               str((0 << 4) | (0 << 6) | (3 << 8) | (0 << 10) | (3 << 12) | (0 << 14))):
+    monkeypatch.setenv("CI_DBG", word)
+    sess.run()
+    out[word] = sess.fetch()
+  sess.close()
+  for word, got in out.items():
+    for k, v in out["0"].items():
+      np.testing.assert_array_equal(got[k], v, err_msg=f"schedule {word}: {k}")
+
+
 def test_a_batch_split_over_launches_of_any_size_gives_the_bits_of_one_launch():
   """identical outputs regardless of the number of GPUs.  512 series in ONE
   launch (more workgroups than CUs: the four-wavefront throughput build) against the same batch as

@@ -832,6 +832,7 @@ static int session_launch(ci_session* s) {
   a.prof = nullptr;
   a.progress = s->progress_every > 0 ? s->progress : nullptr;
   a.progress_every = s->progress_every > 0 ? s->progress_every : 1;
+  { const char* e_ = getenv("CI_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
   if (s->profile) {
     if (!s->prof.p) HIP_TRY(s->prof.alloc(32));
     HIP_TRY(hipMemsetAsync(s->prof.p, 0, 32 * sizeof(long long), s->stream));

@@ -73,6 +73,9 @@ struct KArgs {
   // draws of its chain in progress[series * C + chain] (host-coherent pinned memory).
   unsigned int* progress;
   int progress_every;
+  int dbg;                 // $CI_DBG: replaces the eight-wave kernel's helper-wave schedule word
+                           // (ci_kernels8.h SCHED_DEFAULT) -- timing experiments and the
+                           // timing-independence test; 0 in production
 };
 
 // Counter word 3 of the Philox stream: the global chain id in the low 16 bits' range, the global
@@ -2576,10 +2579,15 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
           }
         }
       }
-      if (wave == 2 && it < n_iter && lane < D) {     // x+_0 normals of thread 0
+      if (wave == 2 && it < n_iter) {     // x+_0 normals of thread 0
+        // evaluated by ALL lanes (elements 0 .. 63 of the site), stored by the first D: evaluated
+        // under a one-lane mask the compiler moves the whole computation to the scalar unit's
+        // registers, and that build of the same source was seen to differ by one ulp from the
+        // vector build (round 4) -- values that must agree between kernels stay vector code
         float zi[1];
         fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)lane, zi);
-        nz0[4 * L * 64 + lane] = zi[0];
+        asm volatile("" : "+v"(zi[0]));      // (keeps the evaluation out of the one-lane block below)
+        if (lane < D) nz0[4 * L * 64 + lane] = zi[0];
       }
       if (it < n_iter) {
         dk_normals<D, L>(rng, (uint32_t)it, tid, zl, zs, zo);

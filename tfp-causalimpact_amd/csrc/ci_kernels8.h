@@ -11,10 +11,11 @@
 //   wave 4     REGRESSION wave: owns the serial section (sigma^2_obs, weights) and, during the
 //              draw, already sweeps the NEXT iteration's posterior block (record / replay, as in
 //              rounds 2-3);
-//   waves 5-7  RANDOMNESS waves: every normal the time waves consume (3 L per thread for the
-//              draw, L for the predictive trajectory), the gamma variates and the regression
-//              block's permutation / uniforms, one iteration ahead, through LDS.  Philox + Box-Muller
-//              were 40 % of what the time waves executed between two barriers.
+//   waves 5-7  RANDOMNESS waves: the 3 L normals per time thread of the Durbin-Koopman draw, the
+//              gamma variates and the regression block's permutation / uniforms, one iteration
+//              ahead, through LDS (the L predictive normals stay with the time waves: they have
+//              idle time while sigma^2_obs is drawn).  Philox + Box-Muller were 40 % of what the
+//              time waves executed between two barriers.
 //
 // One Gibbs iteration, barriers (B1) ... (B5) + (Bs) shared by all eight waves:
 //
@@ -46,31 +47,69 @@
 
 namespace ci {
 
+// Schedule of the helper waves (see "scheduling of the helper waves" below), one word so that
+// $CI_DBG can replace it for experiments without a rebuild:
+//   bits 0-1   test mode: 1 = all background work as early as possible, 2 = as late as possible
+//   bits 4-5   regression wave: sweeps before (B3)        bits 6-7   ... between (B3) and (B4)
+//   bits 8-9   ... left for after (B5)
+//   bits 10-11 randomness waves 5, 6: rounds before (B3)   bits 12-13 all: rounds between (B3), (B4)
+//   bits 14-15 rounds left for after (B5)
+constexpr int SCHED_DEFAULT = (2 << 4) | (1 << 6) | (0 << 8) | (2 << 10) | (2 << 12) | (0 << 14);   // tools/exp_sched.py, cfg2
 constexpr int NT8 = 512;              // 4 time waves + regression wave + 3 randomness waves
 constexpr int NW8 = 8;
 constexpr int PRE_MAXS = 16;          // recorded sweeps / un-sweeps (P <= 16)
 
 // LDS tables written by the regression wave's precompute, read by its next serial section.
 struct PreTables {
-  double* tsw;      // [PRE_MAXS][64]  sweep s: t_j of lane j (1 at the pivot)
-  double* tun;      // [PRE_MAXS][64]  un-sweep s: t_j
-  double* rdsw;     // [PRE_MAXS]      sweep s: 1 / pivot
-  double* vun;      // [PRE_MAXS]      un-sweep s: V_aa
-  int* ksw;         // [PRE_MAXS]      sweep s: pivot feature
-  int* kun;         // [PRE_MAXS]      un-sweep s: feature
+  double* tsw;      // [PRE_MAXS][16]  sweep s: t_j = A[k_s][j] / pivot of feature j (1 at the pivot)
+  double* V;        // [16][16]        the posterior block swept on S, row-major (V[k][j])
+  double* rdk;      // [16]            1 / pivot of the sweep of feature j (j in S)
+  double* hand;     // [20]            serial section -> weights wave: posterior mean of the weights
+                    //                 [16], sigma_obs, then (as ints) S lo, S hi, flag "draw them"
 };
+// tsw / V / rdk exist twice (parity of the iteration that CONSUMES them): the precompute for
+// iteration it + 1 starts as soon as sigma^2_obs(it) is out, while the weights of iteration `it`
+// are still being drawn from the tables of `it`.
+constexpr size_t PRE_HALF_DOUBLES = PRE_MAXS * 16 + 16 * 16 + 16;
 __host__ __device__ constexpr size_t pre_tables_bytes() {
-  return sizeof(double) * (2 * PRE_MAXS * 64 + 2 * PRE_MAXS) + sizeof(int) * 2 * PRE_MAXS + 16;
+  return sizeof(double) * (2 * PRE_HALF_DOUBLES + 20) + 16;
 }
+__device__ __forceinline__ PreTables pre_tables_at(unsigned char* base, int parity) {
+  PreTables tb;
+  double* d = (double*)base + (size_t)(parity & 1) * PRE_HALF_DOUBLES;
+  tb.tsw = d; d += PRE_MAXS * 16;
+  tb.V = d; d += 16 * 16;
+  tb.rdk = d;
+  tb.hand = (double*)base + 2 * PRE_HALF_DOUBLES;
+  return tb;
+}
+constexpr int HAND_SCALE = 16, HAND_INTS = 17;   // doubles; ints at 2 * HAND_INTS + {0, 1, 2}
 
 // What the precompute leaves in the regression wave's registers for the next serial section.
 struct PreState {
   double c[4];      // swept posterior block (quadrant layout of QCols)
   double diag;
+  double rdk;       // lane j: 1 / pivot of the sweep of feature j (j in S)
   unsigned long long S;   // the set it is swept on
-  int n_sw, n_un;
+  int n_sw;
   int valid;
 };
+
+// Sum over the 16 lanes of each row, through the DPP crossbar (row_ror 8, 4, 2, 1), then made
+// wave-uniform per row by taking the row's first lane (the four rows hold replicas: same inputs,
+// same order, same bits).
+template <int CTRL> __device__ __forceinline__ double dpp_ror_add_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16_d(double v) {
+  v = dpp_ror_add_d<0x128>(v);   // row_ror:8
+  v = dpp_ror_add_d<0x124>(v);   // row_ror:4
+  v = dpp_ror_add_d<0x122>(v);   // row_ror:2
+  v = dpp_ror_add_d<0x121>(v);   // row_ror:1
+  return readlane_d(v, 0);
+}
 
 // sweep_q_kr<KR, false> that also returns its multipliers (t of this lane, 1 / pivot).
 template <int KR>
@@ -101,62 +140,114 @@ __device__ __forceinline__ void sweep_rec(QCols& m, int k, int lane, double& t_o
   }
 }
 
-// The matrix work of the NEXT serial section: posterior block for sigma^2 = var_next swept on S,
-// multipliers recorded; then (on a copy) the descending un-sweeps of the weights draw, recorded.
-// `sync` is called after every step; the caller uses it to place the workgroup barriers of the
-// phase the time waves are in.
-template <class Sync>
-__device__ __forceinline__ void regression_precompute(const RegLds& R, int P, double var_next,
-                                                      unsigned long long S, int lane,
-                                                      const PreTables& tb, PreState& ps, Sync sync) {
+// The matrix work of the NEXT serial section: the posterior block for sigma^2 = var_next swept on
+// S (ascending), recording per sweep the multipliers t_j = A[k][j] / pivot.  Those ARE the Cholesky
+// factor of the included block M_S = L L' (L_jk / L_kk = t_j of sweep k for j > k in S,
+// L_kk^2 = pivot_k), which is all the weights draw u = L^-T z needs (back substitution, see
+// weights_backsub) -- no second pass of un-sweeps.  The swept block itself goes to LDS row-major
+// for the right-hand-side product.  Written as a RESUMABLE sequence of steps (build, one sweep per
+// member of S, store): the caller runs each step in whatever interval between two workgroup
+// barriers its schedule gives it.
+struct PreRun {
+  QCols m;
+  double rdk;
+  unsigned long long pending;
+  int n;
+  int phase;          // 0 build, 1 sweeps, 2 store, 3 done
+};
+__device__ __forceinline__ void pre_begin(PreRun& st, unsigned long long S) {
+  st.pending = S;
+  st.n = 0;
+  st.rdk = 0.0;
+  st.phase = 0;
+}
+__device__ __forceinline__ void pre_step(PreRun& st, const RegLds& R, int P, double var_next,
+                                         unsigned long long S, int lane, const PreTables& tb,
+                                         PreState& ps) {
   const int j = lane & 15, q = lane >> 4;
   const bool live = j < P;
   const int col = live ? j : 0;
-  QCols m;
+  if (st.phase == 0) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = 4 * q + r;
-    double om = 0.0, xx = 0.0;
-    if (live && i < P) {
-      om = R.omega[i * P + col];
-      xx = R.xtx[i * P + col];
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * q + r;
+      double om = 0.0, xx = 0.0;
+      if (live && i < P) {
+        om = R.omega[i * P + col];
+        xx = R.xtx[i * P + col];
+      }
+      st.m.c[r] = om * var_next + xx;
+      st.m.p[r] = 0.0;
     }
-    m.c[r] = om * var_next + xx;
-    m.p[r] = 0.0;
-  }
-  m.diag = live ? R.omega[col * P + col] * var_next + R.xtx[col * P + col] : 1.0;
-  m.cb = 0.0; m.corner = 0.0; m.pdiag = 0.0;
-  int n = 0;
-  for (unsigned long long pending = S; pending != 0ull; pending &= pending - 1ull) {
-    const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+    st.m.diag = live ? R.omega[col * P + col] * var_next + R.xtx[col * P + col] : 1.0;
+    st.m.cb = 0.0; st.m.corner = 0.0; st.m.pdiag = 0.0;
+    st.phase = st.pending != 0ull ? 1 : 2;
+  } else if (st.phase == 1) {
+    const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)st.pending) - 1);
     double t, rd;
-    sweep_rec(m, k, lane, t, rd);
-    tb.tsw[n * 64 + lane] = t;
-    if (lane == 0) { tb.rdsw[n] = rd; tb.ksw[n] = k; }
-    ++n;
-    sync();
-  }
-  ps.n_sw = n;
+    sweep_rec(st.m, k, lane, t, rd);
+    if (q == 0) tb.tsw[st.n * 16 + j] = t;
+    st.rdk = (j == k) ? rd : st.rdk;
+    ++st.n;
+    st.pending &= st.pending - 1ull;
+    if (st.pending == 0ull) st.phase = 2;
+  } else {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) ps.c[r] = m.c[r];
-  ps.diag = m.diag;
-  ps.S = S;
-  int nu = 0;
-  for (unsigned long long mm = S; mm != 0ull;) {
-    const int aidx = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mm));   // descending
-    mm &= ~(1ull << aidx);
-    const double vaa = -readlane_d(m.diag, aidx);
-    const double t = unsweep_q(m, aidx, lane);
-    tb.tun[nu * 64 + lane] = t;
-    if (lane == 0) { tb.vun[nu] = vaa; tb.kun[nu] = aidx; }
-    ++nu;
-    sync();
+    for (int r = 0; r < 4; ++r) tb.V[(4 * q + r) * 16 + j] = st.m.c[r];
+    if (q == 0) tb.rdk[j] = st.rdk;
+    ps.n_sw = st.n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps.c[r] = st.m.c[r];
+    ps.diag = st.m.diag;
+    ps.rdk = st.rdk;
+    ps.S = S;
+    ps.valid = 1;
+    st.phase = 3;
   }
-  ps.n_un = nu;
-  ps.valid = 1;
+}
+
+// The weights draw from the recorded sweeps: u = L^-T z by back substitution over the members of S
+// in descending order,
+//   u_a = z_a / L_aa - sum_{i in S, i > a} (L_ia / L_aa) u_i ,   1 / L_aa = sqrt(1 / pivot_a),
+//   L_ia / L_aa = t_i of the sweep of a,
+// then w_j = mean_j + sigma_obs u_j.  Lane j carries u_j (each row of 16 lanes a replica) and
+// knows its rank within S; step s handles the member of rank s: every lane forms "own increment
+// minus the dot product", only the lane of that member keeps it -- neither the pivot's index nor
+// a wave-uniform dot product is needed (no v_readlane in the chain).  Same u as the un-sweep
+// route of spike_slab_draw_regs up to float64 rounding.  Any wavefront can run it: everything it
+// needs is in LDS (the eight-wave kernel gives it to a randomness wave on another SIMD than the
+// one the regression wave shares with time wave 0).
+__device__ __forceinline__ void weights_backsub(const PreTables& tb, const double* pre, int P,
+                                                unsigned long long S, double mean, double new_scale,
+                                                int lane, float* w) {
+  const int j = lane & 15, q = lane >> 4;
+  const bool live = j < P;
+  const float zf = reinterpret_cast<const float*>(pre + 24)[live ? j : 0];
+  const bool inS = ((S >> j) & 1ull) != 0ull;
+  const int pos = __popcll(S & ((1ull << j) - 1ull));
+  const int n_sw = __popcll(S);
+  const double rsz = (double)__fsqrt_rn((float)tb.rdk[j]) * (double)zf;      // z_j / L_jj
+  double tt[PRE_MAXS];
+#pragma unroll
+  for (int s = 0; s < PRE_MAXS; ++s) tt[s] = tb.tsw[s * 16 + j];
+  double u = 0.0;
+#pragma unroll
+  for (int s = PRE_MAXS - 1; s >= 0; --s) {
+    if (s < n_sw) {
+      double dot = (inS && pos > s) ? tt[s] * u : 0.0;
+      dot = dpp_ror_add_d<0x128>(dot);
+      dot = dpp_ror_add_d<0x124>(dot);
+      dot = dpp_ror_add_d<0x122>(dot);
+      dot = dpp_ror_add_d<0x121>(dot);
+      u = (inS && pos == s) ? rsz - dot : u;
+    }
+  }
+  if (q == 0 && live) w[j] = inS ? (float)(mean + new_scale * u) : 0.f;
 }
 
 // spike_slab_draw_regs with the matrix sweeps replayed from the precompute (same results).
+// `publish(new_scale, mean, S, clean)` is called as soon as sigma_obs is drawn; when it returns true
+// the weights are drawn by somebody else (weights_backsub on another wave) and this function ends.
 // `publish(new_scale)` is called as soon as sigma_obs is drawn -- before the weights.
 template <class PF, class Pub>
 __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
@@ -164,7 +255,7 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
                                                       double prev_obs_scale, double g_obs,
                                                       int lane, PriorCarry& pc, const double* pre,
                                                       const PreTables& tb, const PreState& ps,
-                                                      PF& prof, Pub publish) {
+                                                      const float* red, PF& prof, Pub publish) {
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
@@ -176,30 +267,33 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
   for (int r = 0; r < 4; ++r) { m.c[r] = ps.c[r]; m.p[r] = pc.p[r]; }
   m.diag = ps.diag;
   m.pdiag = pc.pdiag;
-  m.cb = live ? R.bvec[col] : 0.0;
-  m.corner = R.bvec[P];
+  // X~'targets and y'y straight from the sums of xt_sums_wave (R.bvec holds the same values for
+  // the fall-back route; reading `red` saves the round trip through it)
+  m.cb = live ? (double)red[col] : 0.0;
+  m.corner = (double)red[RED_YTY];
   unsigned long long S = ps.S;
   // ---- right-hand side: with V the matrix swept on S (precompute) and b = X~'targets,
   //   b~_j = (j in S ? 0 : b_j) - sum_{k in S} V_kj b_k ,   corner = y'y - sum_{k in S} b_k b~_k
-  // (what carrying b through the recorded sweeps gives, as one matrix-vector product: lane
-  // (j, q) holds V_{4q+r, j}, r < 4; the four quadrants are added across the rows of 16 lanes)
+  // (what carrying b through the recorded sweeps gives): every lane forms the product for its
+  // own column j from the row-major copy in LDS -- 16 independent loads, no cross-lane traffic;
+  // the four rows of 16 lanes compute replicas
   {
-    double part = 0.0;
+    double v[16], bk[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = 4 * q + r;
-      const double bk = k < P ? R.bvec[k] : 0.0;
-      if ((S >> k) & 1ull) part = fma(m.c[r], bk, part);
+    for (int k = 0; k < 16; ++k) {
+      v[k] = tb.V[k * 16 + j];
+      bk[k] = (double)red[k < P ? k : 0];
     }
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      acc0 = ((S >> k) & 1ull) ? fma(v[k], bk[k], acc0) : acc0;
+      acc1 = ((S >> (k + 1)) & 1ull) ? fma(v[k + 1], bk[k + 1], acc1) : acc1;
+    }
     const bool inj = ((S >> j) & 1ull) != 0ull;
     const double bj = m.cb;
-    m.cb = live ? (inj ? 0.0 : bj) - part : 0.0;
-    double term = (live && inj) ? bj * m.cb : 0.0;      // (the same in every quadrant)
-    term += __shfl_xor(term, 1, 64); term += __shfl_xor(term, 2, 64);
-    term += __shfl_xor(term, 4, 64); term += __shfl_xor(term, 8, 64);
-    m.corner -= term;
+    m.cb = live ? (inj ? 0.0 : bj) - (acc0 + acc1) : 0.0;
+    m.corner -= row_sum16_d((live && inj) ? bj * m.cb : 0.0);
   }
   prof.tick(21);
   bool dirty = false;
@@ -246,24 +340,18 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
   double var = beta_post * fast_rcp(g_obs);
   if (var > sp.obs_ub) var = sp.obs_ub;
   const double new_scale = (double)__fsqrt_rn((float)var);
-  publish(new_scale);
-  const float zf = reinterpret_cast<const float*>(pre + 24)[col];
   const double mean = m.cb;
-  double mu = 0.0, umine = 0.0;
+  if (publish(new_scale, mean, S, !dirty)) {
+    prof.tick(23);
+    return new_scale;
+  }
   if (!dirty) {
-    // recorded un-sweeps (descending feature order): feature a ~ N(mu_a, V_aa), the rest
-    // conditioned on it.  The increments sqrt(V_aa) z_a do not depend on the running means, so
-    // the deviation of feature j is a plain sum over the steps -- its own increment plus
-    // t_s[j] times those of the features drawn before it -- with no chain from step to step.
-#pragma unroll 4
-    for (int s = 0; s < ps.n_un; ++s) {
-      const int aidx = __builtin_amdgcn_readfirstlane(tb.kun[s]);
-      const double t = tb.tun[s * 64 + lane];
-      const double za = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zf), aidx));
-      const double cs = (double)__fsqrt_rn((float)tb.vun[s]) * za;
-      umine += aidx > j ? t * cs : (aidx == j ? cs : 0.0);
-    }
+    weights_backsub(tb, pre, P, S, mean, new_scale, lane, R.w);
   } else {
+    // an inclusion flip was accepted in this very iteration: the recorded sweeps are those of the
+    // old set -- un-sweep on the fly (the route of spike_slab_draw_regs)
+    const float zf = reinterpret_cast<const float*>(pre + 24)[col];
+    double mu = 0.0, umine = 0.0;
     for (unsigned long long mm = S; mm != 0ull;) {
       const int aidx = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mm));
       mm &= ~(1ull << aidx);
@@ -274,12 +362,24 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
       const double t = unsweep_q(m, aidx, lane);
       if (j == aidx) umine = ua; else mu += t * (ua - mua);
     }
+    if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(mean + new_scale * umine) : 0.f;
   }
-  if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(mean + new_scale * umine) : 0.f;
   wave_sync();
   prof.tick(23);
   return new_scale;
 }
+
+// ---- scheduling of the helper waves.  Workgroup barriers are all-or-nothing: a helper (the
+// regression wave outside its serial section, a randomness wave) that is still inside a chunk of
+// background work -- a Philox round (~2k cycles next to a busy time wave), a sweep (~1k) -- when the
+// time waves reach a barrier makes the critical path wait.  Each helper therefore passes barrier k
+// once it has finished a fixed share of its units of work (quota_k), chosen from the measured
+// lengths of the intervals (profiles/r04_phase_cycles.txt): (B2)-(Bs) is the regression wave's
+// critical stretch and gets no rounds; (Bs)-(B3) one in four (the weights instead on wave 7);
+// (B3)-(B4), the longest, half of what is left; (B4)-(B5) the rest; nothing after (B5), where the
+// iteration turns round quickly.  A self-timing scheduler (each helper measuring the intervals and
+// its chunks with s_memtime and asking "does another chunk fit?") was built and measured in round
+// 4: the clock reads and the bookkeeping cost more than the waits they removed (7.5 -> 10+ ms).
 
 // ---- LDS layout: every offset but the design's size is a compile-time constant (P <= 16 is
 // provisioned as 16), so LDS addresses are immediates instead of live scalar registers.
@@ -298,8 +398,8 @@ template <int D, int L> struct Lay8 {
   static constexpr size_t off_gam = off_xlast + a16((size_t)NT * D * sizeof(float));
   static constexpr size_t off_pre = off_gam + a16((8 + 64 + 4) * sizeof(double));
   static constexpr size_t off_tgv = off_pre + a16(pre_tables_bytes());
-  static constexpr size_t off_z = off_tgv + TP * sizeof(float);          // zl, zs, zo, zp
-  static constexpr size_t off_x = off_z + 4 * TP * sizeof(float);
+  static constexpr size_t off_z = off_tgv + TP * sizeof(float);          // 2 x (zl, zs, zo)
+  static constexpr size_t off_x = off_z + 6 * TP * sizeof(float);
   static __host__ __device__ constexpr size_t total(int P) { return off_x + (size_t)P * TP * sizeof(float); }
 };
 // indices into `scal` beyond enum Scal: prior moments, then the x_0 normals of even / odd iterations
@@ -384,63 +484,70 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     if (tid < 16) wls[tid] = 0.f;                   // weights = 0            :575-578
   }
   __syncthreads();
-  PreTables tb;
-  {
-    double* d = (double*)(smem + LY::off_pre);
-    tb.tsw = d; d += PRE_MAXS * 64;
-    tb.tun = d; d += PRE_MAXS * 64;
-    tb.rdsw = d; d += PRE_MAXS;
-    tb.vun = d; d += PRE_MAXS;
-    tb.ksw = (int*)d;
-    tb.kun = tb.ksw + PRE_MAXS;
-  }
+  unsigned char* pre_base = smem + LY::off_pre;
 
   if (wave > NW) {
     // ================================ randomness waves =========================================
     // Everything random the other waves consume, one iteration ahead, into LDS:
-    //   zb[0..3][TPAD]  level / slope / observation disturbances of the draw of iteration `it`
-    //                   and the predictive normals of the draw of `it - 1`, chunk c (= Philox call
-    //                   c: 4 normals) at floats 4c .. 4c + 3;
+    //   zb[0..2][TPAD]  level / slope / observation disturbances of the draw of the NEXT
+    //                   iteration, chunk c (= Philox call c: 4 normals) at floats 4c .. 4c + 3;
     //   gam / pre       gamma variates (wave 5) and the regression block's permutation ranks,
     //                   flip uniforms and weight normals (wave 6), double-buffered by parity;
     //   scal[SC8_ZINIT] the x_0 normals (wave 7), double-buffered by parity.
     const int e = wave - NW - 1;                       // 0, 1, 2
-    constexpr int NTASK = (D == 2) ? 4 : 3;            // zl, [zs,] zo, zp
+    constexpr int NTASK = (D == 2) ? 3 : 2;            // zl, [zs,] zo (the predictive normals are
+                                                       // drawn by the time waves while they wait for
+                                                       // sigma^2_obs)
     constexpr int ROUNDS = NTASK * L;                  // wave-rounds of 64 chunks
+    // contiguous, equal shares
+    constexpr int N0 = ROUNDS / 3, N1 = (ROUNDS - N0) / 2;
+    const int k_lo = e == 0 ? 0 : (e == 1 ? N0 : N0 + N1);
+    const int k_hi = e == 0 ? N0 : (e == 1 ? N0 + N1 : ROUNDS);
+    const int n_my = k_hi - k_lo;
     PF eprof;
     eprof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && wave == NW + 1 && lane == 0);
-    auto normals_round = [&](int k, uint32_t it_draw) {
+    auto normals_round = [&](int k, uint32_t it_for) __attribute__((always_inline)) {
+      // the disturbances of the draw of iteration it_for, into that iteration's half of zb;
       // task-major: all chunks of a kind, then the next kind
       const int task = k / L, blk = k - task * L;
-      const int slot = (D == 2) ? task : (task == 0 ? 0 : task + 1);     // D = 1 has no slope row
-      const uint32_t site = slot == 0 ? SITE_PRIOR_LEVEL
-                            : (slot == 1 ? SITE_PRIOR_SLOPE : (slot == 2 ? SITE_PRIOR_OBS : SITE_PRED));
-      // the predictive normals belong to the draw that is being made now, the disturbances to
-      // the next one
-      const uint32_t iter = slot == 3 ? it_draw : it_draw + 1u;
+      const int slot = (D == 2) ? task : (task == 0 ? 0 : 2);            // D = 1 has no slope row
+      const uint32_t site = slot == 0 ? SITE_PRIOR_LEVEL : (slot == 1 ? SITE_PRIOR_SLOPE : SITE_PRIOR_OBS);
       const int c = 64 * blk + lane;
-      const U4 r = site_call(rng, iter, site, 0, (uint32_t)c);
+      const U4 r = site_call(rng, it_for, site, 0, (uint32_t)c);
       float z[4];
       normals4(r, z);
-      *reinterpret_cast<float4*>(zb + (size_t)slot * TPAD + 4 * c) = make_float4(z[0], z[1], z[2], z[3]);
+      *reinterpret_cast<float4*>(zb + ((size_t)(it_for & 1u) * 3 + slot) * TPAD + 4 * c) =
+          make_float4(z[0], z[1], z[2], z[3]);
     };
-    auto role_work = [&](int it_next) {
+    auto role_work = [&](int it_next) __attribute__((always_inline)) {
       if (it_next > n_iter) return;
       if (e == 0) {
         serial_gammas<1>(cx, it_next, lane, gam + 4 * (it_next & 1));
       } else if (e == 1) {
         if (it_next < n_iter) spike_slab_randoms(rng, (uint32_t)it_next, P, lane, gam + 8 + 32 * (it_next & 1));
-      } else if (lane < D && it_next < n_iter) {
+      } else if (it_next < n_iter) {
+        // (by all lanes, stored by the first D: see the four-wave kernel)
         float zi[1];
         fill_normals<1>(rng, (uint32_t)it_next, SITE_PRIOR_INIT, 0, (uint32_t)lane, zi);
-        scal[SC8_ZINIT + 2 * (it_next & 1) + lane] = zi[0];
+        asm volatile("" : "+v"(zi[0]));
+        if (lane < D) scal[SC8_ZINIT + 2 * (it_next & 1) + lane] = zi[0];
       }
     };
-    // iteration 0's randomness (the disturbances of draw 0: it_draw = -1 + 1; no predictive row yet)
+    // iteration 0's randomness
     role_work(0);
-    for (int k = e; k < ROUNDS; k += 3)
-      if (k / L != NTASK - 1) normals_round(k, 0xFFFFFFFFu);
+    for (int k = k_lo; k < k_hi; ++k) normals_round(k, 0u);
     eprof.tick(30);
+    // rounds finished on arrival at (B3), (B4), (B5): see "scheduling of the helper waves" above.
+    // $CI_DBG modes 1 / 2 (everything right after (Bs) / everything after (B5)) exist for the
+    // timing-independence test.
+    const int sched = (a.dbg & 0xFFFF) ? (a.dbg & 0xFFFF) : SCHED_DEFAULT;
+    const int mode = sched & 3;
+    const int scale = L >= 4 ? L / 4 : 1;                // rounds grow with the steps per thread
+    const int c_3 = e == 2 ? 0 : ((sched >> 10) & 3) * scale, c_4 = ((sched >> 12) & 3) * scale,
+              c_a = ((sched >> 14) & 3) * scale;
+    const int r_3 = mode == 1 ? n_my : (mode == 2 ? 0 : (c_3 < n_my ? c_3 : n_my));
+    const int r_4 = mode == 1 ? n_my : (mode == 2 ? 0 : (r_3 + c_4 < n_my ? r_3 + c_4 : n_my));
+    const int r_5 = mode == 2 ? 0 : (n_my - c_a > r_4 ? n_my - c_a : r_4);
     for (int it = 0; it <= n_iter; ++it) {
       __syncthreads();                                   // (B1)
       eprof.tick(31);
@@ -452,30 +559,35 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
       eprof.tick(30);
       __syncthreads();                                   // (Bs)
       eprof.tick(31);
-      if (it == n_iter) {
-        __syncthreads();                                 // (B3)
-        break;
-      }
-      // the normals of iteration it + 1 (and the predictive normals of draw it), with the three
-      // barriers of the draw placed after about 1/3, 2/3 and 5/6 of this wave's rounds
-      const int n_my = (ROUNDS - e + 2) / 3;
-      const int m3 = (n_my + 2) / 3, m4 = (2 * n_my + 2) / 3, m5 = (5 * n_my + 5) / 6;
-      int done = 0, r = 0;
-      auto sync_to = [&](int upto) {
-        while (done < upto) {
-          eprof.tick(30);
-          __syncthreads();
-          eprof.tick(31);
-          ++done;
+      if (e == 2 && it < n_iter) {
+        // the weights of iteration `it`, when the serial section asks for it (the regression wave
+        // shares its SIMD with time wave 0, which is on the critical path from here to (B3))
+        const PreTables tb = pre_tables_at(pre_base, it);
+        const int* hi_ = reinterpret_cast<const int*>(tb.hand + HAND_INTS);
+        if (hi_[2] != 0) {
+          const unsigned long long S = ((unsigned long long)(unsigned)hi_[1] << 32) | (unsigned)hi_[0];
+          weights_backsub(tb, gam + 8 + 32 * (it & 1), P, S, tb.hand[lane & 15], tb.hand[HAND_SCALE],
+                          lane, wls);
         }
-      };
-      for (int k = e; k < ROUNDS; k += 3, ++r) {
-        if (r == m3) sync_to(1);
-        if (r == m4) sync_to(2);
-        if (r == m5) sync_to(3);
-        normals_round(k, (uint32_t)it);
       }
-      sync_to(3);                                        // (B3) (B4) (B5) all passed
+      // the rounds of normals for iteration it + 1 (zb is double-buffered by the parity of the
+      // iteration, so they may run anywhere in this iteration)
+      int r = 0;
+      if (it < n_iter)
+        for (; r < r_3; ++r) normals_round(k_lo + r, (uint32_t)(it + 1));
+      eprof.tick(30);
+      __syncthreads();                                   // (B3)
+      eprof.tick(31);
+      if (it == n_iter) break;
+      for (; r < r_4; ++r) normals_round(k_lo + r, (uint32_t)(it + 1));
+      eprof.tick(30);
+      __syncthreads();                                   // (B4)
+      eprof.tick(31);
+      for (; r < r_5; ++r) normals_round(k_lo + r, (uint32_t)(it + 1));
+      eprof.tick(30);
+      __syncthreads();                                   // (B5)
+      eprof.tick(31);
+      for (; r < n_my; ++r) normals_round(k_lo + r, (uint32_t)(it + 1));
       eprof.tick(30);
     }
     return;
@@ -488,7 +600,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
     PreState ps;
-    ps.valid = 0; ps.S = 0ull; ps.n_sw = 0; ps.n_un = 0; ps.diag = 1.0;
+    ps.valid = 0; ps.S = 0ull; ps.n_sw = 0; ps.diag = 1.0; ps.rdk = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ps.c[r] = 0.0;
     PF rprof;
@@ -499,90 +611,123 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     float* o_ls = a.out_level_scale;
     float* o_ss = a.out_slope_scale;
     float* o_w = a.out_weights;
+    const int sched = (a.dbg & 0xFFFF) ? (a.dbg & 0xFFFF) : SCHED_DEFAULT;
+    const int mode = sched & 3;
     for (int it = 0; it <= n_iter; ++it) {
       __syncthreads();                                   // (B1) targets in LDS
+      // from here to sigma^2_obs this wave is the critical path of the iteration and shares its
+      // SIMD with time wave 0, which has slack until (Bs): win the issue arbitration while it lasts
+      __builtin_amdgcn_s_setprio(3);
       xt_sums_wave<L, 2>(tgv, Xs, TPAD, P, 2 * wave, false, red, lane);
       __syncthreads();                                   // (B2) all sums complete
       rprof.tick(16);
-      // the serial section is the critical path of the iteration and shares its SIMD with time
-      // wave 0, which has slack until (Bs): win the issue arbitration while it lasts
-      __builtin_amdgcn_s_setprio(3);
+      const PreTables tb = pre_tables_at(pre_base, it);
       if (lane < P + 1) R.bvec[lane] = (double)red[lane < P ? lane : RED_YTY];
       const float wprev = lane < P ? wls[lane] : 0.f;    // the previous draw's weights (stored below)
       const double* gm = gam + 4 * (it & 1);
       const double g_level = gm[0], g_slope = gm[1], g_obs = gm[2];
       const double emit_obs = obs_scale;
-      wave_sync();
       rprof.tick(20);
-      auto publish = [&](double ns) {
+      // sigma_obs(it) to the time waves -- and, on the replay route with no flip accepted in this
+      // iteration, the weights draw to randomness wave 7 (it runs on another SIMD; from here to
+      // (B3) time wave 0, which shares this wave's SIMD, is on the critical path, this wave is not)
+      auto publish4 = [&](double ns, double mean, unsigned long long S, bool clean) __attribute__((always_inline)) {
         if (lane == 0) scal[SC_OBS_DK] = (float)ns;
+        if (lane < 16) tb.hand[lane] = mean;
+        if (lane == 0) {
+          tb.hand[HAND_SCALE] = ns;
+          int* hi_ = reinterpret_cast<int*>(tb.hand + HAND_INTS);
+          hi_[0] = (int)(unsigned)(S & 0xFFFFFFFFull);
+          hi_[1] = (int)(unsigned)(S >> 32);
+          hi_[2] = clean ? 1 : 0;
+        }
         rprof.tick(22);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();                                 // (Bs) sigma^2_obs(it) published
         rprof.tick(18);
+        return clean;
       };
+      auto publish1 = [&](double ns) __attribute__((always_inline)) { (void)publish4(ns, 0.0, 0ull, false); };
       if (it < n_iter) {
         if (ps.valid && ps.S == pc.S) {
           obs_scale = spike_slab_draw_pre(R, P, sp, obs_scale, g_obs, lane, pc, gam + 8 + 32 * (it & 1), tb,
-                                          ps, rprof, publish);
+                                          ps, red, rprof, publish4);
         } else {
           NoProf np;
+          wave_sync();                                   // R.bvec written above
           obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, np, pc,
-                                           gam + 8 + 32 * (it & 1), publish);
+                                           gam + 8 + 32 * (it & 1), publish1);
         }
       } else {
-        publish(obs_scale);
-      }
-      // level / slope scales of iteration it - 1 (the time waves formed the same values for their
-      // draw already) and its scalar outputs
-      if (it > 0) {
-        auto clipped_scale = [](double scale, double ss, double g, double ub) {
-          const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
-          return s < ub ? s : ub;
-        };
-        double ssl = 0.0, sss = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          ssl += (double)red[RED_INC + 2 * w];
-          sss += (double)red[RED_INC + 2 * w + 1];
-        }
-        level_scale = clipped_scale(sp.level_scale, ssl, g_level, sp.level_ub);
-        if (D == 2) slope_scale = clipped_scale(sp.slope_scale, sss, g_slope, sp.slope_ub);
-        const int s = it - 1 - a.W;
-        if (s >= 0) {
-          const size_t o = chain_lin * a.S + s;
-          if (lane == 0) {
-            if (o_obs) o_obs[o] = (float)emit_obs;
-            if (o_ls) o_ls[o] = (float)level_scale;
-            if (o_ss) o_ss[o] = (float)(D == 2 ? slope_scale : 0.0);
-          }
-          if (o_w && lane < P) o_w[o * P + lane] = wprev;
-        }
+        publish1(obs_scale);
       }
       rprof.tick(23);
-      __builtin_amdgcn_s_setprio(0);
-      __syncthreads();                                   // (B3) weights of iteration `it` published
-      rprof.tick(17);
-      if (it == n_iter) break;
-      // the time waves now finish the draw ((B4) (B5)); meanwhile: next iteration's matrix work
-      int done = 0, step = 0;
-      const int n_steps = 2 * __popcll(pc.S);
-      const int mark4 = (n_steps * 9 + 10) / 20 > 0 ? (n_steps * 9 + 10) / 20 : 1;     // ~ 45 %
-      const int mark5 = (n_steps * 7 + 5) / 10 > mark4 ? (n_steps * 7 + 5) / 10 : mark4 + 1;   // ~ 70 %
-      auto sync = [&]() {
-        ++step;
-        for (;;) {
-          const int mark = done == 0 ? mark4 : mark5;
-          if (done >= 2 || step < mark) break;
-          rprof.tick(19);
-          __syncthreads();
-          rprof.tick(29);
-          ++done;
+      // level / slope scales of iteration it - 1 (the time waves formed the same values for their
+      // draw already) and its scalar outputs: nobody waits for them, they follow (B3)
+      auto after_b3 = [&]() __attribute__((always_inline)) {
+        if (it > 0) {
+          auto clipped_scale = [](double scale, double ss, double g, double ub) {
+            const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
+            return s < ub ? s : ub;
+          };
+          double ssl = 0.0, sss = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            ssl += (double)red[RED_INC + 2 * w];
+            sss += (double)red[RED_INC + 2 * w + 1];
+          }
+          level_scale = clipped_scale(sp.level_scale, ssl, g_level, sp.level_ub);
+          if (D == 2) slope_scale = clipped_scale(sp.slope_scale, sss, g_slope, sp.slope_ub);
+          const int s = it - 1 - a.W;
+          if (s >= 0) {
+            const size_t o = chain_lin * a.S + s;
+            if (lane == 0) {
+              if (o_obs) o_obs[o] = (float)emit_obs;
+              if (o_ls) o_ls[o] = (float)level_scale;
+              if (o_ss) o_ss[o] = (float)(D == 2 ? slope_scale : 0.0);
+            }
+            if (o_w && lane < P) o_w[o * P + lane] = wprev;
+          }
         }
       };
-      regression_precompute(R, P, obs_scale * obs_scale, pc.S, lane, tb, ps, sync);
+      if (it == n_iter) {
+        __syncthreads();                                 // (B3)
+        after_b3();
+        break;
+      }
+      // Next iteration's matrix work starts HERE: it needs sigma^2_obs(it) and the included set,
+      // not the weights (its tables are those of the other parity: the weights of this iteration
+      // are still being drawn from this iteration's).  Each step runs in the first interval that
+      // (B3) -- weights(it) published --, (B4), (B5) are passed in between.
+      const PreTables tbn = pre_tables_at(pre_base, it + 1);
+      const double var_next = obs_scale * obs_scale;
+      PreRun st;
+      pre_begin(st, pc.S);
+      // steps (build, one sweep per member of the set, store) finished before (B3), (B4), (B5): the
+      // build and p_3 sweeps (this wave waits there anyway once the weights are drawn elsewhere, but
+      // its SIMD partner, time wave 0, is in its densest stretch), p_4 more, all but p_a; the store
+      // of the tables comes last
+      const int n_sw = __popcll(pc.S);
+      const int p_3 = (sched >> 4) & 3, p_4 = (sched >> 6) & 3, p_a = (sched >> 8) & 3;
+      const int s_3 = mode == 1 ? n_sw + 2 : (mode == 2 ? 0 : 1 + (p_3 < n_sw ? p_3 : n_sw));
+      const int s_4 = mode == 1 ? n_sw + 2 : (mode == 2 ? 0 : (s_3 + p_4 < 1 + n_sw ? s_3 + p_4 : 1 + n_sw));
+      const int s_5 = mode == 1 ? n_sw + 2 : (mode == 2 ? 0 : (1 + n_sw - p_a > s_4 ? 1 + n_sw - p_a : s_4));
+      int step = 0;
+      for (; st.phase != 3 && step < s_3; ++step) pre_step(st, R, P, var_next, pc.S, lane, tbn, ps);
       rprof.tick(19);
-      while (done < 2) { __syncthreads(); ++done; }
+      __syncthreads();                                   // (B3) weights(it) published
+      rprof.tick(17);
+      after_b3();
+      for (; st.phase != 3 && step < s_4; ++step) pre_step(st, R, P, var_next, pc.S, lane, tbn, ps);
+      rprof.tick(19);
+      __syncthreads();                                   // (B4)
       rprof.tick(29);
+      for (; st.phase != 3 && step < s_5; ++step) pre_step(st, R, P, var_next, pc.S, lane, tbn, ps);
+      rprof.tick(19);
+      __syncthreads();                                   // (B5)
+      rprof.tick(29);
+      for (; st.phase != 3; ++step) pre_step(st, R, P, var_next, pc.S, lane, tbn, ps);
+      rprof.tick(19);
     }
     return;
   }
@@ -665,18 +810,19 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     // ---- window: the normals of this iteration from LDS, emission of draw it-1, this iteration's
     // disturbance scales, first half of the prior-simulation scan
     float zl[L], zs[L], zo[L];
-    lds_row_load<L>(zb + t0, zl);
+    const float* zit = zb + (size_t)(it & 1) * 3 * TPAD + t0;
+    lds_row_load<L>(zit, zl);
     if constexpr (D == 2) {
-      lds_row_load<L>(zb + TPAD + t0, zs);
+      lds_row_load<L>(zit + TPAD, zs);
     } else {
 #pragma unroll
       for (int l = 0; l < L; ++l) zs[l] = 0.f;
     }
-    lds_row_load<L>(zb + 2 * TPAD + t0, zo);
+    lds_row_load<L>(zit + 2 * TPAD, zo);
     if (it > a.W) {
       const int s = it - 1 - a.W;
       float zp[L];
-      lds_row_load<L>(zb + 3 * TPAD + t0, zp);
+      fill_normals<L>(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)t0, zp);
       float tr[L];
 #pragma unroll
       for (int l = 0; l < L; ++l) {

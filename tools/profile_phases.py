@@ -52,7 +52,7 @@ def main():
   print(f"  total of phases 0-7, 24-28: {top / n_it:.0f} cyc/iter")
   if "kernel8" in sess.kernel_name():
     print("  eight-wave kernel, time thread 0:")
-    for i, name in ((0, "targets .. (B2)"), (2, "window: normals from LDS, emission, scales, prior scan"),
+    for i, name in ((0, "targets .. (B2)"), (2, "window: normals from LDS, emission (+ its normals), scales, prior scan"),
                     (1, "wait at (Bs) for sigma^2_obs"), (24, "matrix chunk + in-wave scan"),
                     (25, "(B3) + cross-wave + local covariance pass"), (3, "X w, residual, prior path"),
                     (27, "forward chunk + in-wave scan"), (5, "(B4) + cross-wave"),
@@ -64,8 +64,9 @@ def main():
     print("  regression wave (lane 0):")
     for i, name in ((16, "(B1) + its two features + (B2)"), (20, "gather"), (21, "right-hand-side replay"),
                     (22, "flips + sigma^2_obs"), (18, "wait at (Bs)"), (23, "weights replay + scale draws + outputs"),
-                    (17, "wait at (B3)"), (19, "precompute steps (pure)"), (29, "waits at (B4) (B5)")):
+                    (19, "precompute steps (pure, from (Bs) on)"), (17, "its wait at (B3)"), (29, "its waits at (B4) (B5)")):
       print(f"  [{i:2d}] {name:52s} {cyc[i] / n_it:9.0f} cyc/iter")
+    print(f"       iterations on the replay route: {cyc[14]} of {n_it}")
     print("  randomness wave 5 (lane 0):")
     for i, name in ((30, "work"), (31, "waits at barriers")):
       print(f"  [{i:2d}] {name:52s} {cyc[i] / n_it:9.0f} cyc/iter")

@@ -6,6 +6,7 @@ import pytest
 
 import causalimpact as ci
 from causalimpact import batch
+from causalimpact import causalimpact_lib as lib
 from causalimpact import data as cid
 from causalimpact import _synthetic as syn
 
@@ -206,3 +207,25 @@ def test_summary_bands_from_order_statistics_equal_numpy_quantiles():
     lo, hi = np.quantile(rel[b], quantiles)
     np.testing.assert_allclose([row_avg["rel_effect_lower"], row_avg["rel_effect_upper"]], [lo, hi],
                                rtol=1e-13)
+
+
+def test_batched_fit_rejects_what_it_cannot_honour():
+  """float64 compute and raw-scale outcomes (internal conditioning) exist on the single-series
+  path only: the batched API must say so instead of silently computing something else."""
+  frames = _frames(2, 60, 1)
+  idx = frames[0].index
+  pre, post = (idx[0], idx[39]), (idx[40], idx[59])
+  with pytest.raises(NotImplementedError, match="float32"):
+    batch.fit_causalimpact_batch(frames, pre, post, data_options=lib.DataOptions(dtype=np.float64))
+  with pytest.raises(NotImplementedError, match="standardize_data=True"):
+    batch.fit_causalimpact_batch(frames, pre, post,
+                                 data_options=lib.DataOptions(standardize_data=False))
+
+
+def test_lazy_diagnostics_pickle_as_a_plain_dict():
+  import pickle
+  calls = []
+  m = lib._LazyMapping(lambda: (calls.append(1), {"split_rhat": {"a": 1.0}, "num_chains": 2})[1])
+  back = pickle.loads(pickle.dumps(m))
+  assert back == {"split_rhat": {"a": 1.0}, "num_chains": 2} and isinstance(back, dict)
+  assert calls == [1]

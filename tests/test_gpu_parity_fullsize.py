@@ -5,9 +5,16 @@ north_star: "posterior mean/CI within 1 %".  Each summary is compared within
     max(1 % of the oracle value, 4 Monte-Carlo standard errors)
 where the standard error is COMPUTED from the spread of per-chain summaries on both sides (not
 guessed), and the table of (device, oracle, difference, MC s.e.) is written to
-gpurun_out/parity_fullsize_<cfg>.json for DESIGN.md.  The device chains reuse the oracle's
-Philox streams (chain ids 0..C-1), so the first oracle chains are the same chains up to
-float32 round-off; the remaining oracle chains are independent replicates.
+gpurun_out/parity_fullsize_<cfg>.json for DESIGN.md.  What that band amounts to depends on the
+quantity: for the scale parameters and the weights 32 independent chains a side bring 4 s.e.
+below 1 %, so for them it IS the 1 % band; the post-period average of the predictive DRAWS has a
+Monte-Carlo error of several per cent whatever the sampler (a forecast of a local linear trend
+300 steps ahead), so for it the band is 4 s.e. -- which is why the prediction is ALSO compared
+through `posterior_means` (the Rao-Blackwellised predictor, no observation noise): path-wise over
+all T steps, on independent replicates, in units of the outcome's standard deviation
+(`_compare_paths`).  The device chains reuse the oracle's Philox streams (chain ids 0..C-1), so
+oracle and device chains with the same id are the same chain up to float32 round-off; chains with
+different ids are independent replicates.
 """
 import concurrent.futures
 import json
@@ -29,9 +36,11 @@ def _oracle_chain(args):
   r = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=seed, chain=chain,
                     want=("obs_scale", "level_scale", "slope_scale", "drift_scales", "weights",
                           "trajectories", "pred_mean"))
-  return _chain_summaries(r["obs_scale"], r["level_scale"], r["slope_scale"], r["weights"],
-                          r["trajectories"][:, post].mean(axis=1), r["pred_mean"][post].mean(),
-                          r.get("drift_scales"))
+  out = _chain_summaries(r["obs_scale"], r["level_scale"], r["slope_scale"], r["weights"],
+                         r["trajectories"][:, post].mean(axis=1), r["pred_mean"][post].mean(),
+                         r.get("drift_scales"))
+  out["_pred_mean_path"] = np.asarray(r["pred_mean"], np.float64)
+  return out
 
 
 def _chain_summaries(obs, lvl, slp, w, eff, cf, drift=None):
@@ -55,10 +64,36 @@ def _chain_summaries(obs, lvl, slp, w, eff, cf, drift=None):
   return out
 
 
+def _compare_paths(tag, dev_pm, orc_pm, pre_end, outcome_sd=1.0):
+  """posterior_means (mean over draws of level + X w + seasonal: no predictive noise) of
+  INDEPENDENT chains, [chains, T] a side: the difference of the pooled paths, step by step, against
+  max(1 % of the outcome's s.d., 4 s.e._t) with s.e._t from the spread over chains.  Over the
+  pre-period (observed data: posterior s.d. of the predictor ~ 0.05) the 1 % figure must hold
+  outright at >= 99 % of the steps; the whole table goes to gpurun_out/."""
+  d, o = np.asarray(dev_pm, np.float64), np.asarray(orc_pm, np.float64)
+  diff = d.mean(axis=0) - o.mean(axis=0)
+  se = np.sqrt(d.var(axis=0, ddof=1) / d.shape[0] + o.var(axis=0, ddof=1) / o.shape[0])
+  one = 0.01 * outcome_sd
+  allowed = np.maximum(one, 4.0 * se)
+  rows = dict(max_abs_diff_pre=float(np.abs(diff[:pre_end]).max()),
+              max_abs_diff_post=float(np.abs(diff[pre_end:]).max()),
+              max_se_pre=float(se[:pre_end].max()), max_se_post=float(se[pre_end:].max()),
+              frac_within_1pct_pre=float((np.abs(diff[:pre_end]) <= one).mean()),
+              frac_within_1pct_post=float((np.abs(diff[pre_end:]) <= one).mean()),
+              frac_within_band=float((np.abs(diff) <= allowed).mean()), outcome_sd=outcome_sd)
+  with open(os.path.join(ROOT, "gpurun_out", f"parity_fullsize_{tag}_paths.json"), "w") as f:
+    json.dump(rows, f, indent=1)
+  assert rows["frac_within_band"] >= 0.995, rows          # 4 s.e. over T steps: a few may exceed
+  assert rows["frac_within_1pct_pre"] >= 0.99, rows
+  return rows
+
+
 def _compare(tag, dev_chains, orc_chains, scale_floor):
   keys = sorted(dev_chains[0])
   rows, bad = {}, []
   for k in keys:
+    if k.startswith("_"):
+      continue
     d = np.array([c[k] for c in dev_chains])
     o = np.array([c[k] for c in orc_chains])
     se = float(np.sqrt(d.var(ddof=1) / d.size + o.var(ddof=1) / o.size))
@@ -86,8 +121,11 @@ def test_cfg2_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
   chains (ids 0..63, one launch) and 32 float64 oracle chains (ids 0..31; ~0.2 s each, on the
   host cores).  Two comparisons:
     * INDEPENDENT replicates -- device chains 32..63 against oracle chains 0..31 (disjoint random
-      streams): 32 chains a side bring the Monte-Carlo error of the headline quantities below the
-      1 % mark, so the `allowed = max(1 %, 4 s.e.)` band is the 1 % band for them;
+      streams): for sigma_obs, the disturbance scales and the weights 32 chains a side bring
+      4 s.e. below 1 %, i.e. `allowed = max(1 %, 4 s.e.)` is the 1 % band for them; the
+      post-period average of the predictive draws keeps a band of 4 s.e. (~ 19 %: Monte-Carlo
+      error of a 300-step forecast), and the prediction is pinned through the path of
+      `posterior_means` instead (`_compare_paths`: 1 % of the outcome's s.d. over the pre-period);
     * the SAME chain ids 0..7 on both sides: float32 kernel vs float64 oracle on one random
       stream, i.e. pure arithmetic drift over 1112 iterations."""
   T, p, W, S, C, CO = 1000, 10, 112, 1000, 64, 32
@@ -107,6 +145,9 @@ def test_cfg2_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
   with concurrent.futures.ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
     ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
   rows = _compare("cfg2", dev[CO:], ora, scale_floor=0.05)
+  # the prediction, path-wise, through posterior_means: device chains 32..63 vs oracle chains 0..31
+  _compare_paths("cfg2", g["posterior_means"][0, CO:], np.stack([c["_pred_mean_path"] for c in ora]),
+                 pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))
   # float32 drift over 1112 iterations: the SAME chains (ids 0..7) on both sides
   same = _compare("cfg2_same_chains", dev[:8], ora[:8], scale_floor=0.05)
   assert abs(same["sigma_obs.mean"]["rel"]) < 1e-3
@@ -115,9 +156,11 @@ def test_cfg2_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
 
 def test_cfg4_long_run_posterior_matches_oracle_within_one_percent_or_mc_error():
   """BASELINE cfg4: T=10000, 50 covariates (P=51) + Seasonal(num_seasons=7), time-parallel
-  kernel over its HBM workspace; 4 device chains vs 4 oracle chains (ids 0..3), W=112, S=400
-  (the oracle costs ~8 ms per iteration: ~4 s per chain, run in parallel on the host)."""
-  T, p, W, S, C = 10000, 50, 112, 400, 4
+  kernel over its HBM workspace; W=112, S=400 (the oracle costs ~8 ms per iteration: ~4 s per
+  chain, run in parallel on the host).  8 device chains in one launch against 4 oracle chains
+  (ids 0..3): device chains 4..7 are INDEPENDENT replicates of the oracle's, device chains 0..3
+  the same random streams (float32-vs-float64 drift of one stream)."""
+  T, p, W, S, C, CO = 10000, 50, 112, 400, 8, 4
   seed = (3, 1)
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
   t = np.arange(T)
@@ -134,6 +177,9 @@ def test_cfg4_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
                           g["posterior_trajectories"][0, c][:, post].mean(axis=1),
                           g["posterior_means"][0, c][post].mean(),
                           g["seasonal_drift_scales"][0, c]) for c in range(C)]
-  with concurrent.futures.ProcessPoolExecutor(max_workers=C) as ex:
-    ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(C)]))
-  _compare("cfg4", dev, ora, scale_floor=0.05)
+  with concurrent.futures.ProcessPoolExecutor(max_workers=CO) as ex:
+    ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
+  _compare("cfg4", dev[CO:], ora, scale_floor=0.05)                 # independent replicates
+  _compare("cfg4_same_chains", dev[:CO], ora, scale_floor=0.05)     # drift of the same streams
+  _compare_paths("cfg4", g["posterior_means"][0, CO:], np.stack([c["_pred_mean_path"] for c in ora]),
+                 pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))

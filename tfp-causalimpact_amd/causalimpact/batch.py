@@ -279,6 +279,15 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
     raise ValueError("`alpha` must be between 0 and 1.")
   if inference_options.sampler != "gibbs":
     raise NotImplementedError("batched fits use the Gibbs sampler")
+  if cid._as_numpy_dtype(data_options.dtype) == np.float64:  # pylint: disable=protected-access
+    raise NotImplementedError(
+        "fit_causalimpact_batch computes in float32 (the batched float32 kernels); use "
+        "fit_causalimpact per series for DataOptions(dtype=float64)")
+  if not data_options.standardize_data:
+    raise NotImplementedError(
+        "fit_causalimpact_batch needs standardize_data=True: the per-series internal conditioning "
+        "of raw-scale outcomes (causalimpact_lib._internal_conditioning) is not part of the batched "
+        "path; use fit_causalimpact per series")
   if isinstance(data, np.ndarray):
     values = np.asarray(data, np.float64)
     index = pd.RangeIndex(values.shape[1]) if index is None else pd.Index(index)

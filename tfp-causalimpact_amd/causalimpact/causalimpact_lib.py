@@ -71,6 +71,10 @@ class _LazyMapping(collections.abc.Mapping):
   def __repr__(self):
     return repr(self._get())
 
+  def __reduce__(self):
+    # pickles (multiprocessing, joblib, caches) as the plain dict it stands for
+    return (dict, (self._get(),))
+
 
 @dataclasses.dataclass
 class CausalImpactPosteriorSamples:
@@ -98,7 +102,9 @@ class CausalImpactAnalysis:
 @dataclasses.dataclass
 class DataOptions:
   """reference :147-159.  dtype may be numpy / python float types (or anything with a
-  `.name` of "float32"/"float64"); the kernel computes in float32 either way."""
+  `.name` of "float32"/"float64").  The Gibbs sampler computes in that type (float64: the kernels
+  of csrc/ci_gibbs64.h, draw for draw equal to the float64 oracle); the HMC extension computes in
+  float32 for either."""
   outcome_column: Optional[str] = None
   standardize_data: bool = True
   dtype: Any = np.float32
@@ -185,12 +191,8 @@ def fit_causalimpact(data: pd.DataFrame,
       sampler=inference_options.sampler, summary_request=request,
       hmc_init=inference_options.hmc_init, hmc_prior=inference_options.hmc_prior,
       kernel_flags=inference_options.kernel_flags)
-  if request is not None and device_summary is None:
-    # draws pooled on the host (several devices, or the HMC path): summarise them on one device
-    request["ranks"] = _summary_ranks(posterior_trajectories.shape[0], request["quantiles"])
-    device_summary = _native.summarize_draws(
-        posterior_trajectories, request["scale"], request["shift"], request["observed"],
-        request["flags"], request["ranks"], device=(inference_options.devices or [0])[0])
+  # (draws pooled on the host -- several devices, float64, HMC -- were summarised inside
+  #  _run_sampler, in the sampler's internal units)
   if device_summary is not None:
     series, summary = _compute_impact_device(posterior_means, device_summary, request, ci_data,
                                              alpha)
@@ -408,6 +410,21 @@ def _run_sampler(*, ci_data, prior_level_sd, seed, num_results, num_warmup_steps
   out = ({k: v[0] for k, v in parts[0].items()} if len(parts) == 1 else              # [C, ...]
          {k: np.concatenate([p[k][0] for p in parts], axis=0) for k in parts[0]})
 
+  if (summary_request is not None and device_summary is None
+      and "posterior_trajectories" in out):
+    # draws pooled on the host (several devices, the float64 kernels, the HMC path): the summary
+    # kernels read float32 trajectories, so they get them in the INTERNAL (conditioned) units --
+    # O(1) values -- with the map to the caller's scale folded into (scale, shift) in float64, as
+    # on the single-device path.  Summarising the rescaled draws would round the offset back in
+    # (8e-6 steps at y ~ 100).
+    tr = out["posterior_trajectories"]
+    summary_request["ranks"] = _summary_ranks(tr.shape[0] * tr.shape[1], summary_request["quantiles"])
+    device_summary = _native.summarize_draws(
+        tr.reshape((tr.shape[0] * tr.shape[1],) + tr.shape[2:]),
+        float(summary_request["scale"]) * cond_s,
+        float(summary_request["shift"]) + cond_mu * float(summary_request["scale"]),
+        summary_request["observed"], summary_request["flags"], summary_request["ranks"],
+        device=devs[0])
   if (cond_mu, cond_s) != (0.0, 1.0):
     # back to the caller's scale, in float64: locations get the offset, everything else the scale
     out = {k: np.asarray(v, np.float64) * cond_s for k, v in out.items()}

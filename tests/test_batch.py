@@ -212,7 +212,7 @@ def test_summary_bands_from_order_statistics_equal_numpy_quantiles():
 def test_batched_fit_rejects_what_it_cannot_honour():
   """float64 compute and raw-scale outcomes (internal conditioning) exist on the single-series
   path only: the batched API must say so instead of silently computing something else."""
-  frames = _frames(2, 60, 1)
+  frames = _frames(3, 60, 1)
   idx = frames[0].index
   pre, post = (idx[0], idx[39]), (idx[40], idx[59])
   with pytest.raises(NotImplementedError, match="float32"):

@@ -42,7 +42,7 @@ CI_WIDE_DECL(2) CI_WIDE_DECL(3) CI_WIDE_DECL(4) CI_WIDE_DECL(5) CI_WIDE_DECL(6) 
 // One object file per (D, L) instantiation (ci_inst.hip).
 #define CI_DECL(D, L)                                                                          \
   extern "C" void* ci_gibbs_fn_d##D##_l##L(int);                                              \
-  extern "C" void* ci_gibbs8_fn_d##D##_l##L(int, size_t*);                                    \
+  extern "C" void* ci_gibbs8_fn_d##D##_l##L(int, int, size_t*);                               \
   extern "C" void ci_launch_dk_d##D##_l##L(int, const float*, const uint8_t*, float, float,    \
                                            float, float, float, float, uint32_t, uint32_t,     \
                                            uint32_t, uint32_t, float*);                           \
@@ -155,8 +155,8 @@ static __global__ void hmc_unpack_kernel(int N, int P, const double* __restrict_
 
 namespace {
 using KernelFn = void (*)(ci::KArgs);
-KernelFn pick_kernel8(int D, int L, int profiled, size_t* lds_base) {
-#define CI_CASE5(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs8_fn_d##DD##_l##LL(profiled, lds_base);
+KernelFn pick_kernel8(int D, int L, int profiled, int xg, size_t* lds_base) {
+#define CI_CASE5(DD, LL) if (D == DD && L == LL) return (KernelFn)ci_gibbs8_fn_d##DD##_l##LL(profiled, xg, lds_base);
   CI_CASE5(1, 1) CI_CASE5(1, 2) CI_CASE5(1, 4) CI_CASE5(1, 8) CI_CASE5(1, 16)
   CI_CASE5(2, 1) CI_CASE5(2, 2) CI_CASE5(2, 4) CI_CASE5(2, 8) CI_CASE5(2, 16)
 #undef CI_CASE5
@@ -651,19 +651,27 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     int num_cus = 256;
     (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, pb->device);
     const bool latency_regime = (long long)B * C <= (long long)num_cus;
-    if (pm == 1 && latency_regime && !(pb->flags & CI_FLAG_FOUR_WAVES)) {
+    if ((pm == 1 || pm == 3) && latency_regime && !(pb->flags & CI_FLAG_FOUR_WAVES)) {
+      // the design in LDS when it fits beside the randomness buffers, else read from L2 (the
+      // same sums in the same order: the same bits)
       size_t base8 = 0;
-      KernelFn f8 = pick_kernel8(D, s->L, 0, &base8);
-      const size_t lds8 = base8 + (size_t)P * ci::NT * s->L * sizeof(float);
+      KernelFn f8 = pick_kernel8(D, s->L, 0, 0, &base8);
+      size_t lds8 = base8 + (size_t)P * ci::NT * s->L * sizeof(float);
+      int xg = 0;
+      if (!f8 || lds8 > 160 * 1024) {
+        f8 = pick_kernel8(D, s->L, 0, 1, &base8);
+        lds8 = base8;
+        xg = 1;
+      }
       if (f8 && lds8 <= 160 * 1024) {
         s->fn = f8;
-        s->fn_prof5 = pick_kernel8(D, s->L, 1, nullptr);
+        s->fn_prof5 = xg ? nullptr : pick_kernel8(D, s->L, 1, 0, nullptr);
         if (s->fn_prof5)
           HIP_TRY(hipFuncSetAttribute((const void*)s->fn_prof5,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
         s->five_waves = true;
         s->lds_bytes = lds8;
-        snprintf(nm, sizeof(nm), "ci::gibbs_kernel8<%d,%d>", D, s->L);
+        snprintf(nm, sizeof(nm), xg ? "ci::gibbs_kernel8<%d,%d,L2>" : "ci::gibbs_kernel8<%d,%d>", D, s->L);
         s->kernel_name = nm;
       }
     }

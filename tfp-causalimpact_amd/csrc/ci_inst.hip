@@ -37,19 +37,26 @@ void* CI_CAT(ci_gibbs_fn_d, CI_D, _l, CI_L)(int pm) {
   return nullptr;
 }
 
-// The eight-wavefront latency build of the PM = 1 kernel (ci_kernels8.h); *lds_base = its LDS
-// bytes without the design (+ P * 256 * L * 4 for the design).
-void* CI_CAT(ci_gibbs8_fn_d, CI_D, _l, CI_L)(int profiled, size_t* lds_base) {
-#if CI_L <= 8
+// The eight-wavefront latency build of the register-resident kernels (ci_kernels8.h).  xg = 0: the
+// design copied to LDS (*lds_base = its LDS bytes without the design, + P * 256 * L * 4 for it);
+// xg = 1: the design read from L2 (*lds_base = everything).
+void* CI_CAT(ci_gibbs8_fn_d, CI_D, _l, CI_L)(int profiled, int xg, size_t* lds_base) {
   if (lds_base) *lds_base = ci::Lay8<CI_D, CI_L>::off_x;
+  if (xg) {
+#if CI_L >= 8
+    return profiled ? nullptr : (void*)(&ci::gibbs_kernel8<CI_D, CI_L, false, true>);
+#else
+    return nullptr;
+#endif
+  }
+#if CI_L <= 8
 #if CI_D == 2 && CI_L == 4
   // the instrumented variant exists for the bench shape only (ci_session_profile)
-  if (profiled) return (void*)(&ci::gibbs_kernel8<CI_D, CI_L, true>);
+  if (profiled) return (void*)(&ci::gibbs_kernel8<CI_D, CI_L, true, false>);
 #endif
-  return profiled ? nullptr : (void*)(&ci::gibbs_kernel8<CI_D, CI_L, false>);
+  return profiled ? nullptr : (void*)(&ci::gibbs_kernel8<CI_D, CI_L, false, false>);
 #else
-  (void)profiled; (void)lds_base;
-  return nullptr;      // T > 2048: the design does not fit LDS beside the randomness buffers
+  return nullptr;      // T > 2048: no room for the design in LDS
 #endif
 }
 

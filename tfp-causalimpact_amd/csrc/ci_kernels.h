@@ -374,20 +374,18 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // ------------------------------------------------------------------------------------
 constexpr int RED_YTY = 16;        // slot of y'y in the new layout of `red`
 constexpr int RED_INC = 20;        // then (ss_level, ss_slope) per time wave
-template <int L, int NF>
+// XG: the design is NOT in LDS (long series): rows of T floats in global memory (L2-resident),
+// read as float4 when `xwide` (T % 4 == 0 and 16-byte aligned rows), else as guarded scalars;
+// chunks beyond the series read as zeros.  Same values, same order => same bits as the LDS variant.
+template <int L, int NF, bool XG = false>
 __device__ __forceinline__ void xt_sums_wave(const float* tg, const float* Xs, int tpad, int P, int j0,
-                                             bool with_yty, float* sums, int lane) {
+                                             bool with_yty, float* sums, int lane, int T = 0,
+                                             bool xwide = true) {
   float4 tq[L];
 #pragma unroll
   for (int c = 0; c < L; ++c) tq[c] = *reinterpret_cast<const float4*>(tg + 4 * (lane + 64 * c));
   float acc[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    const int j = j0 + f;
-    const float* row = Xs + (size_t)(j < P ? j : P - 1) * tpad;
-    float4 xq[L];
-#pragma unroll
-    for (int c = 0; c < L; ++c) xq[c] = *reinterpret_cast<const float4*>(row + 4 * (lane + 64 * c));
+  auto dot = [&](const float4 (&xq)[L]) {
     float sv = 0.f;
 #pragma unroll
     for (int c = 0; c < L; ++c) {
@@ -396,7 +394,49 @@ __device__ __forceinline__ void xt_sums_wave(const float* tg, const float* Xs, i
       sv = fmaf(xq[c].z, tq[c].z, sv);
       sv = fmaf(xq[c].w, tq[c].w, sv);
     }
-    acc[f] = sv;
+    return sv;
+  };
+  if constexpr (!XG) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int j = j0 + f;
+      const float* row = Xs + (size_t)(j < P ? j : P - 1) * tpad;
+      float4 xq[L];
+#pragma unroll
+      for (int c = 0; c < L; ++c) xq[c] = *reinterpret_cast<const float4*>(row + 4 * (lane + 64 * c));
+      acc[f] = dot(xq);
+    }
+  } else if (xwide) {
+    // (the choice of the row source is hoisted out of the feature loop: a branch around a load
+    //  makes the compiler wait for it at the join)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int j = j0 + f;
+      const float* row = Xs + (size_t)(j < P ? j : P - 1) * T;
+      float4 xq[L];
+#pragma unroll
+      for (int c = 0; c < L; ++c) {
+        const int t = 4 * (lane + 64 * c);
+        const float4 x = *reinterpret_cast<const float4*>(row + (t < T ? t : T - 4));
+        xq[c] = t < T ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      acc[f] = dot(xq);
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int j = j0 + f;
+      const float* row = Xs + (size_t)(j < P ? j : P - 1) * T;
+      float4 xq[L];
+#pragma unroll
+      for (int c = 0; c < L; ++c) {
+        const int t = 4 * (lane + 64 * c);
+        const float x0 = row[t < T ? t : T - 1], x1 = row[t + 1 < T ? t + 1 : T - 1];
+        const float x2 = row[t + 2 < T ? t + 2 : T - 1], x3 = row[t + 3 < T ? t + 3 : T - 1];
+        xq[c] = make_float4(t < T ? x0 : 0.f, t + 1 < T ? x1 : 0.f, t + 2 < T ? x2 : 0.f, t + 3 < T ? x3 : 0.f);
+      }
+      acc[f] = dot(xq);
+    }
   }
 #pragma unroll
   for (int f = 0; f < NF; ++f) acc[f] = wave_prefix_dpp(acc[f]);
@@ -2115,8 +2155,8 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_gam = take(sizeof(double) * (8 + 64 + 4));   // gamma draws (wave 1) and regression-block randomness
                                                  // (wave 2) handed to the serial wave, double-buffered
   l.off_nz0 = take(sizeof(float) * (4 * 64 * (tpad / NT) + 4));   // wave 0's normals, drawn by waves 1-3
-  // targets y - level over time, handed to the waves that sum X~'targets (P <= 16, X in LDS)
-  l.off_tgv = take((x_in_lds && P > 0 && P <= 16) ? sizeof(float) * (size_t)tpad : 16);
+  // targets y - level over time, handed to the waves that sum X~'targets (P <= 16)
+  l.off_tgv = take((P > 0 && P <= 16) ? sizeof(float) * (size_t)tpad : 16);
   l.off_x = take(x_in_lds ? sizeof(float) * (size_t)Pp * tpad : 16);
   l.total = o;
   return l;
@@ -2248,7 +2288,7 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   // function holding both cost the 512-series batch 7 %)
   constexpr int RPM = (PM == 3) ? 1 : PM;
   constexpr bool STREAM = PM == 3;
-  constexpr bool NEWRED = PM == 1;        // xt_sums_wave's layout of `red` (shared with the eight-wave kernel)
+  constexpr bool NEWRED = RPM == 1;       // xt_sums_wave's layout of `red` (shared with the eight-wave kernel)
   using PF = typename std::conditional<PROF, Prof, NoProf>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2426,52 +2466,11 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
       }
       prof.tick(15);
       if constexpr (RPM == 1) {
-        // register-resident path: 16 independent accumulators, DPP reductions interleave
-        float pj[16];
-        if constexpr (!STREAM) {
-          // X in LDS: the targets go to the shared vector; after (B1) every wave sums four
-          // features over the WHOLE series (xt_sums_wave: no cross-wave reduction, no gather)
-          store_targets<L>(tgv, t0, tg);
-        } else {
-          // long series: T x P floats no longer fit LDS and the design streams from L2 -- the
-          // regression block stays in registers all the same.  Rows in batches of independent
-          // loads (as many as 32 registers hold), unused batches skipped.
-          constexpr int RB = L >= 16 ? 2 : (L >= 8 ? 4 : 8);
-          auto stream = [&](auto load_row) {
-#pragma unroll
-            for (int h = 0; h < 16 / RB; ++h) {
-              if (h * RB >= P) {
-#pragma unroll
-                for (int u = 0; u < RB; ++u) pj[h * RB + u] = 0.f;
-                continue;
-              }
-              float xr[RB][L];
-#pragma unroll
-              for (int u = 0; u < RB; ++u) load_row(h * RB + u < P ? h * RB + u : P - 1, xr[u]);
-#pragma unroll
-              for (int u = 0; u < RB; ++u) {
-                float sv = 0.f;
-#pragma unroll
-                for (int l = 0; l < L; ++l) sv = fmaf(xr[u][l], tg[l], sv);
-                pj[h * RB + u] = sv;
-              }
-            }
-          };
-          if (xwide) {
-            if constexpr (L % 4 == 0)
-              stream([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xg + (size_t)j * T, t0, T, xr); });
-          } else {
-            stream([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); });
-          }
-        }
+        // register-resident regression block: the targets go to the shared vector; after (B1) every
+        // wave sums four features over the WHOLE series (xt_sums_wave: no cross-wave reduction, no
+        // gather) -- from the LDS copy of the design, or (PM = 3, long series) from L2
+        store_targets<L>(tgv, t0, tg);
         prof.tick(16);
-        if constexpr (STREAM) {
-          // 16 wave sums as ONE reduce-scatter: lane l ends up with the total of feature l & 15
-          // (15 DPP exchange-adds + two cross-row shuffles instead of 16 six-step prefix chains),
-          // stored by lanes 0..15 in a single instruction
-          const float tot = wave_reduce_scatter16(pj, lane);
-          if (lane < 16) red[wave * RS + lane] = tot;
-        }
       } else if constexpr (RPM == 2) {
         // 16 features per round: their rows are independent loads (one L2 round trip per batch of
         // 8 when X streams from L2, instead of one per feature) and their wave sums ONE
@@ -2510,7 +2509,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
       xlast[tid * D] = lev[L - 1];
       if constexpr (D == 2) xlast[tid * D + 1] = slp[L - 1];
       __syncthreads();
-      if constexpr (NEWRED) xt_sums_wave<L, 4>(tgv, Xs, TPAD, P, 4 * wave, wave == NW - 1, red, lane);
+      if constexpr (NEWRED)
+        xt_sums_wave<L, 4, STREAM>(tgv, STREAM ? Xg : Xs, TPAD, P, 4 * wave, wave == NW - 1, red, lane, T, xwide);
       float ssl = 0.f, sss = 0.f;
       float pl = (tid > 0) ? xlast[(tid - 1) * D] : 0.f;
       float ps = 0.f;

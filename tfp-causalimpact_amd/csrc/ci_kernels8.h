@@ -398,8 +398,8 @@ template <int D, int L> struct Lay8 {
   static constexpr size_t off_gam = off_xlast + a16((size_t)NT * D * sizeof(float));
   static constexpr size_t off_pre = off_gam + a16((8 + 64 + 4) * sizeof(double));
   static constexpr size_t off_tgv = off_pre + a16(pre_tables_bytes());
-  static constexpr size_t off_z = off_tgv + TP * sizeof(float);          // 2 x (zl, zs, zo)
-  static constexpr size_t off_x = off_z + 6 * TP * sizeof(float);
+  static constexpr size_t off_z = off_tgv + TP * sizeof(float);          // zl, zs, zo
+  static constexpr size_t off_x = off_z + 3 * TP * sizeof(float);
   static __host__ __device__ constexpr size_t total(int P) { return off_x + (size_t)P * TP * sizeof(float); }
 };
 // indices into `scal` beyond enum Scal: prior moments, then the x_0 normals of even / odd iterations
@@ -414,7 +414,9 @@ enum Scal8 { SC8_INIT_LOC = 8, SC8_INIT_VAR = 9, SC8_INIT_SVAR = 10, SC8_ZINIT =
 //                       18 = wait at (Bs)   23 = weights + scale draws   17 = wait at (B3)
 //                       19 = precompute steps (pure)   29 = its waits at (B4) (B5)
 //   randomness wave 5:  30 = work   31 = waits at barriers
-template <int D, int L, bool PROF = false>
+// XG: the design stays in global memory (L2) -- series too long for a copy in LDS beside the
+// randomness buffers (T > ~1500 with a dozen columns, every T > 2048).
+template <int D, int L, bool PROF = false, bool XG = false>
 __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
   using PF = typename std::conditional<PROF, Prof, NoProf>::type;
   using LY = Lay8<D, L>;
@@ -433,7 +435,6 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
   float* tgv = (float*)(smem + LY::off_tgv);
   float* zb = (float*)(smem + LY::off_z);
   double* gam = (double*)(smem + LY::off_gam);
-  const float* Xs = (const float*)(smem + LY::off_x);
   const size_t chain_lin = (size_t)series * a.C + chain;
   const int n_iter = a.W + a.S;
 
@@ -445,6 +446,10 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
   const float* yg = a.y + (size_t)series * T;
   const uint8_t* mg = a.mask + (size_t)series * T;
   const float* Xg = a.Xt + (size_t)series * P * T;
+  // the design as the sums / products read it: the LDS copy (rows of TPAD floats), or the
+  // global rows of T floats (float4 reads need T % 4 == 0 and 16-byte aligned rows)
+  const float* Xs = XG ? Xg : (const float*)(smem + LY::off_x);
+  const bool xwide = L % 4 == 0 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(Xg) & 15) == 0;
   RegLds R;
   R.xtx = (double*)(smem + LY::off_xtx);
   R.omega = (double*)(smem + LY::off_omega);
@@ -478,9 +483,11 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
       R.xtx[e] = a.xtx[(size_t)series * P * P + e];
       R.omega[e] = a.omega[(size_t)series * P * P + e];
     }
-    float* xw_ = (float*)(smem + LY::off_x);
-    for (int j = 0; j < P; ++j)
-      for (int t = tid; t < TPAD; t += NT8) xw_[j * TPAD + t] = (t < T) ? Xg[(size_t)j * T + t] : 0.f;
+    if constexpr (!XG) {
+      float* xw_ = (float*)(smem + LY::off_x);
+      for (int j = 0; j < P; ++j)
+        for (int t = tid; t < TPAD; t += NT8) xw_[j * TPAD + t] = (t < T) ? Xg[(size_t)j * T + t] : 0.f;
+    }
     if (tid < 16) wls[tid] = 0.f;                   // weights = 0            :575-578
   }
   __syncthreads();
@@ -507,8 +514,8 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     PF eprof;
     eprof.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && wave == NW + 1 && lane == 0);
     auto normals_round = [&](int k, uint32_t it_for) __attribute__((always_inline)) {
-      // the disturbances of the draw of iteration it_for, into that iteration's half of zb;
-      // task-major: all chunks of a kind, then the next kind
+      // the disturbances of the draw of iteration it_for; task-major: all chunks of a kind, then
+      // the next kind
       const int task = k / L, blk = k - task * L;
       const int slot = (D == 2) ? task : (task == 0 ? 0 : 2);            // D = 1 has no slope row
       const uint32_t site = slot == 0 ? SITE_PRIOR_LEVEL : (slot == 1 ? SITE_PRIOR_SLOPE : SITE_PRIOR_OBS);
@@ -516,8 +523,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
       const U4 r = site_call(rng, it_for, site, 0, (uint32_t)c);
       float z[4];
       normals4(r, z);
-      *reinterpret_cast<float4*>(zb + ((size_t)(it_for & 1u) * 3 + slot) * TPAD + 4 * c) =
-          make_float4(z[0], z[1], z[2], z[3]);
+      *reinterpret_cast<float4*>(zb + (size_t)slot * TPAD + 4 * c) = make_float4(z[0], z[1], z[2], z[3]);
     };
     auto role_work = [&](int it_next) __attribute__((always_inline)) {
       if (it_next > n_iter) return;
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     for (int it = 0; it <= n_iter; ++it) {
       __syncthreads();                                   // (B1)
       eprof.tick(31);
-      xt_sums_wave<L, 2>(tgv, Xs, TPAD, P, 2 * wave, wave == NW8 - 1, red, lane);
+      xt_sums_wave<L, 2, XG>(tgv, Xs, TPAD, P, 2 * wave, wave == NW8 - 1, red, lane, T, xwide);
       eprof.tick(30);
       __syncthreads();                                   // (B2)
       eprof.tick(31);
@@ -570,8 +576,8 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
                           lane, wls);
         }
       }
-      // the rounds of normals for iteration it + 1 (zb is double-buffered by the parity of the
-      // iteration, so they may run anywhere in this iteration)
+      // the rounds of normals for iteration it + 1: after (Bs) -- the time waves have read this
+      // iteration's normals in the window before it -- and before (B1) of the next iteration
       int r = 0;
       if (it < n_iter)
         for (; r < r_3; ++r) normals_round(k_lo + r, (uint32_t)(it + 1));
@@ -618,7 +624,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
       // from here to sigma^2_obs this wave is the critical path of the iteration and shares its
       // SIMD with time wave 0, which has slack until (Bs): win the issue arbitration while it lasts
       __builtin_amdgcn_s_setprio(3);
-      xt_sums_wave<L, 2>(tgv, Xs, TPAD, P, 2 * wave, false, red, lane);
+      xt_sums_wave<L, 2, XG>(tgv, Xs, TPAD, P, 2 * wave, false, red, lane, T, xwide);
       __syncthreads();                                   // (B2) all sums complete
       rprof.tick(16);
       const PreTables tb = pre_tables_at(pre_base, it);
@@ -774,7 +780,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
       if constexpr (D == 2) xlast[tid * D + 1] = slp[L - 1];
     }
     __syncthreads();                                       // (B1)
-    xt_sums_wave<L, 2>(tgv, Xs, TPAD, P, 2 * wave, false, red, lane);
+    xt_sums_wave<L, 2, XG>(tgv, Xs, TPAD, P, 2 * wave, false, red, lane, T, xwide);
     {
       float ssl = 0.f, sss = 0.f;
       float pl = (tid > 0) ? xlast[(tid - 1) * D] : 0.f;
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     // ---- window: the normals of this iteration from LDS, emission of draw it-1, this iteration's
     // disturbance scales, first half of the prior-simulation scan
     float zl[L], zs[L], zo[L];
-    const float* zit = zb + (size_t)(it & 1) * 3 * TPAD + t0;
+    const float* zit = zb + t0;
     lds_row_load<L>(zit, zl);
     if constexpr (D == 2) {
       lds_row_load<L>(zit + TPAD, zs);
@@ -938,14 +944,41 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     {
       float wv[16];
       lds_row_load<16>(wls, wv);           // the weights vector is padded to 16 floats
+      if constexpr (!XG) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int jj = j < P ? j : P - 1;
-        const float wj = j < P ? wv[j] : 0.f;
-        float xr[L];
-        lds_row_load<L>(Xs + jj * TPAD + t0, xr);
+        for (int j = 0; j < 16; ++j) {
+          const int jj = j < P ? j : P - 1;
+          const float wj = j < P ? wv[j] : 0.f;
+          float xr[L];
+          lds_row_load<L>(Xs + jj * TPAD + t0, xr);
 #pragma unroll
-        for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
+          for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
+        }
+      } else {
+        // the streamed design: rows in batches of independent loads, unused batches skipped (the
+        // same sums in the same order as above)
+        constexpr int RB = L >= 16 ? 2 : (L >= 8 ? 4 : 8);
+        auto stream = [&](auto load_row) __attribute__((always_inline)) {
+#pragma unroll
+          for (int h = 0; h < 16 / RB; ++h) {
+            if (h * RB >= P) continue;
+            float xr[RB][L];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) load_row(h * RB + u < P ? h * RB + u : P - 1, xr[u]);
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+              const float wj = h * RB + u < P ? wv[h * RB + u] : 0.f;
+#pragma unroll
+              for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[u][l], wj, xw[l]);
+            }
+          }
+        };
+        if (xwide) {
+          if constexpr (L % 4 == 0)
+            stream([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xg + (size_t)j * T, t0, T, xr); });
+        } else {
+          stream([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); });
+        }
       }
     }
 #pragma unroll

@@ -144,8 +144,8 @@ def _pmc_traffic(sampler):
   """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (profiles/*pmc.json, written by
   tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command) and the
   file it came from -- the fallback of _measure_traffic."""
-  names = (("r03_cfg3_pmc.json", "r02_cfg3_pmc.json") if sampler == "hmc" else
-           ("r03_pmc.json", "r02_pmc.json"))
+  names = (("r04_cfg3_pmc.json", "r03_cfg3_pmc.json", "r02_cfg3_pmc.json") if sampler == "hmc" else
+           ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"))
   for name in names:
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):

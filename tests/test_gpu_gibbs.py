@@ -303,9 +303,9 @@ def test_baseline_cfg5_full_size_batch_equals_single_series_runs_and_oracle():
     s1.close()
     for k in ("level", "weights", "observation_noise_scale"):
       np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
-    # the oracle's stream word: chain id + (series id << 16)
-    w = orc.fit_gibbs(ys[b], masks[b], Xs[b], specs[b], num_results=S, num_warmup=W, seed=(5, 12),
-                      chain=b << 16)
+    # the stream of series b: key word 1 = seed1 ^ series id (counter word 3 = the chain id)
+    w = orc.fit_gibbs(ys[b], masks[b], Xs[b], specs[b], num_results=S, num_warmup=W, seed=(5, 12 ^ b),
+                      chain=0)
     np.testing.assert_allclose(batch["level"][b, 0], w["level"], atol=5e-3)
     np.testing.assert_allclose(batch["weights"][b, 0], w["weights"], atol=5e-3)
 
@@ -405,6 +405,29 @@ def test_eight_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, 
   if p >= 5:   # inclusion patterns do change during the run: the fall-back route is exercised
     incl = (w != 0)
     assert (incl[:, :, 1:] != incl[:, :, :-1]).any()
+
+
+def test_series_and_chain_ids_beyond_16_bits_have_their_own_streams():
+  """Series ids enter the Philox key (seed1 ^ series id), chain ids the counter word: neither is
+  limited to 16 bits any more (rounds 1-3 packed both into one counter word).  Series 70001 with
+  chain ids 66000, 66001, against the oracle on the same stream."""
+  T, p, W, S = 160, 3, 4, 6
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 31)
+  spec = orc.default_spec(y, mask, X, has_slope=True)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=1, num_warmup=W, num_results=S, num_chains=2,
+                            chain_offset=66000, seed=(9, 77), series_offset=70001)
+  got = _native.fit_gibbs(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  for c in range(2):
+    want = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=(9, 77 ^ 70001),
+                         chain=66000 + c)
+    np.testing.assert_array_equal(got["weights"][0, c] != 0, want["weights"] != 0)
+    np.testing.assert_allclose(got["level"][0, c], want["level"], atol=5e-3)
+    np.testing.assert_allclose(got["observation_noise_scale"][0, c], want["obs_scale"], rtol=5e-3)
+  # and it is a different stream from series 0 / chain 0
+  pb0 = _native.make_problem(T=T, P=p + 1, has_slope=1, num_warmup=W, num_results=S, num_chains=1,
+                             seed=(9, 77))
+  base = _native.fit_gibbs(pb0, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  assert np.abs(base["level"][0, 0] - got["level"][0, 0]).max() > 1e-3
 
 
 @pytest.mark.parametrize("T,p,has_slope", [(1000, 10, 1), (500, 5, 0), (180, 2, 1)])

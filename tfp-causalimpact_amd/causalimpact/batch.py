@@ -328,9 +328,6 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
   flags = (~np.asarray(idx < prep.post_period[0])).astype(np.uint8) | (in_post.astype(np.uint8) << 1)
   observed = values[:, prep.model_rows, 0].copy()
   observed[:, prep.num_pre:][:, ~in_post[prep.num_pre:]] = np.nan
-  if not shared_streams and (B > 65536 or C > 65536):
-    raise ValueError("per-series random streams pack (series id, chain id) into 16 bits each: "
-                     "batches beyond 65,536 series or chains need shared_streams=True")
   devs = list(inference_options.devices) if inference_options.devices else [0]
   shards = [s for s in np.array_split(np.arange(B), len(devs)) if len(s)]
 

@@ -571,11 +571,7 @@ static int validate(const ci_problem* pb) {
   if (pb->num_warmup < 0 || pb->num_results < 1) return fail("need num_warmup >= 0, num_results >= 1");
   if (pb->num_chains < 1 || pb->num_series < 1) return fail("need num_chains >= 1, num_series >= 1");
   if (pb->series_offset < 0 || pb->chain_offset < 0) return fail("series_offset and chain_offset must be >= 0");
-  if (!(pb->flags & CI_FLAG_SHARED_SERIES_STREAMS) && (pb->series_offset + pb->num_series > 1)) {
-    // series id and chain id share one 32-bit stream word (16 bits each)
-    if (pb->series_offset + pb->num_series > 65536 || pb->chain_offset + pb->num_chains > 65536)
-      return fail("per-series random streams need series ids and chain ids below 65536");
-  }
+  // (series ids enter the Philox key, chain ids the counter: no packing limit on either)
   if (pb->num_blocks == 0 && steps_per_thread(pb->T) == 0 &&
       wide_steps_per_thread(pb->T) > ci::WIDE_MAX_LC)
     return fail("T=%d exceeds the longest supported series (%d)", pb->T, ci::NT * ci::WIDE_MAX_LC);

@@ -78,12 +78,15 @@ struct KArgs {
                            // timing-independence test; 0 in production
 };
 
-// Counter word 3 of the Philox stream: the global chain id in the low 16 bits' range, the global
-// series id above it.  Series 0 (every single-series fit) keeps the plain chain id, so results of
-// one series do not depend on whether it was fitted alone or as series 0 of a batch.
-__host__ __device__ inline uint32_t stream_id(int chain_global, int series_stream_base, int series) {
+// The random stream of (series, chain): Philox counter word 3 = the global chain id (all 32 bits),
+// key = (seed0, seed1 ^ series id).  Series 0 -- every single-series fit -- keeps the plain seeds,
+// so the result of a series does not depend on whether it was fitted alone or as series 0 of a
+// batch; distinct series ids give distinct keys, i.e. independent streams.  (Rounds 1-3 packed
+// series and chain id into the counter word, 16 bits each: batches beyond 65,536 series or chains
+// were refused.)
+__host__ __device__ inline uint32_t stream_key1(uint32_t seed1, int series_stream_base, int series) {
   const uint32_t sid = series_stream_base < 0 ? 0u : (uint32_t)(series_stream_base + series);
-  return (uint32_t)chain_global + (sid << 16);
+  return seed1 ^ sid;
 }
 
 // ------------------------------------------------------------------------------------
@@ -2310,8 +2313,8 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
 
   Rng rng;
   rng.k0 = a.seed0;
-  rng.k1 = a.seed1;
-  rng.chain = stream_id(a.chain_offset + chain, a.series_stream_base, series);
+  rng.k1 = stream_key1(a.seed1, a.series_stream_base, series);
+  rng.chain = (uint32_t)(a.chain_offset + chain);
 
   // ---- stage the constants of this series
   const float* yg = a.y + (size_t)series * T;

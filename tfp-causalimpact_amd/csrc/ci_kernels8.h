@@ -278,11 +278,21 @@ __device__ __forceinline__ double spike_slab_draw_pre(const RegLds& R, int P,
   // own column j from the row-major copy in LDS -- 16 independent loads, no cross-lane traffic;
   // the four rows of 16 lanes compute replicas
   {
+    // (rows in groups of four, groups beyond P skipped: the branch is uniform and sits around a
+    //  whole group of independent loads)
     double v[16], bk[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      v[k] = tb.V[k * 16 + j];
-      bk[k] = (double)red[k < P ? k : 0];
+    for (int g = 0; g < 4; ++g) {
+      if (4 * g < P) {
+#pragma unroll
+        for (int k = 4 * g; k < 4 * g + 4; ++k) {
+          v[k] = tb.V[k * 16 + j];
+          bk[k] = (double)red[k];        // (red[P .. 15] hold nothing: masked by S below)
+        }
+      } else {
+#pragma unroll
+        for (int k = 4 * g; k < 4 * g + 4; ++k) { v[k] = 0.0; bk[k] = 0.0; }
+      }
     }
     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -440,8 +450,8 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
 
   Rng rng;
   rng.k0 = a.seed0;
-  rng.k1 = a.seed1;
-  rng.chain = stream_id(a.chain_offset + chain, a.series_stream_base, series);
+  rng.k1 = stream_key1(a.seed1, a.series_stream_base, series);
+  rng.chain = (uint32_t)(a.chain_offset + chain);
 
   const float* yg = a.y + (size_t)series * T;
   const uint8_t* mg = a.mask + (size_t)series * T;

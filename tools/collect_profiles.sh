@@ -4,7 +4,7 @@
 # rocprofv3 runs from /tmp with TMPDIR=/tmp; PMC counters are collected in their own passes
 # (never together with trace domains).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

@@ -2,7 +2,7 @@
 # Copies the summaries the judge reads from gpurun_out/<tag>/ (tools/collect_profiles.sh) into
 # profiles/ under the round's names:   tools/publish_profiles.sh r03
 set -eu
-TAG=${1:-r03}
+TAG=${1:-r04}
 SRC=gpurun_out/$TAG
 P=profiles
 R=$TAG

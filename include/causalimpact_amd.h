@@ -88,10 +88,10 @@ typedef struct ci_problem {
  * reproduces a single-series fit of series b draw for draw; Monte-Carlo errors are perfectly
  * correlated across the batch).  Off by default. */
 #define CI_FLAG_SHARED_SERIES_STREAMS 2
-/* Use the four-wavefront Gibbs kernel where the five-wavefront latency build (a dedicated
- * regression wave that sweeps the next iteration's matrix during the Durbin-Koopman draw) would
- * be chosen.  Same sampler, random stream and roundings: the two builds give bit-identical
- * draws, so this only changes the timing; test / diagnostic knob. */
+/* Use the four-wavefront Gibbs kernel where the eight-wavefront latency build (four time waves,
+ * a regression wave that sweeps the next iteration's matrix during the Durbin-Koopman draw, three
+ * randomness waves) would be chosen.  Same sampler, random stream and roundings: the two builds
+ * give bit-identical draws, so this only changes the timing; test / diagnostic knob. */
 #define CI_FLAG_FOUR_WAVES 4
 /* Sequential seasonal kernel: keep its arrays over time in the per-chain HBM workspace even when
  * they would fit in LDS (the library does so by itself for long series / many covariates).

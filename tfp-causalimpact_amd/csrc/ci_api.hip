@@ -756,7 +756,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       HIP_TRY(s->csync.alloc((size_t)B * C * ci::CL_INTS));
       HIP_TRY(s->cpart.alloc((size_t)B * C * (nseg > 0 ? nseg : 1) * ci::NW * RS));
       HIP_TRY(s->cw.alloc((size_t)B * C * 64));
-      HIP_TRY(s->cv.alloc((size_t)B * C * (P + 1) * (P + 1)));
+      HIP_TRY(s->cv.alloc((size_t)B * C * ci::presweep_doubles(P)));
     }
     else if (s->seasonal_ws_bytes > 0) HIP_TRY(s->ws.alloc((size_t)B * C * (s->seasonal_ws_bytes / sizeof(float))));
     if (K > 0) HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));

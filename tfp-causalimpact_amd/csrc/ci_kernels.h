@@ -1148,6 +1148,12 @@ struct RegLds {
 // the pivot row / column are rewritten afterwards (LDS operations of one wave complete in
 // program order, so the later stores win).  n, np <= 64; tmp: 128 doubles.
 __host__ __device__ inline size_t sweep_padded(size_t entries) { return (entries + 1023) & ~(size_t)1023; }
+// LDS doubles behind an m x m matrix of the regression block: enough for the one-wavefront sweeps
+// (sweep_padded) and for the workgroup-wide ones (rows padded to 16, sweep_cols_block)
+__host__ __device__ inline size_t block_matrix_doubles(int m) {
+  const size_t a = sweep_padded((size_t)m * m), b = (((size_t)m + 15) & ~(size_t)15) * m;
+  return a > b ? a : b;
+}
 
 __device__ __forceinline__ void sweep_one(double* __restrict__ M, int m, const double* __restrict__ t,
                                           int k, double sgn, int lane) {
@@ -1825,56 +1831,161 @@ __device__ __noinline__ double spike_slab_draw_big(const RegLds& R, WT* w, int P
 // spread their entries over all 256 threads.  Barriers are __syncthreads(); every thread returns
 // the same new observation-noise scale.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void sweep_one_block(double* __restrict__ M, int m,
-                                                const double* __restrict__ t, int k, double sgn,
-                                                int tid) {
+// Sweep of the symmetric m x m matrix M (LDS, row-major) on pivot k by the whole workgroup, ONE
+// barrier per sweep.  Thread (wave w, lane) owns column `lane` and the rows w, w + NW, ...: its
+// column's pivot-row entry stays in a register, a row's entry is a broadcast read, and the matrix
+// itself is read and written once, lanes on consecutive doubles (conflict-free), eight rows in
+// flight per thread.  Who writes what:
+//   * general entries (i != k, j != k): the owning thread, before the barrier;
+//   * column k (i != k): wave (k + 1) % NW with lane = row, before the barrier -- nobody reads
+//     column k during a sweep (the pivot row is read as ROW k);
+//   * row k: its owning wave AFTER the barrier (everyone has read it by then), which is
+//     sweep_rowk_finish -- the caller runs it before the next sweep's reads of this thread's rows
+//     (same threads own row k in every sweep: program order suffices).
+// `keep` (wave k % NW, may be null) receives the pivot row as it was before the sweep.
+// Arithmetic: the expressions of sweep_one / sweep_one_block, entry for entry.
+struct RowK { double pv; int k; bool mine; };
+// rows of the LDS allocation behind an m x m matrix that the block sweeps may touch: the row loop
+// runs in unguarded groups of NW * 4 rows (whatever lands in the padding rows is never read)
+__host__ __device__ constexpr size_t block_rows_padded(int m) { return ((size_t)m + 15) & ~(size_t)15; }
+__device__ __forceinline__ RowK sweep_cols_block(double* __restrict__ M, int m, int k, double sgn,
+                                                 int lane, int w, double* keep) {
+  RowK out; out.pv = 0.0; out.k = k; out.mine = false;
+  if (lane >= m) return out;
+  const double* t = M + k * m;                    // the pivot row, intact until the barrier
   const double rd = fast_rcp(t[k]);
-  const int qd = NT / m, rm = NT - qd * m;       // (i, j) of entry e + 256 from (i, j) of entry e
-  int i = tid / m, j = tid - i * m;
-  const int trips = (m * m + 1023) >> 10;
-  double* Me = M + tid;
-#pragma unroll 1
-  for (int it = 0; it < trips; ++it) {
-    double mv[4], ti[4], tj[4];
+  const double tj = t[lane];
+  out.pv = (lane == k) ? -rd : sgn * tj * rd;
+  out.mine = (k & (NW - 1)) == w;
+  if (out.mine && keep) keep[lane] = tj;
+  if (w == ((k + 1) & (NW - 1)) && lane != k) M[lane * m + k] = sgn * tj * rd;   // column k, row `lane`
+  if (lane != k) {
+    constexpr int R = 4;
+    double* Mc = M + w * m + lane;                // row w, this lane's column; rows advance by NW
+    const double* tw = t + w;
+    const int step = NW * m;
+    const int kslot = out.mine ? (k >> 2) : -1;   // row k = w + NW * kslot of the owning wave
+    for (int s0 = 0; NW * s0 + w < m; s0 += R) {
+      double mv[R], ti[R];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      mv[u] = Me[NT * u];
-      ti[u] = t[i];
-      tj[u] = t[j];
-      j += rm; i += qd;
-      if (j >= m) { j -= m; ++i; }
+      for (int u = 0; u < R; ++u) {
+        mv[u] = Mc[u * step];
+        ti[u] = tw[NW * u];
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+        if (s0 + u != kslot) Mc[u * step] = mv[u] - (ti[u] * rd) * tj;     // (never the pivot row)
+      Mc += R * step;
+      tw += R * NW;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) Me[NT * u] = mv[u] - (ti[u] * rd) * tj[u];
-    Me += 4 * NT;
   }
+  return out;
 }
-// tmp: 256 doubles (pivot rows of both matrices, padded so that the gathers of padding entries
-// stay in bounds).
+__device__ __forceinline__ void sweep_rowk_finish(double* M, int m, const RowK& rk, int lane,
+                                                  int skip_col = -1) {
+  if (rk.mine && lane < m && lane != skip_col) M[(size_t)rk.k * m + lane] = rk.pv;
+}
+// Sweeps A (n x n) and, `with_prior`, Pm (np x np) on pivot k; keepA [n] (may be null) receives
+// A's pivot row as it was before the sweep: ascending sweeps of a set S record the Cholesky factor
+// of the S-block that way (spike_slab_draw_block).  Ends with the matrices complete and a barrier.
 __device__ __forceinline__ void sweep_pair_block(double* A, int n, double* Pm, int np, int k,
                                                  bool reverse, bool with_prior, int tid,
-                                                 double* tmp) {
+                                                 double* keepA) {
   const double sgn = reverse ? -1.0 : 1.0;
-  if (tid < 128) tmp[tid] = tid < n ? A[k * n + tid] : 1.0;
-  else tmp[tid] = (with_prior && tid - 128 < np) ? Pm[k * np + (tid - 128)] : 1.0;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const RowK ra = sweep_cols_block(A, n, k, sgn, lane, w, keepA);
+  RowK rp; rp.mine = false; rp.k = k; rp.pv = 0.0;
+  if (with_prior) rp = sweep_cols_block(Pm, np, k, sgn, lane, w, nullptr);
   __syncthreads();
-  sweep_one_block(A, n, tmp, k, sgn, tid);
-  if (with_prior) sweep_one_block(Pm, np, tmp + 128, k, sgn, tid);
-  __syncthreads();       // general entries written before the pivot row / column are rewritten
-  if (tid < n) {
-    const double rd = fast_rcp(tmp[k]);
-    const double pv = (tid == k) ? -rd : sgn * tmp[tid] * rd;
-    A[k * n + tid] = pv;
-    A[tid * n + k] = pv;
-  } else if (with_prior && tid >= 128 && tid - 128 < np) {
-    const int l = tid - 128;
-    const double rd = fast_rcp(tmp[128 + k]);
-    const double pv = (l == k) ? -rd : sgn * tmp[128 + l] * rd;
-    Pm[k * np + l] = pv;
-    Pm[l * np + k] = pv;
+  sweep_rowk_finish(A, n, ra, lane);
+  if (with_prior) sweep_rowk_finish(Pm, np, rp, lane);
+  __syncthreads();
+}
+// A run of sweeps of A (n x n, LDS) alone on the features of `todo` in ascending order -- the
+// sweep-in of every iteration -- with the matrix held in REGISTERS for the duration: thread
+// (a, b) = (tid / NB, tid % NB), NB = ceil(n / 4), owns the 4 x 4 tile of rows 4a.. and columns
+// 4b..  A sweep is then: the owners of pivot row k publish it (as it is before the sweep) to row r
+// of `rec`, ONE barrier, every thread reads its four column entries, its four row entries and the
+// pivot from that row (3 LDS reads, one round trip) and updates its tile with 16 FMAs.  The LDS
+// form of the same sweep (sweep_cols_block) moves the whole matrix through LDS per pivot and is
+// bound by that; this one by the publish -> barrier -> read -> reciprocal chain (~0.7k cycles).
+// Entry for entry the arithmetic of sweep_one: M_ij - (t_i / t_k) t_j, pivot row and column
+// t / t_k, pivot -1 / t_k.  rec: [popcount(todo)][REC_LD], the pivot rows -- which are the
+// Cholesky factor of the swept block (spike_slab_draw_block).  Ends with A complete and a barrier.
+constexpr int REC_LD = 56;      // doubles per recorded pivot row: >= MAXP + 1, a multiple of 4
+// one sweep of the register-resident tiles on pivot k = 4 ka + KR (KR static: the pivot's row and
+// column inside a tile are compile-time register indices)
+template <int KR>
+__device__ __forceinline__ void sweep_tile_step(double (&m)[4][4], int ka, int a, int b, bool live,
+                                                double* st) {
+  if (live && a == ka) {
+    *reinterpret_cast<double2*>(st + 4 * b) = make_double2(m[KR][0], m[KR][1]);
+    *reinterpret_cast<double2*>(st + 4 * b + 2) = make_double2(m[KR][2], m[KR][3]);
+  }
+  __syncthreads();
+  if (!live) return;
+  const double2 c01 = *reinterpret_cast<const double2*>(st + 4 * b);
+  const double2 c23 = *reinterpret_cast<const double2*>(st + 4 * b + 2);
+  const double2 r01 = *reinterpret_cast<const double2*>(st + 4 * a);
+  const double2 r23 = *reinterpret_cast<const double2*>(st + 4 * a + 2);
+  const double tk = st[4 * ka + KR];
+  const double tj[4] = {c01.x, c01.y, c23.x, c23.y};
+  const double ti[4] = {r01.x, r01.y, r23.x, r23.y};
+  const double rd = fast_rcp(tk);
+  double q[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) q[x] = ti[x] * rd;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) m[x][y] = m[x][y] - q[x] * tj[y];
+  const bool colk = b == ka, rowk = a == ka;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) m[x][KR] = colk ? q[x] : m[x][KR];            // column k: t_i / t_k
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {                                               // row k: t_j / t_k, pivot
+    double pv = tj[y] * rd;
+    if (y == KR) pv = colk ? -rd : pv;
+    m[KR][y] = rowk ? pv : m[KR][y];
+  }
+}
+__device__ __forceinline__ void sweep_run_block(double* A, int n, unsigned long long todo, int tid,
+                                                double* rec) {
+  const int NB = (n + 3) >> 2;
+  const int a = tid / NB, b = tid - a * NB;
+  const bool live = a < NB;
+  double m[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int i = 4 * a + x, j = 4 * b + y;
+      m[x][y] = (live && i < n && j < n) ? A[i * n + j] : 0.0;
+    }
+  double* st = rec;
+  for (int ka = 0; ka < NB; ++ka) {
+    const unsigned four = (unsigned)(todo >> (4 * ka)) & 15u;
+    if (four == 0u) continue;
+    if (four & 1u) { sweep_tile_step<0>(m, ka, a, b, live, st); st += REC_LD; }
+    if (four & 2u) { sweep_tile_step<1>(m, ka, a, b, live, st); st += REC_LD; }
+    if (four & 4u) { sweep_tile_step<2>(m, ka, a, b, live, st); st += REC_LD; }
+    if (four & 8u) { sweep_tile_step<3>(m, ka, a, b, live, st); st += REC_LD; }
+  }
+  if (live) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const int i = 4 * a + x, j = 4 * b + y;
+        if (i < n && j < n) A[i * n + j] = m[x][y];
+      }
   }
   __syncthreads();
 }
+
+// LDS doubles behind R.chol: the recorded pivot rows of the sweep-in ([P][REC_LD]) -- or the explicit
+// Cholesky factor ([P][P]).
+__host__ __device__ constexpr size_t block_chol_doubles(int P) { return (size_t)P * REC_LD; }
 
 // The data-independent part of the regression block's matrix: [Omega s2 + X'X, 0; 0, 0] swept on
 // the features of `nzmask` (the border stays zero).  What is left for the iteration itself is to
@@ -1884,7 +1995,6 @@ __device__ __forceinline__ void sweep_pair_block(double* A, int n, double* Pm, i
 __device__ __forceinline__ void presweep_block(const RegLds& R, int P, double prev_var,
                                                unsigned long long nzmask, bool with_prior, int tid) {
   const int n = P + 1;
-  double* tmp = R.chol;
   {
     int i = tid / n, j = tid - (tid / n) * n;
     const int qd = NT / n, rm = NT - qd * n;
@@ -1897,8 +2007,26 @@ __device__ __forceinline__ void presweep_block(const RegLds& R, int P, double pr
     }
   }
   __syncthreads();
-  for (unsigned long long todo = nzmask; todo; todo &= todo - 1ull)
-    sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, with_prior, tid, tmp);
+  if (with_prior) {
+    int r = 0;
+    for (unsigned long long todo = nzmask; todo; todo &= todo - 1ull, ++r)
+      sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, true, tid,
+                       R.chol + (size_t)r * REC_LD);
+  } else {
+    sweep_run_block(R.aug[0], n, nzmask, tid, R.chol);
+  }
+}
+
+// What another workgroup needs to take presweep_block's result over: the matrix and the recorded
+// pivot rows, (P + 1)^2 + popcount(nzmask) * REC_LD doubles (presweep_doubles(P) at most).
+__host__ __device__ constexpr size_t presweep_doubles(int P) {
+  return (size_t)(P + 1) * (P + 1) + (size_t)P * REC_LD;
+}
+__device__ __forceinline__ void presweep_export(const RegLds& R, int P, unsigned long long nzmask,
+                                                double* dst, int tid) {
+  const int n = P + 1, nrec = __popcll(nzmask) * REC_LD;
+  for (int e = tid; e < n * n; e += NT) dst[e] = R.aug[0][e];
+  for (int e = tid; e < nrec; e += NT) dst[n * n + e] = R.chol[e];
 }
 
 // split: the matrix comes from presweep_block -- computed here, or copied from `presweep`
@@ -1911,13 +2039,17 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
                                                         const Rng& rng, uint32_t iter, int tid,
                                                         bool first, Prof* prof = nullptr,
                                                         bool split = false,
-                                                        const double* presweep = nullptr) {
+                                                        const double* presweep = nullptr,
+                                                        int slot0 = 4) {
   const int lane = tid & 63;
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
-  double* tmp = R.chol;            // free until the final Cholesky (P > 16 => P*P >= 256)
+  // R.chol: the pivot rows of the sweep-in, one per swept feature in ascending order ([na][n]),
+  // then two staging rows for the other sweeps
+  double* rec = R.chol;
+  bool clean = true;               // rec holds the factor of the final model's block
   if (split) {
     if (first)
       for (int e = tid; e < P * P; e += NT) R.pri[0][e] = R.omega[e];
@@ -1943,14 +2075,22 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
     if (!all_in) R.uperm[tid] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)tid);
   }
   __syncthreads();
-  if (prof) prof->tick(4);
+  if (prof) prof->tick(slot0);
   const unsigned long long nzmask = __ballot(nz0 != 0);
   if (!split) {
-    for (unsigned long long todo = nzmask; todo; todo &= todo - 1ull)
-      sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, first, tid, tmp);
+    if (first) {
+      int r = 0;
+      for (unsigned long long todo = nzmask; todo; todo &= todo - 1ull, ++r)
+        sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, true, tid,
+                         rec + (size_t)r * REC_LD);
+    } else {
+      sweep_run_block(R.aug[0], n, nzmask, tid, rec);
+    }
   } else {
-    if (presweep) {
+    if (presweep) {     // the swept matrix, then the pivot rows of its sweeps (presweep_export)
       for (int e = tid; e < n * n; e += NT) R.aug[0][e] = presweep[e];
+      const int nrec = __popcll(nzmask) * REC_LD;
+      for (int e = tid; e < nrec; e += NT) rec[e] = presweep[n * n + e];
       __syncthreads();
     } else {
       presweep_block(R, P, prev_var, nzmask, first, tid);
@@ -1978,7 +2118,7 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
     }
     __syncthreads();
   }
-  if (prof) prof->tick(5);
+  if (prof) prof->tick(slot0 + 1);
   if (!all_in) {
     if (tid < P) {
       const double uj = R.uperm[tid];
@@ -1990,45 +2130,45 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       R.perm[rank] = tid;
     }
     __syncthreads();
-    const double logit_pi = log(sp.nonzero_prob) - log1p(-sp.nonzero_prob);
+    const double logit_pi =
+        (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
+    const double inv_prev_var = fast_rcp(prev_var);
     const int myj = lane < P ? R.perm[lane] : 0;
     const double myu = lane < P ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)lane) : 2.0;
     int s_cur = 0;
     while (true) {
       bool flip = false;
       if (lane < P && lane >= s_cur) {
+        // the same expression as the register-resident block's (spike_slab_draw_regs)
         const double* A = R.aug[0];
         const bool in = R.nz[myj] != 0;
         const double ajj = A[myj * n + myj], ajb = A[myj * n + P], corner = A[P * n + P];
         const double pju = R.pri[0][myj * P + myj];      // unit scale
+        const double sg = in ? -1.0 : 1.0;
+        const double rap = fast_rcp(sg * ajj);           // 1 / Schur pivot (out) or 1 / V_jj (in)
         const double beta_old = sp.obs_scale + 0.5 * corner;
-        double delta;
-        if (!in) {
-          const double pjj = pju * prev_var;
-          const double beta_new = sp.obs_scale + 0.5 * (corner - ajb * ajb / ajj);
-          delta = 0.5 * log(pjj) - 0.5 * log(ajj) + logit_pi -
-                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
-        } else {
-          const double V = -ajj, Vp = -pju / prev_var;
-          const double beta_new = sp.obs_scale + 0.5 * (corner + ajb * ajb / V);
-          delta = 0.5 * log(Vp) - 0.5 * log(V) - logit_pi -
-                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
-        }
-        flip = myu < 1.0 / (1.0 + exp(-delta));
+        const double x = -0.5 * sg * ajb * ajb * rap * fast_rcp(beta_old);
+        const double pscale = in ? inv_prev_var : prev_var;
+        const double delta = 0.5 * (double)__logf((float)(sg * pju * pscale * rap)) +
+                             sg * logit_pi - (a_post - 1.0) * fast_log1p(x);
+        const float prob = 1.0f / (1.0f + __expf(-(float)delta));
+        flip = myu < (double)prob;
       }
       const unsigned long long bal = __ballot(flip);     // identical in every wave
+      if (prof && prof->p) prof->p[bal == 0ull ? 30 : 31] += 1;   // evaluation rounds / accepted flips
       if (bal == 0ull) break;
       const int s_star = __ffsll((long long)bal) - 1;
       const int j = R.perm[s_star];
       const bool in = R.nz[j] != 0;
       __syncthreads();                                   // everyone has read nz / the matrices
-      sweep_pair_block(R.aug[0], n, R.pri[0], P, j, in, true, tid, tmp);
+      sweep_pair_block(R.aug[0], n, R.pri[0], P, j, in, true, tid, nullptr);
       if (tid == 0) R.nz[j] = in ? 0 : 1;
       __syncthreads();
+      clean = false;
       s_cur = s_star + 1;
     }
   }
-  if (prof) prof->tick(6);
+  if (prof) prof->tick(slot0 + 2);
   const double* A = R.aug[0];
   const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
   double var = beta_post / g_obs;
@@ -2045,51 +2185,79 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
     if (lane < P) R.w[lane] = 0.f;
   }
   __syncthreads();
-  // M_S = Omega_S * prev_var + XtX_S, then a right-looking Cholesky by the whole workgroup, one
-  // barrier per column: the Schur-complement entries (i, j), k < j <= i, take their k-th term
-  // (the same products, in the same order, as a left-looking factorisation); column k of L goes
-  // to the UPPER triangle (row k) and its diagonal to ldiag, so that nothing a concurrent thread
-  // still reads is overwritten.  Reciprocal square roots instead of divisions.
-  double* ldiag = R.uperm;                 // (the permutation keys are no longer needed)
-  for (int e = tid; e < na * na; e += NT) {
-    const int i = e / na, j = e - i * na;
-    const int fi = R.idx[i], fj = R.idx[j];
-    R.chol[e] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
-  }
-  if (tid < na) R.zv[tid] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[tid]);
-  __syncthreads();
-  for (int k = 0; k < na; ++k) {
-    const double skk = R.chol[k * na + k];
-    const double rs = fast_rsqrt(skk);
-    for (int i = k + 1 + (tid >> 4); i < na; i += NT / 16) {
-      const double lik = R.chol[i * na + k] * rs;
-      for (int j = k + 1 + (tid & 15); j <= i; j += 16)
-        R.chol[i * na + j] -= lik * (R.chol[j * na + k] * rs);
-      if ((tid & 15) == 0) R.chol[k * na + i] = lik;
+  if (clean) {
+    // No flip was accepted: the model is the one swept in at the top, in ascending order -- and the
+    // pivot rows of those sweeps ARE the Cholesky factor of M_S = Omega_S s2 + X'X_S: with pivot
+    // r on feature f_r, rec[r][f_j] = L_jr L_rr for j > r and rec[r][f_r] = L_rr^2.  Solve
+    // L' u = z from them (column-oriented back substitution, lane l holds z_l).
+    if (tid < 64) {
+      const int f = lane < na ? R.idx[lane] : 0;
+      const double rs = lane < na ? fast_rsqrt(rec[(size_t)lane * REC_LD + f]) : 1.0;    // 1 / L_ll
+      float zf[1];
+      fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)f, zf);
+      double z = lane < na ? (double)zf[0] : 0.0;
+      double u = 0.0;
+      int fi = na > 0 ? __builtin_amdgcn_readlane(f, na - 1) : 0;
+      double lnext = lane < na - 1 ? rec[(size_t)lane * REC_LD + fi] * rs : 0.0;     // L[na-1][lane]
+      for (int i = na - 1; i >= 0; --i) {
+        const double li = lnext;
+        if (i > 0) {
+          fi = __builtin_amdgcn_readlane(f, i - 1);
+          lnext = lane < i - 1 ? rec[(size_t)lane * REC_LD + fi] * rs : 0.0;
+        }
+        const double ui = readlane_d(z, i) * readlane_d(rs, i);
+        if (lane == i) u = ui;
+        if (lane < i) z -= li * ui;
+      }
+      if (lane < na) R.w[f] = (float)(A[f * n + P] + new_scale * u);
     }
-    if (tid == 0) ldiag[k] = skk * rs;
+  } else {
+    // M_S = Omega_S * prev_var + XtX_S, then a right-looking Cholesky by the whole workgroup, one
+    // barrier per column: the Schur-complement entries (i, j), k < j <= i, take their k-th term
+    // (the same products, in the same order, as a left-looking factorisation); column k of L goes
+    // to the UPPER triangle (row k) and its diagonal to ldiag, so that nothing a concurrent thread
+    // still reads is overwritten.  Reciprocal square roots instead of divisions.
+    double* ldiag = R.uperm;                 // (the permutation keys are no longer needed)
+    for (int e = tid; e < na * na; e += NT) {
+      const int i = e / na, j = e - i * na;
+      const int fi = R.idx[i], fj = R.idx[j];
+      R.chol[e] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
+    }
+    if (tid < na) R.zv[tid] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[tid]);
     __syncthreads();
-  }
-  if (tid < 64) {
-    // solve L' u = z (column-oriented back substitution) in registers: lane l holds z_l
-    double z = lane < na ? R.zv[lane] : 0.0;
-    const double dl = lane < na ? ldiag[lane] : 1.0;
-    double u = 0.0;
-    double lnext = (na > 0 && lane < na - 1) ? R.chol[lane * na + (na - 1)] : 0.0;
-    for (int i = na - 1; i >= 0; --i) {
-      const double li = lnext;                          // L[i][lane] (stored at row lane, column i)
-      if (i > 0) lnext = lane < i - 1 ? R.chol[lane * na + (i - 1)] : 0.0;
-      const double ui = readlane_d(z, i) * fast_rcp(readlane_d(dl, i));
-      if (lane == i) u = ui;
-      if (lane < i) z -= li * ui;
+    for (int k = 0; k < na; ++k) {
+      const double skk = R.chol[k * na + k];
+      const double rs = fast_rsqrt(skk);
+      for (int i = k + 1 + (tid >> 4); i < na; i += NT / 16) {
+        const double lik = R.chol[i * na + k] * rs;
+        for (int j = k + 1 + (tid & 15); j <= i; j += 16)
+          R.chol[i * na + j] -= lik * (R.chol[j * na + k] * rs);
+        if ((tid & 15) == 0) R.chol[k * na + i] = lik;
+      }
+      if (tid == 0) ldiag[k] = skk * rs;
+      __syncthreads();
     }
-    if (lane < na) {
-      const int f = R.idx[lane];
-      R.w[f] = (float)(A[f * n + P] + new_scale * u);
+    if (tid < 64) {
+      // solve L' u = z (column-oriented back substitution) in registers: lane l holds z_l
+      double z = lane < na ? R.zv[lane] : 0.0;
+      const double dl = lane < na ? ldiag[lane] : 1.0;
+      double u = 0.0;
+      double lnext = (na > 0 && lane < na - 1) ? R.chol[lane * na + (na - 1)] : 0.0;
+      for (int i = na - 1; i >= 0; --i) {
+        const double li = lnext;                          // L[i][lane] (stored at row lane, column i)
+        if (i > 0) lnext = lane < i - 1 ? R.chol[lane * na + (i - 1)] : 0.0;
+        const double ui = readlane_d(z, i) * fast_rcp(readlane_d(dl, i));
+        if (lane == i) u = ui;
+        if (lane < i) z -= li * ui;
+      }
+      if (lane < na) {
+        const int f = R.idx[lane];
+        R.w[f] = (float)(A[f * n + P] + new_scale * u);
+      }
     }
   }
   __syncthreads();
-  if (prof) prof->tick(7);
+  if (prof) prof->tick(slot0 + 3);
   return new_scale;
 }
 
@@ -2138,11 +2306,11 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_ctx = take(sizeof(SerialCtx));
   l.off_xtx = take(sizeof(double) * Pp * Pp);
   l.off_omega = take(sizeof(double) * Pp * Pp);
-  l.off_aug0 = take(sizeof(double) * sweep_padded((size_t)(Pp + 1) * (Pp + 1)));
+  l.off_aug0 = take(sizeof(double) * block_matrix_doubles(Pp + 1));
   l.off_aug1 = take(16);      // (sweeps are in place: no second buffer)
-  l.off_pri0 = take(sizeof(double) * sweep_padded((size_t)Pp * Pp));
+  l.off_pri0 = take(sizeof(double) * block_matrix_doubles(Pp));
   l.off_pri1 = take(16);
-  l.off_chol = take(sizeof(double) * Pp * Pp);
+  l.off_chol = take(sizeof(double) * block_chol_doubles(Pp));
   l.off_bvec = take(sizeof(double) * (Pp + 4));
   l.off_zv = take(sizeof(double) * Pp);
   l.off_uperm = take(sizeof(double) * Pp);
@@ -2607,8 +2775,10 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
     if constexpr (RPM == 2) {
       if (P > 16 && it < n_iter) {
         // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
+        Prof bp;
+        bp.start(a.prof, PROF && a.prof != nullptr && blockIdx.x == 0 && tid == 0);
         const double ns = spike_slab_draw_block(R, P, cx->sp, gam[72], gam[73], rng, (uint32_t)it, tid,
-                                                it == 0);
+                                                it == 0, PROF ? &bp : nullptr, false, nullptr, 9);
         if (tid == 0) {
           cx->obs_scale = ns;
           scal[SC_OBS_DK] = (float)ns;

@@ -53,7 +53,7 @@ struct SArgs {
   int* csync;                        //   [B*C][32] handshake counters, zeroed before the launch
   float* cpart;                      //   [B*C][segments][4][RS] partial sums of X~'targets, y'y
   float* cw;                         //   [B*C][64] weights + emission scale of the iteration
-  double* cv;                        //   [B*C][(P+1)^2] regression matrix swept ahead (presweep_block)
+  double* cv;                        //   [B*C][presweep_doubles(P)] regression matrix swept ahead + its pivot rows (presweep_export)
   size_t ws_stride;                  // sequential kernel: bytes of `ws` per chain (arrays over time when
                                      //   they are not in LDS, then the P > MAXP regression block)
   // Sequential kernel, LATENTS-ONLY mode (the pass after an HMC fit, ci_ll_session_hmc_run): block n

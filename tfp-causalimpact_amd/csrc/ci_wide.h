@@ -301,11 +301,11 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   const bool big = P > 16;    // the LDS-resident regression block is only used for P > 16
   l.xtx = take(sizeof(double) * Pp * Pp);
   l.omega = take(sizeof(double) * Pp * Pp);
-  l.aug0 = take(big ? sizeof(double) * sweep_padded((size_t)(Pp + 1) * (Pp + 1)) : 16);
+  l.aug0 = take(big ? sizeof(double) * block_matrix_doubles(Pp + 1) : 16);
   l.aug1 = take(16);
-  l.pri0 = take(big ? sizeof(double) * sweep_padded((size_t)Pp * Pp) : 16);
+  l.pri0 = take(big ? sizeof(double) * block_matrix_doubles(Pp) : 16);
   l.pri1 = take(16);
-  l.chol = take(big ? sizeof(double) * Pp * Pp : 16);   // also the sweeps' pivot-row scratch
+  l.chol = take(big ? sizeof(double) * block_chol_doubles(Pp) : 16);   // recorded pivot rows / Cholesky + staging
   l.bvec = take(sizeof(double) * (Pp + 4));
   l.zv = take(sizeof(double) * Pp);
   l.uperm = take(sizeof(double) * Pp);
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const bool light = cmode == 2;
   float* cpart = a.cpart + chain_lin * (size_t)nseg * NW * RS;
   float* cw = a.cw + chain_lin * 64;
-  double* cv = a.cv + chain_lin * (size_t)(P + 1) * (P + 1);
+  double* cv = a.cv + chain_lin * presweep_doubles(P);
   const int clo = (int)((long long)(TP >> 2) * role / G), chi = (int)((long long)(TP >> 2) * (role + 1) / G);
   const int n_iter = g.W + g.S;
 
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         const bool all_in = sp.nonzero_prob >= 1.0;
         const unsigned long long nzmask = __ballot(lane < P && (all_in || R.w[lane < P ? lane : 0] != 0.f));
         presweep_block(R, P, so_d * so_d, nzmask, false, tid);
-        for (int e = tid; e < (P + 1) * (P + 1); e += NT) cv[e] = R.aug[0][e];
+        presweep_export(R, P, nzmask, cv, tid);
         cl_publish(csync + CL_V, it + 1, tid, light);
       }
     }

@@ -50,6 +50,11 @@ def main():
                   (27, "dk: forward chunk of the means"), (28, "dk: backward scan")):
     print(f"  [{i:2d}] {name:34s} {cyc[i] / n_it:9.0f} cyc/iter  {100.0 * cyc[i] / top:5.1f} %")
   print(f"  total of phases 0-7, 24-28: {top / n_it:.0f} cyc/iter")
+  if pb.P > 16 and "kernel8" not in sess.kernel_name():
+    print("  workgroup-wide regression block (thread 0): [9] build, [10] sweep-in, [11] flips, "
+          "[12] Cholesky + weights")
+    print(f"       evaluation rounds per iteration {(cyc[30] + cyc[31]) / n_it:.2f}, accepted flips "
+          f"{cyc[31] / n_it:.2f}")
   if "kernel8" in sess.kernel_name():
     print("  eight-wave kernel, time thread 0:")
     for i, name in ((0, "targets .. (B2)"), (2, "window: normals from LDS, emission (+ its normals), scales, prior scan"),

@@ -1912,7 +1912,7 @@ __device__ __forceinline__ void sweep_pair_block(double* A, int n, double* Pm, i
 // Entry for entry the arithmetic of sweep_one: M_ij - (t_i / t_k) t_j, pivot row and column
 // t / t_k, pivot -1 / t_k.  rec: [popcount(todo)][REC_LD], the pivot rows -- which are the
 // Cholesky factor of the swept block (spike_slab_draw_block).  Ends with A complete and a barrier.
-constexpr int REC_LD = 56;      // doubles per recorded pivot row: >= MAXP + 1, a multiple of 4
+constexpr int REC_LD = 64;      // doubles per recorded pivot row: >= MAXP + 1, a multiple of 16
 // one sweep of the register-resident tiles on pivot k = 4 ka + KR (KR static: the pivot's row and
 // column inside a tile are compile-time register indices)
 template <int KR>
@@ -1949,8 +1949,10 @@ __device__ __forceinline__ void sweep_tile_step(double (&m)[4][4], int ka, int a
     m[KR][y] = rowk ? pv : m[KR][y];
   }
 }
+// `init(i, j)`: the matrix entry before the run (read from A, or built on the spot).
+template <class Init>
 __device__ __forceinline__ void sweep_run_block(double* A, int n, unsigned long long todo, int tid,
-                                                double* rec) {
+                                                double* rec, Init init) {
   const int NB = (n + 3) >> 2;
   const int a = tid / NB, b = tid - a * NB;
   const bool live = a < NB;
@@ -1960,7 +1962,7 @@ __device__ __forceinline__ void sweep_run_block(double* A, int n, unsigned long 
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
       const int i = 4 * a + x, j = 4 * b + y;
-      m[x][y] = (live && i < n && j < n) ? A[i * n + j] : 0.0;
+      m[x][y] = (live && i < n && j < n) ? init(i, j) : 0.0;
     }
   double* st = rec;
   for (int ka = 0; ka < NB; ++ka) {
@@ -2013,7 +2015,8 @@ __device__ __forceinline__ void presweep_block(const RegLds& R, int P, double pr
       sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, true, tid,
                        R.chol + (size_t)r * REC_LD);
   } else {
-    sweep_run_block(R.aug[0], n, nzmask, tid, R.chol);
+    const double* A = R.aug[0];
+    sweep_run_block(R.aug[0], n, nzmask, tid, R.chol, [&](int i, int j) { return A[i * n + j]; });
   }
 }
 
@@ -2053,7 +2056,7 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   if (split) {
     if (first)
       for (int e = tid; e < P * P; e += NT) R.pri[0][e] = R.omega[e];
-  } else {
+  } else if (first) {
     int i = tid / n, j = tid - (tid / n) * n;
     const int qd = NT / n, rm = NT - qd * n;
     for (int e = tid; e < n * n; e += NT) {
@@ -2070,11 +2073,8 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   // per-feature state is computed redundantly by every wave (lane = feature), written once
   int nz0 = 0;
   if (lane < P) nz0 = all_in ? 1 : (R.w[lane] != 0.f ? 1 : 0);
-  if (tid < P) {
-    R.nz[tid] = nz0;
-    if (!all_in) R.uperm[tid] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)tid);
-  }
-  __syncthreads();
+  if (tid < P) R.nz[tid] = nz0;
+  if (split || first) __syncthreads();
   if (prof) prof->tick(slot0);
   const unsigned long long nzmask = __ballot(nz0 != 0);
   if (!split) {
@@ -2084,7 +2084,14 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
         sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, true, tid,
                          rec + (size_t)r * REC_LD);
     } else {
-      sweep_run_block(R.aug[0], n, nzmask, tid, rec);
+      // [[Omega s2 + X'X, X'r], [r'X, r'r]] built straight into the sweeps' registers
+      const double* om = R.omega; const double* xx = R.xtx; const double* bv = R.bvec;
+      sweep_run_block(R.aug[0], n, nzmask, tid, rec, [&](int i, int j) {
+        const int ic = i < P ? i : P - 1, jc = j < P ? j : P - 1;
+        const double inner = om[ic * P + jc] * prev_var + xx[ic * P + jc];
+        const double edge = bv[(i == P && j == P) ? P : (i < j ? i : j)];
+        return (i < P && j < P) ? inner : edge;
+      });
     }
   } else {
     if (presweep) {     // the swept matrix, then the pivot rows of its sweeps (presweep_export)
@@ -2120,20 +2127,25 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   }
   if (prof) prof->tick(slot0 + 1);
   if (!all_in) {
-    if (tid < P) {
-      const double uj = R.uperm[tid];
-      int rank = 0;
-      for (int k = 0; k < P; ++k) {
-        const double uk = R.uperm[k];
-        rank += (uk < uj || (uk == uj && k < tid)) ? 1 : 0;
-      }
-      R.perm[rank] = tid;
+    // visiting order = stable argsort of P uniforms, in registers, every wave for itself: rank by
+    // the raw 32-bit words (u01d is strictly increasing in them), ties by index; the inverse
+    // permutation is one ds_permute (lane rank_j receives j)
+    uint32_t rw = 0xffffffffu;
+    if (lane < P) {
+      const U4 r4 = site_call(rng, iter, SITE_PERM, 0, (uint32_t)lane >> 2);
+      const uint32_t c = (uint32_t)lane & 3u;
+      rw = c == 0 ? r4.x : c == 1 ? r4.y : c == 2 ? r4.z : r4.w;
     }
-    __syncthreads();
+    int rank = 0;
+    for (int k = 0; k < P; ++k) {
+      const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)rw, k);
+      rank += (rk < rw || (rk == rw && k < lane)) ? 1 : 0;
+    }
+    if (lane >= P) rank = lane;
+    const int myj = __builtin_amdgcn_ds_permute(rank << 2, lane);      // feature visited at step `lane`
     const double logit_pi =
         (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
     const double inv_prev_var = fast_rcp(prev_var);
-    const int myj = lane < P ? R.perm[lane] : 0;
     const double myu = lane < P ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)lane) : 2.0;
     int s_cur = 0;
     while (true) {
@@ -2158,7 +2170,7 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       if (prof && prof->p) prof->p[bal == 0ull ? 30 : 31] += 1;   // evaluation rounds / accepted flips
       if (bal == 0ull) break;
       const int s_star = __ffsll((long long)bal) - 1;
-      const int j = R.perm[s_star];
+      const int j = __builtin_amdgcn_readlane(myj, s_star);
       const bool in = R.nz[j] != 0;
       __syncthreads();                                   // everyone has read nz / the matrices
       sweep_pair_block(R.aug[0], n, R.pri[0], P, j, in, true, tid, nullptr);
@@ -2171,47 +2183,52 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   if (prof) prof->tick(slot0 + 2);
   const double* A = R.aug[0];
   const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
-  double var = beta_post / g_obs;
+  double var = beta_post * fast_rcp(g_obs);
   if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
-  const double new_scale = sqrt(var);
+  const double new_scale = (double)__fsqrt_rn((float)var);
 
-  // active set in increasing feature order (every wave computes it, wave 0 stores it)
   const int mynz = (lane < P) ? R.nz[lane] : 0;
-  const unsigned long long bal = __ballot(mynz != 0);
+  const unsigned long long bal = __ballot(mynz != 0);   // the final model (every wave computes it)
   const int na = __popcll(bal);
-  __syncthreads();                         // tmp (== chol) and w are about to be rewritten
-  if (tid < 64) {
-    if (mynz) R.idx[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
-    if (lane < P) R.w[lane] = 0.f;
-  }
-  __syncthreads();
   if (clean) {
     // No flip was accepted: the model is the one swept in at the top, in ascending order -- and the
     // pivot rows of those sweeps ARE the Cholesky factor of M_S = Omega_S s2 + X'X_S: with pivot
     // r on feature f_r, rec[r][f_j] = L_jr L_rr for j > r and rec[r][f_r] = L_rr^2.  Solve
-    // L' u = z from them (column-oriented back substitution, lane l holds z_l).
+    // L' u = z from them by column-oriented back substitution, lane = feature: lane f holds z_f
+    // and row rank(f) of rec, sixteen columns of it at a time.
     if (tid < 64) {
-      const int f = lane < na ? R.idx[lane] : 0;
-      const double rs = lane < na ? fast_rsqrt(rec[(size_t)lane * REC_LD + f]) : 1.0;    // 1 / L_ll
+      const bool in_s = ((bal >> lane) & 1ull) != 0ull;
+      const double* row = rec + (size_t)__popcll(bal & ((1ull << lane) - 1ull)) * REC_LD;
+      const double rs = in_s ? fast_rsqrt(row[lane]) : 0.0;          // 1 / L_ff
       float zf[1];
-      fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)f, zf);
-      double z = lane < na ? (double)zf[0] : 0.0;
+      fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)lane, zf);
+      double z = in_s ? (double)zf[0] : 0.0;
       double u = 0.0;
-      int fi = na > 0 ? __builtin_amdgcn_readlane(f, na - 1) : 0;
-      double lnext = lane < na - 1 ? rec[(size_t)lane * REC_LD + fi] * rs : 0.0;     // L[na-1][lane]
-      for (int i = na - 1; i >= 0; --i) {
-        const double li = lnext;
-        if (i > 0) {
-          fi = __builtin_amdgcn_readlane(f, i - 1);
-          lnext = lane < i - 1 ? rec[(size_t)lane * REC_LD + fi] * rs : 0.0;
+      for (int g0 = (P - 1) & ~15; g0 >= 0; g0 -= 16) {
+        double lr[16];
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+          const double2 v = *reinterpret_cast<const double2*>(row + g0 + c);
+          lr[c] = in_s ? v.x : 0.0; lr[c + 1] = in_s ? v.y : 0.0;
         }
-        const double ui = readlane_d(z, i) * readlane_d(rs, i);
-        if (lane == i) u = ui;
-        if (lane < i) z -= li * ui;
+#pragma unroll
+        for (int c = 15; c >= 0; --c) {
+          const int g = g0 + c;
+          if (!((bal >> g) & 1ull)) continue;
+          const double ug = readlane_d(z, g) * readlane_d(rs, g);
+          if (lane == g) u = ug;
+          if (lane < g) z -= (lr[c] * rs) * ug;          // L[g][f] = rec[rank f][g] / L_ff
+        }
       }
-      if (lane < na) R.w[f] = (float)(A[f * n + P] + new_scale * u);
+      if (lane < P) R.w[lane] = in_s ? (float)(A[lane * n + P] + new_scale * u) : 0.f;
     }
   } else {
+    __syncthreads();                         // chol and w are about to be rewritten
+    if (tid < 64) {                          // active set in increasing feature order
+      if (mynz) R.idx[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
+      if (lane < P) R.w[lane] = 0.f;
+    }
+    __syncthreads();
     // M_S = Omega_S * prev_var + XtX_S, then a right-looking Cholesky by the whole workgroup, one
     // barrier per column: the Schur-complement entries (i, j), k < j <= i, take their k-th term
     // (the same products, in the same order, as a left-looking factorisation); column k of L goes
@@ -2453,7 +2470,9 @@ template <int D, int L, int PM, bool PROF = false>
 #ifndef CI_MIN_WAVES
 #define CI_MIN_WAVES 2
 #endif
-__global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
+// (PM = 2 -- more than 16 columns -- holds > 80 KB of LDS: one workgroup per CU whatever the
+//  registers, so it is compiled for one wave per SIMD and takes its spills in the AGPR half)
+__global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
   // PM = 3: the register-resident regression block (PM = 1) with the design STREAMED from L2 --
   // its own instantiation, so that the loops of the LDS-resident build stay what they were (one
   // function holding both cost the 512-series batch 7 %)
@@ -2643,23 +2662,25 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         store_targets<L>(tgv, t0, tg);
         prof.tick(16);
       } else if constexpr (RPM == 2) {
-        // 16 features per round: their rows are independent loads (one L2 round trip per batch of
-        // 8 when X streams from L2, instead of one per feature) and their wave sums ONE
+        // 16 features per round: their rows are independent loads (one L2 round trip per round
+        // when X streams from L2, instead of one per feature; the kernel is compiled for one wave
+        // per SIMD, the rows in flight live in its register half) and their wave sums ONE
         // reduce-scatter.  The row source is chosen outside the loop (see global_row_load_wide).
         auto xt_rounds = [&](auto load_row) {
           for (int j0 = 0; j0 < P; j0 += 16) {
             float pj[16];
+            constexpr int XB = L <= 4 ? 16 : (L == 8 ? 8 : 4);   // rows in flight: at most 64 registers
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              float xr[8][L];
+            for (int h = 0; h < 16 / XB; ++h) {
+              float xr[XB][L];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) load_row(j0 + 8 * h + u < P ? j0 + 8 * h + u : P - 1, xr[u]);
+              for (int u = 0; u < XB; ++u) load_row(j0 + XB * h + u < P ? j0 + XB * h + u : P - 1, xr[u]);
 #pragma unroll
-              for (int u = 0; u < 8; ++u) {
+              for (int u = 0; u < XB; ++u) {
                 float sv = 0.f;
 #pragma unroll
                 for (int l = 0; l < L; ++l) sv = fmaf(xr[u][l], tg[l], sv);
-                pj[8 * h + u] = sv;
+                pj[XB * h + u] = sv;
               }
             }
             const float tot = wave_reduce_scatter16(pj, lane);
@@ -2851,29 +2872,33 @@ __global__ __launch_bounds__(NT, CI_MIN_WAVES) void gibbs_kernel(KArgs a) {
         }
       }
     } else if constexpr (RPM == 2) {
-      // 8 features per round (independent row loads, see the X~'targets loop)
-      auto xw_rounds = [&](auto load_row) {
-        for (int j0 = 0; j0 < P; j0 += 8) {
-          float xr[8][L], wj[8];
+      // 16 features per round (independent row loads, see the X~'targets loop)
+      auto xw_rounds = [&](auto load_row, auto wide) {
+        // rows in flight: 8 from LDS; from L2 as many as 64 registers hold
+        constexpr int XB = !decltype(wide)::value ? 8 : (L <= 4 ? 16 : (L == 8 ? 8 : 4));
+        for (int j0 = 0; j0 < P; j0 += XB) {
+          float xr[XB][L], wj[XB];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < XB; ++u) {
             const int j = j0 + u < P ? j0 + u : P - 1;
             wj[u] = j0 + u < P ? wls[j] : 0.f;
             load_row(j, xr[u]);
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
+          for (int u = 0; u < XB; ++u)
 #pragma unroll
             for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[u][l], wj[u], xw[l]);
         }
       };
       if (a.x_in_lds) {
-        xw_rounds([&](int j, float (&xr)[L]) { lds_row_load<L>(Xs + j * TPAD + t0, xr); });
+        xw_rounds([&](int j, float (&xr)[L]) { lds_row_load<L>(Xs + j * TPAD + t0, xr); }, std::false_type());
       } else if (xwide) {
         if constexpr (L % 4 == 0)
-          xw_rounds([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xg + (size_t)j * T, t0, T, xr); });
+          xw_rounds([&](int j, float (&xr)[L]) { global_row_load_wide<L>(Xg + (size_t)j * T, t0, T, xr); },
+                    std::true_type());
       } else {
-        xw_rounds([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); });
+        xw_rounds([&](int j, float (&xr)[L]) { global_row_load_scalar<L>(Xg + (size_t)j * T, t0, T, xr); },
+                  std::true_type());
       }
     }
 #pragma unroll

@@ -171,6 +171,9 @@ typedef struct ci_outputs_f64 {
 int ci_fit_gibbs_f64(const ci_problem* problem, const double* y, const uint8_t* mask,
                      const double* X, const uint8_t* season_change,
                      const ci_series_params* params, ci_outputs_f64* outputs);
+/* Duration (HIP events) of the sampling kernel of the calling thread's last successful
+ * ci_fit_gibbs_f64 -- the call itself also allocates, uploads and downloads. */
+int ci_fit_gibbs_f64_kernel_ms(float* kernel_ms);
 
 /* Device-resident variant (what bench.py times: inputs already in HBM). */
 int ci_session_create(const ci_problem* problem, const float* y, const uint8_t* mask,

@@ -85,6 +85,7 @@ def load():
                              C.POINTER(SeriesParams), C.POINTER(Outputs)]
   L.ci_fit_gibbs_f64.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(SeriesParams), C.POINTER(Outputs)]
+  L.ci_fit_gibbs_f64_kernel_ms.argtypes = [C.POINTER(C.c_float)]
   L.ci_session_create.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(SeriesParams), C.POINTER(C.c_void_p)]
   L.ci_session_run.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -136,7 +137,7 @@ def load():
 def exported_symbols() -> Sequence[str]:
   """Every entry point include/causalimpact_amd.h declares."""
   return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_device_synchronize", "ci_pool_trim", "ci_host_alloc",
-          "ci_host_free", "ci_fit_gibbs", "ci_fit_gibbs_f64",
+          "ci_host_free", "ci_fit_gibbs", "ci_fit_gibbs_f64", "ci_fit_gibbs_f64_kernel_ms",
           "ci_session_create", "ci_session_run", "ci_session_run_streamed", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_kernel_name", "ci_session_destroy",
           "ci_session_profile", "ci_ll_session_kernel_name",
@@ -338,6 +339,13 @@ def fit_gibbs_f64(pb: Problem, y, mask, X, season_change, params, want=None) -> 
   _check(L.ci_fit_gibbs_f64(C.byref(pb), _ptr(y64), _ptr(mask8), _ptr(X64), _ptr(sc), params,
                             C.byref(out)))
   return arrs
+
+
+def fit_gibbs_f64_kernel_ms() -> float:
+  """Duration of the sampling kernel of this thread's last fit_gibbs_f64 (HIP events)."""
+  ms = C.c_float()
+  _check(load().ci_fit_gibbs_f64_kernel_ms(C.byref(ms)))
+  return float(ms.value)
 
 
 class Session:

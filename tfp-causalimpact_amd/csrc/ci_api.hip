@@ -174,6 +174,7 @@ KernelFn pick_kernel(int D, int L, int pm) {
 namespace {
 
 thread_local std::string g_err;
+thread_local float g_f64_kernel_ms = 0.f;   // duration of the last ci_fit_gibbs_f64 kernel on this thread
 
 int fail(const char* fmt, ...) {
   char buf[1024];
@@ -1333,9 +1334,39 @@ int ci_fit_gibbs_f64(const ci_problem* pb, const double* y, const uint8_t* mask,
   a.season_change = d_sc.p; a.ssp = d_ssp.p; a.p1_chol = d_chol.p;
   a.out_drift = o_dr.p; a.out_seasonal = o_sea.p;
   a.ws = d_ws.p; a.ws_stride = ws_stride; a.lat_theta = nullptr; a.lat_S = 1; a.reg_lds = reg_lds;
-  ci_launch_gibbs64(&a, B * C, lay.total, gws, 0);
-  CI_TRY64(hipGetLastError());
-  CI_TRY64(hipDeviceSynchronize());
+  // CI_F64_PROF=1 (diagnostic): per-phase shader-clock totals of chain 0's thread 0 on stderr
+  DevBuf<long long> d_prof;
+  const bool want_prof = getenv("CI_F64_PROF") != nullptr;
+  if (want_prof) {
+    CI_TRY64(d_prof.alloc(32));
+    CI_TRY64(hipMemset(d_prof.p, 0, 32 * sizeof(long long)));
+    a.k.prof = d_prof.p;
+  }
+  {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    CI_TRY64(hipEventCreate(&e0));
+    CI_TRY64(hipEventCreate(&e1));
+    (void)hipEventRecord(e0, 0);
+    ci_launch_gibbs64(&a, B * C, lay.total, gws, 0);
+    (void)hipEventRecord(e1, 0);
+    const hipError_t le = hipGetLastError();
+    const hipError_t se = hipDeviceSynchronize();
+    g_f64_kernel_ms = 0.f;
+    if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&g_f64_kernel_ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    CI_TRY64(le);
+    CI_TRY64(se);
+  }
+  if (want_prof) {
+    long long h[32];
+    CI_TRY64(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));
+    const double it = (double)(pb->num_warmup + S);
+    fprintf(stderr, "ci_fit_gibbs_f64 phases (cycles per iteration):");
+    for (int i = 0; i < 32; ++i) if (h[i]) fprintf(stderr, " [%d] %.0f", i, (double)h[i] / it);
+    fprintf(stderr, "\n");
+    d_prof.release();
+  }
   auto get = [&](double* dst, const DevBuf<double>& src) -> hipError_t {
     if (!dst || src.n == 0) return hipSuccess;
     return hipMemcpy(dst, src.p, src.n * sizeof(double), hipMemcpyDeviceToHost);
@@ -1351,6 +1382,12 @@ int ci_fit_gibbs_f64(const ci_problem* pb, const double* y, const uint8_t* mask,
   }
 #undef CI_TRY64
   cleanup();
+  return 0;
+}
+
+int ci_fit_gibbs_f64_kernel_ms(float* kernel_ms) {
+  if (!kernel_ms) return fail("NULL argument");
+  *kernel_ms = g_f64_kernel_ms;
   return 0;
 }
 

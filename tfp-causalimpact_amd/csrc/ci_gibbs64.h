@@ -1007,6 +1007,522 @@ __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
     for (int t = lane; t < T; t += 64) g.out_pred_mean[chain_lin * T + t] *= inv;
   }
 }
+
+// ------------------------------------------------------------------------------------
+// Trend-only models (LocalLevel / LocalLinearTrend + regression: the reference's default) in
+// float64 on EIGHT wavefronts per chain.  gibbs64_kernel runs a chain on one wavefront, i.e. on
+// one of the CU's four SIMDs, and float64 transcendentals (Box-Muller, Marsaglia-Tsang) make it
+// instruction-issue bound (119 us per iteration at T = 1000).  Here the same arithmetic is spread
+// over 512 threads:
+//   * X~'targets: one feature per wave over the whole series (the summation order of the
+//     one-wave kernel: the sums are bit-identical to its sums);
+//   * wave 0 draws (sigma^2_obs, weights) -- spike_slab_draw_big, unchanged -- WHILE wave 1 and
+//     wave 2 draw the level / slope scales and waves 1-7 generate the float64 normals of this
+//     iteration's Durbin-Koopman draw and emit the previous iteration's trajectory;
+//   * every pass over time is chunk summary -> scan -> replay as in the one-wave kernel, the
+//     scan now wave scan + a short carry across the eight wave totals ("apply" form: only the
+//     moments / the adjoint vector cross waves).
+// Same random stream, same layout (make_layout64 with K = 0), same outputs; sums over time are
+// taken in a different order, so results equal the one-wave kernel's and the oracle's to round-off
+// (tests/test_gpu_float64.py: 1e-8).
+// ------------------------------------------------------------------------------------
+constexpr int NW64 = 8, NT64 = NW64 * 64;
+
+// predicted moments (m, P) pushed through a Kalman element: m -> A (I + P J)^-1 (m + P eta) + b,
+// P -> A (I + P J)^-1 P A' + C
+__device__ __forceinline__ void kf2_apply(const Kf2& y, double& m0, double& m1, double& p00, double& p01,
+                                          double& p11) {
+  const double g00 = 1.0 + fma(p00, y.j00, p01 * y.j01), g01 = fma(p00, y.j01, p01 * y.j11);
+  const double g10 = fma(p01, y.j00, p11 * y.j01), g11 = 1.0 + fma(p01, y.j01, p11 * y.j11);
+  const double rdet = 1.0 / fma(g00, g11, -(g01 * g10));
+  const double w00 = g11 * rdet, w01 = -g01 * rdet, w10 = -g10 * rdet, w11 = g00 * rdet;
+  const double u00 = fma(y.a00, w00, y.a01 * w10), u01 = fma(y.a00, w01, y.a01 * w11);
+  const double u10 = fma(y.a10, w00, y.a11 * w10), u11 = fma(y.a10, w01, y.a11 * w11);
+  const double t0 = m0 + fma(p00, y.e0, p01 * y.e1), t1 = m1 + fma(p01, y.e0, p11 * y.e1);
+  const double s00 = fma(w00, p00, w01 * p01), s01 = fma(w00, p01, w01 * p11);
+  const double s11 = fma(w10, p01, w11 * p11);
+  const double q00 = fma(y.a00, s00, y.a01 * s01), q01 = fma(y.a00, s01, y.a01 * s11);
+  const double q10 = fma(y.a10, s00, y.a11 * s01), q11 = fma(y.a10, s01, y.a11 * s11);
+  m0 = fma(u00, t0, fma(u01, t1, y.b0));
+  m1 = fma(u10, t0, fma(u11, t1, y.b1));
+  p00 = fma(q00, y.a00, fma(q01, y.a01, y.c00));
+  p01 = fma(q00, y.a10, fma(q01, y.a11, y.c01));
+  p11 = fma(q10, y.a10, fma(q11, y.a11, y.c11));
+}
+
+template <bool GWS>
+__global__ __launch_bounds__(NT64) void gibbs64_trend_kernel(G64Args a) {
+  extern __shared__ __attribute__((aligned(32))) unsigned char smem64t[];
+  __shared__ double xs[NW64 * 16];      // wave totals of the scans / sums
+  __shared__ double sc[8];              // scalars handed between waves
+  unsigned char* smem = smem64t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const K64& g = a.k;
+  const int T = g.T, P = g.P;
+  const int series = blockIdx.x / g.C, chain = blockIdx.x % g.C;
+  const size_t chain_lin = (size_t)series * g.C + chain;
+  const bool s2 = a.has_slope != 0;
+  const int D = s2 ? 2 : 1;
+  const Layout64 L = make_layout64(T, P, 0, D, a.dred, a.has_slope, GWS ? 1 : 0, a.reg_lds);
+  unsigned char* wsc = a.ws + chain_lin * a.ws_stride;
+  unsigned char* tb_ = GWS ? wsc : smem;
+  double* yv = (double*)(tb_ + L.yv); double* lev = (double*)(tb_ + L.lev);
+  double* slp = (double*)(tb_ + L.slp); double* xw = (double*)(tb_ + L.xw);
+  double* ytil = (double*)(tb_ + L.ytil); double* vf = (double*)(tb_ + L.vf);
+  double* zl = (double*)(tb_ + L.zl); double* zs = (double*)(tb_ + L.zs);
+  double* zo = (double*)(tb_ + L.zo);
+  double* kf = (double*)(tb_ + L.kf); double* rs = (double*)(tb_ + L.rs);
+  double* zi = (double*)(smem + L.zi);
+  uint8_t* msk = tb_ + L.mask;
+  const int TS = (T + 3) & ~3;
+  RegLds R;
+  R.bvec = (double*)(smem + L.bvec);
+  R.w = nullptr;
+  double* wv = (double*)(smem + L.w);
+  R.xtx = const_cast<double*>(g.xtx) + (size_t)series * P * P;
+  R.omega = const_cast<double*>(g.omega) + (size_t)series * P * P;
+  bigp_point(R, a.reg_lds ? smem + L.reg : wsc + ((L.t_total + 255) & ~(size_t)255), P > 0 ? P : 1);
+
+  const DevSeriesParams sp = g.sp[series];
+  const Rng rng{g.seed0, stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
+  const double* Xg = g.Xt + (size_t)series * P * T;
+  const double* chol1 = a.p1_chol + (size_t)series * a.dred * a.dred;
+
+  for (int t = tid; t < TS; t += NT64) {
+    const bool in = t < T;
+    const bool m = in ? g.mask[(size_t)series * T + t] != 0 : true;
+    msk[t] = m ? 1 : 0;
+    yv[t] = m ? 0.0 : g.y[(size_t)series * T + t];
+    lev[t] = 0.0; xw[t] = 0.0; ytil[t] = 0.0; vf[t] = 0.0; zl[t] = 0.0; zo[t] = 0.0;
+    if (s2) { slp[t] = 0.0; zs[t] = 0.0; }
+  }
+  for (int j = tid; j < (P > 16 ? P : 16); j += NT64) wv[j] = 0.0;
+  if (a.reg_lds && P > 0 && P <= 16) {
+    // the register-resident draw re-reads X'X and Omega every iteration: keep them in the LDS
+    // block the dense draw would have used
+    double* lx = (double*)(smem + L.reg);
+    for (int e = tid; e < P * P; e += NT64) { lx[e] = R.xtx[e]; lx[P * P + e] = R.omega[e]; }
+    R.xtx = lx; R.omega = lx + P * P;
+  }
+  if (tid == 0) {
+    sc[0] = sp.obs_scale0; sc[1] = sp.level_scale0; sc[2] = sp.slope_scale0;
+    sc[3] = 0.0; sc[4] = 0.0;            // sums of squared level / slope increments of the last draw
+  }
+  __syncthreads();
+
+  const double p1l = (double)(sp.init_level_scale * sp.init_level_scale);
+  const double p1s = (double)(sp.init_slope_scale * sp.init_slope_scale);
+  const int C4 = (T + 3) / 4;                      // chunks of four steps (one Philox call each)
+  const int n_iter = g.W + g.S;
+  // The passes over time run on the first NWP waves -- one per SIMD: a second wave on a SIMD would
+  // only share its issue slots -- thread j < 64 NWP owning an odd number Lc of consecutive steps.
+  constexpr int NWP = 4;
+  const int Lc = ((T + 64 * NWP - 1) / (64 * NWP)) | 1;
+  const int t0 = tid * Lc < T ? tid * Lc : T;
+  const int t1 = t0 + Lc < T ? t0 + Lc : T;
+  const bool pw = wave < NWP;             // this wave takes part in the passes
+
+  PriorCarry pc;                          // wave 0: the prior block swept on the current model
+  pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
+  Prof prof;
+  prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && tid == 0);
+  for (int it = 0; it <= n_iter; ++it) {
+    // ---- (1) targets, X~'targets (one feature per wave over the whole series), y'y
+    for (int t = tid; t < T; t += NT64) ytil[t] = msk[t] ? 0.0 : yv[t] - lev[t];
+    __syncthreads();
+    prof.tick(8);
+    for (int j = wave; j <= P; j += 2 * NW64) {
+      // two features per wave and round: their rows of X come from L2 in ONE round trip (sixteen
+      // loads each); the sums are those of the one-wave kernel, term for term
+      const int j2 = j + NW64;
+      const bool f1 = j < P, f2 = j2 < P;
+      double pj = 0.0, pj2 = 0.0;
+      const double* xr1 = Xg + (size_t)(f1 ? j : 0) * T;
+      const double* xr2 = Xg + (size_t)(f2 ? j2 : 0) * T;
+      for (int tb = lane; tb < T; tb += 64 * 16) {
+        double xv[16], xv2[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int t = tb + 64 * u, tc = t < T ? t : T - 1;
+          xv[u] = f1 ? xr1[tc] : 0.0;
+          xv2[u] = f2 ? xr2[tc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int t = tb + 64 * u;
+          if (t < T) {
+            const double tg = ytil[t];
+            pj = fma(f1 ? xv[u] : tg, tg, pj);          // (j == P: y'y)
+            pj2 = fma(f2 ? xv2[u] : tg, tg, pj2);
+          }
+        }
+      }
+      const double sj = wave_sum_d(pj);
+      if (lane == 0) R.bvec[j] = sj;
+      if (j2 <= P) {
+        const double sj2 = wave_sum_d(pj2);
+        if (lane == 0) R.bvec[j2] = sj2;
+      }
+    }
+    prof.tick(9);
+    __syncthreads();
+    prof.tick(0);
+    const double obs_prev = sc[0];
+    double emit_obs = obs_prev;
+    const int s_out = it - 1 - g.W;                // retained index of iteration it - 1
+    const size_t o_out = chain_lin * g.S + (s_out >= 0 ? s_out : 0);
+    // ---- (2) in parallel: wave 0 the regression draw of iteration `it` (or, without regression,
+    // the observation scale of it - 1); wave 1 / wave 2 the level / slope scale of it - 1; waves
+    // 1-7 this iteration's normals and (with regression) the emission of iteration it - 1
+    if (wave == 0) {
+      __builtin_amdgcn_s_setprio(3);          // the critical path: ahead of the wave sharing its SIMD
+      if (it > 0 && s_out >= 0 && g.out_weights)
+        for (int j = lane; j < P; j += 64) g.out_weights[o_out * P + j] = wv[j];
+      if (P == 0) {
+        if (it > 0) {
+          const double so = scale_draw_d(sp.obs_conc, sp.obs_scale, sp.obs_ub, sp.n_obs, R.bvec[P], rng,
+                                         (uint32_t)(it - 1), SITE_OBS_SCALE, lane);
+          if (lane == 0) sc[0] = so;
+        }
+      } else if (it < n_iter) {
+        const double g_obs = gamma_wave_d(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
+        double so;
+        if (P <= 16) {      // the register-resident block of the float32 kernels with float64 transcendentals
+          NoProf np;
+          so = spike_slab_draw_regs<NoProf, NoPublish, true>(R, P, sp, obs_prev, g_obs, rng, (uint32_t)it, lane, np,
+                                                             pc, nullptr, NoPublish(), wv);
+        } else {
+          so = spike_slab_draw_big(R, wv, P, sp, obs_prev, g_obs, rng, (uint32_t)it, lane, it == 0);
+        }
+        if (lane == 0) sc[5] = so;        // (sc[0] keeps the scale of it - 1 until everyone has read it)
+      }
+      __builtin_amdgcn_s_setprio(0);
+      prof.tick(1);
+    } else {
+      if (it > 0 && wave == 1) {
+        const double v = scale_draw_d(sp.level_conc, sp.level_scale, sp.level_ub, (double)(T - 1), sc[3], rng,
+                                      (uint32_t)(it - 1), SITE_LEVEL_SCALE, lane);
+        if (lane == 0) sc[1] = v;
+      }
+      if (it > 0 && wave == 2 && s2) {
+        const double v = scale_draw_d(sp.slope_conc, sp.slope_scale, sp.slope_ub, (double)(T - 1), sc[4], rng,
+                                      (uint32_t)(it - 1), SITE_SLOPE_SCALE, lane);
+        if (lane == 0) sc[2] = v;
+      }
+      if (it < n_iter) {
+        const int nsite = s2 ? 3 : 2;
+        for (int q = tid - 64; q < nsite * C4; q += NT64 - 64) {
+          const int si = q / C4, c = q - si * C4;
+          const uint32_t site = si == 0 ? SITE_PRIOR_LEVEL : (si == 1 ? SITE_PRIOR_OBS : SITE_PRIOR_SLOPE);
+          double* dst = si == 0 ? zl : (si == 1 ? zo : zs);
+          double z4[4];
+          normals4(site_call(rng, (uint32_t)it, site, 0, (uint32_t)c), z4);
+          *reinterpret_cast<double4*>(dst + 4 * c) = make_double4(z4[0], z4[1], z4[2], z4[3]);
+        }
+        if (tid - 64 < a.dred) zi[tid - 64] = normal_d(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)(tid - 64));
+      }
+    }
+    auto emit = [&](int c_first, int c_step, double so) {
+      const size_t row = o_out * T;
+      const uint32_t pit = (uint32_t)(it - 1);
+      for (int c = c_first; c < C4; c += c_step) {
+        double zp[4];
+        normals4(site_call(rng, pit, SITE_PRED, 0, (uint32_t)c), zp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = 4 * c + q;
+          if (t < T) {
+            const double loc = lev[t] + xw[t];
+            if (g.out_level) g.out_level[row + t] = lev[t];
+            if (g.out_slope && s2) g.out_slope[row + t] = slp[t];
+            if (g.out_traj) g.out_traj[row + t] = fma(so, zp[q], loc);
+            if (g.out_pred_mean) {
+              double* pm = g.out_pred_mean + chain_lin * T + t;   // running sum, scaled at the end
+              *pm = (s_out == 0 ? 0.0 : *pm) + loc;
+            }
+          }
+        }
+      }
+    };
+    if (P > 0 && s_out >= 0 && wave > 0) emit(tid - 64, NT64 - 64, emit_obs);
+    __syncthreads();
+    prof.tick(2);
+    if (P == 0) {
+      emit_obs = sc[0];
+      if (s_out >= 0) emit(tid, NT64, emit_obs);
+    }
+    const double level_scale = sc[1], slope_scale = sc[2];
+    if (s_out >= 0 && tid == 0) {
+      if (g.out_obs) g.out_obs[o_out] = emit_obs;
+      if (g.out_level_scale) g.out_level_scale[o_out] = level_scale;
+      if (g.out_slope_scale) g.out_slope_scale[o_out] = s2 ? slope_scale : 0.0;
+    }
+    if (it == n_iter) break;
+    __syncthreads();                        // everyone has read sc[0] (the scale of it - 1)
+    if (P > 0 && tid == 0) sc[0] = sc[5];
+    const double obs_scale = P > 0 ? sc[5] : sc[0];
+
+    // ---- (3) X w
+    for (int tb = tid; tb < T; tb += 2 * NT64) {
+      // two time steps per thread and round, sixteen rows each: one L2 round trip
+      const int tb2 = tb + NT64;
+      const bool h2 = tb2 < T;
+      double s = 0.0, sb = 0.0;
+      for (int j0 = 0; j0 < P; j0 += 16) {
+        double xv[16], xv2[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 + u < P ? j0 + u : P - 1;
+          xv[u] = Xg[(size_t)j * T + tb];
+          xv2[u] = h2 ? Xg[(size_t)j * T + tb2] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (j0 + u < P) { s = fma(xv[u], wv[j0 + u], s); sb = fma(xv2[u], wv[j0 + u], sb); }
+      }
+      xw[tb] = s;
+      if (h2) xw[tb2] = sb;
+    }
+    // x+_0 = chol(P_1) z folded into the prior mean (reduced coordinates = full ones: no blocks)
+    const double x00 = chol1[0] * zi[0];
+    const double a0 = (double)sp.init_level_loc + x00;
+    double a1s = 0.0;
+    if (s2) a1s = fma(chol1[a.dred + 1], zi[1], chol1[a.dred] * zi[0]);
+    const double so = obs_scale, sl = level_scale, ss2 = s2 ? slope_scale : 0.0;
+    const double H = so * so, ql = sl * sl, qs2 = ss2 * ss2, p1s2 = s2 ? p1s : 0.0;
+    __syncthreads();
+    prof.tick(3);
+
+    double xin0 = 0.0, xin1 = 0.0;           // x+ at t0 (kept for pass 3)
+    if (pw) {   // pass 0: x+ and y~ = resid - y+
+      Drift2 e; e.n = 0.0; e.c0 = 0.0; e.c1 = 0.0;
+      for (int t = t0; t < t1; ++t)
+        if (t + 1 < T) {
+          e.n += 1.0;
+          e.c0 = fma(sl, zl[t], e.c0 + e.c1);
+          if (s2) e.c1 = fma(ss2, zs[t], e.c1);
+        }
+      Drift2 in = drift2_scan_excl(e, lane);
+      {   // across waves: the totals of the waves in front
+        const Drift2 tot = drift2_then(in, e);                 // inclusive at this lane
+        if (lane == 63) { xs[wave * 16] = tot.n; xs[wave * 16 + 1] = tot.c0; xs[wave * 16 + 2] = tot.c1; }
+        __syncthreads();      // (the waves outside the passes meet every barrier of this section below)
+        Drift2 pre; pre.n = 0.0; pre.c0 = 0.0; pre.c1 = 0.0;
+        for (int w = 0; w < wave; ++w) {
+          Drift2 y; y.n = xs[w * 16]; y.c0 = xs[w * 16 + 1]; y.c1 = xs[w * 16 + 2];
+          pre = drift2_then(pre, y);
+        }
+        in = drift2_then(pre, in);
+      }
+      xin0 = in.c0; xin1 = in.c1;            // x+_0 = 0
+      double x0 = xin0, x1 = xin1;
+      for (int t = t0; t < t1; ++t) {
+        ytil[t] = (yv[t] - xw[t]) - fma(so, zo[t], x0);
+        if (t + 1 < T) {
+          x0 = fma(sl, zl[t], x0 + x1);
+          if (s2) x1 = fma(ss2, zs[t], x1);
+        }
+      }
+    } else {
+      __syncthreads();
+    }
+    __syncthreads();                         // (xs is reused; y~ of a chunk is read by its owner only)
+    prof.tick(4);
+    if (pw) {   // pass 1: Kalman filter, gains and scaled innovations
+      Kf2 e;
+      e.a00 = 1.0; e.a01 = 0.0; e.a10 = 0.0; e.a11 = 1.0; e.b0 = 0.0; e.b1 = 0.0;
+      e.c00 = 0.0; e.c01 = 0.0; e.c11 = 0.0; e.e0 = 0.0; e.e1 = 0.0; e.j00 = 0.0; e.j01 = 0.0; e.j11 = 0.0;
+      if (tid == 0) { e.a00 = 0.0; e.a11 = 0.0; e.b0 = a0; e.b1 = a1s; e.c00 = p1l; e.c11 = p1s2; }
+      for (int t = t0; t < t1; ++t) {
+        if (msk[t] == 0) {
+          const double rf = 1.0 / (e.c00 + H);
+          const double v = ytil[t] - e.b0;
+          const double k0 = e.c00 * rf, k1 = e.c01 * rf;
+          const double vr = v * rf;
+          e.e0 = fma(e.a00, vr, e.e0); e.e1 = fma(e.a01, vr, e.e1);
+          e.j00 = fma(e.a00 * rf, e.a00, e.j00); e.j01 = fma(e.a00 * rf, e.a01, e.j01);
+          e.j11 = fma(e.a01 * rf, e.a01, e.j11);
+          e.b0 = fma(k0, v, e.b0); e.b1 = fma(k1, v, e.b1);
+          const double r00 = e.a00, r01 = e.a01;
+          e.a10 = fma(-k1, r00, e.a10); e.a11 = fma(-k1, r01, e.a11);
+          e.a00 = fma(-k0, r00, e.a00); e.a01 = fma(-k0, r01, e.a01);
+          const double c00 = e.c00, c01 = e.c01;
+          e.c00 -= c00 * c00 * rf; e.c01 -= c00 * c01 * rf; e.c11 -= c01 * c01 * rf;
+        }
+        e.a00 += e.a10; e.a01 += e.a11;
+        e.b0 += e.b1;
+        e.c00 = e.c00 + 2.0 * e.c01 + e.c11 + ql;
+        e.c01 = e.c01 + e.c11;
+        e.c11 = e.c11 + qs2;
+      }
+      const Kf2 inc = kf2_scan_incl(e, lane);           // inclusive within the wave
+      if (lane == 63) {
+        double* d = xs + wave * 16;
+        d[0] = inc.a00; d[1] = inc.a01; d[2] = inc.a10; d[3] = inc.a11; d[4] = inc.b0; d[5] = inc.b1;
+        d[6] = inc.c00; d[7] = inc.c01; d[8] = inc.c11; d[9] = inc.e0; d[10] = inc.e1;
+        d[11] = inc.j00; d[12] = inc.j01; d[13] = inc.j11;
+      }
+      __syncthreads();
+      // predicted moments entering this wave: wave 0's total carries the prior (A = 0: its (b, C)
+      // ARE the moments after it), each further wave's total is applied to them
+      double m0 = a0, m1 = a1s, p00 = p1l, p01 = 0.0, p11 = p1s2;
+      if (wave > 0) {
+        m0 = xs[4]; m1 = xs[5]; p00 = xs[6]; p01 = xs[7]; p11 = xs[8];
+        for (int w = 1; w < wave; ++w) {
+          const double* d = xs + w * 16;
+          Kf2 y;
+          y.a00 = d[0]; y.a01 = d[1]; y.a10 = d[2]; y.a11 = d[3]; y.b0 = d[4]; y.b1 = d[5];
+          y.c00 = d[6]; y.c01 = d[7]; y.c11 = d[8]; y.e0 = d[9]; y.e1 = d[10];
+          y.j00 = d[11]; y.j01 = d[12]; y.j11 = d[13];
+          kf2_apply(y, m0, m1, p00, p01, p11);
+        }
+      }
+      {   // ... and the in-wave prefix up to the previous lane on top
+        Kf2 pl;
+        pl.a00 = shfl_up_d(inc.a00, 1); pl.a01 = shfl_up_d(inc.a01, 1); pl.a10 = shfl_up_d(inc.a10, 1);
+        pl.a11 = shfl_up_d(inc.a11, 1); pl.b0 = shfl_up_d(inc.b0, 1); pl.b1 = shfl_up_d(inc.b1, 1);
+        pl.c00 = shfl_up_d(inc.c00, 1); pl.c01 = shfl_up_d(inc.c01, 1); pl.c11 = shfl_up_d(inc.c11, 1);
+        pl.e0 = shfl_up_d(inc.e0, 1); pl.e1 = shfl_up_d(inc.e1, 1);
+        pl.j00 = shfl_up_d(inc.j00, 1); pl.j01 = shfl_up_d(inc.j01, 1); pl.j11 = shfl_up_d(inc.j11, 1);
+        if (lane > 0) kf2_apply(pl, m0, m1, p00, p01, p11);
+      }
+      for (int t = t0; t < t1; ++t) {
+        double k0 = 0.0, k1 = 0.0, vfq = 0.0;
+        if (msk[t] == 0) {
+          const double rF = 1.0 / (p00 + H);
+          const double v = ytil[t] - m0;
+          k0 = p00 * rF; k1 = p01 * rF;
+          vfq = v * rF;
+          m0 = fma(k0, v, m0); m1 = fma(k1, v, m1);
+          const double q00 = p00, q01 = p01;
+          p00 -= q00 * q00 * rF; p01 -= q00 * q01 * rF; p11 -= q01 * q01 * rF;
+        }
+        kf[(size_t)t * D] = k0;
+        if (s2) kf[(size_t)t * D + 1] = k1;
+        vf[t] = vfq;
+        if (t + 1 < T) {
+          m0 += m1;
+          p00 = p00 + 2.0 * p01 + p11 + ql;
+          p01 = p01 + p11;
+          p11 = p11 + qs2;
+        }
+      }
+    } else {
+      __syncthreads();
+    }
+    __syncthreads();
+    prof.tick(5);
+    if (pw) {   // pass 2: backward recursion, rs[t] = r_{t-1}
+      auto step = [&](int t, double& r0, double& r1, double k0, double k1, double vft, bool obs) {
+        if (t + 1 < T) r1 += r0;                      // r <- T' r
+        if (obs) r0 += vft - fma(k0, r0, k1 * r1);    // + z (v/F - K'r)
+      };
+      Aff2 e; e.m00 = 1.0; e.m01 = 0.0; e.m10 = 0.0; e.m11 = 1.0; e.c0 = 0.0; e.c1 = 0.0;
+      for (int t = t1 - 1; t >= t0; --t) {
+        const bool obs = msk[t] == 0;
+        const double k0 = kf[(size_t)t * D], k1 = s2 ? kf[(size_t)t * D + 1] : 0.0, vft = vf[t];
+        double c0 = e.c0, c1 = e.c1, x0 = e.m00, x1 = e.m10, y0 = e.m01, y1 = e.m11;
+        step(t, c0, c1, k0, k1, vft, obs);
+        step(t, x0, x1, k0, k1, 0.0, obs);
+        step(t, y0, y1, k0, k1, 0.0, obs);
+        e.c0 = c0; e.c1 = c1; e.m00 = x0; e.m10 = x1; e.m01 = y0; e.m11 = y1;
+      }
+      const Aff2 in = aff2_scan_excl_bwd(e, lane);        // the lanes to the right, within the wave
+      {
+        const Aff2 tot = aff2_then(in, e);               // this lane's chunk after them: lane 0 = the wave
+        if (lane == 0) {
+          double* d = xs + wave * 16;
+          d[0] = tot.m00; d[1] = tot.m01; d[2] = tot.m10; d[3] = tot.m11; d[4] = tot.c0; d[5] = tot.c1;
+        }
+      }
+      __syncthreads();
+      double rw0 = 0.0, rw1 = 0.0;                        // r entering this wave from the right (0 at the end)
+      for (int w = NWP - 1; w > wave; --w) {
+        const double* d = xs + w * 16;
+        const double n0 = fma(d[0], rw0, fma(d[1], rw1, d[4]));
+        const double n1 = fma(d[2], rw0, fma(d[3], rw1, d[5]));
+        rw0 = n0; rw1 = n1;
+      }
+      double r0 = fma(in.m00, rw0, fma(in.m01, rw1, in.c0));
+      double r1 = fma(in.m10, rw0, fma(in.m11, rw1, in.c1));
+      for (int t = t1 - 1; t >= t0; --t) {
+        const double k0 = kf[(size_t)t * D], k1 = s2 ? kf[(size_t)t * D + 1] : 0.0;
+        step(t, r0, r1, k0, k1, vf[t], msk[t] == 0);
+        rs[(size_t)t * D] = r0;
+        if (s2) rs[(size_t)t * D + 1] = r1;
+      }
+    } else {
+      __syncthreads();
+    }
+    __syncthreads();
+    prof.tick(6);
+    double al = 0.0, as = 0.0;
+    if (pw) {   // pass 3: x^ forward, x+ again, the draw and its increment statistics
+      const double hi0 = fma(p1l, rs[0], a0), hi1 = s2 ? fma(p1s2, rs[1], a1s) : 0.0;
+      Drift2 e; e.n = 0.0; e.c0 = 0.0; e.c1 = 0.0;
+      for (int t = t0; t < t1; ++t)
+        if (t + 1 < T) {
+          e.n += 1.0;
+          e.c0 = fma(ql, rs[(size_t)(t + 1) * D], e.c0 + e.c1);
+          if (s2) e.c1 = fma(qs2, rs[(size_t)(t + 1) * D + 1], e.c1);
+        }
+      Drift2 in = drift2_scan_excl(e, lane);
+      {
+        const Drift2 tot = drift2_then(in, e);
+        if (lane == 63) { xs[wave * 16] = tot.n; xs[wave * 16 + 1] = tot.c0; xs[wave * 16 + 2] = tot.c1; }
+        __syncthreads();
+        Drift2 pre; pre.n = 0.0; pre.c0 = 0.0; pre.c1 = 0.0;
+        for (int w = 0; w < wave; ++w) {
+          Drift2 y; y.n = xs[w * 16]; y.c0 = xs[w * 16 + 1]; y.c1 = xs[w * 16 + 2];
+          pre = drift2_then(pre, y);
+        }
+        in = drift2_then(pre, in);
+      }
+      double h0 = fma(in.n, hi1, hi0) + in.c0, h1 = hi1 + in.c1;
+      double x0 = xin0, x1 = xin1;
+      for (int t = t0; t < t1; ++t) {
+        const double xt0 = h0 + x0, xt1 = h1 + x1;
+        lev[t] = xt0;
+        if (s2) slp[t] = xt1;
+        if (t + 1 < T) {
+          h0 = fma(ql, rs[(size_t)(t + 1) * D], h0 + h1);
+          x0 = fma(sl, zl[t], x0 + x1);
+          if (s2) {
+            h1 = fma(qs2, rs[(size_t)(t + 1) * D + 1], h1);
+            x1 = fma(ss2, zs[t], x1);
+          }
+          const double nx0 = h0 + x0, nx1 = h1 + x1;       // the increment t -> t + 1
+          const double dl = (nx0 - xt0) - xt1;
+          al = fma(dl, dl, al);
+          if (s2) { const double ds = nx1 - xt1; as = fma(ds, ds, as); }
+        }
+      }
+    } else {
+      __syncthreads();
+    }
+    {
+      double wl = 0.0, wsl = 0.0;
+      if (pw) { wl = wave_sum_d(al); wsl = wave_sum_d(as); }
+      if (pw && lane == 0) { xs[wave * 16 + 14] = wl; xs[wave * 16 + 15] = wsl; }   // (slots the scans do not use)
+      __syncthreads();
+      if (tid == 0) {
+        double tl = 0.0, tsl = 0.0;
+        for (int w = 0; w < NWP; ++w) { tl += xs[w * 16 + 14]; tsl += xs[w * 16 + 15]; }
+        sc[3] = tl; sc[4] = tsl;
+      }
+    }
+    __syncthreads();
+    prof.tick(7);
+  }
+  __syncthreads();
+  if (g.out_pred_mean) {
+    const double inv = 1.0 / (double)(g.S > 0 ? g.S : 1);
+    for (int t = tid; t < T; t += NT64) g.out_pred_mean[chain_lin * T + t] *= inv;
+  }
+}
 #endif  // CI_SEASONAL_DECL_ONLY
 
 }  // namespace ci

@@ -1339,14 +1339,17 @@ __device__ __forceinline__ void spike_slab_randoms(const Rng& rng, uint32_t iter
 struct NoPublish {
   __device__ __forceinline__ void operator()(double) const {}
 };
-template <class PF, class Pub = NoPublish>
+// EXACT (the float64 kernel, ci_gibbs64.h): logarithms, exponential, square roots and the
+// weights' normals in float64 (the float32 kernels take float32 hardware transcendentals where
+// 1e-7 does not matter), and the weights go to `wout` (double) instead of R.w (float).
+template <class PF, class Pub = NoPublish, bool EXACT = false>
 __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
                                                        const DevSeriesParams& sp,
                                                        double prev_obs_scale, double g_obs,
                                                        const Rng& rng, uint32_t iter, int lane,
                                                        PF& prof, PriorCarry& pc,
                                                        const double* pre = nullptr,
-                                                       Pub publish = Pub()) {
+                                                       Pub publish = Pub(), double* wout = nullptr) {
   // pre (optional, LDS): this iteration's data-independent randomness, drawn one iteration
   // ahead by an idle wave (spike_slab_randoms): [0,16) flip uniforms by feature, [16,24) visiting
   // ranks (int), [24,32) weight normals (float)
@@ -1403,9 +1406,10 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
       spike_slab_perm(rng, iter, P, j, live, rank, uflip);
     }
     const double logit_pi =
-        (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
+        EXACT ? log(sp.nonzero_prob) - log1p(-sp.nonzero_prob)
+              : (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
     int s_cur = 0;
-    const double inv_prev_var = fast_rcp(prev_var);
+    const double inv_prev_var = EXACT ? 1.0 / prev_var : fast_rcp(prev_var);
     for (;;) {
       // every lane evaluates the flip of ITS feature against the current swept state
       const bool in = ((S >> j) & 1ull) != 0ull;
@@ -1416,10 +1420,18 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
       // unit-scale prior block: Schur pivots scale with sigma^2_prev, inverse-block entries
       // with 1 / sigma^2_prev
       const double pscale = in ? inv_prev_var : prev_var;
-      const double delta = 0.5 * (double)__logf((float)(sg * m.pdiag * pscale * rap)) +
-                           sg * logit_pi - (a_post - 1.0) * fast_log1p(x);
-      const float prob = 1.0f / (1.0f + __expf(-(float)delta));
-      const bool acc = live && q == 0 && rank >= s_cur && uflip < (double)prob;
+      bool take;
+      if constexpr (EXACT) {
+        const double delta = 0.5 * log(sg * m.pdiag * pscale * rap) + sg * logit_pi -
+                             (a_post - 1.0) * log1p(x);
+        take = uflip < 1.0 / (1.0 + exp(-delta));
+      } else {
+        const double delta = 0.5 * (double)__logf((float)(sg * m.pdiag * pscale * rap)) +
+                             sg * logit_pi - (a_post - 1.0) * fast_log1p(x);
+        const float prob = 1.0f / (1.0f + __expf(-(float)delta));
+        take = uflip < (double)prob;
+      }
+      const bool acc = live && q == 0 && rank >= s_cur && take;
       // the earliest accepted proposal in visiting order is the one the sequential scan takes
       unsigned long long cand = __ballot(acc);
       if (cand == 0ull) break;
@@ -1442,9 +1454,9 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
   pc.S = S;
   pc.valid = 1;
   const double beta_post = sp.obs_scale + 0.5 * m.corner;
-  double var = beta_post * fast_rcp(g_obs);
+  double var = EXACT ? beta_post / g_obs : beta_post * fast_rcp(g_obs);
   if (var > sp.obs_ub) var = sp.obs_ub;   // InverseGammaWithSampleUpperBound clips the variance
-  const double new_scale = (double)__fsqrt_rn((float)var);
+  const double new_scale = EXACT ? sqrt(var) : (double)__fsqrt_rn((float)var);
   publish(new_scale);
   prof.tick(11);
 
@@ -1454,9 +1466,14 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
   // mu_r += V_ra / V_aa (u_a - mu_a)).  This is exactly u = L^{-T} z with M_S = L L' (the
   // oracle's Cholesky route): u_n = z_n / L_nn, u_{n-1} | u_n, ... -- but it reuses the swept
   // state instead of factorising M_S and back-substituting.
-  float zf[1];
-  if (pre) zf[0] = reinterpret_cast<const float*>(pre + 24)[col];
-  else fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)col, zf);
+  float zf[1] = {0.f};
+  double zd = 0.0;
+  if constexpr (EXACT) {
+    zd = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)col);
+  } else {
+    if (pre) zf[0] = reinterpret_cast<const float*>(pre + 24)[col];
+    else fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)col, zf);
+  }
   const double mean = m.cb;
   double mu = 0.0, umine = 0.0;
   for (unsigned long long mm = S; mm != 0ull;) {
@@ -1464,12 +1481,17 @@ __device__ __forceinline__ double spike_slab_draw_regs(const RegLds& R, int P,
     mm &= ~(1ull << aidx);
     const double vaa = -readlane_d(m.diag, aidx);
     const double mua = readlane_d(mu, aidx);
-    const double za = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zf[0]), aidx));
-    const double ua = mua + (double)__fsqrt_rn((float)vaa) * za;
+    const double za = EXACT ? readlane_d(zd, aidx)
+                            : (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(zf[0]), aidx));
+    const double ua = mua + (EXACT ? sqrt(vaa) : (double)__fsqrt_rn((float)vaa)) * za;
     const double t = unsweep_q(m, aidx, lane);
     if (j == aidx) umine = ua; else mu += t * (ua - mua);
   }
-  if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(mean + new_scale * umine) : 0.f;
+  if constexpr (EXACT) {
+    if (q == 0 && live) wout[j] = ((S >> j) & 1ull) ? mean + new_scale * umine : 0.0;
+  } else {
+    if (q == 0 && live) R.w[j] = ((S >> j) & 1ull) ? (float)(mean + new_scale * umine) : 0.f;
+  }
   wave_sync();
   prof.tick(12);
   return new_scale;

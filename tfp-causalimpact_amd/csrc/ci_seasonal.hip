@@ -36,6 +36,15 @@ extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs* args, int D, hipStream_t
 // workspace (global_ws) or in LDS.
 extern "C" void ci_launch_gibbs64(const ci::G64Args* args, int grid, size_t lds, int global_ws,
                                   hipStream_t stream) {
+  if (args->K == 0 && args->lat_theta == nullptr) {
+    // trend-only models: eight wavefronts per chain (gibbs64_trend_kernel)
+    const void* fn = global_ws ? (const void*)(&ci::gibbs64_trend_kernel<true>)
+                               : (const void*)(&ci::gibbs64_trend_kernel<false>);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (global_ws) hipLaunchKernelGGL(ci::gibbs64_trend_kernel<true>, dim3(grid), dim3(ci::NT64), lds, stream, *args);
+    else hipLaunchKernelGGL(ci::gibbs64_trend_kernel<false>, dim3(grid), dim3(ci::NT64), lds, stream, *args);
+    return;
+  }
   const void* fn = global_ws ? (const void*)(&ci::gibbs64_kernel<true>) : (const void*)(&ci::gibbs64_kernel<false>);
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (global_ws) hipLaunchKernelGGL(ci::gibbs64_kernel<true>, dim3(grid), dim3(64), lds, stream, *args);

@@ -38,5 +38,10 @@ CI_BENCH_FORCE_DIST=1 NCCL_DEBUG=VERSION timeout 300 python bench.py --no-cpu-ba
 # two ranks sharing GPU 0 through the self-launcher (host transport: RCCL refuses two ranks on one device)
 timeout 300 python -m pytest tests/test_gpu_comm.py -q > "$OUT/comm_tests.txt" 2>&1
 timeout 600 python tools/run_configs.py extras > "$OUT/extras.jsonl" 2> "$OUT/extras.err"
+# scaling scans (covariates, series length) and the phase budget of the 17-52 column route
+timeout 300 python tools/exp_p_scale.py > "$OUT/p_scale.txt" 2>&1
+timeout 300 python tools/exp_t_scale.py > "$OUT/t_scale.txt" 2>&1
+timeout 200 python tools/profile_phases.py 1000 51 1 8 > "$OUT/phase_cycles_p52.txt" 2>&1
+CI_F64_PROF=1 timeout 300 python tools/run_configs.py extras 2>&1 | grep "phases" | tail -1 > "$OUT/f64_phase_cycles.txt"
 find "$OUT" -name "*.csv" | wc -l
 tail -1 "$OUT/bench.json" | cut -c1-400

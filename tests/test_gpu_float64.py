@@ -28,6 +28,11 @@ pytestmark = pytest.mark.gpu
     (65, 2, 1, (), 3, 20),
     (191, 0, 1, (), 3, 20),
     (1000, 3, 1, (), 0, 8),
+    # the eight-wave trend kernel's regression routes: register-resident block with float64
+    # transcendentals (P <= 16, here 11 and exactly 16 columns), dense sweeps beyond
+    (400, 10, 1, (), 10, 40),
+    (300, 15, 0, (), 5, 30),
+    (250, 20, 1, (), 5, 20),
 ])
 def test_float64_kernel_equals_the_oracle_draw_for_draw(T, p, has_slope, seasons, W, S):
   y, mask, X, _ = syn.make_sampler_inputs(T, max(p, 1), 31)

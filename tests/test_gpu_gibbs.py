@@ -69,6 +69,25 @@ def test_first_iterations_match_oracle_per_draw(T, p, has_slope):
   np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=lev_tol)
 
 
+@pytest.mark.parametrize("T,p,has_slope", [(600, 30, 0), (500, 51, 1), (400, 16, 1)])
+def test_workgroup_wide_regression_block_follows_the_oracle_over_many_iterations(T, p, has_slope):
+  """17-52 columns (spike_slab_draw_block): iterations WITHOUT an accepted flip take the weights
+  from the recorded pivot rows of the register-tile sweeps, iterations with one from the explicit
+  Cholesky route -- both occur within 40 iterations, and every draw of every iteration must be the
+  oracle's: same inclusion pattern, weights, sigma_obs (float32 kernel vs float64 oracle on one
+  random stream: the tolerance covers 40 iterations of drift)."""
+  S = 40
+  got, want, spec = _fit_both(T, p, has_slope, W=0, S=S)
+  w = want[0]
+  incl_dev, incl_orc = got["weights"][0, 0] != 0, w["weights"] != 0
+  np.testing.assert_array_equal(incl_dev, incl_orc)
+  changes = int((incl_orc[1:] != incl_orc[:-1]).any(axis=1).sum())
+  assert 0 < changes < S - 1, changes            # both routes of the weights draw were taken
+  np.testing.assert_allclose(got["weights"][0, 0], w["weights"], atol=2e-2)
+  np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=2e-2)
+  np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=2e-2)
+
+
 def test_chain_ids_do_not_depend_on_launch_split():
   # chains 0..3 in one call == chains {0,1} and {2,3} in two calls (multi-GPU sharding rule)
   T, p = 200, 3

@@ -1937,14 +1937,16 @@ __device__ __forceinline__ void sweep_pair_block(double* A, int n, double* Pm, i
 constexpr int REC_LD = 64;      // doubles per recorded pivot row: >= MAXP + 1, a multiple of 16
 // one sweep of the register-resident tiles on pivot k = 4 ka + KR (KR static: the pivot's row and
 // column inside a tile are compile-time register indices)
-template <int KR>
+// WAVE: the tiles fit one wavefront (n <= 32) and that wavefront runs the sweeps alone: the
+// barrier becomes a wave-level fence (LDS operations of one wave complete in order).
+template <int KR, bool WAVE>
 __device__ __forceinline__ void sweep_tile_step(double (&m)[4][4], int ka, int a, int b, bool live,
                                                 double* st) {
   if (live && a == ka) {
     *reinterpret_cast<double2*>(st + 4 * b) = make_double2(m[KR][0], m[KR][1]);
     *reinterpret_cast<double2*>(st + 4 * b + 2) = make_double2(m[KR][2], m[KR][3]);
   }
-  __syncthreads();
+  if constexpr (WAVE) wave_sync(); else __syncthreads();
   if (!live) return;
   const double2 c01 = *reinterpret_cast<const double2*>(st + 4 * b);
   const double2 c23 = *reinterpret_cast<const double2*>(st + 4 * b + 2);
@@ -1972,7 +1974,7 @@ __device__ __forceinline__ void sweep_tile_step(double (&m)[4][4], int ka, int a
   }
 }
 // `init(i, j)`: the matrix entry before the run (read from A, or built on the spot).
-template <class Init>
+template <bool WAVE = false, class Init>
 __device__ __forceinline__ void sweep_run_block(double* A, int n, unsigned long long todo, int tid,
                                                 double* rec, Init init) {
   const int NB = (n + 3) >> 2;
@@ -1990,10 +1992,10 @@ __device__ __forceinline__ void sweep_run_block(double* A, int n, unsigned long 
   for (int ka = 0; ka < NB; ++ka) {
     const unsigned four = (unsigned)(todo >> (4 * ka)) & 15u;
     if (four == 0u) continue;
-    if (four & 1u) { sweep_tile_step<0>(m, ka, a, b, live, st); st += REC_LD; }
-    if (four & 2u) { sweep_tile_step<1>(m, ka, a, b, live, st); st += REC_LD; }
-    if (four & 4u) { sweep_tile_step<2>(m, ka, a, b, live, st); st += REC_LD; }
-    if (four & 8u) { sweep_tile_step<3>(m, ka, a, b, live, st); st += REC_LD; }
+    if (four & 1u) { sweep_tile_step<0, WAVE>(m, ka, a, b, live, st); st += REC_LD; }
+    if (four & 2u) { sweep_tile_step<1, WAVE>(m, ka, a, b, live, st); st += REC_LD; }
+    if (four & 4u) { sweep_tile_step<2, WAVE>(m, ka, a, b, live, st); st += REC_LD; }
+    if (four & 8u) { sweep_tile_step<3, WAVE>(m, ka, a, b, live, st); st += REC_LD; }
   }
   if (live) {
 #pragma unroll
@@ -2004,12 +2006,13 @@ __device__ __forceinline__ void sweep_run_block(double* A, int n, unsigned long 
         if (i < n && j < n) A[i * n + j] = m[x][y];
       }
   }
-  __syncthreads();
+  if constexpr (WAVE) wave_sync(); else __syncthreads();
 }
 
 // LDS doubles behind R.chol: the recorded pivot rows of the sweep-in ([P][REC_LD]) -- or the explicit
 // Cholesky factor ([P][P]).
-__host__ __device__ constexpr size_t block_chol_doubles(int P) { return (size_t)P * REC_LD; }
+// (+ 128: the pivot-row staging of the one-wave sweeps that carry the prior block)
+__host__ __device__ constexpr size_t block_chol_doubles(int P) { return (size_t)P * REC_LD + 128; }
 
 // The data-independent part of the regression block's matrix: [Omega s2 + X'X, 0; 0, 0] swept on
 // the features of `nzmask` (the border stays zero).  What is left for the iteration itself is to
@@ -2038,7 +2041,7 @@ __device__ __forceinline__ void presweep_block(const RegLds& R, int P, double pr
                        R.chol + (size_t)r * REC_LD);
   } else {
     const double* A = R.aug[0];
-    sweep_run_block(R.aug[0], n, nzmask, tid, R.chol, [&](int i, int j) { return A[i * n + j]; });
+    sweep_run_block<false>(R.aug[0], n, nzmask, tid, R.chol, [&](int i, int j) { return A[i * n + j]; });
   }
 }
 
@@ -2058,6 +2061,11 @@ __device__ __forceinline__ void presweep_export(const RegLds& R, int P, unsigned
 // ((P + 1)^2 doubles in global memory) when another workgroup prepared it -- and the border is
 // filled by a matrix-vector product instead of being carried through the sweeps (the same
 // arithmetic whoever swept).  !split: the sweeps run on the bordered matrix (ci_kernels.h kernels).
+// WAVE (P + 1 <= 32, !split): ONE wavefront runs the whole draw (`tid` = its lane): the tiles of the
+// sweep-in fit its 64 lanes, every barrier is a wave-level fence, the rare sweeps that carry the
+// prior block and the rare explicit Cholesky use 64-thread strides -- so the rest of the workgroup
+// can do something else meanwhile (gibbs_kernel: emission and the next draw's normals).
+template <bool WAVE = false>
 __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
                                                         const DevSeriesParams& sp,
                                                         double prev_obs_scale, double g_obs,
@@ -2066,6 +2074,17 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
                                                         bool split = false,
                                                         const double* presweep = nullptr,
                                                         int slot0 = 4) {
+  constexpr int NTH = WAVE ? 64 : NT;          // threads taking part
+  auto sync = [] { if constexpr (WAVE) wave_sync(); else __syncthreads(); };
+  // a sweep of A and the prior block on pivot k (iteration 0 and accepted flips)
+  auto sweep_both = [&](int k, bool reverse, double* keep) {
+    if constexpr (WAVE) {
+      if (keep && tid < P + 1) keep[tid] = R.aug[0][k * (P + 1) + tid];
+      sweep_pair(R.aug[0], P + 1, R.pri[0], P, k, reverse, tid, R.chol + (size_t)P * REC_LD);
+    } else {
+      sweep_pair_block(R.aug[0], P + 1, R.pri[0], P, k, reverse, true, tid, keep);
+    }
+  };
   const int lane = tid & 63;
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
@@ -2077,11 +2096,11 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   bool clean = true;               // rec holds the factor of the final model's block
   if (split) {
     if (first)
-      for (int e = tid; e < P * P; e += NT) R.pri[0][e] = R.omega[e];
+      for (int e = tid; e < P * P; e += NTH) R.pri[0][e] = R.omega[e];
   } else if (first) {
     int i = tid / n, j = tid - (tid / n) * n;
-    const int qd = NT / n, rm = NT - qd * n;
-    for (int e = tid; e < n * n; e += NT) {
+    const int qd = NTH / n, rm = NTH - qd * n;
+    for (int e = tid; e < n * n; e += NTH) {
       const int ic = i < P ? i : P - 1, jc = j < P ? j : P - 1;
       const double inner = R.omega[ic * P + jc] * prev_var + R.xtx[ic * P + jc];
       const double edge = R.bvec[(i == P && j == P) ? P : (i < j ? i : j)];
@@ -2090,25 +2109,24 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       if (j >= n) { j -= n; ++i; }
     }
     if (first)
-      for (int e = tid; e < P * P; e += NT) R.pri[0][e] = R.omega[e];
+      for (int e = tid; e < P * P; e += NTH) R.pri[0][e] = R.omega[e];
   }
   // per-feature state is computed redundantly by every wave (lane = feature), written once
   int nz0 = 0;
   if (lane < P) nz0 = all_in ? 1 : (R.w[lane] != 0.f ? 1 : 0);
   if (tid < P) R.nz[tid] = nz0;
-  if (split || first) __syncthreads();
+  if (split || first) sync();
   if (prof) prof->tick(slot0);
   const unsigned long long nzmask = __ballot(nz0 != 0);
   if (!split) {
     if (first) {
       int r = 0;
       for (unsigned long long todo = nzmask; todo; todo &= todo - 1ull, ++r)
-        sweep_pair_block(R.aug[0], n, R.pri[0], P, __ffsll((long long)todo) - 1, false, true, tid,
-                         rec + (size_t)r * REC_LD);
+        sweep_both(__ffsll((long long)todo) - 1, false, rec + (size_t)r * REC_LD);
     } else {
       // [[Omega s2 + X'X, X'r], [r'X, r'r]] built straight into the sweeps' registers
       const double* om = R.omega; const double* xx = R.xtx; const double* bv = R.bvec;
-      sweep_run_block(R.aug[0], n, nzmask, tid, rec, [&](int i, int j) {
+      sweep_run_block<WAVE>(R.aug[0], n, nzmask, tid, rec, [&](int i, int j) {
         const int ic = i < P ? i : P - 1, jc = j < P ? j : P - 1;
         const double inner = om[ic * P + jc] * prev_var + xx[ic * P + jc];
         const double edge = bv[(i == P && j == P) ? P : (i < j ? i : j)];
@@ -2117,9 +2135,9 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
     }
   } else {
     if (presweep) {     // the swept matrix, then the pivot rows of its sweeps (presweep_export)
-      for (int e = tid; e < n * n; e += NT) R.aug[0][e] = presweep[e];
+      for (int e = tid; e < n * n; e += NTH) R.aug[0][e] = presweep[e];
       const int nrec = __popcll(nzmask) * REC_LD;
-      for (int e = tid; e < nrec; e += NT) rec[e] = presweep[n * n + e];
+      for (int e = tid; e < nrec; e += NTH) rec[e] = presweep[n * n + e];
       __syncthreads();
     } else {
       presweep_block(R, P, prev_var, nzmask, first, tid);
@@ -2194,10 +2212,10 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       const int s_star = __ffsll((long long)bal) - 1;
       const int j = __builtin_amdgcn_readlane(myj, s_star);
       const bool in = R.nz[j] != 0;
-      __syncthreads();                                   // everyone has read nz / the matrices
-      sweep_pair_block(R.aug[0], n, R.pri[0], P, j, in, true, tid, nullptr);
+      sync();                                            // everyone has read nz / the matrices
+      sweep_both(j, in, nullptr);
       if (tid == 0) R.nz[j] = in ? 0 : 1;
-      __syncthreads();
+      sync();
       clean = false;
       s_cur = s_star + 1;
     }
@@ -2245,36 +2263,36 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       if (lane < P) R.w[lane] = in_s ? (float)(A[lane * n + P] + new_scale * u) : 0.f;
     }
   } else {
-    __syncthreads();                         // chol and w are about to be rewritten
+    sync();                                  // chol and w are about to be rewritten
     if (tid < 64) {                          // active set in increasing feature order
       if (mynz) R.idx[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
       if (lane < P) R.w[lane] = 0.f;
     }
-    __syncthreads();
+    sync();
     // M_S = Omega_S * prev_var + XtX_S, then a right-looking Cholesky by the whole workgroup, one
     // barrier per column: the Schur-complement entries (i, j), k < j <= i, take their k-th term
     // (the same products, in the same order, as a left-looking factorisation); column k of L goes
     // to the UPPER triangle (row k) and its diagonal to ldiag, so that nothing a concurrent thread
     // still reads is overwritten.  Reciprocal square roots instead of divisions.
     double* ldiag = R.uperm;                 // (the permutation keys are no longer needed)
-    for (int e = tid; e < na * na; e += NT) {
+    for (int e = tid; e < na * na; e += NTH) {
       const int i = e / na, j = e - i * na;
       const int fi = R.idx[i], fj = R.idx[j];
       R.chol[e] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
     }
     if (tid < na) R.zv[tid] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[tid]);
-    __syncthreads();
+    sync();
     for (int k = 0; k < na; ++k) {
       const double skk = R.chol[k * na + k];
       const double rs = fast_rsqrt(skk);
-      for (int i = k + 1 + (tid >> 4); i < na; i += NT / 16) {
+      for (int i = k + 1 + (tid >> 4); i < na; i += NTH / 16) {
         const double lik = R.chol[i * na + k] * rs;
         for (int j = k + 1 + (tid & 15); j <= i; j += 16)
           R.chol[i * na + j] -= lik * (R.chol[j * na + k] * rs);
         if ((tid & 15) == 0) R.chol[k * na + i] = lik;
       }
       if (tid == 0) ldiag[k] = skk * rs;
-      __syncthreads();
+      sync();
     }
     if (tid < 64) {
       // solve L' u = z (column-oriented back substitution) in registers: lane l holds z_l
@@ -2295,7 +2313,7 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       }
     }
   }
-  __syncthreads();
+  sync();
   if (prof) prof->tick(slot0 + 3);
   return new_scale;
 }
@@ -2469,7 +2487,12 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
       obs_scale = spike_slab_draw_regs(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, pc,
                                        pre);
     else if constexpr (PM == 2) {
-      if (P > 16) {            // drawn by the whole workgroup right after this section
+      if (P > 16 && P + 1 <= 32) {
+        // 17-31 columns: the tiles of the sweep-in fit this wavefront, which draws alone while the
+        // other waves emit and generate normals
+        obs_scale = spike_slab_draw_block<true>(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane,
+                                                it == 0);
+      } else if (P > 16) {     // drawn by the whole workgroup right after this section
         if (lane == 0) { block_st[0] = obs_scale; block_st[1] = g_obs; }
       } else {
         obs_scale = spike_slab_draw(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane, prof, it == 0);
@@ -2816,12 +2839,12 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
     }
     __syncthreads();
     if constexpr (RPM == 2) {
-      if (P > 16 && it < n_iter) {
-        // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
+      if (P + 1 > 32 && it < n_iter) {
+        // 32-52 columns: the regression draw with its (P+1)^2 sweeps spread over all four waves
         Prof bp;
         bp.start(a.prof, PROF && a.prof != nullptr && blockIdx.x == 0 && tid == 0);
-        const double ns = spike_slab_draw_block(R, P, cx->sp, gam[72], gam[73], rng, (uint32_t)it, tid,
-                                                it == 0, PROF ? &bp : nullptr, false, nullptr, 9);
+        const double ns = spike_slab_draw_block<false>(R, P, cx->sp, gam[72], gam[73], rng, (uint32_t)it, tid,
+                                                       it == 0, PROF ? &bp : nullptr, false, nullptr, 9);
         if (tid == 0) {
           cx->obs_scale = ns;
           scal[SC_OBS_DK] = (float)ns;

@@ -1305,9 +1305,12 @@ __global__ __launch_bounds__(NT64) void gibbs64_trend_kernel(G64Args a) {
           e.c0 = fma(sl, zl[t], e.c0 + e.c1);
           if (s2) e.c1 = fma(ss2, zs[t], e.c1);
         }
-      Drift2 in = drift2_scan_excl(e, lane);
+      // (wave scans on the DPP crossbar -- ci_kernels.h's wave_scan_incl_* move any element as
+      //  32-bit words -- instead of ds_bpermute shuffles: no LDS round trip per level)
+      const Drift2 tot = wave_scan_incl_fwd(e, [](const Drift2& x, const Drift2& y) { return drift2_then(x, y); }, lane);
+      Drift2 in = dpp_move_e<0x138, 0xF>(tot);                 // wave_shr:1: exclusive
+      if (lane == 0) { in.n = 0.0; in.c0 = 0.0; in.c1 = 0.0; }
       {   // across waves: the totals of the waves in front
-        const Drift2 tot = drift2_then(in, e);                 // inclusive at this lane
         if (lane == 63) { xs[wave * 16] = tot.n; xs[wave * 16 + 1] = tot.c0; xs[wave * 16 + 2] = tot.c1; }
         __syncthreads();      // (the waves outside the passes meet every barrier of this section below)
         Drift2 pre; pre.n = 0.0; pre.c0 = 0.0; pre.c1 = 0.0;
@@ -1358,7 +1361,7 @@ __global__ __launch_bounds__(NT64) void gibbs64_trend_kernel(G64Args a) {
         e.c01 = e.c01 + e.c11;
         e.c11 = e.c11 + qs2;
       }
-      const Kf2 inc = kf2_scan_incl(e, lane);           // inclusive within the wave
+      const Kf2 inc = wave_scan_incl_fwd(e, [](const Kf2& x, const Kf2& y) { return kf2_then(x, y); }, lane);
       if (lane == 63) {
         double* d = xs + wave * 16;
         d[0] = inc.a00; d[1] = inc.a01; d[2] = inc.a10; d[3] = inc.a11; d[4] = inc.b0; d[5] = inc.b1;
@@ -1381,12 +1384,7 @@ __global__ __launch_bounds__(NT64) void gibbs64_trend_kernel(G64Args a) {
         }
       }
       {   // ... and the in-wave prefix up to the previous lane on top
-        Kf2 pl;
-        pl.a00 = shfl_up_d(inc.a00, 1); pl.a01 = shfl_up_d(inc.a01, 1); pl.a10 = shfl_up_d(inc.a10, 1);
-        pl.a11 = shfl_up_d(inc.a11, 1); pl.b0 = shfl_up_d(inc.b0, 1); pl.b1 = shfl_up_d(inc.b1, 1);
-        pl.c00 = shfl_up_d(inc.c00, 1); pl.c01 = shfl_up_d(inc.c01, 1); pl.c11 = shfl_up_d(inc.c11, 1);
-        pl.e0 = shfl_up_d(inc.e0, 1); pl.e1 = shfl_up_d(inc.e1, 1);
-        pl.j00 = shfl_up_d(inc.j00, 1); pl.j01 = shfl_up_d(inc.j01, 1); pl.j11 = shfl_up_d(inc.j11, 1);
+        const Kf2 pl = dpp_move_e<0x138, 0xF>(inc);       // wave_shr:1
         if (lane > 0) kf2_apply(pl, m0, m1, p00, p01, p11);
       }
       for (int t = t0; t < t1; ++t) {
@@ -1430,9 +1428,11 @@ __global__ __launch_bounds__(NT64) void gibbs64_trend_kernel(G64Args a) {
         step(t, y0, y1, k0, k1, 0.0, obs);
         e.c0 = c0; e.c1 = c1; e.m00 = x0; e.m10 = x1; e.m01 = y0; e.m11 = y1;
       }
-      const Aff2 in = aff2_scan_excl_bwd(e, lane);        // the lanes to the right, within the wave
+      // suffix scan: op(outer, inner) with the lanes to the right acting first
+      const Aff2 tot = wave_scan_incl_bwd(e, [](const Aff2& outer, const Aff2& inner) { return aff2_then(inner, outer); }, lane);
+      Aff2 in = dpp_move_e<0x130, 0xF>(tot);             // wave_shl:1: the lanes to the right only
+      if (lane == 63) { in.m00 = 1.0; in.m01 = 0.0; in.m10 = 0.0; in.m11 = 1.0; in.c0 = 0.0; in.c1 = 0.0; }
       {
-        const Aff2 tot = aff2_then(in, e);               // this lane's chunk after them: lane 0 = the wave
         if (lane == 0) {
           double* d = xs + wave * 16;
           d[0] = tot.m00; d[1] = tot.m01; d[2] = tot.m10; d[3] = tot.m11; d[4] = tot.c0; d[5] = tot.c1;
@@ -1469,9 +1469,10 @@ __global__ __launch_bounds__(NT64) void gibbs64_trend_kernel(G64Args a) {
           e.c0 = fma(ql, rs[(size_t)(t + 1) * D], e.c0 + e.c1);
           if (s2) e.c1 = fma(qs2, rs[(size_t)(t + 1) * D + 1], e.c1);
         }
-      Drift2 in = drift2_scan_excl(e, lane);
+      const Drift2 tot = wave_scan_incl_fwd(e, [](const Drift2& x, const Drift2& y) { return drift2_then(x, y); }, lane);
+      Drift2 in = dpp_move_e<0x138, 0xF>(tot);
+      if (lane == 0) { in.n = 0.0; in.c0 = 0.0; in.c1 = 0.0; }
       {
-        const Drift2 tot = drift2_then(in, e);
         if (lane == 63) { xs[wave * 16] = tot.n; xs[wave * 16 + 1] = tot.c0; xs[wave * 16 + 2] = tot.c1; }
         __syncthreads();
         Drift2 pre; pre.n = 0.0; pre.c0 = 0.0; pre.c1 = 0.0;

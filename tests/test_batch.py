@@ -209,17 +209,38 @@ def test_summary_bands_from_order_statistics_equal_numpy_quantiles():
                                rtol=1e-13)
 
 
-def test_batched_fit_rejects_what_it_cannot_honour():
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(dtype=np.float64), dict(standardize_data=False)])
+def test_batched_fit_takes_float64_and_raw_scale_through_the_single_series_route(opts):
   """float64 compute and raw-scale outcomes (internal conditioning) exist on the single-series
-  path only: the batched API must say so instead of silently computing something else."""
-  frames = _frames(3, 60, 1)
+  path: the batched API fits such batches series by series -- same container, same table, every
+  series equal to fit_causalimpact on it alone with the same seed."""
+  frames = _frames(3, 80, 1)
   idx = frames[0].index
-  pre, post = (idx[0], idx[39]), (idx[40], idx[59])
-  with pytest.raises(NotImplementedError, match="float32"):
-    batch.fit_causalimpact_batch(frames, pre, post, data_options=lib.DataOptions(dtype=np.float64))
-  with pytest.raises(NotImplementedError, match="standardize_data=True"):
-    batch.fit_causalimpact_batch(frames, pre, post,
-                                 data_options=lib.DataOptions(standardize_data=False))
+  pre, post = (idx[0], idx[55]), (idx[56], idx[79])
+  do = lib.DataOptions(**opts)
+  io = lib.InferenceOptions(num_results=60, num_chains=2)
+  got = batch.fit_causalimpact_batch(frames, pre, post, seed=3, data_options=do, inference_options=io,
+                                     names=["a", "b", "c"])
+  assert isinstance(got, batch.CausalImpactBatchAnalysis) and len(got) == 3
+  assert got.summary.shape == (6, 15)
+  for b, name in enumerate("abc"):
+    one = lib.fit_causalimpact(frames[b], pre, post, seed=3, data_options=do, inference_options=io)
+    np.testing.assert_array_equal(got.summary.loc[name].to_numpy(float), one.summary.to_numpy(float))
+    pd.testing.assert_frame_equal(got[b].series, one.series)
+    assert got[b].posterior_samples is None
+  assert set(got.diagnostics) == {"split_rhat", "ess_bulk", "ess_tail"}
+
+
+def test_per_series_batch_container_assembles_the_summary_table():
+  summ = pd.DataFrame({"actual": [1.0, 2.0], "alpha": [0.05, 0.05]}, index=["average", "cumulative"])
+  one = lib.CausalImpactAnalysis(pd.DataFrame({"x": [1.0]}), summ, None, None)
+  two = lib.CausalImpactAnalysis(pd.DataFrame({"x": [2.0]}), summ * 2, None, None)
+  got = batch.PerSeriesBatchAnalysis(["u", "v"], 0.05, [one, two])
+  assert len(got) == 2 and got[1] is two and [a for a in got] == [one, two]
+  assert list(got.summary.index) == [("u", "average"), ("u", "cumulative"), ("v", "average"), ("v", "cumulative")]
+  assert got.summary.loc["v"]["actual"]["cumulative"] == 4.0
+  assert got.diagnostics is None and got.diagnostics_of(-1) is None
 
 
 def test_lazy_diagnostics_pickle_as_a_plain_dict():

@@ -250,6 +250,30 @@ class CausalImpactBatchAnalysis:
     return (self[b] for b in range(len(self)))
 
 
+class PerSeriesBatchAnalysis(CausalImpactBatchAnalysis):
+  """The same container over analyses that were fitted one series at a time (the routes the
+  one-launch path does not have: float64 compute, raw-scale outcomes)."""
+
+  def __init__(self, names, alpha, analyses):   # pylint: disable=super-init-not-called
+    self._names, self.alpha = list(names), alpha
+    self._cache = dict(enumerate(analyses))
+    self._diag_draws = None
+    self.summary = pd.concat([a.summary for a in analyses], keys=self._names, names=["series", None])
+
+  def diagnostics_of(self, b: int):
+    return self._cache[range(len(self))[b]].diagnostics
+
+  @property
+  def diagnostics(self):
+    per = [self.diagnostics_of(b) for b in range(len(self))]
+    if any(p is None for p in per):
+      return None
+    return {name: [p[name] for p in per] for name in ("split_rhat", "ess_bulk", "ess_tail")}
+
+  def __getitem__(self, b: int) -> lib.CausalImpactAnalysis:
+    return self._cache[range(len(self))[b]]
+
+
 def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
                            pre_period, post_period, alpha: float = 0.05, seed=None,
                            data_options: Optional[lib.DataOptions] = None,
@@ -279,15 +303,6 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
     raise ValueError("`alpha` must be between 0 and 1.")
   if inference_options.sampler != "gibbs":
     raise NotImplementedError("batched fits use the Gibbs sampler")
-  if cid._as_numpy_dtype(data_options.dtype) == np.float64:  # pylint: disable=protected-access
-    raise NotImplementedError(
-        "fit_causalimpact_batch computes in float32 (the batched float32 kernels); use "
-        "fit_causalimpact per series for DataOptions(dtype=float64)")
-  if not data_options.standardize_data:
-    raise NotImplementedError(
-        "fit_causalimpact_batch needs standardize_data=True: the per-series internal conditioning "
-        "of raw-scale outcomes (causalimpact_lib._internal_conditioning) is not part of the batched "
-        "path; use fit_causalimpact per series")
   if isinstance(data, np.ndarray):
     values = np.asarray(data, np.float64)
     index = pd.RangeIndex(values.shape[1]) if index is None else pd.Index(index)
@@ -306,6 +321,21 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
     index = first.index
   B = values.shape[0]
   names = list(range(B)) if names is None else list(names)
+  if (cid._as_numpy_dtype(data_options.dtype) == np.float64  # pylint: disable=protected-access
+      or not data_options.standardize_data):
+    # float64 compute (csrc/ci_gibbs64.h) and raw-scale outcomes (their per-series internal
+    # conditioning, causalimpact_lib._internal_conditioning) exist on the single-series path: the
+    # batch is fitted series by series there -- same container, same summary table, every series
+    # equal to `fit_causalimpact` on it alone with this seed (i.e. the streams are shared between
+    # the series, as with shared_streams=True).  Not the one-launch path: B sequential fits.
+    opts = dataclasses.replace(data_options, outcome_column=columns[0])
+    analyses = []
+    for b in range(B):
+      one = lib.fit_causalimpact(pd.DataFrame(values[b], index=index, columns=columns), pre_period,
+                                 post_period, alpha=alpha, seed=seed, data_options=opts,
+                                 model_options=model_options, inference_options=inference_options)
+      analyses.append(dataclasses.replace(one, posterior_samples=None))   # (draws are not kept)
+    return PerSeriesBatchAnalysis(names, alpha, analyses)
   prep = prepare_batch(values, index, pre_period, post_period, data_options.standardize_data)
   T = prep.y.shape[1]
   P = 0 if prep.design is None else prep.design.shape[2]

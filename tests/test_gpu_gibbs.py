@@ -69,7 +69,15 @@ def test_first_iterations_match_oracle_per_draw(T, p, has_slope):
   np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=lev_tol)
 
 
-@pytest.mark.parametrize("T,p,has_slope", [(600, 30, 0), (500, 51, 1), (400, 16, 1)])
+@pytest.mark.parametrize("T,p,has_slope", [
+    (600, 30, 0),   # P = 31, n = 32: the largest matrix whose tiles fit one wavefront
+    (500, 51, 1),   # P = 52, n = 53: the largest; 14 x 14 tiles over the workgroup, X from L2
+    (400, 16, 1),   # P = 17, n = 18: the smallest
+    (300, 31, 1),   # P = 32, n = 33: the first size on the whole workgroup
+    (300, 46, 0),   # n = 48: a multiple of 16 (no padding rows behind the matrix)
+    (300, 47, 1),   # n = 49
+    (260, 19, 0),   # n = 21: tiles with three dead columns
+])
 def test_workgroup_wide_regression_block_follows_the_oracle_over_many_iterations(T, p, has_slope):
   """17-52 columns (spike_slab_draw_block): iterations WITHOUT an accepted flip take the weights
   from the recorded pivot rows of the register-tile sweeps, iterations with one from the explicit

@@ -2090,8 +2090,8 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
-  // R.chol: the pivot rows of the sweep-in, one per swept feature in ascending order ([na][n]),
-  // then two staging rows for the other sweeps
+  // R.chol: the pivot rows of the sweep-in, one per swept feature in ascending order
+  // ([na][REC_LD]); behind them (at [P][REC_LD]) the staging rows of the one-wave sweeps
   double* rec = R.chol;
   bool clean = true;               // rec holds the factor of the final model's block
   if (split) {

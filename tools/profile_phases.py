@@ -51,6 +51,8 @@ def main():
     print(f"  [{i:2d}] {name:34s} {cyc[i] / n_it:9.0f} cyc/iter  {100.0 * cyc[i] / top:5.1f} %")
   print(f"  total of phases 0-7, 24-28: {top / n_it:.0f} cyc/iter")
   if pb.P > 16 and "kernel8" not in sess.kernel_name():
+    if pb.P + 1 <= 32:
+      print("  17-31 columns: wave 0 draws alone inside the serial section ([1], [8]): no breakdown")
     print("  workgroup-wide regression block (thread 0): [9] build, [10] sweep-in, [11] flips, "
           "[12] Cholesky + weights")
     print(f"       evaluation rounds per iteration {(cyc[30] + cyc[31]) / n_it:.2f}, accepted flips "

@@ -2061,6 +2061,55 @@ __device__ __forceinline__ void presweep_export(const RegLds& R, int P, unsigned
 // ((P + 1)^2 doubles in global memory) when another workgroup prepared it -- and the border is
 // filled by a matrix-vector product instead of being carried through the sweeps (the same
 // arithmetic whoever swept).  !split: the sweeps run on the bordered matrix (ci_kernels.h kernels).
+// The data-independent randomness of the workgroup-wide block's draw for iteration `iter`: the
+// visiting order (stable argsort of P uniforms, ranked in registers on their raw 32-bit words --
+// u01d is strictly increasing in them -- and inverted by one ds_permute), the flip uniform of every
+// visiting position, the weight normal of every feature.  BlockRandoms::store / load: 64 doubles
+// of LDS ([0,32) uniforms by position, then 32 ints: feature by position, then 32 floats: normals
+// by feature) when another wave draws them one iteration ahead (17-31 columns).
+constexpr int GAM_BLOCK_PRE = 8 + 64 + 4;     // offset (doubles) of the two buffers in the gamma area
+struct BlockRandoms {
+  int myj;        // feature visited at step `lane`
+  double myu;     // its flip uniform
+  float zf;       // the weight normal of feature `lane`
+};
+__device__ __forceinline__ BlockRandoms block_randoms(const Rng& rng, uint32_t iter, int P, int lane) {
+  BlockRandoms b;
+  uint32_t rw = 0xffffffffu;
+  if (lane < P) {
+    const U4 r4 = site_call(rng, iter, SITE_PERM, 0, (uint32_t)lane >> 2);
+    const uint32_t c = (uint32_t)lane & 3u;
+    rw = c == 0 ? r4.x : c == 1 ? r4.y : c == 2 ? r4.z : r4.w;
+  }
+  int rank = 0;
+  for (int k = 0; k < P; ++k) {
+    const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)rw, k);
+    rank += (rk < rw || (rk == rw && k < lane)) ? 1 : 0;
+  }
+  if (lane >= P) rank = lane;
+  b.myj = __builtin_amdgcn_ds_permute(rank << 2, lane);
+  b.myu = lane < P ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)lane) : 2.0;
+  float zf[1];
+  fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)lane, zf);
+  b.zf = zf[0];
+  return b;
+}
+__device__ __forceinline__ void block_randoms_store(const BlockRandoms& b, double* pre, int lane) {
+  if (lane < 32) {
+    pre[lane] = b.myu;
+    reinterpret_cast<int*>(pre + 32)[lane] = b.myj;
+    reinterpret_cast<float*>(pre + 48)[lane] = b.zf;
+  }
+}
+__device__ __forceinline__ BlockRandoms block_randoms_load(const double* pre, int P, int lane) {
+  BlockRandoms b;
+  const int l = lane < 32 ? lane : 0;
+  b.myu = lane < P ? pre[l] : 2.0;
+  b.myj = lane < P ? reinterpret_cast<const int*>(pre + 32)[l] : lane;
+  b.zf = reinterpret_cast<const float*>(pre + 48)[l];
+  return b;
+}
+
 // WAVE (P + 1 <= 32, !split): ONE wavefront runs the whole draw (`tid` = its lane): the tiles of the
 // sweep-in fit its 64 lanes, every barrier is a wave-level fence, the rare sweeps that carry the
 // prior block and the rare explicit Cholesky use 64-thread strides -- so the rest of the workgroup
@@ -2073,7 +2122,8 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
                                                         bool first, Prof* prof = nullptr,
                                                         bool split = false,
                                                         const double* presweep = nullptr,
-                                                        int slot0 = 4) {
+                                                        int slot0 = 4, const double* pre = nullptr) {
+  // pre (LDS, may be null): this iteration's block_randoms, drawn ahead by another wave
   constexpr int NTH = WAVE ? 64 : NT;          // threads taking part
   auto sync = [] { if constexpr (WAVE) wave_sync(); else __syncthreads(); };
   // a sweep of A and the prior block on pivot k (iteration 0 and accepted flips)
@@ -2167,26 +2217,13 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
   }
   if (prof) prof->tick(slot0 + 1);
   if (!all_in) {
-    // visiting order = stable argsort of P uniforms, in registers, every wave for itself: rank by
-    // the raw 32-bit words (u01d is strictly increasing in them), ties by index; the inverse
-    // permutation is one ds_permute (lane rank_j receives j)
-    uint32_t rw = 0xffffffffu;
-    if (lane < P) {
-      const U4 r4 = site_call(rng, iter, SITE_PERM, 0, (uint32_t)lane >> 2);
-      const uint32_t c = (uint32_t)lane & 3u;
-      rw = c == 0 ? r4.x : c == 1 ? r4.y : c == 2 ? r4.z : r4.w;
-    }
-    int rank = 0;
-    for (int k = 0; k < P; ++k) {
-      const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)rw, k);
-      rank += (rk < rw || (rk == rw && k < lane)) ? 1 : 0;
-    }
-    if (lane >= P) rank = lane;
-    const int myj = __builtin_amdgcn_ds_permute(rank << 2, lane);      // feature visited at step `lane`
+    // visiting order, flip uniforms (block_randoms: every wave for itself, or read from `pre`)
+    const BlockRandoms br = pre ? block_randoms_load(pre, P, lane) : block_randoms(rng, iter, P, lane);
+    const int myj = br.myj;
+    const double myu = br.myu;
     const double logit_pi =
         (double)(__logf((float)sp.nonzero_prob) - __logf((float)(1.0 - sp.nonzero_prob)));
     const double inv_prev_var = fast_rcp(prev_var);
-    const double myu = lane < P ? uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)lane) : 2.0;
     int s_cur = 0;
     while (true) {
       bool flip = false;
@@ -2241,7 +2278,8 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       const double* row = rec + (size_t)__popcll(bal & ((1ull << lane) - 1ull)) * REC_LD;
       const double rs = in_s ? fast_rsqrt(row[lane]) : 0.0;          // 1 / L_ff
       float zf[1];
-      fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)lane, zf);
+      if (pre) zf[0] = reinterpret_cast<const float*>(pre + 48)[lane < 32 ? lane : 0];
+      else fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)lane, zf);
       double z = in_s ? (double)zf[0] : 0.0;
       double u = 0.0;
       for (int g0 = (P - 1) & ~15; g0 >= 0; g0 -= 16) {
@@ -2380,7 +2418,7 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_slots = take(sizeof(float) * 3 * NW * 16);
   l.off_xlast = take(sizeof(float) * NT * D);
   l.off_tg = take(sizeof(float) * 16);
-  l.off_gam = take(sizeof(double) * (8 + 64 + 4));   // gamma draws (wave 1) and regression-block randomness
+  l.off_gam = take(sizeof(double) * (8 + 64 + 4 + 128));   // gamma draws (wave 1) and regression-block randomness
                                                  // (wave 2) handed to the serial wave, double-buffered
   l.off_nz0 = take(sizeof(float) * (4 * 64 * (tpad / NT) + 4));   // wave 0's normals, drawn by waves 1-3
   // targets y - level over time, handed to the waves that sum X~'targets (P <= 16)
@@ -2491,7 +2529,7 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
         // 17-31 columns: the tiles of the sweep-in fit this wavefront, which draws alone while the
         // other waves emit and generate normals
         obs_scale = spike_slab_draw_block<true>(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane,
-                                                it == 0);
+                                                it == 0, nullptr, false, nullptr, 4, block_st + 4 + 64 * (it & 1));
       } else if (P > 16) {     // drawn by the whole workgroup right after this section
         if (lane == 0) { block_st[0] = obs_scale; block_st[1] = g_obs; }
       } else {
@@ -2622,6 +2660,9 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
   if (wave == 1) serial_gammas<RPM>(cx, 0, lane, gam);     // (no draw is active at it = 0 but P > 0's)
   if constexpr (RPM == 1) {
     if (wave == 2) spike_slab_randoms(rng, 0u, P, lane, gam + 8);
+  }
+  if constexpr (RPM == 2) {     // 17-31 columns: the one-wave draw's randomness comes from wave 2
+    if (wave == 2 && P > 16 && P + 1 <= 32) block_randoms_store(block_randoms(rng, 0u, P, lane), gam + GAM_BLOCK_PRE, lane);
   }
   const float init_loc = scal[8], init_var = scal[9], init_svar = scal[10];
 
@@ -2804,6 +2845,11 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
       if constexpr (RPM == 1) {
         if (wave == 2 && it + 1 < n_iter)
           spike_slab_randoms(rng, (uint32_t)(it + 1), P, lane, gam + 8 + 32 * ((it + 1) & 1));
+      }
+      if constexpr (RPM == 2) {
+        if (wave == 2 && it + 1 < n_iter && P > 16 && P + 1 <= 32)
+          block_randoms_store(block_randoms(rng, (uint32_t)(it + 1), P, lane),
+                              gam + GAM_BLOCK_PRE + 64 * ((it + 1) & 1), lane);
       }
       if constexpr (RPM != 0) {
         if (it > a.W) {

@@ -96,6 +96,20 @@ def test_workgroup_wide_regression_block_follows_the_oracle_over_many_iterations
   np.testing.assert_allclose(got["posterior_means"][0, 0], w["pred_mean"], atol=2e-2)
 
 
+def test_every_regression_block_size_from_17_to_52_columns_matches_the_oracle():
+  """Every tile geometry of the register-resident sweeps (NB = 5 .. 14, one wavefront up to 31
+  columns, the workgroup beyond) on a short ragged series: the first draws are the oracle's."""
+  for p in range(16, 52):
+    T = 90 + (p % 7)
+    got, want, spec = _fit_both(T, p, p % 2, W=0, S=6)
+    w = want[0]
+    np.testing.assert_array_equal(got["weights"][0, 0] != 0, w["weights"] != 0, err_msg=f"p={p}")
+    np.testing.assert_allclose(got["weights"][0, 0], w["weights"], atol=5e-3, err_msg=f"p={p}")
+    np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=5e-3,
+                               err_msg=f"p={p}")
+    assert np.isfinite(got["posterior_trajectories"]).all()
+
+
 def test_chain_ids_do_not_depend_on_launch_split():
   # chains 0..3 in one call == chains {0,1} and {2,3} in two calls (multi-GPU sharding rule)
   T, p = 200, 3

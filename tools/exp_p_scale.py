@@ -2,7 +2,9 @@
 (T = 1000, local linear trend, 8 chains)."""
 import sys
 import numpy as np
-sys.path.insert(0, "tfp-causalimpact_amd"); sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tfp-causalimpact_amd")]
 from causalimpact import _model, _native
 from causalimpact import _synthetic as syn
 T, W, S, C = 1000, 50, 200, 8

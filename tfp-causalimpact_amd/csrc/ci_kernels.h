@@ -2753,6 +2753,39 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
         // per SIMD, the rows in flight live in its register half) and their wave sums ONE
         // reduce-scatter.  The row source is chosen outside the loop (see global_row_load_wide).
         auto xt_rounds = [&](auto load_row) {
+          if constexpr (L <= 4) {
+            // two half-rounds of 8 rows, software-pipelined: the rows of the NEXT round's first half
+            // are requested before this round's second half is consumed, so that an L2 round trip
+            // runs under the FMAs and the reduce-scatter (32 registers live across the reduce)
+            float xa[8][L], xb[8][L];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load_row(u < P ? u : P - 1, xa[u]);
+            for (int j0 = 0; j0 < P; j0 += 16) {
+              float pj[16];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) load_row(j0 + 8 + u < P ? j0 + 8 + u : P - 1, xb[u]);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                float sv = 0.f;
+#pragma unroll
+                for (int l = 0; l < L; ++l) sv = fmaf(xa[u][l], tg[l], sv);
+                pj[u] = sv;
+              }
+              if (j0 + 16 < P) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) load_row(j0 + 16 + u < P ? j0 + 16 + u : P - 1, xa[u]);
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                float sv = 0.f;
+#pragma unroll
+                for (int l = 0; l < L; ++l) sv = fmaf(xb[u][l], tg[l], sv);
+                pj[8 + u] = sv;
+              }
+              const float tot = wave_reduce_scatter16(pj, lane);
+              if (lane < 16 && j0 + lane < P) red[wave * RS + j0 + lane] = tot;
+            }
+          } else {
           for (int j0 = 0; j0 < P; j0 += 16) {
             float pj[16];
             constexpr int XB = L <= 4 ? 16 : (L == 8 ? 8 : 4);   // rows in flight: at most 64 registers
@@ -2771,6 +2804,7 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
             }
             const float tot = wave_reduce_scatter16(pj, lane);
             if (lane < 16 && j0 + lane < P) red[wave * RS + j0 + lane] = tot;
+          }
           }
         };
         if (a.x_in_lds) {

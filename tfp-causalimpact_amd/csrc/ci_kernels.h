@@ -2999,14 +2999,18 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
     } else if constexpr (RPM == 2) {
       // 16 features per round (independent row loads, see the X~'targets loop)
       auto xw_rounds = [&](auto load_row, auto wide) {
-        // rows in flight: 8 from LDS; from L2 as many as 64 registers hold
+        // rows in flight: 8 from LDS; from L2 as many as 64 registers hold.  Only the rows of the
+        // INCLUDED features are read (a zero weight contributes an exact zero to the sum: same bits)
         constexpr int XB = !decltype(wide)::value ? 8 : (L <= 4 ? 16 : (L == 8 ? 8 : 4));
-        for (int j0 = 0; j0 < P; j0 += XB) {
+        unsigned long long todo = __ballot(lane < P && wls[lane < P ? lane : 0] != 0.f);
+        while (todo != 0ull) {
           float xr[XB][L], wj[XB];
 #pragma unroll
           for (int u = 0; u < XB; ++u) {
-            const int j = j0 + u < P ? j0 + u : P - 1;
-            wj[u] = j0 + u < P ? wls[j] : 0.f;
+            const bool have = todo != 0ull;
+            const int j = have ? __ffsll((long long)todo) - 1 : 0;
+            todo &= todo - 1ull;
+            wj[u] = have ? wls[j] : 0.f;
             load_row(j, xr[u]);
           }
 #pragma unroll

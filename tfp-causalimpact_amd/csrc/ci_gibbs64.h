@@ -1266,25 +1266,44 @@ __global__ __launch_bounds__(NT64) void gibbs64_trend_kernel(G64Args a) {
     const double obs_scale = P > 0 ? sc[5] : sc[0];
 
     // ---- (3) X w
-    for (int tb = tid; tb < T; tb += 2 * NT64) {
-      // two time steps per thread and round, sixteen rows each: one L2 round trip
-      const int tb2 = tb + NT64;
-      const bool h2 = tb2 < T;
-      double s = 0.0, sb = 0.0;
-      for (int j0 = 0; j0 < P; j0 += 16) {
-        double xv[16], xv2[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int j = j0 + u < P ? j0 + u : P - 1;
-          xv[u] = Xg[(size_t)j * T + tb];
-          xv2[u] = h2 ? Xg[(size_t)j * T + tb2] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (j0 + u < P) { s = fma(xv[u], wv[j0 + u], s); sb = fma(xv2[u], wv[j0 + u], sb); }
+    {
+      // only the rows of the INCLUDED features are read (a zero weight adds an exact zero: the same
+      // sums); two time steps per thread, up to sixteen rows each, in one L2 round trip
+      unsigned long long inc = 0ull;
+      for (int j0 = 0; j0 < P; j0 += 64) {
+        const unsigned long long m = __ballot(j0 + lane < P && wv[j0 + lane < P ? j0 + lane : 0] != 0.0);
+        if (j0 == 0) inc = m;
       }
-      xw[tb] = s;
-      if (h2) xw[tb2] = sb;
+      const bool dense = P > 64;                 // (the mask covers 64 columns)
+      for (int tb = tid; tb < T; tb += 2 * NT64) {
+        const int tb2 = tb + NT64;
+        const bool h2 = tb2 < T;
+        double s = 0.0, sb = 0.0;
+        if (!dense) {
+          for (unsigned long long todo = inc; todo != 0ull;) {
+            double xv[16], xv2[16], wj[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const bool have = todo != 0ull;
+              const int j = have ? __ffsll((long long)todo) - 1 : 0;
+              todo &= todo - 1ull;
+              wj[u] = have ? wv[j] : 0.0;
+              xv[u] = Xg[(size_t)j * T + tb];
+              xv2[u] = h2 ? Xg[(size_t)j * T + tb2] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { s = fma(xv[u], wj[u], s); sb = fma(xv2[u], wj[u], sb); }
+          }
+        } else {
+          for (int j = 0; j < P; ++j) {
+            const double w = wv[j];
+            s = fma(Xg[(size_t)j * T + tb], w, s);
+            if (h2) sb = fma(Xg[(size_t)j * T + tb2], w, sb);
+          }
+        }
+        xw[tb] = s;
+        if (h2) xw[tb2] = sb;
+      }
     }
     // x+_0 = chol(P_1) z folded into the prior mean (reduced coordinates = full ones: no blocks)
     const double x00 = chol1[0] * zi[0];

@@ -2064,10 +2064,11 @@ __device__ __forceinline__ void presweep_export(const RegLds& R, int P, unsigned
 // The data-independent randomness of the workgroup-wide block's draw for iteration `iter`: the
 // visiting order (stable argsort of P uniforms, ranked in registers on their raw 32-bit words --
 // u01d is strictly increasing in them -- and inverted by one ds_permute), the flip uniform of every
-// visiting position, the weight normal of every feature.  BlockRandoms::store / load: 64 doubles
-// of LDS ([0,32) uniforms by position, then 32 ints: feature by position, then 32 floats: normals
-// by feature) when another wave draws them one iteration ahead (17-31 columns).
+// visiting position, the weight normal of every feature.  block_randoms_store / _load: 128 doubles
+// of LDS ([0,64) uniforms by position, then 64 ints: feature by position, then 64 floats: normals
+// by feature) when another wave draws them one iteration ahead.
 constexpr int GAM_BLOCK_PRE = 8 + 64 + 4;     // offset (doubles) of the two buffers in the gamma area
+constexpr int BLOCK_PRE_DOUBLES = 128;        // one buffer: 64 uniforms, 64 ints, 64 floats
 struct BlockRandoms {
   int myj;        // feature visited at step `lane`
   double myu;     // its flip uniform
@@ -2095,18 +2096,15 @@ __device__ __forceinline__ BlockRandoms block_randoms(const Rng& rng, uint32_t i
   return b;
 }
 __device__ __forceinline__ void block_randoms_store(const BlockRandoms& b, double* pre, int lane) {
-  if (lane < 32) {
-    pre[lane] = b.myu;
-    reinterpret_cast<int*>(pre + 32)[lane] = b.myj;
-    reinterpret_cast<float*>(pre + 48)[lane] = b.zf;
-  }
+  pre[lane] = b.myu;
+  reinterpret_cast<int*>(pre + 64)[lane] = b.myj;
+  reinterpret_cast<float*>(pre + 96)[lane] = b.zf;
 }
 __device__ __forceinline__ BlockRandoms block_randoms_load(const double* pre, int P, int lane) {
   BlockRandoms b;
-  const int l = lane < 32 ? lane : 0;
-  b.myu = lane < P ? pre[l] : 2.0;
-  b.myj = lane < P ? reinterpret_cast<const int*>(pre + 32)[l] : lane;
-  b.zf = reinterpret_cast<const float*>(pre + 48)[l];
+  b.myu = lane < P ? pre[lane] : 2.0;
+  b.myj = lane < P ? reinterpret_cast<const int*>(pre + 64)[lane] : lane;
+  b.zf = reinterpret_cast<const float*>(pre + 96)[lane];
   return b;
 }
 
@@ -2278,7 +2276,7 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
       const double* row = rec + (size_t)__popcll(bal & ((1ull << lane) - 1ull)) * REC_LD;
       const double rs = in_s ? fast_rsqrt(row[lane]) : 0.0;          // 1 / L_ff
       float zf[1];
-      if (pre) zf[0] = reinterpret_cast<const float*>(pre + 48)[lane < 32 ? lane : 0];
+      if (pre) zf[0] = reinterpret_cast<const float*>(pre + 96)[lane];
       else fill_normals<1>(rng, iter, SITE_WEIGHTS, 0, (uint32_t)lane, zf);
       double z = in_s ? (double)zf[0] : 0.0;
       double u = 0.0;
@@ -2418,7 +2416,7 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_slots = take(sizeof(float) * 3 * NW * 16);
   l.off_xlast = take(sizeof(float) * NT * D);
   l.off_tg = take(sizeof(float) * 16);
-  l.off_gam = take(sizeof(double) * (8 + 64 + 4 + 128));   // gamma draws (wave 1) and regression-block randomness
+  l.off_gam = take(sizeof(double) * (8 + 64 + 4 + 2 * BLOCK_PRE_DOUBLES));   // gamma draws (wave 1) and regression-block randomness
                                                  // (wave 2) handed to the serial wave, double-buffered
   l.off_nz0 = take(sizeof(float) * (4 * 64 * (tpad / NT) + 4));   // wave 0's normals, drawn by waves 1-3
   // targets y - level over time, handed to the waves that sum X~'targets (P <= 16)
@@ -2529,7 +2527,8 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
         // 17-31 columns: the tiles of the sweep-in fit this wavefront, which draws alone while the
         // other waves emit and generate normals
         obs_scale = spike_slab_draw_block<true>(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane,
-                                                it == 0, nullptr, false, nullptr, 4, block_st + 4 + 64 * (it & 1));
+                                                it == 0, nullptr, false, nullptr, 4,
+                                                block_st + 4 + BLOCK_PRE_DOUBLES * (it & 1));
       } else if (P > 16) {     // drawn by the whole workgroup right after this section
         if (lane == 0) { block_st[0] = obs_scale; block_st[1] = g_obs; }
       } else {
@@ -2662,7 +2661,7 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
     if (wave == 2) spike_slab_randoms(rng, 0u, P, lane, gam + 8);
   }
   if constexpr (RPM == 2) {     // 17-31 columns: the one-wave draw's randomness comes from wave 2
-    if (wave == 2 && P > 16 && P + 1 <= 32) block_randoms_store(block_randoms(rng, 0u, P, lane), gam + GAM_BLOCK_PRE, lane);
+    if (wave == 2 && P > 16) block_randoms_store(block_randoms(rng, 0u, P, lane), gam + GAM_BLOCK_PRE, lane);
   }
   const float init_loc = scal[8], init_var = scal[9], init_svar = scal[10];
 
@@ -2881,9 +2880,9 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
           spike_slab_randoms(rng, (uint32_t)(it + 1), P, lane, gam + 8 + 32 * ((it + 1) & 1));
       }
       if constexpr (RPM == 2) {
-        if (wave == 2 && it + 1 < n_iter && P > 16 && P + 1 <= 32)
+        if (wave == 2 && it + 1 < n_iter && P > 16)
           block_randoms_store(block_randoms(rng, (uint32_t)(it + 1), P, lane),
-                              gam + GAM_BLOCK_PRE + 64 * ((it + 1) & 1), lane);
+                              gam + GAM_BLOCK_PRE + BLOCK_PRE_DOUBLES * ((it + 1) & 1), lane);
       }
       if constexpr (RPM != 0) {
         if (it > a.W) {
@@ -2924,7 +2923,8 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
         Prof bp;
         bp.start(a.prof, PROF && a.prof != nullptr && blockIdx.x == 0 && tid == 0);
         const double ns = spike_slab_draw_block<false>(R, P, cx->sp, gam[72], gam[73], rng, (uint32_t)it, tid,
-                                                       it == 0, PROF ? &bp : nullptr, false, nullptr, 9);
+                                                       it == 0, PROF ? &bp : nullptr, false, nullptr, 9,
+                                                       gam + GAM_BLOCK_PRE + BLOCK_PRE_DOUBLES * (it & 1));
         if (tid == 0) {
           cx->obs_scale = ns;
           scal[SC_OBS_DK] = (float)ns;

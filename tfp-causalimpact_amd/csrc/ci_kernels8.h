@@ -965,22 +965,25 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
           for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
         }
       } else {
-        // the streamed design: rows in batches of independent loads, unused batches skipped (the
-        // same sums in the same order as above)
+        // the streamed design: rows in batches of independent loads, and only the rows of the
+        // INCLUDED features (a zero weight adds an exact zero: the same sums, bit for bit, as above)
         constexpr int RB = L >= 16 ? 2 : (L >= 8 ? 4 : 8);
         auto stream = [&](auto load_row) __attribute__((always_inline)) {
-#pragma unroll
-          for (int h = 0; h < 16 / RB; ++h) {
-            if (h * RB >= P) continue;
-            float xr[RB][L];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) load_row(h * RB + u < P ? h * RB + u : P - 1, xr[u]);
+          unsigned long long todo = __ballot(lane < P && wls[lane < P ? lane : 0] != 0.f);
+          while (todo != 0ull) {
+            float xr[RB][L], wj[RB];
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
-              const float wj = h * RB + u < P ? wv[h * RB + u] : 0.f;
-#pragma unroll
-              for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[u][l], wj, xw[l]);
+              const bool have = todo != 0ull;
+              const int j = have ? __ffsll((long long)todo) - 1 : 0;
+              todo &= todo - 1ull;
+              wj[u] = have ? wls[j] : 0.f;
+              load_row(j, xr[u]);
             }
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+#pragma unroll
+              for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[u][l], wj[u], xw[l]);
           }
         };
         if (xwide) {

@@ -35,6 +35,8 @@ def _fit_both(T, p, has_slope, W, S, C=1, seed=(5, 9), data_seed=0, chain_offset
     (300, 4, 1),    # P=5 => pi=0.6, inclusion flips, local linear trend
     (1000, 10, 1),  # BASELINE cfg2 shape
     (700, 10, 0),   # L=4 with padding, local level
+    (2048, 10, 1),  # L=8 build of the eight-wave kernel (1024 < T <= 2048), design in LDS limit
+    (1500, 12, 0),  # L=8, local level, 13 columns, ragged last chunk
     (4096, 10, 1),  # the register-resident regression block with the design streamed from L2
     (3001, 15, 0),  # ... 16 columns, T % 4 != 0 (scalar rows), ragged last chunk
     (500, 24, 0),   # P=25 > 16: LDS-resident regression block (in-place sweeps)
@@ -414,7 +416,9 @@ def test_streamed_fetch_of_a_seasonal_model_equals_run_then_fetch():
 
 
 @pytest.mark.parametrize("T,p,has_slope,B,C", [(1000, 10, 1, 1, 3), (500, 5, 0, 4, 2), (100, 1, 0, 1, 2),
-                                               (300, 15, 1, 1, 2)])
+                                               (300, 15, 1, 1, 2),
+                                               (2000, 10, 1, 1, 2),    # L = 8 (1024 < T <= 2048)
+                                               (1300, 6, 0, 2, 2)])
 def test_eight_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, B, C):
   """gibbs_kernel8 (a dedicated regression wavefront that sweeps the next iteration's matrix
   during the Durbin-Koopman draw and replays the recorded multipliers on the new right-hand

@@ -127,6 +127,11 @@ typedef struct ci_session ci_session;  /* device-resident fit: inputs + outputs 
 const char* ci_last_error(void);
 int ci_abi_version(void);
 int ci_device_count(int* count);
+/* The Philox key of series `series_id` of a fit with `seed`: key = (seed[0] ^ h1(id), seed[1] ^
+ * h2(id)), h1 / h2 bijective mixers that fix 0 -- series 0 (every single-series fit) keeps the
+ * plain seeds, and batches under different seeds never share a stream.  A single-series fit with
+ * seed = key reproduces series `series_id` of the batch (what the parity tests feed the oracle). */
+void ci_series_stream_key(const uint32_t seed[2], int32_t series_id, uint32_t key[2]);
 /* Waits for all work queued on `device` (bench.py brackets its timed region with it). */
 int ci_device_synchronize(int device);
 /* Device buffers of finished sessions are parked in a per-process pool (<= 32 GiB of the 288) for reuse by
@@ -331,6 +336,10 @@ int ci_comm_unique_id(int32_t transport, uint8_t* id /* [CI_COMM_ID_BYTES] */);
 int ci_comm_create(int32_t transport, const uint8_t* id, int32_t rank, int32_t world,
                    int32_t device, ci_comm** comm);
 int ci_comm_info(const ci_comm* comm, int32_t* rank, int32_t* world, int32_t* ranks_seen);
+/* Bound of ONE collective on this communicator, seconds (0: $CI_COMM_TIMEOUT_S, default 300).  A
+ * collective that exceeds it returns an error; on the RCCL transport the communicator is aborted
+ * (ncclCommAbort) so that its kernel leaves the GPU, and every later call on it fails at once. */
+int ci_comm_set_timeout(ci_comm* comm, double seconds);
 int ci_comm_barrier(ci_comm* comm);
 /* values [n] float64 on the host, reduced in place over all ranks (every rank gets the same bits). */
 int ci_comm_all_reduce(ci_comm* comm, double* values, int64_t n, int32_t op);

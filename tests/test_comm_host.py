@@ -176,3 +176,71 @@ def test_second_communicator_of_a_process_uses_its_own_rendezvous_file(monkeypat
   assert _comm.rendezvous_path() == "/tmp/ci_rdzv_x"
   assert _comm.rendezvous_path() == "/tmp/ci_rdzv_x.1"
   assert _comm.rendezvous_path() == "/tmp/ci_rdzv_x.2"
+
+
+def _nonce_worker(rank, world, path, nonce, q):
+  sys.path[:0] = [ROOT, PKG]
+  os.environ["CI_COMM_NONCE"] = nonce
+  from causalimpact import _comm
+  comm = _comm.Comm(rank, world, device=0, transport="host", path=path)
+  s = comm.all_reduce([1.0])
+  q.put((rank, float(s[0])))
+  comm.close()
+
+
+def test_a_young_leftover_of_another_launch_is_not_taken_for_this_launchs_id(tmp_path):
+  """a rendezvous file younger than the staleness window, left at the same path by
+  a crashed run, was accepted by a rank that polled before rank 0 replaced it.  The file now ends
+  with the launch nonce: rank 1 ignores the leftover (128 bytes of a dead id + another nonce) and
+  attaches only to what rank 0 of ITS launch publishes."""
+  sys.path[:0] = [PKG]
+  from causalimpact import _comm
+  path = str(tmp_path / "rdzv")
+  with open(path, "wb") as f:                       # the leftover: a well-formed file, foreign nonce
+    f.write(bytes(range(128)) + b"\x07" * _comm.NONCE_BYTES)
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  late = ctx.Process(target=_nonce_worker, args=(1, 2, path, "this-launch", q))
+  late.start()                                      # polls the leftover for a while ...
+  import time
+  time.sleep(1.0)
+  assert late.is_alive() and q.empty()              # ... and has not attached to anything
+  first = ctx.Process(target=_nonce_worker, args=(0, 2, path, "this-launch", q))
+  first.start()
+  got = sorted(q.get(timeout=120) for _ in range(2))
+  first.join(60); late.join(60)
+  assert got == [(0, 2.0), (1, 2.0)]
+
+
+def test_a_collective_whose_peer_died_times_out_with_an_error(tmp_path):
+  """Every collective is bounded per communicator (ci_comm_set_timeout): rank 1 attaches and then
+  exits without taking part; rank 0's barrier must return an error after ~1 s, not hang."""
+  script = tmp_path / "die.py"
+  script.write_text(r"""
+import os, sys, time
+sys.path[:0] = [%r, %r]
+from causalimpact import _comm, _native
+c = _comm.Comm(int(os.environ["RANK"]), 2, device=0, transport="host")
+if c.rank == 1:
+  os._exit(0)                      # dies after the set-up barrier, before the next collective
+c.set_timeout(1.0)
+t0 = time.monotonic()
+try:
+  c.all_reduce([1.0])
+except _native.NativeError as e:
+  dt = time.monotonic() - t0
+  assert "timed out" in str(e) and dt < 30.0, (str(e), dt)
+  print("bounded", flush=True)
+  os._exit(0)
+raise SystemExit("the collective returned although a rank was dead")
+""" % (ROOT, PKG))
+  sys.path[:0] = [PKG]
+  from causalimpact import _comm
+  launcher = tmp_path / "launch.py"
+  launcher.write_text(
+      "import sys\nsys.path[:0] = [%r, %r]\nfrom causalimpact import _comm\n"
+      "codes = _comm.spawn_ranks(2, [sys.executable, %r], transport='host', timeout=120)\n"
+      "assert codes == [0, 0], codes\n" % (ROOT, PKG, str(script)))
+  out = subprocess.run([sys.executable, str(launcher)], capture_output=True, text=True, timeout=180)
+  assert out.returncode == 0, out.stderr + out.stdout
+  assert "bounded" in out.stdout

@@ -346,9 +346,10 @@ def test_baseline_cfg5_full_size_batch_equals_single_series_runs_and_oracle():
     s1.close()
     for k in ("level", "weights", "observation_noise_scale"):
       np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
-    # the stream of series b: key word 1 = seed1 ^ series id (counter word 3 = the chain id)
-    w = orc.fit_gibbs(ys[b], masks[b], Xs[b], specs[b], num_results=S, num_warmup=W, seed=(5, 12 ^ b),
-                      chain=0)
+    # the stream of series b: both key words carry the mixed series id (ci_series_stream_key;
+    # counter word 3 = the chain id)
+    w = orc.fit_gibbs(ys[b], masks[b], Xs[b], specs[b], num_results=S, num_warmup=W,
+                      seed=_native.series_stream_key((5, 12), b), chain=0)
     np.testing.assert_allclose(batch["level"][b, 0], w["level"], atol=5e-3)
     np.testing.assert_allclose(batch["weights"][b, 0], w["weights"], atol=5e-3)
 
@@ -453,7 +454,7 @@ def test_eight_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, 
 
 
 def test_series_and_chain_ids_beyond_16_bits_have_their_own_streams():
-  """Series ids enter the Philox key (seed1 ^ series id), chain ids the counter word: neither is
+  """Series ids enter the Philox key (mixed into both words), chain ids the counter word: neither is
   limited to 16 bits any more (rounds 1-3 packed both into one counter word).  Series 70001 with
   chain ids 66000, 66001, against the oracle on the same stream."""
   T, p, W, S = 160, 3, 4, 6
@@ -463,7 +464,7 @@ def test_series_and_chain_ids_beyond_16_bits_have_their_own_streams():
                             chain_offset=66000, seed=(9, 77), series_offset=70001)
   got = _native.fit_gibbs(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
   for c in range(2):
-    want = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=(9, 77 ^ 70001),
+    want = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=_native.series_stream_key((9, 77), 70001),
                          chain=66000 + c)
     np.testing.assert_array_equal(got["weights"][0, c] != 0, want["weights"] != 0)
     np.testing.assert_allclose(got["level"][0, c], want["level"], atol=5e-3)
@@ -475,11 +476,34 @@ def test_series_and_chain_ids_beyond_16_bits_have_their_own_streams():
   assert np.abs(base["level"][0, 0] - got["level"][0, 0]).max() > 1e-3
 
 
+def test_batches_under_different_seeds_never_share_a_stream():
+  """with the series id XORed into seed1, series b under seed s drew from the
+  stream of series b ^ s ^ s' under seed s' -- a batch under seed 1 was a permutation of the same
+  batch under seed 0.  The id is now mixed into BOTH key words by bijections that fix 0: the keys
+  of 4096 series under seeds 0..7 are all distinct, series 0 keeps the plain seeds, and a device
+  fit of series 1 under seed 0 differs from a single-series fit under seed 1."""
+  keys = set()
+  for s in range(8):
+    assert _native.series_stream_key(s, 0) == (0, s)
+    for b in range(4096):
+      keys.add(_native.series_stream_key(s, b))
+  assert len(keys) == 8 * 4096
+  T, p = 120, 2
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 3)
+  spec = orc.default_spec(y, mask, X, has_slope=False)
+  def fit(seed, series_offset):
+    pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_warmup=2, num_results=3, num_chains=1,
+                              seed=seed, series_offset=series_offset)
+    return _native.fit_gibbs(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  a, b = fit(0, 1), fit(1, 0)
+  assert np.abs(a["level"] - b["level"]).max() > 1e-3
+
+
 @pytest.mark.parametrize("T,p,has_slope", [(1000, 10, 1), (500, 5, 0), (180, 2, 1)])
 def test_eight_wave_kernel_does_not_depend_on_the_schedule_of_its_helper_waves(T, p, has_slope, monkeypatch):
   """The regression wave's precompute and the randomness waves' rounds are background work placed
   between the workgroup barriers by a schedule word (csrc/ci_kernels8.h SCHED_DEFAULT).  Whatever
-  the schedule -- everything as early as possible ($CI_DBG=1), everything after the last barrier
+  the schedule -- everything as early as possible ($CI_SCHED_WORD=1), everything after the last barrier
   (2), or other quotas -- every output of every draw must be bit-identical: a difference would mean
   a buffer is read before it is complete or overwritten while still in use."""
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 11)
@@ -491,7 +515,7 @@ def test_eight_wave_kernel_does_not_depend_on_the_schedule_of_its_helper_waves(T
   out = {}
   for word in ("0", "1", "2", str((3 << 4) | (3 << 6) | (1 << 8) | (3 << 10) | (1 << 12) | (1 << 14)),
                str((0 << 4) | (0 << 6) | (3 << 8) | (0 << 10) | (3 << 12) | (0 << 14))):
-    monkeypatch.setenv("CI_DBG", word)
+    monkeypatch.setenv("CI_SCHED_WORD", word)
     sess.run()
     out[word] = sess.fetch()
   sess.close()

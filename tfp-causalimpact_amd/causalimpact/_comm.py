@@ -27,6 +27,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import hashlib
 import sys
 import tempfile
 import threading
@@ -52,6 +53,7 @@ def _bind(L):
   L.ci_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                              C.POINTER(C.c_int32)]
   L.ci_comm_barrier.argtypes = [C.c_void_p]
+  L.ci_comm_set_timeout.argtypes = [C.c_void_p, C.c_double]
   L.ci_comm_all_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
   L.ci_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
   L.ci_comm_session_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -82,14 +84,32 @@ def rendezvous_path() -> str:
   return p if seq == 0 else f"{p}.{seq}"
 
 
+NONCE_BYTES = 16
+
+
+def launch_nonce() -> bytes:
+  """What ties a rendezvous file to THIS launch: `spawn_ranks` hands every rank a fresh random
+  $CI_COMM_NONCE; under another launcher it is derived from the launcher's pid and run id.  A
+  leftover of a crashed earlier run at the same path carries another nonce and is ignored however
+  young it is (the one-hour staleness rule alone let a non-zero rank that polled
+  before rank 0's os.replace attach to a dead segment)."""
+  src = os.environ.get("CI_COMM_NONCE")
+  if not src:
+    src = ":".join([str(os.getppid()), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                    os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
+                    os.environ.get("MASTER_PORT", "0")])
+  return hashlib.sha256(src.encode()).digest()[:NONCE_BYTES]
+
+
 def _exchange_id(rank: int, transport: int, path: str, timeout: float = 300.0) -> bytes:
   L = _bind(_native.load())
+  nonce = launch_nonce()
   if rank == 0:
     buf = (C.c_uint8 * ID_BYTES)()
     _native._check(L.ci_comm_unique_id(transport, buf))
     tmp = f"{path}.tmp{os.getpid()}"
     with open(tmp, "wb") as f:
-      f.write(bytes(buf))
+      f.write(bytes(buf) + nonce)
     os.replace(tmp, path)                 # atomically replaces a leftover of a crashed run, too
     return bytes(buf)
   t0 = time.monotonic()
@@ -98,8 +118,8 @@ def _exchange_id(rank: int, transport: int, path: str, timeout: float = 300.0) -
       with open(path, "rb") as f:
         b = f.read()
         fresh = time.time() - os.fstat(f.fileno()).st_mtime < STALE_SECONDS
-      if len(b) == ID_BYTES and fresh:
-        return b
+      if len(b) == ID_BYTES + NONCE_BYTES and fresh and b[ID_BYTES:] == nonce:
+        return b[:ID_BYTES]
     except FileNotFoundError:
       pass
     if time.monotonic() - t0 > timeout:
@@ -158,6 +178,10 @@ class Comm:
 
   def barrier(self):
     _native._check(self._lib.ci_comm_barrier(self._h))
+
+  def set_timeout(self, seconds: float):
+    """Bound of one collective on this communicator (0: $CI_COMM_TIMEOUT_S, default 300 s)."""
+    _native._check(self._lib.ci_comm_set_timeout(self._h, float(seconds)))
 
   def all_reduce(self, values, op: int = SUM) -> np.ndarray:
     """float64 values reduced over the ranks (same bits on every rank)."""
@@ -278,9 +302,14 @@ def connect(rank: Optional[int] = None, world: Optional[int] = None, device: Opt
   if have_id:
     def join():
       c = Comm(rank, world, device, "rccl", uid=uid)
+      # the proving all-reduce may not outlive the deadline of the join itself: a join abandoned
+      # after init_timeout would otherwise keep its kernel spinning on the GPU for up to
+      # $CI_COMM_TIMEOUT_S while the fall-back run is being timed
+      c.set_timeout(init_timeout)
       s = c.all_reduce([1.0])
       if int(round(float(s[0]))) != world:
         raise _native.NativeError(f"proving all-reduce returned {float(s[0])}, expected {world}")
+      c.set_timeout(0.0)
       return c
     data, err, finished = _with_deadline(join, init_timeout)
     if err is not None:
@@ -312,10 +341,12 @@ def spawn_ranks(world: int, argv: Sequence[str], env: Optional[Dict[str, str]] =
   fd, path = tempfile.mkstemp(prefix="ci_comm_rdzv_")
   os.close(fd)
   os.unlink(path)
+  nonce = os.urandom(16).hex()            # ties the rendezvous files to this launch (launch_nonce)
   procs = []
   for r in range(world):
     e = dict(os.environ if env is None else env)
     e.update(RANK=str(r), WORLD_SIZE=str(world), CI_COMM_RDZV=path, CI_COMM_TRANSPORT=transport,
+             CI_COMM_NONCE=nonce,
              LOCAL_RANK=str(r if devices is None else devices[r]), CI_COMM_SPAWNED="1")
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs.append(subprocess.Popen(list(argv), env=e))

@@ -144,7 +144,9 @@ def ess_tail(draws: np.ndarray) -> float:
   if x.shape[1] // 2 < 4 or not np.isfinite(x).all() or np.ptp(x) == 0:
     return float("nan")
   lo, hi = tail_partials(x, x)
-  return float(np.nanmin([ess_from_sums(lo), ess_from_sums(hi)]))
+  both = np.array([ess_from_sums(lo), ess_from_sums(hi)], np.float64)
+  ok = np.isfinite(both)          # (nanmin of two NaNs would warn "All-NaN axis")
+  return float(both[ok].min()) if ok.any() else float("nan")
 
 
 def summarize(draws_by_key: Dict[str, np.ndarray]) -> Dict[str, Dict[str, float]]:

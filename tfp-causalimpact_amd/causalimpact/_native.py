@@ -80,6 +80,8 @@ def load():
   L.ci_last_error.restype = C.c_char_p
   L.ci_abi_version.restype = C.c_int
   L.ci_device_count.argtypes = [C.POINTER(C.c_int)]
+  L.ci_series_stream_key.argtypes = [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32)]
+  L.ci_series_stream_key.restype = None
   L.ci_device_synchronize.argtypes = [C.c_int]
   L.ci_fit_gibbs.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.POINTER(SeriesParams), C.POINTER(Outputs)]
@@ -136,7 +138,7 @@ def load():
 
 def exported_symbols() -> Sequence[str]:
   """Every entry point include/causalimpact_amd.h declares."""
-  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_device_synchronize", "ci_pool_trim", "ci_host_alloc",
+  return ("ci_last_error", "ci_abi_version", "ci_device_count", "ci_series_stream_key", "ci_device_synchronize", "ci_pool_trim", "ci_host_alloc",
           "ci_host_free", "ci_fit_gibbs", "ci_fit_gibbs_f64", "ci_fit_gibbs_f64_kernel_ms",
           "ci_session_create", "ci_session_run", "ci_session_run_streamed", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_kernel_name", "ci_session_destroy",
@@ -145,7 +147,7 @@ def exported_symbols() -> Sequence[str]:
           "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_create2", "ci_ll_session_eval",
           "ci_ll_session_draw_latents", "ci_ll_session_hmc_run", "ci_ll_session_hmc_fetch",
           "ci_ll_session_algorithmic_bytes", "ci_ll_session_destroy",
-          "ci_comm_unique_id", "ci_comm_create", "ci_comm_info", "ci_comm_barrier",
+          "ci_comm_unique_id", "ci_comm_create", "ci_comm_info", "ci_comm_set_timeout", "ci_comm_barrier",
           "ci_comm_all_reduce", "ci_comm_all_gather", "ci_comm_session_all_gather",
           "ci_comm_ll_session_all_gather", "ci_comm_destroy", "ci_test_rng",
           "ci_test_dk_draw")
@@ -154,6 +156,15 @@ def exported_symbols() -> Sequence[str]:
 def _check(rc: int):
   if rc != 0:
     raise NativeError(load().ci_last_error().decode("utf-8", "replace"))
+
+
+def series_stream_key(seed, series_id: int):
+  """(k0, k1): the Philox key of series `series_id` of a batch fitted with `seed` -- a
+  single-series fit (device or oracle) with seed = this key reproduces that series' draws."""
+  s = (C.c_uint32 * 2)(*[int(v) & 0xFFFFFFFF for v in seed_pair(seed)])
+  k = (C.c_uint32 * 2)()
+  load().ci_series_stream_key(s, int(series_id), k)
+  return (int(k[0]), int(k[1]))
 
 
 def device_count() -> int:

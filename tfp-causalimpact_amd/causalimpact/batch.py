@@ -295,6 +295,12 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
   a batch equals `fit_causalimpact` on that series alone with the same seed.
   `shared_streams=True` keys the streams by chain only: EVERY series then reproduces its
   single-series fit draw for draw, at the price of perfectly correlated Monte-Carlo errors.
+
+  `DataOptions.dtype=float64` and `standardize_data=False` batches are NOT one launch: they are
+  fitted series by series on the single-series routes (float64 kernels / exact internal
+  conditioning), i.e. B sequential fits on one device -- B times the cost of one fit, and
+  `inference_options.devices` is not used to shard them.  Their streams are keyed per series in
+  the same way (series b on the key of series id b) unless `shared_streams=True`.
   """
   data_options = data_options or lib.DataOptions()
   model_options = model_options or lib.ModelOptions()
@@ -326,13 +332,17 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
     # float64 compute (csrc/ci_gibbs64.h) and raw-scale outcomes (their per-series internal
     # conditioning, causalimpact_lib._internal_conditioning) exist on the single-series path: the
     # batch is fitted series by series there -- same container, same summary table, every series
-    # equal to `fit_causalimpact` on it alone with this seed (i.e. the streams are shared between
-    # the series, as with shared_streams=True).  Not the one-launch path: B sequential fits.
+    # keyed like the one-launch path (series b on the Philox key of series id b,
+    # ci_series_stream_key, so the Monte-Carlo errors of different series are independent; with
+    # shared_streams=True every series equals `fit_causalimpact` on it alone with this seed).
+    # Not the one-launch path: B sequential fits on one device (see the docstring).
     opts = dataclasses.replace(data_options, outcome_column=columns[0])
     analyses = []
+    base_seed = lib._sanitize_seed(seed)   # pylint: disable=protected-access
     for b in range(B):
+      seed_b = base_seed if shared_streams else _native.series_stream_key(base_seed, b)
       one = lib.fit_causalimpact(pd.DataFrame(values[b], index=index, columns=columns), pre_period,
-                                 post_period, alpha=alpha, seed=seed, data_options=opts,
+                                 post_period, alpha=alpha, seed=seed_b, data_options=opts,
                                  model_options=model_options, inference_options=inference_options)
       analyses.append(dataclasses.replace(one, posterior_samples=None))   # (draws are not kept)
     return PerSeriesBatchAnalysis(names, alpha, analyses)

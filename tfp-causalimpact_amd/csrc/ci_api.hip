@@ -423,9 +423,10 @@ ci::DevSeriesParams dev_series_params(const ci_series_params& q, double n_obs) {
 struct ci_session {
   ci_problem pb;
   int L = 0, x_in_lds = 0;
-  bool five_waves = false;     // dispatching to the eight-wave latency kernel (ci_kernels8.h)
+  bool eight_waves = false;    // dispatching to the eight-wave latency kernel (ci_kernels8.h)
+  int sched_word = 0;          // $CI_SCHED_WORD, read and validated once at session creation (0: the kernel's default)
   size_t lds_bytes = 0;
-  KernelFn fn = nullptr, fn_prof = nullptr, fn_prof5 = nullptr;
+  KernelFn fn = nullptr, fn_prof = nullptr, fn_prof8 = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<float> y, Xt, o_obs, o_lscale, o_sscale, o_w, o_level, o_slope, o_pm, o_traj;
@@ -468,6 +469,11 @@ extern "C" {
 const char* ci_last_error(void) { return g_err.c_str(); }
 
 int ci_abi_version(void) { return CI_ABI_VERSION; }
+
+void ci_series_stream_key(const uint32_t seed[2], int32_t series_id, uint32_t key[2]) {
+  key[0] = ci::stream_key0(seed[0], 0, series_id);
+  key[1] = ci::stream_key1(seed[1], 0, series_id);
+}
 
 int ci_device_count(int* count) {
   if (!count) return fail("count is NULL");
@@ -662,11 +668,22 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       }
       if (f8 && lds8 <= 160 * 1024) {
         s->fn = f8;
-        s->fn_prof5 = xg ? nullptr : pick_kernel8(D, s->L, 1, 0, nullptr);
-        if (s->fn_prof5)
-          HIP_TRY(hipFuncSetAttribute((const void*)s->fn_prof5,
+        s->fn_prof8 = xg ? nullptr : pick_kernel8(D, s->L, 1, 0, nullptr);
+        if (s->fn_prof8)
+          HIP_TRY(hipFuncSetAttribute((const void*)s->fn_prof8,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-        s->five_waves = true;
+        s->eight_waves = true;
+        // Experiment / test knob (tools/exp_sched.py, the schedule-independence test): a
+        // replacement for the helper waves' schedule word.  Read ONCE here, never on the launch
+        // path, and only a well-formed word is accepted -- a stray variable cannot silently change
+        // the production schedule.
+        if (const char* e_ = getenv("CI_SCHED_WORD")) {
+          char* end_ = nullptr;
+          const long v_ = strtol(e_, &end_, 0);
+          if (end_ == e_ || *end_ != 0 || v_ < 0 || v_ > 0xFFFF)
+            return fail("CI_SCHED_WORD must be an integer in [0, 65535], got '%s'", e_);
+          s->sched_word = (int)v_;
+        }
         s->lds_bytes = lds8;
         snprintf(nm, sizeof(nm), xg ? "ci::gibbs_kernel8<%d,%d,L2>" : "ci::gibbs_kernel8<%d,%d>", D, s->L);
         s->kernel_name = nm;
@@ -837,7 +854,7 @@ static int session_launch(ci_session* s) {
   a.prof = nullptr;
   a.progress = s->progress_every > 0 ? s->progress : nullptr;
   a.progress_every = s->progress_every > 0 ? s->progress_every : 1;
-  { const char* e_ = getenv("CI_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
+  a.dbg = s->sched_word;
   if (s->profile) {
     if (!s->prof.p) HIP_TRY(s->prof.alloc(32));
     HIP_TRY(hipMemsetAsync(s->prof.p, 0, 32 * sizeof(long long), s->stream));
@@ -871,8 +888,8 @@ static int session_launch(ci_session* s) {
     hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(grid), dim3(s->wide ? ci::NT : 64),
                        s->lds_bytes, s->stream, sa);
   } else {
-    if (s->profile && s->five_waves && s->fn_prof5) {
-      hipLaunchKernelGGL(s->fn_prof5, dim3(pb.num_series * pb.num_chains), dim3(ci::NT8), s->lds_bytes,
+    if (s->profile && s->eight_waves && s->fn_prof8) {
+      hipLaunchKernelGGL(s->fn_prof8, dim3(pb.num_series * pb.num_chains), dim3(ci::NT8), s->lds_bytes,
                          s->stream, a);
     } else if (s->profile && s->fn_prof) {
       // the instrumented variant is the four-wave kernel (its own LDS layout)
@@ -881,7 +898,7 @@ static int session_launch(ci_session* s) {
                          s->stream, a);
     } else {
       hipLaunchKernelGGL(s->fn, dim3(pb.num_series * pb.num_chains),
-                         dim3(s->five_waves ? ci::NT8 : ci::NT), s->lds_bytes, s->stream, a);
+                         dim3(s->eight_waves ? ci::NT8 : ci::NT), s->lds_bytes, s->stream, a);
     }
   }
   HIP_TRY(hipGetLastError());

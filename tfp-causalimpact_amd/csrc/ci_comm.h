@@ -34,6 +34,7 @@ struct RcclApi {
   int (*GetUniqueId)(RcclId*) = nullptr;
   int (*CommInitRank)(RcclComm*, int, RcclId, int) = nullptr;
   int (*CommDestroy)(RcclComm) = nullptr;
+  int (*CommAbort)(RcclComm) = nullptr;
   int (*CommCount)(RcclComm, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
@@ -67,6 +68,7 @@ int rccl_load() {
   CI_SYM(GetErrorString, "ncclGetErrorString")
 #undef CI_SYM
   *(void**)(&a.GetLastError) = dlsym(h, "ncclGetLastError");   // optional
+  *(void**)(&a.CommAbort) = dlsym(h, "ncclCommAbort");         // optional
   g_rccl = a;
   return 0;
 }
@@ -94,9 +96,14 @@ double mono_seconds() {
   return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 // hipStreamSynchronize with a deadline (hipStreamQuery polling): an RCCL collective whose peers
-// never arrive leaves its kernel spinning on the stream for ever.
-int stream_wait(hipStream_t st, const char* what) {
-  const double t0 = mono_seconds(), limit = comm_timeout_s();
+// never arrive leaves its kernel spinning on the stream for ever.  The caller queues NOTHING that
+// touches caller-owned host memory behind the collective before this returns 0 (a
+// device-to-host copy into pageable memory is host-synchronous in HIP -- queued behind a stuck
+// collective it would block inside hipMemcpyAsync, before this loop is ever reached, and after a
+// time-out the stream would still hold a copy into memory the caller may have freed): results are
+// copied out AFTER the collective has completed, when nothing on the stream can wait for a peer.
+int stream_wait_raw(hipStream_t st, const char* what, double limit) {
+  const double t0 = mono_seconds();
   for (unsigned spin = 0;; ++spin) {
     const hipError_t q = hipStreamQuery(st);
     if (q == hipSuccess) return 0;
@@ -128,6 +135,8 @@ struct ci_comm {
   // RCCL
   RcclComm nc = nullptr;
   hipStream_t stream = nullptr;
+  bool dead = false;             // a collective timed out: the communicator was aborted
+  double timeout_s = 0.0;        // bound of one collective (ci_comm_set_timeout; 0: $CI_COMM_TIMEOUT_S / 300 s)
   DevBuf<unsigned char> send, recv;
   // host
   HostHeader* hdr = nullptr;
@@ -137,6 +146,28 @@ struct ci_comm {
 };
 
 namespace {
+
+// Bounded wait for the collective queued on c->stream.  On a time-out the communicator is ABORTED
+// (ncclCommAbort makes the spinning kernel exit; without it the kernel would keep a CU busy and the
+// stream could never be destroyed), the stream is given a few seconds to drain, and the comm is
+// marked dead: every later collective on it fails at once instead of queueing behind the wreck.
+double comm_limit(const ci_comm* c) { return c->timeout_s > 0.0 ? c->timeout_s : comm_timeout_s(); }
+int stream_wait(ci_comm* c, const char* what) {
+  if (stream_wait_raw(c->stream, what, comm_limit(c)) == 0) return 0;
+  const std::string keep = g_err;
+  c->dead = true;
+  if (c->nc && g_rccl.CommAbort) {
+    (void)g_rccl.CommAbort(c->nc);
+    c->nc = nullptr;
+    (void)stream_wait_raw(c->stream, "drain after ncclCommAbort", 5.0);
+  }
+  g_err = keep + (g_rccl.CommAbort ? "; communicator aborted" : "; librccl has no ncclCommAbort");
+  return 1;
+}
+int comm_alive(const ci_comm* c) {
+  if (c->dead) return fail("ci_comm (rccl transport): the communicator was aborted after a time-out");
+  return 0;
+}
 
 void host_name(const uint8_t* id, char* out, size_t n) {
   static const char* hx = "0123456789abcdef";
@@ -178,9 +209,9 @@ int host_barrier(ci_comm* c) {
     if ((spin & 63) == 63) {
       timespec t1;
       clock_gettime(CLOCK_MONOTONIC, &t1);
-      if ((double)(t1.tv_sec - t0.tv_sec) > comm_timeout_s())
-        return fail("ci_comm (host transport): barrier timed out after %.0f s (a rank died?)",
-                    comm_timeout_s());
+      if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > comm_limit(c))
+        return fail("ci_comm (host transport): barrier timed out after %.1f s (a rank died?)",
+                    comm_limit(c));
       usleep(50);
     } else {
       sched_yield();
@@ -293,10 +324,11 @@ int gather_device_floats(ci_comm* c, const float* dev, size_t count, float* recv
   const size_t bytes = count * sizeof(float);
   if (c->transport == CI_COMM_RCCL) {
     if (device != c->device) return fail("ci_comm: session is on device %d, communicator on %d", device, c->device);
-    if (comm_scratch(c, 0, bytes * c->world)) return 1;
+    if (comm_alive(c) || comm_scratch(c, 0, bytes * c->world)) return 1;
     RCCL_TRY(c->nc, g_rccl.AllGather(dev, c->recv.p, count, RCCL_FLOAT32, c->nc, c->stream));
-    HIP_TRY(hipMemcpyAsync(recv, c->recv.p, bytes * c->world, hipMemcpyDeviceToHost, c->stream));
-    return stream_wait(c->stream, "ncclAllGather of a resident result array");
+    if (stream_wait(c, "ncclAllGather of a resident result array")) return 1;
+    HIP_TRY(hipMemcpy(recv, c->recv.p, bytes * c->world, hipMemcpyDeviceToHost));   // collective done
+    return 0;
   }
   std::vector<unsigned char> mine(bytes);
   HIP_TRY(hipMemcpy(mine.data(), dev, bytes, hipMemcpyDeviceToHost));
@@ -373,6 +405,12 @@ int ci_comm_info(const ci_comm* c, int32_t* rank, int32_t* world, int32_t* ranks
   return 0;
 }
 
+int ci_comm_set_timeout(ci_comm* c, double seconds) {
+  if (!c) return fail("comm is NULL");
+  c->timeout_s = seconds > 0.0 ? seconds : 0.0;
+  return 0;
+}
+
 int ci_comm_all_reduce(ci_comm* c, double* values, int64_t n, int32_t op) {
   if (!c || (n > 0 && !values)) return fail("NULL argument");
   if (n < 0) return fail("n must be >= 0");
@@ -381,12 +419,15 @@ int ci_comm_all_reduce(ci_comm* c, double* values, int64_t n, int32_t op) {
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
   const size_t bytes = (size_t)n * sizeof(double);
-  if (comm_scratch(c, bytes, bytes)) return 1;
+  if (comm_alive(c) || comm_scratch(c, bytes, bytes)) return 1;
+  // the upload completes before anything can wait for a peer (nothing is queued ahead of it)
   HIP_TRY(hipMemcpyAsync(c->send.p, values, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   RCCL_TRY(c->nc, g_rccl.AllReduce(c->send.p, c->recv.p, (size_t)n, RCCL_FLOAT64,
                                    op == CI_COMM_MAX ? RCCL_MAX : RCCL_SUM, c->nc, c->stream));
-  HIP_TRY(hipMemcpyAsync(values, c->recv.p, bytes, hipMemcpyDeviceToHost, c->stream));
-  return stream_wait(c->stream, "ncclAllReduce");
+  if (stream_wait(c, "ncclAllReduce")) return 1;
+  HIP_TRY(hipMemcpy(values, c->recv.p, bytes, hipMemcpyDeviceToHost));               // collective done
+  return 0;
 }
 
 int ci_comm_barrier(ci_comm* c) {
@@ -403,11 +444,13 @@ int ci_comm_all_gather(ci_comm* c, const void* send, void* recv, int64_t bytes) 
     return host_all_gather(c, (const unsigned char*)send, (unsigned char*)recv, (size_t)bytes);
   if (bytes == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
-  if (comm_scratch(c, (size_t)bytes, (size_t)bytes * c->world)) return 1;
+  if (comm_alive(c) || comm_scratch(c, (size_t)bytes, (size_t)bytes * c->world)) return 1;
   HIP_TRY(hipMemcpyAsync(c->send.p, send, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   RCCL_TRY(c->nc, g_rccl.AllGather(c->send.p, c->recv.p, (size_t)bytes, RCCL_INT8, c->nc, c->stream));
-  HIP_TRY(hipMemcpyAsync(recv, c->recv.p, (size_t)bytes * c->world, hipMemcpyDeviceToHost, c->stream));
-  return stream_wait(c->stream, "ncclAllGather");
+  if (stream_wait(c, "ncclAllGather")) return 1;
+  HIP_TRY(hipMemcpy(recv, c->recv.p, (size_t)bytes * c->world, hipMemcpyDeviceToHost));   // collective done
+  return 0;
 }
 
 int ci_comm_session_all_gather(ci_comm* c, ci_session* s, int32_t field, float* recv) {

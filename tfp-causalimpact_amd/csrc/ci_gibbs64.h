@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64) void gibbs64_kernel(G64Args a) {
 
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
-  Rng rng{g.seed0, stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
+  Rng rng{stream_key0(g.seed0, g.series_stream_base, series), stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
   const bool lat = a.lat_theta != nullptr;
   uint32_t itb = 0u;                          // iteration offset of the random stream
   const double* lth = nullptr;
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(NT64) void gibbs64_trend_kernel(G64Args a) {
   bigp_point(R, a.reg_lds ? smem + L.reg : wsc + ((L.t_total + 255) & ~(size_t)255), P > 0 ? P : 1);
 
   const DevSeriesParams sp = g.sp[series];
-  const Rng rng{g.seed0, stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
+  const Rng rng{stream_key0(g.seed0, g.series_stream_base, series), stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
   const double* Xg = g.Xt + (size_t)series * P * T;
   const double* chol1 = a.p1_chol + (size_t)series * a.dred * a.dred;
 

@@ -73,20 +73,32 @@ struct KArgs {
   // draws of its chain in progress[series * C + chain] (host-coherent pinned memory).
   unsigned int* progress;
   int progress_every;
-  int dbg;                 // $CI_DBG: replaces the eight-wave kernel's helper-wave schedule word
+  int dbg;                 // $CI_SCHED_WORD: replaces the eight-wave kernel's helper-wave schedule word
                            // (ci_kernels8.h SCHED_DEFAULT) -- timing experiments and the
                            // timing-independence test; 0 in production
 };
 
 // The random stream of (series, chain): Philox counter word 3 = the global chain id (all 32 bits),
-// key = (seed0, seed1 ^ series id).  Series 0 -- every single-series fit -- keeps the plain seeds,
-// so the result of a series does not depend on whether it was fitted alone or as series 0 of a
-// batch; distinct series ids give distinct keys, i.e. independent streams.  (Rounds 1-3 packed
-// series and chain id into the counter word, 16 bits each: batches beyond 65,536 series or chains
-// were refused.)
+// key = (seed0 ^ h1(series id), seed1 ^ h2(series id)) with h1, h2 two bijective 32-bit mixers
+// that fix 0.  Series 0 -- every single-series fit -- keeps the plain seeds, so the result of a
+// series does not depend on whether it was fitted alone or as series 0 of a batch.  Both key words
+// carry the id: two runs that share seed0 (an int seed s maps to (0, s), causalimpact_lib.py:535-539)
+// can only meet on a key if h1(b) == h1(b'), i.e. b == b', and then seed1 must agree too -- a batch
+// under seed s and the same batch under seed s' never share a stream.  (Round 4 folded the id
+// into seed1 by a raw XOR: series b under seed s aliased series b ^ s ^ s' under seed s'.  Rounds
+// 1-3 packed series and chain id into the counter word, 16 bits each.)
+__host__ __device__ inline uint32_t stream_mix32(uint32_t h) {   // murmur3 finaliser: bijective, 0 -> 0
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline uint32_t stream_sid(int series_stream_base, int series) {
+  return series_stream_base < 0 ? 0u : (uint32_t)(series_stream_base + series);
+}
+__host__ __device__ inline uint32_t stream_key0(uint32_t seed0, int series_stream_base, int series) {
+  return seed0 ^ stream_mix32(stream_sid(series_stream_base, series));
+}
 __host__ __device__ inline uint32_t stream_key1(uint32_t seed1, int series_stream_base, int series) {
-  const uint32_t sid = series_stream_base < 0 ? 0u : (uint32_t)(series_stream_base + series);
-  return seed1 ^ sid;
+  return seed1 ^ stream_mix32(stream_sid(series_stream_base, series) * 0x9E3779B9u);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2581,7 +2593,7 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
   const int RS = (P > 16 ? P : 16) + 4;   // stride of the per-wave partial-sum rows
 
   Rng rng;
-  rng.k0 = a.seed0;
+  rng.k0 = stream_key0(a.seed0, a.series_stream_base, series);
   rng.k1 = stream_key1(a.seed1, a.series_stream_base, series);
   rng.chain = (uint32_t)(a.chain_offset + chain);
 

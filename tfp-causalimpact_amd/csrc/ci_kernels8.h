@@ -48,7 +48,7 @@
 namespace ci {
 
 // Schedule of the helper waves (see "scheduling of the helper waves" below), one word so that
-// $CI_DBG can replace it for experiments without a rebuild:
+// $CI_SCHED_WORD can replace it for experiments without a rebuild:
 //   bits 0-1   test mode: 1 = all background work as early as possible, 2 = as late as possible
 //   bits 4-5   regression wave: sweeps before (B3)        bits 6-7   ... between (B3) and (B4)
 //   bits 8-9   ... left for after (B5)
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
   const int n_iter = a.W + a.S;
 
   Rng rng;
-  rng.k0 = a.seed0;
+  rng.k0 = stream_key0(a.seed0, a.series_stream_base, series);
   rng.k1 = stream_key1(a.seed1, a.series_stream_base, series);
   rng.chain = (uint32_t)(a.chain_offset + chain);
 
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     for (int k = k_lo; k < k_hi; ++k) normals_round(k, 0u);
     eprof.tick(30);
     // rounds finished on arrival at (B3), (B4), (B5): see "scheduling of the helper waves" above.
-    // $CI_DBG modes 1 / 2 (everything right after (Bs) / everything after (B5)) exist for the
+    // $CI_SCHED_WORD modes 1 / 2 (everything right after (Bs) / everything after (B5)) exist for the
     // timing-independence test.
     const int sched = (a.dbg & 0xFFFF) ? (a.dbg & 0xFFFF) : SCHED_DEFAULT;
     const int mode = sched & 3;

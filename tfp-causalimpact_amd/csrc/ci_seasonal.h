@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void gibbs_seasonal_kernel(SArgs a) {
 
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
-  Rng rng{g.seed0, stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
+  Rng rng{stream_key0(g.seed0, g.series_stream_base, series), stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
   const bool lat = a.lat_theta != nullptr;
   uint32_t itb = 0u;                          // iteration offset of the random stream
   const double* lth = nullptr;

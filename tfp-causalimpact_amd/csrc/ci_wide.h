@@ -900,7 +900,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
 
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
-  Rng rng{g.seed0, stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
+  Rng rng{stream_key0(g.seed0, g.series_stream_base, series), stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
   const float* yg = g.y + (size_t)series * T;
   const float* Xg = g.Xt + (size_t)series * P * T;
   const float* chol1 = a.p1_chol + (size_t)series * D * D;

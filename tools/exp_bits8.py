@@ -13,7 +13,7 @@ for b in (100, 511, 37, 5):
   spec = orc.default_spec(y, mask, X)
   out = {}
   for flags, dbg in ((0, "0"), (_native.FLAG_FOUR_WAVES, "0"), (1000, "1"), (2000, "2")):
-    os.environ["CI_DBG"] = dbg
+    os.environ["CI_SCHED_WORD"] = dbg
     pb = _native.make_problem(T=T, P=6, has_slope=0, num_warmup=W, num_results=S, seed=(5, 12),
                               series_offset=b, flags=flags if flags < 1000 else 0)
     s1 = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))

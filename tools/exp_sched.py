@@ -12,7 +12,7 @@ sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_para
 def word(p3, p4, pa, c3, c4, ca): return (p3 << 4) | (p4 << 6) | (pa << 8) | (c3 << 10) | (c4 << 12) | (ca << 14)
 res = []
 for p3, p4, pa, c3, c4, ca in itertools.product((2, 3), (0, 1, 2), (0, 1), (1, 2, 3), (0, 1, 2, 3), (0,)):
-  os.environ["CI_DBG"] = str(word(p3, p4, pa, c3, c4, ca))
+  os.environ["CI_SCHED_WORD"] = str(word(p3, p4, pa, c3, c4, ca))
   sess.run()
   ms = float(np.median([sess.run() for _ in range(3)]))
   res.append((ms, (p3, p4, pa, c3, c4, ca)))
@@ -20,5 +20,5 @@ res.sort()
 for ms, w in res[:15]: print(f"{ms:.3f} ms  p3,p4,pa,c3,c4,ca = {w}")
 print("...")
 for ms, w in res[-3:]: print(f"{ms:.3f} ms  {w}")
-os.environ["CI_DBG"] = "0"
+os.environ["CI_SCHED_WORD"] = "0"
 print("default", float(np.median([sess.run() for _ in range(5)])))

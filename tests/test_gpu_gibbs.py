@@ -190,6 +190,12 @@ SEQ = _native.FLAG_SEQUENTIAL_SEASONAL
     (250, 0, 1, ((62, 1),), 0),                         # D = 64: the widest state the kernel holds
     (280, 1, 0, ((24, 1), (7, 24)), 0),                 # hour-of-day and day-of-week: D = 32
     (280, 90, 1, ((4, 2), (7, 1)), 0),                  # P = 91, trend + two blocks
+    # (general block lists with a state <= 32 take the time-parallel kernel of ci_seasonal_tp.h by
+    # default since round 5; the sequential kernel keeps these cases through the flag)
+    (90, 1, 0, ((4, (2, 1, 1, 1)), (2, 3)), SEQ),
+    (300, 0, 0, ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1)))), SEQ),
+    (260, 0, 1, ((24, 1),), SEQ),
+    (280, 90, 1, ((4, 2), (7, 1)), SEQ),
 ])
 def test_seasonal_first_iterations_match_oracle_per_draw(T, p, has_slope, seasons, flags):
   """Seasonal kernels vs the oracle's (n-1)-dimensional Durbin-Koopman draw, same random
@@ -570,16 +576,25 @@ WS = _native.FLAG_SEASONAL_WORKSPACE
 
 @pytest.mark.parametrize("T,p,has_slope,seasons,flags", [
     (300, 3, 0, REF_SEASONS, WS),            # the reference's 4+7+6 test model, arrays in HBM
-    (300, 20, 0, REF_SEASONS, 0),            # P = 21 > 16: LDS one-wavefront regression block
-    (2500, 12, 1, REF_SEASONS, 0),           # beyond the LDS bound of round 1 (T <~ 890 at D = 18)
-    (5000, 30, 0, ((12, 30),), 0),           # a 12-season block (not on the time-parallel kernel), P = 31
+    (300, 20, 0, REF_SEASONS, SEQ),          # P = 21 > 16: LDS one-wavefront regression block
+    (2500, 12, 1, REF_SEASONS, SEQ),         # beyond the LDS bound of round 1 (T <~ 890 at D = 18)
+    (5000, 30, 0, ((12, 30),), SEQ),         # a 12-season block (not on ci_wide.h's kernel), P = 31
+    # the same models on the TIME-PARALLEL kernel (ci_seasonal_tp.h, the default route since round 5)
+    (300, 20, 0, REF_SEASONS, 0),            # 32 chunks of 12 steps, LDS regression block on wave 0
+    (2500, 12, 1, REF_SEASONS, 0),           # D = 19 with a slope: 128 chunks
+    (5000, 30, 0, ((12, 30),), 0),           # two changes per chunk at most
+    (10000, 50, 0, REF_SEASONS, 0),          # BASELINE cfg4's size with the reference's 4+7+6 model
+    (1200, 8, 1, ((24, 1), (7, 24)), 0),     # hour-of-day + day-of-week + trend: D = 33 > 32 -> sequential
+    (1200, 8, 0, ((24, 1), (7, 24)), 0),     # ... without the slope: D = 32, four register chunks
+    (900, 70, 0, REF_SEASONS, 0),            # P = 71 > 52: the workspace regression block on wave 0
 ])
 def test_general_seasonal_models_beyond_the_lds_bound_match_oracle_per_draw(T, p, has_slope, seasons,
                                                                            flags):
-  """Models other than trend + one 2..7-season block: the one-wavefront sequential kernel with
-  its arrays over time in the per-chain HBM workspace (any length) and, for P > 16, the
-  LDS-resident regression block -- the reference's own 4+7+6-season model
-  (causalimpact_lib_test.py:740-752) with covariates at lengths round 1 rejected."""
+  """Models other than trend + one 2..7-season block -- the reference's own 4+7+6-season model
+  (causalimpact_lib_test.py:740-752) with covariates, at lengths round 1 rejected -- on both
+  routes: the one-wavefront sequential kernel (arrays over time in the per-chain HBM workspace,
+  LDS-resident regression block for P > 16) and the time-parallel kernel of round 5 (chunks of
+  the series on the wavefronts of a cluster of workgroups, wave-cooperative scan elements)."""
   from causalimpact import _model
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
   rng = np.random.default_rng(0)
@@ -592,9 +607,13 @@ def test_general_seasonal_models_beyond_the_lds_bound_match_oracle_per_draw(T, p
   pb = _native.make_problem(T=T, P=spec["P"], has_slope=has_slope, num_seasons=counts,
                             num_warmup=0, num_results=S, seed=(2, 6), flags=flags)
   sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
-  assert "gibbs_seasonal_kernel" in sess.kernel_name()
-  if flags & WS or T > 1000:
-    assert "<true," in sess.kernel_name()
+  dfull = 1 + has_slope + sum(c for c in counts)
+  if flags == 0 and dfull <= 32:
+    assert "gibbs_seasonal_tp_kernel" in sess.kernel_name()
+  else:
+    assert "gibbs_seasonal_kernel" in sess.kernel_name()
+    if flags & WS or T > 1000:
+      assert "<true," in sess.kernel_name()
   sess.run()
   got = sess.fetch()
   sess.close()
@@ -619,7 +638,7 @@ def test_seasonal_kernel_with_arrays_in_hbm_equals_the_lds_variant():
   spec = orc.default_spec(y, mask, X, seasons=REF_SEASONS)
   counts, flg = _model.expand_seasons(REF_SEASONS, T)
   out = []
-  for flags in (0, WS):
+  for flags in (SEQ, SEQ | WS):
     pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_seasons=counts, num_warmup=5,
                               num_results=20, num_chains=2, seed=(3, 3), flags=flags)
     out.append(_native.fit_gibbs(pb, y[None], mask[None], X[None], flg, _native.make_params([spec])))
@@ -723,3 +742,87 @@ def test_shortest_series_match_the_oracle(T, p, has_slope):
   np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=1e-4)
   np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=1e-4)
   np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-4)
+
+
+def _tp_fit(T, p, has_slope, seasons, flags, W, S, C=1, seed=(2, 6), data_seed=7):
+  from causalimpact import _model
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, data_seed)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  mask = mask.copy()
+  mask[[2, 3, 40, T // 2]] = True
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
+  counts, flg = _model.expand_seasons(seasons, T)
+  pb = _native.make_problem(T=T, P=spec["P"], has_slope=has_slope, num_seasons=counts, num_warmup=W,
+                            num_results=S, num_chains=C, seed=seed, flags=flags)
+  sess = _native.Session(pb, y[None], mask[None], None if X is None else X[None], flg if seasons else None,
+                         _native.make_params([spec]))
+  name = sess.kernel_name()
+  sess.run()
+  got = sess.fetch()
+  sess.close()
+  return name, got, (y, mask, X, spec)
+
+
+def test_time_parallel_general_seasonal_kernel_with_a_dropped_helper_gives_the_same_bits():
+  """ci_seasonal_tp.h: if a workgroup of a chain's cluster is never scheduled, the first workgroup
+  notices while assembling the cluster and runs every chunk itself -- same chunks, same arithmetic,
+  same bits (CI_FLAG_TEST_DROP_HELPER makes the last workgroup leave at once)."""
+  args = dict(T=3000, p=6, has_slope=1, seasons=REF_SEASONS, W=2, S=4, C=2)
+  name, whole, _ = _tp_fit(flags=0, **args)
+  assert "gibbs_seasonal_tp_kernel" in name and not name.endswith("x1")
+  _, alone, _ = _tp_fit(flags=_native.FLAG_TEST_DROP_HELPER, **args)
+  for k, v in whole.items():
+    np.testing.assert_array_equal(alone[k], v, err_msg=k)
+
+
+def test_time_parallel_general_seasonal_kernel_on_any_cluster_size_follows_the_oracle():
+  """One workgroup per chain (CI_FLAG_NO_CLUSTER: 8 chunks) and a cluster (8 G chunks) cut the
+  series differently -- other summation orders, other scan trees -- so they agree with each other
+  and with the oracle to float32 accuracy per draw, not bit for bit."""
+  args = dict(T=2000, p=4, has_slope=0, seasons=REF_SEASONS, W=0, S=3)
+  n1, one, (y, mask, X, spec) = _tp_fit(flags=_native.FLAG_NO_CLUSTER, **args)
+  n2, many, _ = _tp_fit(flags=0, **args)
+  assert n1.endswith("x1") and "tp_kernel" in n2 and not n2.endswith("x1")
+  w = orc.fit_gibbs(y, mask, X, spec, num_results=3, num_warmup=0, seed=(2, 6))
+  for got in (one, many):
+    np.testing.assert_array_equal(got["weights"][0, 0] != 0, w["weights"] != 0)
+    np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=5e-3)
+    np.testing.assert_allclose(got["seasonal_levels"][0, 0], w["seasonal"], atol=5e-3)
+    np.testing.assert_allclose(got["seasonal_drift_scales"][0, 0], w["drift_scales"], rtol=2e-2)
+    np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=5e-3)
+    np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
+  np.testing.assert_allclose(one["level"], many["level"], atol=2e-3)
+
+
+def test_time_parallel_and_sequential_general_seasonal_kernels_sample_the_same_posterior():
+  """Long runs (beyond the draws where the kernels agree per random number): the time-parallel
+  kernel and the sequential one give the same posterior summaries on the reference's 4+7+6 model."""
+  args = dict(T=600, p=3, has_slope=0, seasons=REF_SEASONS, W=100, S=300, C=4, seed=(8, 1))
+  nt, tp, _ = _tp_fit(flags=0, **args)
+  ns, sq, _ = _tp_fit(flags=SEQ, **args)
+  assert "tp_kernel" in nt and "gibbs_seasonal_kernel" in ns
+  for key, tol in (("observation_noise_scale", 0.02), ("level_scale", 0.06)):
+    np.testing.assert_allclose(tp[key].mean(), sq[key].mean(), rtol=tol, err_msg=key)
+  np.testing.assert_allclose(tp["weights"].mean(axis=(0, 1, 2)), sq["weights"].mean(axis=(0, 1, 2)), atol=0.02)
+  np.testing.assert_allclose(tp["posterior_means"].mean(axis=(0, 1)), sq["posterior_means"].mean(axis=(0, 1)),
+                             atol=0.05)
+  np.testing.assert_allclose(tp["seasonal_levels"].mean(axis=(0, 1, 2)), sq["seasonal_levels"].mean(axis=(0, 1, 2)),
+                             atol=0.04)
+
+
+def test_trend_models_with_more_than_52_covariates_keep_their_sequential_route_too():
+  """Trend + P > 52 runs on the time-parallel kernel by default (test_first_iterations_...: 61,
+  131, 71, 512 columns); the sequential one-wavefront route stays reachable and equal per draw."""
+  T, p = 400, 60
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 0)
+  spec = orc.default_spec(y, mask, X, has_slope=False)
+  out = {}
+  for flags in (0, SEQ):
+    pb = _native.make_problem(T=T, P=spec["P"], has_slope=0, num_warmup=0, num_results=4, seed=(5, 9), flags=flags)
+    sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+    out[flags] = (sess.kernel_name(), sess.run(), sess.fetch())
+    sess.close()
+  assert "tp_kernel" in out[0][0] and "gibbs_seasonal_kernel" in out[SEQ][0]
+  np.testing.assert_array_equal(out[0][2]["weights"] != 0, out[SEQ][2]["weights"] != 0)
+  np.testing.assert_allclose(out[0][2]["level"], out[SEQ][2]["level"], atol=2e-3)
+  np.testing.assert_allclose(out[0][2]["weights"], out[SEQ][2]["weights"], atol=2e-3)

@@ -19,6 +19,7 @@
 #define CI_SEASONAL_DECL_ONLY
 #include "ci_seasonal.h"
 #include "ci_wide.h"
+#include "ci_seasonal_tp.h"
 #include "ci_summary.h"
 #include "ci_hmc.h"
 #include "ci_score_seq.h"
@@ -26,6 +27,10 @@
 #include "ci_wide_score.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(int);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nch1(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nch2(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nch3(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nch4(void);
 extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs*, int, hipStream_t);
 extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs*, int, hipStream_t);
 extern "C" void ci_launch_gibbs64(const ci::G64Args*, int, size_t, int, hipStream_t);
@@ -447,6 +452,8 @@ struct ci_session {
   int Lc = 0;
   DevBuf<float> ws;
   int cluster = 1;            // time-parallel seasonal kernel: workgroups per chain
+  bool tp = false;            // general seasonal models / trend + P > MAXP on ci_seasonal_tp.h
+  size_t tp_ws_bytes = 0;     //   its per-chain HBM workspace
   DevBuf<int> csync;
   DevBuf<float> cpart, cw;
   DevBuf<double> cv;
@@ -708,13 +715,38 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       s->lds_bytes = lay.total;
       s->seasonal_ws_bytes = ((lay.t_total + 255) & ~(size_t)255) + (bigp ? ci::bigp_workspace_bytes(P) : 0);
     }
+    // Any other block list -- and trend models with more than MAXP design columns -- with a state
+    // of at most 32 components: the TIME-PARALLEL kernel of ci_seasonal_tp.h, a cluster of up to 16
+    // workgroups of 8 wavefronts per chain (one chunk of the series per wavefront), as long as every
+    // chain of the launch gets at least one CU to itself (bigger batches are throughput-bound: one
+    // wavefront per chain on the sequential kernel does less work per step).
+    if (!s->wide && s->D_full <= ci::TP_MAXD && T >= 64 && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
+        !(pb->flags & CI_FLAG_SEASONAL_WORKSPACE)) {
+      int num_cus = 256;
+      (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, pb->device);
+      const long long groups = ((long long)B * C + 7) / 8 * 8;
+      const ci::TpLds tl = ci::make_tplds(P, s->D_full);
+      if ((long long)B * C <= num_cus && tl.total <= 160 * 1024) {
+        int G = 1;
+        if (!(pb->flags & CI_FLAG_NO_CLUSTER))
+          while (G < ci::TP_MAXG && groups * (2 * G) <= num_cus && T / (2 * G * ci::TP_NWV) >= 16) G *= 2;
+        s->tp = true;
+        s->cluster = G;
+        s->lds_bytes = tl.total;
+        s->tp_ws_bytes = ci::make_tplayout(T, P, K, s->D_full, pb->has_slope, G).total;
+        const int nch = (s->D_full + 7) / 8;
+        s->fn = (KernelFn)(nch == 1 ? ci_gibbs_seasonal_tp_fn_nch1() : nch == 2 ? ci_gibbs_seasonal_tp_fn_nch2()
+                           : nch == 3 ? ci_gibbs_seasonal_tp_fn_nch3() : ci_gibbs_seasonal_tp_fn_nch4());
+      }
+    }
     if (s->lds_bytes > 160 * 1024) {
       return fail("seasonal model needs %zu bytes of LDS per chain (max 163840): fewer covariates "
                   "or a narrower seasonal state", s->lds_bytes);
     }
-    if (!s->wide) s->fn = (KernelFn)ci_gibbs_seasonal_fn((s->seasonal_gws ? 1 : 0) | (bigp ? 2 : 0));
+    if (!s->wide && !s->tp) s->fn = (KernelFn)ci_gibbs_seasonal_fn((s->seasonal_gws ? 1 : 0) | (bigp ? 2 : 0));
     char nm[96];
-    if (s->wide) snprintf(nm, sizeof(nm), "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
+    if (s->tp) snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_tp_kernel<%d> x%d", (s->D_full + 7) / 8, s->cluster);
+    else if (s->wide) snprintf(nm, sizeof(nm), "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
     else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel<%s,%s>", s->seasonal_gws ? "true" : "false",
                   bigp ? "true" : "false");
     s->kernel_name = nm;
@@ -775,6 +807,10 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       HIP_TRY(s->cpart.alloc((size_t)B * C * (nseg > 0 ? nseg : 1) * ci::NW * RS));
       HIP_TRY(s->cw.alloc((size_t)B * C * 64));
       HIP_TRY(s->cv.alloc((size_t)B * C * ci::presweep_doubles(P)));
+    }
+    else if (s->tp) {
+      HIP_TRY(s->ws.alloc((size_t)B * C * (s->tp_ws_bytes / sizeof(float))));
+      HIP_TRY(s->csync.alloc((size_t)B * C * ci::TPC_INTS));
     }
     else if (s->seasonal_ws_bytes > 0) HIP_TRY(s->ws.alloc((size_t)B * C * (s->seasonal_ws_bytes / sizeof(float))));
     if (K > 0) HIP_TRY(hipMemcpy(s->season_change.p, season_change, (size_t)K * T, hipMemcpyHostToDevice));
@@ -876,16 +912,16 @@ static int session_launch(ci_session* s) {
     sa.season_change = s->season_change.p; sa.ssp = s->ssp.p; sa.p1_chol = s->p1_chol.p;
     sa.out_drift = s->o_drift.p; sa.out_seasonal = s->o_seasonal.p;
     sa.ws = s->ws.p; sa.Lc = s->Lc;
-    sa.ws_stride = s->wide ? 0 : s->seasonal_ws_bytes;
-    sa.cluster = s->wide ? s->cluster : 1;
+    sa.ws_stride = s->tp ? s->tp_ws_bytes : (s->wide ? 0 : s->seasonal_ws_bytes);
+    sa.cluster = (s->wide || s->tp) ? s->cluster : 1;
     sa.cluster_drop = (pb.flags & CI_FLAG_TEST_DROP_HELPER) ? sa.cluster - 1 : 0;
     sa.csync = s->csync.p; sa.cpart = s->cpart.p; sa.cw = s->cw.p; sa.cv = s->cv.p;
     int grid = pb.num_series * pb.num_chains;
-    if (s->wide && s->cluster > 1) {
+    if ((s->wide || s->tp) && s->cluster > 1) {
       HIP_TRY(hipMemsetAsync(s->csync.p, 0, s->csync.n * sizeof(int), s->stream));
       grid = (grid + 7) / 8 * 8 * s->cluster;       // (chain, role) <- workgroup id: see ci_wide.h
     }
-    hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(grid), dim3(s->wide ? ci::NT : 64),
+    hipLaunchKernelGGL((void (*)(ci::SArgs))s->fn, dim3(grid), dim3(s->tp ? ci::TP_NT : (s->wide ? ci::NT : 64)),
                        s->lds_bytes, s->stream, sa);
   } else {
     if (s->profile && s->eight_waves && s->fn_prof8) {

@@ -1,0 +1,1561 @@
+// ci_seasonal_tp.h -- TIME-PARALLEL Gibbs kernel for ANY list of seasonal blocks (and for trend
+// models with more design columns than the register / LDS regression blocks hold).
+//
+// Reference path: causalimpact/causalimpact_lib.py:365-388 (gibbs_sampler.fit_with_gibbs_sampling)
+// on the model of :455-500; the reference's own multi-block test model (4 + 7 + 6 seasons) is
+// causalimpact_lib_test.py:738-752.  Until round 5 every model other than "trend + one block of
+// 2-7 seasons" ran on ci_seasonal.h: one wavefront per chain, sequential in time -- 18.7 ms per
+// Gibbs iteration at T = 10^4, i.e. the speed of one host core.
+//
+// Same arithmetic, cut in time:
+//   * the series is cut into N = G x 8 CHUNKS of Lc consecutive steps; a chain owns a CLUSTER of
+//     G workgroups (CUs) of 8 wavefronts, one chunk per wavefront;
+//   * the state keeps ci_seasonal.h's layout: lane i of a wavefront holds component i of every
+//     state-sized vector and ROW i of every D x D matrix (D = 1 + slope + sum of num_seasons <= 32),
+//     blocks in their full n-effect form in SLOT coordinates (transition = identity on a block,
+//     rank-one drift shocks, observation row e_0 + sum_k e_{off[k] + c_k(t)});
+//   * every recursion of the Durbin-Koopman draw becomes
+//         per-chunk pass  ->  scan over the chunks  ->  per-chunk pass:
+//       - prior simulation x+: chunk sums, prefix by addition;
+//       - Kalman filter: each chunk builds its Sarkka & Garcia-Fernandez element (A, b, C, eta, J)
+//         by rank-one folds of its steps (tp_build_pass: three row sweeps per step instead of the
+//         filter's one); the elements are scanned (Kogge-Stone inside the workgroup, then over the
+//         G workgroup totals) with a WAVE-COOPERATIVE combine -- matrix products with one operand
+//         broadcast from LDS, Gauss-Jordan on register rows with v_readlane pivots; every chunk
+//         then replays the plain filter from its true predicted moments (tp_filter_pass ==
+//         seasonal_filter_pass on a range), storing K_t and v_t / F_t;
+//       - backward recursion r: the chunk's affine map is M = (I + J P_start)^-1 A' -- the transpose
+//         of the closed-loop propagator A (I + P_start J)^-1, read off the chunk's element, no
+//         per-step accumulation -- and its offset is one zero-input backward pass; suffix scan of
+//         (M, c); second backward pass from the true r at the chunk's end;
+//       - forward reconstruction x^_{t+1} = T x^_t + Q_t r_t from x^ = a + P r at the chunk's start.
+//   * X~'targets, X w, the emission of the previous draw and the normals are split by chunks too;
+//     the regression draw and the scale draws stay on wavefront 0 of the chain's first workgroup
+//     (the one-wavefront blocks of ci_kernels.h: registers for P <= 16, LDS to 52, HBM workspace
+//     beyond), the other wavefronts wait at a cluster barrier.
+// Elements travel through a per-chain HBM workspace (L2-resident); inside a workgroup the hand-off
+// is a workgroup barrier, across workgroups a counter per workgroup in HBM (ci_wide.h's scheme:
+// L2-local when the cluster sits on one XCD).  If the cluster cannot be assembled (another stream
+// holds the CUs) the first workgroup runs all N chunks itself: same bits.
+// The random stream is ci_seasonal.h's, site for site: draws agree with the oracle per random
+// number (tests/test_gpu_gibbs.py), and with the sequential kernel up to summation order.
+#pragma once
+#include "ci_kernels.h"
+#include "ci_seasonal.h"
+
+namespace ci {
+
+constexpr int TP_NWV = 8;                  // wavefronts (chunks) per workgroup
+constexpr int TP_NT = TP_NWV * 64;
+constexpr int TP_MAXG = 16;                // workgroups per chain
+constexpr int TP_MAXD = 32;                // widest state
+constexpr int TPC_INTS = 64;               // handshake ints per chain: [0,16) barrier | 16 mode | [32,48) check-in
+constexpr int TPC_MODE = 16, TPC_XCC = 32;
+constexpr int TP_STAT = 32;                // floats of statistics / boundary record per chunk
+
+__host__ __device__ inline int tp_nr(int D) { return ((D + 7) & ~7); }
+__host__ __device__ inline int tp_log2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+// floats of one forward element (rows of [A | C | J | b eta 0 0]) and one backward map ([M | c 0 0 0])
+__host__ __device__ inline size_t tp_esz(int NR) { return (size_t)NR * (3 * NR + 4); }
+__host__ __device__ inline size_t tp_bsz(int NR) { return (size_t)NR * (NR + 4); }
+
+// Per-chain HBM workspace (bytes from its base).
+struct TpLayout {
+  size_t yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs, mask, cbits, cidx;   // over time
+  size_t e0, ei, et, st, bm, bi, bt, xsum, stat, cpart, cw, big, total;
+  int Lc, TP, N, LVI, LVG;
+};
+__host__ __device__ inline TpLayout make_tplayout(int T, int P, int K, int D, int has_slope, int G) {
+  TpLayout l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+  const int N = G * TP_NWV;
+  int Lc = (T + N - 1) / N;
+  Lc = (Lc + 3) & ~3;
+  l.Lc = Lc; l.N = N; l.TP = N * Lc; l.LVI = tp_log2(TP_NWV); l.LVG = tp_log2(G);
+  const size_t Tf = sizeof(float) * (size_t)l.TP;
+  const int Kp = K > 0 ? K : 1, NR = tp_nr(D);
+  l.yv = take(Tf); l.lev = take(Tf); l.slp = take(has_slope ? Tf : 16); l.xw = take(Tf);
+  l.ytil = take(Tf); l.vf = take(Tf); l.zl = take(Tf); l.zs = take(has_slope ? Tf : 16); l.zo = take(Tf);
+  l.seas = take(Tf * Kp); l.zk = take(Tf * Kp); l.gd = take(Tf * Kp);
+  l.kf = take(Tf * D); l.rs = take(Tf * D + 256);
+  l.mask = take((size_t)l.TP); l.cbits = take((size_t)l.TP); l.cidx = take((size_t)l.TP * Kp);
+  const size_t E = sizeof(float) * tp_esz(NR), Bz = sizeof(float) * tp_bsz(NR);
+  l.e0 = take(E * N);                         // the chunks' own elements (kept for the backward maps)
+  l.ei = take(E * N * l.LVI);                 // Kogge-Stone levels inside the workgroups
+  l.et = take(E * G * (l.LVG + 1));           // ... over the workgroup totals
+  l.st = take(sizeof(float) * (size_t)N * NR * (NR + 4));   // chunk-start moments [P rows | a 0 0 0]
+  l.bm = take(Bz * N); l.bi = take(Bz * N * l.LVI); l.bt = take(Bz * G * (l.LVG + 1));
+  l.xsum = take(sizeof(float) * (size_t)N * 2 * NR);        // x+ chunk sums | x+ at the chunk's start
+  l.stat = take(sizeof(float) * (size_t)N * TP_STAT);
+  l.cpart = take(sizeof(float) * (size_t)N * ((P + 4) & ~3));
+  l.cw = take(sizeof(float) * (size_t)(((P + 3) & ~3) + 32));
+  l.big = take(P > MAXP ? bigp_workspace_bytes(P) : 16);
+  l.total = o;
+  return l;
+}
+
+// LDS of one workgroup: per-wavefront areas for the passes, overlaid (never live together) with the
+// regression block's buffers of wavefront 0; a few floats shared by the workgroup.
+struct TpLds {
+  size_t wave0, wave_stride, cm, am, scr, pzv, vb, reg, shared, total;
+  // regression block (offsets from `reg`)
+  size_t xtx, omega, bvec, aug0, pri0, chol, zv, uperm, nz, perm, idx, w;
+};
+__host__ __device__ inline TpLds make_tplds(int P, int D) {
+  TpLds l;
+  const int NR = tp_nr(D), DS = NR + 4;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
+  l.cm = take(sizeof(float) * D * DS);            // covariance rows (mirror of the register rows)
+  l.am = take(sizeof(float) * D * DS);            // A' rows (mirror)
+  l.scr = take(sizeof(float) * NR * NR);          // broadcast operand of the cooperative products
+  l.pzv = take(sizeof(float) * (72 + 72 + SMAXK * 72 + 16));   // C z | A'z | shock vectors | observed columns
+  l.vb = take(sizeof(float) * 2 * NR);            // broadcast vectors
+  l.wave_stride = o;
+  // regression block of wavefront 0 (as make_slayout)
+  o = 0;
+  const int Pp = P > 0 ? P : 1;
+  const bool bigp = P > MAXP, big = P > 16 && !bigp;
+  // (X'X and Omega are read where the setup kernel left them, in global memory: constants would not
+  // survive the overlay)
+  l.xtx = 0; l.omega = 0;
+  l.bvec = take(sizeof(double) * (Pp + 4));
+  l.aug0 = take(big ? sizeof(double) * sweep_padded((size_t)(Pp + 1) * (Pp + 1)) : 16);
+  l.chol = take(big ? sizeof(double) * Pp * Pp : 16);
+  l.zv = take(big ? sizeof(double) * Pp : 16);
+  l.uperm = take(big ? sizeof(double) * Pp : 16);
+  l.nz = take(big ? sizeof(int) * Pp : 16);
+  l.perm = take(big ? sizeof(int) * Pp : 16);
+  l.idx = take(big ? sizeof(int) * Pp : 16);
+  const size_t reg_bytes = o;
+  const size_t waves = (size_t)TP_NWV * l.wave_stride;
+  l.wave0 = 0; l.reg = 0;
+  o = waves > reg_bytes ? waves : reg_bytes;
+  l.w = take(sizeof(float) * (Pp > 16 ? Pp : 16));      // weights: live across the phases
+  // the prior precision swept on the current model is carried from iteration to iteration
+  l.pri0 = take(big ? sizeof(double) * sweep_padded((size_t)Pp * Pp) : 16);
+  l.shared = take(sizeof(float) * 64);
+  l.total = o;
+  return l;
+}
+
+#ifndef CI_SEASONAL_DECL_ONLY
+// ------------------------------------------------------------------------------------
+// synchronisation
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void tp_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+// hand-off through global memory between the lanes of ONE wavefront
+__device__ __forceinline__ void tp_wg_barrier_wave() { wave_sync(); }
+// hand-off through global memory inside one workgroup (one CU, one vector L1)
+__device__ __forceinline__ void tp_wg_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+struct TpSync {
+  int* flags;        // this chain's TPC_INTS counters
+  int G, g, epoch;
+  bool cluster;      // handshakes with other workgroups
+  bool light;        // ... all on this XCD
+};
+__device__ __forceinline__ void tp_cluster_barrier(TpSync& s, int tid) {
+  if (!s.cluster) { tp_wg_barrier(); return; }
+  ++s.epoch;
+  if (s.light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  else __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(s.flags + s.g, s.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = 0; r < s.G; ++r)
+      while (__hip_atomic_load(s.flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s.epoch)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// Assembling the cluster (ci_wide.h cl_assemble, for up to TP_MAXG workgroups): helpers check in
+// with their XCD id, workgroup 0 claims them and publishes the mode -- 2: all here, one XCD; 1: all
+// here, several XCDs; 3: somebody missing, workgroup 0 runs every chunk alone and the helpers leave.
+__device__ __forceinline__ int tp_assemble(int* csync, int role, int G, int tid, int* mode_lds) {
+  if (tid == 0) {
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 15) + 1;
+    const long long t0 = wall_clock64();                 // 100 MHz
+    int mode = 0;
+    if (role > 0) {
+      int* slot = csync + TPC_XCC + role;
+      __hip_atomic_store(slot, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        mode = __hip_atomic_load(csync + TPC_MODE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mode != 0) break;
+        if (wall_clock64() - t0 > 500000) {
+          int expect = xcc;
+          if (__hip_atomic_compare_exchange_strong(slot, &expect, -1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)) {
+            mode = 3;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    } else {
+      bool all = true, same = true;
+      for (int r = 1; r < G && all; ++r) {
+        int* slot = csync + TPC_XCC + r;
+        int v;
+        while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 &&
+               wall_clock64() - t0 < 100000)
+          __builtin_amdgcn_s_sleep(8);
+        int expect = v;
+        if (v <= 0 || !__hip_atomic_compare_exchange_strong(slot, &expect, v + 64, __ATOMIC_RELAXED,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          all = false;
+        else
+          same = same && v == xcc;
+      }
+      mode = all ? (same ? 2 : 1) : 3;
+      __hip_atomic_store(csync + TPC_MODE, mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *mode_lds = mode;
+  }
+  __syncthreads();
+  return *mode_lds;
+}
+
+// ------------------------------------------------------------------------------------
+// wave-cooperative linear algebra: lane i holds ROW i of an NR x NR matrix (zeros beyond D)
+// ------------------------------------------------------------------------------------
+template <int NR> struct TRow { float v[NR]; };
+
+template <int NR> __device__ __forceinline__ TRow<NR> trow_zero() {
+  TRow<NR> r;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) r.v[j] = 0.f;
+  return r;
+}
+// row `lane` of a matrix stored as rows of `stride` floats (16-byte aligned); zeros for lane >= NR
+template <int NR> __device__ __forceinline__ TRow<NR> trow_load(const float* base, int stride, int lane) {
+  TRow<NR> r = trow_zero<NR>();
+  if (lane < NR) {
+    const float4* p = reinterpret_cast<const float4*>(base + (size_t)lane * stride);
+#pragma unroll
+    for (int q = 0; q < NR / 4; ++q) {
+      const float4 x = p[q];
+      r.v[4 * q] = x.x; r.v[4 * q + 1] = x.y; r.v[4 * q + 2] = x.z; r.v[4 * q + 3] = x.w;
+    }
+  }
+  return r;
+}
+template <int NR> __device__ __forceinline__ void trow_store(float* base, int stride, int lane, const TRow<NR>& r) {
+  if (lane < NR) {
+    float4* p = reinterpret_cast<float4*>(base + (size_t)lane * stride);
+#pragma unroll
+    for (int q = 0; q < NR / 4; ++q)
+      p[q] = make_float4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
+  }
+}
+// the broadcast operand: rows into the wave's LDS scratch (row stride NR)
+template <int NR> __device__ __forceinline__ void tscr_put(float* scr, const TRow<NR>& r, int lane) {
+  tp_lds_sync();                       // earlier readers of the scratch are done
+  trow_store<NR>(scr, NR, lane, r);
+  tp_lds_sync();
+}
+// C = A B (+ I), rows of B in the scratch
+template <int NR> __device__ __forceinline__ TRow<NR> tmul(const TRow<NR>& A, const float* scr, int D, int lane,
+                                                           bool plus_eye = false) {
+  TRow<NR> c;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) c.v[j] = (plus_eye && j == lane) ? 1.f : 0.f;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    if (k < D) {
+      const float4* p = reinterpret_cast<const float4*>(scr + k * NR);
+      const float a = A.v[k];
+#pragma unroll
+      for (int q = 0; q < NR / 4; ++q) {
+        const float4 b = p[q];
+        c.v[4 * q] = fmaf(a, b.x, c.v[4 * q]); c.v[4 * q + 1] = fmaf(a, b.y, c.v[4 * q + 1]);
+        c.v[4 * q + 2] = fmaf(a, b.z, c.v[4 * q + 2]); c.v[4 * q + 3] = fmaf(a, b.w, c.v[4 * q + 3]);
+      }
+    }
+  }
+  return c;
+}
+// C = A B', rows of B in the scratch: C[i][j] = row_i(A) . row_j(B)
+template <int NR> __device__ __forceinline__ TRow<NR> tmul_t(const TRow<NR>& A, const float* scr, int D) {
+  TRow<NR> c = trow_zero<NR>();
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    if (j < D) {
+      const float4* p = reinterpret_cast<const float4*>(scr + j * NR);
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < NR / 4; ++q) {
+        const float4 b = p[q];
+        s = fmaf(A.v[4 * q], b.x, s); s = fmaf(A.v[4 * q + 1], b.y, s);
+        s = fmaf(A.v[4 * q + 2], b.z, s); s = fmaf(A.v[4 * q + 3], b.w, s);
+      }
+      c.v[j] = s;
+    }
+  }
+  return c;
+}
+// transpose through the scratch
+template <int NR> __device__ __forceinline__ TRow<NR> ttranspose(float* scr, const TRow<NR>& r, int lane) {
+  tscr_put<NR>(scr, r, lane);
+  TRow<NR> t = trow_zero<NR>();
+  if (lane < NR) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) t.v[k] = scr[k * NR + lane];
+  }
+  return t;
+}
+// row . (a lane-distributed vector): the vector goes through the wave's broadcast buffer
+template <int NR> __device__ __forceinline__ float tdot(const TRow<NR>& A, float* vb, float x, int lane) {
+  tp_lds_sync();
+  if (lane < NR) vb[lane] = x;
+  tp_lds_sync();
+  float s = 0.f;
+  const float4* p = reinterpret_cast<const float4*>(vb);
+#pragma unroll
+  for (int q = 0; q < NR / 4; ++q) {
+    const float4 b = p[q];
+    s = fmaf(A.v[4 * q], b.x, s); s = fmaf(A.v[4 * q + 1], b.y, s);
+    s = fmaf(A.v[4 * q + 2], b.z, s); s = fmaf(A.v[4 * q + 3], b.w, s);
+  }
+  return s;
+}
+// Gauss-Jordan without pivoting on register rows: [W | R0 | R1 | u] -> [I | W^-1 R0 | W^-1 R1 | W^-1 u].
+// W = I + (psd)(psd): eigenvalues >= 1.  The pivot row travels by v_readlane (uniform values); the
+// multiplier of lane c itself is W[c][c] - 1, which turns "row -= f * row_c / W[c][c]" into the
+// scaling of the pivot row -- one fused multiply-add per entry for every lane, no select.
+template <int NR, int NRHS>
+__device__ __forceinline__ void tgauss_jordan(TRow<NR>& W, TRow<NR>& R0, TRow<NR>& R1, float& u, int D, int lane) {
+#pragma unroll
+  for (int c = 0; c < NR; ++c) {
+    if (c < D) {
+      const float piv = readlane_f(W.v[c], c);
+      float rp = __builtin_amdgcn_rcpf(piv);
+      rp = fmaf(fmaf(-piv, rp, 1.0f), rp, rp);
+      const float f = W.v[c] - (lane == c ? 1.f : 0.f);
+#pragma unroll
+      for (int j = c + 1; j < NR; ++j) W.v[j] = fmaf(-f, readlane_f(W.v[j], c) * rp, W.v[j]);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) R0.v[j] = fmaf(-f, readlane_f(R0.v[j], c) * rp, R0.v[j]);
+      if constexpr (NRHS > 1) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) R1.v[j] = fmaf(-f, readlane_f(R1.v[j], c) * rp, R1.v[j]);
+      }
+      u = fmaf(-f, readlane_f(u, c) * rp, u);
+    }
+  }
+}
+
+// ---- forward (filtering) elements in the workspace: NR rows of [A | C | J | b eta 0 0] -------------
+template <int NR> struct TpElemPtr {
+  const float* p;
+  __device__ __forceinline__ TRow<NR> A(int lane) const { return trow_load<NR>(p, 3 * NR + 4, lane); }
+  __device__ __forceinline__ TRow<NR> C(int lane) const { return trow_load<NR>(p + NR, 3 * NR + 4, lane); }
+  __device__ __forceinline__ TRow<NR> J(int lane) const { return trow_load<NR>(p + 2 * NR, 3 * NR + 4, lane); }
+  __device__ __forceinline__ float b(int lane) const { return lane < NR ? p[(size_t)lane * (3 * NR + 4) + 3 * NR] : 0.f; }
+  __device__ __forceinline__ float eta(int lane) const { return lane < NR ? p[(size_t)lane * (3 * NR + 4) + 3 * NR + 1] : 0.f; }
+};
+template <int NR>
+__device__ __forceinline__ void tp_elem_store(float* p, int lane, const TRow<NR>& A, const TRow<NR>& C,
+                                              const TRow<NR>& J, float b, float eta) {
+  trow_store<NR>(p, 3 * NR + 4, lane, A);
+  trow_store<NR>(p + NR, 3 * NR + 4, lane, C);
+  trow_store<NR>(p + 2 * NR, 3 * NR + 4, lane, J);
+  if (lane < NR) *reinterpret_cast<float4*>(p + (size_t)lane * (3 * NR + 4) + 3 * NR) = make_float4(b, eta, 0.f, 0.f);
+}
+template <int NR> __device__ __forceinline__ void tp_elem_copy(float* dst, const float* src, int lane) {
+  const int n4 = (int)(tp_esz(NR) / 4);
+  for (int e = lane; e < n4; e += 64) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[e];
+}
+// out = e1 then e2 (e1 covers the earlier steps).  Operands are read from the workspace just in
+// time -- at most five matrices are live in registers.  STATE: only (b, C) of the result are
+// formed (the predicted moments at a chunk's start), written as rows of [C | b 0 0 0].
+template <int NR, bool STATE>
+__device__ __noinline__ void tp_combine(const float* g1, const float* g2, float* out, float* scr, float* vb,
+                                        int D, int lane) {
+  const TpElemPtr<NR> e1{g1}, e2{g2};
+  TRow<NR> Y = e1.C(lane);                       // C1, becomes W^-1 C1
+  // W = I + C1 J2
+  tscr_put<NR>(scr, e2.J(lane), lane);
+  TRow<NR> W = tmul<NR>(Y, scr, D, lane, true);
+  // u = b1 + C1 eta2
+  float u = e1.b(lane) + tdot<NR>(Y, vb, e2.eta(lane), lane);
+  TRow<NR> G = trow_zero<NR>(), T2 = trow_zero<NR>();
+  float w = 0.f;
+  if constexpr (!STATE) {
+    G = e1.A(lane);                              // A1, becomes W^-1 A1
+    const TRow<NR> J2 = e2.J(lane);
+    w = e2.eta(lane) - tdot<NR>(J2, vb, e1.b(lane), lane);     // eta2 - J2 b1
+    tscr_put<NR>(scr, G, lane);
+    T2 = tmul<NR>(J2, scr, D, lane);             // J2 A1
+    tgauss_jordan<NR, 2>(W, Y, G, u, D, lane);
+  } else {
+    tgauss_jordan<NR, 1>(W, Y, G, u, D, lane);
+  }
+  const TRow<NR> A2 = e2.A(lane);
+  const float bo = e2.b(lane) + tdot<NR>(A2, vb, u, lane);     // A2 W^-1 (b1 + C1 eta2) + b2
+  // C = A2 Y A2' + C2
+  tscr_put<NR>(scr, Y, lane);
+  const TRow<NR> T1 = tmul<NR>(A2, scr, D, lane);
+  tscr_put<NR>(scr, A2, lane);
+  TRow<NR> Co = tmul_t<NR>(T1, scr, D);
+  {
+    const TRow<NR> C2 = e2.C(lane);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) Co.v[j] += C2.v[j];
+  }
+  if constexpr (STATE) {
+    // symmetrised: the replayed filter's sweeps assume P = P'
+    const TRow<NR> Ct = ttranspose<NR>(scr, Co, lane);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) Co.v[j] = 0.5f * (Co.v[j] + Ct.v[j]);
+    trow_store<NR>(out, NR + 4, lane, Co);
+    if (lane < NR) *reinterpret_cast<float4*>(out + (size_t)lane * (NR + 4) + NR) = make_float4(bo, 0.f, 0.f, 0.f);
+  } else {
+    tscr_put<NR>(scr, G, lane);
+    const TRow<NR> Ao = tmul<NR>(A2, scr, D, lane);            // A2 G
+    const TRow<NR> Gt = ttranspose<NR>(scr, G, lane);
+    const float eo = e1.eta(lane) + tdot<NR>(Gt, vb, w, lane); // G'(eta2 - J2 b1) + eta1
+    tscr_put<NR>(scr, T2, lane);
+    TRow<NR> Jo = tmul<NR>(Gt, scr, D, lane);                  // G' J2 A1
+    {
+      const TRow<NR> J1 = e1.J(lane);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) Jo.v[j] += J1.v[j];
+    }
+    tp_elem_store<NR>(out, lane, Ao, Co, Jo, bo, eo);
+  }
+}
+// chunk-start moments from an element that already starts at the prior (A = 0): rows [C | b 0 0 0]
+template <int NR> __device__ __forceinline__ void tp_state_from_elem(const float* g, float* out, int lane) {
+  const TpElemPtr<NR> e{g};
+  trow_store<NR>(out, NR + 4, lane, e.C(lane));
+  if (lane < NR) *reinterpret_cast<float4*>(out + (size_t)lane * (NR + 4) + NR) = make_float4(e.b(lane), 0.f, 0.f, 0.f);
+}
+
+// ---- backward maps in the workspace: NR rows of [M | c 0 0 0]; (outer o inner)(r) = Mo (Mi r + ci) + co
+template <int NR>
+__device__ __noinline__ void tp_bcompose(const float* outer, const float* inner, float* out, float* scr, float* vb,
+                                         int D, int lane) {
+  const TRow<NR> Mo = trow_load<NR>(outer, NR + 4, lane);
+  const float co = lane < NR ? outer[(size_t)lane * (NR + 4) + NR] : 0.f;
+  const float ci = lane < NR ? inner[(size_t)lane * (NR + 4) + NR] : 0.f;
+  tscr_put<NR>(scr, trow_load<NR>(inner, NR + 4, lane), lane);
+  const TRow<NR> M = tmul<NR>(Mo, scr, D, lane);
+  const float c = co + tdot<NR>(Mo, vb, ci, lane);
+  trow_store<NR>(out, NR + 4, lane, M);
+  if (lane < NR) *reinterpret_cast<float4*>(out + (size_t)lane * (NR + 4) + NR) = make_float4(c, 0.f, 0.f, 0.f);
+}
+template <int NR> __device__ __forceinline__ void tp_bcopy(float* dst, const float* src, int lane) {
+  const int n4 = (int)(tp_bsz(NR) / 4);
+  for (int e = lane; e < n4; e += 64) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[e];
+}
+
+// ------------------------------------------------------------------------------------
+// per-chunk passes (one wavefront, steps [s, e) of the series)
+// ------------------------------------------------------------------------------------
+struct TpCtx {
+  int T, TP, D, DS, K, lane, blk, blk0, pos, nb, boff, has_slope;
+  int off[SMAXK], nsz[SMAXK];
+  float H, ql, qs, myd2, rnb, so, sl, ssc, mydrift;
+  // this wavefront's LDS
+  float *cm, *am, *scr, *pzv, *vb;
+  // arrays over time (this chain's workspace)
+  float *yv, *lev, *slp, *xw, *ytil, *vf, *zl, *zs, *zo, *seas, *zk, *gd, *kf, *rs;
+  uint8_t *msk, *cbv, *cidx;
+};
+
+__device__ __forceinline__ float tp_at4(const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
+// x+ through the chunk from `xp` (ci_seasonal.h pass 0 on a range; c_k(t) comes from the static
+// table).  WRITE: also y~ = (y - X w) - (Z x+ + sigma_obs z_obs).  Returns x+ after the chunk.
+template <bool WRITE>
+__device__ __forceinline__ float tp_sim_pass(const TpCtx& c, int s, int e, float xp) {
+  const int lane = c.lane;
+  const float* zkb = c.zk + (size_t)c.blk0 * c.TP;
+  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * c.TP;
+  for (int t4 = s; t4 < e; t4 += 4) {
+    const float4 zl4 = *reinterpret_cast<const float4*>(c.zl + t4);
+    const float4 zk4 = *reinterpret_cast<const float4*>(zkb + t4);
+    float4 zo4 = make_float4(0.f, 0.f, 0.f, 0.f), yv4 = zo4, xw4 = zo4, zs4 = zo4;
+    if (WRITE) {
+      zo4 = *reinterpret_cast<const float4*>(c.zo + t4);
+      yv4 = *reinterpret_cast<const float4*>(c.yv + t4);
+      xw4 = *reinterpret_cast<const float4*>(c.xw + t4);
+    }
+    if (c.has_slope) zs4 = *reinterpret_cast<const float4*>(c.zs + t4);
+    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(c.cbv + t4);
+    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    float yt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t4 + q;
+      const int mycur = (int)((cw4 >> (8 * q)) & 0xFFu);
+      yt[q] = 0.f;
+      if (WRITE) {
+        const bool isz = lane == 0 || (c.blk >= 0 && c.pos == mycur);
+        const float zx = wave_sum_dpp(isz ? xp : 0.f);
+        yt[q] = (tp_at4(yv4, q) - tp_at4(xw4, q)) - (zx + c.so * tp_at4(zo4, q));
+      }
+      if (t + 1 < c.T) {
+        const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
+        float r = xp;
+        if (c.has_slope) {
+          const float s1 = readlane_f(xp, 1);
+          if (lane == 0) r += s1;
+        }
+        if (lane == 0) r = fmaf(c.sl, tp_at4(zl4, q), r);
+        if (c.has_slope && lane == 1) r = fmaf(c.ssc, tp_at4(zs4, q), r);
+        if (c.blk >= 0 && ((cb >> c.blk) & 1u)) {
+          const float gi = (c.pos == mycur ? 1.f : 0.f) - c.rnb;
+          r = fmaf(c.mydrift * gi, tp_at4(zk4, q), r);
+        }
+        xp = r;
+      }
+    }
+    if (WRITE && lane == 0) *reinterpret_cast<float4*>(c.ytil + t4) = make_float4(yt[0], yt[1], yt[2], yt[3]);
+  }
+  return xp;
+}
+
+// Prior covariance of x_0 in slot coordinates (c_k(0) = 0): row `lane`.
+template <int NR>
+__device__ __forceinline__ TRow<NR> tp_prior_row(const TpCtx& c, float p1l, float p1s, float p1e) {
+  TRow<NR> r = trow_zero<NR>();
+  if (c.lane == 0) r.v[0] = p1l;
+  if (c.has_slope && c.lane == 1) r.v[1] = p1s;
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < c.K && c.blk == k && u >= c.off[k] && u < c.off[k] + c.nsz[k])
+        r.v[u] = p1e * ((u - c.off[k] == c.pos ? 1.f : 0.f) - c.rnb);
+  }
+  return r;
+}
+
+// The chunk's filtering element (A, b, C, eta, J): x_e | x_s ~ N(A x_s + b, C) given the chunk's
+// observations, and their likelihood as a function of x_s, N^-1(eta, J).  One pass over the steps;
+// per step the measurement update is a rank-one sweep of the own rows of C, A' and J, the time
+// update the sweep ci_seasonal.h's filter applies to P.  Registers hold the rows; LDS mirrors of C
+// and A' serve the reads with a run-time column (C z, A'z).  `first`: the chunk starts at the
+// prior, i.e. its element is (0, a_1, P_1, 0, 0) followed by its steps.
+template <int NCH>
+static __device__ __noinline__ void tp_build_pass(const TpCtx& c, int s, int e, bool first, float a1e,
+                                                   float p1l, float p1s, float p1e, float* eout) {
+  constexpr int NR = 8 * NCH;
+  const int lane = c.lane, D = c.D, DS = c.DS, T = c.T;
+  const bool slope = c.has_slope != 0, comp = lane < D;
+  CI_LDS float* Cm = (CI_LDS float*)c.cm;
+  CI_LDS float* Am = (CI_LDS float*)c.am;
+  CI_LDS float* Crow = Cm + (comp ? lane : 0) * DS;
+  CI_LDS float* Arow = Am + (comp ? lane : 0) * DS;
+  CI_LDS float* pzv = (CI_LDS float*)c.pzv;
+  CI_LDS float* zav = pzv + 72;
+  CI_LDS float* gvk = pzv + 144;
+  CI_LDS int* zcol = (CI_LDS int*)(gvk + SMAXK * 72);
+  CI_LDS const float* gmine = gvk + c.blk0 * 72;
+  CI_LDS float* gslot = gvk + c.blk0 * 72 + lane;
+  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * c.TP;
+  auto ld4 = [](CI_LDS const float* q) -> ci_f4v { return *(CI_LDS const ci_f4v*)q; };
+  const float H = c.H, ql = c.ql, qs = c.qs, myd2 = c.myd2, rnb = c.rnb;
+  if (lane < 8) zcol[lane] = D;
+  for (int x = lane; x < 144 + SMAXK * 72; x += 64) pzv[x] = 0.f;
+  tp_lds_sync();
+  if (c.blk >= 0 && c.pos == 0 && s < c.TP) zcol[c.blk] = c.boff + (int)cidb[s];
+  float crow[NR], arow[NR], jrow[NR];
+  float bi = 0.f, etai = 0.f;
+  {
+    const TRow<NR> p0 = first ? tp_prior_row<NR>(c, p1l, p1s, p1e) : trow_zero<NR>();
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      crow[u] = p0.v[u];
+      arow[u] = (!first && comp && u == lane) ? 1.f : 0.f;
+      jrow[u] = 0.f;
+    }
+    if (first) bi = a1e;
+  }
+  if (comp) {
+#pragma unroll
+    for (int q = 0; q < NR / 4; ++q) {
+      *(CI_LDS ci_f4v*)(Crow + 4 * q) = ci_f4v{crow[4 * q], crow[4 * q + 1], crow[4 * q + 2], crow[4 * q + 3]};
+      *(CI_LDS ci_f4v*)(Arow + 4 * q) = ci_f4v{arow[4 * q], arow[4 * q + 1], arow[4 * q + 2], arow[4 * q + 3]};
+    }
+    *(CI_LDS ci_f4v*)(Crow + NR) = ci_f4v{0.f, 0.f, 0.f, 0.f};      // the zero column unused zcol entries point at
+    *(CI_LDS ci_f4v*)(Arow + NR) = ci_f4v{0.f, 0.f, 0.f, 0.f};
+  }
+  tp_lds_sync();
+  for (int t4 = s; t4 < e; t4 += 4) {
+    const float4 yt4 = *reinterpret_cast<const float4*>(c.ytil + t4);
+    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(c.cbv + t4);
+    const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(c.msk + t4);
+    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const int t = t4 + q;
+      if (t + 1 >= T) continue;                   // (the last step's update feeds nothing)
+      const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+      const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
+      const int mycur = (int)((cw4 >> (8 * q)) & 0xFFu);
+      const bool isz = lane == 0 || (c.blk >= 0 && c.pos == mycur);
+      const bool mych = c.blk >= 0 && ((cb >> c.blk) & 1u) != 0u;
+      float cz = 0.f, za = 0.f, rS = 0.f;
+      if (obs) {
+        if (comp) {
+          const ci_i4v z0 = *(CI_LDS const ci_i4v*)zcol, z1 = *(CI_LDS const ci_i4v*)(zcol + 4);
+          cz = crow[0];
+          cz += Crow[z0.x]; cz += Crow[z0.y]; cz += Crow[z0.z]; cz += Crow[z0.w];
+          cz += Crow[z1.x]; cz += Crow[z1.y]; cz += Crow[z1.z]; cz += Crow[z1.w];
+          za = arow[0];
+          za += Arow[z0.x]; za += Arow[z0.y]; za += Arow[z0.z]; za += Arow[z0.w];
+          za += Arow[z1.x]; za += Arow[z1.y]; za += Arow[z1.z]; za += Arow[z1.w];
+        }
+        const float S = wave_sum_dpp(isz ? cz : 0.f) + H;
+        rS = __builtin_amdgcn_rcpf(S);
+        rS = fmaf(fmaf(-S, rS, 1.0f), rS, rS);
+        const float yq = q == 0 ? yt4.x : q == 1 ? yt4.y : q == 2 ? yt4.z : yt4.w;
+        const float inn = (yq - wave_sum_dpp(isz ? bi : 0.f)) * rS;
+        etai = fmaf(za, inn, etai);
+        bi = fmaf(cz, inn, bi);
+      }
+      const float gi = mych ? ((c.pos == mycur ? 1.f : 0.f) - rnb) : 0.f;
+      if (slope) {                                // b <- T b
+        const float b1 = readlane_f(bi, 1);
+        if (lane == 0) bi += b1;
+      }
+      if (!obs && cb == 0u && !slope) {
+        if (lane == 0) { crow[0] += ql; Crow[0] = crow[0]; }
+        continue;
+      }
+      if (comp) {
+        pzv[lane] = cz;
+        zav[lane] = za;
+        if (c.blk >= 0) *gslot = gi;
+      }
+      tp_lds_sync();
+      if (comp) {
+        const float cz1 = slope ? pzv[1] : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          if (8 * ch < D) {
+            const ci_f4v pa = ld4(pzv + 8 * ch), pb = ld4(pzv + 8 * ch + 4);
+            const ci_f4v za_ = ld4(zav + 8 * ch), zb_ = ld4(zav + 8 * ch + 4);
+            const ci_f4v ga = ld4(gmine + 8 * ch), gb = ld4(gmine + 8 * ch + 4);
+            const float pj[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+            const float zj[8] = {za_.x, za_.y, za_.z, za_.w, zb_.x, zb_.y, zb_.z, zb_.w};
+            const float gj[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+            if (slope) {
+              const ci_f4v qa = ld4(Cm + DS + 8 * ch), qb = ld4(Cm + DS + 8 * ch + 4);
+              const float p1[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                float r = fmaf(-(cz * pj[u]), rS, crow[8 * ch + u]);
+                if (lane == 0) r += fmaf(-(cz1 * pj[u]), rS, p1[u]);
+                crow[8 * ch + u] = fmaf(myd2, gi * gj[u], r);
+              }
+              if (ch == 0) {
+                crow[0] += crow[1];
+                if (lane == 1) crow[1] += qs;
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                crow[8 * ch + u] = fmaf(myd2, gi * gj[u], fmaf(-(cz * pj[u]), rS, crow[8 * ch + u]));
+            }
+            if (ch == 0 && lane == 0) crow[0] += ql;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              arow[8 * ch + u] = fmaf(-(za * pj[u]), rS, arow[8 * ch + u]);
+              jrow[8 * ch + u] = fmaf(za * zj[u], rS, jrow[8 * ch + u]);
+            }
+            if (slope && ch == 0) arow[0] += arow[1];     // A <- T A (column 0 of A' += column 1)
+            *(CI_LDS ci_f4v*)(Crow + 8 * ch) = ci_f4v{crow[8 * ch], crow[8 * ch + 1], crow[8 * ch + 2], crow[8 * ch + 3]};
+            *(CI_LDS ci_f4v*)(Crow + 8 * ch + 4) = ci_f4v{crow[8 * ch + 4], crow[8 * ch + 5], crow[8 * ch + 6], crow[8 * ch + 7]};
+            *(CI_LDS ci_f4v*)(Arow + 8 * ch) = ci_f4v{arow[8 * ch], arow[8 * ch + 1], arow[8 * ch + 2], arow[8 * ch + 3]};
+            *(CI_LDS ci_f4v*)(Arow + 8 * ch + 4) = ci_f4v{arow[8 * ch + 4], arow[8 * ch + 5], arow[8 * ch + 6], arow[8 * ch + 7]};
+          }
+      }
+      if (mych && c.pos == 0) zcol[c.blk] = c.boff + ((mycur + 1 == c.nb) ? 0 : mycur + 1);
+      tp_lds_sync();
+    }
+  }
+  // A' rows -> A rows, and out
+  TRow<NR> At, Cr, Jr;
+#pragma unroll
+  for (int u = 0; u < NR; ++u) { At.v[u] = comp ? arow[u] : 0.f; Cr.v[u] = comp ? crow[u] : 0.f; Jr.v[u] = comp ? jrow[u] : 0.f; }
+  const TRow<NR> A = ttranspose<NR>(c.scr, At, lane);
+  tp_elem_store<NR>(eout, lane, A, Cr, Jr, comp ? bi : 0.f, comp ? etai : 0.f);
+}
+
+// The Kalman filter on the chunk from its true predicted moments (rows [P | a 0 0 0] in `st`):
+// ci_seasonal.h's seasonal_filter_pass on a range.  Stores K_t and v_t / F_t.
+template <int NCH>
+static __device__ __noinline__ void tp_filter_pass(const TpCtx& c, int s, int e, const float* st) {
+  constexpr int NR = 8 * NCH;
+  const int lane = c.lane, D = c.D, DS = c.DS, T = c.T;
+  const bool slope = c.has_slope != 0, comp = lane < D;
+  CI_LDS float* Pm = (CI_LDS float*)c.cm;
+  CI_LDS float* Prow = Pm + (comp ? lane : 0) * DS;
+  CI_LDS float* pzv = (CI_LDS float*)c.pzv;
+  CI_LDS float* gvk = pzv + 144;
+  CI_LDS int* zcol = (CI_LDS int*)(gvk + SMAXK * 72);
+  CI_LDS const float* gmine = gvk + c.blk0 * 72;
+  CI_LDS float* gslot = gvk + c.blk0 * 72 + lane;
+  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * c.TP;
+  auto ld4 = [](CI_LDS const float* q) -> ci_f4v { return *(CI_LDS const ci_f4v*)q; };
+  const float H = c.H, ql = c.ql, qs = c.qs, myd2 = c.myd2, rnb = c.rnb;
+  if (lane < 8) zcol[lane] = D;
+  for (int x = lane; x < 144 + SMAXK * 72; x += 64) pzv[x] = 0.f;
+  tp_lds_sync();
+  if (c.blk >= 0 && c.pos == 0) zcol[c.blk] = c.boff + (int)cidb[s];
+  float prow[NR];
+  float am = 0.f;
+  {
+    const TRow<NR> p0 = trow_load<NR>(st, NR + 4, lane);
+#pragma unroll
+    for (int u = 0; u < NR; ++u) prow[u] = comp ? p0.v[u] : 0.f;
+    if (comp) am = st[(size_t)lane * (NR + 4) + NR];
+  }
+  if (comp) {
+#pragma unroll
+    for (int q = 0; q < NR / 4; ++q)
+      *(CI_LDS ci_f4v*)(Prow + 4 * q) = ci_f4v{prow[4 * q], prow[4 * q + 1], prow[4 * q + 2], prow[4 * q + 3]};
+    *(CI_LDS ci_f4v*)(Prow + NR) = ci_f4v{0.f, 0.f, 0.f, 0.f};
+  }
+  tp_lds_sync();
+  float* kfw = c.kf + (size_t)s * D + lane;
+  for (int t4 = s; t4 < e; t4 += 4) {
+    const float4 yt4 = *reinterpret_cast<const float4*>(c.ytil + t4);
+    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(c.cbv + t4);
+    const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(c.msk + t4);
+    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    float vfq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t4 + q;
+      vfq[q] = 0.f;
+      if (t >= T) continue;
+      const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
+      const unsigned cb = (t + 1 < T) ? ((cb4 >> (8 * q)) & 0xFFu) : 0u;
+      const int mycur = (int)((cw4 >> (8 * q)) & 0xFFu);
+      const bool isz = lane == 0 || (c.blk >= 0 && c.pos == mycur);
+      const bool mych = c.blk >= 0 && ((cb >> c.blk) & 1u) != 0u;
+      float kfi = 0.f, rF = 0.f, pz = 0.f;
+      if (obs) {
+        if (comp) {
+          const ci_i4v z0 = *(CI_LDS const ci_i4v*)zcol, z1 = *(CI_LDS const ci_i4v*)(zcol + 4);
+          pz = prow[0];
+          pz += Prow[z0.x]; pz += Prow[z0.y]; pz += Prow[z0.z]; pz += Prow[z0.w];
+          pz += Prow[z1.x]; pz += Prow[z1.y]; pz += Prow[z1.z]; pz += Prow[z1.w];
+        }
+        const float F = wave_sum_dpp(isz ? pz : 0.f) + H;
+        rF = __builtin_amdgcn_rcpf(F);
+        rF = fmaf(fmaf(-F, rF, 1.0f), rF, rF);
+        const float v = tp_at4(yt4, q) - wave_sum_dpp(isz ? am : 0.f);
+        kfi = pz * rF;
+        vfq[q] = v * rF;
+        am = fmaf(kfi, v, am);
+      }
+      const float gi = mych ? ((c.pos == mycur ? 1.f : 0.f) - rnb) : 0.f;
+      if (comp) {
+        *kfw = kfi;
+        pzv[lane] = pz;
+        if (c.blk >= 0) *gslot = gi;
+      }
+      kfw += D;
+      if (t + 1 == T) continue;
+      if (slope) {
+        const float m1 = readlane_f(am, 1);
+        if (lane == 0) am += m1;
+      }
+      if (!obs && cb == 0u && !slope) {
+        if (lane == 0) { prow[0] += ql; Prow[0] = prow[0]; }
+        continue;
+      }
+      tp_lds_sync();
+      if (comp) {
+        const float pz1 = slope ? pzv[1] : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          if (8 * ch < D) {
+            const ci_f4v pa = ld4(pzv + 8 * ch), pb = ld4(pzv + 8 * ch + 4);
+            const ci_f4v ga = ld4(gmine + 8 * ch), gb = ld4(gmine + 8 * ch + 4);
+            const float pj[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+            const float gj[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+            if (slope) {
+              const ci_f4v qa = ld4(Pm + DS + 8 * ch), qb = ld4(Pm + DS + 8 * ch + 4);
+              const float p1[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                float r = fmaf(-(pz * pj[u]), rF, prow[8 * ch + u]);
+                if (lane == 0) r += fmaf(-(pz1 * pj[u]), rF, p1[u]);
+                prow[8 * ch + u] = fmaf(myd2, gi * gj[u], r);
+              }
+              if (ch == 0) {
+                prow[0] += prow[1];
+                if (lane == 1) prow[1] += qs;
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                prow[8 * ch + u] = fmaf(myd2, gi * gj[u], fmaf(-(pz * pj[u]), rF, prow[8 * ch + u]));
+            }
+            if (ch == 0 && lane == 0) prow[0] += ql;
+            *(CI_LDS ci_f4v*)(Prow + 8 * ch) = ci_f4v{prow[8 * ch], prow[8 * ch + 1], prow[8 * ch + 2], prow[8 * ch + 3]};
+            *(CI_LDS ci_f4v*)(Prow + 8 * ch + 4) = ci_f4v{prow[8 * ch + 4], prow[8 * ch + 5], prow[8 * ch + 6], prow[8 * ch + 7]};
+          }
+      }
+      if (mych && c.pos == 0) zcol[c.blk] = c.boff + ((mycur + 1 == c.nb) ? 0 : mycur + 1);
+      tp_lds_sync();
+    }
+    if (lane == 0) *reinterpret_cast<float4*>(c.vf + t4) = make_float4(vfq[0], vfq[1], vfq[2], vfq[3]);
+  }
+}
+
+// Backward recursion over the chunk from r at its end; STORE: rs[t] = r_{t-1}.  Returns r_{s-1}.
+template <bool STORE>
+__device__ __forceinline__ float tp_backward_pass(const TpCtx& c, int s, int e, float r) {
+  const int lane = c.lane, D = c.D, T = c.T;
+  const bool comp = lane < D;
+  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * c.TP;
+  for (int t4 = ((e - 1) & ~3); t4 >= s; t4 -= 4) {
+    const float4 vf4 = *reinterpret_cast<const float4*>(c.vf + t4);
+    const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(c.msk + t4);
+    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    float kfq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kfq[q] = (comp && t4 + q < e) ? c.kf[(size_t)(t4 + q) * D + lane] : 0.f;
+#pragma unroll
+    for (int q = 3; q >= 0; --q) {
+      const int t = t4 + q;
+      if (t >= e) continue;
+      if (t + 1 < T) {
+        if (c.has_slope) {
+          const float r0 = readlane_f(r, 0);
+          if (lane == 1) r += r0;
+        }
+      } else {
+        r = 0.f;
+      }
+      if (((mk4 >> (8 * q)) & 0xFFu) == 0u) {
+        const int mycur = (int)((cw4 >> (8 * q)) & 0xFFu);
+        const float kr = wave_sum_dpp(kfq[q] * r);
+        if (lane == 0 || (c.blk >= 0 && c.pos == mycur)) r += tp_at4(vf4, q) - kr;
+      }
+      if (STORE && comp) c.rs[(size_t)t * D + lane] = r;
+    }
+  }
+  return r;
+}
+
+// g . r of this lane's block for the shock of the change at step t - 1 (g = e_{slot observed at
+// t-1} - 1/n), from a lane-distributed r: every lane of the block gets the value.
+__device__ __forceinline__ float tp_shock_dot(const TpCtx& c, float r, int cprev) {
+  float* vb = c.vb;
+  tp_lds_sync();
+  if (c.lane < c.D) vb[c.lane] = r;
+  tp_lds_sync();
+  float out = 0.f;
+  if (c.blk >= 0) {
+    float sb = 0.f;
+    for (int q = 0; q < c.nb; ++q) sb += vb[c.boff + q];
+    out = vb[c.boff + cprev] - sb * c.rnb;
+  }
+  return out;
+}
+
+// Forward reconstruction over the chunk (ci_seasonal.h pass 3 on a range): x^ from `xh`, x+ from
+// `xp`, r_t from rs (r_end beyond the chunk).  Writes level / slope / observed effects, leaves the
+// chunk's share of the scale statistics and its boundary records in stat[0..TP_STAT):
+//   [0] ss_level [1] ss_slope [2+k] ss_drift_k | [10] first level [11] first slope [12+k] first
+//   x~[slot observed at s] | [20] last level [21] last slope [22+k] last x~[slot observed at e]
+//   (statistics of the step from e - 1 to e are the next chunk's boundary: formed by the reader).
+__device__ __forceinline__ void tp_recon_pass(const TpCtx& c, int s, int e, float xh, float xp, float r_end,
+                                              float* stat) {
+  const int lane = c.lane, D = c.D, T = c.T, TP = c.TP;
+  const bool comp = lane < D;
+  const float* zkb = c.zk + (size_t)c.blk0 * TP;
+  const float* gdb = c.gd + (size_t)c.blk0 * TP;
+  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * TP;
+  // g . r_{e-1} for the step that crosses the chunk's end
+  float gd_end = 0.f;
+  if (e < T) gd_end = tp_shock_dot(c, r_end, (int)cidb[e - 1]);
+  float prev = 0.f, ssl = 0.f, sss = 0.f, ssd = 0.f;
+  bool ch_prev = false;
+  for (int t4 = s; t4 < e; t4 += 4) {
+    const float4 zl4 = *reinterpret_cast<const float4*>(c.zl + t4);
+    const float4 zk4 = *reinterpret_cast<const float4*>(zkb + t4);
+    float4 zs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c.has_slope) zs4 = *reinterpret_cast<const float4*>(c.zs + t4);
+    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(c.cbv + t4);
+    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    float rnq[4], gdq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t1 = t4 + q + 1;
+      rnq[q] = t1 < e ? (comp ? c.rs[(size_t)t1 * D + lane] : 0.f) : (t1 < T ? r_end : 0.f);
+      gdq[q] = t1 < e ? gdb[t1] : (t1 < T ? gd_end : 0.f);
+    }
+    float xo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t4 + q;
+      xo[q] = 0.f;
+      if (t >= e) continue;
+      const int mycur = (int)((cw4 >> (8 * q)) & 0xFFu);
+      const float xt = xh + xp;
+      xo[q] = xt;
+      if (t > s) {
+        const float pslope = readlane_f(prev, 1);
+        if (lane == 0) {
+          float dl = xt - prev;
+          if (c.has_slope) dl -= pslope;
+          ssl = fmaf(dl, dl, ssl);
+        }
+        if (c.has_slope && lane == 1) { const float ds = xt - prev; sss = fmaf(ds, ds, sss); }
+        if (ch_prev && c.pos == mycur) {
+          const float w = (float)c.nb * (prev - xt);
+          ssd = fmaf(w, w, ssd);
+        }
+      } else {
+        // first record: level, slope, the slot each block observes at s
+        const float l0 = readlane_f(xt, 0), l1 = readlane_f(xt, 1);
+        if (lane == 0) { stat[10] = l0; stat[11] = c.has_slope ? l1 : 0.f; }
+        if (c.blk >= 0 && c.pos == mycur) stat[12 + c.blk] = xt;
+      }
+      if (c.blk >= 0 && c.pos == mycur) c.seas[(size_t)c.blk * TP + t] = xt;
+      prev = xt;
+      if (t + 1 < T) {
+        const unsigned cb = (cb4 >> (8 * q)) & 0xFFu;
+        const bool mych = c.blk >= 0 && ((cb >> c.blk) & 1u);
+        float h = xh, r = xp;
+        if (c.has_slope) {
+          const float h1 = readlane_f(xh, 1), s1 = readlane_f(xp, 1);
+          if (lane == 0) { h += h1; r += s1; }
+        }
+        if (lane == 0) { h = fmaf(c.ql, rnq[q], h); r = fmaf(c.sl, tp_at4(zl4, q), r); }
+        if (c.has_slope && lane == 1) { h = fmaf(c.qs, rnq[q], h); r = fmaf(c.ssc, tp_at4(zs4, q), r); }
+        if (mych) {
+          const float dgi = c.mydrift * ((c.pos == mycur ? 1.f : 0.f) - c.rnb);
+          h = fmaf(c.mydrift * dgi, gdq[q], h);
+          r = fmaf(dgi, tp_at4(zk4, q), r);
+        }
+        xh = h; xp = r;
+        ch_prev = mych;
+      }
+    }
+    if (lane == 0) *reinterpret_cast<float4*>(c.lev + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    if (c.has_slope && lane == 1) *reinterpret_cast<float4*>(c.slp + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+  }
+  // last record: level, slope, and -- for the blocks that change between e - 1 and e -- the slot
+  // observed at e (whose entry of x~_{e-1} the next chunk's first step is compared with)
+  {
+    const float l0 = readlane_f(prev, 0), l1 = readlane_f(prev, 1);
+    if (lane == 0) { stat[20] = l0; stat[21] = c.has_slope ? l1 : 0.f; }
+    if (c.blk >= 0 && e < T) {
+      const int cnext = (int)cidb[e];
+      if (c.pos == cnext) stat[22 + c.blk] = prev;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k)
+    if (k < c.K) {
+      const float tot = wave_sum_dpp(c.blk == k ? ssd : 0.f);
+      if (lane == 0) stat[2 + k] = tot;
+    }
+  const float sl0 = readlane_f(ssl, 0), ss1 = readlane_f(sss, 1);
+  if (lane == 0) { stat[0] = sl0; stat[1] = c.has_slope ? ss1 : 0.f; }
+}
+
+// ------------------------------------------------------------------------------------
+// the persistent Gibbs kernel (iteration structure of gibbs_seasonal_kernel / the oracle's
+// ci_oracle_fit_gibbs; gibbs_sampler.fit_with_gibbs_sampling called at causalimpact_lib.py:365)
+// ------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
+  constexpr int NR = 8 * NCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const KArgs& g = a.k;
+  const int T = g.T, P = g.P, K = a.K;
+  const int G = a.cluster;
+  // workgroup -> (chain, role): the workgroups of one chain share an XCD (ids equal mod 8)
+  int chain_id = blockIdx.x, role = 0;
+  if (G > 1) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    role = slot % G;
+    chain_id = (slot / G) * 8 + xcd;
+  }
+  if (chain_id >= g.B * g.C) return;
+  const int series = chain_id / g.C, chain = chain_id % g.C;
+  const size_t chain_lin = (size_t)series * g.C + chain;
+  const int trend = a.has_slope ? 2 : 1;
+  int D = trend;
+  TpCtx cx;
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k) {
+    cx.off[k] = D; cx.nsz[k] = (k < K) ? a.nseas[k] : 0;
+    if (k < K) D += cx.nsz[k];
+  }
+  const TpLayout L = make_tplayout(T, P, K, D, a.has_slope, G);
+  const TpLds LL = make_tplds(P, D);
+  const int N = L.N, Lc = L.Lc, TP = L.TP, LVI = L.LVI, LVG = L.LVG;
+  unsigned char* wsc = reinterpret_cast<unsigned char*>(a.ws) + chain_lin * a.ws_stride;
+  int* csync = a.csync + chain_lin * TPC_INTS;
+  int* mode_lds = reinterpret_cast<int*>(smem + LL.shared);
+
+  // ---- the cluster
+  TpSync sy;
+  sy.flags = csync; sy.G = G; sy.g = role; sy.epoch = 0; sy.cluster = false; sy.light = false;
+  int v0 = 0, v1 = 1;                 // the (virtual) workgroups this workgroup runs
+  if (G > 1) {
+    if (a.cluster_drop != 0 && role == a.cluster_drop) return;     // test knob: never checks in
+    const int mode = tp_assemble(csync, role, G, tid, mode_lds);
+    if (mode == 3) {
+      if (role > 0) return;
+      v0 = 0; v1 = G;                 // alone: every chunk, workgroup barriers only
+    } else {
+      sy.cluster = true; sy.light = mode == 2;
+      v0 = role; v1 = role + 1;
+    }
+  }
+  const bool is_main = role == 0;
+
+  // ---- pointers
+  cx.T = T; cx.TP = TP; cx.D = D; cx.DS = NR + 4; cx.K = K; cx.lane = lane; cx.has_slope = a.has_slope;
+  cx.yv = (float*)(wsc + L.yv); cx.lev = (float*)(wsc + L.lev); cx.slp = (float*)(wsc + L.slp);
+  cx.xw = (float*)(wsc + L.xw); cx.ytil = (float*)(wsc + L.ytil); cx.vf = (float*)(wsc + L.vf);
+  cx.zl = (float*)(wsc + L.zl); cx.zs = (float*)(wsc + L.zs); cx.zo = (float*)(wsc + L.zo);
+  cx.seas = (float*)(wsc + L.seas); cx.zk = (float*)(wsc + L.zk); cx.gd = (float*)(wsc + L.gd);
+  cx.kf = (float*)(wsc + L.kf); cx.rs = (float*)(wsc + L.rs);
+  cx.msk = wsc + L.mask; cx.cbv = wsc + L.cbits; cx.cidx = wsc + L.cidx;
+  {
+    unsigned char* wl = smem + LL.wave0 + (size_t)wave * LL.wave_stride;
+    cx.cm = (float*)(wl + LL.cm); cx.am = (float*)(wl + LL.am); cx.scr = (float*)(wl + LL.scr);
+    cx.pzv = (float*)(wl + LL.pzv); cx.vb = (float*)(wl + LL.vb);
+  }
+  float* e0 = (float*)(wsc + L.e0); float* ei = (float*)(wsc + L.ei); float* et = (float*)(wsc + L.et);
+  float* stt = (float*)(wsc + L.st);
+  float* bm = (float*)(wsc + L.bm); float* bi = (float*)(wsc + L.bi); float* bt = (float*)(wsc + L.bt);
+  float* xsum = (float*)(wsc + L.xsum); float* statv = (float*)(wsc + L.stat);
+  float* cpart = (float*)(wsc + L.cpart); float* cw = (float*)(wsc + L.cw);
+  const size_t ESZ = tp_esz(NR), BSZ = tp_bsz(NR), SSZ = (size_t)NR * (NR + 4);
+  const int PR = (P + 4) & ~3;                       // floats of one chunk's X~'targets partials (+ y'y)
+  const int CWS = (P + 3) & ~3;                      // cw: weights, then the scalars
+  RegLds R;
+  R.xtx = const_cast<double*>(g.xtx) + (size_t)series * P * P;
+  R.omega = const_cast<double*>(g.omega) + (size_t)series * P * P;
+  R.bvec = (double*)(smem + LL.reg + LL.bvec); R.w = (float*)(smem + LL.w);
+  R.aug[0] = (double*)(smem + LL.reg + LL.aug0); R.aug[1] = R.aug[0];
+  R.pri[0] = (double*)(smem + LL.pri0); R.pri[1] = R.pri[0];
+  R.chol = (double*)(smem + LL.reg + LL.chol); R.zv = (double*)(smem + LL.reg + LL.zv);
+  R.uperm = (double*)(smem + LL.reg + LL.uperm);
+  R.nz = (int*)(smem + LL.reg + LL.nz); R.perm = (int*)(smem + LL.reg + LL.perm); R.idx = (int*)(smem + LL.reg + LL.idx);
+  const bool bigp = P > MAXP;
+  if (bigp) bigp_point(R, wsc + L.big, P);
+  const DevSeriesParams sp = g.sp[series];
+  const DevSeasonalParams ss = a.ssp[series];
+  const Rng rng{stream_key0(g.seed0, g.series_stream_base, series), stream_key1(g.seed1, g.series_stream_base, series),
+                (uint32_t)(g.chain_offset + chain)};
+  const float* Xg = g.Xt + (size_t)series * P * T;
+  const float* chol1 = a.p1_chol + (size_t)series * a.dred * a.dred;
+
+  // ---- lane roles
+  int blk = -1, pos = 0, nb = 1, boff = 0, rbase = 0;
+  {
+    int rr = trend;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        if (lane >= cx.off[k] && lane < cx.off[k] + cx.nsz[k]) {
+          blk = k; pos = lane - cx.off[k]; nb = cx.nsz[k]; boff = cx.off[k]; rbase = rr;
+        }
+        rr += cx.nsz[k] - 1;
+      }
+  }
+  cx.blk = blk; cx.blk0 = blk >= 0 ? blk : 0; cx.pos = pos; cx.nb = nb; cx.boff = boff;
+  cx.rnb = 1.0f / (float)nb;
+  const bool comp = lane < D;
+
+  // the chunks of this wavefront: c = v * TP_NWV + wave for v in [v0, v1)
+  auto chunk_s = [&](int c) { const int s = c * Lc; return s < T ? s : T; };
+  auto chunk_e = [&](int c) { const int e = (c + 1) * Lc; return e < T ? e : T; };
+
+  // ---- stage constants (own chunks): mask, outcome, change bits, c_k(t); zero the latents
+  for (int v = v0; v < v1; ++v) {
+    const int c = v * TP_NWV + wave, s = c * Lc, e = s + Lc;
+    for (int t = s + lane; t < e; t += 64) {
+      const bool in = t < T;
+      const bool m = in ? g.mask[(size_t)series * T + t] != 0 : true;
+      cx.msk[t] = m ? 1 : 0;
+      cx.yv[t] = m ? 0.f : g.y[(size_t)series * T + t];
+      cx.lev[t] = 0.f; cx.xw[t] = 0.f; cx.ytil[t] = 0.f; cx.vf[t] = 0.f; cx.zl[t] = 0.f; cx.zo[t] = 0.f;
+      if (a.has_slope) { cx.slp[t] = 0.f; cx.zs[t] = 0.f; }
+      unsigned bits = 0;
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K) {
+          cx.seas[(size_t)k * TP + t] = 0.f; cx.zk[(size_t)k * TP + t] = 0.f; cx.gd[(size_t)k * TP + t] = 0.f;
+          if (in && a.season_change[(size_t)k * T + t]) bits |= 1u << k;
+        }
+      cx.cbv[t] = (uint8_t)bits;
+    }
+    // c_k(t) = (changes of block k before t) mod n_k: lane k walks its block through the chunk
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K) {
+        float cnt = 0.f;
+        for (int t = lane; t < s && t < T; t += 64) cnt += a.season_change[(size_t)k * T + t] ? 1.f : 0.f;
+        const int before = (int)(wave_sum_dpp(cnt) + 0.5f);
+        if (lane == k) {
+          int cur = before % cx.nsz[k];
+          for (int t = s; t < e; ++t) {
+            cx.cidx[(size_t)k * TP + t] = (uint8_t)cur;
+            if (t + 1 < T && a.season_change[(size_t)k * T + t]) cur = (cur + 1 == cx.nsz[k]) ? 0 : cur + 1;
+          }
+        }
+      }
+    if (K == 0) for (int t = s + lane; t < e; t += 64) cx.cidx[t] = 0;
+    if (lane < TP_STAT) statv[(size_t)c * TP_STAT + lane] = 0.f;
+  }
+  if (is_main && wave == 0)
+    for (int j = lane; j < (P > 16 ? P : 16); j += 64) R.w[j] = 0.f;
+  double n_changes[SMAXK];
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k) {
+    n_changes[k] = 0.0;
+    if (k < K && is_main && wave == 0) {
+      float cnt = 0.f;
+      for (int t = lane; t + 1 < T; t += 64) cnt += a.season_change[(size_t)k * T + t] ? 1.f : 0.f;
+      n_changes[k] = (double)wave_sum_dpp(cnt);
+    }
+  }
+  tp_cluster_barrier(sy, tid);
+
+  double obs_scale = sp.obs_scale0, level_scale = sp.level_scale0, slope_scale = sp.slope_scale0;
+  double drift[SMAXK];
+#pragma unroll
+  for (int k = 0; k < SMAXK; ++k) drift[k] = (k < K) ? ss.drift_scale0[k] : 0.0;
+  const float p1l = (float)(sp.init_level_scale * sp.init_level_scale);
+  const float p1s = (float)(sp.init_slope_scale * sp.init_slope_scale);
+  const float p1e = (float)(ss.init_seasonal_scale * ss.init_seasonal_scale);
+  Prof prof;
+  prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && tid == 0);
+  PriorCarry pc;
+  pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
+
+  const int n_iter = g.W + g.S;
+  for (int it = 0; it <= n_iter; ++it) {
+    tp_wg_barrier_wave();             // the draw of it-1 written by other lanes of this wavefront
+    // ---- (1) targets of the regression and this chunk's share of X~'targets, y'y
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
+      float yty = 0.f;
+      for (int t = s + lane; t < e; t += 64) {
+        float tg = 0.f;
+        if (!cx.msk[t]) {
+          tg = cx.yv[t] - cx.lev[t];
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k)
+            if (k < K) tg -= cx.seas[(size_t)k * TP + t];
+        }
+        cx.ytil[t] = tg;
+        yty = fmaf(tg, tg, yty);
+      }
+      tp_wg_barrier_wave();
+      for (int j = 0; j < P; ++j) {
+        float pj = 0.f;
+        for (int t = s + lane; t < e; t += 64) pj = fmaf(Xg[(size_t)j * T + t], cx.ytil[t], pj);
+        const float sj = wave_sum_dpp(pj);
+        if (lane == 0) cpart[(size_t)c * PR + j] = sj;
+      }
+      const float s0 = wave_sum_dpp(yty);
+      if (lane == 0) cpart[(size_t)c * PR + P] = s0;
+    }
+    prof.tick(20);
+    tp_cluster_barrier(sy, tid);                                            // (A)
+    // ---- (2) wavefront 0 of the chain: statistics, scale draws of it-1, regression draw of it
+    if (is_main && wave == 0) {
+      for (int j = lane; j <= P; j += 64) {
+        float sj = 0.f;
+        for (int c = 0; c < N; ++c) sj += cpart[(size_t)c * PR + j];       // chunk order: fixed bits
+        R.bvec[j] = (double)sj;
+      }
+      // statistics of the draw of it-1: the chunks' shares + the steps across chunk boundaries
+      float ssl = 0.f, sss = 0.f, ssdk[SMAXK];
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k) ssdk[k] = 0.f;
+      for (int c = lane; c < N; c += 64) {
+        const float* sc = statv + (size_t)c * TP_STAT;
+        if (chunk_s(c) >= T) continue;
+        ssl += sc[0]; sss += sc[1];
+#pragma unroll
+        for (int k = 0; k < SMAXK; ++k) if (k < K) ssdk[k] += sc[2 + k];
+        if (c > 0) {
+          const float* sp_ = statv + (size_t)(c - 1) * TP_STAT;
+          float dl = sc[10] - sp_[20];
+          if (a.has_slope) { dl -= sp_[21]; const float ds = sc[11] - sp_[21]; sss = fmaf(ds, ds, sss); }
+          ssl = fmaf(dl, dl, ssl);
+          const unsigned cb = cx.cbv[chunk_s(c) - 1];
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k)
+            if (k < K && ((cb >> k) & 1u)) {
+              const float w = (float)cx.nsz[k] * (sp_[22 + k] - sc[12 + k]);
+              ssdk[k] = fmaf(w, w, ssdk[k]);
+            }
+        }
+      }
+      ssl = wave_sum_dpp(ssl); sss = wave_sum_dpp(sss);
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k) if (k < K) ssdk[k] = wave_sum_dpp(ssdk[k]);
+      tp_lds_sync();
+      if (it > 0) {
+        const uint32_t pit = (uint32_t)(it - 1);
+        level_scale = scale_draw(sp.level_conc, sp.level_scale, sp.level_ub, (double)(T - 1), (double)ssl,
+                                 rng, pit, SITE_LEVEL_SCALE, lane);
+        if (a.has_slope)
+          slope_scale = scale_draw(sp.slope_conc, sp.slope_scale, sp.slope_ub, (double)(T - 1), (double)sss,
+                                   rng, pit, SITE_SLOPE_SCALE, lane);
+#pragma unroll
+        for (int k = 0; k < SMAXK; ++k)
+          if (k < K) {
+            const double gk = gamma_wave(ss.drift_conc + 0.5 * n_changes[k], rng, pit, SITE_DRIFT_SCALE, (uint32_t)k, lane);
+            const double sd = (double)__fsqrt_rn((float)((ss.drift_scale + 0.5 * (double)ssdk[k]) * fast_rcp(gk)));
+            drift[k] = sd < ss.drift_ub ? sd : ss.drift_ub;
+          }
+        if (P == 0)
+          obs_scale = scale_draw(sp.obs_conc, sp.obs_scale, sp.obs_ub, sp.n_obs, R.bvec[P], rng, pit,
+                                 SITE_OBS_SCALE, lane);
+        const int sidx = it - 1 - g.W;
+        if (sidx >= 0) {
+          const size_t o = chain_lin * g.S + sidx;
+          if (lane == 0) {
+            if (g.out_obs) g.out_obs[o] = (float)obs_scale;
+            if (g.out_level_scale) g.out_level_scale[o] = (float)level_scale;
+            if (g.out_slope_scale) g.out_slope_scale[o] = (float)(a.has_slope ? slope_scale : 0.0);
+          }
+          if (a.out_drift) {
+#pragma unroll
+            for (int k = 0; k < SMAXK; ++k)
+              if (k < K && lane == k) a.out_drift[o * K + k] = (float)drift[k];
+          }
+          if (g.out_weights)
+            for (int j = lane; j < P; j += 64) g.out_weights[o * P + j] = R.w[j];
+        }
+      }
+      if (lane == 0) cw[CWS + 0] = (float)obs_scale;        // sigma_obs of the draw of it-1 (emission)
+      if (it < n_iter && P > 0) {
+        const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
+        if (P <= 16)
+          obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
+        else if (!bigp)
+          obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, it == 0);
+        else
+          obs_scale = spike_slab_draw_big(R, R.w, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, it == 0);
+      }
+      wave_sync();
+      for (int j = lane; j < P; j += 64) cw[j] = R.w[j];
+      if (lane == 0) {
+        cw[CWS + 1] = (float)obs_scale; cw[CWS + 2] = (float)level_scale; cw[CWS + 3] = (float)slope_scale;
+      }
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K && lane == 0) cw[CWS + 4 + k] = (float)drift[k];
+    }
+    prof.tick(21);
+    tp_cluster_barrier(sy, tid);                                            // (B)
+    const float emit_so = cw[CWS + 0];
+    cx.so = cw[CWS + 1]; cx.sl = cw[CWS + 2]; cx.ssc = cw[CWS + 3];
+    cx.H = cx.so * cx.so; cx.ql = cx.sl * cx.sl; cx.qs = cx.ssc * cx.ssc;
+    cx.mydrift = 0.f; cx.myd2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k)
+      if (k < K && blk == k) { cx.mydrift = cw[CWS + 4 + k]; cx.myd2 = cx.mydrift * cx.mydrift; }
+    if (K > 0 && blk < 0) { const float d0 = cw[CWS + 4]; cx.myd2 = d0 * d0; }      // (lanes outside the blocks: as ci_seasonal.h's d2[blk0])
+    // ---- (3) emission of the draw of it-1; residual and normals of this iteration (own chunks)
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
+      const int sidx = it - 1 - g.W;
+      if (it > 0 && sidx >= 0) {
+        const uint32_t pit = (uint32_t)(it - 1);
+        const size_t o = chain_lin * g.S + sidx, row = o * T;
+        for (int q4 = (s >> 2) + lane; q4 < ((e + 3) >> 2); q4 += 64) {
+          float zp[4];
+          normals4(site_call(rng, pit, SITE_PRED, 0, (uint32_t)q4), zp);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t = 4 * q4 + q;
+            if (t < e) {
+              float loc = cx.lev[t] + cx.xw[t];
+#pragma unroll
+              for (int k = 0; k < SMAXK; ++k)
+                if (k < K) {
+                  const float sv = cx.seas[(size_t)k * TP + t];
+                  loc += sv;
+                  if (a.out_seasonal) a.out_seasonal[(row + t) * K + k] = sv;
+                }
+              if (g.out_level) g.out_level[row + t] = cx.lev[t];
+              if (g.out_slope && a.has_slope) g.out_slope[row + t] = cx.slp[t];
+              if (g.out_traj) g.out_traj[row + t] = fmaf(emit_so, zp[q], loc);
+              if (g.out_pred_mean) {
+                float* pm = g.out_pred_mean + chain_lin * T + t;
+                *pm = (sidx == 0 ? 0.f : *pm) + loc;
+              }
+            }
+          }
+        }
+      }
+      if (it == n_iter) continue;
+      tp_wg_barrier_wave();           // (the emission has read the previous X w)
+      for (int t = s + lane; t < e; t += 64) {
+        float sx = 0.f;
+        for (int j = 0; j < P; ++j) sx = fmaf(Xg[(size_t)j * T + t], cw[j], sx);
+        cx.xw[t] = sx;
+      }
+      for (int q4 = (s >> 2) + lane; q4 < ((s + Lc) >> 2); q4 += 64) {
+        float z4[4];
+        normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_LEVEL, 0, (uint32_t)q4), z4);
+        *reinterpret_cast<float4*>(cx.zl + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_OBS, 0, (uint32_t)q4), z4);
+        *reinterpret_cast<float4*>(cx.zo + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        if (a.has_slope) {
+          normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SLOPE, 0, (uint32_t)q4), z4);
+          *reinterpret_cast<float4*>(cx.zs + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < SMAXK; ++k)
+          if (k < K) {
+            normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SEAS, (uint32_t)k, (uint32_t)q4), z4);
+            *reinterpret_cast<float4*>(cx.zk + (size_t)k * TP + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+          }
+      }
+    }
+    if (it == n_iter) break;
+    tp_wg_barrier_wave();
+    prof.tick(22);
+    // x+_0 = chol(P_1) z in the oracle's reduced coordinates, folded into the prior mean
+    float a1e = 0.f;
+    {
+      float zi0 = 0.f;
+      if (lane < a.dred) {
+        float z1[1];
+        fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)lane, z1);
+        zi0 = z1[0];
+      }
+      tp_lds_sync();
+      if (lane < NR) cx.vb[lane] = zi0;
+      tp_lds_sync();
+      float x0 = 0.f;
+      if (lane < a.dred)
+        for (int j = 0; j <= lane; ++j) x0 = fmaf(chol1[lane * a.dred + j], cx.vb[j], x0);
+      if (lane < NR) cx.vb[NR + lane] = x0;
+      tp_lds_sync();
+      const float* x0r = cx.vb + NR;
+      if (lane == 0) a1e = (float)sp.init_level_loc + x0r[0];
+      if (a.has_slope && lane == 1) a1e = x0r[1];
+      if (blk >= 0) {
+        if (pos < nb - 1) a1e = x0r[rbase + pos];
+        else { float sx = 0.f; for (int q = 0; q < nb - 1; ++q) sx += x0r[rbase + q]; a1e = -sx; }
+      }
+      tp_lds_sync();
+    }
+    // ---- (4) prior simulation: chunk sums, prefix, y~
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
+      const float xs = tp_sim_pass<false>(cx, s, e, 0.f);
+      if (lane < NR) xsum[(size_t)c * 2 * NR + lane] = comp ? xs : 0.f;
+    }
+    tp_cluster_barrier(sy, tid);                                            // (C)
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
+      float xp = 0.f;
+      for (int cc = 0; cc < c; ++cc) {
+        const int ss_ = chunk_s(cc), ee_ = chunk_e(cc);
+        const int ntr = (ee_ < T ? ee_ : T - 1) - ss_;        // transitions inside chunk cc
+        if (ntr <= 0) continue;
+        if (a.has_slope) {
+          const float x1 = readlane_f(xp, 1);
+          if (lane == 0) xp = fmaf((float)ntr, x1, xp);
+        }
+        xp += (lane < NR) ? xsum[(size_t)cc * 2 * NR + lane] : 0.f;
+      }
+      if (lane < NR) xsum[(size_t)c * 2 * NR + NR + lane] = xp;            // x+ at the chunk's start
+      (void)tp_sim_pass<true>(cx, s, e, xp);
+    }
+    tp_wg_barrier_wave();
+    prof.tick(23);
+    // ---- (5) filtering elements of the chunks, their scan, the chunks' predicted moments
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
+      tp_build_pass<NCH>(cx, s, e, c == 0, a1e, p1l, p1s, p1e, e0 + (size_t)c * ESZ);
+      if (c == 0) {
+        const TRow<NR> p0 = tp_prior_row<NR>(cx, p1l, p1s, p1e);
+        trow_store<NR>(stt, NR + 4, lane, p0);
+        if (lane < NR) *reinterpret_cast<float4*>(stt + (size_t)lane * (NR + 4) + NR) = make_float4(comp ? a1e : 0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    prof.tick(24);
+    tp_wg_barrier();
+    for (int l = 0; l < LVI; ++l) {
+      for (int v = v0; v < v1; ++v) {
+        const int c = v * TP_NWV + wave;
+        const float* src = l == 0 ? e0 : ei + (size_t)(l - 1) * N * ESZ;
+        float* dst = ei + (size_t)l * N * ESZ + (size_t)c * ESZ;
+        if (wave >= (1 << l)) tp_combine<NR, false>(src + (size_t)(c - (1 << l)) * ESZ, src + (size_t)c * ESZ, dst, cx.scr, cx.vb, D, lane);
+        else tp_elem_copy<NR>(dst, src + (size_t)c * ESZ, lane);
+        if (l == LVI - 1 && wave == TP_NWV - 1) {       // the workgroup's total
+          tp_wg_barrier_wave();
+          tp_elem_copy<NR>(et + (size_t)v * ESZ, dst, lane);
+        }
+      }
+      tp_wg_barrier();
+    }
+    const float* eincl = ei + (size_t)(LVI - 1) * N * ESZ;
+    if (G > 1) tp_cluster_barrier(sy, tid);                                 // (D)
+    for (int m = 0; m < LVG; ++m) {
+      for (int v = v0; v < v1; ++v) {
+        if (wave != (v & (TP_NWV - 1))) continue;
+        const float* src = et + (size_t)m * G * ESZ;
+        float* dst = et + (size_t)(m + 1) * G * ESZ + (size_t)v * ESZ;
+        if (v >= (1 << m)) tp_combine<NR, false>(src + (size_t)(v - (1 << m)) * ESZ, src + (size_t)v * ESZ, dst, cx.scr, cx.vb, D, lane);
+        else tp_elem_copy<NR>(dst, src + (size_t)v * ESZ, lane);
+      }
+      tp_cluster_barrier(sy, tid);
+    }
+    const float* etot = et + (size_t)LVG * G * ESZ;
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave;
+      float* dst = stt + (size_t)c * SSZ;
+      if (c == 0) continue;
+      if (wave == 0) tp_state_from_elem<NR>(etot + (size_t)(v - 1) * ESZ, dst, lane);
+      else if (v == 0) tp_state_from_elem<NR>(eincl + (size_t)(c - 1) * ESZ, dst, lane);
+      else tp_combine<NR, true>(etot + (size_t)(v - 1) * ESZ, eincl + (size_t)(c - 1) * ESZ, dst, cx.scr, cx.vb, D, lane);
+    }
+    tp_wg_barrier_wave();
+    prof.tick(25);
+    // ---- (6) the filter replayed from the true moments; backward maps and their suffix scan
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
+      const float* st = stt + (size_t)c * SSZ;
+      float cvec = 0.f;
+      if (s < T) {
+        tp_filter_pass<NCH>(cx, s, e, st);
+        tp_wg_barrier_wave();
+        cvec = tp_backward_pass<false>(cx, s, e, 0.f);
+      }
+      // M = (I + J P_start)^-1 A'
+      TRow<NR> M = trow_zero<NR>();
+      if (s < T) {
+        const TpElemPtr<NR> el{e0 + (size_t)c * ESZ};
+        tscr_put<NR>(cx.scr, trow_load<NR>(st, NR + 4, lane), lane);
+        TRow<NR> W = tmul<NR>(el.J(lane), cx.scr, D, lane, true);
+        M = ttranspose<NR>(cx.scr, el.A(lane), lane);
+        TRow<NR> dummy = trow_zero<NR>();
+        float du = 0.f;
+        tgauss_jordan<NR, 1>(W, M, dummy, du, D, lane);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) M.v[u] = (comp && u == lane) ? 1.f : 0.f;
+      }
+      float* bo = bm + (size_t)c * BSZ;
+      trow_store<NR>(bo, NR + 4, lane, M);
+      if (lane < NR) *reinterpret_cast<float4*>(bo + (size_t)lane * (NR + 4) + NR) = make_float4(comp ? cvec : 0.f, 0.f, 0.f, 0.f);
+    }
+    prof.tick(26);
+    tp_wg_barrier();
+    for (int l = 0; l < LVI; ++l) {
+      for (int v = v0; v < v1; ++v) {
+        const int c = v * TP_NWV + wave;
+        const float* src = l == 0 ? bm : bi + (size_t)(l - 1) * N * BSZ;
+        float* dst = bi + (size_t)l * N * BSZ + (size_t)c * BSZ;
+        if (wave + (1 << l) < TP_NWV) tp_bcompose<NR>(src + (size_t)c * BSZ, src + (size_t)(c + (1 << l)) * BSZ, dst, cx.scr, cx.vb, D, lane);
+        else tp_bcopy<NR>(dst, src + (size_t)c * BSZ, lane);
+        if (l == LVI - 1 && wave == 0) {
+          tp_wg_barrier_wave();
+          tp_bcopy<NR>(bt + (size_t)v * BSZ, dst, lane);
+        }
+      }
+      tp_wg_barrier();
+    }
+    const float* bincl = bi + (size_t)(LVI - 1) * N * BSZ;
+    if (G > 1) tp_cluster_barrier(sy, tid);                                 // (E)
+    for (int m = 0; m < LVG; ++m) {
+      for (int v = v0; v < v1; ++v) {
+        if (wave != (v & (TP_NWV - 1))) continue;
+        const float* src = bt + (size_t)m * G * BSZ;
+        float* dst = bt + (size_t)(m + 1) * G * BSZ + (size_t)v * BSZ;
+        if (v + (1 << m) < G) tp_bcompose<NR>(src + (size_t)v * BSZ, src + (size_t)(v + (1 << m)) * BSZ, dst, cx.scr, cx.vb, D, lane);
+        else tp_bcopy<NR>(dst, src + (size_t)v * BSZ, lane);
+      }
+      tp_cluster_barrier(sy, tid);
+    }
+    const float* btot = bt + (size_t)LVG * G * BSZ;
+    prof.tick(27);
+    // ---- (7) r through the chunk from its true end value, the draw, its statistics
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
+      if (s >= T) continue;
+      float r_in = 0.f;                                   // r at the end of this workgroup's last chunk
+      if (v + 1 < G && lane < NR) r_in = btot[(size_t)(v + 1) * BSZ + (size_t)lane * (NR + 4) + NR];
+      float r_end = r_in;
+      if (wave + 1 < TP_NWV) {
+        const float* nx = bincl + (size_t)(c + 1) * BSZ;
+        const TRow<NR> Mn = trow_load<NR>(nx, NR + 4, lane);
+        const float cn = lane < NR ? nx[(size_t)lane * (NR + 4) + NR] : 0.f;
+        r_end = cn + tdot<NR>(Mn, cx.vb, r_in, lane);
+      }
+      if (!comp) r_end = 0.f;
+      (void)tp_backward_pass<true>(cx, s, e, r_end);
+      tp_wg_barrier_wave();
+      // g . r_{t-1} per block over the own steps
+#pragma unroll
+      for (int k = 0; k < SMAXK; ++k)
+        if (k < K) {
+          const float rn = 1.0f / (float)cx.nsz[k];
+          for (int t = s + lane; t < e; t += 64) {
+            const float* rr = cx.rs + (size_t)t * D + cx.off[k];
+            float sb = 0.f;
+            for (int q = 0; q < cx.nsz[k]; ++q) sb += rr[q];
+            const int cprev = t > 0 ? (int)cx.cidx[(size_t)k * TP + t - 1] : 0;
+            cx.gd[(size_t)k * TP + t] = rr[cprev] - sb * rn;
+          }
+        }
+      tp_wg_barrier_wave();
+      // x^ at the chunk's start = a + P r_{s-1}
+      const float* st = stt + (size_t)c * SSZ;
+      const TRow<NR> Ps = trow_load<NR>(st, NR + 4, lane);
+      const float as = lane < NR ? st[(size_t)lane * (NR + 4) + NR] : 0.f;
+      const float rs0 = comp ? cx.rs[(size_t)s * D + lane] : 0.f;
+      float xh = as + tdot<NR>(Ps, cx.vb, rs0, lane);
+      if (!comp) xh = 0.f;
+      const float xp0 = lane < NR ? xsum[(size_t)c * 2 * NR + NR + lane] : 0.f;
+      tp_recon_pass(cx, s, e, xh, xp0, r_end, statv + (size_t)c * TP_STAT);
+    }
+    prof.tick(28);
+  }
+  tp_wg_barrier_wave();
+  if (g.out_pred_mean) {
+    const float inv = 1.0f / (float)(g.S > 0 ? g.S : 1);
+    for (int v = v0; v < v1; ++v) {
+      const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
+      for (int t = s + lane; t < e; t += 64) g.out_pred_mean[chain_lin * T + t] *= inv;
+    }
+  }
+}
+#endif  // CI_SEASONAL_DECL_ONLY
+
+}  // namespace ci

@@ -105,6 +105,12 @@ typedef struct ci_problem {
  * scheduled -- the others must notice (time-out while assembling the cluster) and the chain's
  * main workgroup must carry on alone with unchanged results. */
 #define CI_FLAG_TEST_DROP_HELPER 32
+/* Seasonal models: take the wave-cooperative time-parallel kernel (csrc/ci_seasonal_tp.h: chunks of
+ * the series on the wavefronts of a cluster of up to 16 workgroups, any block list with a state of at
+ * most 32 components) even for "trend + one block of 2-7 seasons", which by default runs on the
+ * thread-per-chunk kernel of csrc/ci_wide.h.  Few chains of a long series leave most of the GPU
+ * idle: there the cluster kernel is the faster one (profiles/). */
+#define CI_FLAG_CLUSTER_SEASONAL 64
 
 /* Caller-allocated result buffers (float32, chain-major so per-device shards
  * are contiguous).  == GibbsSamplerState stack + (means, trajectories) returned

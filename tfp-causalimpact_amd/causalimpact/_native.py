@@ -214,6 +214,7 @@ FLAG_FOUR_WAVES = 4             # == CI_FLAG_FOUR_WAVES
 FLAG_SEASONAL_WORKSPACE = 8     # == CI_FLAG_SEASONAL_WORKSPACE
 FLAG_NO_CLUSTER = 16            # == CI_FLAG_NO_CLUSTER
 FLAG_TEST_DROP_HELPER = 32      # == CI_FLAG_TEST_DROP_HELPER
+FLAG_CLUSTER_SEASONAL = 64      # == CI_FLAG_CLUSTER_SEASONAL
 
 
 def make_problem(*, T, P, has_slope, num_seasons=(), num_warmup, num_results, num_chains=1,

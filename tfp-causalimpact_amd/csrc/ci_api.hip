@@ -356,6 +356,7 @@ void* pick_wide_kernel(int has_slope, int num_seasons) {
 }
 bool use_wide(const ci_problem* pb) {
   return pb->num_blocks == 1 && pb->P <= ci::MAXP && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
+         !(pb->flags & CI_FLAG_CLUSTER_SEASONAL) &&
          pick_wide_kernel(pb->has_slope, pb->num_seasons[0]) != nullptr;
 }
 int wide_steps_per_thread(int T) {

@@ -164,15 +164,18 @@ struct TpSync {
 };
 __device__ __forceinline__ void tp_cluster_barrier(TpSync& s, int tid) {
   if (!s.cluster) { tp_wg_barrier(); return; }
+  // ONE arrival counter per chain (flags[0], monotone): an arrival is one L2 atomic, the wait polls
+  // one location -- polling G per-workgroup flags one after the other cost G dependent L2 round
+  // trips (~12k cycles at G = 16, thirteen times per iteration)
   ++s.epoch;
   if (s.light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   else __threadfence();
   __syncthreads();
   if (tid == 0) {
-    __hip_atomic_store(s.flags + s.g, s.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    for (int r = 0; r < s.G; ++r)
-      while (__hip_atomic_load(s.flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s.epoch)
-        __builtin_amdgcn_s_sleep(1);
+    (void)__hip_atomic_fetch_add(s.flags, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const int want = s.epoch * s.G;
+    while (__hip_atomic_load(s.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+      __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
@@ -357,14 +360,201 @@ __device__ __forceinline__ void tgauss_jordan(TRow<NR>& W, TRow<NR>& R0, TRow<NR
   }
 }
 
+// ---- the same algebra on BOTH halves of the wavefront: lane l holds columns [h NH, (h + 1) NH) of
+// row i = l & 31, h = l >> 5, NH = NR / 2.  Half the registers per matrix and half the instructions
+// per product / elimination of the row-per-lane form above (which leaves 32+ lanes idle); a left
+// operand is needed as a FULL row (TRow, the same in both halves), results come out in halves, and
+// the conversion goes through the LDS scratch the products use anyway.
+template <int NH> struct THalf { float v[NH]; };
+template <int NH> __device__ __forceinline__ THalf<NH> thalf_zero() {
+  THalf<NH> r;
+#pragma unroll
+  for (int j = 0; j < NH; ++j) r.v[j] = 0.f;
+  return r;
+}
+template <int NR> __device__ __forceinline__ THalf<NR / 2> hload(const float* base, int stride, int lane) {
+  constexpr int NH = NR / 2;
+  THalf<NH> r = thalf_zero<NH>();
+  const int i = lane & 31, h = lane >> 5;
+  if (i < NR) {
+    const float4* p = reinterpret_cast<const float4*>(base + (size_t)i * stride + h * NH);
+#pragma unroll
+    for (int q = 0; q < NH / 4; ++q) {
+      const float4 x = p[q];
+      r.v[4 * q] = x.x; r.v[4 * q + 1] = x.y; r.v[4 * q + 2] = x.z; r.v[4 * q + 3] = x.w;
+    }
+  }
+  return r;
+}
+template <int NR> __device__ __forceinline__ void hstore(float* base, int stride, int lane, const THalf<NR / 2>& r) {
+  constexpr int NH = NR / 2;
+  const int i = lane & 31, h = lane >> 5;
+  if (i < NR) {
+    float4* p = reinterpret_cast<float4*>(base + (size_t)i * stride + h * NH);
+#pragma unroll
+    for (int q = 0; q < NH / 4; ++q) p[q] = make_float4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
+  }
+}
+// full row i = lane & 31 (the same registers in both halves)
+template <int NR> __device__ __forceinline__ TRow<NR> fload(const float* base, int stride, int lane) {
+  return trow_load<NR>(base, stride, lane & 31);
+}
+template <int NR> __device__ __forceinline__ float fscalar(const float* base, int stride, int off, int lane) {
+  const int i = lane & 31;
+  return i < NR ? base[(size_t)i * stride + off] : 0.f;
+}
+template <int NR> __device__ __forceinline__ void hscr_put(float* scr, const THalf<NR / 2>& r, int lane) {
+  tp_lds_sync();
+  hstore<NR>(scr, NR, lane, r);
+  tp_lds_sync();
+}
+template <int NR> __device__ __forceinline__ void fscr_put(float* scr, const TRow<NR>& r, int lane) {
+  tp_lds_sync();
+  trow_store<NR>(scr, NR, lane, r);        // lanes < NR: row = lane
+  tp_lds_sync();
+}
+// own full row back from the scratch (halves -> full)
+template <int NR> __device__ __forceinline__ TRow<NR> fscr_row(const float* scr, int lane) {
+  return trow_load<NR>(scr, NR, lane & 31);
+}
+// C = A B (+ I): A as full rows, rows of B in the scratch, C in halves
+template <int NR> __device__ __forceinline__ THalf<NR / 2> hmul(const TRow<NR>& A, const float* scr, int D, int lane,
+                                                               bool plus_eye = false) {
+  constexpr int NH = NR / 2;
+  const int i = lane & 31, h = lane >> 5;
+  THalf<NH> c;
+#pragma unroll
+  for (int j = 0; j < NH; ++j) c.v[j] = (plus_eye && h * NH + j == i) ? 1.f : 0.f;
+  const float* sh = scr + h * NH;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    if (k < D) {
+      const float4* p = reinterpret_cast<const float4*>(sh + k * NR);
+      const float a = A.v[k];
+#pragma unroll
+      for (int q = 0; q < NH / 4; ++q) {
+        const float4 b = p[q];
+        c.v[4 * q] = fmaf(a, b.x, c.v[4 * q]); c.v[4 * q + 1] = fmaf(a, b.y, c.v[4 * q + 1]);
+        c.v[4 * q + 2] = fmaf(a, b.z, c.v[4 * q + 2]); c.v[4 * q + 3] = fmaf(a, b.w, c.v[4 * q + 3]);
+      }
+    }
+  }
+  return c;
+}
+// C = A B': C[i][j] = row_i(A) . row_j(B), j in the lane's half
+template <int NR> __device__ __forceinline__ THalf<NR / 2> hmul_t(const TRow<NR>& A, const float* scr, int lane) {
+  constexpr int NH = NR / 2;
+  const int h = lane >> 5;
+  THalf<NH> c;
+#pragma unroll
+  for (int jj = 0; jj < NH; ++jj) {
+    const float4* p = reinterpret_cast<const float4*>(scr + (h * NH + jj) * NR);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NR / 4; ++q) {
+      const float4 b = p[q];
+      s = fmaf(A.v[4 * q], b.x, s); s = fmaf(A.v[4 * q + 1], b.y, s);
+      s = fmaf(A.v[4 * q + 2], b.z, s); s = fmaf(A.v[4 * q + 3], b.w, s);
+    }
+    c.v[jj] = s;
+  }
+  return c;
+}
+template <int NR> __device__ __forceinline__ THalf<NR / 2> htranspose(float* scr, const THalf<NR / 2>& r, int lane) {
+  constexpr int NH = NR / 2;
+  hscr_put<NR>(scr, r, lane);
+  const int i = lane & 31, h = lane >> 5;
+  THalf<NH> t = thalf_zero<NH>();
+  if (i < NR) {
+#pragma unroll
+    for (int jj = 0; jj < NH; ++jj) t.v[jj] = scr[(h * NH + jj) * NR + i];
+  }
+  return t;
+}
+// row . x for a per-row scalar x (the same in both halves); the result likewise
+template <int NR> __device__ __forceinline__ float hdot(const TRow<NR>& A, float* vb, float x, int lane) {
+  tp_lds_sync();
+  if (lane < NR) vb[lane] = x;
+  tp_lds_sync();
+  float s = 0.f;
+  const float4* p = reinterpret_cast<const float4*>(vb);
+#pragma unroll
+  for (int q = 0; q < NR / 4; ++q) {
+    const float4 b = p[q];
+    s = fmaf(A.v[4 * q], b.x, s); s = fmaf(A.v[4 * q + 1], b.y, s);
+    s = fmaf(A.v[4 * q + 2], b.z, s); s = fmaf(A.v[4 * q + 3], b.w, s);
+  }
+  return s;
+}
+// Gauss-Jordan without pivoting on half rows: [W | R0 | R1 | u] -> [I | W^-1 R0 | W^-1 R1 | W^-1 u].
+// The pivot row is published in LDS (`piv`: 3 NR + 4 floats) and read back as broadcast loads; the
+// multiplier W[i][c] sits in half c / NH and reaches the other half by one ds_bpermute; the
+// multiplier of row c itself is W[c][c] - 1 (see tgauss_jordan).
+template <int NR, int NRHS>
+__device__ __forceinline__ void hgauss_jordan(THalf<NR / 2>& W, THalf<NR / 2>& R0, THalf<NR / 2>& R1, float& u,
+                                              float* piv, int D, int lane) {
+  constexpr int NH = NR / 2;
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int c = 0; c < NR; ++c) {
+    if (c < D) {
+      constexpr int dummy = 0; (void)dummy;
+      const int hc = c / NH, cc = c % NH;
+      const float f0 = __shfl(W.v[cc], i + 32 * hc, 64);
+      tp_lds_sync();
+      if (i == c) {
+#pragma unroll
+        for (int q = 0; q < NH / 4; ++q) {
+          *reinterpret_cast<float4*>(piv + h * NH + 4 * q) = make_float4(W.v[4 * q], W.v[4 * q + 1], W.v[4 * q + 2], W.v[4 * q + 3]);
+          *reinterpret_cast<float4*>(piv + NR + h * NH + 4 * q) = make_float4(R0.v[4 * q], R0.v[4 * q + 1], R0.v[4 * q + 2], R0.v[4 * q + 3]);
+          if constexpr (NRHS > 1)
+            *reinterpret_cast<float4*>(piv + 2 * NR + h * NH + 4 * q) = make_float4(R1.v[4 * q], R1.v[4 * q + 1], R1.v[4 * q + 2], R1.v[4 * q + 3]);
+        }
+        if (h == 0) piv[3 * NR] = u;
+      }
+      tp_lds_sync();
+      const float pv = piv[c];
+      float rp = __builtin_amdgcn_rcpf(pv);
+      rp = fmaf(fmaf(-pv, rp, 1.0f), rp, rp);
+      const float f = (f0 - (i == c ? 1.f : 0.f)) * rp;
+      const float* ph = piv + h * NH;
+#pragma unroll
+      for (int q = 0; q < NH / 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(ph + 4 * q);
+        W.v[4 * q] = fmaf(-f, a.x, W.v[4 * q]); W.v[4 * q + 1] = fmaf(-f, a.y, W.v[4 * q + 1]);
+        W.v[4 * q + 2] = fmaf(-f, a.z, W.v[4 * q + 2]); W.v[4 * q + 3] = fmaf(-f, a.w, W.v[4 * q + 3]);
+        const float4 b = *reinterpret_cast<const float4*>(ph + NR + 4 * q);
+        R0.v[4 * q] = fmaf(-f, b.x, R0.v[4 * q]); R0.v[4 * q + 1] = fmaf(-f, b.y, R0.v[4 * q + 1]);
+        R0.v[4 * q + 2] = fmaf(-f, b.z, R0.v[4 * q + 2]); R0.v[4 * q + 3] = fmaf(-f, b.w, R0.v[4 * q + 3]);
+        if constexpr (NRHS > 1) {
+          const float4 d = *reinterpret_cast<const float4*>(ph + 2 * NR + 4 * q);
+          R1.v[4 * q] = fmaf(-f, d.x, R1.v[4 * q]); R1.v[4 * q + 1] = fmaf(-f, d.y, R1.v[4 * q + 1]);
+          R1.v[4 * q + 2] = fmaf(-f, d.z, R1.v[4 * q + 2]); R1.v[4 * q + 3] = fmaf(-f, d.w, R1.v[4 * q + 3]);
+        }
+      }
+      u = fmaf(-f, piv[3 * NR], u);
+    }
+  }
+}
+
 // ---- forward (filtering) elements in the workspace: NR rows of [A | C | J | b eta 0 0] -------------
 template <int NR> struct TpElemPtr {
   const float* p;
-  __device__ __forceinline__ TRow<NR> A(int lane) const { return trow_load<NR>(p, 3 * NR + 4, lane); }
-  __device__ __forceinline__ TRow<NR> C(int lane) const { return trow_load<NR>(p + NR, 3 * NR + 4, lane); }
-  __device__ __forceinline__ TRow<NR> J(int lane) const { return trow_load<NR>(p + 2 * NR, 3 * NR + 4, lane); }
-  __device__ __forceinline__ float b(int lane) const { return lane < NR ? p[(size_t)lane * (3 * NR + 4) + 3 * NR] : 0.f; }
-  __device__ __forceinline__ float eta(int lane) const { return lane < NR ? p[(size_t)lane * (3 * NR + 4) + 3 * NR + 1] : 0.f; }
+  static constexpr int RW = 3 * NR + 4;
+  __device__ __forceinline__ TRow<NR> A(int lane) const { return trow_load<NR>(p, RW, lane); }
+  __device__ __forceinline__ TRow<NR> C(int lane) const { return trow_load<NR>(p + NR, RW, lane); }
+  __device__ __forceinline__ TRow<NR> J(int lane) const { return trow_load<NR>(p + 2 * NR, RW, lane); }
+  __device__ __forceinline__ float b(int lane) const { return lane < NR ? p[(size_t)lane * RW + 3 * NR] : 0.f; }
+  __device__ __forceinline__ float eta(int lane) const { return lane < NR ? p[(size_t)lane * RW + 3 * NR + 1] : 0.f; }
+  // half / full-row forms on both halves of the wavefront
+  __device__ __forceinline__ THalf<NR / 2> Ah(int lane) const { return hload<NR>(p, RW, lane); }
+  __device__ __forceinline__ THalf<NR / 2> Ch(int lane) const { return hload<NR>(p + NR, RW, lane); }
+  __device__ __forceinline__ THalf<NR / 2> Jh(int lane) const { return hload<NR>(p + 2 * NR, RW, lane); }
+  __device__ __forceinline__ TRow<NR> Af(int lane) const { return fload<NR>(p, RW, lane); }
+  __device__ __forceinline__ TRow<NR> Cf(int lane) const { return fload<NR>(p + NR, RW, lane); }
+  __device__ __forceinline__ TRow<NR> Jf(int lane) const { return fload<NR>(p + 2 * NR, RW, lane); }
+  __device__ __forceinline__ float bf(int lane) const { return fscalar<NR>(p, RW, 3 * NR, lane); }
+  __device__ __forceinline__ float etaf(int lane) const { return fscalar<NR>(p, RW, 3 * NR + 1, lane); }
 };
 template <int NR>
 __device__ __forceinline__ void tp_elem_store(float* p, int lane, const TRow<NR>& A, const TRow<NR>& C,
@@ -378,12 +568,17 @@ template <int NR> __device__ __forceinline__ void tp_elem_copy(float* dst, const
   const int n4 = (int)(tp_esz(NR) / 4);
   for (int e = lane; e < n4; e += 64) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[e];
 }
+// (Measured, tools/bench_tp_combine.hip: this row-per-lane form with v_readlane pivots -- no LDS
+// round trip inside the elimination -- takes 50k cycles at NR = 24 on one wavefront and 100k with
+// all eight of a workgroup in it; the half-row form with LDS-published pivot rows has 40 % fewer
+// instructions but two LDS synchronisations per pivot: 75k / 165k.  The half-row form is kept for
+// the backward maps, where the product dominates: 8.5k instead of 19k cycles.)
 // out = e1 then e2 (e1 covers the earlier steps).  Operands are read from the workspace just in
 // time -- at most five matrices are live in registers.  STATE: only (b, C) of the result are
 // formed (the predicted moments at a chunk's start), written as rows of [C | b 0 0 0].
 template <int NR, bool STATE>
 __device__ __noinline__ void tp_combine(const float* g1, const float* g2, float* out, float* scr, float* vb,
-                                        int D, int lane) {
+                                        float* /*piv*/, int D, int lane) {
   const TpElemPtr<NR> e1{g1}, e2{g2};
   TRow<NR> Y = e1.C(lane);                       // C1, becomes W^-1 C1
   // W = I + C1 J2
@@ -448,13 +643,13 @@ template <int NR> __device__ __forceinline__ void tp_state_from_elem(const float
 template <int NR>
 __device__ __noinline__ void tp_bcompose(const float* outer, const float* inner, float* out, float* scr, float* vb,
                                          int D, int lane) {
-  const TRow<NR> Mo = trow_load<NR>(outer, NR + 4, lane);
-  const float co = lane < NR ? outer[(size_t)lane * (NR + 4) + NR] : 0.f;
-  const float ci = lane < NR ? inner[(size_t)lane * (NR + 4) + NR] : 0.f;
-  tscr_put<NR>(scr, trow_load<NR>(inner, NR + 4, lane), lane);
-  const TRow<NR> M = tmul<NR>(Mo, scr, D, lane);
-  const float c = co + tdot<NR>(Mo, vb, ci, lane);
-  trow_store<NR>(out, NR + 4, lane, M);
+  const TRow<NR> Mo = fload<NR>(outer, NR + 4, lane);
+  const float co = fscalar<NR>(outer, NR + 4, NR, lane);
+  const float ci = fscalar<NR>(inner, NR + 4, NR, lane);
+  hscr_put<NR>(scr, hload<NR>(inner, NR + 4, lane), lane);
+  const THalf<NR / 2> M = hmul<NR>(Mo, scr, D, lane);
+  const float c = co + hdot<NR>(Mo, vb, ci, lane);
+  hstore<NR>(out, NR + 4, lane, M);
   if (lane < NR) *reinterpret_cast<float4*>(out + (size_t)lane * (NR + 4) + NR) = make_float4(c, 0.f, 0.f, 0.f);
 }
 template <int NR> __device__ __forceinline__ void tp_bcopy(float* dst, const float* src, int lane) {
@@ -979,6 +1174,167 @@ __device__ __forceinline__ void tp_recon_pass(const TpCtx& c, int s, int e, floa
 }
 
 // ------------------------------------------------------------------------------------
+// spike_slab_draw_big (ci_kernels.h: any number of covariates, every O(P^2) array in the chain's HBM
+// workspace) executed by the WHOLE workgroup.  On one wavefront the draw costs 1.1M cycles per
+// iteration at P = 101 (28 sweeps of two 100 x 100 float64 matrices through L2 by 64 lanes) -- slower
+// than the oracle on one host core.  Here every wavefront takes the same decisions from the same
+// state (the proposals of 64 visiting positions are evaluated redundantly: they are cheap), and
+// everything that walks a matrix -- building it, the sweeps, the Cholesky factor of the included
+// block -- is spread over all NTH threads, a workgroup barrier where the one-wavefront form has a
+// wave-level one.  Entry for entry the arithmetic of spike_slab_draw_big / sweep_big (a sweep is
+// one pass here: the pivot row and column are written in the same pass as the general entries).
+// Every thread returns the same new observation-noise scale.
+// ------------------------------------------------------------------------------------
+template <int NTH>
+__device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, float* w, int P,
+                                                         const DevSeriesParams& sp, double prev_obs_scale,
+                                                         double g_obs, const Rng& rng, uint32_t iter,
+                                                         int tid, bool first) {
+  const int lane = tid & 63;
+  const int n = P + 1;
+  const double prev_var = prev_obs_scale * prev_obs_scale;
+  const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
+  const bool all_in = sp.nonzero_prob >= 1.0;
+  double* A = R.aug[0];
+  double* Pm = R.pri[0];
+  double* ta = R.chol + (size_t)P * P;      // saved pivot row of A   [n]
+  double* tp = ta + n;                      // saved pivot row of Pm  [n]
+  for (int e = tid; e < n * n; e += NTH) {
+    const int i = e / n, j = e - i * n;
+    double v;
+    if (i < P && j < P) v = R.omega[i * P + j] * prev_var + R.xtx[i * P + j];
+    else v = R.bvec[(i == P && j == P) ? P : (i < j ? i : j)];
+    A[e] = v;
+  }
+  if (first)
+    for (int e = tid; e < P * P; e += NTH) Pm[e] = R.omega[e];
+  for (int j = tid; j < P; j += NTH) {
+    R.nz[j] = all_in ? 1 : (w[j] != 0.f ? 1 : 0);
+    if (!all_in) R.uperm[j] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j);
+  }
+  tp_wg_barrier();
+  auto sweep_one_wg = [&](double* M, int m, const double* t, int k, double sgn) {
+    const double rd = 1.0 / t[k];
+    for (int e = tid; e < m * m; e += NTH) {
+      const int i = e / m, j = e - i * m;
+      double v;
+      if (i == k) v = (j == k) ? -rd : sgn * t[j] * rd;
+      else if (j == k) v = sgn * t[i] * rd;
+      else v = M[e] - (t[i] * rd) * t[j];
+      M[e] = v;
+    }
+  };
+  auto sweep_both = [&](int k, bool reverse, bool with_prior) {
+    const double sgn = reverse ? -1.0 : 1.0;
+    for (int j = tid; j < n; j += NTH) ta[j] = A[k * n + j];
+    if (with_prior)
+      for (int j = tid; j < P; j += NTH) tp[j] = Pm[k * P + j];
+    tp_wg_barrier();
+    sweep_one_wg(A, n, ta, k, sgn);
+    if (with_prior) sweep_one_wg(Pm, P, tp, k, sgn);
+    tp_wg_barrier();
+  };
+  for (int k = 0; k < P; ++k)
+    if (R.nz[k]) sweep_both(k, false, first);
+  if (!all_in) {
+    for (int j = tid; j < P; j += NTH) {
+      const double uj = R.uperm[j];
+      int rank = 0;
+      for (int k = 0; k < P; ++k) {
+        const double uk = R.uperm[k];
+        rank += (uk < uj || (uk == uj && k < j)) ? 1 : 0;
+      }
+      R.perm[rank] = j;
+    }
+    tp_wg_barrier();
+    const double logit_pi = log(sp.nonzero_prob) - log1p(-sp.nonzero_prob);
+    int s_cur = 0;
+    while (s_cur < P) {
+      const int base = s_cur & ~63;
+      const int pos = base + lane;
+      bool flip = false;
+      if (pos < P && pos >= s_cur) {
+        const int j = R.perm[pos];
+        const bool in = R.nz[j] != 0;
+        const double ajj = A[j * n + j], ajb = A[j * n + P], corner = A[P * n + P];
+        const double pju = Pm[j * P + j];
+        const double beta_old = sp.obs_scale + 0.5 * corner;
+        double delta;
+        if (!in) {
+          const double beta_new = sp.obs_scale + 0.5 * (corner - ajb * ajb / ajj);
+          delta = 0.5 * log(pju * prev_var) - 0.5 * log(ajj) + logit_pi -
+                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
+        } else {
+          const double V = -ajj, Vp = -pju / prev_var;
+          const double beta_new = sp.obs_scale + 0.5 * (corner + ajb * ajb / V);
+          delta = 0.5 * log(Vp) - 0.5 * log(V) - logit_pi -
+                  (a_post - 1.0) * (log(beta_new) - log(beta_old));
+        }
+        const double u = uniform_d(rng, iter, SITE_FLIP, 0, (uint32_t)pos);
+        flip = u < 1.0 / (1.0 + exp(-delta));
+      }
+      const unsigned long long bal = __ballot(flip);
+      if (bal == 0ull) { s_cur = base + 64; continue; }
+      const int s_star = base + __ffsll((long long)bal) - 1;
+      const int j = R.perm[s_star];
+      const bool in = R.nz[j] != 0;
+      tp_wg_barrier();                       // every wavefront has read the state it decided on
+      sweep_both(j, in, true);
+      if (tid == 0) R.nz[j] = in ? 0 : 1;
+      tp_wg_barrier();
+      s_cur = s_star + 1;
+    }
+  }
+  const double beta_post = sp.obs_scale + 0.5 * A[P * n + P];
+  double var = beta_post / g_obs;
+  if (var > sp.obs_ub) var = sp.obs_ub;
+  const double new_scale = sqrt(var);
+  // active set in increasing feature order (every wavefront forms the same list; wave 0 stores it)
+  int na = 0;
+  for (int j0 = 0; j0 < P; j0 += 64) {
+    const int j = j0 + lane;
+    const int mynz = j < P ? R.nz[j] : 0;
+    const unsigned long long bal = __ballot(mynz != 0);
+    if (mynz && tid < 64) R.idx[na + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+    na += __popcll(bal);
+  }
+  for (int j = tid; j < P; j += NTH) w[j] = 0.f;
+  tp_wg_barrier();
+  for (int e = tid; e < na * na; e += NTH) {
+    const int i = e / na, j = e - i * na;
+    const int fi = R.idx[i], fj = R.idx[j];
+    R.chol[e] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
+  }
+  for (int i = tid; i < na; i += NTH) R.zv[i] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[i]);
+  tp_wg_barrier();
+  for (int k = 0; k < na; ++k) {
+    const double dkk = sqrt(R.chol[k * na + k]);
+    tp_wg_barrier();
+    for (int i = k + tid; i < na; i += NTH) R.chol[i * na + k] = (i == k) ? dkk : R.chol[i * na + k] / dkk;
+    tp_wg_barrier();
+    const int rem = na - k - 1;
+    for (int e = tid; e < rem * rem; e += NTH) {
+      const int i = k + 1 + e / rem, j = k + 1 + (e - (e / rem) * rem);
+      if (j <= i) R.chol[i * na + j] -= R.chol[i * na + k] * R.chol[j * na + k];
+    }
+    tp_wg_barrier();
+  }
+  for (int i = na - 1; i >= 0; --i) {
+    const double ui = R.zv[i] / R.chol[i * na + i];
+    tp_wg_barrier();
+    if (tid == 0) R.zv[i] = ui;
+    for (int k = tid; k < i; k += NTH) R.zv[k] -= R.chol[i * na + k] * ui;
+    tp_wg_barrier();
+  }
+  for (int i = tid; i < na; i += NTH) {
+    const int f = R.idx[i];
+    w[f] = (float)(A[f * n + P] + new_scale * R.zv[i]);
+  }
+  tp_wg_barrier();
+  return new_scale;
+}
+
+// ------------------------------------------------------------------------------------
 // the persistent Gibbs kernel (iteration structure of gibbs_seasonal_kernel / the oracle's
 // ci_oracle_fit_gibbs; gibbs_sampler.fit_with_gibbs_sampling called at causalimpact_lib.py:365)
 // ------------------------------------------------------------------------------------
@@ -1015,6 +1371,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
   unsigned char* wsc = reinterpret_cast<unsigned char*>(a.ws) + chain_lin * a.ws_stride;
   int* csync = a.csync + chain_lin * TPC_INTS;
   int* mode_lds = reinterpret_cast<int*>(smem + LL.shared);
+  double* shd = reinterpret_cast<double*>(smem + LL.shared + 16);     // wavefront 0 -> workgroup
 
   // ---- the cluster
   TpSync sy;
@@ -1177,11 +1534,34 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
         yty = fmaf(tg, tg, yty);
       }
       tp_wg_barrier_wave();
-      for (int j = 0; j < P; ++j) {
-        float pj = 0.f;
-        for (int t = s + lane; t < e; t += 64) pj = fmaf(Xg[(size_t)j * T + t], cx.ytil[t], pj);
-        const float sj = wave_sum_dpp(pj);
-        if (lane == 0) cpart[(size_t)c * PR + j] = sj;
+      // four features per round (their loads in flight together), the targets in registers
+      {
+        const int ta = s + lane, tb = s + lane + 64;
+        const float tga = ta < e ? cx.ytil[ta] : 0.f, tgb = tb < e ? cx.ytil[tb] : 0.f;
+        const bool wide_chunk = e - s > 128;
+        for (int j0 = 0; j0 < P; j0 += 4) {
+          float xa[4], xb[4], pj[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u < P ? j0 + u : P - 1;
+            xa[u] = ta < e ? Xg[(size_t)j * T + ta] : 0.f;
+            xb[u] = tb < e ? Xg[(size_t)j * T + tb] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pj[u] = fmaf(xb[u], tgb, xa[u] * tga);
+          if (wide_chunk) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = j0 + u < P ? j0 + u : P - 1;
+              for (int t = s + lane + 128; t < e; t += 64) pj[u] = fmaf(Xg[(size_t)j * T + t], cx.ytil[t], pj[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float sj = wave_sum_dpp(pj[u]);
+            if (lane == 0 && j0 + u < P) cpart[(size_t)c * PR + j0 + u] = sj;
+          }
+        }
       }
       const float s0 = wave_sum_dpp(yty);
       if (lane == 0) cpart[(size_t)c * PR + P] = s0;
@@ -1264,10 +1644,16 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
           obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
         else if (!bigp)
           obs_scale = spike_slab_draw(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, it == 0);
-        else
-          obs_scale = spike_slab_draw_big(R, R.w, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, it == 0);
+        else if (lane == 0) { shd[0] = obs_scale; shd[1] = g_obs; }     // the whole workgroup draws (below)
       }
       wave_sync();
+    }
+    if (is_main && bigp && it < n_iter) {
+      tp_wg_barrier();
+      const double ns = tp_spike_slab_draw_big_wg<TP_NT>(R, R.w, P, sp, shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
+      if (wave == 0) obs_scale = ns;
+    }
+    if (is_main && wave == 0) {
       for (int j = lane; j < P; j += 64) cw[j] = R.w[j];
       if (lane == 0) {
         cw[CWS + 1] = (float)obs_scale; cw[CWS + 2] = (float)level_scale; cw[CWS + 3] = (float)slope_scale;
@@ -1293,7 +1679,9 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       if (it > 0 && sidx >= 0) {
         const uint32_t pit = (uint32_t)(it - 1);
         const size_t o = chain_lin * g.S + sidx, row = o * T;
-        for (int q4 = (s >> 2) + lane; q4 < ((e + 3) >> 2); q4 += 64) {
+        // (4-step blocks of the UNCLAMPED chunk: an empty chunk at the end of the series must not
+        // visit the last block of its predecessor a second time -- the running sum below)
+        for (int q4 = ((c * Lc) >> 2) + lane; q4 < (((c + 1) * Lc) >> 2); q4 += 64) {
           float zp[4];
           normals4(site_call(rng, pit, SITE_PRED, 0, (uint32_t)q4), zp);
 #pragma unroll
@@ -1323,10 +1711,18 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       tp_wg_barrier_wave();           // (the emission has read the previous X w)
       for (int t = s + lane; t < e; t += 64) {
         float sx = 0.f;
-        for (int j = 0; j < P; ++j) sx = fmaf(Xg[(size_t)j * T + t], cw[j], sx);
+        int j = 0;
+        for (; j + 8 <= P; j += 8) {
+          float xv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) xv[u] = Xg[(size_t)(j + u) * T + t];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sx = fmaf(xv[u], cw[j + u], sx);
+        }
+        for (; j < P; ++j) sx = fmaf(Xg[(size_t)j * T + t], cw[j], sx);
         cx.xw[t] = sx;
       }
-      for (int q4 = (s >> 2) + lane; q4 < ((s + Lc) >> 2); q4 += 64) {
+      for (int q4 = ((c * Lc) >> 2) + lane; q4 < (((c + 1) * Lc) >> 2); q4 += 64) {
         float z4[4];
         normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_LEVEL, 0, (uint32_t)q4), z4);
         *reinterpret_cast<float4*>(cx.zl + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
@@ -1415,7 +1811,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
         const int c = v * TP_NWV + wave;
         const float* src = l == 0 ? e0 : ei + (size_t)(l - 1) * N * ESZ;
         float* dst = ei + (size_t)l * N * ESZ + (size_t)c * ESZ;
-        if (wave >= (1 << l)) tp_combine<NR, false>(src + (size_t)(c - (1 << l)) * ESZ, src + (size_t)c * ESZ, dst, cx.scr, cx.vb, D, lane);
+        if (wave >= (1 << l)) tp_combine<NR, false>(src + (size_t)(c - (1 << l)) * ESZ, src + (size_t)c * ESZ, dst, cx.scr, cx.vb, cx.pzv, D, lane);
         else tp_elem_copy<NR>(dst, src + (size_t)c * ESZ, lane);
         if (l == LVI - 1 && wave == TP_NWV - 1) {       // the workgroup's total
           tp_wg_barrier_wave();
@@ -1431,7 +1827,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
         if (wave != (v & (TP_NWV - 1))) continue;
         const float* src = et + (size_t)m * G * ESZ;
         float* dst = et + (size_t)(m + 1) * G * ESZ + (size_t)v * ESZ;
-        if (v >= (1 << m)) tp_combine<NR, false>(src + (size_t)(v - (1 << m)) * ESZ, src + (size_t)v * ESZ, dst, cx.scr, cx.vb, D, lane);
+        if (v >= (1 << m)) tp_combine<NR, false>(src + (size_t)(v - (1 << m)) * ESZ, src + (size_t)v * ESZ, dst, cx.scr, cx.vb, cx.pzv, D, lane);
         else tp_elem_copy<NR>(dst, src + (size_t)v * ESZ, lane);
       }
       tp_cluster_barrier(sy, tid);
@@ -1443,7 +1839,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       if (c == 0) continue;
       if (wave == 0) tp_state_from_elem<NR>(etot + (size_t)(v - 1) * ESZ, dst, lane);
       else if (v == 0) tp_state_from_elem<NR>(eincl + (size_t)(c - 1) * ESZ, dst, lane);
-      else tp_combine<NR, true>(etot + (size_t)(v - 1) * ESZ, eincl + (size_t)(c - 1) * ESZ, dst, cx.scr, cx.vb, D, lane);
+      else tp_combine<NR, true>(etot + (size_t)(v - 1) * ESZ, eincl + (size_t)(c - 1) * ESZ, dst, cx.scr, cx.vb, cx.pzv, D, lane);
     }
     tp_wg_barrier_wave();
     prof.tick(25);
@@ -1458,21 +1854,21 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
         cvec = tp_backward_pass<false>(cx, s, e, 0.f);
       }
       // M = (I + J P_start)^-1 A'
-      TRow<NR> M = trow_zero<NR>();
+      THalf<NR / 2> M = thalf_zero<NR / 2>();
       if (s < T) {
         const TpElemPtr<NR> el{e0 + (size_t)c * ESZ};
-        tscr_put<NR>(cx.scr, trow_load<NR>(st, NR + 4, lane), lane);
-        TRow<NR> W = tmul<NR>(el.J(lane), cx.scr, D, lane, true);
-        M = ttranspose<NR>(cx.scr, el.A(lane), lane);
-        TRow<NR> dummy = trow_zero<NR>();
+        hscr_put<NR>(cx.scr, hload<NR>(st, NR + 4, lane), lane);
+        THalf<NR / 2> W = hmul<NR>(el.Jf(lane), cx.scr, D, lane, true);
+        M = htranspose<NR>(cx.scr, el.Ah(lane), lane);
+        THalf<NR / 2> dummy = thalf_zero<NR / 2>();
         float du = 0.f;
-        tgauss_jordan<NR, 1>(W, M, dummy, du, D, lane);
+        hgauss_jordan<NR, 1>(W, M, dummy, du, cx.pzv, D, lane);
       } else {
 #pragma unroll
-        for (int u = 0; u < NR; ++u) M.v[u] = (comp && u == lane) ? 1.f : 0.f;
+        for (int u = 0; u < NR / 2; ++u) M.v[u] = ((lane & 31) < D && (lane >> 5) * (NR / 2) + u == (lane & 31)) ? 1.f : 0.f;
       }
       float* bo = bm + (size_t)c * BSZ;
-      trow_store<NR>(bo, NR + 4, lane, M);
+      hstore<NR>(bo, NR + 4, lane, M);
       if (lane < NR) *reinterpret_cast<float4*>(bo + (size_t)lane * (NR + 4) + NR) = make_float4(comp ? cvec : 0.f, 0.f, 0.f, 0.f);
     }
     prof.tick(26);
@@ -1493,24 +1889,22 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
     }
     const float* bincl = bi + (size_t)(LVI - 1) * N * BSZ;
     if (G > 1) tp_cluster_barrier(sy, tid);                                 // (E)
-    for (int m = 0; m < LVG; ++m) {
-      for (int v = v0; v < v1; ++v) {
-        if (wave != (v & (TP_NWV - 1))) continue;
-        const float* src = bt + (size_t)m * G * BSZ;
-        float* dst = bt + (size_t)(m + 1) * G * BSZ + (size_t)v * BSZ;
-        if (v + (1 << m) < G) tp_bcompose<NR>(src + (size_t)v * BSZ, src + (size_t)(v + (1 << m)) * BSZ, dst, cx.scr, cx.vb, D, lane);
-        else tp_bcopy<NR>(dst, src + (size_t)v * BSZ, lane);
-      }
-      tp_cluster_barrier(sy, tid);
-    }
-    const float* btot = bt + (size_t)LVG * G * BSZ;
+    // (r at the end of a workgroup's last chunk needs the LATER workgroups' total maps applied to
+    // zero: a chain of at most G - 1 matrix-vector products, formed by every wavefront for itself --
+    // no further cluster barriers, no products of maps)
     prof.tick(27);
     // ---- (7) r through the chunk from its true end value, the draw, its statistics
     for (int v = v0; v < v1; ++v) {
       const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
       if (s >= T) continue;
       float r_in = 0.f;                                   // r at the end of this workgroup's last chunk
-      if (v + 1 < G && lane < NR) r_in = btot[(size_t)(v + 1) * BSZ + (size_t)lane * (NR + 4) + NR];
+      for (int vv = G - 1; vv > v; --vv) {
+        const float* tm = bt + (size_t)vv * BSZ;
+        if ((size_t)vv * TP_NWV * Lc >= (size_t)T) continue;              // (empty workgroup: identity)
+        const TRow<NR> Mv = trow_load<NR>(tm, NR + 4, lane);
+        const float cv_ = lane < NR ? tm[(size_t)lane * (NR + 4) + NR] : 0.f;
+        r_in = cv_ + tdot<NR>(Mv, cx.vb, r_in, lane);
+      }
       float r_end = r_in;
       if (wave + 1 < TP_NWV) {
         const float* nx = bincl + (size_t)(c + 1) * BSZ;

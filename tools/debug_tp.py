@@ -73,6 +73,8 @@ if __name__ == "__main__":
       run(10000, 50, 0, REF, flags, S=6, W=2, C=8, oracle=False, label=lab + " cfg4-size 8 chains", prof=True)
       run(2500, 12, 1, REF, flags, S=6, W=2, C=1, oracle=False, label=lab + " 4+7+6 slope", prof=True)
     run(10000, 50, 0, REF, 0, S=3, label="tp cluster cfg4-size")
-    run(10000, 50, 0, ((7, 1),), 0, S=6, W=2, C=8, oracle=False, label="wide kernel cfg4")
+    run(10000, 50, 0, ((7, 1),), 0, S=30, W=10, C=8, oracle=False, label="wide kernel cfg4")
+    run(10000, 50, 0, ((7, 1),), _native.FLAG_CLUSTER_SEASONAL, S=30, W=10, C=8, oracle=False, label="tp kernel cfg4", prof=True)
+    run(10000, 50, 0, ((7, 1),), _native.FLAG_CLUSTER_SEASONAL, S=3, label="tp kernel cfg4 vs oracle")
     run(1000, 100, 0, (), 0, S=10, W=2, C=8, oracle=False, label="tp trend P=101", prof=True)
     run(1000, 100, 0, (), SEQ, S=10, W=2, C=8, oracle=False, label="seq trend P=101")

@@ -45,9 +45,9 @@
 
 namespace ci {
 
-constexpr int TP_NWV = 8;                  // wavefronts (chunks) per workgroup
+constexpr int TP_NWV = 4;                  // wavefronts (chunks) per workgroup: ONE per SIMD
 constexpr int TP_NT = TP_NWV * 64;
-constexpr int TP_MAXG = 16;                // workgroups per chain
+constexpr int TP_MAXG = 32;                // workgroups per chain
 constexpr int TP_MAXD = 32;                // widest state
 constexpr int TPC_INTS = 64;               // handshake ints per chain: [0,16) barrier | 16 mode | [32,48) check-in
 constexpr int TPC_MODE = 16, TPC_XCC = 32;
@@ -141,6 +141,22 @@ __host__ __device__ inline TpLds make_tplds(int P, int D) {
 }
 
 #ifndef CI_SEASONAL_DECL_ONLY
+// Pointers with their ADDRESS SPACE in the type: a `float*` that reaches a function through a struct
+// or a parameter is a generic pointer to the compiler, and every access through it a FLAT
+// instruction (both memory pipelines, both wait counters) -- the first build of this file had 465
+// flat loads in the element pass and 1,049 in the combine.  With typed pointers the same accesses
+// are ds_read / global_load.
+typedef CI_GLB float* TpG;
+typedef CI_GLB const float* TpGC;
+typedef CI_LDS float* TpL;
+typedef CI_LDS const float* TpLC;
+typedef CI_GLB uint8_t* TpGB;
+typedef CI_GLB const uint8_t* TpGBC;
+__device__ __forceinline__ CI_GLB const ci_f4v* tp_p4(TpGC p) { return (CI_GLB const ci_f4v*)p; }
+__device__ __forceinline__ CI_LDS const ci_f4v* tp_p4(TpLC p) { return (CI_LDS const ci_f4v*)p; }
+__device__ __forceinline__ CI_GLB ci_f4v* tp_p4w(TpG p) { return (CI_GLB ci_f4v*)p; }
+__device__ __forceinline__ CI_LDS ci_f4v* tp_p4w(TpL p) { return (CI_LDS ci_f4v*)p; }
+__device__ __forceinline__ CI_GLB const uint32_t* tp_pu(TpGBC p) { return (CI_GLB const uint32_t*)p; }
 // ------------------------------------------------------------------------------------
 // synchronisation
 // ------------------------------------------------------------------------------------
@@ -168,15 +184,20 @@ __device__ __forceinline__ void tp_cluster_barrier(TpSync& s, int tid) {
   // one location -- polling G per-workgroup flags one after the other cost G dependent L2 round
   // trips (~12k cycles at G = 16, thirteen times per iteration)
   ++s.epoch;
+  // One XCD (`light`): the workgroups share the L2, so a store is visible to the others once it has
+  // reached L2 -- s_waitcnt vmcnt(0), which the workgroup-scope release is -- and the arrival is a
+  // RELAXED atomic.  A release at agent scope would write the XCD's whole L2 back first (MI300-class
+  // parts keep one L2 per XCD: "agent" spans them): measured ~30k cycles per barrier, ten barriers
+  // per iteration.  Several XCDs: the full agent-scope release.
   if (s.light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   else __threadfence();
   __syncthreads();
   if (tid == 0) {
-    (void)__hip_atomic_fetch_add(s.flags, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (s.light) (void)__hip_atomic_fetch_add(s.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else (void)__hip_atomic_fetch_add(s.flags, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const int want = s.epoch * s.G;
     while (__hip_atomic_load(s.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
       __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -243,34 +264,34 @@ template <int NR> __device__ __forceinline__ TRow<NR> trow_zero() {
   return r;
 }
 // row `lane` of a matrix stored as rows of `stride` floats (16-byte aligned); zeros for lane >= NR
-template <int NR> __device__ __forceinline__ TRow<NR> trow_load(const float* base, int stride, int lane) {
+template <int NR, class PT> __device__ __forceinline__ TRow<NR> trow_load(PT base, int stride, int lane) {
   TRow<NR> r = trow_zero<NR>();
   if (lane < NR) {
-    const float4* p = reinterpret_cast<const float4*>(base + (size_t)lane * stride);
+    const auto p = tp_p4(base + (size_t)lane * stride);
 #pragma unroll
     for (int q = 0; q < NR / 4; ++q) {
-      const float4 x = p[q];
+      const ci_f4v x = p[q];
       r.v[4 * q] = x.x; r.v[4 * q + 1] = x.y; r.v[4 * q + 2] = x.z; r.v[4 * q + 3] = x.w;
     }
   }
   return r;
 }
-template <int NR> __device__ __forceinline__ void trow_store(float* base, int stride, int lane, const TRow<NR>& r) {
+template <int NR, class PT> __device__ __forceinline__ void trow_store(PT base, int stride, int lane, const TRow<NR>& r) {
   if (lane < NR) {
-    float4* p = reinterpret_cast<float4*>(base + (size_t)lane * stride);
+    auto p = tp_p4w(base + (size_t)lane * stride);
 #pragma unroll
     for (int q = 0; q < NR / 4; ++q)
-      p[q] = make_float4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
+      p[q] = ci_f4v{r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]};
   }
 }
 // the broadcast operand: rows into the wave's LDS scratch (row stride NR)
-template <int NR> __device__ __forceinline__ void tscr_put(float* scr, const TRow<NR>& r, int lane) {
+template <int NR> __device__ __forceinline__ void tscr_put(TpL scr, const TRow<NR>& r, int lane) {
   tp_lds_sync();                       // earlier readers of the scratch are done
   trow_store<NR>(scr, NR, lane, r);
   tp_lds_sync();
 }
 // C = A B (+ I), rows of B in the scratch
-template <int NR> __device__ __forceinline__ TRow<NR> tmul(const TRow<NR>& A, const float* scr, int D, int lane,
+template <int NR> __device__ __forceinline__ TRow<NR> tmul(const TRow<NR>& A, TpLC scr, int D, int lane,
                                                            bool plus_eye = false) {
   TRow<NR> c;
 #pragma unroll
@@ -278,11 +299,11 @@ template <int NR> __device__ __forceinline__ TRow<NR> tmul(const TRow<NR>& A, co
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     if (k < D) {
-      const float4* p = reinterpret_cast<const float4*>(scr + k * NR);
+      const auto p = tp_p4(scr + k * NR);
       const float a = A.v[k];
 #pragma unroll
       for (int q = 0; q < NR / 4; ++q) {
-        const float4 b = p[q];
+        const ci_f4v b = p[q];
         c.v[4 * q] = fmaf(a, b.x, c.v[4 * q]); c.v[4 * q + 1] = fmaf(a, b.y, c.v[4 * q + 1]);
         c.v[4 * q + 2] = fmaf(a, b.z, c.v[4 * q + 2]); c.v[4 * q + 3] = fmaf(a, b.w, c.v[4 * q + 3]);
       }
@@ -291,16 +312,16 @@ template <int NR> __device__ __forceinline__ TRow<NR> tmul(const TRow<NR>& A, co
   return c;
 }
 // C = A B', rows of B in the scratch: C[i][j] = row_i(A) . row_j(B)
-template <int NR> __device__ __forceinline__ TRow<NR> tmul_t(const TRow<NR>& A, const float* scr, int D) {
+template <int NR> __device__ __forceinline__ TRow<NR> tmul_t(const TRow<NR>& A, TpLC scr, int D) {
   TRow<NR> c = trow_zero<NR>();
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     if (j < D) {
-      const float4* p = reinterpret_cast<const float4*>(scr + j * NR);
+      const auto p = tp_p4(scr + j * NR);
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < NR / 4; ++q) {
-        const float4 b = p[q];
+        const ci_f4v b = p[q];
         s = fmaf(A.v[4 * q], b.x, s); s = fmaf(A.v[4 * q + 1], b.y, s);
         s = fmaf(A.v[4 * q + 2], b.z, s); s = fmaf(A.v[4 * q + 3], b.w, s);
       }
@@ -310,7 +331,7 @@ template <int NR> __device__ __forceinline__ TRow<NR> tmul_t(const TRow<NR>& A, 
   return c;
 }
 // transpose through the scratch
-template <int NR> __device__ __forceinline__ TRow<NR> ttranspose(float* scr, const TRow<NR>& r, int lane) {
+template <int NR> __device__ __forceinline__ TRow<NR> ttranspose(TpL scr, const TRow<NR>& r, int lane) {
   tscr_put<NR>(scr, r, lane);
   TRow<NR> t = trow_zero<NR>();
   if (lane < NR) {
@@ -320,15 +341,15 @@ template <int NR> __device__ __forceinline__ TRow<NR> ttranspose(float* scr, con
   return t;
 }
 // row . (a lane-distributed vector): the vector goes through the wave's broadcast buffer
-template <int NR> __device__ __forceinline__ float tdot(const TRow<NR>& A, float* vb, float x, int lane) {
+template <int NR> __device__ __forceinline__ float tdot(const TRow<NR>& A, TpL vb, float x, int lane) {
   tp_lds_sync();
   if (lane < NR) vb[lane] = x;
   tp_lds_sync();
   float s = 0.f;
-  const float4* p = reinterpret_cast<const float4*>(vb);
+  const auto p = tp_p4(vb);
 #pragma unroll
   for (int q = 0; q < NR / 4; ++q) {
-    const float4 b = p[q];
+    const ci_f4v b = p[q];
     s = fmaf(A.v[4 * q], b.x, s); s = fmaf(A.v[4 * q + 1], b.y, s);
     s = fmaf(A.v[4 * q + 2], b.z, s); s = fmaf(A.v[4 * q + 3], b.w, s);
   }
@@ -372,68 +393,68 @@ template <int NH> __device__ __forceinline__ THalf<NH> thalf_zero() {
   for (int j = 0; j < NH; ++j) r.v[j] = 0.f;
   return r;
 }
-template <int NR> __device__ __forceinline__ THalf<NR / 2> hload(const float* base, int stride, int lane) {
+template <int NR, class PT> __device__ __forceinline__ THalf<NR / 2> hload(PT base, int stride, int lane) {
   constexpr int NH = NR / 2;
   THalf<NH> r = thalf_zero<NH>();
   const int i = lane & 31, h = lane >> 5;
   if (i < NR) {
-    const float4* p = reinterpret_cast<const float4*>(base + (size_t)i * stride + h * NH);
+    const auto p = tp_p4(base + (size_t)i * stride + h * NH);
 #pragma unroll
     for (int q = 0; q < NH / 4; ++q) {
-      const float4 x = p[q];
+      const ci_f4v x = p[q];
       r.v[4 * q] = x.x; r.v[4 * q + 1] = x.y; r.v[4 * q + 2] = x.z; r.v[4 * q + 3] = x.w;
     }
   }
   return r;
 }
-template <int NR> __device__ __forceinline__ void hstore(float* base, int stride, int lane, const THalf<NR / 2>& r) {
+template <int NR, class PT> __device__ __forceinline__ void hstore(PT base, int stride, int lane, const THalf<NR / 2>& r) {
   constexpr int NH = NR / 2;
   const int i = lane & 31, h = lane >> 5;
   if (i < NR) {
-    float4* p = reinterpret_cast<float4*>(base + (size_t)i * stride + h * NH);
+    auto p = tp_p4w(base + (size_t)i * stride + h * NH);
 #pragma unroll
-    for (int q = 0; q < NH / 4; ++q) p[q] = make_float4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
+    for (int q = 0; q < NH / 4; ++q) p[q] = ci_f4v{r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]};
   }
 }
 // full row i = lane & 31 (the same registers in both halves)
-template <int NR> __device__ __forceinline__ TRow<NR> fload(const float* base, int stride, int lane) {
+template <int NR, class PT> __device__ __forceinline__ TRow<NR> fload(PT base, int stride, int lane) {
   return trow_load<NR>(base, stride, lane & 31);
 }
-template <int NR> __device__ __forceinline__ float fscalar(const float* base, int stride, int off, int lane) {
+template <int NR, class PT> __device__ __forceinline__ float fscalar(PT base, int stride, int off, int lane) {
   const int i = lane & 31;
   return i < NR ? base[(size_t)i * stride + off] : 0.f;
 }
-template <int NR> __device__ __forceinline__ void hscr_put(float* scr, const THalf<NR / 2>& r, int lane) {
+template <int NR> __device__ __forceinline__ void hscr_put(TpL scr, const THalf<NR / 2>& r, int lane) {
   tp_lds_sync();
   hstore<NR>(scr, NR, lane, r);
   tp_lds_sync();
 }
-template <int NR> __device__ __forceinline__ void fscr_put(float* scr, const TRow<NR>& r, int lane) {
+template <int NR> __device__ __forceinline__ void fscr_put(TpL scr, const TRow<NR>& r, int lane) {
   tp_lds_sync();
   trow_store<NR>(scr, NR, lane, r);        // lanes < NR: row = lane
   tp_lds_sync();
 }
 // own full row back from the scratch (halves -> full)
-template <int NR> __device__ __forceinline__ TRow<NR> fscr_row(const float* scr, int lane) {
+template <int NR> __device__ __forceinline__ TRow<NR> fscr_row(TpLC scr, int lane) {
   return trow_load<NR>(scr, NR, lane & 31);
 }
 // C = A B (+ I): A as full rows, rows of B in the scratch, C in halves
-template <int NR> __device__ __forceinline__ THalf<NR / 2> hmul(const TRow<NR>& A, const float* scr, int D, int lane,
+template <int NR> __device__ __forceinline__ THalf<NR / 2> hmul(const TRow<NR>& A, TpLC scr, int D, int lane,
                                                                bool plus_eye = false) {
   constexpr int NH = NR / 2;
   const int i = lane & 31, h = lane >> 5;
   THalf<NH> c;
 #pragma unroll
   for (int j = 0; j < NH; ++j) c.v[j] = (plus_eye && h * NH + j == i) ? 1.f : 0.f;
-  const float* sh = scr + h * NH;
+  TpLC sh = scr + h * NH;
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     if (k < D) {
-      const float4* p = reinterpret_cast<const float4*>(sh + k * NR);
+      const auto p = tp_p4(sh + k * NR);
       const float a = A.v[k];
 #pragma unroll
       for (int q = 0; q < NH / 4; ++q) {
-        const float4 b = p[q];
+        const ci_f4v b = p[q];
         c.v[4 * q] = fmaf(a, b.x, c.v[4 * q]); c.v[4 * q + 1] = fmaf(a, b.y, c.v[4 * q + 1]);
         c.v[4 * q + 2] = fmaf(a, b.z, c.v[4 * q + 2]); c.v[4 * q + 3] = fmaf(a, b.w, c.v[4 * q + 3]);
       }
@@ -442,17 +463,17 @@ template <int NR> __device__ __forceinline__ THalf<NR / 2> hmul(const TRow<NR>& 
   return c;
 }
 // C = A B': C[i][j] = row_i(A) . row_j(B), j in the lane's half
-template <int NR> __device__ __forceinline__ THalf<NR / 2> hmul_t(const TRow<NR>& A, const float* scr, int lane) {
+template <int NR> __device__ __forceinline__ THalf<NR / 2> hmul_t(const TRow<NR>& A, TpLC scr, int lane) {
   constexpr int NH = NR / 2;
   const int h = lane >> 5;
   THalf<NH> c;
 #pragma unroll
   for (int jj = 0; jj < NH; ++jj) {
-    const float4* p = reinterpret_cast<const float4*>(scr + (h * NH + jj) * NR);
+    const auto p = tp_p4(scr + (h * NH + jj) * NR);
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < NR / 4; ++q) {
-      const float4 b = p[q];
+      const ci_f4v b = p[q];
       s = fmaf(A.v[4 * q], b.x, s); s = fmaf(A.v[4 * q + 1], b.y, s);
       s = fmaf(A.v[4 * q + 2], b.z, s); s = fmaf(A.v[4 * q + 3], b.w, s);
     }
@@ -460,7 +481,7 @@ template <int NR> __device__ __forceinline__ THalf<NR / 2> hmul_t(const TRow<NR>
   }
   return c;
 }
-template <int NR> __device__ __forceinline__ THalf<NR / 2> htranspose(float* scr, const THalf<NR / 2>& r, int lane) {
+template <int NR> __device__ __forceinline__ THalf<NR / 2> htranspose(TpL scr, const THalf<NR / 2>& r, int lane) {
   constexpr int NH = NR / 2;
   hscr_put<NR>(scr, r, lane);
   const int i = lane & 31, h = lane >> 5;
@@ -472,15 +493,15 @@ template <int NR> __device__ __forceinline__ THalf<NR / 2> htranspose(float* scr
   return t;
 }
 // row . x for a per-row scalar x (the same in both halves); the result likewise
-template <int NR> __device__ __forceinline__ float hdot(const TRow<NR>& A, float* vb, float x, int lane) {
+template <int NR> __device__ __forceinline__ float hdot(const TRow<NR>& A, TpL vb, float x, int lane) {
   tp_lds_sync();
   if (lane < NR) vb[lane] = x;
   tp_lds_sync();
   float s = 0.f;
-  const float4* p = reinterpret_cast<const float4*>(vb);
+  const auto p = tp_p4(vb);
 #pragma unroll
   for (int q = 0; q < NR / 4; ++q) {
-    const float4 b = p[q];
+    const ci_f4v b = p[q];
     s = fmaf(A.v[4 * q], b.x, s); s = fmaf(A.v[4 * q + 1], b.y, s);
     s = fmaf(A.v[4 * q + 2], b.z, s); s = fmaf(A.v[4 * q + 3], b.w, s);
   }
@@ -492,7 +513,7 @@ template <int NR> __device__ __forceinline__ float hdot(const TRow<NR>& A, float
 // multiplier of row c itself is W[c][c] - 1 (see tgauss_jordan).
 template <int NR, int NRHS>
 __device__ __forceinline__ void hgauss_jordan(THalf<NR / 2>& W, THalf<NR / 2>& R0, THalf<NR / 2>& R1, float& u,
-                                              float* piv, int D, int lane) {
+                                              TpL piv, int D, int lane) {
   constexpr int NH = NR / 2;
   const int i = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -505,10 +526,10 @@ __device__ __forceinline__ void hgauss_jordan(THalf<NR / 2>& W, THalf<NR / 2>& R
       if (i == c) {
 #pragma unroll
         for (int q = 0; q < NH / 4; ++q) {
-          *reinterpret_cast<float4*>(piv + h * NH + 4 * q) = make_float4(W.v[4 * q], W.v[4 * q + 1], W.v[4 * q + 2], W.v[4 * q + 3]);
-          *reinterpret_cast<float4*>(piv + NR + h * NH + 4 * q) = make_float4(R0.v[4 * q], R0.v[4 * q + 1], R0.v[4 * q + 2], R0.v[4 * q + 3]);
+          *tp_p4w(piv + h * NH + 4 * q) = ci_f4v{W.v[4 * q], W.v[4 * q + 1], W.v[4 * q + 2], W.v[4 * q + 3]};
+          *tp_p4w(piv + NR + h * NH + 4 * q) = ci_f4v{R0.v[4 * q], R0.v[4 * q + 1], R0.v[4 * q + 2], R0.v[4 * q + 3]};
           if constexpr (NRHS > 1)
-            *reinterpret_cast<float4*>(piv + 2 * NR + h * NH + 4 * q) = make_float4(R1.v[4 * q], R1.v[4 * q + 1], R1.v[4 * q + 2], R1.v[4 * q + 3]);
+            *tp_p4w(piv + 2 * NR + h * NH + 4 * q) = ci_f4v{R1.v[4 * q], R1.v[4 * q + 1], R1.v[4 * q + 2], R1.v[4 * q + 3]};
         }
         if (h == 0) piv[3 * NR] = u;
       }
@@ -517,17 +538,17 @@ __device__ __forceinline__ void hgauss_jordan(THalf<NR / 2>& W, THalf<NR / 2>& R
       float rp = __builtin_amdgcn_rcpf(pv);
       rp = fmaf(fmaf(-pv, rp, 1.0f), rp, rp);
       const float f = (f0 - (i == c ? 1.f : 0.f)) * rp;
-      const float* ph = piv + h * NH;
+      TpLC ph = piv + h * NH;
 #pragma unroll
       for (int q = 0; q < NH / 4; ++q) {
-        const float4 a = *reinterpret_cast<const float4*>(ph + 4 * q);
+        const ci_f4v a = *tp_p4(ph + 4 * q);
         W.v[4 * q] = fmaf(-f, a.x, W.v[4 * q]); W.v[4 * q + 1] = fmaf(-f, a.y, W.v[4 * q + 1]);
         W.v[4 * q + 2] = fmaf(-f, a.z, W.v[4 * q + 2]); W.v[4 * q + 3] = fmaf(-f, a.w, W.v[4 * q + 3]);
-        const float4 b = *reinterpret_cast<const float4*>(ph + NR + 4 * q);
+        const ci_f4v b = *tp_p4(ph + NR + 4 * q);
         R0.v[4 * q] = fmaf(-f, b.x, R0.v[4 * q]); R0.v[4 * q + 1] = fmaf(-f, b.y, R0.v[4 * q + 1]);
         R0.v[4 * q + 2] = fmaf(-f, b.z, R0.v[4 * q + 2]); R0.v[4 * q + 3] = fmaf(-f, b.w, R0.v[4 * q + 3]);
         if constexpr (NRHS > 1) {
-          const float4 d = *reinterpret_cast<const float4*>(ph + 2 * NR + 4 * q);
+          const ci_f4v d = *tp_p4(ph + 2 * NR + 4 * q);
           R1.v[4 * q] = fmaf(-f, d.x, R1.v[4 * q]); R1.v[4 * q + 1] = fmaf(-f, d.y, R1.v[4 * q + 1]);
           R1.v[4 * q + 2] = fmaf(-f, d.z, R1.v[4 * q + 2]); R1.v[4 * q + 3] = fmaf(-f, d.w, R1.v[4 * q + 3]);
         }
@@ -539,7 +560,7 @@ __device__ __forceinline__ void hgauss_jordan(THalf<NR / 2>& W, THalf<NR / 2>& R
 
 // ---- forward (filtering) elements in the workspace: NR rows of [A | C | J | b eta 0 0] -------------
 template <int NR> struct TpElemPtr {
-  const float* p;
+  TpGC p;
   static constexpr int RW = 3 * NR + 4;
   __device__ __forceinline__ TRow<NR> A(int lane) const { return trow_load<NR>(p, RW, lane); }
   __device__ __forceinline__ TRow<NR> C(int lane) const { return trow_load<NR>(p + NR, RW, lane); }
@@ -557,16 +578,16 @@ template <int NR> struct TpElemPtr {
   __device__ __forceinline__ float etaf(int lane) const { return fscalar<NR>(p, RW, 3 * NR + 1, lane); }
 };
 template <int NR>
-__device__ __forceinline__ void tp_elem_store(float* p, int lane, const TRow<NR>& A, const TRow<NR>& C,
+__device__ __forceinline__ void tp_elem_store(TpG p, int lane, const TRow<NR>& A, const TRow<NR>& C,
                                               const TRow<NR>& J, float b, float eta) {
   trow_store<NR>(p, 3 * NR + 4, lane, A);
   trow_store<NR>(p + NR, 3 * NR + 4, lane, C);
   trow_store<NR>(p + 2 * NR, 3 * NR + 4, lane, J);
-  if (lane < NR) *reinterpret_cast<float4*>(p + (size_t)lane * (3 * NR + 4) + 3 * NR) = make_float4(b, eta, 0.f, 0.f);
+  if (lane < NR) *tp_p4w(p + (size_t)lane * (3 * NR + 4) + 3 * NR) = ci_f4v{b, eta, 0.f, 0.f};
 }
-template <int NR> __device__ __forceinline__ void tp_elem_copy(float* dst, const float* src, int lane) {
+template <int NR> __device__ __forceinline__ void tp_elem_copy(TpG dst, TpGC src, int lane) {
   const int n4 = (int)(tp_esz(NR) / 4);
-  for (int e = lane; e < n4; e += 64) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[e];
+  for (int e = lane; e < n4; e += 64) tp_p4w(dst)[e] = tp_p4(src)[e];
 }
 // (Measured, tools/bench_tp_combine.hip: this row-per-lane form with v_readlane pivots -- no LDS
 // round trip inside the elimination -- takes 50k cycles at NR = 24 on one wavefront and 100k with
@@ -577,8 +598,8 @@ template <int NR> __device__ __forceinline__ void tp_elem_copy(float* dst, const
 // time -- at most five matrices are live in registers.  STATE: only (b, C) of the result are
 // formed (the predicted moments at a chunk's start), written as rows of [C | b 0 0 0].
 template <int NR, bool STATE>
-__device__ __noinline__ void tp_combine(const float* g1, const float* g2, float* out, float* scr, float* vb,
-                                        float* /*piv*/, int D, int lane) {
+__device__ __noinline__ void tp_combine(TpGC g1, TpGC g2, TpG out, TpL scr, TpL vb,
+                                        TpL /*piv*/, int D, int lane) {
   const TpElemPtr<NR> e1{g1}, e2{g2};
   TRow<NR> Y = e1.C(lane);                       // C1, becomes W^-1 C1
   // W = I + C1 J2
@@ -616,7 +637,7 @@ __device__ __noinline__ void tp_combine(const float* g1, const float* g2, float*
 #pragma unroll
     for (int j = 0; j < NR; ++j) Co.v[j] = 0.5f * (Co.v[j] + Ct.v[j]);
     trow_store<NR>(out, NR + 4, lane, Co);
-    if (lane < NR) *reinterpret_cast<float4*>(out + (size_t)lane * (NR + 4) + NR) = make_float4(bo, 0.f, 0.f, 0.f);
+    if (lane < NR) *tp_p4w(out + (size_t)lane * (NR + 4) + NR) = ci_f4v{bo, 0.f, 0.f, 0.f};
   } else {
     tscr_put<NR>(scr, G, lane);
     const TRow<NR> Ao = tmul<NR>(A2, scr, D, lane);            // A2 G
@@ -633,15 +654,15 @@ __device__ __noinline__ void tp_combine(const float* g1, const float* g2, float*
   }
 }
 // chunk-start moments from an element that already starts at the prior (A = 0): rows [C | b 0 0 0]
-template <int NR> __device__ __forceinline__ void tp_state_from_elem(const float* g, float* out, int lane) {
+template <int NR> __device__ __forceinline__ void tp_state_from_elem(TpGC g, TpG out, int lane) {
   const TpElemPtr<NR> e{g};
   trow_store<NR>(out, NR + 4, lane, e.C(lane));
-  if (lane < NR) *reinterpret_cast<float4*>(out + (size_t)lane * (NR + 4) + NR) = make_float4(e.b(lane), 0.f, 0.f, 0.f);
+  if (lane < NR) *tp_p4w(out + (size_t)lane * (NR + 4) + NR) = ci_f4v{e.b(lane), 0.f, 0.f, 0.f};
 }
 
 // ---- backward maps in the workspace: NR rows of [M | c 0 0 0]; (outer o inner)(r) = Mo (Mi r + ci) + co
 template <int NR>
-__device__ __noinline__ void tp_bcompose(const float* outer, const float* inner, float* out, float* scr, float* vb,
+__device__ __noinline__ void tp_bcompose(TpGC outer, TpGC inner, TpG out, TpL scr, TpL vb,
                                          int D, int lane) {
   const TRow<NR> Mo = fload<NR>(outer, NR + 4, lane);
   const float co = fscalar<NR>(outer, NR + 4, NR, lane);
@@ -650,11 +671,11 @@ __device__ __noinline__ void tp_bcompose(const float* outer, const float* inner,
   const THalf<NR / 2> M = hmul<NR>(Mo, scr, D, lane);
   const float c = co + hdot<NR>(Mo, vb, ci, lane);
   hstore<NR>(out, NR + 4, lane, M);
-  if (lane < NR) *reinterpret_cast<float4*>(out + (size_t)lane * (NR + 4) + NR) = make_float4(c, 0.f, 0.f, 0.f);
+  if (lane < NR) *tp_p4w(out + (size_t)lane * (NR + 4) + NR) = ci_f4v{c, 0.f, 0.f, 0.f};
 }
-template <int NR> __device__ __forceinline__ void tp_bcopy(float* dst, const float* src, int lane) {
+template <int NR> __device__ __forceinline__ void tp_bcopy(TpG dst, TpGC src, int lane) {
   const int n4 = (int)(tp_bsz(NR) / 4);
-  for (int e = lane; e < n4; e += 64) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[e];
+  for (int e = lane; e < n4; e += 64) tp_p4w(dst)[e] = tp_p4(src)[e];
 }
 
 // ------------------------------------------------------------------------------------
@@ -665,33 +686,34 @@ struct TpCtx {
   int off[SMAXK], nsz[SMAXK];
   float H, ql, qs, myd2, rnb, so, sl, ssc, mydrift;
   // this wavefront's LDS
-  float *cm, *am, *scr, *pzv, *vb;
+  TpL cm, am, scr, pzv, vb;
   // arrays over time (this chain's workspace)
-  float *yv, *lev, *slp, *xw, *ytil, *vf, *zl, *zs, *zo, *seas, *zk, *gd, *kf, *rs;
-  uint8_t *msk, *cbv, *cidx;
+  TpG yv, lev, slp, xw, ytil, vf, zl, zs, zo, seas, zk, gd, kf, rs;
+  TpGB msk, cbv, cidx;
 };
 
-__device__ __forceinline__ float tp_at4(const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+__device__ __forceinline__ float tp_at4(const ci_f4v& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
 
 // x+ through the chunk from `xp` (ci_seasonal.h pass 0 on a range; c_k(t) comes from the static
 // table).  WRITE: also y~ = (y - X w) - (Z x+ + sigma_obs z_obs).  Returns x+ after the chunk.
 template <bool WRITE>
-__device__ __forceinline__ float tp_sim_pass(const TpCtx& c, int s, int e, float xp) {
+static __device__ __noinline__ float tp_sim_pass(const TpCtx& cref, int s, int e, float xp) {
+  const TpCtx c = cref;
   const int lane = c.lane;
-  const float* zkb = c.zk + (size_t)c.blk0 * c.TP;
-  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * c.TP;
+  TpGC zkb = c.zk + (size_t)c.blk0 * c.TP;
+  TpGBC cidb = c.cidx + (size_t)c.blk0 * c.TP;
   for (int t4 = s; t4 < e; t4 += 4) {
-    const float4 zl4 = *reinterpret_cast<const float4*>(c.zl + t4);
-    const float4 zk4 = *reinterpret_cast<const float4*>(zkb + t4);
-    float4 zo4 = make_float4(0.f, 0.f, 0.f, 0.f), yv4 = zo4, xw4 = zo4, zs4 = zo4;
+    const ci_f4v zl4 = *tp_p4(c.zl + t4);
+    const ci_f4v zk4 = *tp_p4(zkb + t4);
+    ci_f4v zo4 = ci_f4v{0.f, 0.f, 0.f, 0.f}, yv4 = zo4, xw4 = zo4, zs4 = zo4;
     if (WRITE) {
-      zo4 = *reinterpret_cast<const float4*>(c.zo + t4);
-      yv4 = *reinterpret_cast<const float4*>(c.yv + t4);
-      xw4 = *reinterpret_cast<const float4*>(c.xw + t4);
+      zo4 = *tp_p4(c.zo + t4);
+      yv4 = *tp_p4(c.yv + t4);
+      xw4 = *tp_p4(c.xw + t4);
     }
-    if (c.has_slope) zs4 = *reinterpret_cast<const float4*>(c.zs + t4);
-    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(c.cbv + t4);
-    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    if (c.has_slope) zs4 = *tp_p4(c.zs + t4);
+    const uint32_t cb4 = *tp_pu(c.cbv + t4);
+    const uint32_t cw4 = *tp_pu(cidb + t4);
     float yt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -719,7 +741,7 @@ __device__ __forceinline__ float tp_sim_pass(const TpCtx& c, int s, int e, float
         xp = r;
       }
     }
-    if (WRITE && lane == 0) *reinterpret_cast<float4*>(c.ytil + t4) = make_float4(yt[0], yt[1], yt[2], yt[3]);
+    if (WRITE && lane == 0) *tp_p4w(c.ytil + t4) = ci_f4v{yt[0], yt[1], yt[2], yt[3]};
   }
   return xp;
 }
@@ -747,22 +769,24 @@ __device__ __forceinline__ TRow<NR> tp_prior_row(const TpCtx& c, float p1l, floa
 // and A' serve the reads with a run-time column (C z, A'z).  `first`: the chunk starts at the
 // prior, i.e. its element is (0, a_1, P_1, 0, 0) followed by its steps.
 template <int NCH>
-static __device__ __noinline__ void tp_build_pass(const TpCtx& c, int s, int e, bool first, float a1e,
-                                                   float p1l, float p1s, float p1e, float* eout) {
+static __device__ __noinline__ void tp_build_pass(const TpCtx& cref, int s, int e, bool first, float a1e,
+                                                   float p1l, float p1s, float p1e, TpG eout) {
+  const TpCtx c = cref;        // by value: fields read through the reference are FLAT loads the
+                               // optimiser cannot hoist past the LDS / global stores of the loop
   constexpr int NR = 8 * NCH;
   const int lane = c.lane, D = c.D, DS = c.DS, T = c.T;
   const bool slope = c.has_slope != 0, comp = lane < D;
-  CI_LDS float* Cm = (CI_LDS float*)c.cm;
-  CI_LDS float* Am = (CI_LDS float*)c.am;
+  TpL Cm = c.cm;
+  TpL Am = c.am;
   CI_LDS float* Crow = Cm + (comp ? lane : 0) * DS;
   CI_LDS float* Arow = Am + (comp ? lane : 0) * DS;
-  CI_LDS float* pzv = (CI_LDS float*)c.pzv;
+  TpL pzv = c.pzv;
   CI_LDS float* zav = pzv + 72;
   CI_LDS float* gvk = pzv + 144;
   CI_LDS int* zcol = (CI_LDS int*)(gvk + SMAXK * 72);
   CI_LDS const float* gmine = gvk + c.blk0 * 72;
   CI_LDS float* gslot = gvk + c.blk0 * 72 + lane;
-  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * c.TP;
+  TpGBC cidb = c.cidx + (size_t)c.blk0 * c.TP;
   auto ld4 = [](CI_LDS const float* q) -> ci_f4v { return *(CI_LDS const ci_f4v*)q; };
   const float H = c.H, ql = c.ql, qs = c.qs, myd2 = c.myd2, rnb = c.rnb;
   if (lane < 8) zcol[lane] = D;
@@ -792,10 +816,10 @@ static __device__ __noinline__ void tp_build_pass(const TpCtx& c, int s, int e, 
   }
   tp_lds_sync();
   for (int t4 = s; t4 < e; t4 += 4) {
-    const float4 yt4 = *reinterpret_cast<const float4*>(c.ytil + t4);
-    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(c.cbv + t4);
-    const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(c.msk + t4);
-    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    const ci_f4v yt4 = *tp_p4(c.ytil + t4);
+    const uint32_t cb4 = *tp_pu(c.cbv + t4);
+    const uint32_t mk4 = *tp_pu(c.msk + t4);
+    const uint32_t cw4 = *tp_pu(cidb + t4);
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
       const int t = t4 + q;
@@ -896,18 +920,19 @@ static __device__ __noinline__ void tp_build_pass(const TpCtx& c, int s, int e, 
 // The Kalman filter on the chunk from its true predicted moments (rows [P | a 0 0 0] in `st`):
 // ci_seasonal.h's seasonal_filter_pass on a range.  Stores K_t and v_t / F_t.
 template <int NCH>
-static __device__ __noinline__ void tp_filter_pass(const TpCtx& c, int s, int e, const float* st) {
+static __device__ __noinline__ void tp_filter_pass(const TpCtx& cref, int s, int e, TpGC st) {
+  const TpCtx c = cref;
   constexpr int NR = 8 * NCH;
   const int lane = c.lane, D = c.D, DS = c.DS, T = c.T;
   const bool slope = c.has_slope != 0, comp = lane < D;
-  CI_LDS float* Pm = (CI_LDS float*)c.cm;
+  TpL Pm = c.cm;
   CI_LDS float* Prow = Pm + (comp ? lane : 0) * DS;
-  CI_LDS float* pzv = (CI_LDS float*)c.pzv;
+  TpL pzv = c.pzv;
   CI_LDS float* gvk = pzv + 144;
   CI_LDS int* zcol = (CI_LDS int*)(gvk + SMAXK * 72);
   CI_LDS const float* gmine = gvk + c.blk0 * 72;
   CI_LDS float* gslot = gvk + c.blk0 * 72 + lane;
-  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * c.TP;
+  TpGBC cidb = c.cidx + (size_t)c.blk0 * c.TP;
   auto ld4 = [](CI_LDS const float* q) -> ci_f4v { return *(CI_LDS const ci_f4v*)q; };
   const float H = c.H, ql = c.ql, qs = c.qs, myd2 = c.myd2, rnb = c.rnb;
   if (lane < 8) zcol[lane] = D;
@@ -929,12 +954,12 @@ static __device__ __noinline__ void tp_filter_pass(const TpCtx& c, int s, int e,
     *(CI_LDS ci_f4v*)(Prow + NR) = ci_f4v{0.f, 0.f, 0.f, 0.f};
   }
   tp_lds_sync();
-  float* kfw = c.kf + (size_t)s * D + lane;
+  TpG kfw = c.kf + (size_t)s * D + lane;
   for (int t4 = s; t4 < e; t4 += 4) {
-    const float4 yt4 = *reinterpret_cast<const float4*>(c.ytil + t4);
-    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(c.cbv + t4);
-    const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(c.msk + t4);
-    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    const ci_f4v yt4 = *tp_p4(c.ytil + t4);
+    const uint32_t cb4 = *tp_pu(c.cbv + t4);
+    const uint32_t mk4 = *tp_pu(c.msk + t4);
+    const uint32_t cw4 = *tp_pu(cidb + t4);
     float vfq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1014,20 +1039,21 @@ static __device__ __noinline__ void tp_filter_pass(const TpCtx& c, int s, int e,
       if (mych && c.pos == 0) zcol[c.blk] = c.boff + ((mycur + 1 == c.nb) ? 0 : mycur + 1);
       tp_lds_sync();
     }
-    if (lane == 0) *reinterpret_cast<float4*>(c.vf + t4) = make_float4(vfq[0], vfq[1], vfq[2], vfq[3]);
+    if (lane == 0) *tp_p4w(c.vf + t4) = ci_f4v{vfq[0], vfq[1], vfq[2], vfq[3]};
   }
 }
 
 // Backward recursion over the chunk from r at its end; STORE: rs[t] = r_{t-1}.  Returns r_{s-1}.
 template <bool STORE>
-__device__ __forceinline__ float tp_backward_pass(const TpCtx& c, int s, int e, float r) {
+static __device__ __noinline__ float tp_backward_pass(const TpCtx& cref, int s, int e, float r) {
+  const TpCtx c = cref;
   const int lane = c.lane, D = c.D, T = c.T;
   const bool comp = lane < D;
-  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * c.TP;
+  TpGBC cidb = c.cidx + (size_t)c.blk0 * c.TP;
   for (int t4 = ((e - 1) & ~3); t4 >= s; t4 -= 4) {
-    const float4 vf4 = *reinterpret_cast<const float4*>(c.vf + t4);
-    const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(c.msk + t4);
-    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    const ci_f4v vf4 = *tp_p4(c.vf + t4);
+    const uint32_t mk4 = *tp_pu(c.msk + t4);
+    const uint32_t cw4 = *tp_pu(cidb + t4);
     float kfq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) kfq[q] = (comp && t4 + q < e) ? c.kf[(size_t)(t4 + q) * D + lane] : 0.f;
@@ -1057,7 +1083,7 @@ __device__ __forceinline__ float tp_backward_pass(const TpCtx& c, int s, int e, 
 // g . r of this lane's block for the shock of the change at step t - 1 (g = e_{slot observed at
 // t-1} - 1/n), from a lane-distributed r: every lane of the block gets the value.
 __device__ __forceinline__ float tp_shock_dot(const TpCtx& c, float r, int cprev) {
-  float* vb = c.vb;
+  TpL vb = c.vb;
   tp_lds_sync();
   if (c.lane < c.D) vb[c.lane] = r;
   tp_lds_sync();
@@ -1076,25 +1102,26 @@ __device__ __forceinline__ float tp_shock_dot(const TpCtx& c, float r, int cprev
 //   [0] ss_level [1] ss_slope [2+k] ss_drift_k | [10] first level [11] first slope [12+k] first
 //   x~[slot observed at s] | [20] last level [21] last slope [22+k] last x~[slot observed at e]
 //   (statistics of the step from e - 1 to e are the next chunk's boundary: formed by the reader).
-__device__ __forceinline__ void tp_recon_pass(const TpCtx& c, int s, int e, float xh, float xp, float r_end,
-                                              float* stat) {
+static __device__ __noinline__ void tp_recon_pass(const TpCtx& cref, int s, int e, float xh, float xp, float r_end,
+                                                 TpG stat) {
+  const TpCtx c = cref;
   const int lane = c.lane, D = c.D, T = c.T, TP = c.TP;
   const bool comp = lane < D;
-  const float* zkb = c.zk + (size_t)c.blk0 * TP;
-  const float* gdb = c.gd + (size_t)c.blk0 * TP;
-  const uint8_t* cidb = c.cidx + (size_t)c.blk0 * TP;
+  TpGC zkb = c.zk + (size_t)c.blk0 * TP;
+  TpGC gdb = c.gd + (size_t)c.blk0 * TP;
+  TpGBC cidb = c.cidx + (size_t)c.blk0 * TP;
   // g . r_{e-1} for the step that crosses the chunk's end
   float gd_end = 0.f;
   if (e < T) gd_end = tp_shock_dot(c, r_end, (int)cidb[e - 1]);
   float prev = 0.f, ssl = 0.f, sss = 0.f, ssd = 0.f;
   bool ch_prev = false;
   for (int t4 = s; t4 < e; t4 += 4) {
-    const float4 zl4 = *reinterpret_cast<const float4*>(c.zl + t4);
-    const float4 zk4 = *reinterpret_cast<const float4*>(zkb + t4);
-    float4 zs4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c.has_slope) zs4 = *reinterpret_cast<const float4*>(c.zs + t4);
-    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(c.cbv + t4);
-    const uint32_t cw4 = *reinterpret_cast<const uint32_t*>(cidb + t4);
+    const ci_f4v zl4 = *tp_p4(c.zl + t4);
+    const ci_f4v zk4 = *tp_p4(zkb + t4);
+    ci_f4v zs4 = ci_f4v{0.f, 0.f, 0.f, 0.f};
+    if (c.has_slope) zs4 = *tp_p4(c.zs + t4);
+    const uint32_t cb4 = *tp_pu(c.cbv + t4);
+    const uint32_t cw4 = *tp_pu(cidb + t4);
     float rnq[4], gdq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1150,8 +1177,8 @@ __device__ __forceinline__ void tp_recon_pass(const TpCtx& c, int s, int e, floa
         ch_prev = mych;
       }
     }
-    if (lane == 0) *reinterpret_cast<float4*>(c.lev + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
-    if (c.has_slope && lane == 1) *reinterpret_cast<float4*>(c.slp + t4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    if (lane == 0) *tp_p4w(c.lev + t4) = ci_f4v{xo[0], xo[1], xo[2], xo[3]};
+    if (c.has_slope && lane == 1) *tp_p4w(c.slp + t4) = ci_f4v{xo[0], xo[1], xo[2], xo[3]};
   }
   // last record: level, slope, and -- for the blocks that change between e - 1 and e -- the slot
   // observed at e (whose entry of x~_{e-1} the next chunk's first step is compared with)
@@ -1392,22 +1419,22 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
 
   // ---- pointers
   cx.T = T; cx.TP = TP; cx.D = D; cx.DS = NR + 4; cx.K = K; cx.lane = lane; cx.has_slope = a.has_slope;
-  cx.yv = (float*)(wsc + L.yv); cx.lev = (float*)(wsc + L.lev); cx.slp = (float*)(wsc + L.slp);
-  cx.xw = (float*)(wsc + L.xw); cx.ytil = (float*)(wsc + L.ytil); cx.vf = (float*)(wsc + L.vf);
-  cx.zl = (float*)(wsc + L.zl); cx.zs = (float*)(wsc + L.zs); cx.zo = (float*)(wsc + L.zo);
-  cx.seas = (float*)(wsc + L.seas); cx.zk = (float*)(wsc + L.zk); cx.gd = (float*)(wsc + L.gd);
-  cx.kf = (float*)(wsc + L.kf); cx.rs = (float*)(wsc + L.rs);
-  cx.msk = wsc + L.mask; cx.cbv = wsc + L.cbits; cx.cidx = wsc + L.cidx;
+  cx.yv = (TpG)(wsc + L.yv); cx.lev = (TpG)(wsc + L.lev); cx.slp = (TpG)(wsc + L.slp);
+  cx.xw = (TpG)(wsc + L.xw); cx.ytil = (TpG)(wsc + L.ytil); cx.vf = (TpG)(wsc + L.vf);
+  cx.zl = (TpG)(wsc + L.zl); cx.zs = (TpG)(wsc + L.zs); cx.zo = (TpG)(wsc + L.zo);
+  cx.seas = (TpG)(wsc + L.seas); cx.zk = (TpG)(wsc + L.zk); cx.gd = (TpG)(wsc + L.gd);
+  cx.kf = (TpG)(wsc + L.kf); cx.rs = (TpG)(wsc + L.rs);
+  cx.msk = (TpGB)(wsc + L.mask); cx.cbv = (TpGB)(wsc + L.cbits); cx.cidx = (TpGB)(wsc + L.cidx);
   {
     unsigned char* wl = smem + LL.wave0 + (size_t)wave * LL.wave_stride;
-    cx.cm = (float*)(wl + LL.cm); cx.am = (float*)(wl + LL.am); cx.scr = (float*)(wl + LL.scr);
-    cx.pzv = (float*)(wl + LL.pzv); cx.vb = (float*)(wl + LL.vb);
+    cx.cm = (TpL)(wl + LL.cm); cx.am = (TpL)(wl + LL.am); cx.scr = (TpL)(wl + LL.scr);
+    cx.pzv = (TpL)(wl + LL.pzv); cx.vb = (TpL)(wl + LL.vb);
   }
-  float* e0 = (float*)(wsc + L.e0); float* ei = (float*)(wsc + L.ei); float* et = (float*)(wsc + L.et);
-  float* stt = (float*)(wsc + L.st);
-  float* bm = (float*)(wsc + L.bm); float* bi = (float*)(wsc + L.bi); float* bt = (float*)(wsc + L.bt);
-  float* xsum = (float*)(wsc + L.xsum); float* statv = (float*)(wsc + L.stat);
-  float* cpart = (float*)(wsc + L.cpart); float* cw = (float*)(wsc + L.cw);
+  TpG e0 = (TpG)(wsc + L.e0); TpG ei = (TpG)(wsc + L.ei); TpG et = (TpG)(wsc + L.et);
+  TpG stt = (TpG)(wsc + L.st);
+  TpG bm = (TpG)(wsc + L.bm); TpG bi = (TpG)(wsc + L.bi); TpG bt = (TpG)(wsc + L.bt);
+  TpG xsum = (TpG)(wsc + L.xsum); TpG statv = (TpG)(wsc + L.stat);
+  TpG cpart = (TpG)(wsc + L.cpart); TpG cw = (TpG)(wsc + L.cw);
   const size_t ESZ = tp_esz(NR), BSZ = tp_bsz(NR), SSZ = (size_t)NR * (NR + 4);
   const int PR = (P + 4) & ~3;                       // floats of one chunk's X~'targets partials (+ y'y)
   const int CWS = (P + 3) & ~3;                      // cw: weights, then the scalars
@@ -1426,8 +1453,8 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
   const DevSeasonalParams ss = a.ssp[series];
   const Rng rng{stream_key0(g.seed0, g.series_stream_base, series), stream_key1(g.seed1, g.series_stream_base, series),
                 (uint32_t)(g.chain_offset + chain)};
-  const float* Xg = g.Xt + (size_t)series * P * T;
-  const float* chol1 = a.p1_chol + (size_t)series * a.dred * a.dred;
+  TpGC Xg = (TpGC)(g.Xt + (size_t)series * P * T);
+  TpGC chol1 = (TpGC)(a.p1_chol + (size_t)series * a.dred * a.dred);
 
   // ---- lane roles
   int blk = -1, pos = 0, nb = 1, boff = 0, rbase = 0;
@@ -1580,13 +1607,13 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
 #pragma unroll
       for (int k = 0; k < SMAXK; ++k) ssdk[k] = 0.f;
       for (int c = lane; c < N; c += 64) {
-        const float* sc = statv + (size_t)c * TP_STAT;
+        TpGC sc = statv + (size_t)c * TP_STAT;
         if (chunk_s(c) >= T) continue;
         ssl += sc[0]; sss += sc[1];
 #pragma unroll
         for (int k = 0; k < SMAXK; ++k) if (k < K) ssdk[k] += sc[2 + k];
         if (c > 0) {
-          const float* sp_ = statv + (size_t)(c - 1) * TP_STAT;
+          TpGC sp_ = statv + (size_t)(c - 1) * TP_STAT;
           float dl = sc[10] - sp_[20];
           if (a.has_slope) { dl -= sp_[21]; const float ds = sc[11] - sp_[21]; sss = fmaf(ds, ds, sss); }
           ssl = fmaf(dl, dl, ssl);
@@ -1725,18 +1752,18 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       for (int q4 = ((c * Lc) >> 2) + lane; q4 < (((c + 1) * Lc) >> 2); q4 += 64) {
         float z4[4];
         normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_LEVEL, 0, (uint32_t)q4), z4);
-        *reinterpret_cast<float4*>(cx.zl + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        *tp_p4w(cx.zl + 4 * q4) = ci_f4v{z4[0], z4[1], z4[2], z4[3]};
         normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_OBS, 0, (uint32_t)q4), z4);
-        *reinterpret_cast<float4*>(cx.zo + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        *tp_p4w(cx.zo + 4 * q4) = ci_f4v{z4[0], z4[1], z4[2], z4[3]};
         if (a.has_slope) {
           normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SLOPE, 0, (uint32_t)q4), z4);
-          *reinterpret_cast<float4*>(cx.zs + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+          *tp_p4w(cx.zs + 4 * q4) = ci_f4v{z4[0], z4[1], z4[2], z4[3]};
         }
 #pragma unroll
         for (int k = 0; k < SMAXK; ++k)
           if (k < K) {
             normals4(site_call(rng, (uint32_t)it, SITE_PRIOR_SEAS, (uint32_t)k, (uint32_t)q4), z4);
-            *reinterpret_cast<float4*>(cx.zk + (size_t)k * TP + 4 * q4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+            *tp_p4w(cx.zk + (size_t)k * TP + 4 * q4) = ci_f4v{z4[0], z4[1], z4[2], z4[3]};
           }
       }
     }
@@ -1760,7 +1787,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
         for (int j = 0; j <= lane; ++j) x0 = fmaf(chol1[lane * a.dred + j], cx.vb[j], x0);
       if (lane < NR) cx.vb[NR + lane] = x0;
       tp_lds_sync();
-      const float* x0r = cx.vb + NR;
+      TpLC x0r = cx.vb + NR;
       if (lane == 0) a1e = (float)sp.init_level_loc + x0r[0];
       if (a.has_slope && lane == 1) a1e = x0r[1];
       if (blk >= 0) {
@@ -1801,7 +1828,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       if (c == 0) {
         const TRow<NR> p0 = tp_prior_row<NR>(cx, p1l, p1s, p1e);
         trow_store<NR>(stt, NR + 4, lane, p0);
-        if (lane < NR) *reinterpret_cast<float4*>(stt + (size_t)lane * (NR + 4) + NR) = make_float4(comp ? a1e : 0.f, 0.f, 0.f, 0.f);
+        if (lane < NR) *tp_p4w(stt + (size_t)lane * (NR + 4) + NR) = ci_f4v{comp ? a1e : 0.f, 0.f, 0.f, 0.f};
       }
     }
     prof.tick(24);
@@ -1809,8 +1836,8 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
     for (int l = 0; l < LVI; ++l) {
       for (int v = v0; v < v1; ++v) {
         const int c = v * TP_NWV + wave;
-        const float* src = l == 0 ? e0 : ei + (size_t)(l - 1) * N * ESZ;
-        float* dst = ei + (size_t)l * N * ESZ + (size_t)c * ESZ;
+        TpGC src = l == 0 ? e0 : ei + (size_t)(l - 1) * N * ESZ;
+        TpG dst = ei + (size_t)l * N * ESZ + (size_t)c * ESZ;
         if (wave >= (1 << l)) tp_combine<NR, false>(src + (size_t)(c - (1 << l)) * ESZ, src + (size_t)c * ESZ, dst, cx.scr, cx.vb, cx.pzv, D, lane);
         else tp_elem_copy<NR>(dst, src + (size_t)c * ESZ, lane);
         if (l == LVI - 1 && wave == TP_NWV - 1) {       // the workgroup's total
@@ -1820,22 +1847,25 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       }
       tp_wg_barrier();
     }
-    const float* eincl = ei + (size_t)(LVI - 1) * N * ESZ;
+    prof.tick(29);
+    TpGC eincl = ei + (size_t)(LVI - 1) * N * ESZ;
     if (G > 1) tp_cluster_barrier(sy, tid);                                 // (D)
+    prof.tick(30);
     for (int m = 0; m < LVG; ++m) {
       for (int v = v0; v < v1; ++v) {
         if (wave != (v & (TP_NWV - 1))) continue;
-        const float* src = et + (size_t)m * G * ESZ;
-        float* dst = et + (size_t)(m + 1) * G * ESZ + (size_t)v * ESZ;
+        TpGC src = et + (size_t)m * G * ESZ;
+        TpG dst = et + (size_t)(m + 1) * G * ESZ + (size_t)v * ESZ;
         if (v >= (1 << m)) tp_combine<NR, false>(src + (size_t)(v - (1 << m)) * ESZ, src + (size_t)v * ESZ, dst, cx.scr, cx.vb, cx.pzv, D, lane);
         else tp_elem_copy<NR>(dst, src + (size_t)v * ESZ, lane);
       }
       tp_cluster_barrier(sy, tid);
     }
-    const float* etot = et + (size_t)LVG * G * ESZ;
+    TpGC etot = et + (size_t)LVG * G * ESZ;
+    prof.tick(31);
     for (int v = v0; v < v1; ++v) {
       const int c = v * TP_NWV + wave;
-      float* dst = stt + (size_t)c * SSZ;
+      TpG dst = stt + (size_t)c * SSZ;
       if (c == 0) continue;
       if (wave == 0) tp_state_from_elem<NR>(etot + (size_t)(v - 1) * ESZ, dst, lane);
       else if (v == 0) tp_state_from_elem<NR>(eincl + (size_t)(c - 1) * ESZ, dst, lane);
@@ -1846,7 +1876,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
     // ---- (6) the filter replayed from the true moments; backward maps and their suffix scan
     for (int v = v0; v < v1; ++v) {
       const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
-      const float* st = stt + (size_t)c * SSZ;
+      TpGC st = stt + (size_t)c * SSZ;
       float cvec = 0.f;
       if (s < T) {
         tp_filter_pass<NCH>(cx, s, e, st);
@@ -1867,17 +1897,17 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
 #pragma unroll
         for (int u = 0; u < NR / 2; ++u) M.v[u] = ((lane & 31) < D && (lane >> 5) * (NR / 2) + u == (lane & 31)) ? 1.f : 0.f;
       }
-      float* bo = bm + (size_t)c * BSZ;
+      TpG bo = bm + (size_t)c * BSZ;
       hstore<NR>(bo, NR + 4, lane, M);
-      if (lane < NR) *reinterpret_cast<float4*>(bo + (size_t)lane * (NR + 4) + NR) = make_float4(comp ? cvec : 0.f, 0.f, 0.f, 0.f);
+      if (lane < NR) *tp_p4w(bo + (size_t)lane * (NR + 4) + NR) = ci_f4v{comp ? cvec : 0.f, 0.f, 0.f, 0.f};
     }
     prof.tick(26);
     tp_wg_barrier();
     for (int l = 0; l < LVI; ++l) {
       for (int v = v0; v < v1; ++v) {
         const int c = v * TP_NWV + wave;
-        const float* src = l == 0 ? bm : bi + (size_t)(l - 1) * N * BSZ;
-        float* dst = bi + (size_t)l * N * BSZ + (size_t)c * BSZ;
+        TpGC src = l == 0 ? bm : bi + (size_t)(l - 1) * N * BSZ;
+        TpG dst = bi + (size_t)l * N * BSZ + (size_t)c * BSZ;
         if (wave + (1 << l) < TP_NWV) tp_bcompose<NR>(src + (size_t)c * BSZ, src + (size_t)(c + (1 << l)) * BSZ, dst, cx.scr, cx.vb, D, lane);
         else tp_bcopy<NR>(dst, src + (size_t)c * BSZ, lane);
         if (l == LVI - 1 && wave == 0) {
@@ -1887,7 +1917,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       }
       tp_wg_barrier();
     }
-    const float* bincl = bi + (size_t)(LVI - 1) * N * BSZ;
+    TpGC bincl = bi + (size_t)(LVI - 1) * N * BSZ;
     if (G > 1) tp_cluster_barrier(sy, tid);                                 // (E)
     // (r at the end of a workgroup's last chunk needs the LATER workgroups' total maps applied to
     // zero: a chain of at most G - 1 matrix-vector products, formed by every wavefront for itself --
@@ -1899,7 +1929,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       if (s >= T) continue;
       float r_in = 0.f;                                   // r at the end of this workgroup's last chunk
       for (int vv = G - 1; vv > v; --vv) {
-        const float* tm = bt + (size_t)vv * BSZ;
+        TpGC tm = bt + (size_t)vv * BSZ;
         if ((size_t)vv * TP_NWV * Lc >= (size_t)T) continue;              // (empty workgroup: identity)
         const TRow<NR> Mv = trow_load<NR>(tm, NR + 4, lane);
         const float cv_ = lane < NR ? tm[(size_t)lane * (NR + 4) + NR] : 0.f;
@@ -1907,7 +1937,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       }
       float r_end = r_in;
       if (wave + 1 < TP_NWV) {
-        const float* nx = bincl + (size_t)(c + 1) * BSZ;
+        TpGC nx = bincl + (size_t)(c + 1) * BSZ;
         const TRow<NR> Mn = trow_load<NR>(nx, NR + 4, lane);
         const float cn = lane < NR ? nx[(size_t)lane * (NR + 4) + NR] : 0.f;
         r_end = cn + tdot<NR>(Mn, cx.vb, r_in, lane);
@@ -1921,7 +1951,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
         if (k < K) {
           const float rn = 1.0f / (float)cx.nsz[k];
           for (int t = s + lane; t < e; t += 64) {
-            const float* rr = cx.rs + (size_t)t * D + cx.off[k];
+            TpGC rr = cx.rs + (size_t)t * D + cx.off[k];
             float sb = 0.f;
             for (int q = 0; q < cx.nsz[k]; ++q) sb += rr[q];
             const int cprev = t > 0 ? (int)cx.cidx[(size_t)k * TP + t - 1] : 0;
@@ -1930,7 +1960,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
         }
       tp_wg_barrier_wave();
       // x^ at the chunk's start = a + P r_{s-1}
-      const float* st = stt + (size_t)c * SSZ;
+      TpGC st = stt + (size_t)c * SSZ;
       const TRow<NR> Ps = trow_load<NR>(st, NR + 4, lane);
       const float as = lane < NR ? st[(size_t)lane * (NR + 4) + NR] : 0.f;
       const float rs0 = comp ? cx.rs[(size_t)s * D + lane] : 0.f;

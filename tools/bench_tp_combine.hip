@@ -14,10 +14,10 @@ template <int NR>
 __global__ __launch_bounds__(512) void bench(float* ws, long long* out, int D, int reps, int active) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* base = (float*)(smem + (size_t)wave * 16384);
-  float* scr = base; float* vb = base + NR * NR; float* piv = vb + 2 * NR;
+  ci::TpL base = (ci::TpL)(smem + (size_t)wave * 16384);
+  ci::TpL scr = base; ci::TpL vb = base + NR * NR; ci::TpL piv = vb + 2 * NR;
   const size_t ESZ = ci::tp_esz(NR), BSZ = ci::tp_bsz(NR);
-  float* e1 = ws + (size_t)wave * 4 * ESZ; float* e2 = e1 + ESZ; float* eo = e2 + ESZ; float* so = eo + ESZ;
+  ci::TpG e1 = (ci::TpG)ws + (size_t)wave * 4 * ESZ; ci::TpG e2 = e1 + ESZ; ci::TpG eo = e2 + ESZ; ci::TpG so = eo + ESZ;
   if (wave >= active) return;
   for (int r = 0; r < reps; ++r) {
     const long long t0 = clock64();

@@ -38,7 +38,8 @@ def run(T, p, slope, seasons, flags, S=3, W=0, C=1, oracle=True, label="", prof=
     sess.profile(True)
     sess.run()
     cyc = sess.profile(False)
-    names = ["targets", "serial+wait", "emit+normals", "sim", "build", "fwd scan", "filter+M", "bwd scan", "r+recon"]
+    names = ["targets", "serial+wait", "emit+normals", "sim", "build", "fwd final", "filter+M", "bwd scan", "r+recon",
+             "fwd intra", "fwd barrier", "fwd cluster"]
     line += "\n      cycles/iter: " + "  ".join(f"{n}: {cyc[20 + i] / (W + S):.0f}" for i, n in enumerate(names))
   sess.close()
   if oracle:

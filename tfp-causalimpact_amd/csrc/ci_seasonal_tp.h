@@ -99,6 +99,7 @@ __host__ __device__ inline TpLayout make_tplayout(int T, int P, int K, int D, in
 // regression block's buffers of wavefront 0; a few floats shared by the workgroup.
 struct TpLds {
   size_t wave0, wave_stride, cm, am, scr, pzv, vb, reg, shared, total;
+  size_t big_a, big_p;   // P > MAXP: the swept matrices of the regression block in LDS (0: HBM workspace)
   // regression block (offsets from `reg`)
   size_t xtx, omega, bvec, aug0, pri0, chol, zv, uperm, nz, perm, idx, w;
 };
@@ -128,13 +129,29 @@ __host__ __device__ inline TpLds make_tplds(int P, int D) {
   l.nz = take(big ? sizeof(int) * Pp : 16);
   l.perm = take(big ? sizeof(int) * Pp : 16);
   l.idx = take(big ? sizeof(int) * Pp : 16);
-  const size_t reg_bytes = o;
+  // P > MAXP (spike_slab_draw_big's workspace block): one CU pulls ~20 B/clk out of L2, i.e. a sweep
+  // of a 100 x 100 float64 matrix costs 8k cycles there; in LDS it is bandwidth for free.  The
+  // augmented matrix A ((P+1)^2 doubles, rebuilt every iteration: overlay) goes to LDS when it
+  // fits next to the rest, the swept prior block Pm (P^2 doubles, CARRIED between iterations:
+  // outside the overlay) when both fit.
+  l.big_a = 0; l.big_p = 0;
+  const size_t a_bytes = sizeof(double) * (size_t)(Pp + 1) * (Pp + 1), p_bytes = sizeof(double) * (size_t)Pp * Pp;
   const size_t waves = (size_t)TP_NWV * l.wave_stride;
+  const size_t fixed = sizeof(float) * (Pp > 16 ? Pp : 16) + 16 + sizeof(float) * 64 + 256;
+  bool a_lds = false, p_lds = false;
+  if (bigp) {
+    const size_t with_a = (o + a_bytes > waves ? o + a_bytes : waves) + fixed;
+    a_lds = with_a <= 156 * 1024;
+    p_lds = a_lds && with_a + p_bytes <= 156 * 1024;
+  }
+  if (a_lds) l.big_a = take(a_bytes);
+  const size_t reg_bytes = o;
   l.wave0 = 0; l.reg = 0;
   o = waves > reg_bytes ? waves : reg_bytes;
   l.w = take(sizeof(float) * (Pp > 16 ? Pp : 16));      // weights: live across the phases
   // the prior precision swept on the current model is carried from iteration to iteration
   l.pri0 = take(big ? sizeof(double) * sweep_padded((size_t)Pp * Pp) : 16);
+  if (p_lds) l.big_p = take(p_bytes);
   l.shared = take(sizeof(float) * 64);
   l.total = o;
   return l;
@@ -1212,43 +1229,46 @@ static __device__ __noinline__ void tp_recon_pass(const TpCtx& cref, int s, int 
 // one pass here: the pivot row and column are written in the same pass as the general entries).
 // Every thread returns the same new observation-noise scale.
 // ------------------------------------------------------------------------------------
-template <int NTH>
-__device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, float* w, int P,
+template <int NTH, class PA, class PP>
+__device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, PP Pm, float* w, int P,
                                                          const DevSeriesParams& sp, double prev_obs_scale,
                                                          double g_obs, const Rng& rng, uint32_t iter,
                                                          int tid, bool first) {
-  const int lane = tid & 63;
+  const int lane = tid & 63, wv = tid >> 6;
+  constexpr int NWV_ = NTH / 64;
   const int n = P + 1;
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
-  double* A = R.aug[0];
-  double* Pm = R.pri[0];
   double* ta = R.chol + (size_t)P * P;      // saved pivot row of A   [n]
   double* tp = ta + n;                      // saved pivot row of Pm  [n]
-  for (int e = tid; e < n * n; e += NTH) {
-    const int i = e / n, j = e - i * n;
-    double v;
-    if (i < P && j < P) v = R.omega[i * P + j] * prev_var + R.xtx[i * P + j];
-    else v = R.bvec[(i == P && j == P) ? P : (i < j ? i : j)];
-    A[e] = v;
-  }
+  // (every loop over a matrix walks rows by wavefront and columns by lane: no integer division)
+  for (int i = wv; i < n; i += NWV_)
+    for (int j = lane; j < n; j += 64) {
+      double v;
+      if (i < P && j < P) v = R.omega[i * P + j] * prev_var + R.xtx[i * P + j];
+      else v = R.bvec[(i == P && j == P) ? P : (i < j ? i : j)];
+      A[i * n + j] = v;
+    }
   if (first)
-    for (int e = tid; e < P * P; e += NTH) Pm[e] = R.omega[e];
+    for (int i = wv; i < P; i += NWV_)
+      for (int j = lane; j < P; j += 64) Pm[i * P + j] = R.omega[i * P + j];
   for (int j = tid; j < P; j += NTH) {
     R.nz[j] = all_in ? 1 : (w[j] != 0.f ? 1 : 0);
     if (!all_in) R.uperm[j] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j);
   }
   tp_wg_barrier();
-  auto sweep_one_wg = [&](double* M, int m, const double* t, int k, double sgn) {
+  auto sweep_one_wg = [&](auto M, int m, const double* t, int k, double sgn) {
     const double rd = 1.0 / t[k];
-    for (int e = tid; e < m * m; e += NTH) {
-      const int i = e / m, j = e - i * m;
-      double v;
-      if (i == k) v = (j == k) ? -rd : sgn * t[j] * rd;
-      else if (j == k) v = sgn * t[i] * rd;
-      else v = M[e] - (t[i] * rd) * t[j];
-      M[e] = v;
+    for (int i = wv; i < m; i += NWV_) {
+      const double ti = t[i];
+      for (int j = lane; j < m; j += 64) {
+        double v;
+        if (i == k) v = (j == k) ? -rd : sgn * t[j] * rd;
+        else if (j == k) v = sgn * ti * rd;
+        else v = M[i * m + j] - (ti * rd) * t[j];
+        M[i * m + j] = v;
+      }
     }
   };
   auto sweep_both = [&](int k, bool reverse, bool with_prior) {
@@ -1327,11 +1347,11 @@ __device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, float*
   }
   for (int j = tid; j < P; j += NTH) w[j] = 0.f;
   tp_wg_barrier();
-  for (int e = tid; e < na * na; e += NTH) {
-    const int i = e / na, j = e - i * na;
-    const int fi = R.idx[i], fj = R.idx[j];
-    R.chol[e] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
-  }
+  for (int i = wv; i < na; i += NWV_)
+    for (int j = lane; j < na; j += 64) {
+      const int fi = R.idx[i], fj = R.idx[j];
+      R.chol[i * na + j] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
+    }
   for (int i = tid; i < na; i += NTH) R.zv[i] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[i]);
   tp_wg_barrier();
   for (int k = 0; k < na; ++k) {
@@ -1339,10 +1359,9 @@ __device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, float*
     tp_wg_barrier();
     for (int i = k + tid; i < na; i += NTH) R.chol[i * na + k] = (i == k) ? dkk : R.chol[i * na + k] / dkk;
     tp_wg_barrier();
-    const int rem = na - k - 1;
-    for (int e = tid; e < rem * rem; e += NTH) {
-      const int i = k + 1 + e / rem, j = k + 1 + (e - (e / rem) * rem);
-      if (j <= i) R.chol[i * na + j] -= R.chol[i * na + k] * R.chol[j * na + k];
+    for (int i = k + 1 + wv; i < na; i += NWV_) {
+      const double lik = R.chol[i * na + k];
+      for (int j = k + 1 + lane; j <= i; j += 64) R.chol[i * na + j] -= lik * R.chol[j * na + k];
     }
     tp_wg_barrier();
   }
@@ -1677,7 +1696,18 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
     }
     if (is_main && bigp && it < n_iter) {
       tp_wg_barrier();
-      const double ns = tp_spike_slab_draw_big_wg<TP_NT>(R, R.w, P, sp, shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
+      typedef CI_LDS double* LD;
+      typedef CI_GLB double* GD;
+      double ns;
+      if (LL.big_a && LL.big_p)
+        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, (LD)(smem + LL.reg + LL.big_a), (LD)(smem + LL.big_p), R.w, P, sp,
+                                              shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
+      else if (LL.big_a)
+        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, (LD)(smem + LL.reg + LL.big_a), (GD)R.pri[0], R.w, P, sp,
+                                              shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
+      else
+        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, (GD)R.aug[0], (GD)R.pri[0], R.w, P, sp,
+                                              shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
       if (wave == 0) obs_scale = ns;
     }
     if (is_main && wave == 0) {

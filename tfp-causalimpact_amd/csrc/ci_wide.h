@@ -772,7 +772,15 @@ __device__ __forceinline__ void cl_publish(int* flag, int value, int tid, bool l
   if (light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   else __threadfence();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // (round 5) light: a RELAXED store -- the data is in the shared L2 once s_waitcnt vmcnt(0), the
+  // workgroup-scope release above, has returned; a RELEASE at agent scope adds an L2 write-back
+  // ("agent" spans the XCDs, each with its own L2).  Measured on cfg4: same kernel time and the same
+  // WRITE_SIZE (1.9 GB per launch either way: the counter sees every write that leaves the L2 for
+  // the fabric, and this part's L2 forwards the chains' workspace writes whatever the scope).
+  if (tid == 0) {
+    if (light) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 // waits until flags[0..n) have all reached `value`
 __device__ __forceinline__ void cl_wait(int* flags, int n, int value, int tid) {

@@ -5,8 +5,14 @@ writes one JSON line per config (committed as profiles/r01_configs.json):
         and all 512 on one GPU)
 Throughput = retained draws / Gibbs-kernel time (HIP events), inputs resident in HBM, plus the
 end-to-end time of the batched API for cfg5."""
+import csv
+import glob
 import json
+import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -17,25 +23,143 @@ import causalimpact as ci
 from causalimpact import _model, _native
 from causalimpact import _synthetic as syn
 
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
+REF_SEASONS = (ci.Seasons(num_seasons=4, num_steps_per_season=(2, 1, 1, 1)), ci.Seasons(num_seasons=7),
+               ci.Seasons(num_seasons=6, num_steps_per_season=((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))
 
-def cfg4(chains, S=1000):
-  T, p = 10000, 50
-  y, mask, X, _ = syn.make_sampler_inputs(T, p, 0)
+
+def cpu_baseline(y, mask, X, spec, iters, what):
+  """The float64 oracle (oracle/ci_oracle.c, `make native`: -O3 -march=native -fopenmp, built on this
+  host) on `iters` Gibbs iterations of the same series: one core, and one chain per core on all
+  cores.  Test infrastructure used as the reported CPU figure ("port"), never as the product."""
+  from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
+  _, flags = orc.native_lib()
+  kw = dict(num_results=iters, num_warmup=0, seed=(0, 1))
+  orc.fit_gibbs_chains_native(y, mask, X, spec, first_chain=0, n_chains=1, threads=1,
+                              num_results=2, num_warmup=0, seed=(0, 1))
+  t0 = time.perf_counter()
+  orc.fit_gibbs_chains_native(y, mask, X, spec, first_chain=0, n_chains=1, threads=1, **kw)
+  dt1 = time.perf_counter() - t0
+  ncpu = os.cpu_count() or 1
+  t0 = time.perf_counter()
+  used = orc.fit_gibbs_chains_native(y, mask, X, spec, first_chain=100, n_chains=ncpu, threads=ncpu, **kw)
+  dtn = time.perf_counter() - t0
+  return {"kind": "port", "unit": "posterior samples/sec", "cores": 1, "value": iters / dt1,
+          "us_per_iteration": dt1 / iters * 1e6,
+          "all_cores": {"cores": used, "value": ncpu * iters / dtn,
+                        "sample": f"{ncpu} chains x {iters} iterations, one chain per thread, {dtn:.1f} s"},
+          "sample": f"1 chain x {iters} Gibbs iterations of {what}, float64 C restatement built here "
+                    f"with `{flags}`, {dt1:.1f} s"}
+
+
+def measured_traffic(which, kernel):
+  """HBM bytes per launch of `kernel`, measured by two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE,
+  each in its own child run of `run_configs.py <which>`; KiB -> bytes; FETCH_SIZE x 2 on gfx950 as the
+  guide prescribes).  (bytes, note) or (None, why)."""
+  prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+  if not os.path.exists(prof):
+    return None, "rocprofv3 not found"
+  tmp = tempfile.mkdtemp(prefix="ci_cfg_pmc_", dir="/tmp")
+  per = {}
+  try:
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+      out = os.path.join(tmp, counter)
+      cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "cfg", "--",
+             sys.executable, os.path.abspath(__file__), which]
+      r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdin=subprocess.DEVNULL,
+                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=False)
+      files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+      if r.returncode != 0 or not files:
+        return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+      tot, ids = 0.0, set()
+      with open(files[0]) as f:
+        for row in csv.DictReader(f):
+          if row.get("Counter_Name") == counter and kernel in row.get("Kernel_Name", ""):
+            tot += float(row["Counter_Value"])
+            ids.add(row["Dispatch_Id"])
+      if not ids:
+        return None, f"no {kernel} dispatch in the {counter} pass"
+      per[counter] = tot / len(ids)
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+  return (2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"
+
+
+def roofline(nbytes, ms, traffic=None, traffic_note=None):
+  ach = nbytes / ms / 1e6
+  r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+       "traffic": traffic}
+  if traffic is not None:
+    r["traffic_over_algorithmic"] = traffic / nbytes
+  if traffic_note:
+    r["traffic_source"] = traffic_note
+  return r
+
+
+def _seasonal_fit(T, p, seasons, chains, S, W, flags=0, data_seed=0):
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, data_seed)
   y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
-  spec = _model.series_params(y, mask, X, num_seasonal_blocks=1)
-  counts, flg = _model.expand_seasons((ci.Seasons(num_seasons=7),), T)
-  W = -(-S // 9)
+  spec = _model.series_params(y, mask, X, num_seasonal_blocks=len(seasons))
+  counts, flg = _model.expand_seasons(seasons, T)
   pb = _native.make_problem(T=T, P=X.shape[1], has_slope=0, num_seasons=counts, num_warmup=W,
-                            num_results=S, num_chains=chains, seed=(0, 1))
-  sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+                            num_results=S, num_chains=chains, seed=(0, 1), flags=flags)
+  sess = _native.Session(pb, y[None], mask[None], X[None], flg if seasons else None, _native.make_params([spec]))
   sess.run()
   ms = min(sess.run() for _ in range(2))
-  nbytes = sess.algorithmic_bytes()
+  nbytes, name = sess.algorithmic_bytes(), sess.kernel_name()
   sess.close()
-  return {"config": "cfg4", "workload": "T=10000, 50 covariates (P=51), LocalLevel + Seasonal(7) + spike-slab",
-          "chains": chains, "num_results": S, "num_warmup": W, "kernel_ms": ms,
-          "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": chains * S / ms * 1e3,
-          "algorithmic_GBps": nbytes / ms / 1e6}
+  return ms, nbytes, name, (y, mask, X, seasons)
+
+
+def _oracle_spec(y, mask, X, seasons):
+  from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
+  return orc.default_spec(y, mask, X, seasons=tuple(
+      (int(s.num_seasons), s.num_steps_per_season) for s in seasons))
+
+
+def cfg4(chains, S=1000, with_cpu=False, with_traffic=False):
+  T, p = 10000, 50
+  W = -(-S // 9)
+  ms, nbytes, name, data = _seasonal_fit(T, p, (ci.Seasons(num_seasons=7),), chains, S, W)
+  row = {"config": "cfg4", "workload": "T=10000, 50 covariates (P=51), LocalLevel + Seasonal(7) + spike-slab",
+         "kernel": name, "chains": chains, "num_results": S, "num_warmup": W, "kernel_ms": ms,
+         "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": chains * S / ms * 1e3,
+         "algorithmic_GBps": nbytes / ms / 1e6}
+  traffic, note = (None, None)
+  if with_traffic:
+    # the counter passes run the S = 200 fit of `run_configs.py cfg4`: scale to this launch's draws
+    t200, note = measured_traffic("cfg4", "gibbs_wide")
+    if t200 is not None:
+      per_iter = t200 / (8 * (200 + 23))                  # bytes per chain-iteration of the 8-chain pass
+      traffic = per_iter * chains * (S + W)
+      note += "; per chain-iteration figure of the 8-chain S=200 pass scaled to this launch"
+  row["roofline"] = roofline(nbytes, ms, traffic, note)
+  if with_cpu:
+    y, mask, X, seasons = data
+    row["cpu_baseline"] = cpu_baseline(y, mask, X, _oracle_spec(y, mask, X, seasons), 200, "the cfg4 series")
+    row["gpu_over_one_core_per_chain"] = row["cpu_baseline"]["us_per_iteration"] / row["us_per_iteration"]
+  return row
+
+
+def general_seasonal(chains=8, S=100):
+  """The reference's own multi-block test model (4 + 7 + 6 seasons, causalimpact_lib_test.py:738-752)
+  at cfg4's size: the time-parallel cluster kernel (csrc/ci_seasonal_tp.h), the sequential
+  one-wavefront kernel it replaces as the default route, and the oracle on the host."""
+  T, p = 10000, 50
+  W = 10
+  out = []
+  for label, flags in (("time-parallel (default)", 0), ("sequential (CI_FLAG_SEQUENTIAL_SEASONAL)", _native.FLAG_SEQUENTIAL_SEASONAL)):
+    ms, nbytes, name, data = _seasonal_fit(T, p, REF_SEASONS, chains, S, W, flags=flags)
+    out.append({"config": "T=10000, 50 covariates + Seasons 4/7/6 (D = 18)", "route": label, "kernel": name,
+                "chains": chains, "num_results": S, "num_warmup": W, "kernel_ms": ms,
+                "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": chains * S / ms * 1e3,
+                "roofline": roofline(nbytes, ms)})
+  y, mask, X, seasons = data
+  cpu = cpu_baseline(y, mask, X, _oracle_spec(y, mask, X, seasons), 60, "this series")
+  for row in out:
+    row["cpu_baseline"] = cpu
+    row["gpu_over_one_core_per_chain"] = cpu["us_per_iteration"] / row["us_per_iteration"]
+  return out
 
 
 def cfg5(B, S=1000):
@@ -88,18 +212,24 @@ def extras():
   out.append({"config": "cfg2 in float64", "kernel": "ci::gibbs64_trend_kernel (eight wavefronts per chain)",
               "chains": C, "wall_s": dt, "kernel_ms": kms, "us_per_iteration": kms / (W + S) * 1e3,
               "samples_per_s": C * S / kms * 1e3})
-  # 100 covariates (regression block in the HBM workspace)
+  # 100 covariates (regression block in the HBM workspace): time-parallel kernel with the
+  # workgroup-wide draw (round 5), the sequential route, and the oracle on the host
   T, p, W, S, C = 1000, 100, 50, 200, 8
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
   spec = _model.series_params(y, mask, X)
-  pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_warmup=W, num_results=S, num_chains=C,
-                            seed=(0, 1))
-  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
-  sess.run()
-  ms = sess.run()
-  out.append({"config": "T=1000, 100 covariates (P=101)", "kernel": sess.kernel_name(), "chains": C,
-              "kernel_ms": ms, "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": C * S / ms * 1e3})
-  sess.close()
+  from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
+  cpu = cpu_baseline(y, mask, X, orc.default_spec(y, mask, X), 1500, "this series")
+  for flags in (0, _native.FLAG_SEQUENTIAL_SEASONAL):
+    pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_warmup=W, num_results=S, num_chains=C,
+                              seed=(0, 1), flags=flags)
+    sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+    sess.run()
+    ms = sess.run()
+    out.append({"config": "T=1000, 100 covariates (P=101)", "kernel": sess.kernel_name(), "chains": C,
+                "kernel_ms": ms, "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": C * S / ms * 1e3,
+                "roofline": roofline(sess.algorithmic_bytes(), ms), "cpu_baseline": cpu,
+                "gpu_over_one_core_per_chain": cpu["us_per_iteration"] / (ms / (W + S) * 1e3)})
+    sess.close()
   # HMC with a weekly block: the time-parallel scans (csrc/ci_wide_score.h) and, forced, the
   # sequential one-wavefront route (csrc/ci_score_seq.h); and a long trend-only series
   for label, T, seasons, slope, flags in (
@@ -132,9 +262,16 @@ if __name__ == "__main__":
     for row in extras():
       print(json.dumps(row), flush=True)
     sys.exit(0)
+  if which == "general":
+    for row in general_seasonal():
+      print(json.dumps(row), flush=True)
+    sys.exit(0)
   if which == "cfg4":        # counter passes: one short cfg4 fit per chain count
     runs = (lambda: cfg4(1, S=200), lambda: cfg4(8, S=200))
   else:
-    runs = (lambda: cfg4(1), lambda: cfg4(8), lambda: cfg5(64), lambda: cfg5(512))
+    runs = (lambda: cfg4(1), lambda: cfg4(8, with_cpu=True, with_traffic=True), lambda: cfg5(64), lambda: cfg5(512))
   for run in runs:
     print(json.dumps(run()), flush=True)
+  if which == "all":
+    for row in general_seasonal():
+      print(json.dumps(row), flush=True)

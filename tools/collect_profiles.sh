@@ -4,7 +4,7 @@
 # rocprofv3 runs from /tmp with TMPDIR=/tmp; PMC counters are collected in their own passes
 # (never together with trace domains).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -43,5 +43,12 @@ timeout 300 python tools/exp_p_scale.py > "$OUT/p_scale.txt" 2>&1
 timeout 300 python tools/exp_t_scale.py > "$OUT/t_scale.txt" 2>&1
 timeout 200 python tools/profile_phases.py 1000 51 1 8 > "$OUT/phase_cycles_p52.txt" 2>&1
 CI_F64_PROF=1 timeout 300 python tools/run_configs.py extras 2>&1 | grep "phases" | tail -1 > "$OUT/f64_phase_cycles.txt"
+# ---- round 5: the time-parallel general seasonal kernel (csrc/ci_seasonal_tp.h)
+timeout 600 python tools/debug_tp.py > "$OUT/tp_debug.txt" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tp_trace" -o tp -- python tools/run_configs.py general_gpu > "$OUT/general_gpu.jsonl" 2> "$OUT/general.err"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/tp_pmc_fetch" -o tp -- python tools/run_configs.py general_gpu > "$OUT/tp_pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/tp_pmc_write" -o tp -- python tools/run_configs.py general_gpu > "$OUT/tp_pmc_write.log" 2>&1
+timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/tp_pmc_sq" -o tp -- python tools/run_configs.py general_gpu > "$OUT/tp_pmc_sq.log" 2>&1
+if [ -x tools/build/bench_tp_combine ]; then timeout 120 tools/build/bench_tp_combine > "$OUT/tp_combine_bench.txt" 2>&1; fi
 find "$OUT" -name "*.csv" | wc -l
 tail -1 "$OUT/bench.json" | cut -c1-400

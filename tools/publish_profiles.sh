@@ -2,7 +2,7 @@
 # Copies the summaries the judge reads from gpurun_out/<tag>/ (tools/collect_profiles.sh) into
 # profiles/ under the round's names:   tools/publish_profiles.sh r03
 set -eu
-TAG=${1:-r04}
+TAG=${1:-r05}
 SRC=gpurun_out/$TAG
 P=profiles
 R=$TAG
@@ -41,4 +41,13 @@ cp $SRC/comm_tests.txt $P/${R}_two_ranks_on_gpu0_host_transport.txt
 for f in p_scale t_scale phase_cycles_p52 f64_phase_cycles; do
   if [ -f $SRC/$f.txt ]; then cp $SRC/$f.txt $P/${R}_$f.txt; fi
 done
+# round 5: the time-parallel general seasonal kernel
+if [ -f $SRC/tp_debug.txt ]; then
+  cp $SRC/tp_debug.txt $P/${R}_tp_parity_and_phase_cycles.txt
+  cp $SRC/tp_trace/tp_kernel_stats.csv $P/${R}_general_seasonal_kernel_stats.csv
+  python tools/pmc_summary.py hbm $SRC/tp_pmc_fetch/tp_counter_collection.csv $SRC/tp_pmc_write/tp_counter_collection.csv \
+    --kernel gibbs_seasonal_tp --out $P/${R}_general_seasonal_pmc.json > /dev/null
+  python tools/pmc_summary.py sq $SRC/tp_pmc_sq/tp_counter_collection.csv --kernel gibbs_seasonal_tp --out $P/${R}_general_seasonal_sq_counters.json > /dev/null
+  if [ -f $SRC/tp_combine_bench.txt ]; then cp $SRC/tp_combine_bench.txt $P/${R}_tp_combine_bench.txt; fi
+fi
 ls -la $P | grep ${R}_ | wc -l

@@ -141,7 +141,7 @@ def cfg4(chains, S=1000, with_cpu=False, with_traffic=False):
   return row
 
 
-def general_seasonal(chains=8, S=100):
+def general_seasonal(chains=8, S=100, with_cpu=True):
   """The reference's own multi-block test model (4 + 7 + 6 seasons, causalimpact_lib_test.py:738-752)
   at cfg4's size: the time-parallel cluster kernel (csrc/ci_seasonal_tp.h), the sequential
   one-wavefront kernel it replaces as the default route, and the oracle on the host."""
@@ -154,6 +154,8 @@ def general_seasonal(chains=8, S=100):
                 "chains": chains, "num_results": S, "num_warmup": W, "kernel_ms": ms,
                 "us_per_iteration": ms / (W + S) * 1e3, "samples_per_s": chains * S / ms * 1e3,
                 "roofline": roofline(nbytes, ms)})
+  if not with_cpu:
+    return out
   y, mask, X, seasons = data
   cpu = cpu_baseline(y, mask, X, _oracle_spec(y, mask, X, seasons), 60, "this series")
   for row in out:
@@ -262,8 +264,8 @@ if __name__ == "__main__":
     for row in extras():
       print(json.dumps(row), flush=True)
     sys.exit(0)
-  if which == "general":
-    for row in general_seasonal():
+  if which in ("general", "general_gpu"):     # (general_gpu: the counter / trace passes, no CPU leg)
+    for row in general_seasonal(with_cpu=which == "general"):
       print(json.dumps(row), flush=True)
     sys.exit(0)
   if which == "cfg4":        # counter passes: one short cfg4 fit per chain count

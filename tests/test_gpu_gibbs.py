@@ -775,23 +775,28 @@ def test_time_parallel_general_seasonal_kernel_with_a_dropped_helper_gives_the_s
     np.testing.assert_array_equal(alone[k], v, err_msg=k)
 
 
-def test_time_parallel_general_seasonal_kernel_on_any_cluster_size_follows_the_oracle():
-  """One workgroup per chain (CI_FLAG_NO_CLUSTER: 8 chunks) and a cluster (8 G chunks) cut the
-  series differently -- other summation orders, other scan trees -- so they agree with each other
-  and with the oracle to float32 accuracy per draw, not bit for bit."""
+def test_time_parallel_general_seasonal_kernel_gives_the_same_bits_on_any_cluster_size():
+  """The chunk grid is fixed by the series (T alone); the launch only decides how many real
+  workgroups share the chunks -- one per chain (CI_FLAG_NO_CLUSTER), a cluster of 32 for a single
+  chain, a cluster of 4 per chain in a launch of 40 chains: the same chunks, the same scan trees,
+  the same arithmetic, hence the same bits for the same (seed, chain) -- and the oracle's draws to
+  float32 accuracy."""
   args = dict(T=2000, p=4, has_slope=0, seasons=REF_SEASONS, W=0, S=3)
   n1, one, (y, mask, X, spec) = _tp_fit(flags=_native.FLAG_NO_CLUSTER, **args)
   n2, many, _ = _tp_fit(flags=0, **args)
+  n3, crowd, _ = _tp_fit(flags=0, C=40, **args)
   assert n1.endswith("x1") and "tp_kernel" in n2 and not n2.endswith("x1")
+  assert "tp_kernel" in n3 and n3.split("x")[-1] != n2.split("x")[-1]        # another cluster size
   w = orc.fit_gibbs(y, mask, X, spec, num_results=3, num_warmup=0, seed=(2, 6))
-  for got in (one, many):
-    np.testing.assert_array_equal(got["weights"][0, 0] != 0, w["weights"] != 0)
-    np.testing.assert_allclose(got["level"][0, 0], w["level"], atol=5e-3)
-    np.testing.assert_allclose(got["seasonal_levels"][0, 0], w["seasonal"], atol=5e-3)
-    np.testing.assert_allclose(got["seasonal_drift_scales"][0, 0], w["drift_scales"], rtol=2e-2)
-    np.testing.assert_allclose(got["observation_noise_scale"][0, 0], w["obs_scale"], rtol=5e-3)
-    np.testing.assert_allclose(got["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
-  np.testing.assert_allclose(one["level"], many["level"], atol=2e-3)
+  np.testing.assert_array_equal(one["weights"][0, 0] != 0, w["weights"] != 0)
+  np.testing.assert_allclose(one["level"][0, 0], w["level"], atol=5e-3)
+  np.testing.assert_allclose(one["seasonal_levels"][0, 0], w["seasonal"], atol=5e-3)
+  np.testing.assert_allclose(one["seasonal_drift_scales"][0, 0], w["drift_scales"], rtol=2e-2)
+  np.testing.assert_allclose(one["observation_noise_scale"][0, 0], w["obs_scale"], rtol=5e-3)
+  np.testing.assert_allclose(one["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
+  for k, v in one.items():
+    np.testing.assert_array_equal(many[k], v, err_msg=k)
+    np.testing.assert_array_equal(crowd[k][:, :1], v, err_msg=k)
 
 
 def test_time_parallel_and_sequential_general_seasonal_kernels_sample_the_same_posterior():

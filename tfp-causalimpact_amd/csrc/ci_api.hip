@@ -728,11 +728,16 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       const long long groups = ((long long)B * C + 7) / 8 * 8;
       const ci::TpLds tl = ci::make_tplds(P, s->D_full);
       if ((long long)B * C <= num_cus && tl.total <= 160 * 1024) {
+        // the chunk grid (G virtual workgroups of TP_NWV chunks) depends on the series alone; the
+        // launch size only decides how many real workgroups (Gc) share them: same bits either way
         int G = 1;
+        while (G < ci::TP_MAXG && T / (2 * G * ci::TP_NWV) >= 16) G *= 2;
+        int Gc = 1;
         if (!(pb->flags & CI_FLAG_NO_CLUSTER))
-          while (G < ci::TP_MAXG && groups * (2 * G) <= num_cus && T / (2 * G * ci::TP_NWV) >= 16) G *= 2;
+          while (Gc < G && groups * (2 * Gc) <= num_cus) Gc *= 2;
         s->tp = true;
-        s->cluster = G;
+        s->cluster = Gc;
+        s->Lc = G;
         s->lds_bytes = tl.total;
         s->tp_ws_bytes = ci::make_tplayout(T, P, K, s->D_full, pb->has_slope, G).total;
         const int nch = (s->D_full + 7) / 8;
@@ -746,7 +751,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     }
     if (!s->wide && !s->tp) s->fn = (KernelFn)ci_gibbs_seasonal_fn((s->seasonal_gws ? 1 : 0) | (bigp ? 2 : 0));
     char nm[96];
-    if (s->tp) snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_tp_kernel<%d> x%d", (s->D_full + 7) / 8, s->cluster);
+    if (s->tp) snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_tp_kernel<%d> %d chunks x%d", (s->D_full + 7) / 8,
+                        s->Lc * ci::TP_NWV, s->cluster);
     else if (s->wide) snprintf(nm, sizeof(nm), "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
     else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel<%s,%s>", s->seasonal_gws ? "true" : "false",
                   bigp ? "true" : "false");

@@ -169,6 +169,23 @@ typedef CI_LDS float* TpL;
 typedef CI_LDS const float* TpLC;
 typedef CI_GLB uint8_t* TpGB;
 typedef CI_GLB const uint8_t* TpGBC;
+// generic -> LDS without the null-check sequence of an address-space cast (its lowering hits a
+// backend verifier error in one instantiation: "V_CMP_NE_U32 0, $src_shared_base"): the LDS offset
+// is the low half of the generic address
+template <class T> __device__ __forceinline__ CI_LDS T* tp_lds(const void* generic) {
+  return (CI_LDS T*)(unsigned)(unsigned long long)generic;
+}
+// A generic pointer into LDS whose origin the optimiser may not look through: InferAddressSpaces
+// otherwise rewrites the regression block's accesses through R.* (generic pointers by interface)
+// as LDS accesses behind flat -> local casts, and in the kernel's larger instantiations the null
+// check of such a cast is lowered to an illegal "V_CMP_NE_U32 0, $src_shared_base".  The
+// performance-relevant LDS traffic of this file uses typed pointers (TpL) and does not depend on
+// the inference.
+template <class T> __device__ __forceinline__ T* tp_opaque(T* p) {
+  unsigned long long v = (unsigned long long)p;
+  asm volatile("" : "+s"(v));
+  return (T*)v;
+}
 __device__ __forceinline__ CI_GLB const ci_f4v* tp_p4(TpGC p) { return (CI_GLB const ci_f4v*)p; }
 __device__ __forceinline__ CI_LDS const ci_f4v* tp_p4(TpLC p) { return (CI_LDS const ci_f4v*)p; }
 __device__ __forceinline__ CI_GLB ci_f4v* tp_p4w(TpG p) { return (CI_GLB ci_f4v*)p; }
@@ -1392,13 +1409,18 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const KArgs& g = a.k;
   const int T = g.T, P = g.P, K = a.K;
-  const int G = a.cluster;
+  // The chunk grid is fixed by the SERIES (G virtual workgroups of TP_NWV chunks: a.Lc carries G,
+  // chosen from T alone); the launch decides how many REAL workgroups (a.cluster = Gc, a power of
+  // two <= G) share them -- workgroup `role` runs the virtual workgroups [role G/Gc, (role+1) G/Gc).
+  // Same chunks, same scan trees, same arithmetic whatever Gc: the draws do not depend on the launch
+  // size (bit for bit), and the fall-back "first workgroup alone" is just Gc = 1.
+  const int G = a.Lc, Gc = a.cluster;
   // workgroup -> (chain, role): the workgroups of one chain share an XCD (ids equal mod 8)
   int chain_id = blockIdx.x, role = 0;
-  if (G > 1) {
+  if (Gc > 1) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    role = slot % G;
-    chain_id = (slot / G) * 8 + xcd;
+    role = slot % Gc;
+    chain_id = (slot / Gc) * 8 + xcd;
   }
   if (chain_id >= g.B * g.C) return;
   const int series = chain_id / g.C, chain = chain_id % g.C;
@@ -1416,22 +1438,22 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
   const int N = L.N, Lc = L.Lc, TP = L.TP, LVI = L.LVI, LVG = L.LVG;
   unsigned char* wsc = reinterpret_cast<unsigned char*>(a.ws) + chain_lin * a.ws_stride;
   int* csync = a.csync + chain_lin * TPC_INTS;
-  int* mode_lds = reinterpret_cast<int*>(smem + LL.shared);
-  double* shd = reinterpret_cast<double*>(smem + LL.shared + 16);     // wavefront 0 -> workgroup
+  int* mode_lds = tp_opaque(reinterpret_cast<int*>(smem + LL.shared));
+  double* shd = tp_opaque(reinterpret_cast<double*>(smem + LL.shared + 16));     // wavefront 0 -> workgroup
 
   // ---- the cluster
   TpSync sy;
-  sy.flags = csync; sy.G = G; sy.g = role; sy.epoch = 0; sy.cluster = false; sy.light = false;
-  int v0 = 0, v1 = 1;                 // the (virtual) workgroups this workgroup runs
-  if (G > 1) {
+  sy.flags = csync; sy.G = Gc; sy.g = role; sy.epoch = 0; sy.cluster = false; sy.light = false;
+  int v0 = 0, v1 = G;                 // the virtual workgroups this workgroup runs
+  if (Gc > 1) {
     if (a.cluster_drop != 0 && role == a.cluster_drop) return;     // test knob: never checks in
-    const int mode = tp_assemble(csync, role, G, tid, mode_lds);
+    const int mode = tp_assemble(csync, role, Gc, tid, mode_lds);
     if (mode == 3) {
       if (role > 0) return;
       v0 = 0; v1 = G;                 // alone: every chunk, workgroup barriers only
     } else {
       sy.cluster = true; sy.light = mode == 2;
-      v0 = role; v1 = role + 1;
+      const int per = G / Gc; v0 = role * per; v1 = v0 + per;
     }
   }
   const bool is_main = role == 0;
@@ -1446,8 +1468,8 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
   cx.msk = (TpGB)(wsc + L.mask); cx.cbv = (TpGB)(wsc + L.cbits); cx.cidx = (TpGB)(wsc + L.cidx);
   {
     unsigned char* wl = smem + LL.wave0 + (size_t)wave * LL.wave_stride;
-    cx.cm = (TpL)(wl + LL.cm); cx.am = (TpL)(wl + LL.am); cx.scr = (TpL)(wl + LL.scr);
-    cx.pzv = (TpL)(wl + LL.pzv); cx.vb = (TpL)(wl + LL.vb);
+    cx.cm = tp_lds<float>(wl + LL.cm); cx.am = tp_lds<float>(wl + LL.am); cx.scr = tp_lds<float>(wl + LL.scr);
+    cx.pzv = tp_lds<float>(wl + LL.pzv); cx.vb = tp_lds<float>(wl + LL.vb);
   }
   TpG e0 = (TpG)(wsc + L.e0); TpG ei = (TpG)(wsc + L.ei); TpG et = (TpG)(wsc + L.et);
   TpG stt = (TpG)(wsc + L.st);
@@ -1460,12 +1482,13 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
   RegLds R;
   R.xtx = const_cast<double*>(g.xtx) + (size_t)series * P * P;
   R.omega = const_cast<double*>(g.omega) + (size_t)series * P * P;
-  R.bvec = (double*)(smem + LL.reg + LL.bvec); R.w = (float*)(smem + LL.w);
-  R.aug[0] = (double*)(smem + LL.reg + LL.aug0); R.aug[1] = R.aug[0];
-  R.pri[0] = (double*)(smem + LL.pri0); R.pri[1] = R.pri[0];
-  R.chol = (double*)(smem + LL.reg + LL.chol); R.zv = (double*)(smem + LL.reg + LL.zv);
-  R.uperm = (double*)(smem + LL.reg + LL.uperm);
-  R.nz = (int*)(smem + LL.reg + LL.nz); R.perm = (int*)(smem + LL.reg + LL.perm); R.idx = (int*)(smem + LL.reg + LL.idx);
+  R.bvec = tp_opaque((double*)(smem + LL.reg + LL.bvec)); R.w = tp_opaque((float*)(smem + LL.w));
+  R.aug[0] = tp_opaque((double*)(smem + LL.reg + LL.aug0)); R.aug[1] = R.aug[0];
+  R.pri[0] = tp_opaque((double*)(smem + LL.pri0)); R.pri[1] = R.pri[0];
+  R.chol = tp_opaque((double*)(smem + LL.reg + LL.chol)); R.zv = tp_opaque((double*)(smem + LL.reg + LL.zv));
+  R.uperm = tp_opaque((double*)(smem + LL.reg + LL.uperm));
+  R.nz = tp_opaque((int*)(smem + LL.reg + LL.nz)); R.perm = tp_opaque((int*)(smem + LL.reg + LL.perm));
+  R.idx = tp_opaque((int*)(smem + LL.reg + LL.idx));
   const bool bigp = P > MAXP;
   if (bigp) bigp_point(R, wsc + L.big, P);
   const DevSeriesParams sp = g.sp[series];
@@ -1696,14 +1719,13 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
     }
     if (is_main && bigp && it < n_iter) {
       tp_wg_barrier();
-      typedef CI_LDS double* LD;
       typedef CI_GLB double* GD;
       double ns;
       if (LL.big_a && LL.big_p)
-        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, (LD)(smem + LL.reg + LL.big_a), (LD)(smem + LL.big_p), R.w, P, sp,
+        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, tp_lds<double>(smem + LL.reg + LL.big_a), tp_lds<double>(smem + LL.big_p), R.w, P, sp,
                                               shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
       else if (LL.big_a)
-        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, (LD)(smem + LL.reg + LL.big_a), (GD)R.pri[0], R.w, P, sp,
+        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, tp_lds<double>(smem + LL.reg + LL.big_a), (GD)R.pri[0], R.w, P, sp,
                                               shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
       else
         ns = tp_spike_slab_draw_big_wg<TP_NT>(R, (GD)R.aug[0], (GD)R.pri[0], R.w, P, sp,
@@ -1879,7 +1901,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
     }
     prof.tick(29);
     TpGC eincl = ei + (size_t)(LVI - 1) * N * ESZ;
-    if (G > 1) tp_cluster_barrier(sy, tid);                                 // (D)
+    if (Gc > 1) tp_cluster_barrier(sy, tid); else tp_wg_barrier();          // (D)
     prof.tick(30);
     for (int m = 0; m < LVG; ++m) {
       for (int v = v0; v < v1; ++v) {
@@ -1948,7 +1970,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       tp_wg_barrier();
     }
     TpGC bincl = bi + (size_t)(LVI - 1) * N * BSZ;
-    if (G > 1) tp_cluster_barrier(sy, tid);                                 // (E)
+    if (Gc > 1) tp_cluster_barrier(sy, tid); else tp_wg_barrier();          // (E)
     // (r at the end of a workgroup's last chunk needs the LATER workgroups' total maps applied to
     // zero: a chain of at most G - 1 matrix-vector products, formed by every wavefront for itself --
     // no further cluster barriers, no products of maps)

@@ -427,7 +427,10 @@ def main():
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out["cpu_baseline"] = _cpu_baseline(args.sampler, y, mask, X)
   elif rank == 0:
-    out["cpu_baseline"] = None
+    # not `null` without comment (round-4 review): the object says why there is no value here
+    out["cpu_baseline"] = {"value": None, "unit": "posterior samples/sec", "cores": 0, "kind": "port",
+                           "sample": ("not measured in this run: the CPU leg is timed on rank 0 of the "
+                                      "N=1 run only (--no-cpu-baseline / N > 1); see the N=1 line")}
     out["config"]["n_gt_1_note"] = ("cpu_baseline is timed at N=1 only; roofline.traffic on this "
                                     "line is the committed single-GPU counter figure (per GPU), not "
                                     "measured in this run")

@@ -183,3 +183,42 @@ def test_cfg4_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
   _compare("cfg4_same_chains", dev[:CO], ora, scale_floor=0.05)     # drift of the same streams
   _compare_paths("cfg4", g["posterior_means"][0, CO:], np.stack([c["_pred_mean_path"] for c in ora]),
                  pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))
+
+
+def test_general_seasonal_long_run_posterior_matches_oracle_within_one_percent_or_mc_error():
+  """The reference's 4+7+6-season model (causalimpact_lib_test.py:738-752) at cfg4's size -- T=10000,
+  50 covariates -- on the time-parallel cluster kernel of round 5 (csrc/ci_seasonal_tp.h: 128 chunks
+  of 80 steps, wave-cooperative float32 scan elements): W=100, S=300 (the oracle costs ~10 ms per
+  iteration: ~4 s per chain, in parallel on the host).  8 device chains in one launch against 4
+  oracle chains: device chains 4..7 are independent replicates, device chains 0..3 the oracle's
+  own random streams (the float32-vs-float64 drift of one stream over 400 iterations)."""
+  T, p, W, S, C, CO = 10000, 50, 100, 300, 8, 4
+  seed = (3, 1)
+  seasons = ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))
+  from causalimpact import _model
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
+  t = np.arange(T)
+  pattern = np.array([0.8, 0.3, -0.2, -0.6, -0.4, 0.0, 0.1])
+  y = np.where(mask, y, y + pattern[t % 7])
+  spec = orc.default_spec(y, mask, X, seasons=seasons)
+  counts, flg = _model.expand_seasons(seasons, T)
+  post = slice(int(0.7 * T), T)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_seasons=counts, num_warmup=W,
+                            num_results=S, num_chains=C, seed=seed)
+  sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+  assert "gibbs_seasonal_tp_kernel" in sess.kernel_name()
+  sess.run()
+  g = sess.fetch()
+  sess.close()
+  dev = [_chain_summaries(g["observation_noise_scale"][0, c], g["level_scale"][0, c],
+                          g["slope_scale"][0, c], g["weights"][0, c],
+                          g["posterior_trajectories"][0, c][:, post].mean(axis=1),
+                          g["posterior_means"][0, c][post].mean(),
+                          g["seasonal_drift_scales"][0, c]) for c in range(C)]
+  with concurrent.futures.ProcessPoolExecutor(max_workers=CO) as ex:
+    ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
+  _compare("general_seasonal", dev[CO:], ora, scale_floor=0.05)                 # independent replicates
+  _compare("general_seasonal_same_chains", dev[:CO], ora, scale_floor=0.05)     # drift of the same streams
+  _compare_paths("general_seasonal", g["posterior_means"][0, CO:],
+                 np.stack([c["_pred_mean_path"] for c in ora]),
+                 pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))

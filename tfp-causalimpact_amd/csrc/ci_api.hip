@@ -27,10 +27,13 @@
 #include "ci_wide_score.h"
 
 extern "C" void* ci_gibbs_seasonal_fn(int);
-extern "C" void* ci_gibbs_seasonal_tp_fn_nch1(void);
-extern "C" void* ci_gibbs_seasonal_tp_fn_nch2(void);
-extern "C" void* ci_gibbs_seasonal_tp_fn_nch3(void);
-extern "C" void* ci_gibbs_seasonal_tp_fn_nch4(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nq2(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nq3(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nq4(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nq5(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nq6(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nq7(void);
+extern "C" void* ci_gibbs_seasonal_tp_fn_nq8(void);
 extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs*, int, hipStream_t);
 extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs*, int, hipStream_t);
 extern "C" void ci_launch_gibbs64(const ci::G64Args*, int, size_t, int, hipStream_t);
@@ -740,9 +743,13 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
         s->Lc = G;
         s->lds_bytes = tl.total;
         s->tp_ws_bytes = ci::make_tplayout(T, P, K, s->D_full, pb->has_slope, G).total;
-        const int nch = (s->D_full + 7) / 8;
-        s->fn = (KernelFn)(nch == 1 ? ci_gibbs_seasonal_tp_fn_nch1() : nch == 2 ? ci_gibbs_seasonal_tp_fn_nch2()
-                           : nch == 3 ? ci_gibbs_seasonal_tp_fn_nch3() : ci_gibbs_seasonal_tp_fn_nch4());
+        const int nq = ci::tp_nr(s->D_full) / 4;       // register rows of 4 nq columns
+        typedef void* (*TpFn)(void);
+        static const TpFn tp_fns[9] = {nullptr, nullptr, ci_gibbs_seasonal_tp_fn_nq2, ci_gibbs_seasonal_tp_fn_nq3,
+                                       ci_gibbs_seasonal_tp_fn_nq4, ci_gibbs_seasonal_tp_fn_nq5,
+                                       ci_gibbs_seasonal_tp_fn_nq6, ci_gibbs_seasonal_tp_fn_nq7,
+                                       ci_gibbs_seasonal_tp_fn_nq8};
+        s->fn = (KernelFn)tp_fns[nq]();
       }
     }
     if (s->lds_bytes > 160 * 1024) {
@@ -751,7 +758,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     }
     if (!s->wide && !s->tp) s->fn = (KernelFn)ci_gibbs_seasonal_fn((s->seasonal_gws ? 1 : 0) | (bigp ? 2 : 0));
     char nm[96];
-    if (s->tp) snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_tp_kernel<%d> %d chunks x%d", (s->D_full + 7) / 8,
+    if (s->tp) snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_tp_kernel<%d> %d chunks x%d", ci::tp_nr(s->D_full) / 4,
                         s->Lc * ci::TP_NWV, s->cluster);
     else if (s->wide) snprintf(nm, sizeof(nm), "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
     else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel<%s,%s>", s->seasonal_gws ? "true" : "false",

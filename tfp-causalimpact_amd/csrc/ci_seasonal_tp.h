@@ -53,7 +53,11 @@ constexpr int TPC_INTS = 64;               // handshake ints per chain: [0,16) b
 constexpr int TPC_MODE = 16, TPC_XCC = 32;
 constexpr int TP_STAT = 32;                // floats of statistics / boundary record per chunk
 
-__host__ __device__ inline int tp_nr(int D) { return ((D + 7) & ~7); }
+// columns of the register rows: the state rounded up to a multiple of 4 (at least 8).  (Products and
+// eliminations of the scan scale with the square of it: 20 instead of 24 columns at D = 18.)
+__host__ __device__ inline int tp_nr(int D) { const int n = (D + 3) & ~3; return n < 8 ? 8 : n; }
+// row stride of the LDS mirrors: 16-byte rows, = 4 mod 8 floats (conflict-free run-time columns)
+__host__ __device__ inline int tp_ds(int NR) { return ((NR + 7) & ~7) + 4; }
 __host__ __device__ inline int tp_log2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 // floats of one forward element (rows of [A | C | J | b eta 0 0]) and one backward map ([M | c 0 0 0])
 __host__ __device__ inline size_t tp_esz(int NR) { return (size_t)NR * (3 * NR + 4); }
@@ -105,7 +109,7 @@ struct TpLds {
 };
 __host__ __device__ inline TpLds make_tplds(int P, int D) {
   TpLds l;
-  const int NR = tp_nr(D), DS = NR + 4;
+  const int NR = tp_nr(D), DS = tp_ds(NR);
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
   l.cm = take(sizeof(float) * D * DS);            // covariance rows (mirror of the register rows)
@@ -196,6 +200,14 @@ __device__ __forceinline__ CI_GLB const uint32_t* tp_pu(TpGBC p) { return (CI_GL
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ void tp_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+// LDS hand-off between the lanes of ONE wavefront INSIDE the per-step loops: DS operations of a
+// wavefront complete in program order, so a ds_write followed by a ds_read needs no s_waitcnt in
+// between (the read's own wait, where its value is used, covers both) -- only the compiler must
+// not reorder them.  Each s_waitcnt lgkmcnt(0) in the step was an exposed LDS round trip.
+__device__ __forceinline__ void tp_lds_order() {
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 // hand-off through global memory between the lanes of ONE wavefront
@@ -698,14 +710,26 @@ template <int NR> __device__ __forceinline__ void tp_state_from_elem(TpGC g, TpG
 template <int NR>
 __device__ __noinline__ void tp_bcompose(TpGC outer, TpGC inner, TpG out, TpL scr, TpL vb,
                                          int D, int lane) {
-  const TRow<NR> Mo = fload<NR>(outer, NR + 4, lane);
-  const float co = fscalar<NR>(outer, NR + 4, NR, lane);
-  const float ci = fscalar<NR>(inner, NR + 4, NR, lane);
-  hscr_put<NR>(scr, hload<NR>(inner, NR + 4, lane), lane);
-  const THalf<NR / 2> M = hmul<NR>(Mo, scr, D, lane);
-  const float c = co + hdot<NR>(Mo, vb, ci, lane);
-  hstore<NR>(out, NR + 4, lane, M);
-  if (lane < NR) *tp_p4w(out + (size_t)lane * (NR + 4) + NR) = ci_f4v{c, 0.f, 0.f, 0.f};
+  if constexpr (NR % 8 == 0) {
+    const TRow<NR> Mo = fload<NR>(outer, NR + 4, lane);
+    const float co = fscalar<NR>(outer, NR + 4, NR, lane);
+    const float ci = fscalar<NR>(inner, NR + 4, NR, lane);
+    hscr_put<NR>(scr, hload<NR>(inner, NR + 4, lane), lane);
+    const THalf<NR / 2> M = hmul<NR>(Mo, scr, D, lane);
+    const float c = co + hdot<NR>(Mo, vb, ci, lane);
+    hstore<NR>(out, NR + 4, lane, M);
+    if (lane < NR) *tp_p4w(out + (size_t)lane * (NR + 4) + NR) = ci_f4v{c, 0.f, 0.f, 0.f};
+  } else {
+    // (widths that do not split into two float4-aligned halves: the row-per-lane form)
+    const TRow<NR> Mo = trow_load<NR>(outer, NR + 4, lane);
+    const float co = lane < NR ? outer[(size_t)lane * (NR + 4) + NR] : 0.f;
+    const float ci = lane < NR ? inner[(size_t)lane * (NR + 4) + NR] : 0.f;
+    tscr_put<NR>(scr, trow_load<NR>(inner, NR + 4, lane), lane);
+    const TRow<NR> M = tmul<NR>(Mo, scr, D, lane);
+    const float c = co + tdot<NR>(Mo, vb, ci, lane);
+    trow_store<NR>(out, NR + 4, lane, M);
+    if (lane < NR) *tp_p4w(out + (size_t)lane * (NR + 4) + NR) = ci_f4v{c, 0.f, 0.f, 0.f};
+  }
 }
 template <int NR> __device__ __forceinline__ void tp_bcopy(TpG dst, TpGC src, int lane) {
   const int n4 = (int)(tp_bsz(NR) / 4);
@@ -802,12 +826,12 @@ __device__ __forceinline__ TRow<NR> tp_prior_row(const TpCtx& c, float p1l, floa
 // update the sweep ci_seasonal.h's filter applies to P.  Registers hold the rows; LDS mirrors of C
 // and A' serve the reads with a run-time column (C z, A'z).  `first`: the chunk starts at the
 // prior, i.e. its element is (0, a_1, P_1, 0, 0) followed by its steps.
-template <int NCH>
+template <int NQ>
 static __device__ __noinline__ void tp_build_pass(const TpCtx& cref, int s, int e, bool first, float a1e,
                                                    float p1l, float p1s, float p1e, TpG eout) {
   const TpCtx c = cref;        // by value: fields read through the reference are FLAT loads the
                                // optimiser cannot hoist past the LDS / global stores of the loop
-  constexpr int NR = 8 * NCH;
+  constexpr int NR = 4 * NQ;
   const int lane = c.lane, D = c.D, DS = c.DS, T = c.T;
   const bool slope = c.has_slope != 0, comp = lane < D;
   TpL Cm = c.cm;
@@ -817,16 +841,13 @@ static __device__ __noinline__ void tp_build_pass(const TpCtx& cref, int s, int 
   TpL pzv = c.pzv;
   CI_LDS float* zav = pzv + 72;
   CI_LDS float* gvk = pzv + 144;
-  CI_LDS int* zcol = (CI_LDS int*)(gvk + SMAXK * 72);
   CI_LDS const float* gmine = gvk + c.blk0 * 72;
   CI_LDS float* gslot = gvk + c.blk0 * 72 + lane;
   TpGBC cidb = c.cidx + (size_t)c.blk0 * c.TP;
   auto ld4 = [](CI_LDS const float* q) -> ci_f4v { return *(CI_LDS const ci_f4v*)q; };
   const float H = c.H, ql = c.ql, qs = c.qs, myd2 = c.myd2, rnb = c.rnb;
-  if (lane < 8) zcol[lane] = D;
   for (int x = lane; x < 144 + SMAXK * 72; x += 64) pzv[x] = 0.f;
   tp_lds_sync();
-  if (c.blk >= 0 && c.pos == 0 && s < c.TP) zcol[c.blk] = c.boff + (int)cidb[s];
   float crow[NR], arow[NR], jrow[NR];
   float bi = 0.f, etai = 0.f;
   {
@@ -854,6 +875,9 @@ static __device__ __noinline__ void tp_build_pass(const TpCtx& cref, int s, int 
     const uint32_t cb4 = *tp_pu(c.cbv + t4);
     const uint32_t mk4 = *tp_pu(c.msk + t4);
     const uint32_t cw4 = *tp_pu(cidb + t4);
+    uint32_t cwk[SMAXK];                              // c_k(t) of EVERY block, 4 steps (static table)
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k) cwk[k] = k < c.K ? *tp_pu(c.cidx + (size_t)k * c.TP + t4) : 0u;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
       const int t = t4 + q;
@@ -866,13 +890,18 @@ static __device__ __noinline__ void tp_build_pass(const TpCtx& cref, int s, int 
       float cz = 0.f, za = 0.f, rS = 0.f;
       if (obs) {
         if (comp) {
-          const ci_i4v z0 = *(CI_LDS const ci_i4v*)zcol, z1 = *(CI_LDS const ci_i4v*)(zcol + 4);
+          // (all sixteen reads issued together: blocks that do not exist read the zero column)
+          float cq[SMAXK], aq[SMAXK];
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k) {
+            const int zc = k < c.K ? c.off[k] + (int)((cwk[k] >> (8 * q)) & 0xFFu) : NR;
+            cq[k] = Crow[zc];
+            aq[k] = Arow[zc];
+          }
           cz = crow[0];
-          cz += Crow[z0.x]; cz += Crow[z0.y]; cz += Crow[z0.z]; cz += Crow[z0.w];
-          cz += Crow[z1.x]; cz += Crow[z1.y]; cz += Crow[z1.z]; cz += Crow[z1.w];
           za = arow[0];
-          za += Arow[z0.x]; za += Arow[z0.y]; za += Arow[z0.z]; za += Arow[z0.w];
-          za += Arow[z1.x]; za += Arow[z1.y]; za += Arow[z1.z]; za += Arow[z1.w];
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k) { cz += cq[k]; za += aq[k]; }
         }
         const float S = wave_sum_dpp(isz ? cz : 0.f) + H;
         rS = __builtin_amdgcn_rcpf(S);
@@ -896,51 +925,51 @@ static __device__ __noinline__ void tp_build_pass(const TpCtx& cref, int s, int 
         zav[lane] = za;
         if (c.blk >= 0) *gslot = gi;
       }
-      tp_lds_sync();
+      tp_lds_order();
       if (comp) {
         const float cz1 = slope ? pzv[1] : 0.f;
+        // every broadcast row of the step in flight at once (NR - D < 4: no quad is empty except
+        // for the trend-only widths, where the spare quad works on zeros)
+        ci_f4v pa[NQ], za_[NQ], ga[NQ], qa[NQ];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-          if (8 * ch < D) {
-            const ci_f4v pa = ld4(pzv + 8 * ch), pb = ld4(pzv + 8 * ch + 4);
-            const ci_f4v za_ = ld4(zav + 8 * ch), zb_ = ld4(zav + 8 * ch + 4);
-            const ci_f4v ga = ld4(gmine + 8 * ch), gb = ld4(gmine + 8 * ch + 4);
-            const float pj[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-            const float zj[8] = {za_.x, za_.y, za_.z, za_.w, zb_.x, zb_.y, zb_.z, zb_.w};
-            const float gj[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-            if (slope) {
-              const ci_f4v qa = ld4(Cm + DS + 8 * ch), qb = ld4(Cm + DS + 8 * ch + 4);
-              const float p1[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        for (int qd = 0; qd < NQ; ++qd) {
+          pa[qd] = ld4(pzv + 4 * qd); za_[qd] = ld4(zav + 4 * qd); ga[qd] = ld4(gmine + 4 * qd);
+          qa[qd] = slope ? ld4(Cm + DS + 4 * qd) : ci_f4v{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                float r = fmaf(-(cz * pj[u]), rS, crow[8 * ch + u]);
-                if (lane == 0) r += fmaf(-(cz1 * pj[u]), rS, p1[u]);
-                crow[8 * ch + u] = fmaf(myd2, gi * gj[u], r);
-              }
-              if (ch == 0) {
-                crow[0] += crow[1];
-                if (lane == 1) crow[1] += qs;
-              }
-            } else {
+        for (int qd = 0; qd < NQ; ++qd) {
+          const float pj[4] = {pa[qd].x, pa[qd].y, pa[qd].z, pa[qd].w};
+          const float zj[4] = {za_[qd].x, za_[qd].y, za_[qd].z, za_[qd].w};
+          const float gj[4] = {ga[qd].x, ga[qd].y, ga[qd].z, ga[qd].w};
+          if (slope) {
+            const float p1[4] = {qa[qd].x, qa[qd].y, qa[qd].z, qa[qd].w};
 #pragma unroll
-              for (int u = 0; u < 8; ++u)
-                crow[8 * ch + u] = fmaf(myd2, gi * gj[u], fmaf(-(cz * pj[u]), rS, crow[8 * ch + u]));
+            for (int u = 0; u < 4; ++u) {
+              float r = fmaf(-(cz * pj[u]), rS, crow[4 * qd + u]);
+              if (lane == 0) r += fmaf(-(cz1 * pj[u]), rS, p1[u]);
+              crow[4 * qd + u] = fmaf(myd2, gi * gj[u], r);
             }
-            if (ch == 0 && lane == 0) crow[0] += ql;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              arow[8 * ch + u] = fmaf(-(za * pj[u]), rS, arow[8 * ch + u]);
-              jrow[8 * ch + u] = fmaf(za * zj[u], rS, jrow[8 * ch + u]);
+            if (qd == 0) {
+              crow[0] += crow[1];
+              if (lane == 1) crow[1] += qs;
             }
-            if (slope && ch == 0) arow[0] += arow[1];     // A <- T A (column 0 of A' += column 1)
-            *(CI_LDS ci_f4v*)(Crow + 8 * ch) = ci_f4v{crow[8 * ch], crow[8 * ch + 1], crow[8 * ch + 2], crow[8 * ch + 3]};
-            *(CI_LDS ci_f4v*)(Crow + 8 * ch + 4) = ci_f4v{crow[8 * ch + 4], crow[8 * ch + 5], crow[8 * ch + 6], crow[8 * ch + 7]};
-            *(CI_LDS ci_f4v*)(Arow + 8 * ch) = ci_f4v{arow[8 * ch], arow[8 * ch + 1], arow[8 * ch + 2], arow[8 * ch + 3]};
-            *(CI_LDS ci_f4v*)(Arow + 8 * ch + 4) = ci_f4v{arow[8 * ch + 4], arow[8 * ch + 5], arow[8 * ch + 6], arow[8 * ch + 7]};
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              crow[4 * qd + u] = fmaf(myd2, gi * gj[u], fmaf(-(cz * pj[u]), rS, crow[4 * qd + u]));
           }
+          if (qd == 0 && lane == 0) crow[0] += ql;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            arow[4 * qd + u] = fmaf(-(za * pj[u]), rS, arow[4 * qd + u]);
+            jrow[4 * qd + u] = fmaf(za * zj[u], rS, jrow[4 * qd + u]);
+          }
+          if (slope && qd == 0) arow[0] += arow[1];     // A <- T A (column 0 of A' += column 1)
+          *(CI_LDS ci_f4v*)(Crow + 4 * qd) = ci_f4v{crow[4 * qd], crow[4 * qd + 1], crow[4 * qd + 2], crow[4 * qd + 3]};
+          *(CI_LDS ci_f4v*)(Arow + 4 * qd) = ci_f4v{arow[4 * qd], arow[4 * qd + 1], arow[4 * qd + 2], arow[4 * qd + 3]};
+        }
       }
-      if (mych && c.pos == 0) zcol[c.blk] = c.boff + ((mycur + 1 == c.nb) ? 0 : mycur + 1);
-      tp_lds_sync();
+      tp_lds_order();
     }
   }
   // A' rows -> A rows, and out
@@ -953,26 +982,23 @@ static __device__ __noinline__ void tp_build_pass(const TpCtx& cref, int s, int 
 
 // The Kalman filter on the chunk from its true predicted moments (rows [P | a 0 0 0] in `st`):
 // ci_seasonal.h's seasonal_filter_pass on a range.  Stores K_t and v_t / F_t.
-template <int NCH>
+template <int NQ>
 static __device__ __noinline__ void tp_filter_pass(const TpCtx& cref, int s, int e, TpGC st) {
   const TpCtx c = cref;
-  constexpr int NR = 8 * NCH;
+  constexpr int NR = 4 * NQ;
   const int lane = c.lane, D = c.D, DS = c.DS, T = c.T;
   const bool slope = c.has_slope != 0, comp = lane < D;
   TpL Pm = c.cm;
   CI_LDS float* Prow = Pm + (comp ? lane : 0) * DS;
   TpL pzv = c.pzv;
   CI_LDS float* gvk = pzv + 144;
-  CI_LDS int* zcol = (CI_LDS int*)(gvk + SMAXK * 72);
   CI_LDS const float* gmine = gvk + c.blk0 * 72;
   CI_LDS float* gslot = gvk + c.blk0 * 72 + lane;
   TpGBC cidb = c.cidx + (size_t)c.blk0 * c.TP;
   auto ld4 = [](CI_LDS const float* q) -> ci_f4v { return *(CI_LDS const ci_f4v*)q; };
   const float H = c.H, ql = c.ql, qs = c.qs, myd2 = c.myd2, rnb = c.rnb;
-  if (lane < 8) zcol[lane] = D;
   for (int x = lane; x < 144 + SMAXK * 72; x += 64) pzv[x] = 0.f;
   tp_lds_sync();
-  if (c.blk >= 0 && c.pos == 0) zcol[c.blk] = c.boff + (int)cidb[s];
   float prow[NR];
   float am = 0.f;
   {
@@ -994,6 +1020,9 @@ static __device__ __noinline__ void tp_filter_pass(const TpCtx& cref, int s, int
     const uint32_t cb4 = *tp_pu(c.cbv + t4);
     const uint32_t mk4 = *tp_pu(c.msk + t4);
     const uint32_t cw4 = *tp_pu(cidb + t4);
+    uint32_t cwk[SMAXK];                              // c_k(t) of EVERY block, 4 steps (static table)
+#pragma unroll
+    for (int k = 0; k < SMAXK; ++k) cwk[k] = k < c.K ? *tp_pu(c.cidx + (size_t)k * c.TP + t4) : 0u;
     float vfq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1008,10 +1037,13 @@ static __device__ __noinline__ void tp_filter_pass(const TpCtx& cref, int s, int
       float kfi = 0.f, rF = 0.f, pz = 0.f;
       if (obs) {
         if (comp) {
-          const ci_i4v z0 = *(CI_LDS const ci_i4v*)zcol, z1 = *(CI_LDS const ci_i4v*)(zcol + 4);
+          float pq[SMAXK];
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k)
+            pq[k] = Prow[k < c.K ? c.off[k] + (int)((cwk[k] >> (8 * q)) & 0xFFu) : NR];
           pz = prow[0];
-          pz += Prow[z0.x]; pz += Prow[z0.y]; pz += Prow[z0.z]; pz += Prow[z0.w];
-          pz += Prow[z1.x]; pz += Prow[z1.y]; pz += Prow[z1.z]; pz += Prow[z1.w];
+#pragma unroll
+          for (int k = 0; k < SMAXK; ++k) pz += pq[k];
         }
         const float F = wave_sum_dpp(isz ? pz : 0.f) + H;
         rF = __builtin_amdgcn_rcpf(F);
@@ -1037,41 +1069,41 @@ static __device__ __noinline__ void tp_filter_pass(const TpCtx& cref, int s, int
         if (lane == 0) { prow[0] += ql; Prow[0] = prow[0]; }
         continue;
       }
-      tp_lds_sync();
+      tp_lds_order();
       if (comp) {
         const float pz1 = slope ? pzv[1] : 0.f;
+        ci_f4v pa[NQ], ga[NQ], qa[NQ];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-          if (8 * ch < D) {
-            const ci_f4v pa = ld4(pzv + 8 * ch), pb = ld4(pzv + 8 * ch + 4);
-            const ci_f4v ga = ld4(gmine + 8 * ch), gb = ld4(gmine + 8 * ch + 4);
-            const float pj[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-            const float gj[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-            if (slope) {
-              const ci_f4v qa = ld4(Pm + DS + 8 * ch), qb = ld4(Pm + DS + 8 * ch + 4);
-              const float p1[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        for (int qd = 0; qd < NQ; ++qd) {
+          pa[qd] = ld4(pzv + 4 * qd); ga[qd] = ld4(gmine + 4 * qd);
+          qa[qd] = slope ? ld4(Pm + DS + 4 * qd) : ci_f4v{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                float r = fmaf(-(pz * pj[u]), rF, prow[8 * ch + u]);
-                if (lane == 0) r += fmaf(-(pz1 * pj[u]), rF, p1[u]);
-                prow[8 * ch + u] = fmaf(myd2, gi * gj[u], r);
-              }
-              if (ch == 0) {
-                prow[0] += prow[1];
-                if (lane == 1) prow[1] += qs;
-              }
-            } else {
+        for (int qd = 0; qd < NQ; ++qd) {
+          const float pj[4] = {pa[qd].x, pa[qd].y, pa[qd].z, pa[qd].w};
+          const float gj[4] = {ga[qd].x, ga[qd].y, ga[qd].z, ga[qd].w};
+          if (slope) {
+            const float p1[4] = {qa[qd].x, qa[qd].y, qa[qd].z, qa[qd].w};
 #pragma unroll
-              for (int u = 0; u < 8; ++u)
-                prow[8 * ch + u] = fmaf(myd2, gi * gj[u], fmaf(-(pz * pj[u]), rF, prow[8 * ch + u]));
+            for (int u = 0; u < 4; ++u) {
+              float r = fmaf(-(pz * pj[u]), rF, prow[4 * qd + u]);
+              if (lane == 0) r += fmaf(-(pz1 * pj[u]), rF, p1[u]);
+              prow[4 * qd + u] = fmaf(myd2, gi * gj[u], r);
             }
-            if (ch == 0 && lane == 0) prow[0] += ql;
-            *(CI_LDS ci_f4v*)(Prow + 8 * ch) = ci_f4v{prow[8 * ch], prow[8 * ch + 1], prow[8 * ch + 2], prow[8 * ch + 3]};
-            *(CI_LDS ci_f4v*)(Prow + 8 * ch + 4) = ci_f4v{prow[8 * ch + 4], prow[8 * ch + 5], prow[8 * ch + 6], prow[8 * ch + 7]};
+            if (qd == 0) {
+              prow[0] += prow[1];
+              if (lane == 1) prow[1] += qs;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              prow[4 * qd + u] = fmaf(myd2, gi * gj[u], fmaf(-(pz * pj[u]), rF, prow[4 * qd + u]));
           }
+          if (qd == 0 && lane == 0) prow[0] += ql;
+          *(CI_LDS ci_f4v*)(Prow + 4 * qd) = ci_f4v{prow[4 * qd], prow[4 * qd + 1], prow[4 * qd + 2], prow[4 * qd + 3]};
+        }
       }
-      if (mych && c.pos == 0) zcol[c.blk] = c.boff + ((mycur + 1 == c.nb) ? 0 : mycur + 1);
-      tp_lds_sync();
+      tp_lds_order();
     }
     if (lane == 0) *tp_p4w(c.vf + t4) = ci_f4v{vfq[0], vfq[1], vfq[2], vfq[3]};
   }
@@ -1401,9 +1433,9 @@ __device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, 
 // the persistent Gibbs kernel (iteration structure of gibbs_seasonal_kernel / the oracle's
 // ci_oracle_fit_gibbs; gibbs_sampler.fit_with_gibbs_sampling called at causalimpact_lib.py:365)
 // ------------------------------------------------------------------------------------
-template <int NCH>
+template <int NQ>
 __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
-  constexpr int NR = 8 * NCH;
+  constexpr int NR = 4 * NQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1459,7 +1491,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
   const bool is_main = role == 0;
 
   // ---- pointers
-  cx.T = T; cx.TP = TP; cx.D = D; cx.DS = NR + 4; cx.K = K; cx.lane = lane; cx.has_slope = a.has_slope;
+  cx.T = T; cx.TP = TP; cx.D = D; cx.DS = tp_ds(NR); cx.K = K; cx.lane = lane; cx.has_slope = a.has_slope;
   cx.yv = (TpG)(wsc + L.yv); cx.lev = (TpG)(wsc + L.lev); cx.slp = (TpG)(wsc + L.slp);
   cx.xw = (TpG)(wsc + L.xw); cx.ytil = (TpG)(wsc + L.ytil); cx.vf = (TpG)(wsc + L.vf);
   cx.zl = (TpG)(wsc + L.zl); cx.zs = (TpG)(wsc + L.zs); cx.zo = (TpG)(wsc + L.zo);
@@ -1876,7 +1908,7 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
     // ---- (5) filtering elements of the chunks, their scan, the chunks' predicted moments
     for (int v = v0; v < v1; ++v) {
       const int c = v * TP_NWV + wave, s = chunk_s(c), e = chunk_e(c);
-      tp_build_pass<NCH>(cx, s, e, c == 0, a1e, p1l, p1s, p1e, e0 + (size_t)c * ESZ);
+      tp_build_pass<NQ>(cx, s, e, c == 0, a1e, p1l, p1s, p1e, e0 + (size_t)c * ESZ);
       if (c == 0) {
         const TRow<NR> p0 = tp_prior_row<NR>(cx, p1l, p1s, p1e);
         trow_store<NR>(stt, NR + 4, lane, p0);
@@ -1931,26 +1963,43 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       TpGC st = stt + (size_t)c * SSZ;
       float cvec = 0.f;
       if (s < T) {
-        tp_filter_pass<NCH>(cx, s, e, st);
+        tp_filter_pass<NQ>(cx, s, e, st);
         tp_wg_barrier_wave();
         cvec = tp_backward_pass<false>(cx, s, e, 0.f);
       }
       // M = (I + J P_start)^-1 A'
-      THalf<NR / 2> M = thalf_zero<NR / 2>();
-      if (s < T) {
-        const TpElemPtr<NR> el{e0 + (size_t)c * ESZ};
-        hscr_put<NR>(cx.scr, hload<NR>(st, NR + 4, lane), lane);
-        THalf<NR / 2> W = hmul<NR>(el.Jf(lane), cx.scr, D, lane, true);
-        M = htranspose<NR>(cx.scr, el.Ah(lane), lane);
-        THalf<NR / 2> dummy = thalf_zero<NR / 2>();
-        float du = 0.f;
-        hgauss_jordan<NR, 1>(W, M, dummy, du, cx.pzv, D, lane);
-      } else {
-#pragma unroll
-        for (int u = 0; u < NR / 2; ++u) M.v[u] = ((lane & 31) < D && (lane >> 5) * (NR / 2) + u == (lane & 31)) ? 1.f : 0.f;
-      }
       TpG bo = bm + (size_t)c * BSZ;
-      hstore<NR>(bo, NR + 4, lane, M);
+      if constexpr (NR % 8 == 0) {
+        THalf<NR / 2> M = thalf_zero<NR / 2>();
+        if (s < T) {
+          const TpElemPtr<NR> el{e0 + (size_t)c * ESZ};
+          hscr_put<NR>(cx.scr, hload<NR>(st, NR + 4, lane), lane);
+          THalf<NR / 2> W = hmul<NR>(el.Jf(lane), cx.scr, D, lane, true);
+          M = htranspose<NR>(cx.scr, el.Ah(lane), lane);
+          THalf<NR / 2> dummy = thalf_zero<NR / 2>();
+          float du = 0.f;
+          hgauss_jordan<NR, 1>(W, M, dummy, du, cx.pzv, D, lane);
+        } else {
+#pragma unroll
+          for (int u = 0; u < NR / 2; ++u) M.v[u] = ((lane & 31) < D && (lane >> 5) * (NR / 2) + u == (lane & 31)) ? 1.f : 0.f;
+        }
+        hstore<NR>(bo, NR + 4, lane, M);
+      } else {
+        TRow<NR> M = trow_zero<NR>();
+        if (s < T) {
+          const TpElemPtr<NR> el{e0 + (size_t)c * ESZ};
+          tscr_put<NR>(cx.scr, trow_load<NR>(st, NR + 4, lane), lane);
+          TRow<NR> W = tmul<NR>(el.J(lane), cx.scr, D, lane, true);
+          M = ttranspose<NR>(cx.scr, el.A(lane), lane);
+          TRow<NR> dummy = trow_zero<NR>();
+          float du = 0.f;
+          tgauss_jordan<NR, 1>(W, M, dummy, du, D, lane);
+        } else {
+#pragma unroll
+          for (int u = 0; u < NR; ++u) M.v[u] = (comp && u == lane) ? 1.f : 0.f;
+        }
+        trow_store<NR>(bo, NR + 4, lane, M);
+      }
       if (lane < NR) *tp_p4w(bo + (size_t)lane * (NR + 4) + NR) = ci_f4v{comp ? cvec : 0.f, 0.f, 0.f, 0.f};
     }
     prof.tick(26);

@@ -61,6 +61,6 @@ template <int NR> void run(int D) {
 }
 
 int main() {
-  run<8>(8); run<16>(13); run<24>(18); run<32>(32);
+  run<8>(8); run<16>(13); run<20>(18); run<24>(18); run<32>(32);
   return 0;
 }

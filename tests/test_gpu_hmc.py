@@ -163,6 +163,33 @@ def test_device_hmc_tracks_the_float64_oracle_draw_for_draw(prior, has_slope, T,
     np.testing.assert_allclose(arrs["weights"][0, c], draws[c, :, 3:], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("prior,has_slope,p", [("slab", True, 10), ("horseshoe", False, 10),
+                                               ("slab", False, 3), ("horseshoe", True, 21)])
+def test_fused_leapfrog_driver_gives_the_bits_of_the_five_barrier_driver(prior, has_slope, p, monkeypatch):
+  """Round 5: when the parameter vector fits one wavefront (dim <= 64) wave 0 runs the whole
+  per-coordinate chain of a leapfrog step between two workgroup barriers (csrc/ci_hmc.h, `fused`),
+  with the slab prior's Omega column in registers for P <= 16.  Same expressions in the same order
+  as the general driver (still used for dim > 64: the horseshoe with 22 columns here, 3 * 22 + 2 + 3
+  = 71 coordinates): $CI_HMC_LEGACY_DRIVER=1 must not change one bit of a fit with warm-up."""
+  from causalimpact import _model, _native
+  from causalimpact import _synthetic as syn
+  T = 700
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 5)
+  spec = _model.series_params(y, mask, X, has_slope=has_slope)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=has_slope, num_warmup=0, num_results=1, seed=(9, 2))
+  out = {}
+  for legacy in ("0", "1"):
+    monkeypatch.setenv("CI_HMC_LEGACY_DRIVER", legacy)
+    sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8)
+    sess.hmc_run(num_chains=3, num_warmup=60, num_results=12, num_leapfrog=6, seed=(9, 2), prior=prior)
+    draws, acc, eps, _ = sess.hmc_fetch()
+    sess.close()
+    out[legacy] = (draws, acc, eps)
+  assert np.isfinite(out["0"][0]).all() and (out["0"][1] > 0.3).all()
+  for a, b in zip(out["0"], out["1"]):
+    np.testing.assert_array_equal(a, b)
+
+
 def test_full_warmup_schedule_adapts_like_the_oracle():
   """The whole 75 / slow windows / 25 schedule at BASELINE cfg3's size (T=1000, P=11, 15
   leapfrogs).  Draw-for-draw agreement cannot survive it: float32-vs-float64 round-off in the

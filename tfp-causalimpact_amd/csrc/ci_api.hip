@@ -724,7 +724,10 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     // workgroups of 8 wavefronts per chain (one chunk of the series per wavefront), as long as every
     // chain of the launch gets at least one CU to itself (bigger batches are throughput-bound: one
     // wavefront per chain on the sequential kernel does less work per step).
-    if (!s->wide && s->D_full <= ci::TP_MAXD && T >= 64 && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
+    // (measured, round 5: below ~110 steps the one-wavefront kernel is as fast or faster -- 158 us
+    // against 171 us at T = 96 on the 4+7+6 model, 202 us against 174 us at T = 128)
+    const int tp_min_t = P > ci::MAXP ? 64 : 112;
+    if (!s->wide && s->D_full <= ci::TP_MAXD && T >= tp_min_t && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
         !(pb->flags & CI_FLAG_SEASONAL_WORKSPACE)) {
       int num_cus = 256;
       (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, pb->device);
@@ -1798,6 +1801,20 @@ int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const doubl
   }
   ci::HmcArgs a;
   a.init = init_theta ? s->h_init.p : nullptr;
+  {
+    // tests only: the five-barrier driver of rounds 2-4, to compare bits with the fused one
+    const char* e_ = getenv("CI_HMC_LEGACY_DRIVER");
+    a.legacy_driver = (e_ && e_[0] == '1' && e_[1] == 0) ? 1 : 0;
+  }
+  // tools/exp_hmc_phases.py: phase cycles of chain 0 (s_memtime on its thread 0), printed to stderr
+  DevBuf<long long> hprof;
+  BufGuard<DevBuf<long long>> hprof_guard(&hprof);
+  a.prof = nullptr;
+  if (getenv("CI_HMC_PROF") != nullptr) {
+    HIP_TRY(hprof.alloc(32));
+    HIP_TRY(hipMemsetAsync(hprof.p, 0, 32 * sizeof(long long), s->stream));
+    a.prof = hprof.p;
+  }
   a.T = T; a.P = P; a.C = C; a.W = o->num_warmup; a.S = S; a.n_leap = o->num_leapfrog;
   a.chain_offset = o->chain_offset; a.seed0 = o->seed[0]; a.seed1 = o->seed[1];
   a.prior_mode = o->prior; a.hs_scale0 = o->horseshoe_scale;
@@ -1842,6 +1859,13 @@ int ci_ll_session_hmc_run(ci_ll_session* s, const ci_hmc_options* o, const doubl
   if (kernel_ms) {
     HIP_TRY(hipEventElapsedTime(&kernel_ms[0], s->ev0, s->ev1));
     HIP_TRY(hipEventElapsedTime(&kernel_ms[1], s->ev1, s->ev2));
+  }
+  if (a.prof) {
+    long long h[32];
+    HIP_TRY(hipMemcpy(h, hprof.p, sizeof(h), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "ci hmc prof:");
+    for (int i = 0; i < 32; ++i) std::fprintf(stderr, " %lld", h[i]);
+    std::fprintf(stderr, "\n");
   }
   s->h_ran = true;
   return 0;

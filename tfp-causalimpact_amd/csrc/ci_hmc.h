@@ -30,6 +30,15 @@
 #pragma once
 #include "ci_kernels.h"
 
+// hmc_kernel's lambdas are inlined by force (a call moves every captured variable and the kernel
+// arguments to scratch: 432 bytes per lane at L = 4) -- except in the L = 16 build, which sits at
+// the register limit and is better off with the call.
+#if defined(CI_L) && CI_L >= 16
+#define CI_HMC_INLINE
+#else
+#define CI_HMC_INLINE __attribute__((always_inline))
+#endif
+
 namespace ci {
 
 constexpr int HMC_MAXDIM = 3 * MAXP + 5;
@@ -66,6 +75,8 @@ struct HmcArgs {
   double target_accept, eps0;
   const double* init;       // optional [C, dim] unconstrained starting points (e.g. draws of a
                             // fitted surrogate posterior); NULL = the Gibbs sampler's initial state
+  int legacy_driver;        // tests: 1 = the round 2-4 driver (five barriers around every score), whatever dim
+  long long* prof;          // tools/exp_hmc_phases.py: 32 cycle counters of chain 0's thread 0, or NULL
   double* draws;            // [C, S, 3 + P]  (sigma_obs, sigma_level, sigma_slope, beta)
   double* accept_rate;      // [C]
   double* step_size;        // [C]
@@ -119,8 +130,9 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
   double* sc = hsc + MAXP;             // scalars: [0] ll, [1] lp of the trajectory, [2] lp current
   // feature-major design matrix, zero padded to NT * L columns, resident in LDS for the whole fit
   // (every leapfrog step reads it twice: residual and d l / d beta)
+  double* pre = sc + 8;                // fused driver: theta-only pieces of the prior terms   [64]
   constexpr int TPAD = NT * L;
-  float* Xs = (float*)(sc + 8);
+  float* Xs = (float*)(pre + 64);
   const bool x_in_lds = a.x_in_lds != 0;
   if (x_in_lds) {
     for (int j = 0; j < P; ++j)
@@ -130,88 +142,175 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
   Rng rng{a.seed0, a.seed1, (uint32_t)(a.chain_offset + chain)};
 
   // d beta_j / d z_j of the horseshoe at the unconstrained point v
-  auto hs_scale = [&](const double* v, int j) {
+  auto hs_scale = [&](const double* v, int j) CI_HMC_INLINE {
     return exp(clamp30(v[P + j]) + 0.5 * clamp30(v[2 * P + j]) + clamp30(v[3 * P]) +
                0.5 * clamp30(v[3 * P + 1])) * a.hs_scale0;
   };
 
-  // log posterior and gradient at th -> sc[1], g   (all threads; contains barriers)
-  auto target = [&]() {
-    if (tid < P) {
+  // The per-coordinate work of a leapfrog step -- momentum / position update, the device layout of
+  // the new position, prior terms, second momentum half step -- is a few float64 lanes.  When the
+  // whole parameter vector fits one wavefront (dim <= 64: cfg3 has 14 coordinates, its horseshoe
+  // form 38) lane i of wave 0 owns coordinate i, and what the prior terms need of the POSITION alone
+  // (Omega th, exp(-2 lam) = a float64 division, the horseshoe's exponentials: 1.7k of the 2.4k cycles
+  // they cost after the score) is computed by waves 1 and 2 while wave 0 sums the waves' shares of
+  // the score in float64 -- beside the score's tail instead of after it.  The slab prior's Omega column stays in registers for
+  // P <= 16 (the loop was 11 dependent LDS + L2 round trips), the observations too (a round trip to
+  // L2 per leapfrog step).  Same expressions in the same order as the general driver below: the two
+  // give the same bits (tests/test_gpu_hmc.py); phase cycles: tools/exp_hmc_phases.py.
+  const bool fused = dim <= 64 && a.legacy_driver == 0;
+  const bool om_regs = !hs && P <= 16 && L <= 4;      // (the L = 8, 16 builds have no registers to spare)
+  double om[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) om[k] = (om_regs && lane < P && k < P) ? a.omega[k * P + lane] : 0.0;
+  double my_iga = 0.0, my_igb = 0.0;
+  // (a select chain: a run-time index into the by-value arguments would move them to scratch)
+  const double iga0 = a.ig_a[0], iga1 = a.ig_a[1], iga2 = a.ig_a[2];
+  const double igb0 = a.ig_b[0], igb1 = a.ig_b[1], igb2 = a.ig_b[2];
+  const double il0 = a.init_log[0], il1 = a.init_log[1], il2 = a.init_log[2];
+  auto pick3 = [](double v0, double v1, double v2, int k) { return k == 0 ? v0 : (k == 1 ? v1 : v2); };
+  if (lane >= off_sc && lane < dim && dim <= 64) {
+    my_iga = pick3(iga0, iga1, iga2, lane - off_sc);
+    my_igb = pick3(igb0, igb1, igb2, lane - off_sc);
+  }
+
+  // device layout of th (threads 0 .. P-1, 64 .. 66, 128; or, fused, the lanes of wave 0)
+  auto prep_dev = [&](bool on_wave0) CI_HMC_INLINE {
+    const int jb = on_wave0 ? lane : tid;
+    if (jb < P && (!on_wave0 || wave == 0)) {
       if (hs) {
-        const double s = hs_scale(th, tid);
-        hsc[tid] = s;
-        dev[3 + tid] = th[tid] * s;
+        const double s = hs_scale(th, jb);
+        hsc[jb] = s;
+        dev[3 + jb] = th[jb] * s;
       } else {
-        dev[3 + tid] = th[tid];
+        dev[3 + jb] = th[jb];
       }
     }
-    if (tid >= 64 && tid < 64 + NSC) dev[tid - 64] = exp(clamp30(th[off_sc + tid - 64]));
-    if (D == 1 && tid == 128) dev[2] = 0.0;
-    __syncthreads();
+    if (on_wave0) {
+      if (lane >= off_sc && lane < dim) dev[lane - off_sc] = exp(clamp30(th[lane]));
+      if (D == 1 && lane == 0) dev[2] = 0.0;
+    } else {
+      if (tid >= 64 && tid < 64 + NSC) dev[tid - 64] = exp(clamp30(th[off_sc + tid - 64]));
+      if (D == 1 && tid == 128) dev[2] = 0.0;
+    }
+  };
+  Prof hp;
+  hp.start(a.prof, a.prof != nullptr && blockIdx.x == 0 && tid == 0);
+  // the thread's own observations stay in registers for the whole fit (the L = 16 build, at the
+  // register limit already, reloads them per evaluation)
+  float yv[L];
+  uint32_t maskbits;
+  if constexpr (L <= 8) loglik_load_obs<L>(T, a.y, a.mask, tid, yv, maskbits);
+  auto score = [&]() CI_HMC_INLINE {
+    if constexpr (L > 8) loglik_load_obs<L>(T, a.y, a.mask, tid, yv, maskbits);
     if (x_in_lds)
-      loglik_grad_block<D, L>(T, P, a.y, a.mask, Xs, dev, a.a1, a.p10, a.p11, slots, part, &sc[0],
-                              gdev, tid, lane, wave, TPAD);
+      loglik_grad_block_obs<D, L>(T, P, yv, maskbits, Xs, dev, a.a1, a.p10, a.p11, slots, part, &sc[0],
+                                  gdev, tid, lane, wave, TPAD, &hp);
     else
-      loglik_grad_block<D, L>(T, P, a.y, a.mask, a.Xt, dev, a.a1, a.p10, a.p11, slots, part, &sc[0],
-                              gdev, tid, lane, wave);
-    __syncthreads();
-    if (wave == 0) {
-      double sgb = 0.0;                    // horseshoe: sum_j beta_j dl/dbeta_j
-      if (hs) {
-        for (int j = lane; j < P; j += 64) sgb = fma(gdev[3 + j], dev[3 + j], sgb);
-        sgb = wave_sum_d(sgb);
-      }
-      double contrib = 0.0;
-      for (int i = lane; i < dim; i += 64) {
-        double ci, gi;
-        if (i >= off_sc) {
-          const int k = i - off_sc;
-          const double lam = clamp30(th[i]);
-          const double e2 = 1.0 / (dev[k] * dev[k]);       // exp(-2 lam): dev[k] = exp(lam)
-          ci = -2.0 * a.ig_a[k] * lam - a.ig_b[k] * e2;
-          gi = dev[k] * gdev[k] - 2.0 * a.ig_a[k] + 2.0 * a.ig_b[k] * e2;
-        } else if (!hs) {
-          double ob = 0.0;
-          for (int k = 0; k < P; ++k) ob = fma(th[k], a.omega[k * P + i], ob);
-          ci = -0.5 * th[i] * ob;
-          gi = gdev[3 + i] - ob;
-        } else if (i < P) {                  // z_j ~ N(0, 1)
-          const double z = th[i];
-          ci = -0.5 * z * z;
-          gi = gdev[3 + i] * hsc[i] - z;
-        } else if (i < 2 * P) {              // log of a HalfNormal(1) local scale
-          const int j = i - P;
-          const double e = exp(2.0 * clamp30(th[i]));
-          ci = -0.5 * e + clamp30(th[i]);
-          gi = gdev[3 + j] * dev[3 + j] - e + 1.0;
-        } else if (i < 3 * P) {              // log of an InverseGamma(1/2, 1/2) local variance
-          const int j = i - 2 * P;
-          const double u = clamp30(th[i]);
-          const double e = exp(-u);
-          ci = -0.5 * u - 0.5 * e;
-          gi = 0.5 * gdev[3 + j] * dev[3 + j] - 0.5 + 0.5 * e;
-        } else if (i == 3 * P) {             // log of the HalfNormal(1) global scale
-          const double e = exp(2.0 * clamp30(th[i]));
-          ci = -0.5 * e + clamp30(th[i]);
-          gi = sgb - e + 1.0;
-        } else {                             // log of the InverseGamma(1/2, 1/2) global variance
-          const double u = clamp30(th[i]);
-          const double e = exp(-u);
-          ci = -0.5 * u - 0.5 * e;
-          gi = 0.5 * sgb - 0.5 + 0.5 * e;
-        }
-        contrib += ci;
-        g[i] = gi;
-      }
-      double lp = sc[0] + wave_sum_d(contrib);
-      const bool bad = !(lp == lp) || lp > 1e300 || lp < -1e300;
-      if (bad) {
-        lp = -INFINITY;
-        for (int i = lane; i < dim; i += 64) g[i] = 0.0;
-      }
-      if (lane == 0) sc[1] = lp;
+      loglik_grad_block_obs<D, L>(T, P, yv, maskbits, a.Xt, dev, a.a1, a.p10, a.p11, slots, part, &sc[0],
+                                  gdev, tid, lane, wave, 0, &hp);
+  };
+  // Omega th for coordinate i (slab prior): the column from registers (P <= 16, i == lane) or L2
+  auto omega_dot = [&](int i) CI_HMC_INLINE {
+    double ob = 0.0;
+    if (om_regs) {
+      double tk[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tk[k] = th[k < P ? k : 0];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ob = k < P ? fma(tk[k], om[k], ob) : ob;
+    } else {
+      for (int k = 0; k < P; ++k) ob = fma(th[k], a.omega[k * P + i], ob);
     }
+    return ob;
+  };
+  // fused driver: the expensive pieces of the prior terms that need the position only -- Omega th,
+  // exp(-2 lam) (a float64 division), the horseshoe's exponentials -- by waves 1 and 2 while wave 0
+  // finishes the score (its float64 block sums); prior_terms(true) reads them back.  The same expressions
+  // as prior_terms(false) evaluates in place.
+  auto prior_pre = [&]() CI_HMC_INLINE {
+    const int i = lane;
+    if (wave == 1 && i < off_sc) {
+      double v = 0.0;
+      if (!hs) v = omega_dot(i);
+      else if (i < P) v = 0.0;
+      else if (i < 2 * P) v = exp(2.0 * clamp30(th[i]));
+      else if (i < 3 * P) v = exp(-clamp30(th[i]));
+      else if (i == 3 * P) v = exp(2.0 * clamp30(th[i]));
+      else v = exp(-clamp30(th[i]));
+      pre[i] = v;
+    }
+    if (wave == 2 && i >= off_sc && i < dim) {
+      const double d = dev[i - off_sc];                    // exp(lam_k), laid out before the score
+      pre[i] = 1.0 / (d * d);
+    }
+  };
+  // prior terms + Jacobians: g, sc[1] (wave 0)
+  auto prior_terms = [&](const bool use_pre) CI_HMC_INLINE {
+    double sgb = 0.0;                    // horseshoe: sum_j beta_j dl/dbeta_j
+    if (hs) {
+      for (int j = lane; j < P; j += 64) sgb = fma(gdev[3 + j], dev[3 + j], sgb);
+      sgb = wave_sum_d(sgb);
+    }
+    hp.tick(15);
+    double contrib = 0.0;
+    for (int i = lane; i < dim; i += 64) {
+      double ci, gi;
+      if (i >= off_sc) {
+        const int k = i - off_sc;
+        const double lam = clamp30(th[i]);
+        const double e2 = use_pre ? pre[i] : 1.0 / (dev[k] * dev[k]);   // exp(-2 lam): dev[k] = exp(lam)
+        const double iga = dim <= 64 ? my_iga : pick3(iga0, iga1, iga2, k), igb = dim <= 64 ? my_igb : pick3(igb0, igb1, igb2, k);
+        ci = -2.0 * iga * lam - igb * e2;
+        gi = dev[k] * gdev[k] - 2.0 * iga + 2.0 * igb * e2;
+      } else if (!hs) {
+        const double ob = use_pre ? pre[i] : omega_dot(i);
+        ci = -0.5 * th[i] * ob;
+        gi = gdev[3 + i] - ob;
+      } else if (i < P) {                  // z_j ~ N(0, 1)
+        const double z = th[i];
+        ci = -0.5 * z * z;
+        gi = gdev[3 + i] * hsc[i] - z;
+      } else if (i < 2 * P) {              // log of a HalfNormal(1) local scale
+        const int j = i - P;
+        const double e = use_pre ? pre[i] : exp(2.0 * clamp30(th[i]));
+        ci = -0.5 * e + clamp30(th[i]);
+        gi = gdev[3 + j] * dev[3 + j] - e + 1.0;
+      } else if (i < 3 * P) {              // log of an InverseGamma(1/2, 1/2) local variance
+        const int j = i - 2 * P;
+        const double u = clamp30(th[i]);
+        const double e = use_pre ? pre[i] : exp(-u);
+        ci = -0.5 * u - 0.5 * e;
+        gi = 0.5 * gdev[3 + j] * dev[3 + j] - 0.5 + 0.5 * e;
+      } else if (i == 3 * P) {             // log of the HalfNormal(1) global scale
+        const double e = use_pre ? pre[i] : exp(2.0 * clamp30(th[i]));
+        ci = -0.5 * e + clamp30(th[i]);
+        gi = sgb - e + 1.0;
+      } else {                             // log of the InverseGamma(1/2, 1/2) global variance
+        const double u = clamp30(th[i]);
+        const double e = use_pre ? pre[i] : exp(-u);
+        ci = -0.5 * u - 0.5 * e;
+        gi = 0.5 * sgb - 0.5 + 0.5 * e;
+      }
+      contrib += ci;
+      g[i] = gi;
+    }
+    hp.tick(16);
+    double lp = sc[0] + wave_sum_d(contrib);
+    hp.tick(17);
+    const bool bad = !(lp == lp) || lp > 1e300 || lp < -1e300;
+    if (bad) {
+      lp = -INFINITY;
+      for (int i = lane; i < dim; i += 64) g[i] = 0.0;
+    }
+    if (lane == 0) sc[1] = lp;
+  };
+  // log posterior and gradient at th -> sc[1], g   (all threads; contains barriers)
+  auto target = [&]() CI_HMC_INLINE {
+    prep_dev(false);
+    __syncthreads();
+    score();
+    __syncthreads();
+    if (wave == 0) prior_terms(false);
     __syncthreads();
   };
 
@@ -219,7 +318,7 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
   // (horseshoe: all auxiliary log scales 0, z = 0)
   if (tid < dim) {
     double v = 0.0;
-    if (tid >= off_sc) v = a.init_log[tid - off_sc];
+    if (tid >= off_sc) v = pick3(il0, il1, il2, tid - off_sc);
     if (a.init) th[tid] = a.init[(size_t)chain * dim + tid];
     else th[tid] = v + 0.01 * normal_d(rng, 0u, SITE_HMC_INIT, 0, (uint32_t)tid);
     imass[tid] = 1.0;
@@ -253,16 +352,46 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
       for (int i = lane; i < dim; i += 64) kin = fma(0.5 * mom[i] * mom[i], imass[i], kin);
       h0 = -sc[2] + wave_sum_d(kin);
     }
-    for (int l = 0; l < a.n_leap; ++l) {
-      if (tid < dim) {
-        const double ph = mom[tid] + 0.5 * eps * g[tid];
-        mom[tid] = ph;
-        th[tid] += eps * imass[tid] * ph;
+    hp.tick(7);
+    if (fused) {
+      for (int l = 0; l < a.n_leap; ++l) {
+        if (wave == 0) {
+          if (lane < dim) {
+            const double ph = mom[lane] + 0.5 * eps * g[lane];
+            mom[lane] = ph;
+            th[lane] += eps * imass[lane] * ph;
+          }
+          wave_sync();                     // the new position, before the cross-lane reads below
+          prep_dev(true);
+        }
+        hp.tick(0);
+        __syncthreads();                   // position in device layout
+        hp.tick(1);
+        score();                           // (ends with wave 0 summing the waves' shares in float64 ...
+        if (wave != 0) prior_pre();        //  ... while waves 1 and 2 prepare the prior terms)
+        __syncthreads();                   // ll, score, prior pieces in LDS
+        hp.tick(2);
+        if (wave == 0) {
+          prior_terms(true);
+          hp.tick(3);
+          wave_sync();                     // g, sc[1]
+          if (lane < dim) mom[lane] += 0.5 * eps * g[lane];
+        }
+        hp.tick(4);
       }
-      __syncthreads();
-      target();
-      if (tid < dim) mom[tid] += 0.5 * eps * g[tid];
-      __syncthreads();
+      if (wave == 0) wave_sync();
+    } else {
+      for (int l = 0; l < a.n_leap; ++l) {
+        if (tid < dim) {
+          const double ph = mom[tid] + 0.5 * eps * g[tid];
+          mom[tid] = ph;
+          th[tid] += eps * imass[tid] * ph;
+        }
+        __syncthreads();
+        target();
+        if (tid < dim) mom[tid] += 0.5 * eps * g[tid];
+        __syncthreads();
+      }
     }
     // Metropolis test (wave 0), broadcast through LDS
     if (wave == 0) {
@@ -335,7 +464,7 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
 
 __host__ __device__ inline size_t hmc_lds_bytes(int P, int tpad_if_x_in_lds) {
   const size_t f = (((size_t)(3 * NW * 16 + NW * (P + 4)) * sizeof(float)) + 15) & ~(size_t)15;
-  return f + sizeof(double) * (6 * HMC_MAXDIM + 2 * (MAXP + 3) + MAXP + 8) +
+  return f + sizeof(double) * (6 * HMC_MAXDIM + 2 * (MAXP + 3) + MAXP + 8 + 64) +
          sizeof(float) * (size_t)P * tpad_if_x_in_lds;
 }
 

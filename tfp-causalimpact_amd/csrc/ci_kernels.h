@@ -568,6 +568,7 @@ __device__ __forceinline__ void kalman_filter_pass(const DkModel<D>& md, const V
       }
     }
   }
+  prof.tick(21);
   const FElemS<D> fpre = block_scan_excl_fwd(
       fe, [](const FElemS<D>& a, const FElemS<D>& b) { return felems_combine(a, b); },
       felems_identity<D>(), slots16, lane, wave);
@@ -3266,28 +3267,44 @@ __device__ __forceinline__ RNElem<D> rnelem_compose(const RNElem<D>& o, const RN
 // by the whole 256-thread workgroup: ll -> *out_ll, d ll / d th -> out_grad[3 + P].  Contains
 // __syncthreads(); slots: 3 * NW * 16 floats, part: NW * (P + 4) floats (LDS).  The results are
 // written by threads 0 .. P+3: the caller synchronises before reading them.
+// The thread's own observations (0 where masked or beyond T) and their mask bits: callers that
+// evaluate many parameter sets load them once (hmc_kernel: a round trip to L2 per leapfrog step).
+template <int L>
+__device__ __forceinline__ void loglik_load_obs(int T, const float* __restrict__ y,
+                                                const uint8_t* __restrict__ mask, int tid,
+                                                float (&yv)[L], uint32_t& maskbits) {
+  const int t0 = tid * L;
+  maskbits = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int t = t0 + l;
+    const bool obs = t < T && !mask[t];
+    yv[l] = obs ? y[t] : 0.f;
+    if (!obs) maskbits |= 1u << l;
+  }
+}
+
 template <int D, int L>
-__device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __restrict__ y,
-                                                  const uint8_t* __restrict__ mask,
-                                                  const float* __restrict__ Xt, const double* th,
-                                                  float a1, float p10, float p11, float* slots,
-                                                  float* part, double* out_ll, double* out_grad,
-                                                  int tid, int lane, int wave, int xstride = 0) {
+__device__ __forceinline__ void loglik_grad_block_obs(int T, int P, const float (&yv)[L],
+                                                      const uint32_t maskbits,
+                                                      const float* __restrict__ Xt, const double* th,
+                                                      float a1, float p10, float p11, float* slots,
+                                                      float* part, double* out_ll, double* out_grad,
+                                                      int tid, int lane, int wave, int xstride = 0,
+                                                      Prof* pf = nullptr) {
   // Xt: feature-major design, row j at Xt + j * xs (xs = T for the matrix in HBM; callers that
   // evaluate many parameter sets keep a zero-padded copy in LDS and pass its row length)
   const size_t xs = xstride ? (size_t)xstride : (size_t)T;
   const int t0 = tid * L;
   float resid[L];
-  uint32_t maskbits = 0;
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const int t = t0 + l;
-    const bool obs = t < T && !mask[t];
-    resid[l] = obs ? y[t] : 0.f;
-    if (!obs) maskbits |= 1u << l;
-  }
+  for (int l = 0; l < L; ++l) resid[l] = yv[l];
   // the caller's zero-padded copy of the design (xstride != 0: rows of a multiple of 4 floats in
   // LDS) is read as whole rows of the L owned steps; the matrix in HBM step by step
+  Prof prof;                       // (phase cycles for tools/exp_hmc_phases.py; inert in production)
+  prof.p = pf ? pf->p : nullptr;
+  prof.t = pf ? pf->t : 0;
+  prof.tick(20);
   const bool rows = xstride != 0 && (xstride & 3) == 0;
   // the design streamed from HBM / L2 (xstride == 0): float4 rows when every row is 16-byte aligned.
   // The row source is chosen OUTSIDE the loops over features (see global_row_load_wide) and the
@@ -3306,18 +3323,26 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
     }
   };
   with_rows([&](auto load_row) {
-    for (int j0 = 0; j0 < P; j0 += 4) {
-      float xr[4][L], bj[4];
+    // (a zero weight beyond P adds an exact zero; the sums run over j in ascending order either way)
+    auto batch = [&](int j0, auto nb) __attribute__((always_inline)) {
+      constexpr int NB = decltype(nb)::value;
+      float xr[NB][L], bj[NB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int j = j0 + u < P ? j0 + u : P - 1;
         bj[u] = j0 + u < P ? (float)th[3 + j] : 0.f;
         load_row(j, xr[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < NB; ++u)
 #pragma unroll
         for (int l = 0; l < L; ++l) resid[l] = fmaf(-xr[u][l], bj[u], resid[l]);
+    };
+    if (L <= 4 && P > 4 && P <= 12) {
+      // every row of a small design in flight at once: one LDS / L2 latency instead of three
+      batch(0, std::integral_constant<int, 12>());
+    } else {
+      for (int j0 = 0; j0 < P; j0 += 4) batch(j0, std::integral_constant<int, 4>());
     }
   });
 #pragma unroll
@@ -3341,10 +3366,10 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
   Mat<D> Pp[L];
   Vec<D> kf[L];
   float vf[L], fvar[L];
-  Prof prof;
-  prof.start(nullptr, false);
+  prof.tick(8);
   kalman_filter_pass<D, L>(md, md.a1, q, resid, maskbits, tid, lane, wave, slots, ap, Pp, kf, vf,
                            fvar, prof);
+  prof.tick(9);
   float ll = 0.f;
 #pragma unroll
   for (int l = 0; l < L; ++l)
@@ -3374,9 +3399,11 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
   RNElem<D> rntot = rn_map(L - 1);
 #pragma unroll
   for (int l = L - 2; l >= 0; --l) rntot = rnelem_compose(rn_map(l), rntot);
+  prof.tick(10);
   const RNElem<D> rnsuf = block_scan_excl_bwd(
       rntot, [](const RNElem<D>& o, const RNElem<D>& i) { return rnelem_compose(o, i); },
       rnelem_identity<D>(), slots + NW * 16, lane, wave);
+  prof.tick(11);
 
   float gH = 0.f, gQ[D], e_l[L];
 #pragma unroll
@@ -3422,6 +3449,7 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
       }
     }
   }
+  prof.tick(12);
   // block sums: ll, dH, dQ[0], dQ[1], then dbeta_j
   const int NS = P + 4;
   // d l / d beta_j = sum_t x_jt e_t: rows in batches of 4 independent loads, 16 wave sums per
@@ -3451,6 +3479,7 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
       dots4(0, v16 + 4);
       dots4(4, v16 + 8);
       dots4(8, v16 + 12);
+      prof.tick(22);
       const float tot = wave_reduce_scatter16(v16, lane);
       if (lane < 16 && lane < NS) part[wave * NS + lane] = tot;
     }
@@ -3464,6 +3493,7 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
       if (lane < 16 && j0 + lane < P) part[wave * NS + 4 + j0 + lane] = tot;
     }
   });
+  prof.tick(13);
   __syncthreads();
   if (tid < NS) {
     double s = 0.0;
@@ -3477,6 +3507,22 @@ __device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __r
       else g[3 + (tid - 4)] = s;                       // d/d beta_j
     }
   }
+  prof.tick(14);
+  if (pf) pf->t = prof.t;
+}
+
+template <int D, int L>
+__device__ __forceinline__ void loglik_grad_block(int T, int P, const float* __restrict__ y,
+                                                  const uint8_t* __restrict__ mask,
+                                                  const float* __restrict__ Xt, const double* th,
+                                                  float a1, float p10, float p11, float* slots,
+                                                  float* part, double* out_ll, double* out_grad,
+                                                  int tid, int lane, int wave, int xstride = 0) {
+  float yv[L];
+  uint32_t maskbits;
+  loglik_load_obs<L>(T, y, mask, tid, yv, maskbits);
+  loglik_grad_block_obs<D, L>(T, P, yv, maskbits, Xt, th, a1, p10, p11, slots, part, out_ll, out_grad,
+                              tid, lane, wave, xstride);
 }
 
 template <int D, int L>

@@ -114,3 +114,49 @@ def test_argument_errors_match_reference_behaviour():
     cid.CausalImpactData(df, (df.index[10], df.index[1]), (df.index[40], df.index[-1]))
   assert lib.InferenceOptions().num_warmup_steps == 100              # ceil(900 / 9)
   assert lib.InferenceOptions(num_results=1000).num_warmup_steps == 112
+
+
+def _estimates_case(kind):
+  rng = np.random.default_rng(10 + kind)
+  T, p = 400, 3
+  X = rng.normal(size=(T, p))
+  y = X[:, 0] + np.cumsum(rng.normal(scale=0.05, size=T)) + rng.normal(scale=0.3, size=T)
+  df = pd.DataFrame(np.column_stack([y, X]), columns=["y"] + [f"x{i}" for i in range(p)])
+  if kind == 0:
+    return df, (0, 279), (280, 399)
+  if kind == 1:      # a gap, a tail, missing outcome values, a datetime index
+    df.index = pd.date_range("2020-01-01", periods=T, freq="D")
+    df.iloc[[5, 6, 250, 300, 301, 355], 0] = np.nan
+    return df, ("2020-01-01", "2020-09-20"), ("2020-10-05", "2021-01-10")
+  df = df[["y"]].copy()      # no covariates, an integer index that does not start at 0
+  df.index = np.arange(100, 100 + T)
+  df.iloc[[320], 0] = np.nan
+  return df, (0, 249), (260, 379)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_series_frame_from_arrays_equals_the_frame_by_frame_construction(kind):
+  """`_compute_impact_estimates` builds the 14-column `series` frame from arrays in one
+  constructor call (round 5: 4 ms -> 1 ms of host time per fit); its frame-by-frame predecessor
+  (`_compute_impact_estimates_frames`, the restatement of causalimpact_lib.py:840-931 that the
+  reference-generated goldens above pin) stays as the route for unusual dtypes.  Same values bit
+  for bit, same dtypes, columns and index object type -- with a gap, a tail, missing outcomes, a
+  datetime index and no covariates."""
+  from causalimpact import posterior_processing as pp
+  df, pre, post = _estimates_case(kind)
+  cd = cid.CausalImpactData(df, pre, post)
+  idx = pp.model_index(cd)
+  rng = np.random.default_rng(kind)
+  n = len(idx)
+  ts = pd.DataFrame({c: rng.normal(size=n) for c in ("posterior_mean", "posterior_lower", "posterior_upper")},
+                    index=idx)
+  bands = {k: pd.DataFrame({k + "_lower": rng.normal(size=n), k + "_upper": rng.normal(size=n)}, index=idx)
+           for k in ("point_effects", "cumulative_effects")}
+  _, obs_full = lib._observed_series(cd)
+  fast = lib._compute_impact_estimates(posterior_trajectory_summary=ts, trajectory_dict=None,
+                                       observed_ts_full=obs_full, ci_data=cd, quantiles=(0.025, 0.975),
+                                       bands=bands)
+  slow = lib._compute_impact_estimates_frames(ts, obs_full, cd, bands)
+  pd.testing.assert_frame_equal(slow, fast, check_exact=True)
+  assert list(slow.dtypes) == list(fast.dtypes) and type(slow.index) is type(fast.index)
+  assert fast["point_effects_mean"].isna().any() == slow["point_effects_mean"].isna().any()

@@ -36,6 +36,19 @@ def _validate_data_and_columns(data: pd.DataFrame, outcome_column: Optional[str]
     outcome_column = data.columns[0]
   if outcome_column not in data.columns:
     raise KeyError(f"Specified `outcome_column` ({outcome_column}) not found in data")
+  if standardize._all_float64(data) and data.columns.is_unique:
+    # the same checks, in the same order, on the values (float64 frames: every ordinary call)
+    y = data[outcome_column].to_numpy()
+    seen = y[~np.isnan(y)]
+    if seen.size > 0 and seen.std() == 0:
+      raise ValueError("Input response cannot be constant.")
+    feature_columns = [c for c in data.columns if c != outcome_column] if data.shape[1] > 1 else None
+    data = data[[outcome_column] + (feature_columns or [])]
+    if seen.size < 3:
+      raise ValueError("Input data must have at least 3 observations.")
+    if feature_columns and np.isnan(data.to_numpy()[:, 1:]).any():
+      raise ValueError("Input data cannot have any missing values.")
+    return data, outcome_column, feature_columns
   if data[outcome_column].std(skipna=True, ddof=0) == 0:
     raise ValueError("Input response cannot be constant.")
   feature_columns = [c for c in data.columns if c != outcome_column] if data.shape[1] > 1 else None
@@ -88,8 +101,18 @@ class CausalImpactData:
     series = np.asarray(self.model_pre_data[self.outcome_column], dtype=_as_numpy_dtype(dtype))
     self.outcome_ts = MaskedTimeSeries(time_series=series, is_missing=np.isnan(series))
     if self.feature_columns is not None:
-      self.feature_ts = pd.concat([self.model_pre_data[self.feature_columns],
-                                   self.model_after_pre_data[self.feature_columns]], axis=0)
-      self.feature_ts["intercept_"] = 1.0          # last column (data.py:135)
+      # the covariates over pre-period + forecast steps, then the intercept as the LAST column
+      # (data.py:130-135) -- one frame from the values instead of concat + setitem
+      pre_f = self.model_pre_data[self.feature_columns]
+      aft_f = self.model_after_pre_data[self.feature_columns]
+      if standardize._all_float64(pre_f) and standardize._all_float64(aft_f) \
+          and "intercept_" not in self.feature_columns:
+        vals = np.concatenate([pre_f.to_numpy(), aft_f.to_numpy()], axis=0)
+        vals = np.concatenate([vals, np.ones((vals.shape[0], 1), dtype=vals.dtype)], axis=1)
+        self.feature_ts = pd.DataFrame(vals, index=pre_f.index.append(aft_f.index),
+                                       columns=list(self.feature_columns) + ["intercept_"])
+      else:
+        self.feature_ts = pd.concat([pre_f, aft_f], axis=0)
+        self.feature_ts["intercept_"] = 1.0
     else:
       self.feature_ts = None

@@ -11,6 +11,11 @@ import numpy as np
 import pandas as pd
 
 
+def _all_float64(df: pd.DataFrame) -> bool:
+  dts = df.dtypes.to_numpy()
+  return len(dts) > 0 and dts[0] == np.float64 and bool((dts == dts[0]).all())
+
+
 class NotFittedError(ValueError, AttributeError):
   """Scaler used before fit()."""
 
@@ -34,6 +39,13 @@ class Scaler:
 
   def transform(self, df: pd.DataFrame) -> pd.DataFrame:
     self._require_fit()
+    if isinstance(df, pd.DataFrame) and _all_float64(df):
+      # plain float frames (every fit): the same IEEE operations on the values, without pandas'
+      # alignment machinery (1 ms of a 13 ms fit_causalimpact call)
+      v = df.to_numpy()
+      with np.errstate(invalid="ignore", divide="ignore"):
+        scaled = np.where(self.stddev_ > 0, (v - self.mean_) / self.stddev_, v)
+      return pd.DataFrame(scaled, index=df.index, columns=df.columns)
     scaled = np.where(self.stddev_ > 0, (df - self.mean_) / self.stddev_, df)
     return pd.DataFrame(scaled, index=df.index, columns=df.columns)
 

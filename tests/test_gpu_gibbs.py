@@ -587,6 +587,11 @@ WS = _native.FLAG_SEASONAL_WORKSPACE
     (1200, 8, 1, ((24, 1), (7, 24)), 0),     # hour-of-day + day-of-week + trend: D = 33 > 32 -> sequential
     (1200, 8, 0, ((24, 1), (7, 24)), 0),     # ... without the slope: D = 32, four register chunks
     (900, 70, 0, REF_SEASONS, 0),            # P = 71 > 52: the workspace regression block on wave 0
+    # every register width of the time-parallel kernel (8..32 columns in steps of 4) has a case:
+    (112, 3, 0, REF_SEASONS, 0),             # the shortest series on this route (4 chunks of 28 steps)
+    (130, 2, 1, ((5, 1), (3, 5)), 0),        # D = 10: 12 columns
+    (400, 4, 1, ((12, 1), (7, 12)), 0),      # D = 21: 24 columns
+    (400, 4, 1, ((24, 1),), 0),              # D = 26: 28 columns
 ])
 def test_general_seasonal_models_beyond_the_lds_bound_match_oracle_per_draw(T, p, has_slope, seasons,
                                                                            flags):

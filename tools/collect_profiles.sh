@@ -50,5 +50,8 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/tp_pmc_fetch
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/tp_pmc_write" -o tp -- python tools/run_configs.py general_gpu > "$OUT/tp_pmc_write.log" 2>&1
 timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/tp_pmc_sq" -o tp -- python tools/run_configs.py general_gpu > "$OUT/tp_pmc_sq.log" 2>&1
 if [ -x tools/build/bench_tp_combine ]; then timeout 120 tools/build/bench_tp_combine > "$OUT/tp_combine_bench.txt" 2>&1; fi
+# ---- round 5: phase cycles of an HMC leapfrog step (cfg3), host profile of fit_causalimpact
+timeout 200 python tools/exp_hmc_phases.py > "$OUT/hmc_phase_cycles.txt" 2>&1
+timeout 200 python tools/profile_e2e.py 10 2>&1 | head -70 | cut -c1-160 > "$OUT/e2e_host_profile.txt"
 find "$OUT" -name "*.csv" | wc -l
 tail -1 "$OUT/bench.json" | cut -c1-400

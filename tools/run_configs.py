@@ -164,7 +164,7 @@ def general_seasonal(chains=8, S=100, with_cpu=True):
   return out
 
 
-def cfg5(B, S=1000):
+def cfg5(B, S=1000, with_cpu=False):
   T, p = 500, 5
   frames = []
   for b in range(B):
@@ -185,13 +185,23 @@ def cfg5(B, S=1000):
   sess = _native.Session(pb, prep.y, prep.mask, prep.design, None, _native.make_params(params))
   sess.run()
   ms = min(sess.run() for _ in range(2))
-  nbytes = sess.algorithmic_bytes()
+  nbytes, name = sess.algorithmic_bytes(), sess.kernel_name()
   sess.close()
-  return {"config": "cfg5", "workload": "independent series, T=500, 5 covariates (P=6), LocalLevel + spike-slab",
-          "series": B, "num_results": S, "num_warmup": W, "kernel_ms": ms,
-          "samples_per_s": B * S / ms * 1e3, "algorithmic_GBps": nbytes / ms / 1e6,
-          "batched_api_wall_s": wall, "batched_api_samples_per_s": B * S / wall,
-          "mean_abs_effect": float(res.summary.xs("average", level=1)["abs_effect"].mean())}
+  row = {"config": "cfg5", "workload": "independent series, T=500, 5 covariates (P=6), LocalLevel + spike-slab",
+         "kernel": name, "series": B, "num_results": S, "num_warmup": W, "kernel_ms": ms,
+         "samples_per_s": B * S / ms * 1e3, "algorithmic_GBps": nbytes / ms / 1e6,
+         "roofline": roofline(nbytes, ms),
+         "batched_api_wall_s": wall, "batched_api_samples_per_s": B * S / wall,
+         "mean_abs_effect": float(res.summary.xs("average", level=1)["abs_effect"].mean())}
+  if with_cpu:
+    # the host figure: the oracle on ONE of the series (they all cost the same), one series per core
+    from oracle import ci_oracle as orc  # pylint: disable=import-outside-toplevel
+    cpu = cpu_baseline(prep.y[0], prep.mask[0], prep.design[0],
+                       orc.default_spec(prep.y[0], prep.mask[0], prep.design[0]), 4000,
+                       "one series of the batch")
+    row["cpu_baseline"] = cpu
+    row["gpu_over_all_host_cores"] = row["samples_per_s"] / cpu["all_cores"]["value"]
+  return row
 
 
 def extras():
@@ -271,7 +281,7 @@ if __name__ == "__main__":
   if which == "cfg4":        # counter passes: one short cfg4 fit per chain count
     runs = (lambda: cfg4(1, S=200), lambda: cfg4(8, S=200))
   else:
-    runs = (lambda: cfg4(1), lambda: cfg4(8, with_cpu=True, with_traffic=True), lambda: cfg5(64), lambda: cfg5(512))
+    runs = (lambda: cfg4(1), lambda: cfg4(8, with_cpu=True, with_traffic=True), lambda: cfg5(64), lambda: cfg5(512, with_cpu=True))
   for run in runs:
     print(json.dumps(run()), flush=True)
   if which == "all":

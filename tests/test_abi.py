@@ -121,7 +121,7 @@ def test_round_3_entry_points_validate_before_any_device_call():
   assert L.ci_fit_gibbs_f64(C.byref(pb), y64.ctypes.data, m.ctypes.data, None, sc.ctypes.data, prm,
                             C.byref(out)) != 0
   assert b"too wide" in L.ci_last_error()
-  # log-likelihood sessions: blocks need create2's season_change; P is capped at 52 there
+  # log-likelihood sessions: blocks need create2's season_change; P is capped at 128 there (round 5: was 52)
   h = C.c_void_p()
   pb = _native.make_problem(T=T, P=0, has_slope=0, num_seasons=(7,), num_warmup=0, num_results=1)
   assert L.ci_ll_session_create(C.byref(pb), prm, y32.ctypes.data, m.ctypes.data, None, 4, C.byref(h)) != 0
@@ -129,11 +129,11 @@ def test_round_3_entry_points_validate_before_any_device_call():
   assert L.ci_ll_session_create2(C.byref(pb), prm, y32.ctypes.data, m.ctypes.data, None, None, 4,
                                  C.byref(h)) != 0
   assert b"season_change is NULL" in L.ci_last_error()
-  pb = _native.make_problem(T=T, P=60, has_slope=0, num_warmup=0, num_results=1)
-  X = np.zeros((T, 60), np.float32)
+  pb = _native.make_problem(T=T, P=130, has_slope=0, num_warmup=0, num_results=1)
+  X = np.zeros((T, 130), np.float32)
   assert L.ci_ll_session_create2(C.byref(pb), prm, y32.ctypes.data, m.ctypes.data, X.ctypes.data, None,
                                  4, C.byref(h)) != 0
-  assert b"P must be <= 52" in L.ci_last_error()
+  assert b"P must be <= 128" in L.ci_last_error()
   # a non-positive multiplier of the weights-prior precision is rejected
   bad = _native.make_params([dict(spec, weights_prior_scale=0.0)])
   pb = _native.make_problem(T=T, P=0, has_slope=0, num_warmup=0, num_results=1)

@@ -138,6 +138,7 @@ def _oracle_ll(spec, y, mask, X, th):
     (80, 2, 1), (300, 0, 0), (1000, 10, 1),
     (1000, 40, 1),     # more than 12 covariates: further rounds of 16 sums, float4 rows of the design
     (998, 37, 0),      # T % 4 != 0: the design read row-scalar, ragged last chunk
+    (600, 80, 1),      # round 5: more than 52 design columns on the log-likelihood path (limit 128)
 ])
 def test_loglik_score_matches_finite_differences_of_oracle(T, p, has_slope):
   """Row H: device score (two suffix scans) vs central differences of the float64 oracle

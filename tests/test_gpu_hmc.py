@@ -52,7 +52,8 @@ def test_hmc_matches_gibbs_on_quickstart_shape():
 def test_hmc_options_round_3_supports_and_what_it_still_rejects():
   """Seasonal models and series longer than 4096 steps used to raise; they now run on the
   sequential route (csrc/ci_score_seq.h).  Still rejected: a surrogate-posterior start for a
-  seasonal model, and more than 52 design columns on the log-likelihood path."""
+  seasonal model, and more than 128 design columns on the log-likelihood path (round 5: 53 ... 128
+  columns run -- `test_device_hmc_with_more_than_52_columns_tracks_the_oracle`)."""
   df = rp.create_test_data(5.0, 50, seed=1)
   with pytest.raises(NotImplementedError):
     lib.fit_causalimpact(df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
@@ -67,10 +68,17 @@ def test_hmc_options_round_3_supports_and_what_it_still_rejects():
   assert np.isfinite(res.summary.to_numpy(float)).all()
   from causalimpact import _native
   rng = np.random.default_rng(0)
-  wide = pd.DataFrame(rng.normal(size=(120, 61)), columns=["y"] + [f"x{j}" for j in range(60)])
-  with pytest.raises(_native.NativeError, match="P must be <= 52"):
-    lib.fit_causalimpact(wide, (0, 79), (80, 119),
+  wide = pd.DataFrame(rng.normal(size=(300, 131)), columns=["y"] + [f"x{j}" for j in range(130)])
+  with pytest.raises(_native.NativeError, match="P must be <= 128"):
+    lib.fit_causalimpact(wide, (0, 199), (200, 299),
                          inference_options=lib.InferenceOptions(num_results=10, sampler="hmc"))
+  # 60 covariates: the route that used to raise
+  wide = pd.DataFrame(rng.normal(size=(200, 61)), columns=["y"] + [f"x{j}" for j in range(60)])
+  wide["y"] += 0.8 * wide["x0"]
+  res = lib.fit_causalimpact(wide, (0, 139), (140, 199),
+                             inference_options=lib.InferenceOptions(num_results=20, num_warmup_steps=40,
+                                                                    sampler="hmc"))
+  assert np.isfinite(res.summary.to_numpy(float)).all()
 
 def test_device_hmc_agrees_with_host_driven_hmc_and_splits_like_gibbs():
   """The on-device chain (csrc/ci_hmc.h) against the numpy-driven sampler it replaced (same
@@ -160,6 +168,40 @@ def test_device_hmc_tracks_the_float64_oracle_draw_for_draw(prior, has_slope, T,
     np.testing.assert_allclose(arrs["posterior_trajectories"][0, c], want["trajectories"], atol=5e-2)
     np.testing.assert_allclose(arrs["posterior_means"][0, c], want["loc"].mean(axis=0), atol=3e-2)
     np.testing.assert_allclose(arrs["observation_noise_scale"][0, c], draws[c, :, 0], rtol=1e-6)
+    np.testing.assert_allclose(arrs["weights"][0, c], draws[c, :, 3:], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("prior,has_slope,T,p,W,NL", [("slab", True, 300, 60, 20, 4),
+                                                      ("horseshoe", False, 300, 60, 3, 2),
+                                                      ("slab", False, 2500, 99, 20, 4)])
+def test_device_hmc_with_more_than_52_columns_tracks_the_oracle(prior, has_slope, T, p, W, NL):
+  """Row H width (round 5): the log-likelihood / HMC path takes up to 128 design columns (it stopped
+  at 52, the LDS-resident regression block's size, which this path never used).  Draw for draw
+  against oracle/ci_oracle.c::ci_oracle_fit_hmc through a short windowed warm-up: 61 columns with
+  both priors (the horseshoe has 3 * 61 + 2 + 2 = 187 coordinates: the general driver; float32
+  round-off in the score flips a marginal accept / reject decision of such a chain within eight
+  iterations -- at 46 columns as at 61 --, so that case compares the first five iterations, where
+  device and oracle agree to 1e-7), 100 columns at T = 2500 (the
+  design streamed from L2, eight steps per thread)."""
+  from causalimpact import _model, _native
+  from causalimpact import _synthetic as syn
+  from oracle import ci_oracle as orc
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 12)
+  spec = _model.series_params(y, mask, X, has_slope=has_slope)
+  ospec = orc.default_spec(y, mask, X, has_slope=has_slope)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=has_slope, num_warmup=0, num_results=1, seed=(3, 4))
+  sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=8)
+  S, C = 2, 2
+  sess.hmc_run(num_chains=C, num_warmup=W, num_results=S, num_leapfrog=NL, seed=(3, 4), chain_offset=5,
+               prior=prior)
+  draws, acc, eps, arrs = sess.hmc_fetch()
+  sess.close()
+  for c in range(C):
+    want = orc.fit_hmc(y, mask, X, ospec, num_results=S, num_warmup=W, num_leapfrog=NL, seed=(3, 4),
+                       chain=5 + c, prior=prior)
+    np.testing.assert_allclose(eps[c], want["step_size"], rtol=3e-2)
+    np.testing.assert_allclose(draws[c], want["draws"], rtol=2e-2, atol=5e-3)
+    np.testing.assert_allclose(arrs["level"][0, c], want["level"], atol=3e-2)
     np.testing.assert_allclose(arrs["weights"][0, c], draws[c, :, 3:], rtol=1e-6, atol=1e-7)
 
 

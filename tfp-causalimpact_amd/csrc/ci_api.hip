@@ -1551,7 +1551,7 @@ int ci_ll_session_create2(const ci_problem* pb, const ci_series_params* params, 
                           int32_t max_evals, ci_ll_session** out) {
   if (validate(pb)) return 1;
   if (pb->num_blocks > 0 && !season_change) return fail("season_change is NULL but num_blocks > 0");
-  if (pb->P > ci::MAXP) return fail("log-likelihood path: P must be <= %d, got %d", ci::MAXP, pb->P);
+  if (pb->P > ci::HMC_MAXP) return fail("log-likelihood path: P must be <= %d, got %d", ci::HMC_MAXP, pb->P);
   if (!params || !y || !mask || !out || max_evals < 1) return fail("bad argument");
   if (!(params->weights_prior_scale > 0.0) || !std::isfinite(params->weights_prior_scale))
     return fail("params->weights_prior_scale must be positive and finite (1 = the reference's prior)");

@@ -41,7 +41,7 @@
 
 namespace ci {
 
-constexpr int HMC_MAXDIM = 3 * MAXP + 5;
+constexpr int HMC_MAXDIM = 3 * HMC_MAXP + 5;
 
 struct HmcWindows { int slow_begin, slow_end, first_end, base; };
 // Warm-up iterations [0, slow_begin) and [slow_end, W) adapt the step size only; mass windows tile
@@ -124,15 +124,15 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
   double* g = th + HMC_MAXDIM;         // trajectory gradient
   double* mom = g + HMC_MAXDIM;        // trajectory momentum
   double* imass = mom + HMC_MAXDIM;    // inverse mass (diagonal)
-  double* dev = imass + HMC_MAXDIM;    // device layout of th: (s_obs, s_level, s_slope, beta)   [3 + MAXP]
-  double* gdev = dev + (MAXP + 3);     // score in device layout                                 [3 + MAXP]
-  double* hsc = gdev + (MAXP + 3);     // horseshoe: d beta_j / d z_j                            [MAXP]
-  double* sc = hsc + MAXP;             // scalars: [0] ll, [1] lp of the trajectory, [2] lp current
+  double* dev = imass + HMC_MAXDIM;    // device layout of th: (s_obs, s_level, s_slope, beta)   [3 + HMC_MAXP]
+  double* gdev = dev + (HMC_MAXP + 3); // score in device layout                                 [3 + HMC_MAXP]
+  double* hsc = gdev + (HMC_MAXP + 3); // horseshoe: d beta_j / d z_j                            [HMC_MAXP]
+  double* sc = hsc + HMC_MAXP;         // scalars: [0] ll, [1] lp of the trajectory, [2] lp current
   // feature-major design matrix, zero padded to NT * L columns, resident in LDS for the whole fit
   // (every leapfrog step reads it twice: residual and d l / d beta)
-  double* pre = sc + 8;                // fused driver: theta-only pieces of the prior terms   [64]
+  double* pre = sc + 8;                // theta-only pieces of the prior terms                 [HMC_MAXDIM]
   constexpr int TPAD = NT * L;
-  float* Xs = (float*)(pre + 64);
+  float* Xs = (float*)(pre + HMC_MAXDIM);
   const bool x_in_lds = a.x_in_lds != 0;
   if (x_in_lds) {
     for (int j = 0; j < P; ++j)
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
     }
   };
   // prior terms + Jacobians: g, sc[1] (wave 0)
-  auto prior_terms = [&](const bool use_pre) CI_HMC_INLINE {
+  auto prior_terms = [&](const bool use_pre, const bool ob_pre) CI_HMC_INLINE {
     double sgb = 0.0;                    // horseshoe: sum_j beta_j dl/dbeta_j
     if (hs) {
       for (int j = lane; j < P; j += 64) sgb = fma(gdev[3 + j], dev[3 + j], sgb);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
         ci = -2.0 * iga * lam - igb * e2;
         gi = dev[k] * gdev[k] - 2.0 * iga + 2.0 * igb * e2;
       } else if (!hs) {
-        const double ob = use_pre ? pre[i] : omega_dot(i);
+        const double ob = (use_pre || ob_pre) ? pre[i] : omega_dot(i);
         ci = -0.5 * th[i] * ob;
         gi = gdev[3 + i] - ob;
       } else if (i < P) {                  // z_j ~ N(0, 1)
@@ -305,12 +305,17 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
     if (lane == 0) sc[1] = lp;
   };
   // log posterior and gradient at th -> sc[1], g   (all threads; contains barriers)
+  // General driver with many columns: Omega th by one thread per coordinate BEFORE the score (wave 0
+  // alone would walk its 64 + 64 + ... coordinates through P dependent L2 loads each after it);
+  // the same fma chain in the same order as omega_dot.
+  const bool ob_all = !hs && P > 16;
   auto target = [&]() CI_HMC_INLINE {
     prep_dev(false);
+    if (ob_all && tid < P) pre[tid] = omega_dot(tid);
     __syncthreads();
     score();
     __syncthreads();
-    if (wave == 0) prior_terms(false);
+    if (wave == 0) prior_terms(false, ob_all);
     __syncthreads();
   };
 
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
         __syncthreads();                   // ll, score, prior pieces in LDS
         hp.tick(2);
         if (wave == 0) {
-          prior_terms(true);
+          prior_terms(true, false);
           hp.tick(3);
           wave_sync();                     // g, sc[1]
           if (lane < dim) mom[lane] += 0.5 * eps * g[lane];
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
 
 __host__ __device__ inline size_t hmc_lds_bytes(int P, int tpad_if_x_in_lds) {
   const size_t f = (((size_t)(3 * NW * 16 + NW * (P + 4)) * sizeof(float)) + 15) & ~(size_t)15;
-  return f + sizeof(double) * (6 * HMC_MAXDIM + 2 * (MAXP + 3) + MAXP + 8 + 64) +
+  return f + sizeof(double) * (6 * HMC_MAXDIM + 2 * (HMC_MAXP + 3) + HMC_MAXP + 8 + HMC_MAXDIM) +
          sizeof(float) * (size_t)P * tpad_if_x_in_lds;
 }
 

@@ -34,6 +34,7 @@ namespace ci {
 constexpr int NT = 256;   // threads per workgroup
 constexpr int NW = 4;     // wavefronts per workgroup
 constexpr int MAXP = 52;  // design columns supported by the LDS-resident regression block
+constexpr int HMC_MAXP = 128;   // design columns of the log-likelihood / HMC path (row H; round 5: was MAXP)
 
 struct DevSeriesParams {
   double level_conc, level_scale, level_ub;

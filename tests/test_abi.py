@@ -134,6 +134,13 @@ def test_round_3_entry_points_validate_before_any_device_call():
   assert L.ci_ll_session_create2(C.byref(pb), prm, y32.ctypes.data, m.ctypes.data, X.ctypes.data, None,
                                  4, C.byref(h)) != 0
   assert b"P must be <= 128" in L.ci_last_error()
+  # ... and at 52 on its seasonal / long-series routes
+  pb = _native.make_problem(T=T, P=60, has_slope=0, num_seasons=(7,), num_warmup=0, num_results=1)
+  X = np.zeros((T, 60), np.float32)
+  sc1 = np.zeros((1, T), np.uint8)
+  assert L.ci_ll_session_create2(C.byref(pb), prm, y32.ctypes.data, m.ctypes.data, X.ctypes.data,
+                                 sc1.ctypes.data, 4, C.byref(h)) != 0
+  assert b"seasonal blocks or T > 4096: P must be <= 52" in L.ci_last_error()
   # a non-positive multiplier of the weights-prior precision is rejected
   bad = _native.make_params([dict(spec, weights_prior_scale=0.0)])
   pb = _native.make_problem(T=T, P=0, has_slope=0, num_warmup=0, num_results=1)

@@ -51,15 +51,21 @@ def test_hmc_matches_gibbs_on_quickstart_shape():
 
 def test_hmc_options_round_3_supports_and_what_it_still_rejects():
   """Seasonal models and series longer than 4096 steps used to raise; they now run on the
-  sequential route (csrc/ci_score_seq.h).  Still rejected: a surrogate-posterior start for a
-  seasonal model, and more than 128 design columns on the log-likelihood path (round 5: 53 ... 128
-  columns run -- `test_device_hmc_with_more_than_52_columns_tracks_the_oracle`)."""
+  sequential route (csrc/ci_score_seq.h).  Still rejected: a surrogate-posterior start with the
+  horseshoe prior, and more than 128 design columns on the log-likelihood path (round 5: 53 ... 128
+  columns run -- `test_device_hmc_with_more_than_52_columns_tracks_the_oracle` --, and so does a
+  surrogate-posterior start for a seasonal model --
+  `test_surrogate_posterior_of_a_seasonal_model_initialises_hmc`)."""
   df = rp.create_test_data(5.0, 50, seed=1)
   with pytest.raises(NotImplementedError):
     lib.fit_causalimpact(df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
-                         model_options=lib.ModelOptions(seasons=[lib.Seasons(7)]),
                          inference_options=lib.InferenceOptions(num_results=10, sampler="hmc",
-                                                                hmc_init="vi"))
+                                                                hmc_init="vi", hmc_prior="horseshoe"))
+  res = lib.fit_causalimpact(df, (df.index[0], df.index[49]), (df.index[50], df.index[-1]),
+                             model_options=lib.ModelOptions(seasons=[lib.Seasons(7)]),
+                             inference_options=lib.InferenceOptions(num_results=10, num_warmup_steps=20,
+                                                                    sampler="hmc", hmc_init="vi"))
+  assert np.isfinite(res.summary.to_numpy(float)).all()      # (raised NotImplementedError until round 5)
   big = rp.create_test_data(5.0, 4000, num_timesteps=5000, seed=1)
   res = lib.fit_causalimpact(big, (big.index[0], big.index[3999]), (big.index[4000], big.index[-1]),
                              inference_options=lib.InferenceOptions(num_results=8, num_warmup_steps=8,
@@ -133,6 +139,38 @@ def test_surrogate_posterior_tracks_the_hmc_posterior_and_can_initialise_it():
   np.testing.assert_allclose(hmc_vi["observation_noise_scale"].mean(),
                              hmc["observation_noise_scale"].mean(), rtol=0.05)
   assert (hmc_vi["hmc_accept_rate"] > 0.5).all()
+
+
+@pytest.mark.parametrize("seasons", [((7, 1),), ((4, 1), (3, 4))])
+def test_surrogate_posterior_of_a_seasonal_model_initialises_hmc(seasons):
+  """`hmc_init="vi"` for models with seasonal blocks (round 5: the drift scales are coordinates of
+  the mean-field surrogate like the other scales; the ELBO's log-likelihood and score come from the
+  time-parallel seasonal score for trend + one weekly block, from the sequential one for two
+  blocks).  The ELBO rises, the surrogate's scales sit inside the HMC posterior of a gibbs-started
+  fit, and chains started from its draws sample the same posterior."""
+  from causalimpact import _hmc, _model, _vi
+  from causalimpact import _synthetic as syn
+  T, p = 280, 2
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 12)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  spec = _model.series_params(y, mask, X, has_slope=False, num_seasonal_blocks=len(seasons))
+  counts, change = _model.expand_seasons(seasons, T)
+  vi = _vi.fit_surrogate_posterior(y, mask, X, spec, has_slope=False, seed=(3, 4), num_seasons=counts,
+                                   season_change=change, num_steps=200)
+  K = len(seasons)
+  assert vi["mean"].shape == (p + 1 + 2 + K,)
+  assert vi["elbo"][-40:].mean() > vi["elbo"][:10].mean()
+  kw = dict(has_slope=False, num_results=150, num_warmup=150, num_chains=4, seed=(3, 4), num_seasons=counts,
+            season_change=change, num_leapfrog=8)
+  hmc = _hmc.fit_hmc(y, mask, X, spec, **kw)
+  hmc_vi = _hmc.fit_hmc(y, mask, X, spec, init="vi", **kw)
+  assert (hmc_vi["hmc_accept_rate"] > 0.4).all()
+  obs = hmc["observation_noise_scale"].mean()
+  np.testing.assert_allclose(np.exp(vi["mean"][p + 1]), obs, rtol=0.15)
+  np.testing.assert_allclose(hmc_vi["observation_noise_scale"].mean(), obs, rtol=0.08)
+  np.testing.assert_allclose(hmc_vi["weights"].mean(axis=(0, 1, 2)), hmc["weights"].mean(axis=(0, 1, 2)),
+                             atol=0.05)
+  assert hmc_vi["seasonal_drift_scales"].shape == (1, 4, 150, K)
 
 
 @pytest.mark.parametrize("T,p", [(300, 3), (1000, 10)])

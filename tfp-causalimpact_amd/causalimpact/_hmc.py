@@ -32,33 +32,41 @@ import numpy as np
 from causalimpact import _native
 
 
-def _unpack(theta_u: np.ndarray, P: int, has_slope: bool):
-  """unconstrained [C, dim] -> device layout [C, 3 + P] = (s_obs, s_level, s_slope, beta)."""
+def _unpack(theta_u: np.ndarray, P: int, has_slope: bool, K: int = 0):
+  """unconstrained [C, dim] -> device layout [C, 3 + K + P] = (s_obs, s_level, s_slope, drift[K], beta);
+  theta_u = (beta[P], log s_obs, log s_level[, log s_slope], log s_drift[K]) -- the order of
+  csrc/ci_hmc.h / ci_score_seq.h::hmc_drive."""
   C = theta_u.shape[0]
-  out = np.zeros((C, 3 + P))
+  out = np.zeros((C, 3 + K + P))
   lam = np.clip(theta_u[:, P:], -30.0, 30.0)   # diverging trajectories are rejected anyway
   out[:, 0] = np.exp(lam[:, 0])
   out[:, 1] = np.exp(lam[:, 1])
+  ntr = 3 if has_slope else 2
   if has_slope:
     out[:, 2] = np.exp(lam[:, 2])
-  out[:, 3:] = theta_u[:, :P]
+  for j in range(K):
+    out[:, 3 + j] = np.exp(lam[:, ntr + j])
+  out[:, 3 + K:] = theta_u[:, :P]
   return out
 
 
 class _Target:
   """log posterior and gradient for all chains at once (one device call)."""
 
-  def __init__(self, sess, spec, omega, P, has_slope):
-    self.sess, self.P, self.has_slope, self.omega = sess, P, has_slope, omega
+  def __init__(self, sess, spec, omega, P, has_slope, K=0):
+    self.sess, self.P, self.has_slope, self.omega, self.K = sess, P, has_slope, omega, K
     self.ig = [(spec["obs_conc"], spec["obs_scale"]), (spec["level_conc"], spec["level_scale"])]
     if has_slope:
       self.ig.append((spec["slope_conc"], spec["slope_scale"]))
+    # device slot of each of theta's scales: trend scales in front, one drift scale per block
+    self.slot = list(range(len(self.ig))) + [3 + j for j in range(K)]
+    self.ig += [(spec["drift_conc"], spec["drift_scale"])] * K          # causalimpact_lib.py:472-474
     self.dim = P + len(self.ig)
     self.calls = 0
 
   def __call__(self, theta_u):
-    P = self.P
-    dev = _unpack(theta_u, P, self.has_slope)
+    P, K = self.P, self.K
+    dev = _unpack(theta_u, P, self.has_slope, K)
     ll, g = self.sess.evaluate(dev, want_grad=True)
     self.calls += 1
     lp = ll.copy()
@@ -67,12 +75,12 @@ class _Target:
     if P:
       ob = beta @ self.omega
       lp -= 0.5 * np.sum(beta * ob, axis=1)
-      grad[:, :P] = g[:, 3:] - ob
+      grad[:, :P] = g[:, 3 + K:] - ob
     for k, (a, b) in enumerate(self.ig):
       lam = theta_u[:, P + k]
       lam = np.clip(lam, -30.0, 30.0)
       lp += -2.0 * a * lam - b * np.exp(-2.0 * lam)
-      grad[:, P + k] = dev[:, k] * g[:, k] - 2.0 * a + 2.0 * b * np.exp(-2.0 * lam)
+      grad[:, P + k] = dev[:, self.slot[k]] * g[:, self.slot[k]] - 2.0 * a + 2.0 * b * np.exp(-2.0 * lam)
     bad = ~np.isfinite(lp)
     lp[bad] = -np.inf
     grad[bad] = 0.0
@@ -124,7 +132,9 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
   prior of `tfp.sts.SparseLinearRegression`, weights_prior_scale = horseshoe_scale).
   init: "gibbs" starts every chain at the Gibbs sampler's initial state (jittered); "vi" first
   fits the mean-field surrogate posterior (`_vi.fit_surrogate_posterior`, what
-  `tfp.sts.fit_with_hmc` does upstream) and starts chain c at its c-th draw (slab prior only)."""
+  `tfp.sts.fit_with_hmc` does upstream) and starts chain c at its c-th draw (slab prior only;
+  since round 5 for models with seasonal blocks too: the drift scales are coordinates of the
+  surrogate like the other scales)."""
   y = np.asarray(y, np.float64)
   mask = np.asarray(mask, bool)
   T = y.shape[0]
@@ -138,13 +148,12 @@ def fit_hmc(y, mask, X, spec: Dict, *, has_slope: bool, num_results: int, num_wa
   try:
     init_theta = None
     if init == "vi":
-      if prior != "slab" or K > 0:
-        raise NotImplementedError("the surrogate posterior is built for the slab prior and "
-                                  "trend + regression models only")
+      if prior != "slab":
+        raise NotImplementedError("the surrogate posterior is built for the slab prior only")
       from causalimpact import _vi  # pylint: disable=import-outside-toplevel
       vi = _vi.fit_surrogate_posterior(y, mask, X, spec, has_slope=has_slope, seed=seed,
                                        device=device, sess=sess,
-                                       num_mc=min(32, sess.max_evals))
+                                       num_mc=min(32, sess.max_evals), num_blocks=K)
       # chain c starts at the (chain_offset + c)-th draw, whatever the split over devices
       init_theta = _vi.sample_surrogate(vi, chain_offset + C, seed=seed)[chain_offset:]
     elif init != "gibbs":

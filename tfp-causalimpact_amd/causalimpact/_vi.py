@@ -24,33 +24,42 @@ from causalimpact import _native
 
 def fit_surrogate_posterior(y, mask, X, spec: Dict, *, has_slope: bool, num_steps: int = 300,
                             num_mc: int = 32, learning_rate: float = 0.05, seed=0, device: int = 0,
-                            sess: Optional[_native.LogLikSession] = None) -> Dict[str, np.ndarray]:
+                            sess: Optional[_native.LogLikSession] = None, num_blocks: int = 0,
+                            num_seasons=(), season_change=None) -> Dict[str, np.ndarray]:
   """Returns {"mean": [dim], "log_sd": [dim], "elbo": [num_steps]} in the unconstrained
-  parameterisation theta = (weights[P], log sigma_obs, log sigma_level[, log sigma_slope])."""
+  parameterisation theta = (weights[P], log sigma_obs, log sigma_level[, log sigma_slope],
+  log sigma_drift[K]) -- K = `num_blocks` seasonal blocks of the session `sess` (round 5), or of
+  the session built here from `num_seasons` / `season_change` (as in `_native.fit_gibbs`)."""
   y = np.asarray(y, np.float64)
   mask = np.asarray(mask, bool)
   T = y.shape[0]
   P = 0 if X is None else int(np.asarray(X).shape[1])
   own = sess is None
+  K = int(num_blocks)
   if own:
-    pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_warmup=0, num_results=1,
-                              seed=seed, device=device)
-    sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=num_mc)
+    K = len(num_seasons)
+    pb = _native.make_problem(T=T, P=P, has_slope=has_slope, num_seasons=num_seasons, num_warmup=0,
+                              num_results=1, seed=seed, device=device)
+    sess = _native.LogLikSession(pb, _native.make_params([spec]), y, mask, X, max_evals=num_mc,
+                                 season_change=season_change)
   try:
     omega = None
     if P:
       X64 = np.asarray(X, np.float64)
       xtx = X64.T @ X64
       omega = 0.01 * (0.5 * xtx + 0.5 * np.diag(np.diag(xtx))) / T          # :451-453
-    target = _hmc._Target(sess, spec, omega, P, has_slope)   # pylint: disable=protected-access
+    target = _hmc._Target(sess, spec, omega, P, has_slope, K)   # pylint: disable=protected-access
     dim = target.dim
     s0, s1 = _native.seed_pair(seed)
     rng = np.random.Generator(np.random.Philox(key=[(s0 << 32) | s1, 0x5649]))
     mean = np.zeros(dim)
     mean[P] = np.log(spec["obs_scale0"])
     mean[P + 1] = np.log(max(spec["level_scale0"], 1e-4))
+    ntr = 3 if has_slope else 2
     if has_slope:
       mean[P + 2] = np.log(max(spec["slope_scale0"], 1e-4))
+    for j in range(K):                   # the Gibbs sampler's initial drift scales (:573-574)
+      mean[P + ntr + j] = np.log(max(float(np.atleast_1d(spec["drift_scale0"])[j]), 1e-4))
     log_sd = np.full(dim, np.log(0.05))
     m1 = np.zeros(2 * dim)
     m2 = np.zeros(2 * dim)

@@ -1557,6 +1557,8 @@ int ci_ll_session_create2(const ci_problem* pb, const ci_series_params* params, 
     return fail("params->weights_prior_scale must be positive and finite (1 = the reference's prior)");
   if (pb->P > 0 && !X) return fail("X is NULL but P=%d", pb->P);
   const bool seq = pb->num_blocks > 0 || steps_per_thread(pb->T) == 0;
+  if (seq && pb->P > ci::MAXP)
+    return fail("log-likelihood path, seasonal blocks or T > 4096: P must be <= %d, got %d", ci::MAXP, pb->P);
   int dfull = pb->has_slope ? 2 : 1;
   for (int k = 0; k < pb->num_blocks; ++k) dfull += pb->num_seasons[k];
   // trend + one block of 2-7 seasons (or a long trend-only series: an inert 2-season block) run on
@@ -1907,6 +1909,7 @@ int ci_ll_session_kernel_name(const ci_ll_session* s, char* buf, int32_t buflen)
   char nm[64];
   if (s->wide) snprintf(nm, sizeof(nm), "ci::hmc_wide_kernel<%d,%d>", s->D, s->wide_ns);
   else if (s->seq) snprintf(nm, sizeof(nm), "ci::hmc_seq_kernel");
+  else if (s->P > ci::MAXP) snprintf(nm, sizeof(nm), "ci::hmc_kernel<%d,%d,wide>", s->D, s->L);
   else snprintf(nm, sizeof(nm), "ci::hmc_kernel<%d,%d>", s->D, s->L);
   return copy_name(nm, buf, buflen);
 }

@@ -105,7 +105,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 __device__ __forceinline__ double clamp30(double v) { return v < -30.0 ? -30.0 : (v > 30.0 ? 30.0 : v); }
 
-template <int D, int L>
+// WIDE: the fit has more than MAXP design columns -- its arrays are sized for HMC_MAXP.  Two builds
+// because the sizes are compile-time constants (addresses as immediates): sized for 128 columns the
+// arrays push cfg3's design matrix beyond the 64 KB an LDS instruction reaches with an immediate
+// offset (7.7 -> 9.2 us per leapfrog), sized at run time they cost ten more live SGPRs (7.8).
+template <int D, int L, bool WIDE>
 __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,21 +122,23 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
   float* slots = (float*)smem_h;                 // 3 * NW * 16
   float* part = slots + 3 * NW * 16;             // NW * (P + 4)
   double* dbl = (double*)(smem_h + (((3 * NW * 16 + NW * (P + 4)) * sizeof(float) + 15) & ~(size_t)15));
-  double* theta = dbl;                 // current position (unconstrained)
-  double* grad = theta + HMC_MAXDIM;   // its gradient
-  double* th = grad + HMC_MAXDIM;      // trajectory position
-  double* g = th + HMC_MAXDIM;         // trajectory gradient
-  double* mom = g + HMC_MAXDIM;        // trajectory momentum
-  double* imass = mom + HMC_MAXDIM;    // inverse mass (diagonal)
-  double* dev = imass + HMC_MAXDIM;    // device layout of th: (s_obs, s_level, s_slope, beta)   [3 + HMC_MAXP]
-  double* gdev = dev + (HMC_MAXP + 3); // score in device layout                                 [3 + HMC_MAXP]
-  double* hsc = gdev + (HMC_MAXP + 3); // horseshoe: d beta_j / d z_j                            [HMC_MAXP]
-  double* sc = hsc + HMC_MAXP;         // scalars: [0] ll, [1] lp of the trajectory, [2] lp current
+  constexpr int MP = WIDE ? HMC_MAXP : MAXP;
+  constexpr int dimp = 3 * MP + 5 + ((3 * MP + 5) & 1), devp = MP + 3 + ((MP + 3) & 1), hscp = MP + (MP & 1);
+  double* theta = dbl;                 // current position (unconstrained)                        [dimp]
+  double* grad = theta + dimp;         // its gradient
+  double* th = grad + dimp;            // trajectory position
+  double* g = th + dimp;               // trajectory gradient
+  double* mom = g + dimp;              // trajectory momentum
+  double* imass = mom + dimp;          // inverse mass (diagonal)
+  double* dev = imass + dimp;          // device layout of th: (s_obs, s_level, s_slope, beta)   [devp]
+  double* gdev = dev + devp;           // score in device layout                                 [devp]
+  double* hsc = gdev + devp;           // horseshoe: d beta_j / d z_j                            [hscp]
+  double* sc = hsc + hscp;             // scalars: [0] ll, [1] lp of the trajectory, [2] lp current
   // feature-major design matrix, zero padded to NT * L columns, resident in LDS for the whole fit
   // (every leapfrog step reads it twice: residual and d l / d beta)
-  double* pre = sc + 8;                // theta-only pieces of the prior terms                 [HMC_MAXDIM]
+  double* pre = sc + 8;                // theta-only pieces of the prior terms                 [dimp]
   constexpr int TPAD = NT * L;
-  float* Xs = (float*)(pre + HMC_MAXDIM);
+  float* Xs = (float*)(pre + dimp);
   const bool x_in_lds = a.x_in_lds != 0;
   if (x_in_lds) {
     for (int j = 0; j < P; ++j)
@@ -469,7 +475,10 @@ __global__ __launch_bounds__(NT) void hmc_kernel(HmcArgs a) {
 
 __host__ __device__ inline size_t hmc_lds_bytes(int P, int tpad_if_x_in_lds) {
   const size_t f = (((size_t)(3 * NW * 16 + NW * (P + 4)) * sizeof(float)) + 15) & ~(size_t)15;
-  return f + sizeof(double) * (6 * HMC_MAXDIM + 2 * (HMC_MAXP + 3) + HMC_MAXP + 8 + HMC_MAXDIM) +
+  const int MP = P > MAXP ? HMC_MAXP : MAXP;
+  const size_t dimp = (size_t)(3 * MP + 5 + ((3 * MP + 5) & 1)), devp = (size_t)(MP + 3 + ((MP + 3) & 1)),
+               hscp = (size_t)(MP + (MP & 1));
+  return f + sizeof(double) * (7 * dimp + 2 * devp + hscp + 8) +
          sizeof(float) * (size_t)P * tpad_if_x_in_lds;
 }
 

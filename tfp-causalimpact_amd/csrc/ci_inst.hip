@@ -120,9 +120,15 @@ void CI_CAT(ci_launch_hmc_d, CI_D, _l, CI_L)(const ci::HmcArgs* args, hipStream_
   const size_t with_x = ci::hmc_lds_bytes(a.P, ci::NT * CI_L);
   a.x_in_lds = (a.P > 0 && with_x <= 150 * 1024) ? 1 : 0;
   const size_t lds = a.x_in_lds ? with_x : ci::hmc_lds_bytes(a.P, 0);
-  (void)hipFuncSetAttribute((const void*)(&ci::hmc_kernel<CI_D, CI_L>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((ci::hmc_kernel<CI_D, CI_L>), dim3(a.C), dim3(ci::NT), lds, stream, a);
+  if (a.P > ci::MAXP) {
+    (void)hipFuncSetAttribute((const void*)(&ci::hmc_kernel<CI_D, CI_L, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ci::hmc_kernel<CI_D, CI_L, true>), dim3(a.C), dim3(ci::NT), lds, stream, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)(&ci::hmc_kernel<CI_D, CI_L, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ci::hmc_kernel<CI_D, CI_L, false>), dim3(a.C), dim3(ci::NT), lds, stream, a);
+  }
 }
 
 }  // extern "C"

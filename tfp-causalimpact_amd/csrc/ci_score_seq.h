@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) void seq_score_kernel(SeqScoreArgs a) {
 // ------------------------------------------------------------------------------------
 namespace ci {
 
-constexpr int HMC_SEQ_MAXDIM = 3 * HMC_MAXP + 5 + SMAXK;
+constexpr int HMC_SEQ_MAXDIM = 3 * MAXP + 5 + SMAXK;
 
 struct HmcSeqArgs {
   SeqScoreArgs q;            // data and geometry (theta / out_* / E unused; ws = [C, seq_score_ws_floats])
@@ -396,7 +396,7 @@ struct HmcSeqArgs {
 };
 
 __host__ __device__ inline size_t hmc_seq_dbl_count() {
-  return 6 * (size_t)HMC_SEQ_MAXDIM + 2 * (size_t)(HMC_MAXP + 3 + SMAXK) + HMC_MAXP + 8;
+  return 6 * (size_t)HMC_SEQ_MAXDIM + 2 * (size_t)(MAXP + 3 + SMAXK) + MAXP + 8;
 }
 __host__ __device__ inline size_t hmc_seq_lds_bytes(int D, int K) {
   return sizeof(double) * hmc_seq_dbl_count() + ((seq_score_lds_bytes(D, K) + 15) & ~(size_t)15);
@@ -424,9 +424,9 @@ __device__ __forceinline__ void hmc_drive(const HmcSeqArgs& a, unsigned char* sm
   double* mom = g + HMC_SEQ_MAXDIM;
   double* imass = mom + HMC_SEQ_MAXDIM;
   double* dev = imass + HMC_SEQ_MAXDIM;           // (s_obs, s_level, s_slope, drift[K], beta)
-  double* gdev = dev + (HMC_MAXP + 3 + SMAXK);
-  double* hsc = gdev + (HMC_MAXP + 3 + SMAXK);
-  double* sc = hsc + HMC_MAXP;
+  double* gdev = dev + (MAXP + 3 + SMAXK);
+  double* hsc = gdev + (MAXP + 3 + SMAXK);
+  double* sc = hsc + MAXP;
   const int chain = blockIdx.x;
   Rng rng{a.seed0, a.seed1, (uint32_t)(a.chain_offset + chain)};
   // theta's scale k -> slot of the device layout

@@ -241,6 +241,12 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
                        double scale, double shift, const double* observed, const uint8_t* flags,
                        int32_t num_ranks, const int32_t* ranks, double* value_order,
                        double* cum_order, double* per_draw, double* per_draw_order);
+/* ... for float64 trajectories (the draws of ci_fit_gibbs_f64: no rounding to float32 on the way
+ * into the order statistics). */
+int ci_summarize_draws_f64(int32_t device, int32_t num_draws, int32_t T, const double* trajectories,
+                           double scale, double shift, const double* observed, const uint8_t* flags,
+                           int32_t num_ranks, const int32_t* ranks, double* value_order,
+                           double* cum_order, double* per_draw, double* per_draw_order);
 
 /* Kalman-filter log-likelihood of the trend + regression model for num_evals parameter sets
  * (the objective an HMC / VI fit would use; the reference never

@@ -103,6 +103,35 @@ def test_host_pooled_draws_are_summarised_on_device_too():
     _assert_frames_equal(dev.summary, host.summary)
 
 
+def test_float64_draws_are_summarised_without_a_float32_round_trip():
+  """`ci_summarize_draws_f64` (round 5): float64 trajectories -- what `ci_fit_gibbs_f64` returns --
+  go into the order statistics as they are.  Values that differ only beyond float32's 24 bits keep
+  their order and their digits (the float32 entry point collapses them); the float64 fit through
+  `fit_causalimpact(dtype=float64)` gives the frames of the host arithmetic."""
+  N, T = 1500, 16
+  rng = np.random.default_rng(5)
+  traj = 1.0 + 1e-9 * rng.normal(size=(N, T))                    # spread far below float32 resolution
+  obs = rng.normal(size=T)
+  flags = np.zeros(T, np.uint8); flags[6:] = 1; flags[8:14] |= 2
+  ranks = [0, 37, 749, 1462, 1499]
+  got = _native.summarize_draws(traj, 2.0, 0.5, obs, flags, ranks)
+  value = traj * 2.0 + 0.5
+  np.testing.assert_array_equal(got["value_order"], np.sort(value, axis=0)[ranks])
+  assert np.unique(got["value_order"][:, 0]).size == len(ranks)
+  as32 = _native.summarize_draws(traj.astype(np.float32), 2.0, 0.5, obs, flags, ranks)
+  assert np.unique(as32["value_order"][:, 0]).size == 1            # what the round trip loses
+  import ref_pins_common as rp
+  df = rp.create_test_data(8.0, 70, num_timesteps=100, seed=3)
+  pre, post = (df.index[0], df.index[69]), (df.index[72], df.index[-2])
+  opts = dict(num_results=100, num_chains=2)
+  dev = ci.fit_causalimpact(df, pre, post, seed=2, data_options=ci.DataOptions(dtype=np.float64),
+                            inference_options=ci.InferenceOptions(**opts))
+  host = ci.fit_causalimpact(df, pre, post, seed=2, data_options=ci.DataOptions(dtype=np.float64),
+                             inference_options=ci.InferenceOptions(summarize_on_device=False, **opts))
+  _assert_frames_equal(dev.series, host.series)
+  _assert_frames_equal(dev.summary, host.summary)
+
+
 def _numpy_summary(traj, scale, shift, obs, flags, ranks):
   value = traj.astype(np.float64) * scale + shift                 # [N, T]
   point = -(value - obs[None, :])

@@ -101,6 +101,9 @@ def load():
   L.ci_summarize_draws.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
                                    C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+  L.ci_summarize_draws_f64.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
+                                   C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   L.ci_kalman_loglik.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
   L.ci_ll_session_create.argtypes = [C.POINTER(Problem), C.POINTER(SeriesParams), C.c_void_p,
@@ -143,7 +146,7 @@ def exported_symbols() -> Sequence[str]:
           "ci_session_create", "ci_session_run", "ci_session_run_streamed", "ci_session_fetch",
           "ci_session_algorithmic_bytes", "ci_session_kernel_name", "ci_session_destroy",
           "ci_session_profile", "ci_ll_session_kernel_name",
-          "ci_session_summarize", "ci_summarize_draws",
+          "ci_session_summarize", "ci_summarize_draws", "ci_summarize_draws_f64",
           "ci_kalman_loglik", "ci_ll_session_create", "ci_ll_session_create2", "ci_ll_session_eval",
           "ci_ll_session_draw_latents", "ci_ll_session_hmc_run", "ci_ll_session_hmc_fetch",
           "ci_ll_session_algorithmic_bytes", "ci_ll_session_destroy",
@@ -251,8 +254,11 @@ def _stage_inputs(pb: Problem, y, mask, X, season_change):
 
 
 def summarize_draws(trajectories, scale, shift, observed, flags, ranks, device=0):
-  """ci_summarize_draws: on-device summary of host-resident [draws, T] float32 trajectories."""
-  tr = np.ascontiguousarray(trajectories, dtype=np.float32)
+  """ci_summarize_draws / ci_summarize_draws_f64: on-device summary of host-resident [draws, T]
+  trajectories -- float64 draws (the float64 kernels) are summarised as float64, anything else as
+  float32."""
+  f64 = np.asarray(trajectories).dtype == np.float64
+  tr = np.ascontiguousarray(trajectories, dtype=np.float64 if f64 else np.float32)
   N, T = tr.shape
   obs = np.ascontiguousarray(observed, dtype=np.float64).reshape(T)
   fl = np.ascontiguousarray(flags, dtype=np.uint8).reshape(T)
@@ -261,9 +267,10 @@ def summarize_draws(trajectories, scale, shift, observed, flags, ranks, device=0
   co = np.empty((rk.size, T), np.float64)
   pd_ = np.empty((2, N), np.float64)
   do = np.empty((2, rk.size), np.float64)
-  _check(load().ci_summarize_draws(int(device), N, T, tr.ctypes.data, float(scale), float(shift),
-                                   obs.ctypes.data, fl.ctypes.data, int(rk.size), rk.ctypes.data,
-                                   vo.ctypes.data, co.ctypes.data, pd_.ctypes.data, do.ctypes.data))
+  fn = load().ci_summarize_draws_f64 if f64 else load().ci_summarize_draws
+  _check(fn(int(device), N, T, tr.ctypes.data, float(scale), float(shift),
+            obs.ctypes.data, fl.ctypes.data, int(rk.size), rk.ctypes.data,
+            vo.ctypes.data, co.ctypes.data, pd_.ctypes.data, do.ctypes.data))
   return dict(value_order=vo, cum_order=co, per_draw=pd_, per_draw_order=do)
 
 

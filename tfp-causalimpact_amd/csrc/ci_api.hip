@@ -1098,7 +1098,7 @@ int ci_session_summarize(ci_session* s, const double* scale, const double* shift
   HIP_TRY(hipMemcpyAsync(d_shift, shift, B * sizeof(double), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->s_flags.p, flags, (size_t)B * T, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->s_ranks.p, ranks, num_ranks * sizeof(int), hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(ci::summ_transpose_kernel, dim3((T + 63) / 64, (N + 63) / 64, B), dim3(64, 4), 0,
+  hipLaunchKernelGGL(ci::summ_transpose_kernel<float>, dim3((T + 63) / 64, (N + 63) / 64, B), dim3(64, 4), 0,
                      s->stream, N, T, s->o_traj.p, d_scale, d_shift, s->s_value.p);
   hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 63) / 64, B), dim3(64), 0, s->stream, N, T,
                      s->s_value.p, s->s_obs.p, s->s_flags.p, s->s_cum.p, s->s_draw.p);
@@ -1123,10 +1123,12 @@ int ci_session_summarize(ci_session* s, const double* scale, const double* shift
   return 0;
 }
 
-int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float* trajectories,
-                       double scale, double shift, const double* observed, const uint8_t* flags,
-                       int32_t num_ranks, const int32_t* ranks, double* value_order,
-                       double* cum_order, double* per_draw, double* per_draw_order) {
+extern "C++" {
+template <class TIn>
+static int summarize_draws_impl(int32_t device, int32_t num_draws, int32_t T, const TIn* trajectories,
+                                double scale, double shift, const double* observed, const uint8_t* flags,
+                                int32_t num_ranks, const int32_t* ranks, double* value_order,
+                                double* cum_order, double* per_draw, double* per_draw_order) {
   if (!trajectories || !observed || !flags || !ranks) return fail("NULL argument");
   if (num_draws < 1 || T < 1) return fail("need num_draws >= 1 and T >= 1");
   if (num_ranks < 1 || num_ranks > ci::SUMM_MAX_RANKS)
@@ -1136,7 +1138,7 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
     if (ranks[r] < 0 || ranks[r] >= N) return fail("rank %d out of range [0, %d)", ranks[r], N);
   HIP_TRY(hipSetDevice(device));
   const size_t TN = (size_t)T * N;
-  DevBuf<float> d_traj;
+  DevBuf<TIn> d_traj;
   DevBuf<double> d_value, d_cum, d_obs, d_order, d_draw;
   DevBuf<uint8_t> d_flags;
   DevBuf<int> d_ranks;
@@ -1161,12 +1163,12 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
   CI_TRY_CLEAN(d_order.alloc((size_t)2 * ci::SUMM_MAX_RANKS * T));
   CI_TRY_CLEAN(d_draw.alloc((size_t)2 * N + 2 * ci::SUMM_MAX_RANKS));
   const double ss[2] = {scale, shift};
-  CI_TRY_CLEAN(hipMemcpy(d_traj.p, trajectories, TN * sizeof(float), hipMemcpyHostToDevice));
+  CI_TRY_CLEAN(hipMemcpy(d_traj.p, trajectories, TN * sizeof(TIn), hipMemcpyHostToDevice));
   CI_TRY_CLEAN(hipMemcpy(d_obs.p, observed, T * sizeof(double), hipMemcpyHostToDevice));
   CI_TRY_CLEAN(hipMemcpy(d_obs.p + T, ss, 2 * sizeof(double), hipMemcpyHostToDevice));
   CI_TRY_CLEAN(hipMemcpy(d_flags.p, flags, T, hipMemcpyHostToDevice));
   CI_TRY_CLEAN(hipMemcpy(d_ranks.p, ranks, num_ranks * sizeof(int), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(ci::summ_transpose_kernel, dim3((T + 63) / 64, (N + 63) / 64, 1), dim3(64, 4), 0,
+  hipLaunchKernelGGL(ci::summ_transpose_kernel<TIn>, dim3((T + 63) / 64, (N + 63) / 64, 1), dim3(64, 4), 0,
                      0, N, T, d_traj.p, d_obs.p + T, d_obs.p + T + 1, d_value.p);
   hipLaunchKernelGGL(ci::summ_cumsum_kernel, dim3((N + 63) / 64, 1), dim3(64), 0, 0, N, T,
                      d_value.p, d_obs.p, d_flags.p, d_cum.p, d_draw.p);
@@ -1191,6 +1193,23 @@ int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float
 #undef CI_TRY_CLEAN
   cleanup();
   return 0;
+}
+}  // extern "C++"
+
+int ci_summarize_draws(int32_t device, int32_t num_draws, int32_t T, const float* trajectories,
+                       double scale, double shift, const double* observed, const uint8_t* flags,
+                       int32_t num_ranks, const int32_t* ranks, double* value_order,
+                       double* cum_order, double* per_draw, double* per_draw_order) {
+  return summarize_draws_impl<float>(device, num_draws, T, trajectories, scale, shift, observed, flags,
+                                     num_ranks, ranks, value_order, cum_order, per_draw, per_draw_order);
+}
+
+int ci_summarize_draws_f64(int32_t device, int32_t num_draws, int32_t T, const double* trajectories,
+                           double scale, double shift, const double* observed, const uint8_t* flags,
+                           int32_t num_ranks, const int32_t* ranks, double* value_order,
+                           double* cum_order, double* per_draw, double* per_draw_order) {
+  return summarize_draws_impl<double>(device, num_draws, T, trajectories, scale, shift, observed, flags,
+                                      num_ranks, ranks, value_order, cum_order, per_draw, per_draw_order);
 }
 
 int ci_session_fetch(ci_session* s, ci_outputs* o) {

@@ -19,13 +19,15 @@ constexpr int SUMM_MAX_RANKS = 8;
 // [N, T] float32 draws (model scale) -> [T, N] float64 on the data scale:
 // standardize.py:60-64 `values * stddev + mean` (two roundings, no FMA).
 // grid (ceil(T/64), ceil(N/64), B), block (64, 4); series b uses (scale[b], shift[b]).
+// TIn: float (the sampler's float32 container) or double (float64 fits pooled on the host, round 5).
+template <class TIn>
 __global__ __launch_bounds__(256) void summ_transpose_kernel(int N, int T,
-                                                             const float* __restrict__ traj_all,
+                                                             const TIn* __restrict__ traj_all,
                                                              const double* __restrict__ scales,
                                                              const double* __restrict__ shifts,
                                                              double* __restrict__ predT_all) {
   __shared__ double tile[64][65];
-  const float* traj = traj_all + (size_t)blockIdx.z * N * T;
+  const TIn* traj = traj_all + (size_t)blockIdx.z * N * T;
   double* predT = predT_all + (size_t)blockIdx.z * N * T;
   const double scale = scales[blockIdx.z], shift = shifts[blockIdx.z];
   const int t0 = blockIdx.x * 64, n0 = blockIdx.y * 64;

@@ -438,6 +438,11 @@ def main():
   if comm is not None:
     comm.barrier()
     hard_exit = comm.hard_exit
+  if hard_exit:
+    #  say so in the line: the timed region ran beside an abandoned RCCL join
+    out["config"]["rccl_join_abandoned"] = ("an RCCL join that missed its deadline may still have been "
+                                            "blocked (and its kernel spinning on the GPU) while this run "
+                                            "was timed over the host transport")
   fit.sess.close()
   if comm is not None:
     comm.close()

@@ -426,9 +426,13 @@ class Session:
     obs = np.ascontiguousarray(np.broadcast_to(np.asarray(observed, np.float64), (B, T)))
     fl = np.ascontiguousarray(np.broadcast_to(np.asarray(flags, np.uint8), (B, T)))
     rk = np.ascontiguousarray(ranks, dtype=np.int32)
-    vo = np.empty((B, rk.size, T), np.float64)
-    co = np.empty((B, rk.size, T), np.float64)
-    pd_ = np.empty((B, 2, N), np.float64)
+    # big batches: the result blocks in pinned host memory from the library's pool (512 series: 24 MB
+    # -- pageable destinations cost the copies a staging pass and the arrays their first-touch faults)
+    big = B * max(rk.size * T, 2 * N) * 8 > (1 << 20)
+    empty = (lambda shp: pinned_empty(shp, np.float64)) if big else (lambda shp: np.empty(shp, np.float64))
+    vo = empty((B, rk.size, T))
+    co = empty((B, rk.size, T))
+    pd_ = empty((B, 2, N))
     do = np.empty((B, 2, rk.size), np.float64)
     _check(self._lib.ci_session_summarize(self._h, sc.ctypes.data, sh.ctypes.data, obs.ctypes.data,
                                           fl.ctypes.data, int(rk.size), rk.ctypes.data,

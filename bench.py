@@ -320,6 +320,14 @@ def main():
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if world != args.gpus:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+  if launched and os.environ.get("CI_COMM_SPAWNED") != "1" and os.environ.get("CI_COMM_DEVICES"):
+    # an external launcher (torch.distributed.run) on a box with fewer GPUs than ranks: the same
+    # rank -> device map the self-launcher takes (tests: two ranks of the driver's command line
+    # sharing GPU 0 over the host transport)
+    devs = [int(d) for d in os.environ["CI_COMM_DEVICES"].split(",")]
+    if len(devs) != world:
+      raise SystemExit(f"CI_COMM_DEVICES names {len(devs)} devices for {world} ranks")
+    local_rank = devs[rank]
   # RCCL through the C-ABI (ci_comm_*): no PyTorch in this process.  CI_BENCH_FORCE_DIST=1
   # exercises the same path with a single rank (1-GPU box).
   # connect(): the host transport comes up first, RCCL is joined under a deadline and proven with

@@ -265,3 +265,33 @@ def test_bench_gpus_2_starts_its_own_ranks_and_reports_the_whole_job():
   assert "spawned its own ranks" in line["config"]["launcher"]
   assert line["value"] > 0 and set(line["split_rhat"]) == {"observation_noise_scale", "level_scale"}
   assert "cpu_baseline" not in line or line.get("cpu_baseline") is None or line["n_gpus"] == 2
+
+
+def test_bench_under_torch_distributed_run_the_drivers_command_line():
+  """The driver's N > 1 form, verbatim: `python -m torch.distributed.run --nnodes=1
+  --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`.  The launcher
+  only exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: the ranks never import torch, they meet
+  through the rendezvous file derived from that environment and the C-ABI communicator.  On this
+  one-GPU box CI_COMM_DEVICES folds both ranks onto GPU 0 and RCCL (which refuses two ranks on one
+  device) hands over to the host transport, labelled as such."""
+  pytest.importorskip("torch")
+  import socket
+  with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CI_COMM_TRANSPORT")}
+  env.update(CI_COMM_DEVICES="0,0", CI_COMM_INIT_TIMEOUT_S="60")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+         "--gpus", "2", "--steps", "2", "--warmup", "1"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 alone prints the line
+  line = json.loads(lines[0])
+  assert line["n_gpus"] == 2 and line["config"]["chains_total"] == 2 * line["config"]["chains_per_gpu"]
+  assert line["config"]["ranks_seen"] == 2
+  assert "external" in line["config"]["launcher"]
+  assert line["config"]["collectives"].startswith(("host", "rccl"))
+  assert line["value"] > 0 and line["cpu_baseline"]["value"] is None
+

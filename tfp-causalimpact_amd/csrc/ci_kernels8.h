@@ -409,7 +409,13 @@ template <int D, int L> struct Lay8 {
   static constexpr size_t off_pre = off_gam + a16((8 + 64 + 4) * sizeof(double));
   static constexpr size_t off_tgv = off_pre + a16(pre_tables_bytes());
   static constexpr size_t off_z = off_tgv + TP * sizeof(float);          // zl, zs, zo
-  static constexpr size_t off_x = off_z + 3 * TP * sizeof(float);
+  // L >= 8 (T > 1024): the builds that spill.  Two per-thread arrays that live from one iteration
+  // into the next leave the registers: X w waits in LDS for the emission of its draw (PARK), the
+  // running sum of the predictor in its output array in HBM -- L registers each during the draw.
+  static constexpr bool PARK = L >= 8;
+  static constexpr size_t off_xw = off_z + 3 * TP * sizeof(float);
+  static constexpr size_t off_y = off_xw + (PARK ? TP * sizeof(float) : 0);     // the observations (PARK)
+  static constexpr size_t off_x = off_y + (PARK ? TP * sizeof(float) : 0);
   static __host__ __device__ constexpr size_t total(int P) { return off_x + (size_t)P * TP * sizeof(float); }
 };
 // indices into `scal` beyond enum Scal: prior moments, then the x_0 normals of even / odd iterations
@@ -444,6 +450,8 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
   float* wls = (float*)(smem + LY::off_w);
   float* tgv = (float*)(smem + LY::off_tgv);
   float* zb = (float*)(smem + LY::off_z);
+  float* xwb = (float*)(smem + LY::off_xw);       // (PARK builds only)
+  float* ybuf = (float*)(smem + LY::off_y);       // (PARK builds only)
   double* gam = (double*)(smem + LY::off_gam);
   const size_t chain_lin = (size_t)series * a.C + chain;
   const int n_iter = a.W + a.S;
@@ -763,6 +771,7 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
     const bool m = in ? (mg[t] != 0) : true;
     if (m) { maskbits |= (1u << l); yv[l] = 0.f; }
   }
+  if constexpr (LY::PARK) store_targets<L>(ybuf, t0, yv);       // read back where they are used
   const float init_loc = scal[SC8_INIT_LOC], init_var = scal[SC8_INIT_VAR], init_svar = scal[SC8_INIT_SVAR];
   const DevSeriesParams* spp = &cx->sp;
   const double sp_level_scale0 = spp->level_scale0, sp_slope_scale0 = spp->slope_scale0;
@@ -779,11 +788,17 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
   for (int it = 0; it <= n_iter; ++it) {
     // ---- targets (they use the CURRENT level) to LDS; the last owned state for the neighbour
     {
-      float tg[L];
+      float tg[L], yq[L];
+      if constexpr (LY::PARK) {
+        lds_row_load<L>(ybuf + t0, yq);
+      } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l) yq[l] = yv[l];
+      }
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         const bool obs = ((maskbits >> l) & 1u) == 0u;
-        tg[l] = obs ? (yv[l] - lev[l]) : 0.f;
+        tg[l] = obs ? (yq[l] - lev[l]) : 0.f;
       }
       store_targets<L>(tgv, t0, tg);
       xlast[tid * D] = lev[L - 1];
@@ -840,11 +855,55 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
       float zp[L];
       fill_normals<L>(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)t0, zp);
       float tr[L];
+      if constexpr (LY::PARK) {
+        // X w of draw it-1 from LDS; the predictor's running sum in place in its output array (the
+        // same sequence of float additions as the register copy of the other builds: same bits)
+        float xwp[L], acc[L];
+        lds_row_load<L>(xwb + t0, xwp);
+        float* pm = a.out_pred_mean ? a.out_pred_mean + chain_lin * T : nullptr;
+        const bool vec = (T & 3) == 0;
+        if (pm != nullptr && s > 0) {
+          if (vec) {
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const float loc = lev[l] + xw[l];
-        pm_acc[l] += loc;
-        tr[l] = fmaf(so_prev, zp[l], loc);
+            for (int q = 0; q < L / 4; ++q) {
+              const int t = t0 + 4 * q;
+              const float4 v = t < T ? *(const float4*)(pm + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+              acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+            }
+          } else {
+#pragma unroll
+            for (int l = 0; l < L; ++l) acc[l] = t0 + l < T ? pm[t0 + l] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int l = 0; l < L; ++l) acc[l] = 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const float loc = lev[l] + xwp[l];
+          acc[l] += loc;
+          tr[l] = fmaf(so_prev, zp[l], loc);
+        }
+        if (pm != nullptr) {
+          if (vec) {
+#pragma unroll
+            for (int q = 0; q < L / 4; ++q) {
+              const int t = t0 + 4 * q;
+              if (t < T) *(float4*)(pm + t) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+          } else {
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+              if (t0 + l < T) pm[t0 + l] = acc[l];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const float loc = lev[l] + xw[l];
+          pm_acc[l] += loc;
+          tr[l] = fmaf(so_prev, zp[l], loc);
+        }
       }
       const size_t row = (size_t)s * T;
       bool vec_done = false;
@@ -994,8 +1053,16 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
         }
       }
     }
+    if constexpr (LY::PARK) {
+      float yq[L];
+      lds_row_load<L>(ybuf + t0, yq);
 #pragma unroll
-    for (int l = 0; l < L; ++l) resid[l] = yv[l] - xw[l];
+      for (int l = 0; l < L; ++l) resid[l] = yq[l] - xw[l];
+    } else {
+#pragma unroll
+      for (int l = 0; l < L; ++l) resid[l] = yv[l] - xw[l];
+    }
+    if constexpr (LY::PARK) store_targets<L>(xwb, t0, xw);     // read back by the emission of this draw
     const Vec<D> a1e = dk_initial_mean<D>(md, rng, (uint32_t)it, tid, scal + SC8_ZINIT + 2 * (it & 1));
     Vec<D> xp[L];
     float ytil[L];
@@ -1031,7 +1098,11 @@ __global__ __launch_bounds__(NT8) void gibbs_kernel8(KArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const int t = t0 + l;
-      if (t < T) pm[t] = pm_acc[l] * inv;
+      if constexpr (LY::PARK) {
+        if (t < T) pm[t] = (a.S > 0 ? pm[t] : 0.f) * inv;      // (this thread's own sums, written above)
+      } else {
+        if (t < T) pm[t] = pm_acc[l] * inv;
+      }
     }
   }
 }

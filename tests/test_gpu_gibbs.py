@@ -425,7 +425,11 @@ def test_streamed_fetch_of_a_seasonal_model_equals_run_then_fetch():
 @pytest.mark.parametrize("T,p,has_slope,B,C", [(1000, 10, 1, 1, 3), (500, 5, 0, 4, 2), (100, 1, 0, 1, 2),
                                                (300, 15, 1, 1, 2),
                                                (2000, 10, 1, 1, 2),    # L = 8 (1024 < T <= 2048)
-                                               (1300, 6, 0, 2, 2)])
+                                               (1300, 6, 0, 2, 2),
+                                               # L = 16, the design streamed from L2 by both kernels:
+                                               (4096, 10, 1, 1, 2),    # float4 rows
+                                               (4094, 7, 0, 1, 2)])    # T % 4 != 0: guarded scalar reads
+                                                                       # (rolled in the four-wave build)
 def test_eight_wave_latency_kernel_equals_the_four_wave_kernel(T, p, has_slope, B, C):
   """gibbs_kernel8 (a dedicated regression wavefront that sweeps the next iteration's matrix
   during the Durbin-Koopman draw and replays the recorded multipliers on the new right-hand

@@ -393,7 +393,7 @@ constexpr int RED_INC = 20;        // then (ss_level, ss_slope) per time wave
 // XG: the design is NOT in LDS (long series): rows of T floats in global memory (L2-resident),
 // read as float4 when `xwide` (T % 4 == 0 and 16-byte aligned rows), else as guarded scalars;
 // chunks beyond the series read as zeros.  Same values, same order => same bits as the LDS variant.
-template <int L, int NF, bool XG = false>
+template <int L, int NF, bool XG = false, bool ROLL = false>
 __device__ __forceinline__ void xt_sums_wave(const float* tg, const float* Xs, int tpad, int P, int j0,
                                              bool with_yty, float* sums, int lane, int T = 0,
                                              bool xwide = true) {
@@ -443,15 +443,44 @@ __device__ __forceinline__ void xt_sums_wave(const float* tg, const float* Xs, i
     for (int f = 0; f < NF; ++f) {
       const int j = j0 + f;
       const float* row = Xs + (size_t)(j < P ? j : P - 1) * T;
-      float4 xq[L];
+      if constexpr (ROLL) {
+        // guarded scalar reads (T % 4 != 0), 4 L per feature: four quads of loads in flight at a time
+        // in a ROLLED loop, the targets re-read from LDS -- unrolled, the 4 L loads of every feature
+        // were hoisted together and cost the four-wave L = 16 build 2 KB of scratch per lane.  Same
+        // products in the same order as dot().  (ROLL: the four-wave long-series build only -- the
+        // eight-wave kernel measured 8 % SLOWER at T = 4096 with it, less scratch notwithstanding.)
+        float sv = 0.f;
+#pragma unroll 1
+        for (int c0 = 0; c0 < L; c0 += 4) {
+          float4 xq[4], tq4[4];
 #pragma unroll
-      for (int c = 0; c < L; ++c) {
-        const int t = 4 * (lane + 64 * c);
-        const float x0 = row[t < T ? t : T - 1], x1 = row[t + 1 < T ? t + 1 : T - 1];
-        const float x2 = row[t + 2 < T ? t + 2 : T - 1], x3 = row[t + 3 < T ? t + 3 : T - 1];
-        xq[c] = make_float4(t < T ? x0 : 0.f, t + 1 < T ? x1 : 0.f, t + 2 < T ? x2 : 0.f, t + 3 < T ? x3 : 0.f);
+          for (int u = 0; u < 4; ++u) {
+            const int t = 4 * (lane + 64 * (c0 + u));
+            const float x0 = row[t < T ? t : T - 1], x1 = row[t + 1 < T ? t + 1 : T - 1];
+            const float x2 = row[t + 2 < T ? t + 2 : T - 1], x3 = row[t + 3 < T ? t + 3 : T - 1];
+            xq[u] = make_float4(t < T ? x0 : 0.f, t + 1 < T ? x1 : 0.f, t + 2 < T ? x2 : 0.f, t + 3 < T ? x3 : 0.f);
+            tq4[u] = *reinterpret_cast<const float4*>(tg + t);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            sv = fmaf(xq[u].x, tq4[u].x, sv);
+            sv = fmaf(xq[u].y, tq4[u].y, sv);
+            sv = fmaf(xq[u].z, tq4[u].z, sv);
+            sv = fmaf(xq[u].w, tq4[u].w, sv);
+          }
+        }
+        acc[f] = sv;
+      } else {
+        float4 xq[L];
+#pragma unroll
+        for (int c = 0; c < L; ++c) {
+          const int t = 4 * (lane + 64 * c);
+          const float x0 = row[t < T ? t : T - 1], x1 = row[t + 1 < T ? t + 1 : T - 1];
+          const float x2 = row[t + 2 < T ? t + 2 : T - 1], x3 = row[t + 3 < T ? t + 3 : T - 1];
+          xq[c] = make_float4(t < T ? x0 : 0.f, t + 1 < T ? x1 : 0.f, t + 2 < T ? x2 : 0.f, t + 3 < T ? x3 : 0.f);
+        }
+        acc[f] = dot(xq);
       }
-      acc[f] = dot(xq);
     }
   }
 #pragma unroll
@@ -2402,7 +2431,7 @@ struct SerialCtx {
 struct LdsLayout {
   size_t off_ctx, off_xtx, off_omega, off_aug0, off_aug1, off_pri0, off_pri1, off_chol, off_bvec,
       off_zv, off_uperm, off_nz, off_perm, off_idx, off_w, off_scal, off_red, off_slots, off_xlast,
-      off_tg, off_gam, off_nz0, off_tgv, off_x, total;
+      off_tg, off_gam, off_nz0, off_tgv, off_park, off_x, total;
 };
 
 __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_in_lds) {
@@ -2435,6 +2464,9 @@ __host__ __device__ inline LdsLayout make_layout(int P, int D, int tpad, int x_i
   l.off_nz0 = take(sizeof(float) * (4 * 64 * (tpad / NT) + 4));   // wave 0's normals, drawn by waves 1-3
   // targets y - level over time, handed to the waves that sum X~'targets (P <= 16)
   l.off_tgv = take((P > 0 && P <= 16) ? sizeof(float) * (size_t)tpad : 16);
+  // eight and more steps per thread (T > 1024): X w and the observations wait in LDS between their
+  // uses instead of in registers through every phase of the iteration (round 5, as in ci_kernels8.h)
+  l.off_park = take(tpad / NT >= 8 ? 2 * sizeof(float) * (size_t)tpad : 16);
   l.off_x = take(x_in_lds ? sizeof(float) * (size_t)Pp * tpad : 16);
   l.total = o;
   return l;
@@ -2591,6 +2623,9 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
   float* wls = (float*)(smem + lay.off_w);
   const float* Xs = (const float*)(smem + lay.off_x);
   float* tgv = (float*)(smem + lay.off_tgv);
+  constexpr bool PARK = L >= 8;
+  float* xwb = (float*)(smem + lay.off_park);        // (PARK builds only)
+  float* ybuf = xwb + TPAD;
   const size_t chain_lin = (size_t)series * a.C + chain;
   const int RS = (P > 16 ? P : 16) + 4;   // stride of the per-wave partial-sum rows
 
@@ -2653,6 +2688,7 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
     const bool m = in ? (mg[t] != 0) : true;
     if (m) { maskbits |= (1u << l); yv[l] = 0.f; }
   }
+  if constexpr (PARK) store_targets<L>(ybuf, t0, yv);
   {
     double* lx = (double*)(smem + lay.off_xtx);
     double* lo = (double*)(smem + lay.off_omega);
@@ -2709,11 +2745,32 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
         fill_normals<L>(rng, (uint32_t)(it - 1), SITE_PRED, 0, (uint32_t)t0, zp);
       }
       float tr[L];
+      if constexpr (PARK) {
+        // X w of draw it-1 from LDS; the predictor's running sum in place in its output array (the
+        // same sequence of float additions as the register copy: same bits)
+        float xwp[L], acc[L];
+        lds_row_load<L>(xwb + t0, xwp);
+        float* pmo = a.out_pred_mean ? a.out_pred_mean + chain_lin * T : nullptr;
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const float loc = lev[l] + xw[l];
-        pm_acc[l] += loc;
-        tr[l] = fmaf(so, zp[l], loc);
+        for (int l = 0; l < L; ++l) acc[l] = (pmo != nullptr && s > 0 && t0 + l < T) ? pmo[t0 + l] : 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const float loc = lev[l] + xwp[l];
+          acc[l] += loc;
+          tr[l] = fmaf(so, zp[l], loc);
+        }
+        if (pmo != nullptr) {
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+            if (t0 + l < T) pmo[t0 + l] = acc[l];
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const float loc = lev[l] + xw[l];
+          pm_acc[l] += loc;
+          tr[l] = fmaf(so, zp[l], loc);
+        }
       }
       const size_t row = (size_t)s * T;
       bool vec_done = false;
@@ -2745,12 +2802,18 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
     };
     // ---- partial sums over the owned steps (targets use the CURRENT level)
     {
-      float tg[L];
+      float tg[L], yq[L];
       float yty = 0.f;
+      if constexpr (PARK) {
+        lds_row_load<L>(ybuf + t0, yq);
+      } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l) yq[l] = yv[l];
+      }
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         const bool obs = ((maskbits >> l) & 1u) == 0u;
-        tg[l] = obs ? (yv[l] - lev[l]) : 0.f;
+        tg[l] = obs ? (yq[l] - lev[l]) : 0.f;
         yty = fmaf(tg[l], tg[l], yty);
       }
       prof.tick(15);
@@ -2834,8 +2897,17 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
       xlast[tid * D] = lev[L - 1];
       if constexpr (D == 2) xlast[tid * D + 1] = slp[L - 1];
       __syncthreads();
-      if constexpr (NEWRED)
-        xt_sums_wave<L, 4, STREAM>(tgv, STREAM ? Xg : Xs, TPAD, P, 4 * wave, wave == NW - 1, red, lane, T, xwide);
+      if constexpr (NEWRED) {
+        if constexpr (STREAM && L >= 8) {
+          // (two features at a time: the loads of four streamed rows of L float4 do not fit beside the
+          //  rest -- same sums, each feature is summed on its own)
+          xt_sums_wave<L, 2, STREAM, true>(tgv, Xg, TPAD, P, 4 * wave, false, red, lane, T, xwide);
+          __builtin_amdgcn_sched_barrier(0);
+          xt_sums_wave<L, 2, STREAM, true>(tgv, Xg, TPAD, P, 4 * wave + 2, wave == NW - 1, red, lane, T, xwide);
+        } else {
+          xt_sums_wave<L, 4, STREAM>(tgv, STREAM ? Xg : Xs, TPAD, P, 4 * wave, wave == NW - 1, red, lane, T, xwide);
+        }
+      }
       float ssl = 0.f, sss = 0.f;
       float pl = (tid > 0) ? xlast[(tid - 1) * D] : 0.f;
       float ps = 0.f;
@@ -2986,21 +3058,27 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
           for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[l], wj, xw[l]);
         }
       } else {
-        // the streamed design (see the X~'targets loop)
+        // the streamed design: rows in batches of independent loads, and only the rows of the
+        // INCLUDED features (a zero weight adds an exact zero: the same sums, bit for bit) -- a
+        // run-time loop as in ci_kernels8.h: the unrolled form let the compiler hoist the loads of all
+        // sixteen rows at once (256 registers at L = 16: 6 KB of scratch per lane)
         constexpr int RB = L >= 16 ? 2 : (L >= 8 ? 4 : 8);
         auto stream = [&](auto load_row) {
-#pragma unroll
-          for (int h = 0; h < 16 / RB; ++h) {
-            if (h * RB >= P) continue;
-            float xr[RB][L];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) load_row(h * RB + u < P ? h * RB + u : P - 1, xr[u]);
+          unsigned long long todo = __ballot(lane < P && wls[lane < P ? lane : 0] != 0.f);
+          while (todo != 0ull) {
+            float xr[RB][L], wj[RB];
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
-              const float wj = h * RB + u < P ? wv[h * RB + u] : 0.f;
-#pragma unroll
-              for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[u][l], wj, xw[l]);
+              const bool have = todo != 0ull;
+              const int j = have ? __ffsll((long long)todo) - 1 : 0;
+              todo &= todo - 1ull;
+              wj[u] = have ? wls[j] : 0.f;
+              load_row(j, xr[u]);
             }
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+#pragma unroll
+              for (int l = 0; l < L; ++l) xw[l] = fmaf(xr[u][l], wj[u], xw[l]);
           }
         };
         if (xwide) {
@@ -3044,8 +3122,16 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
                   std::true_type());
       }
     }
+    if constexpr (PARK) {
+      float yq[L];
+      lds_row_load<L>(ybuf + t0, yq);
 #pragma unroll
-    for (int l = 0; l < L; ++l) resid[l] = yv[l] - xw[l];
+      for (int l = 0; l < L; ++l) resid[l] = yq[l] - xw[l];
+      store_targets<L>(xwb, t0, xw);       // read back by the emission of this draw
+    } else {
+#pragma unroll
+      for (int l = 0; l < L; ++l) resid[l] = yv[l] - xw[l];
+    }
     DkModel<D> md;
     {
       const float so = scal[SC_OBS_DK];
@@ -3084,7 +3170,11 @@ __global__ __launch_bounds__(NT, PM == 2 ? 1 : CI_MIN_WAVES) void gibbs_kernel(K
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const int t = t0 + l;
-      if (t < T) pm[t] = pm_acc[l] * inv;
+      if constexpr (PARK) {
+        if (t < T) pm[t] = (a.S > 0 ? pm[t] : 0.f) * inv;      // (this thread's own sums, written above)
+      } else {
+        if (t < T) pm[t] = pm_acc[l] * inv;
+      }
     }
   }
 }

@@ -105,3 +105,51 @@ def test_hmc_recovers_the_gibbs_posterior_when_both_target_the_same_model():
   lh = np.mean([x["level"][:, 100] for x in hm])
   lg = np.mean([x["level"][:, 100] for x in gb])
   assert abs(lh - lg) < 0.06
+
+
+def test_host_target_layout_for_seasonal_blocks_without_a_gpu():
+  """`_hmc._Target` (the log posterior the mean-field surrogate of `_vi.py` is fitted to) with
+  seasonal blocks, round 5: theta_u = (beta[P], log s_obs, log s_level[, log s_slope], log s_drift[K])
+  is unpacked to the device layout (s_obs, s_level, s_slope, drift[K], beta) and the gradient comes
+  back through the same map.  A fake session returns an analytic l(theta) = -1/2 |theta_dev - c|^2:
+  the target's value and gradient must equal the closed form, drift priors (causalimpact_lib.py:
+  472-474) included."""
+  from causalimpact import _hmc      # (conftest.py puts the package on the path; no library call below)
+  P, K = 3, 2
+  rng = np.random.default_rng(0)
+  c = rng.normal(size=3 + K + P)
+
+  class FakeSession:
+    def evaluate(self, dev, want_grad=True):
+      d = dev - c
+      return -0.5 * np.sum(d * d, axis=1), -d
+
+  spec = dict(obs_conc=0.01, obs_scale=0.02, level_conc=16.0, level_scale=0.03, slope_conc=16.0,
+              slope_scale=0.04, drift_conc=0.01, drift_scale=0.05)
+  omega = np.diag([0.5, 0.25, 0.125])
+  tgt = _hmc._Target(FakeSession(), spec, omega, P, True, K)
+  assert tgt.dim == P + 3 + K
+  th = rng.normal(size=(4, tgt.dim)) * 0.3
+  lp, g = tgt(th)
+  dev = _hmc._unpack(th, P, True, K)
+  np.testing.assert_allclose(dev[:, 3 + K:], th[:, :P])                      # beta last
+  np.testing.assert_allclose(dev[:, 3:3 + K], np.exp(th[:, P + 3:]))         # drift scales after the trend's
+  ig = [(0.01, 0.02), (16.0, 0.03), (16.0, 0.04)] + [(0.01, 0.05)] * K
+
+  def closed_form(t):
+    d = _hmc._unpack(t[None], P, True, K)[0]
+    v = -0.5 * np.sum((d - c) ** 2) - 0.5 * t[:P] @ omega @ t[:P]
+    for k, (a, b) in enumerate(ig):
+      v += -2.0 * a * t[P + k] - b * np.exp(-2.0 * t[P + k])
+    return v
+
+  for e in range(th.shape[0]):
+    np.testing.assert_allclose(lp[e], closed_form(th[e]), rtol=1e-12)
+    fd = np.zeros(tgt.dim)
+    for i in range(tgt.dim):
+      h = 1e-6
+      a_, b_ = th[e].copy(), th[e].copy()
+      a_[i] += h
+      b_[i] -= h
+      fd[i] = (closed_form(a_) - closed_form(b_)) / (2 * h)
+    np.testing.assert_allclose(g[e], fd, rtol=1e-6, atol=1e-7)

@@ -2,14 +2,17 @@
 C-ABI) against the float64 oracle (oracle/ci_oracle.c) on the same seeded inputs.
 
 north_star: "posterior mean/CI within 1 %".  Each summary is compared within
-    max(1 % of the oracle value, 4 Monte-Carlo standard errors)
+    max(1 % of the oracle VALUE, 4 Monte-Carlo standard errors)
 where the standard error is COMPUTED from the spread of per-chain summaries on both sides (not
-guessed), and the table of (device, oracle, difference, MC s.e.) is written to
-gpurun_out/parity_fullsize_<cfg>.json for DESIGN.md.  What that band amounts to depends on the
-quantity: for the scale parameters and the weights 32 independent chains a side bring 4 s.e.
-below 1 %, so for them it IS the 1 % band; the post-period average of the predictive DRAWS has a
-Monte-Carlo error of several per cent whatever the sampler (a forecast of a local linear trend
-300 steps ahead), so for it the band is 4 s.e. -- which is why the prediction is ALSO compared
+guessed), and the table of (device, oracle, difference, MC s.e., difference relative to the value,
+band as per cent of the value) is written to gpurun_out/parity_fullsize_<cfg>.json for DESIGN.md.
+Round 6: the reference of the 1 % figure is the value itself for every scale parameter -- the
+floor of 0.05 that rounds 2-5 applied to all quantities is kept for regression weights and
+inclusion frequencies only -- and enough chains are run that sigma_obs and, at cfg2, sigma_level
+reach 4 s.e. < 1 % and are ASSERTED at 1 %; the quantities that cannot (sigma_slope, sigma_drift,
+the 95 % interval ends of slowly mixing scales, the post-period average of the predictive DRAWS,
+which has a Monte-Carlo error of several per cent whatever the sampler) are listed with the band
+they were held to under `_summary.mc_limited`.  The prediction is ALSO compared
 through `posterior_means` (the Rao-Blackwellised predictor, no observation noise): path-wise over
 all T steps, on independent replicates, in units of the outcome's standard deviation
 (`_compare_paths`).  The device chains reuse the oracle's Philox streams (chain ids 0..C-1), so
@@ -88,7 +91,15 @@ def _compare_paths(tag, dev_pm, orc_pm, pre_end, outcome_sd=1.0):
   return rows
 
 
-def _compare(tag, dev_chains, orc_chains, scale_floor):
+def _compare(tag, dev_chains, orc_chains, weight_floor=0.05, must_reach_1pct=()):
+  """Every summary against `max(1 % of |oracle value|, 4 Monte-Carlo s.e.)`.  The reference of the
+  1 % figure is the ORACLE VALUE ITSELF for every scale parameter and prediction summary (round-5
+  review: a floor of 0.05 on a sigma_level of 0.004 made the "1 %" band 13 % wide); only the
+  regression weights and inclusion frequencies -- most of them exactly or nearly zero -- keep an
+  absolute floor (`weight_floor`, in units of the standardised outcome).  `rel` is the difference
+  relative to the oracle value.  Quantities whose Monte-Carlo error cannot reach 1 % with the chains
+  run are LISTED (`_summary.mc_limited`, with the band they were actually held to), not hidden;
+  those named in `must_reach_1pct` must have 4 s.e. < 1 % AND meet the 1 % figure."""
   keys = sorted(dev_chains[0])
   rows, bad = {}, []
   for k in keys:
@@ -98,37 +109,46 @@ def _compare(tag, dev_chains, orc_chains, scale_floor):
     o = np.array([c[k] for c in orc_chains])
     se = float(np.sqrt(d.var(ddof=1) / d.size + o.var(ddof=1) / o.size))
     diff = float(d.mean() - o.mean())
-    # inclusion frequencies and near-zero weights have no meaningful relative scale
-    ref = max(abs(o.mean()), scale_floor)
+    val = abs(float(o.mean()))
+    ref = max(val, weight_floor) if k.startswith("w") else val
     allowed = max(0.01 * ref, 4.0 * se)
     rows[k] = dict(device=float(d.mean()), oracle=float(o.mean()), diff=diff, mc_se=se,
-                   rel=diff / ref, allowed=allowed)
+                   rel=(diff / val if val > 0 else None), ref=ref, allowed=allowed,
+                   band_pct_of_value=(100.0 * allowed / val if val > 0 else None),
+                   mc_limited=bool(4.0 * se > 0.01 * ref))
     if abs(diff) > allowed:
       bad.append((k, rows[k]))
+  head = [k for k in rows if not k.startswith("w")]
+  rows["_summary"] = dict(
+      chains=dict(device=len(dev_chains), oracle=len(orc_chains)),
+      within_1pct_of_value=[k for k in head if rows[k]["rel"] is not None and abs(rows[k]["rel"]) < 0.01],
+      mc_limited={k: rows[k]["band_pct_of_value"] for k in head if rows[k]["mc_limited"]},
+      worst_rel={k: rows[k]["rel"] for k in head})
   os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
   with open(os.path.join(ROOT, "gpurun_out", f"parity_fullsize_{tag}.json"), "w") as f:
     json.dump(rows, f, indent=1)
   assert not bad, bad
-  # the headline quantities must meet the 1 % figure outright whenever their MC error allows it
-  for k in ("sigma_obs.mean", "post_mean_prediction.mean"):
-    if rows[k]["mc_se"] < 0.0025 * max(abs(rows[k]["oracle"]), scale_floor):
-      assert abs(rows[k]["rel"]) < 0.01, (k, rows[k])
+  for k in must_reach_1pct:
+    assert not rows[k]["mc_limited"], ("not enough chains for a 1 % statement", k, rows[k])
+    assert abs(rows[k]["rel"]) < 0.01, (k, rows[k])
   return rows
 
 
 def test_cfg2_long_run_posterior_matches_oracle_within_one_percent_or_mc_error():
-  """BASELINE cfg2: T=1000, P=11, LocalLinearTrend + spike-and-slab, W=112, S=1000.  64 device
-  chains (ids 0..63, one launch) and 32 float64 oracle chains (ids 0..31; ~0.2 s each, on the
+  """BASELINE cfg2: T=1000, P=11, LocalLinearTrend + spike-and-slab, W=112, S=1000.  256 device
+  chains (ids 0..255, one launch) and 128 float64 oracle chains (ids 0..127; ~0.2 s each, on the
   host cores).  Two comparisons:
-    * INDEPENDENT replicates -- device chains 32..63 against oracle chains 0..31 (disjoint random
-      streams): for sigma_obs, the disturbance scales and the weights 32 chains a side bring
-      4 s.e. below 1 %, i.e. `allowed = max(1 %, 4 s.e.)` is the 1 % band for them; the
-      post-period average of the predictive draws keeps a band of 4 s.e. (~ 19 %: Monte-Carlo
-      error of a 300-step forecast), and the prediction is pinned through the path of
-      `posterior_means` instead (`_compare_paths`: 1 % of the outcome's s.d. over the pre-period);
+    * INDEPENDENT replicates -- device chains 128..255 against oracle chains 0..127 (disjoint
+      random streams).  128 chains a side are what brings 4 s.e. of sigma_level (a slowly mixing
+      scale of ~0.01) below 1 % OF ITS OWN VALUE: sigma_obs and sigma_level must meet the 1 %
+      figure outright (`must_reach_1pct`); sigma_slope (~0.001, posterior c.v. ~ 40 %) and the
+      post-period average of the predictive draws (Monte-Carlo error of a 300-step forecast) are
+      held to 4 s.e. and listed with that band in the table -- and the prediction is pinned
+      through the path of `posterior_means` instead (`_compare_paths`: 1 % of the outcome's s.d.
+      over the pre-period);
     * the SAME chain ids 0..7 on both sides: float32 kernel vs float64 oracle on one random
       stream, i.e. pure arithmetic drift over 1112 iterations."""
-  T, p, W, S, C, CO = 1000, 10, 112, 1000, 64, 32
+  T, p, W, S, C, CO = 1000, 10, 112, 1000, 256, 128
   seed = (0, 20240927)
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 2024)
   spec = orc.default_spec(y, mask, X, has_slope=True)
@@ -142,25 +162,28 @@ def test_cfg2_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
                           g["slope_scale"][0, c], g["weights"][0, c],
                           g["posterior_trajectories"][0, c][:, post].mean(axis=1),
                           g["posterior_means"][0, c][post].mean()) for c in range(C)]
-  with concurrent.futures.ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+  with concurrent.futures.ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
     ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
-  rows = _compare("cfg2", dev[CO:], ora, scale_floor=0.05)
-  # the prediction, path-wise, through posterior_means: device chains 32..63 vs oracle chains 0..31
+  rows = _compare("cfg2", dev[CO:], ora, must_reach_1pct=("sigma_obs.mean", "sigma_level.mean"))
+  # the prediction, path-wise, through posterior_means: device chains 128..255 vs oracle chains 0..127
   _compare_paths("cfg2", g["posterior_means"][0, CO:], np.stack([c["_pred_mean_path"] for c in ora]),
                  pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))
   # float32 drift over 1112 iterations: the SAME chains (ids 0..7) on both sides
-  same = _compare("cfg2_same_chains", dev[:8], ora[:8], scale_floor=0.05)
+  same = _compare("cfg2_same_chains", dev[:8], ora[:8])
   assert abs(same["sigma_obs.mean"]["rel"]) < 1e-3
   assert rows["sigma_obs.mean"]["oracle"] > 0
 
 
 def test_cfg4_long_run_posterior_matches_oracle_within_one_percent_or_mc_error():
   """BASELINE cfg4: T=10000, 50 covariates (P=51) + Seasonal(num_seasons=7), time-parallel
-  kernel over its HBM workspace; W=112, S=400 (the oracle costs ~8 ms per iteration: ~4 s per
-  chain, run in parallel on the host).  8 device chains in one launch against 4 oracle chains
-  (ids 0..3): device chains 4..7 are INDEPENDENT replicates of the oracle's, device chains 0..3
-  the same random streams (float32-vs-float64 drift of one stream)."""
-  T, p, W, S, C, CO = 10000, 50, 112, 400, 8, 4
+  kernel over its HBM workspace; W=112, S=400 -- NOT the configuration's 1000 draws: the oracle
+  costs ~8 ms per iteration, ~4 s per chain, run in parallel on the host.  32 device chains in one
+  launch against 16 oracle chains (ids 0..15): device chains 16..31 are INDEPENDENT replicates of
+  the oracle's, device chains 0..15 the same random streams (float32-vs-float64 drift of one
+  stream).  sigma_obs must meet 1 % of its value outright; sigma_level (0.004) and sigma_drift
+  (0.001) mix slowly -- their bands are 4 s.e. and are written, as per cent of the value, into
+  the table's `_summary.mc_limited`."""
+  T, p, W, S, C, CO = 10000, 50, 112, 400, 32, 16
   seed = (3, 1)
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
   t = np.arange(T)
@@ -171,16 +194,18 @@ def test_cfg4_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
   pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_seasons=(7,), num_warmup=W,
                             num_results=S, num_chains=C, seed=seed)
   sc = np.stack(spec["season_change"])
-  g = _native.fit_gibbs(pb, y[None], mask[None], X[None], sc, _native.make_params([spec]))
+  g = _native.fit_gibbs(pb, y[None], mask[None], X[None], sc, _native.make_params([spec]),
+                        want=("observation_noise_scale", "level_scale", "slope_scale", "weights",
+                              "posterior_trajectories", "posterior_means", "seasonal_drift_scales"))
   dev = [_chain_summaries(g["observation_noise_scale"][0, c], g["level_scale"][0, c],
                           g["slope_scale"][0, c], g["weights"][0, c],
                           g["posterior_trajectories"][0, c][:, post].mean(axis=1),
                           g["posterior_means"][0, c][post].mean(),
                           g["seasonal_drift_scales"][0, c]) for c in range(C)]
-  with concurrent.futures.ProcessPoolExecutor(max_workers=CO) as ex:
+  with concurrent.futures.ProcessPoolExecutor(max_workers=min(CO, os.cpu_count() or 1)) as ex:
     ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
-  _compare("cfg4", dev[CO:], ora, scale_floor=0.05)                 # independent replicates
-  _compare("cfg4_same_chains", dev[:CO], ora, scale_floor=0.05)     # drift of the same streams
+  _compare("cfg4", dev[CO:], ora, must_reach_1pct=("sigma_obs.mean",))     # independent replicates
+  _compare("cfg4_same_chains", dev[:CO], ora)                              # drift of the same streams
   _compare_paths("cfg4", g["posterior_means"][0, CO:], np.stack([c["_pred_mean_path"] for c in ora]),
                  pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))
 
@@ -189,10 +214,10 @@ def test_general_seasonal_long_run_posterior_matches_oracle_within_one_percent_o
   """The reference's 4+7+6-season model (causalimpact_lib_test.py:738-752) at cfg4's size -- T=10000,
   50 covariates -- on the time-parallel cluster kernel of round 5 (csrc/ci_seasonal_tp.h: 128 chunks
   of 80 steps, wave-cooperative float32 scan elements): W=100, S=300 (the oracle costs ~10 ms per
-  iteration: ~4 s per chain, in parallel on the host).  8 device chains in one launch against 4
-  oracle chains: device chains 4..7 are independent replicates, device chains 0..3 the oracle's
+  iteration: ~4 s per chain, in parallel on the host).  16 device chains in one launch against 8
+  oracle chains: device chains 8..15 are independent replicates, device chains 0..7 the oracle's
   own random streams (the float32-vs-float64 drift of one stream over 400 iterations)."""
-  T, p, W, S, C, CO = 10000, 50, 100, 300, 8, 4
+  T, p, W, S, C, CO = 10000, 50, 100, 300, 16, 8
   seed = (3, 1)
   seasons = ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))
   from causalimpact import _model
@@ -208,17 +233,18 @@ def test_general_seasonal_long_run_posterior_matches_oracle_within_one_percent_o
   sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
   assert "gibbs_seasonal_tp_kernel" in sess.kernel_name()
   sess.run()
-  g = sess.fetch()
+  g = sess.fetch(["observation_noise_scale", "level_scale", "slope_scale", "weights",
+                  "posterior_trajectories", "posterior_means", "seasonal_drift_scales"])
   sess.close()
   dev = [_chain_summaries(g["observation_noise_scale"][0, c], g["level_scale"][0, c],
                           g["slope_scale"][0, c], g["weights"][0, c],
                           g["posterior_trajectories"][0, c][:, post].mean(axis=1),
                           g["posterior_means"][0, c][post].mean(),
                           g["seasonal_drift_scales"][0, c]) for c in range(C)]
-  with concurrent.futures.ProcessPoolExecutor(max_workers=CO) as ex:
+  with concurrent.futures.ProcessPoolExecutor(max_workers=min(CO, os.cpu_count() or 1)) as ex:
     ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
-  _compare("general_seasonal", dev[CO:], ora, scale_floor=0.05)                 # independent replicates
-  _compare("general_seasonal_same_chains", dev[:CO], ora, scale_floor=0.05)     # drift of the same streams
+  _compare("general_seasonal", dev[CO:], ora, must_reach_1pct=("sigma_obs.mean",))   # independent replicates
+  _compare("general_seasonal_same_chains", dev[:CO], ora)                            # drift of the same streams
   _compare_paths("general_seasonal", g["posterior_means"][0, CO:],
                  np.stack([c["_pred_mean_path"] for c in ora]),
                  pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))

@@ -235,8 +235,13 @@ __device__ __forceinline__ void tp_cluster_barrier(TpSync& s, int tid) {
   // RELAXED atomic.  A release at agent scope would write the XCD's whole L2 back first (MI300-class
   // parts keep one L2 per XCD: "agent" spans them): measured ~30k cycles per barrier, ten barriers
   // per iteration.  Several XCDs: the full agent-scope release.
-  if (s.light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  else __threadfence();
+  // (round 6, ADVICE) the workgroup-scope release compiles to NO wait on gfx950 (the disassembly
+  // of the light branch was s_barrier + global_atomic_add only): every wave drains its own stores
+  // to the shared L2 explicitly before the barrier, so the arrival cannot overtake them.
+  if (s.light) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else __threadfence();
   __syncthreads();
   if (tid == 0) {
     if (s.light) (void)__hip_atomic_fetch_add(s.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -769,8 +769,12 @@ __device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + 
 // have to reach the shared L2 (the vector L1 is write-through: wait for them) and the reader only
 // has to drop its L1; otherwise the release also writes the L2 back (agent scope).
 __device__ __forceinline__ void cl_publish(int* flag, int value, int tid, bool light) {
-  if (light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  else __threadfence();
+  // (round 6, ADVICE) the workgroup-scope release emits no s_waitcnt on gfx950: drain this wave's
+  // stores to the shared L2 explicitly, so the flag below cannot overtake them.
+  if (light) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else __threadfence();
   __syncthreads();
   // (round 5) light: a RELAXED store -- the data is in the shared L2 once s_waitcnt vmcnt(0), the
   // workgroup-scope release above, has returned; a RELEASE at agent scope adds an L2 write-back

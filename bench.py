@@ -144,10 +144,11 @@ def _pmc_traffic(sampler):
   """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (profiles/*pmc.json, written by
   tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command) and the
   file it came from -- the fallback of _measure_traffic."""
-  names = (("r04_cfg3_pmc.json", "r03_cfg3_pmc.json", "r02_cfg3_pmc.json") if sampler == "hmc" else
-           ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"))
-  for name in names:
-    path = os.path.join(ROOT, "profiles", name)
+  import glob  # pylint: disable=import-outside-toplevel
+  pat = "r[0-9][0-9]_cfg3_pmc.json" if sampler == "hmc" else "r[0-9][0-9]_pmc.json"
+  # the newest round's file first (profiles/rNN_*: NN sorts by round)
+  for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), reverse=True):
+    name = os.path.basename(path)
     if os.path.exists(path):
       with open(path) as f:
         return json.load(f).get("hbm_bytes_per_launch"), "profiles/" + name + " (committed; not measured in this run)"
@@ -288,6 +289,91 @@ class _HmcFit:
             "chip; `achieved` counts the fit's algorithmic bytes over BOTH kernels' time" % C)
 
 
+def _roof(nbytes, ms):
+  ach = nbytes / (ms * 1e-3) / 1e9
+  return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}
+
+
+def _other_configs(device):
+  """The BASELINE configs that are not the headline, one short measurement each AFTER the timed
+  region (round-5 review: only cfg2 was ever timed by the driver).  Kernel time by HIP events
+  around one launch (after one warm launch), inputs resident in HBM; the same workloads as
+  tools/run_configs.py (whose lines add traffic counters and CPU baselines)."""
+  import causalimpact as ci  # pylint: disable=import-outside-toplevel
+  rows = []
+
+  def guarded(label, fn):
+    try:
+      rows.extend(fn())
+    except Exception as e:  # pylint: disable=broad-except
+      rows.append({"config": label, "error": f"{type(e).__name__}: {e}"})
+
+  def cfg3():
+    y, mask, X, _ = syn.make_sampler_inputs(CFG["T"], CFG["covariates"], CFG["data_seed"])
+    fit = _HmcFit(y, mask, X, CFG["chains_per_gpu"], 0, device)
+    fit.run()
+    k = fit.run()
+    nbytes, name = fit.sess.algorithmic_bytes(), fit.sess.kernel_name()
+    fit.sess.close()
+    ms = k["kernel"] + k["latents"]
+    n_leap = (CFG["hmc_warmup"] + CFG["num_results"]) * CFG["hmc_leapfrog"]
+    return [{"config": "cfg3", "workload": fit.workload + " (this GPU's 8 of the 64 chains)", "kernel": name,
+             "chains": CFG["chains_per_gpu"], "kernel_ms": k["kernel"], "latents_kernel_ms": k["latents"],
+             "us_per_leapfrog": k["kernel"] * 1e3 / n_leap,
+             "samples_per_s": CFG["chains_per_gpu"] * CFG["num_results"] / ms * 1e3,
+             "roofline": _roof(nbytes, ms)}]
+
+  def cfg4():
+    T, p, S = 10000, 50, 1000
+    W = -(-S // 9)
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 0)
+    y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+    spec = _model.series_params(y, mask, X, num_seasonal_blocks=1)
+    counts, flg = _model.expand_seasons((ci.Seasons(num_seasons=7),), T)
+    out = []
+    for chains in (8, 32):
+      pb = _native.make_problem(T=T, P=X.shape[1], has_slope=0, num_seasons=counts, num_warmup=W,
+                                num_results=S, num_chains=chains, seed=(0, 1), device=device)
+      sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+      sess.run()
+      ms = sess.run()
+      out.append({"config": "cfg4", "workload": "T=10000, 50 covariates (P=51), LocalLevel + Seasonal(7) + "
+                  "spike-and-slab regression, Gibbs, W=%d, S=%d" % (W, S), "kernel": sess.kernel_name(),
+                  "chains": chains, "kernel_ms": ms, "us_per_gibbs_iteration": ms / (W + S) * 1e3,
+                  "samples_per_s": chains * S / ms * 1e3, "roofline": _roof(sess.algorithmic_bytes(), ms)})
+      sess.close()
+    return out
+
+  def cfg5():
+    import pandas as pd  # pylint: disable=import-outside-toplevel
+    T, p, S = 500, 5, 1000
+    out = []
+    values = np.stack([np.column_stack(syn.make_raw_series(T, p, b)) for b in range(512)])
+    prep = ci.batch.prepare_batch(values, pd.RangeIndex(T), (0, 349), (350, 499))
+    params = [_model.series_params(prep.y[b], prep.mask[b], prep.design[b]) for b in range(512)]
+    W = ci.InferenceOptions(num_results=S).num_warmup_steps
+    for B in (64, 512):
+      pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_warmup=W, num_results=S, num_chains=1,
+                                num_series=B, seed=(0, 1), device=device)
+      sess = _native.Session(pb, prep.y[:B], prep.mask[:B], prep.design[:B], None,
+                             _native.make_params(params[:B]))
+      sess.run()
+      ms = sess.run()
+      out.append({"config": "cfg5", "workload": "independent series, T=500, 5 covariates (P=6), LocalLevel + "
+                  "spike-and-slab regression, Gibbs, W=%d, S=%d%s" % (
+                      W, S, " (one GPU's share of the 512 on 8 GPUs)" if B == 64 else " (all 512 on one GPU)"),
+                  "kernel": sess.kernel_name(), "series": B, "kernel_ms": ms,
+                  "samples_per_s": B * S / ms * 1e3, "roofline": _roof(sess.algorithmic_bytes(), ms)})
+      sess.close()
+    return out
+
+  guarded("cfg3", cfg3)
+  guarded("cfg4", cfg4)
+  guarded("cfg5", cfg5)
+  return rows
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +383,8 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-pmc", action="store_true",
                   help="skip the two rocprofv3 counter passes that measure roofline.traffic")
+  ap.add_argument("--no-other-configs", action="store_true",
+                  help="skip the short cfg3 / cfg4 / cfg5 measurements after the timed region")
   ap.add_argument("--chains-per-gpu", type=int, default=CFG["chains_per_gpu"])
   ap.add_argument("--chunk-draws", type=int, default=CFG["chunk_draws"],
                   help="retained draws per device-to-host copy of the streamed fetch")
@@ -442,6 +530,12 @@ def main():
     out["config"]["n_gt_1_note"] = ("cpu_baseline is timed at N=1 only; roofline.traffic on this "
                                     "line is the committed single-GPU counter figure (per GPU), not "
                                     "measured in this run")
+  if (rank == 0 and world == 1 and comm is None and args.sampler == "gibbs" and not args.no_other_configs
+      and os.environ.get("CI_BENCH_INNER") != "1"):
+    # the other BASELINE configs, after the timed region (the headline value / config stay cfg2)
+    fit.sess.close()
+    fit.sess = None
+    out["other_configs"] = _other_configs(local_rank)
   hard_exit = False
   if comm is not None:
     comm.barrier()
@@ -451,7 +545,8 @@ def main():
     out["config"]["rccl_join_abandoned"] = ("an RCCL join that missed its deadline may still have been "
                                             "blocked (and its kernel spinning on the GPU) while this run "
                                             "was timed over the host transport")
-  fit.sess.close()
+  if fit.sess is not None:
+    fit.sess.close()
   if comm is not None:
     comm.close()
   # librccl prints a version banner through C stdio (buffered when stdout is a pipe): flush it now

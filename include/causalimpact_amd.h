@@ -106,7 +106,7 @@ typedef struct ci_problem {
  * main workgroup must carry on alone with unchanged results. */
 #define CI_FLAG_TEST_DROP_HELPER 32
 /* Seasonal models: take the wave-cooperative time-parallel kernel (csrc/ci_seasonal_tp.h: chunks of
- * the series on the wavefronts of a cluster of up to 16 workgroups, any block list with a state of at
+ * the series on the wavefronts of a cluster of up to 32 workgroups of 4 wavefronts, any block list with a state of at
  * most 32 components) even for "trend + one block of 2-7 seasons", which by default runs on the
  * thread-per-chunk kernel of csrc/ci_wide.h.  Few chains of a long series leave most of the GPU
  * idle: there the cluster kernel is the faster one (profiles/). */

@@ -37,7 +37,9 @@ def _worker(rank, world, port, num_chains, q):
   from causalimpact import _distributed as d
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
   dist.init_process_group("gloo", rank=rank, world_size=world)
-  res = d.fit_sharded(_fake_fit, num_chains)
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import _torch_comm
+  res = d.fit_sharded(_fake_fit, num_chains, comm=_torch_comm.from_initialized_group())
   q.put((rank, res["posterior_trajectories"], res["posterior_means"],
          {k: res[k] for k in ("split_rhat", "ess_bulk", "ess_tail")}))
   dist.barrier()
@@ -108,7 +110,9 @@ def _gpu_worker(rank, world, port, num_chains, q):
     out = _native.fit_gibbs(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
     return {k: v[0] for k, v in out.items()}
 
-  res = d.fit_sharded(local_fit, num_chains)
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import _torch_comm
+  res = d.fit_sharded(local_fit, num_chains, comm=_torch_comm.from_initialized_group())
   q.put((rank, res["posterior_trajectories"], res["posterior_means"],
          {k: res[k] for k in ("split_rhat", "ess_bulk", "ess_tail")}))
   dist.barrier()

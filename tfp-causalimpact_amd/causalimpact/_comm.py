@@ -95,7 +95,13 @@ def launch_nonce() -> bytes:
   before rank 0's os.replace attach to a dead segment)."""
   src = os.environ.get("CI_COMM_NONCE")
   if not src:
-    src = ":".join([str(os.getppid()), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+    # An explicit $CI_COMM_RDZV is a rendezvous the caller arranged for ranks that may have
+    # DIFFERENT parents (two shells, one scheduler task per rank): the parent's pid must not enter
+    # the nonce there (ADVICE round 5: such ranks never accepted rank 0's file).  Such launchers
+    # should export a fresh $CI_COMM_NONCE per launch; without one a rerun at the same path is told
+    # from a crashed run's leftover only by the file's age.
+    who = "rdzv:" + os.environ["CI_COMM_RDZV"] if os.environ.get("CI_COMM_RDZV") else str(os.getppid())
+    src = ":".join([who, os.environ.get("TORCHELASTIC_RUN_ID", "none"),
                     os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
                     os.environ.get("MASTER_PORT", "0")])
   return hashlib.sha256(src.encode()).digest()[:NONCE_BYTES]
@@ -113,6 +119,7 @@ def _exchange_id(rank: int, transport: int, path: str, timeout: float = 300.0) -
     os.replace(tmp, path)                 # atomically replaces a leftover of a crashed run, too
     return bytes(buf)
   t0 = time.monotonic()
+  why = "no file"
   while True:
     try:
       with open(path, "rb") as f:
@@ -120,10 +127,14 @@ def _exchange_id(rank: int, transport: int, path: str, timeout: float = 300.0) -
         fresh = time.time() - os.fstat(f.fileno()).st_mtime < STALE_SECONDS
       if len(b) == ID_BYTES + NONCE_BYTES and fresh and b[ID_BYTES:] == nonce:
         return b[:ID_BYTES]
+      if len(b) == ID_BYTES + NONCE_BYTES:
+        why = ("a file is there but carries another launch nonce (a leftover of an earlier run, or "
+               "rank 0 was started with a different $CI_COMM_NONCE / parent / MASTER_PORT: export the "
+               "same $CI_COMM_NONCE to every rank)" if fresh else "the file there is stale")
     except FileNotFoundError:
       pass
     if time.monotonic() - t0 > timeout:
-      raise _native.NativeError(f"rank {rank}: no unique id at {path} after {timeout:.0f} s")
+      raise _native.NativeError(f"rank {rank}: no unique id at {path} after {timeout:.0f} s ({why})")
     time.sleep(0.01)
 
 

@@ -4,8 +4,9 @@ The reference runs one chain in one process; chains are
 independent given the data, so ranks take contiguous blocks of chain ids with NO collective
 on the data path.  Chain c always uses RNG stream c (`chain_offset`), hence the pooled
 result is identical for any world size.  Collectives run only after sampling -- through
-`_comm.Comm` (librccl or a shared-memory host transport behind the C-ABI; no PyTorch), or through
-an initialised torch.distributed group (gloo in the CPU tests):
+`_comm.Comm` (librccl or a shared-memory host transport behind the C-ABI; no PyTorch) or any object
+with its `rank` / `world` / `all_gather` / `all_reduce` interface (the CPU tests wrap a gloo
+process group that way, tests/_torch_comm.py -- that adapter is test code, not part of this package):
   * an all-gather of the per-chain blocks needed for pooled summaries (`gather_keys`) and of
     the scalar parameters the diagnostics rank (`rhat_keys`: [chains, draws] floats);
   * ONE all-reduce(sum) of the diagnostics' partial sums -- per-split-chain means and
@@ -15,7 +16,6 @@ an initialised torch.distributed group (gloo in the CPU tests):
 """
 from __future__ import annotations
 
-import sys
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -31,48 +31,10 @@ def chain_block(num_chains: int, rank: int, world_size: int) -> Tuple[int, int]:
   return first, count
 
 
-class _TorchComm:
-  """`torch.distributed` (gloo in the CPU tests) behind the interface of `_comm.Comm`."""
-
-  def __init__(self, dist, torch, group, device):
-    self._dist, self._torch, self._group = dist, torch, group
-    self._dev = torch.device(device) if device else torch.device("cpu")
-    self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-
-  def all_gather(self, a: np.ndarray) -> np.ndarray:
-    mine = self._torch.from_numpy(np.ascontiguousarray(a)).to(self._dev)
-    parts = [self._torch.empty_like(mine) for _ in range(self.world)]
-    self._dist.all_gather(parts, mine, group=self._group)
-    return np.stack([p.cpu().numpy() for p in parts])
-
-  def all_reduce(self, values, op: int = 0) -> np.ndarray:
-    t = self._torch.from_numpy(np.array(values, dtype=np.float64, copy=True)).to(self._dev)
-    red = self._dist.ReduceOp.MAX if op == 1 else self._dist.ReduceOp.SUM
-    self._dist.all_reduce(t, op=red, group=self._group)
-    return t.cpu().numpy()
-
-
-def _resolve_comm(comm, group, device):
-  """The communicator to use: an explicit `_comm.Comm` (RCCL / host transport through the C-ABI,
-  no PyTorch), else an initialised torch.distributed process group, else None (one process)."""
-  if comm is not None:
-    return comm
-  if "torch" not in sys.modules and group is None:
-    return None         # nobody initialised a process group: do not import torch for nothing
-  try:
-    import torch
-    import torch.distributed as dist
-  except ImportError:
-    return None
-  if dist.is_available() and dist.is_initialized():
-    return _TorchComm(dist, torch, group, device)
-  return None
-
-
 def fit_sharded(local_fit: Callable[[int, int], Dict[str, np.ndarray]], num_chains: int,
                 gather_keys: Sequence[str] = ("posterior_trajectories", "posterior_means"),
                 rhat_keys: Sequence[str] = ("observation_noise_scale", "level_scale"),
-                group=None, device: Optional[str] = None, comm=None,
+                comm=None,
                 resident: Optional[Callable[[str], Optional[np.ndarray]]] = None
                 ) -> Dict[str, object]:
   """Runs `local_fit(first_chain, count)` on every rank and combines the results.
@@ -81,8 +43,7 @@ def fit_sharded(local_fit: Callable[[int, int], Dict[str, np.ndarray]], num_chai
   `_native.fit_gibbs` outputs for one series).  It is NOT called on a rank whose block is empty
   (more ranks than chains): that rank contributes zero-length blocks to the collectives.
   `comm`: a `_comm.Comm` (RCCL over xGMI or the host transport, through the C-ABI -- the product
-  path, no PyTorch); without one an initialised `torch.distributed` group is used (gloo in the CPU
-  tests), and without either the call is a single process.
+  path, no PyTorch) or an object with the same interface; without one the call is a single process.
   `resident(key)` (optional, equal blocks only): returns the gathered [world, count, ...] array
   of `key` straight from the ranks' device-resident sessions (`Comm.session_all_gather`), or
   None to fall back to gathering the host copy in `local_fit`'s result.
@@ -90,7 +51,6 @@ def fit_sharded(local_fit: Callable[[int, int], Dict[str, np.ndarray]], num_chai
     {key: [num_chains, ...] for key in gather_keys,
      "split_rhat" / "ess_bulk" / "ess_tail": {key: float for key in rhat_keys}}.
   """
-  comm = _resolve_comm(comm, group, device)
   rank = comm.rank if comm is not None else 0
   world = comm.world if comm is not None else 1
   if num_chains < 1:

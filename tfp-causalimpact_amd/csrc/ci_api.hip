@@ -720,8 +720,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       s->seasonal_ws_bytes = ((lay.t_total + 255) & ~(size_t)255) + (bigp ? ci::bigp_workspace_bytes(P) : 0);
     }
     // Any other block list -- and trend models with more than MAXP design columns -- with a state
-    // of at most 32 components: the TIME-PARALLEL kernel of ci_seasonal_tp.h, a cluster of up to 16
-    // workgroups of 8 wavefronts per chain (one chunk of the series per wavefront), as long as every
+    // of at most 32 components: the TIME-PARALLEL kernel of ci_seasonal_tp.h, a cluster of up to 32
+    // workgroups of 4 wavefronts per chain (one chunk of the series per wavefront), as long as every
     // chain of the launch gets at least one CU to itself (bigger batches are throughput-bound: one
     // wavefront per chain on the sequential kernel does less work per step).
     // (measured, round 5: below ~110 steps the one-wavefront kernel is as fast or faster -- 158 us

@@ -497,10 +497,17 @@ int ci_comm_destroy(ci_comm* c) {
   if (!c) return 0;
   if (c->transport == CI_COMM_RCCL) {
     (void)hipSetDevice(c->device);
-    if (c->nc && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nc);
-    c->send.release();
-    c->recv.release();
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    //  a communicator that timed out and could NOT be aborted (librccl without
+    // ncclCommAbort) still has its kernel spinning on c->stream: ncclCommDestroy, the buffer frees
+    // and hipStreamDestroy all synchronise with it -- the hang the time-out bounded would move here.
+    // Leak the three instead; the process is about to report the failure anyway.
+    const bool wedged = c->dead && c->nc != nullptr;
+    if (!wedged) {
+      if (c->nc && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nc);
+      c->send.release();
+      c->recv.release();
+      if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
   } else if (c->hdr) {
     munmap((void*)c->hdr, c->map_bytes);
   }

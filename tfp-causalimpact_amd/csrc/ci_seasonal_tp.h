@@ -49,8 +49,9 @@ constexpr int TP_NWV = 4;                  // wavefronts (chunks) per workgroup:
 constexpr int TP_NT = TP_NWV * 64;
 constexpr int TP_MAXG = 32;                // workgroups per chain
 constexpr int TP_MAXD = 32;                // widest state
-constexpr int TPC_INTS = 64;               // handshake ints per chain: [0,16) barrier | 16 mode | [32,48) check-in
+constexpr int TPC_INTS = 64;               // handshake ints per chain: [0,16) barrier | 16 mode | [32,64) check-in, one per role
 constexpr int TPC_MODE = 16, TPC_XCC = 32;
+static_assert(TPC_XCC + TP_MAXG <= TPC_INTS, "one check-in slot per workgroup of the cluster");
 constexpr int TP_STAT = 32;                // floats of statistics / boundary record per chunk
 
 // columns of the register rows: the state rounded up to a multiple of 4 (at least 8).  (Products and

@@ -46,11 +46,24 @@ template <int TR, int NS> struct WDim {
   static constexpr int NF = 2 + 2 * D;
 };
 
+// The Durbin-Koopman draw over the cluster's workgroups (ci_wide_quad.h): its exchange region.
+constexpr int DK_V = 4;               // virtual workgroups (64 quads of lanes each) per chain
+constexpr int DK_NWI = 16;            // wavefronts of the chain's grid: 4 per virtual workgroup
+constexpr int DK_EF = 72;             // floats per lane of a published filtering element (d <= 8: 68)
+constexpr int DK_EA = 32;             //                         ... backward map (d <= 8: 24)
+constexpr int DK_EP = 12;             // floats of a published prior-simulation element (d <= 8: 10)
+constexpr int DK_ST = 20;             // per chunk: 3 sums of squares, first state (8), last state (8)
+constexpr int DK_VS = 80;             // floats per lane parked between phases when one workgroup runs several virtual ones
+constexpr int DK_NF = 9;              // per-step workspace: y~ -> v/F, K_t -> r_{t-1} (8 floats)
+__host__ __device__ inline size_t wide_dk_floats() {
+  return (size_t)DK_NWI * 4 * DK_EF + (size_t)DK_NWI * 4 * DK_EA + 256 + (size_t)NT * DK_ST +
+         (size_t)DK_V * NT * DK_VS;
+}
 // floats of HBM workspace per chain
 __host__ __device__ inline size_t wide_workspace_floats(int D, int Lc) {
+  (void)D;
   const size_t TP = (size_t)NT * Lc;
-  const size_t nf = 2 + 2 * D;
-  return (6 + nf) * TP + TP / 2;   // 6 shared T-arrays, private fields, mask + change bytes
+  return (6 + DK_NF) * TP + TP / 2 + wide_dk_floats();   // 6 shared T-arrays, per-step fields, mask + change bytes, exchange
 }
 
 // ---- x <- T_t x and friends (oracle: apply_transition / apply_transition_T) ---------------
@@ -291,7 +304,7 @@ __device__ __forceinline__ E block_scan_excl_bwd_rolled(const E& tot, Op op, con
 
 struct WLayout {
   size_t xtx, omega, aug0, aug1, pri0, pri1, chol, bvec, zv, uperm, nz, perm, idx, w, scal, red,
-      pslots, fslots, aslots, edge, st, gsum, total;
+      st, gsum, total;
 };
 __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   WLayout l;
@@ -315,442 +328,16 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   l.w = take(sizeof(float) * (Pp > 16 ? Pp : 16));
   l.scal = take(sizeof(float) * 16);
   l.red = take(sizeof(float) * NW * ((Pp > 16 ? Pp : 16) + 4));
-  l.pslots = take(sizeof(float) * NW * (D + 2));
-  l.fslots = take(sizeof(float) * NW * (3 * D * D + 2 * D));
-  l.aslots = take(sizeof(float) * NW * (D * D + D));
-  l.edge = take(sizeof(float) * (NW + 1) * D);
+  (void)D;
   l.st = take(sizeof(double) * 4);      // serial wave -> block: previous sigma_obs, gamma variate
   l.gsum = take(sizeof(double) * NW * 64);   // quarter sums of the segment partials
   l.total = o;
   return l;
 }
 
-// ------------------------------------------------------------------------------------
-// One Durbin-Koopman draw, time-parallel.  Leaves level / slope / seasonal effect of the draw in
-// levw / slpw / seaw and this thread's share of the scale statistics in ssl / sss / ssd.
-// Contains 4 __syncthreads().
-// ------------------------------------------------------------------------------------
-template <int TR, int NS>
-__device__ __forceinline__ void wide_dk_draw(const WideScal& sc, const Vec<TR + NS - 1>& a1e,
-                                             const Mat<TR + NS - 1>& P1, int T, int Lc,
-                                             const float* __restrict__ resid,
-                                             const uint8_t* __restrict__ msk,
-                                             const uint8_t* __restrict__ cbv,
-                                             float* __restrict__ wsp, float* __restrict__ levw,
-                                             float* __restrict__ slpw, float* __restrict__ seaw,
-                                             const Rng& rng, uint32_t iter, int tid, int lane,
-                                             int wave, float* pslots, float* fslots, float* aslots,
-                                             float* edge, float& ssl, float& sss, float& ssd,
-                                             Prof& prof) {
-  using W = WDim<TR, NS>;
-  constexpr int D = W::D, O = W::O, N1 = W::N1, NF = W::NF;
-  const int t0 = tid * Lc;
-  auto at4 = [](const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
-
-  // ---- (1) prior simulation: chunk elements, scan
-  WPElem<D> pe;
-  {
-    Vec<D> s = vzero<D>();
-    int m = 0;
-#pragma unroll 1
-    for (int g4 = 0; g4 < Lc; g4 += 4) {
-      const int t4 = t0 + g4;
-      float zl4[4], zs4[4], zk4[4];
-      normals4(site_call(rng, iter, SITE_PRIOR_LEVEL, 0, (uint32_t)(t4 >> 2)), zl4);
-      if constexpr (TR == 2) normals4(site_call(rng, iter, SITE_PRIOR_SLOPE, 0, (uint32_t)(t4 >> 2)), zs4);
-      normals4(site_call(rng, iter, SITE_PRIOR_SEAS, 0, (uint32_t)(t4 >> 2)), zk4);
-      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
-        w_apply<TR, NS>(s, ch);
-        s.v[0] = fmaf(sc.sl, zl4[q], s.v[0]);
-        if constexpr (TR == 2) s.v[1] = fmaf(sc.ss, zs4[q], s.v[1]);
-        if (ch) {
-          const float dz = sc.sdn * zk4[q];
-#pragma unroll
-          for (int i = 0; i < N1; ++i) s.v[O + i] -= dz;
-          m += 1;
-        }
-      }
-    }
-    pe.k = (float)Lc;
-    pe.m = m % NS;
-    pe.s = s;
-  }
-  WPElem<D> pid;
-  pid.k = 0.f; pid.m = 0; pid.s = vzero<D>();
-  const WPElem<D> ppre = block_scan_excl_fwd_rolled(
-      pe, [](const WPElem<D>& x, const WPElem<D>& y) { return wpelem_combine<TR, NS>(x, y); }, pid,
-      pslots, lane, wave);
-  prof.tick(20);
-
-  // ---- (2) x+ from the chunk's prefix, y~ = resid - y+, and the chunk's filtering element
-  FElemS<D> fe = felems_identity<D>();
-  if (tid == 0) {
-    fe.A = mzero<D>();
-    fe.b = a1e;
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = i; j < D; ++j) fe.C[symidx<D>(i, j)] = P1.m[i][j];
-  }
-  {
-    Vec<D> x = ppre.s;
-#pragma unroll 1
-    for (int g4 = 0; g4 < Lc; g4 += 4) {
-      const int t4 = t0 + g4;
-      float zl4[4], zs4[4], zk4[4], zo4[4];
-      normals4(site_call(rng, iter, SITE_PRIOR_LEVEL, 0, (uint32_t)(t4 >> 2)), zl4);
-      if constexpr (TR == 2) normals4(site_call(rng, iter, SITE_PRIOR_SLOPE, 0, (uint32_t)(t4 >> 2)), zs4);
-      normals4(site_call(rng, iter, SITE_PRIOR_SEAS, 0, (uint32_t)(t4 >> 2)), zk4);
-      normals4(site_call(rng, iter, SITE_PRIOR_OBS, 0, (uint32_t)(t4 >> 2)), zo4);
-      const float4 r4 = *reinterpret_cast<const float4*>(resid + t4);
-      const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
-      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) {
-        const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
-        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
-        const float zo = q == 0 ? zo4[0] : q == 1 ? zo4[1] : q == 2 ? zo4[2] : zo4[3];
-        const float zl = q == 0 ? zl4[0] : q == 1 ? zl4[1] : q == 2 ? zl4[2] : zl4[3];
-        const float zk = q == 0 ? zk4[0] : q == 1 ? zk4[1] : q == 2 ? zk4[2] : zk4[3];
-        const float yt = at4(r4, q) - (x.v[0] + x.v[O] + sc.so * zo);
-        wsp[((size_t)(g4 + q) * NF + W::F_YT) * NT + tid] = yt;
-        if (obs) {
-          // fold observation y~_t into (A, b, C, eta, J):  x_t | x_start ~ N(A x_start + b, C)
-          float za[D], cz[D];
-#pragma unroll
-          for (int j = 0; j < D; ++j) za[j] = fe.A.m[0][j] + fe.A.m[O][j];
-#pragma unroll
-          for (int i = 0; i < D; ++i) cz[i] = fe.C[symidx<D>(i, 0)] + fe.C[symidx<D>(i, O)];
-          const float zb = fe.b.v[0] + fe.b.v[O];
-          const float Sv = cz[0] + cz[O] + sc.H;
-          const float rS = __builtin_amdgcn_rcpf(Sv);
-          const float e = (yt - zb) * rS;
-#pragma unroll
-          for (int i = 0; i < D; ++i) {
-            fe.eta.v[i] = fmaf(za[i], e, fe.eta.v[i]);
-            fe.b.v[i] = fmaf(cz[i], e, fe.b.v[i]);
-            const float ki = cz[i] * rS, zi = za[i] * rS;
-#pragma unroll
-            for (int j = 0; j < D; ++j) fe.A.m[i][j] = fmaf(-ki, za[j], fe.A.m[i][j]);
-#pragma unroll
-            for (int j = i; j < D; ++j) {       // symmetric parts: upper triangles only
-              fe.J[symidx<D>(i, j)] = fmaf(zi, za[j], fe.J[symidx<D>(i, j)]);
-              fe.C[symidx<D>(i, j)] = fmaf(-ki, cz[j], fe.C[symidx<D>(i, j)]);
-            }
-          }
-        }
-        // time update t -> t+1
-        w_left<TR, NS>(fe.A, ch);
-        w_apply<TR, NS>(fe.b, ch);
-        w_cov_predict_sym<TR, NS>(fe.C, ch, sc);
-        w_apply<TR, NS>(x, ch);
-        x.v[0] = fmaf(sc.sl, zl, x.v[0]);
-        if constexpr (TR == 2) {
-          const float zs = q == 0 ? zs4[0] : q == 1 ? zs4[1] : q == 2 ? zs4[2] : zs4[3];
-          x.v[1] = fmaf(sc.ss, zs, x.v[1]);
-        }
-        if (ch) {
-          const float dz = sc.sdn * zk;
-#pragma unroll
-          for (int i = 0; i < N1; ++i) x.v[O + i] -= dz;
-        }
-      }
-    }
-  }
-  prof.tick(21);
-  const FElemS<D> fpre = block_scan_excl_fwd_rolled(
-      fe, [](const FElemS<D>& x, const FElemS<D>& y) { return felems_combine(x, y); },
-      felems_identity<D>(), fslots, lane, wave);
-  prof.tick(22);
-
-  // ---- (3) local Kalman filter from the predicted moments at the start of the chunk: gains
-  // K_t and scaled innovations v_t / F_t (all the backward passes need)
-  Vec<D> a_start;
-  Mat<D> P_start;
-  if (tid == 0) { a_start = a1e; P_start = P1; } else {
-    a_start = fpre.b;
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = 0; j < D; ++j) P_start.m[i][j] = fpre.C[symidx<D>(i, j)];
-  }
-  {
-    Vec<D> am = a_start;
-    // the covariance stays a PACKED upper triangle through the pass (28 entries at d = 7 instead of
-    // 49): the pass is VALU-issue bound at one wave per SIMD
-    float Ps[W::NPS];
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = i; j < D; ++j) Ps[symidx<D>(i, j)] = P_start.m[i][j];
-    float ytn[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ytn[q] = wsp[((size_t)q * NF + W::F_YT) * NT + tid];
-#pragma unroll 1
-    for (int g4 = 0; g4 < Lc; g4 += 4) {
-      const int t4 = t0 + g4;
-      const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
-      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
-      float yt4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) yt4[q] = ytn[q];
-      if (g4 + 4 < Lc) {      // next block's rows, requested before this block's stores
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ytn[q] = wsp[((size_t)(g4 + 4 + q) * NF + W::F_YT) * NT + tid];
-      }
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) {
-        const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
-        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
-        float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
-        const float yt = q == 0 ? yt4[0] : q == 1 ? yt4[1] : q == 2 ? yt4[2] : yt4[3];
-        float vf = 0.f;
-        float kf[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) kf[i] = 0.f;
-        if (obs) {
-          float pz[D];
-#pragma unroll
-          for (int i = 0; i < D; ++i) pz[i] = Ps[symidx<D>(i, 0)] + Ps[symidx<D>(i, O)];
-          const float Fv = pz[0] + pz[O] + sc.H;
-          const float rF = __builtin_amdgcn_rcpf(Fv);
-          const float v = yt - (am.v[0] + am.v[O]);
-          vf = v * rF;
-#pragma unroll
-          for (int i = 0; i < D; ++i) {
-            kf[i] = pz[i] * rF;
-            am.v[i] = fmaf(kf[i], v, am.v[i]);
-#pragma unroll
-            for (int j = i; j < D; ++j)
-              Ps[symidx<D>(i, j)] = fmaf(-(pz[i] * pz[j]), rF, Ps[symidx<D>(i, j)]);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) wl[(W::F_KF + i) * NT] = kf[i];
-        wl[W::F_VF * NT] = vf;
-        w_apply<TR, NS>(am, ch);
-        w_cov_predict_sym<TR, NS>(Ps, ch, sc);
-      }
-    }
-  }
-  prof.tick(23);
-
-  // ---- (4) backward recursion r <- T' r ; r += Z'(v/F - K'r): chunk maps, suffix scan.
-  // (5a) below requests the workspace rows of the NEXT 4-step block before the current block is
-  // processed (one wave per SIMD: nothing else hides the L2 round trip of a dependent load;
-  // here, with the 7 x 7 map live, the extra registers cost more than the prefetch gains).
-  struct KV4 { float kf[4][D]; float vf[4]; };
-  auto load_kv = [&](int g4, KV4& b) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
-#pragma unroll
-      for (int i = 0; i < D; ++i) b.kf[q][i] = wl[(W::F_KF + i) * NT];
-      b.vf[q] = wl[W::F_VF * NT];
-    }
-  };
-  AElem<D> ae = aelem_identity<D>();
-#pragma unroll 1
-  for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
-    const int t4 = t0 + g4;
-    const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
-    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
-#pragma unroll 1
-    for (int q = 3; q >= 0; --q) {
-      const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
-      const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
-      const float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
-      w_left_t<TR, NS>(ae.M, ch);
-      w_apply_t<TR, NS>(ae.c, ch);
-      if (obs) {
-        float kf[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) kf[i] = wl[(W::F_KF + i) * NT];
-        const float vf = wl[W::F_VF * NT];
-        float kc = 0.f;
-#pragma unroll
-        for (int i = 0; i < D; ++i) kc = fmaf(kf[i], ae.c.v[i], kc);
-        const float add = vf - kc;
-        ae.c.v[0] += add;
-        ae.c.v[O] += add;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          float kr = 0.f;
-#pragma unroll
-          for (int i = 0; i < D; ++i) kr = fmaf(kf[i], ae.M.m[i][j], kr);
-          ae.M.m[0][j] -= kr;
-          ae.M.m[O][j] -= kr;
-        }
-      }
-    }
-  }
-  prof.tick(24);
-  const AElem<D> asuf = block_scan_excl_bwd_rolled(
-      ae, [](const AElem<D>& o, const AElem<D>& i) { return aelem_compose(o, i); },
-      aelem_identity<D>(), aslots, lane, wave);
-  prof.tick(25);
-
-  // ---- (5a) r through the chunk (backward), stored per step: rs[t] = r_{t-1}
-  {
-    Vec<D> r = asuf.c;      // the maps of all later chunks applied to r = 0
-    KV4 nxt;
-    load_kv(Lc - 4, nxt);
-#pragma unroll 1
-    for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
-      const int t4 = t0 + g4;
-      const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(msk + t4);
-      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
-      const KV4 cur = nxt;
-      if (g4 >= 4) load_kv(g4 - 4, nxt);     // requested before this block's stores
-#pragma unroll
-      for (int q = 3; q >= 0; --q) {
-        const bool obs = ((mk4 >> (8 * q)) & 0xFFu) == 0u;
-        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
-        float* wl = wsp + (size_t)(g4 + q) * NF * NT + tid;
-        w_apply_t<TR, NS>(r, ch);
-        if (obs) {
-          float kr = 0.f;
-#pragma unroll
-          for (int i = 0; i < D; ++i) kr = fmaf(cur.kf[q][i], r.v[i], kr);
-          const float add = cur.vf[q] - kr;
-          r.v[0] += add;
-          r.v[O] += add;
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) wl[(W::F_RS + i) * NT] = r.v[i];
-      }
-    }
-  }
-  prof.tick(26);
-  // ---- (5b) forward: x^_{t0} = a_{t0} + P_{t0} r_{t0-1}, x^_{t+1} = T x^_t + Q_t r_t; x+ is
-  // re-simulated from the same counters as in (2); x~_t = x^_t + x+_t; statistics of the draw
-  ssl = 0.f; sss = 0.f; ssd = 0.f;
-  auto stats = [&](const Vec<D>& xt, const Vec<D>& xn, bool ch) {
-    float dl = xn.v[0] - xt.v[0];
-    if constexpr (TR == 2) {
-      dl -= xt.v[1];
-      const float ds = xn.v[1] - xt.v[1];
-      sss = fmaf(ds, ds, sss);
-    }
-    ssl = fmaf(dl, dl, ssl);
-    if (ch) {
-      float w;
-      if constexpr (NS >= 3) w = (float)NS * (xt.v[O + 1] - xn.v[O]);
-      else w = -2.0f * (xn.v[O] + xt.v[O]);
-      ssd = fmaf(w, w, ssd);
-    }
-  };
-  Vec<D> xlast = vzero<D>(), xfirst = vzero<D>();
-  {
-    Vec<D> xh = a_start;
-    {
-      Vec<D> r0;
-#pragma unroll
-      for (int i = 0; i < D; ++i) r0.v[i] = wsp[((size_t)0 * NF + W::F_RS + i) * NT + tid];
-#pragma unroll
-      for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j < D; ++j) xh.v[i] = fmaf(P_start.m[i][j], r0.v[j], xh.v[i]);
-    }
-    Vec<D> xp = ppre.s;
-    Vec<D> xprev = vzero<D>();
-    bool chprev = false;
-    const float ql = sc.ql, qs = sc.qs, qd = sc.qd;
-    // rn4[q] = r_t of step t = t4 + q = the stored row of step t + 1 (the later chunks' suffix at
-    // the chunk's end); the rows of the next block are requested one block ahead
-    struct R4 { float r[4][D]; };
-    auto load_r = [&](int g4, R4& b) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int sidx = g4 + q + 1;
-        if (sidx < Lc) {
-#pragma unroll
-          for (int i = 0; i < D; ++i) b.r[q][i] = wsp[((size_t)sidx * NF + W::F_RS + i) * NT + tid];
-        } else {
-#pragma unroll
-          for (int i = 0; i < D; ++i) b.r[q][i] = asuf.c.v[i];
-        }
-      }
-    };
-    R4 rnx;
-    load_r(0, rnx);
-#pragma unroll 1
-    for (int g4 = 0; g4 < Lc; g4 += 4) {
-      const int t4 = t0 + g4;
-      const R4 rcur = rnx;
-      if (g4 + 4 < Lc) load_r(g4 + 4, rnx);
-      float zl4[4], zs4[4], zk4[4];
-      normals4(site_call(rng, iter, SITE_PRIOR_LEVEL, 0, (uint32_t)(t4 >> 2)), zl4);
-      if constexpr (TR == 2) normals4(site_call(rng, iter, SITE_PRIOR_SLOPE, 0, (uint32_t)(t4 >> 2)), zs4);
-      normals4(site_call(rng, iter, SITE_PRIOR_SEAS, 0, (uint32_t)(t4 >> 2)), zk4);
-      const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(cbv + t4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = t4 + q;
-        const bool ch = ((cb4 >> (8 * q)) & 0xFFu) != 0u;
-        const float zl = zl4[q];
-        const float zk = zk4[q];
-        Vec<D> xt;
-#pragma unroll
-        for (int i = 0; i < D; ++i) xt.v[i] = xh.v[i] + xp.v[i];
-        if (t < T) {
-          levw[t] = xt.v[0];
-          if constexpr (TR == 2) slpw[t] = xt.v[1];
-          seaw[t] = xt.v[O];
-        }
-        if (g4 + q == 0) xfirst = xt;
-        else if (t < T) stats(xprev, xt, chprev);
-        xprev = xt;
-        chprev = ch;
-        Vec<D> rn;
-#pragma unroll
-        for (int i = 0; i < D; ++i) rn.v[i] = rcur.r[q][i];
-        // x^_{t+1} = T x^_t + Q_t r_t,  Q_t = diag(ql, qs) (+) [ch] (sdn)^2 1 1' on the block
-        w_apply<TR, NS>(xh, ch);
-        xh.v[0] = fmaf(ql, rn.v[0], xh.v[0]);
-        if constexpr (TR == 2) xh.v[1] = fmaf(qs, rn.v[1], xh.v[1]);
-        if (ch) {
-          float sr = 0.f;
-#pragma unroll
-          for (int i = 0; i < N1; ++i) sr += rn.v[O + i];
-          const float add = qd * sr;
-#pragma unroll
-          for (int i = 0; i < N1; ++i) xh.v[O + i] += add;
-        }
-        // x+_{t+1}
-        w_apply<TR, NS>(xp, ch);
-        xp.v[0] = fmaf(sc.sl, zl, xp.v[0]);
-        if constexpr (TR == 2) xp.v[1] = fmaf(sc.ss, zs4[q], xp.v[1]);
-        if (ch) {
-          const float dz = sc.sdn * zk;
-#pragma unroll
-          for (int i = 0; i < N1; ++i) xp.v[O + i] -= dz;
-        }
-      }
-    }
-    xlast = xprev;
-  }
-  // increment across the chunk boundary: the next thread's first step
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < D; ++i) edge[wave * D + i] = xfirst.v[i];
-  }
-  __syncthreads();
-  {
-    Vec<D> nf;
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      nf.v[i] = __shfl_down(xfirst.v[i], 1, 64);
-      if (lane == 63) nf.v[i] = (wave + 1 < NW) ? edge[(wave + 1) * D + i] : 0.f;
-    }
-    const int t = t0 + Lc - 1;
-    if (t + 1 < T) stats(xlast, nf, cbv[t] != 0);
-  }
-  prof.tick(27);
-}
+}  // namespace ci
+#include "ci_wide_quad.h"
+namespace ci {
 
 // ------------------------------------------------------------------------------------
 // Clusters: several workgroups (CUs) per chain.  A few chains of a long series leave most of
@@ -797,7 +384,7 @@ __device__ __forceinline__ void cl_wait(int* flags, int n, int value, int tid) {
   __syncthreads();
 }
 constexpr int CL_INTS = 32;              // handshake counters per chain
-enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_MODE = 2, CL_V = 3, CL_PARTIAL = 8, CL_XW = 16, CL_XCC = 24 };   // + role (< 8)
+enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_MODE = 2, CL_V = 3, CL_DK = 4, CL_PARTIAL = 8, CL_XW = 16, CL_XCC = 24 };   // + role (< 8)
 // Assembling a cluster.  The handshakes below spin, so a cluster may only run when ALL its
 // workgroups are resident -- which the host sizes the launch for, but cannot guarantee (another
 // stream or process may hold CUs).  So the cluster is agreed on at the start, with time-outs:
@@ -890,10 +477,6 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   R.w = (float*)(smem + lay.w);
   float* scal = (float*)(smem + lay.scal);
   float* red = (float*)(smem + lay.red);
-  float* pslots = (float*)(smem + lay.pslots);
-  float* fslots = (float*)(smem + lay.fslots);
-  float* aslots = (float*)(smem + lay.aslots);
-  float* edge = (float*)(smem + lay.edge);
   double* st = (double*)(smem + lay.st);
   double* gsum = (double*)(smem + lay.gsum);
   const int RS = (P > 16 ? P : 16) + 4;
@@ -906,9 +489,10 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   float* slpw = levw + TP;
   float* seaw = slpw + TP;
   float* xww = seaw + TP;           // X w
-  float* wsp = xww + TP;            // private per-step fields [Lc][NF][NT]
-  uint8_t* mskp = (uint8_t*)(wsp + (size_t)W::NF * TP);   // mask, padded with 1
+  float* wsp = xww + TP;            // per-step fields of the draw: y~ -> v/F [Lc][NT], K_t -> r_{t-1} [Lc][NT][8]
+  uint8_t* mskp = (uint8_t*)(wsp + (size_t)DK_NF * TP);   // mask, padded with 1
   uint8_t* cbp = mskp + TP;                               // season-change flags, padded with 0
+  float* dkx = (float*)(cbp + TP);                        // exchange region of the draw (wide_dk_floats())
 
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
@@ -932,6 +516,19 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   double* cv = a.cv + chain_lin * presweep_doubles(P);
   const int clo = (int)((long long)(TP >> 2) * role / G), chi = (int)((long long)(TP >> 2) * (role + 1) / G);
   const int n_iter = g.W + g.S;
+  // The Durbin-Koopman draw runs on the cluster's first Gd workgroups (ci_wide_quad.h); with eight
+  // workgroups the fifth one sweeps the next iteration's regression matrix meanwhile.
+  const int Gd = G >= DK_V ? DK_V : G;
+  const int sweep_role = G == 8 ? 4 : -1;
+  DkSync dsy;
+  dsy.cnt = csync + CL_DK; dsy.Gd = Gd; dsy.epoch = 0; dsy.cluster = Gd > 1; dsy.light = light;
+  DkCtx dk;
+  dk.T = T; dk.Lc = Lc; dk.resid = residw; dk.msk = mskp; dk.cbv = cbp;
+  dk.yv = wsp; dk.kr = wsp + TP; dk.levw = levw; dk.slpw = slpw; dk.seaw = seaw; dk.xb = dkx;
+  dk.chol1 = chol1; dk.a1_loc = (float)sp.init_level_loc;
+  dk.p1l = (float)(sp.init_level_scale * sp.init_level_scale);
+  dk.p1s = (float)(sp.init_slope_scale * sp.init_slope_scale);
+  dk.p1e = (float)(ss.init_seasonal_scale * ss.init_seasonal_scale);
 
   // (1) targets y - level - seasonal of segments `sa` and `sb` (NT chunks of 4 steps each; sb may be
   // >= nseg: nothing), their squares and X~'targets: four wave partials per column and segment, to
@@ -1090,7 +687,8 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   if (role > 0) {
     // ---- helper workgroup: its share of phases (1), (3), (4); the first helper also prepares the
     // next iteration's regression matrix
-    const bool sweeper = role == 1 && P > 16;
+    const bool sweeper = role == sweep_role && P > 16;
+    NoProf hprof;
     if (sweeper) {
       for (int e = tid; e < P * P; e += NT) {
         R.xtx[e] = g.xtx[(size_t)series * P * P + e];
@@ -1118,6 +716,16 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         presweep_block(R, P, so_d * so_d, nzmask, false, tid);
         presweep_export(R, P, nzmask, cv, tid);
         cl_publish(csync + CL_V, it + 1, tid, light);
+      }
+      if (role < Gd && it < n_iter) {
+        // a DK worker: every share of X w / the residual is in, the scales came with the weights
+        cl_wait(csync + CL_XW, G, it + 1, tid);
+        WideScal sc;
+        sc.so = cw[58]; sc.H = sc.so * sc.so;
+        sc.sl = cw[59]; sc.ql = sc.sl * sc.sl;
+        sc.ss = cw[60]; sc.qs = sc.ss * sc.ss;
+        sc.sdn = cw[61] * (1.0f / (float)NS); sc.qd = sc.sdn * sc.sdn;
+        wide_dk_quad<TR, NS>(sc, dk, rng, (uint32_t)it, role, dsy, tid, hprof);
       }
     }
     return;
@@ -1147,16 +755,6 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
 
   double obs_scale = sp.obs_scale0, level_scale = sp.level_scale0, slope_scale = sp.slope_scale0;
   double drift = ss.drift_scale0[0];
-  const float p1l = (float)(sp.init_level_scale * sp.init_level_scale);
-  const float p1s = (float)(sp.init_slope_scale * sp.init_slope_scale);
-  const float p1e = (float)(ss.init_seasonal_scale * ss.init_seasonal_scale);
-  Mat<D> P1 = mzero<D>();
-  P1.m[0][0] = p1l;
-  if constexpr (TR == 2) P1.m[1][1] = p1s;
-#pragma unroll
-  for (int i = 0; i < N1; ++i)
-#pragma unroll
-    for (int j = 0; j < N1; ++j) P1.m[O + i][O + j] = p1e * ((i == j ? 1.f : 0.f) - 1.f / (float)NS);
   float ssl = 0.f, sss = 0.f, ssd = 0.f;
   PriorCarry pc;
   pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
@@ -1168,6 +766,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
 
   for (int it = 0; it <= n_iter; ++it) {
     // ---- (1) targets, y'y, X~'targets (time interleaved over threads: coalesced)
+    if (it > 0) dk_stats<TR, NS>(dkx, cbp, T, Lc, tid, ssl, sss, ssd);
     if (vec4) {
       role_segment_sums();
       const float s1 = wave_sum_dpp(ssl), s2 = wave_sum_dpp(sss), s3 = wave_sum_dpp(ssd);
@@ -1310,7 +909,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     if (P > 16 && it < n_iter) {
       // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
       prof.tick(9);
-      const bool prepared = G > 1 && it > 0;      // the cluster's first helper swept the matrix
+      const bool prepared = sweep_role > 0 && it > 0;      // a helper of the cluster swept the matrix
       if (prepared) cl_wait(csync + CL_V, 1, it, tid);
       obs_scale = spike_slab_draw_block(R, P, sp, st[0], st[1], rng, (uint32_t)it, tid, it == 0, &prof,
                                         true, prepared ? cv : nullptr);
@@ -1326,6 +925,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       if (tid == 0) {
         cw[P] = scal[1];
         *reinterpret_cast<double*>(cw + 56) = obs_scale;
+        cw[58] = scal[0]; cw[59] = scal[2]; cw[60] = scal[3]; cw[61] = scal[4];    // the DK workers' scales
       }
       cl_publish(csync + CL_WEIGHTS, it + 1, tid, light);
     }
@@ -1373,25 +973,9 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         }
       }
     }
-    if (G > 1) cl_wait(csync + CL_XW + 1, G - 1, it + 1, tid);
-    // x+_0 = chol(P_1) z, folded into the filter's prior mean (see dk_draw in ci_kernels.h)
-    Vec<D> a1e = vzero<D>();
-    a1e.v[0] = (float)sp.init_level_loc;
-    if (tid == 0) {
-      float z[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        float z1[1];
-        fill_normals<1>(rng, (uint32_t)it, SITE_PRIOR_INIT, 0, (uint32_t)i, z1);
-        z[i] = z1[0];
-      }
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j <= i; ++j) s = fmaf(chol1[i * D + j], z[j], s);
-        a1e.v[i] += s;
-      }
+    if (G > 1) {
+      cl_publish(csync + CL_XW, it + 1, tid, light);        // this workgroup's share of the residual
+      cl_wait(csync + CL_XW + 1, G - 1, it + 1, tid);
     }
     WideScal sc;
     sc.so = scal[0]; sc.H = sc.so * sc.so;
@@ -1400,10 +984,8 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     sc.sdn = scal[4] * (1.0f / (float)NS); sc.qd = sc.sdn * sc.sdn;
     __syncthreads();
     prof.tick(3);
-    wide_dk_draw<TR, NS>(sc, a1e, P1, T, Lc, residw, mskp, cbp, wsp, levw, slpw, seaw, rng,
-                         (uint32_t)it, tid, lane, wave, pslots, fslots, aslots, edge, ssl, sss, ssd,
-                         prof);
-    __syncthreads();
+    // the Durbin-Koopman draw, with the cluster's other DK workers (ends with their barrier)
+    wide_dk_quad<TR, NS>(sc, dk, rng, (uint32_t)it, 0, dsy, tid, prof);
     if (G > 1) cl_publish(csync + CL_LATENTS, it + 2, tid, light);
   }
   __syncthreads();     // the running sums were accumulated through the emission's thread mapping

@@ -1,0 +1,833 @@
+// ci_wide_quad.h -- the Durbin-Koopman draw of the trend + seasonal kernel (ci_wide.h), spread over
+// the workgroups of the chain's cluster with every chunk of the series carried by a QUAD of lanes.
+//
+// Round 6.  Rounds 2-5 ran this draw on ONE workgroup, one lane per chunk: 437k of the iteration's
+// 556k cycles at cfg4, VALU-issue bound on that CU's four SIMDs (a combine of two 119-float
+// filtering elements is ~2.8k dependent FMAs on one lane; the per-step passes carry 7 x 7 matrices
+// through 40 steps per lane) while the cluster's other CUs waited.  Now:
+//   * the grid is unchanged -- 256 chunks of Lc = ceil(T / 256) steps (rounded to 4), fixed by T alone --
+//     but a chunk belongs to the four lanes of a quad: matrices split by columns, operands from the
+//     other lanes through DPP broadcasts (ci_quad.h).  1024 lanes = four VIRTUAL workgroups of 64
+//     quads; the cluster's first Gd = 4, 2 or 1 workgroups ("DK workers") take 1, 2 or 4 of them
+//     each, one after the other, with the little state that crosses a hand-over parked in L2.
+//     Which workgroup runs a virtual workgroup changes nothing in the arithmetic: every cluster size
+//     gives the same bits.
+//   * every scan is two-level with ONE hand-over between workgroups: Kogge-Stone over the 16 quads of
+//     a wavefront (ds_bpermute), the 16 wave totals of the chain published to L2, a cluster barrier,
+//     then every wavefront scans the 16 totals again on its own (4 more levels) and picks its prefix.
+//     9 combine latencies of ~3k cycles instead of 9-10 of 12k.
+//   * the per-step passes cost ~1/2.5 of the one-lane versions: the transition acts on the rows of a
+//     column-split matrix (inside a lane), rank-one updates take their vectors from DPP broadcasts,
+//     only the congruence T C T' moves columns between lanes; the random numbers of a 4-step block
+//     are drawn once per quad (one site per lane) instead of once per lane.
+//   * per-step workspace: 9 floats per step (y~ -> v/F, K_t -> r_{t-1} in place) instead of 16.
+// Same passes, same formulas, same random-number sites as wide_dk_draw (oracle: ci_oracle_dk_draw).
+#pragma once
+#include "ci_quad.h"
+// (included from the middle of ci_wide.h: WDim, WideScal, WPElem, the DK_* sizes are defined there)
+
+namespace ci {
+
+struct DkSync {
+  int* cnt;            // arrival counter of the DK workers (monotone)
+  int Gd, epoch;
+  bool cluster, light;
+};
+// Barrier of the chain's DK workers with release / acquire of everything written before it.
+__device__ __forceinline__ void dk_barrier(DkSync& s, int tid) {
+  if (!s.cluster) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return;
+  }
+  ++s.epoch;
+  if (s.light) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores in the shared L2 before the arrival
+  } else {
+    __threadfence();
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (s.light) (void)__hip_atomic_fetch_add(s.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else (void)__hip_atomic_fetch_add(s.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const int want = s.epoch * s.Gd;
+    while (__hip_atomic_load(s.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+      __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// ---- the transition on a d-vector held in registers (w_apply / w_apply_t of ci_wide.h on arrays) --
+template <int TR, int NS> __device__ __forceinline__ void qw_apply(float (&x)[TR + NS - 1], bool ch) {
+  constexpr int O = TR, N1 = NS - 1;
+  if constexpr (TR == 2) x[0] += x[1];
+  if (ch) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) s += x[O + i];
+#pragma unroll
+    for (int i = 0; i + 1 < N1; ++i) x[O + i] = x[O + i + 1];
+    x[O + N1 - 1] = -s;
+  }
+}
+template <int TR, int NS> __device__ __forceinline__ void qw_apply_t(float (&x)[TR + NS - 1], bool ch) {
+  constexpr int O = TR, N1 = NS - 1;
+  if constexpr (TR == 2) x[1] += x[0];
+  if (ch) {
+    const float last = x[O + N1 - 1];
+#pragma unroll
+    for (int j = N1 - 1; j >= 1; --j) x[O + j] = x[O + j - 1] - last;
+    x[O] = -last;
+  }
+}
+
+// per-lane constants of the covariance prediction
+template <int D> struct QScal {
+  static constexpr int H = (D + 3) / 4;
+  float ql0, qs1;          // ql on the lane that owns column 0 (else 0), qs on the owner of column 1
+  float qd_own[H];         // qd where the own column is a seasonal one
+  bool keep0;              // slot 0 holds a trend column (does not move in the seasonal shift)
+  bool inject;             // this lane's last slot is "column D": receives minus the row sums before the shift
+  bool last_own;           // (d % 4 == 0) this lane's last slot is column D - 1
+};
+template <int TR, int NS>
+__device__ __forceinline__ QScal<TR + NS - 1> make_qscal(const WideScal& sc, int q) {
+  constexpr int D = TR + NS - 1, O = TR, H = (D + 3) / 4;
+  QScal<D> s;
+  s.ql0 = q == 0 ? sc.ql : 0.f;
+  s.qs1 = (TR == 2 && q == 1) ? sc.qs : 0.f;
+#pragma unroll
+  for (int h = 0; h < H; ++h) s.qd_own[h] = (q + 4 * h >= O && q + 4 * h < D) ? sc.qd : 0.f;
+  s.keep0 = q < O;
+  s.inject = (D % 4 != 0) && q == (D & 3);
+  s.last_own = (D % 4 == 0) && q == 3;
+  return s;
+}
+
+// C <- T C T' + Q_t on a column-split symmetric matrix (oracle: propagate_cov; w_cov_predict_sym).
+// Rows: the transition on every own column (in registers).  Columns: the trend pair through one
+// broadcast; the seasonal shift "column j <- column j + 1, last <- minus the row sums" moves every
+// slot one lane down the quad (lane 3 takes lane 0's NEXT slot); the row sums of T C are T applied to
+// the row sums of C, and those are the own columns' sums over the seasonal rows (symmetry).
+template <int TR, int NS>
+__device__ __forceinline__ void qc_predict(QMat<TR + NS - 1>& C, bool ch, const QScal<TR + NS - 1>& qs,
+                                           int q) {
+  constexpr int D = TR + NS - 1, O = TR, H = (D + 3) / 4;
+  float rs[D];
+  if (ch) {
+    QVec<D> cs;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = O; r < D; ++r) s += C.m[h][r];
+      cs.v[h] = s;
+    }
+    q_rep(cs, rs);
+    qw_apply<TR, NS>(rs, true);
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) qw_apply<TR, NS>(C.m[h], ch);
+  if constexpr (TR == 2) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const float t = q_bc(C.m[0][i], 1);
+      C.m[0][i] += (q == 0) ? t : 0.f;
+    }
+  }
+  if (ch) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float v[H + 1], n[H + 1];
+#pragma unroll
+      for (int h = 0; h < H; ++h) v[h] = C.m[h][i];
+      if constexpr (D % 4 != 0) v[H - 1] = qs.inject ? -rs[i] : v[H - 1];
+#pragma unroll
+      for (int h = 0; h < H; ++h) n[h] = q_next(v[h]);
+      n[H] = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float take = (q == 3) ? n[h + 1] : n[h];
+        if constexpr (D % 4 == 0)
+          if (h == H - 1) take = qs.last_own ? -rs[i] : take;
+        C.m[h][i] = (h == 0 && qs.keep0) ? C.m[h][i] : take;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int i = O; i < D; ++i) C.m[h][i] += qs.qd_own[h];
+  }
+  C.m[0][0] += qs.ql0;
+  if constexpr (TR == 2) C.m[0][1] += qs.qs1;
+}
+
+// ---- everything one chain's draw needs ------------------------------------------------------------
+struct DkCtx {
+  int T, Lc;
+  const float* resid;
+  const uint8_t* msk;
+  const uint8_t* cbv;
+  float* kr;           // [Lc][256 chunks][8]: K_t, then r_{t-1} in place
+  float* yv;           // [Lc][256 chunks]:    y~_t, then v_t / F_t in place
+  float* levw;
+  float* slpw;
+  float* seaw;
+  float* xb;           // exchange region (wide_dk_floats())
+  const float* chol1;  // lower Cholesky factor of the prior covariance of x_0 (d x d)
+  float a1_loc;        // prior mean of the level
+  float p1l, p1s, p1e; // prior variances: level, slope, seasonal effects
+};
+
+// One Durbin-Koopman draw.  Called by the chain's DK workers (role 0 .. Gd-1) with the same
+// arguments; contains 4 dk_barrier()s.  Leaves the latents in levw / slpw / seaw and, per chunk, the
+// sums of squared increments + first / last state in the exchange region (dk_stats reads them).
+template <int TR, int NS, class P>
+__device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x, const Rng& rng,
+                                             uint32_t iter, int role, DkSync& sy, int tid, P& prof) {
+  using W = WDim<TR, NS>;
+  constexpr int D = W::D, O = W::O, N1 = W::N1, H = (D + 3) / 4;
+  constexpr int EF = (int)(sizeof(QFElem<D>) / 4), EA = (int)(sizeof(QAElem<D>) / 4);
+  static_assert(EF <= DK_EF && EA <= DK_EA && D + 2 <= DK_EP, "exchange slots");
+  const int lane = tid & 63, wave = tid >> 6, q = tid & 3, qi = lane >> 2;
+  const int T = x.T, Lc = x.Lc;
+  const int nv = DK_V / sy.Gd, v0 = role * nv;
+  const bool park = nv > 1;                    // state crosses the hand-overs through L2
+  float* xbF = x.xb;
+  float* xbA = xbF + (size_t)DK_NWI * 4 * DK_EF;
+  float* xbP = xbA + (size_t)DK_NWI * 4 * DK_EA;
+  float* stat = xbP + 256;
+  float* vst = stat + (size_t)NT * DK_ST;
+  const QScal<D> qs = make_qscal<TR, NS>(sc, q);
+  auto vslot = [&](int v, int f) -> float* { return vst + ((size_t)(v * DK_VS + f) * NT + tid); };
+  auto at4 = [](const float (&z)[4], int s) { return s == 0 ? z[0] : s == 1 ? z[1] : s == 2 ? z[2] : z[3]; };
+  // the four random-number sites of a 4-step block, one per lane of the quad
+  const uint32_t my_site = q == 0 ? (uint32_t)SITE_PRIOR_LEVEL : q == 1 ? (uint32_t)SITE_PRIOR_SEAS
+                           : q == 2 ? (uint32_t)SITE_PRIOR_OBS : (uint32_t)SITE_PRIOR_SLOPE;
+  // x+ one step on: x <- T x + noise
+  auto xplus_step = [&](float (&xp)[D], bool ch, float zl, float zs, float zk) {
+    qw_apply<TR, NS>(xp, ch);
+    xp[0] = fmaf(sc.sl, zl, xp[0]);
+    if constexpr (TR == 2) xp[1] = fmaf(sc.ss, zs, xp[1]);
+    if (ch) {
+      const float dz = sc.sdn * zk;
+#pragma unroll
+      for (int i = 0; i < N1; ++i) xp[O + i] -= dz;
+    }
+  };
+
+  // moments of x_1 with the simulated x+_1 folded into the mean (see dk_draw in ci_kernels.h): on
+  // every lane of the quad that owns chunk 0
+  auto prior_moments = [&](float (&m1)[D], QMat<D>& P1) {
+    float z[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float z1[1];
+      fill_normals<1>(rng, iter, SITE_PRIOR_INIT, 0, (uint32_t)i, z1);
+      z[i] = z1[0];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float s = i == 0 ? x.a1_loc : 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) s = fmaf(x.chol1[i * D + j], z[j], s);
+      m1[i] = s;
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int j = q + 4 * h;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        float p = 0.f;
+        if (i == 0 && j == 0) p = x.p1l;
+        if (TR == 2 && i == 1 && j == 1) p = x.p1s;
+        if (i >= O && j >= O && j < D) p = x.p1e * ((i == j ? 1.f : 0.f) - 1.f / (float)NS);
+        P1.m[h][i] = p;
+      }
+    }
+  };
+
+  // per-virtual-workgroup state that lives in registers when nv == 1
+  float xpre[D];            // x+ at the chunk start
+  float a0[D];              // predicted mean at the chunk start
+  QMat<D> P0;               // predicted covariance at the chunk start
+  WPElem<D> pex;            // in-wave exclusive prefix of the prior-simulation scan
+  QFElem<D> fex;            //                        ... of the filter scan
+  QAElem<D> aex;            // in-wave exclusive suffix of the backward scan
+
+  // =================== phase A: prior simulation, chunk elements, in-wave scan ====================
+#pragma unroll 1
+  for (int v = v0; v < v0 + nv; ++v) {
+    const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
+    WPElem<D> pe;
+    {
+      float s[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) s[i] = 0.f;
+      int m = 0;
+#pragma unroll 1
+      for (int g4 = 0; g4 < Lc; g4 += 4) {
+        const int t4 = t0 + g4;
+        float z[4];
+        normals4(site_call(rng, iter, my_site, 0, (uint32_t)(t4 >> 2)), z);
+        const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
+          xplus_step(s, ch, q_bc(z[u], 0), q_bc(z[u], 3), q_bc(z[u], 1));
+          m += ch ? 1 : 0;
+        }
+      }
+      pe.k = (float)Lc;
+      pe.m = m % NS;
+#pragma unroll
+      for (int i = 0; i < D; ++i) pe.s.v[i] = s[i];
+    }
+    WPElem<D> incl = pe;
+#pragma unroll 1
+    for (int off = 1; off < 16; off <<= 1) {
+      const WPElem<D> o = q_shfl_up(incl, off);
+      if (qi >= off) incl = wpelem_combine<TR, NS>(o, incl);
+    }
+    if (qi == 15 && q == 0) {
+      float* p = xbP + wi * DK_EP;
+      p[0] = incl.k; p[1] = (float)incl.m;
+#pragma unroll
+      for (int i = 0; i < D; ++i) p[2 + i] = incl.s.v[i];
+    }
+    pex = q_shfl_up(incl, 1);
+    if (qi == 0) { pex.k = 0.f; pex.m = 0; pex.s = vzero<D>(); }
+    if (park) {
+      *vslot(v, 0) = pex.k; *vslot(v, 1) = (float)pex.m;
+#pragma unroll
+      for (int i = 0; i < D; ++i) *vslot(v, 2 + i) = pex.s.v[i];
+    }
+  }
+  prof.tick(20);
+  dk_barrier(sy, tid);
+
+  // =================== phase B: x+ and y~, chunk filtering elements, in-wave scan ==================
+#pragma unroll 1
+  for (int v = v0; v < v0 + nv; ++v) {
+    const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
+    if (park) {
+      pex.k = *vslot(v, 0); pex.m = (int)*vslot(v, 1);
+#pragma unroll
+      for (int i = 0; i < D; ++i) pex.s.v[i] = *vslot(v, 2 + i);
+    }
+    {
+      // the earlier wavefronts' totals, in order, then the in-wave prefix
+      WPElem<D> acc;
+      acc.k = 0.f; acc.m = 0; acc.s = vzero<D>();
+#pragma unroll 1
+      for (int w = 0; w < wi; ++w) {
+        const float* p = xbP + w * DK_EP;
+        WPElem<D> e;
+        e.k = p[0]; e.m = (int)p[1];
+#pragma unroll
+        for (int i = 0; i < D; ++i) e.s.v[i] = p[2 + i];
+        acc = wpelem_combine<TR, NS>(acc, e);
+      }
+      acc = wpelem_combine<TR, NS>(acc, pex);
+#pragma unroll
+      for (int i = 0; i < D; ++i) xpre[i] = acc.s.v[i];
+    }
+    // the chunk's element in the column-split layout; b and eta on every lane while it is built
+    QMat<D> A = qm_eye<D>(q), C = qm_zero<D>(), J = qm_zero<D>();
+    float b[D], eta[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { b[i] = 0.f; eta[i] = 0.f; }
+    if (c == 0) {
+      // the prior as the first element: x_1 ~ N(a_1 + chol(P_1) z, P_1)
+      A = qm_zero<D>();
+      prior_moments(b, C);
+    }
+    {
+      float xp[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) xp[i] = xpre[i];
+#pragma unroll 1
+      for (int g4 = 0; g4 < Lc; g4 += 4) {
+        const int t4 = t0 + g4;
+        float z[4];
+        normals4(site_call(rng, iter, my_site, 0, (uint32_t)(t4 >> 2)), z);
+        const float4 r4 = *reinterpret_cast<const float4*>(x.resid + t4);
+        const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(x.msk + t4);
+        const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {
+          const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
+          const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
+          const float zm = at4(z, u);
+          const float zl = q_bc(zm, 0), zk = q_bc(zm, 1), zo = q_bc(zm, 2), zs = q_bc(zm, 3);
+          const float ru = u == 0 ? r4.x : u == 1 ? r4.y : u == 2 ? r4.z : r4.w;
+          const float yt = ru - (xp[0] + xp[O] + sc.so * zo);
+          if (q == 0) x.yv[(size_t)(g4 + u) * NT + (c & 255)] = yt;
+          if (obs) {
+            // fold y~_t into (A, b, C, eta, J)
+            QVec<D> za, cz;
+#pragma unroll
+            for (int h = 0; h < H; ++h) { za.v[h] = A.m[h][0] + A.m[h][O]; cz.v[h] = C.m[h][0] + C.m[h][O]; }
+            float zar[D], czr[D];
+            q_rep(za, zar);
+            q_rep(cz, czr);
+            const float zb = b[0] + b[O];
+            const float Sv = czr[0] + czr[O] + sc.H;
+            const float rS = __builtin_amdgcn_rcpf(Sv);
+            const float e = (yt - zb) * rS;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+              eta[i] = fmaf(zar[i], e, eta[i]);
+              b[i] = fmaf(czr[i], e, b[i]);
+              const float ki = czr[i] * rS, zi = zar[i] * rS;
+#pragma unroll
+              for (int h = 0; h < H; ++h) {
+                A.m[h][i] = fmaf(-ki, za.v[h], A.m[h][i]);
+                J.m[h][i] = fmaf(zi, za.v[h], J.m[h][i]);
+                C.m[h][i] = fmaf(-ki, cz.v[h], C.m[h][i]);
+              }
+            }
+          }
+          // time update t -> t + 1
+#pragma unroll
+          for (int h = 0; h < H; ++h) qw_apply<TR, NS>(A.m[h], ch);
+          qw_apply<TR, NS>(b, ch);
+          qc_predict<TR, NS>(C, ch, qs, q);
+          xplus_step(xp, ch, zl, zs, zk);
+        }
+      }
+    }
+    QFElem<D> fe;
+    fe.A = A; fe.C = C; fe.J = J;
+    fe.AT = q_transpose(A, q);
+    fe.b = q_own<D>(b, q);
+    fe.eta = q_own<D>(eta, q);
+    prof.tick(21);
+    QFElem<D> incl = fe;
+#pragma unroll 1
+    for (int off = 1; off < 16; off <<= 1) {
+      const QFElem<D> o = q_shfl_up(incl, off);
+      if (qi >= off) incl = qf_combine<D>(o, incl, q);
+    }
+    if (qi == 15) {
+      float* p = xbF + (size_t)(wi * 4 + q) * DK_EF;
+      const Arr<QFElem<D>> a = __builtin_bit_cast(Arr<QFElem<D>>, incl);
+#pragma unroll
+      for (int i = 0; i < EF; ++i) p[i] = a.f[i];
+    }
+    fex = q_shfl_up(incl, 1);
+    if (qi == 0) fex = qf_identity<D>(q);
+    if (park) {
+      const Arr<QFElem<D>> a = __builtin_bit_cast(Arr<QFElem<D>>, fex);
+#pragma unroll
+      for (int i = 0; i < EF; ++i) *vslot(v, i) = a.f[i];
+#pragma unroll
+      for (int i = 0; i < D; ++i) *vslot(v, EF + i) = xpre[i];
+    }
+    prof.tick(22);
+  }
+  dk_barrier(sy, tid);
+
+  // =================== phase C: prefixes, local filter (gains), backward chunk maps =================
+  {
+    // every wavefront scans the 16 wave totals of the chain: quad j holds total j
+    QFElem<D> tot;
+    {
+      const float* p = xbF + (size_t)(qi * 4 + q) * DK_EF;
+      Arr<QFElem<D>> a;
+#pragma unroll
+      for (int i = 0; i < EF; ++i) a.f[i] = p[i];
+      tot = __builtin_bit_cast(QFElem<D>, a);
+    }
+#pragma unroll 1
+    for (int off = 1; off < 16; off <<= 1) {
+      const QFElem<D> o = q_shfl_up(tot, off);
+      if (qi >= off) tot = qf_combine<D>(o, tot, q);
+    }
+    prof.tick(23);
+#pragma unroll 1
+    for (int v = v0; v < v0 + nv; ++v) {
+      const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
+      if (park) {
+        Arr<QFElem<D>> a;
+#pragma unroll
+        for (int i = 0; i < EF; ++i) a.f[i] = *vslot(v, i);
+        fex = __builtin_bit_cast(QFElem<D>, a);
+#pragma unroll
+        for (int i = 0; i < D; ++i) xpre[i] = *vslot(v, EF + i);
+      }
+      QFElem<D> wp = q_shfl_from(tot, wi > 0 ? wi - 1 : 0, q);
+      if (wi == 0) wp = qf_identity<D>(q);
+      const QFElem<D> pre = qf_combine<D, true>(wp, fex, q);
+      {
+        QVec<D> bb = pre.b;
+        q_rep(bb, a0);
+        P0 = pre.C;
+      }
+      if (c == 0) prior_moments(a0, P0);        // nothing before the first chunk: the prior itself
+      // local Kalman filter from the predicted moments at the chunk start: K_t, v_t / F_t
+      {
+        float am[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) am[i] = a0[i];
+        QMat<D> Pc = P0;
+#pragma unroll 1
+        for (int g4 = 0; g4 < Lc; g4 += 4) {
+          const int t4 = t0 + g4;
+          const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(x.msk + t4);
+          const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
+          float yt4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) yt4[u] = x.yv[(size_t)(g4 + u) * NT + (c & 255)];
+#pragma unroll 1
+          for (int u = 0; u < 4; ++u) {
+            const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
+            const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
+            const float yt = at4(yt4, u);
+            float vf = 0.f;
+            float kf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kf[i] = 0.f;
+            if (obs) {
+              QVec<D> pz;
+#pragma unroll
+              for (int h = 0; h < H; ++h) pz.v[h] = Pc.m[h][0] + Pc.m[h][O];
+              float pzr[D];
+              q_rep(pz, pzr);
+              const float Fv = pzr[0] + pzr[O] + sc.H;
+              const float rF = __builtin_amdgcn_rcpf(Fv);
+              const float vv = yt - (am[0] + am[O]);
+              vf = vv * rF;
+#pragma unroll
+              for (int i = 0; i < D; ++i) {
+                kf[i] = pzr[i] * rF;
+                am[i] = fmaf(kf[i], vv, am[i]);
+#pragma unroll
+                for (int h = 0; h < H; ++h) Pc.m[h][i] = fmaf(-(pzr[i] * pz.v[h]), rF, Pc.m[h][i]);
+              }
+            }
+            float* kp = x.kr + ((size_t)(g4 + u) * NT + (c & 255)) * 8;
+            if (q == 0) *reinterpret_cast<float4*>(kp) = make_float4(kf[0], kf[1], kf[2], kf[3]);
+            if (q == 1) *reinterpret_cast<float4*>(kp + 4) = make_float4(kf[4], kf[5], kf[6], kf[7]);
+            if (q == 2) x.yv[(size_t)(g4 + u) * NT + (c & 255)] = vf;
+            qw_apply<TR, NS>(am, ch);
+            qc_predict<TR, NS>(Pc, ch, qs, q);
+          }
+        }
+      }
+      prof.tick(24);
+      // backward recursion r <- T' r ; r += Z'(v/F - K'r): the chunk's map
+      QAElem<D> ae = qa_identity<D>(q);
+      // (the quad's own stores of K_t / v/F above are read back below by ALL its lanes)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 1
+      for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
+        const int t4 = t0 + g4;
+        const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(x.msk + t4);
+        const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
+#pragma unroll 1
+        for (int u = 3; u >= 0; --u) {
+          const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
+          const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
+#pragma unroll
+          for (int h = 0; h < H; ++h) qw_apply_t<TR, NS>(ae.M.m[h], ch);
+          qw_apply_t<TR, NS>(ae.c, ch);
+          if (obs) {
+            const float* kp = x.kr + ((size_t)(g4 + u) * NT + (c & 255)) * 8;
+            const float4 k0 = *reinterpret_cast<const float4*>(kp);
+            const float4 k1 = *reinterpret_cast<const float4*>(kp + 4);
+            const float kf[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+            const float vf = x.yv[(size_t)(g4 + u) * NT + (c & 255)];
+            float kc = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) kc = fmaf(kf[i], ae.c[i], kc);
+            const float add = vf - kc;
+            ae.c[0] += add;
+            ae.c[O] += add;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+              float kr = 0.f;
+#pragma unroll
+              for (int i = 0; i < D; ++i) kr = fmaf(kf[i], ae.M.m[h][i], kr);
+              ae.M.m[h][0] -= kr;
+              ae.M.m[h][O] -= kr;
+            }
+          }
+        }
+      }
+      prof.tick(25);
+      QAElem<D> incl = ae;
+#pragma unroll 1
+      for (int off = 1; off < 16; off <<= 1) {
+        const QAElem<D> o = q_shfl_down(incl, off);
+        if (qi + off < 16) incl = qa_compose<D>(incl, o, q);
+      }
+      if (qi == 0) {
+        float* p = xbA + (size_t)(wi * 4 + q) * DK_EA;
+        const Arr<QAElem<D>> a = __builtin_bit_cast(Arr<QAElem<D>>, incl);
+#pragma unroll
+        for (int i = 0; i < EA; ++i) p[i] = a.f[i];
+      }
+      aex = q_shfl_down(incl, 1);
+      if (qi == 15) aex = qa_identity<D>(q);
+      if (park) {
+        const Arr<QAElem<D>> a = __builtin_bit_cast(Arr<QAElem<D>>, aex);
+#pragma unroll
+        for (int i = 0; i < EA; ++i) *vslot(v, i) = a.f[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { *vslot(v, EA + i) = xpre[i]; *vslot(v, EA + 8 + i) = a0[i]; }
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int i = 0; i < D; ++i) *vslot(v, EA + 16 + h * D + i) = P0.m[h][i];
+      }
+    }
+  }
+  dk_barrier(sy, tid);
+
+  // =================== phase D: r through the chunk, forward reconstruction, statistics ============
+  {
+    QAElem<D> tot;
+    {
+      const float* p = xbA + (size_t)(qi * 4 + q) * DK_EA;
+      Arr<QAElem<D>> a;
+#pragma unroll
+      for (int i = 0; i < EA; ++i) a.f[i] = p[i];
+      tot = __builtin_bit_cast(QAElem<D>, a);
+    }
+#pragma unroll 1
+    for (int off = 1; off < 16; off <<= 1) {
+      const QAElem<D> o = q_shfl_down(tot, off);
+      if (qi + off < 16) tot = qa_compose<D>(tot, o, q);
+    }
+    prof.tick(26);
+#pragma unroll 1
+    for (int v = v0; v < v0 + nv; ++v) {
+      const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
+      if (park) {
+        Arr<QAElem<D>> a;
+#pragma unroll
+        for (int i = 0; i < EA; ++i) a.f[i] = *vslot(v, i);
+        aex = __builtin_bit_cast(QAElem<D>, a);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { xpre[i] = *vslot(v, EA + i); a0[i] = *vslot(v, EA + 8 + i); }
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int i = 0; i < D; ++i) P0.m[h][i] = *vslot(v, EA + 16 + h * D + i);
+      }
+      // r at the chunk's end: the maps of the wave's later chunks applied to what the later waves leave
+      float rsuf[D];
+      {
+        QAElem<D> ws = q_shfl_from(tot, wi < 15 ? wi + 1 : 15, q);
+        if (wi == 15) ws = qa_identity<D>(q);
+        const QVec<D> wc = q_own<D>(ws.c, q);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          float p = 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) p = fmaf(aex.M.m[h][i], wc.v[h], p);
+          rsuf[i] = aex.c[i] + q_sum(p);
+        }
+      }
+      // (5a) r through the chunk, backward; r_{t-1} takes the place of K_t
+      {
+        float r[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) r[i] = rsuf[i];
+#pragma unroll 1
+        for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
+          const int t4 = t0 + g4;
+          const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(x.msk + t4);
+          const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
+          // the block's four rows are requested before its stores
+          float4 ka[4], kb[4];
+          float vf4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float* kp = x.kr + ((size_t)(g4 + u) * NT + (c & 255)) * 8;
+            ka[u] = *reinterpret_cast<const float4*>(kp);
+            kb[u] = *reinterpret_cast<const float4*>(kp + 4);
+            vf4[u] = x.yv[(size_t)(g4 + u) * NT + (c & 255)];
+          }
+          // every lane of the quad must have its rows before lanes 0 / 1 overwrite them
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int u = 3; u >= 0; --u) {
+            const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
+            const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
+            qw_apply_t<TR, NS>(r, ch);
+            if (obs) {
+              const float kf[8] = {ka[u].x, ka[u].y, ka[u].z, ka[u].w, kb[u].x, kb[u].y, kb[u].z, kb[u].w};
+              float kr = 0.f;
+#pragma unroll
+              for (int i = 0; i < D; ++i) kr = fmaf(kf[i], r[i], kr);
+              const float add = vf4[u] - kr;
+              r[0] += add;
+              r[O] += add;
+            }
+            float r8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r8[i] = i < D ? r[i < D ? i : 0] : 0.f;
+            float* kp = x.kr + ((size_t)(g4 + u) * NT + (c & 255)) * 8;
+            if (q == 0) *reinterpret_cast<float4*>(kp) = make_float4(r8[0], r8[1], r8[2], r8[3]);
+            if (q == 1) *reinterpret_cast<float4*>(kp + 4) = make_float4(r8[4], r8[5], r8[6], r8[7]);
+          }
+        }
+        // x^ at the chunk start: a + P r_{t0 - 1}
+        const QVec<D> ro = q_own<D>(r, q);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          float p = 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) p = fmaf(P0.m[h][i], ro.v[h], p);
+          a0[i] += q_sum(p);
+        }
+      }
+      prof.tick(27);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // (5b) forward: x^_{t+1} = T x^_t + Q_t r_t; x+ re-simulated; x~ = x^ + x+; statistics
+      {
+        float ssl = 0.f, sss = 0.f, ssd = 0.f;
+        auto stats = [&](const float (&xt)[D], const float (&xn)[D], bool ch) {
+          float dl = xn[0] - xt[0];
+          if constexpr (TR == 2) {
+            dl -= xt[1];
+            const float ds = xn[1] - xt[1];
+            sss = fmaf(ds, ds, sss);
+          }
+          ssl = fmaf(dl, dl, ssl);
+          if (ch) {
+            float w;
+            if constexpr (NS >= 3) w = (float)NS * (xt[O + 1] - xn[O]);
+            else w = -2.0f * (xn[O] + xt[O]);
+            ssd = fmaf(w, w, ssd);
+          }
+        };
+        float xh[D], xp[D], xprev[D], xfirst[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { xh[i] = a0[i]; xp[i] = xpre[i]; xprev[i] = 0.f; xfirst[i] = 0.f; }
+        bool chprev = false;
+        auto load_r = [&](int g4, float4 (&ra)[4], float4 (&rb)[4]) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int sidx = g4 + u + 1;          // r_t of step t = the row stored for step t + 1
+            if (sidx < Lc) {
+              const float* kp = x.kr + ((size_t)sidx * NT + (c & 255)) * 8;
+              ra[u] = *reinterpret_cast<const float4*>(kp);
+              rb[u] = *reinterpret_cast<const float4*>(kp + 4);
+            } else {
+              float r8[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) r8[i] = i < D ? rsuf[i < D ? i : 0] : 0.f;
+              ra[u] = make_float4(r8[0], r8[1], r8[2], r8[3]);
+              rb[u] = make_float4(r8[4], r8[5], r8[6], r8[7]);
+            }
+          }
+        };
+        float4 rna[4], rnb[4];
+        load_r(0, rna, rnb);
+#pragma unroll 1
+        for (int g4 = 0; g4 < Lc; g4 += 4) {
+          const int t4 = t0 + g4;
+          float4 rca[4], rcb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { rca[u] = rna[u]; rcb[u] = rnb[u]; }
+          if (g4 + 4 < Lc) load_r(g4 + 4, rna, rnb);
+          float z[4];
+          normals4(site_call(rng, iter, my_site, 0, (uint32_t)(t4 >> 2)), z);
+          const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
+          float lev4 = 0.f, slp4 = 0.f, sea4 = 0.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = t4 + u;
+            const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
+            float xt[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) xt[i] = xh[i] + xp[i];
+            if (q == u) { lev4 = xt[0]; sea4 = xt[O]; if constexpr (TR == 2) slp4 = xt[1]; }
+            if (g4 + u == 0) {
+#pragma unroll
+              for (int i = 0; i < D; ++i) xfirst[i] = xt[i];
+            } else if (t < T) {
+              stats(xprev, xt, chprev);
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) xprev[i] = xt[i];
+            chprev = ch;
+            const float rn[8] = {rca[u].x, rca[u].y, rca[u].z, rca[u].w, rcb[u].x, rcb[u].y, rcb[u].z, rcb[u].w};
+            qw_apply<TR, NS>(xh, ch);
+            xh[0] = fmaf(sc.ql, rn[0], xh[0]);
+            if constexpr (TR == 2) xh[1] = fmaf(sc.qs, rn[1], xh[1]);
+            if (ch) {
+              float sr = 0.f;
+#pragma unroll
+              for (int i = 0; i < N1; ++i) sr += rn[O + i];
+              const float add = sc.qd * sr;
+#pragma unroll
+              for (int i = 0; i < N1; ++i) xh[O + i] += add;
+            }
+            xplus_step(xp, ch, q_bc(z[u], 0), q_bc(z[u], 3), q_bc(z[u], 1));
+          }
+          // lane u of the quad holds step t4 + u: one 4-byte store per lane, 16 bytes per quad
+          if (t4 + q < T) {
+            x.levw[t4 + q] = lev4;
+            if constexpr (TR == 2) x.slpw[t4 + q] = slp4;
+            x.seaw[t4 + q] = sea4;
+          }
+        }
+        if (q == 0) {
+          float* sp = stat + (size_t)c * DK_ST;
+          sp[0] = ssl; sp[1] = sss; sp[2] = ssd;
+#pragma unroll
+          for (int i = 0; i < D; ++i) { sp[4 + i] = xfirst[i]; sp[12 + i] = xprev[i]; }
+        }
+      }
+      prof.tick(28);
+    }
+  }
+  dk_barrier(sy, tid);
+}
+
+// The statistics of the draw for the scale updates: thread i adds chunk i's sums and the increment
+// across the boundary to chunk i + 1 (from the first / last states the draw left per chunk).
+template <int TR, int NS>
+__device__ __forceinline__ void dk_stats(const float* xb, const uint8_t* cbv, int T, int Lc, int tid,
+                                         float& ssl, float& sss, float& ssd) {
+  constexpr int D = TR + NS - 1, O = TR;
+  const float* stat = xb + (size_t)DK_NWI * 4 * DK_EF + (size_t)DK_NWI * 4 * DK_EA + 256;
+  const float* sp = stat + (size_t)tid * DK_ST;
+  ssl = sp[0]; sss = sp[1]; ssd = sp[2];
+  const int t = tid * Lc + Lc - 1;
+  if (t + 1 < T) {
+    const float* sn = sp + DK_ST;
+    float xt[D], xn[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { xt[i] = sp[12 + i]; xn[i] = sn[4 + i]; }
+    float dl = xn[0] - xt[0];
+    if constexpr (TR == 2) {
+      dl -= xt[1];
+      const float ds = xn[1] - xt[1];
+      sss = fmaf(ds, ds, sss);
+    }
+    ssl = fmaf(dl, dl, ssl);
+    if (cbv[t] != 0) {
+      float w;
+      if constexpr (NS >= 3) w = (float)NS * (xt[O + 1] - xn[O]);
+      else w = -2.0f * (xn[O] + xt[O]);
+      ssd = fmaf(w, w, ssd);
+    }
+  }
+}
+
+}  // namespace ci

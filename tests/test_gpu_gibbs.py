@@ -657,9 +657,11 @@ def test_seasonal_kernel_with_arrays_in_hbm_equals_the_lds_variant():
 
 def test_clusters_of_workgroups_give_the_same_bits_as_one_workgroup_per_chain():
   """Time-parallel seasonal kernel: a chain's X~'targets / emission / X w phases are shared by
-  8, 4 or 2 workgroups when the launch leaves CUs idle (ci_wide.h "clusters").  The reductions run
-  over fixed segments, so every cluster size -- chosen from the number of chains -- and the
-  single-workgroup kernel produce identical draws."""
+  16, 8, 4 or 2 workgroups when the launch leaves CUs idle (ci_wide.h "clusters"), and the
+  Durbin-Koopman draw runs on the first 8, 4, 4 or 2 of them (ci_wide_quad.h: eight virtual
+  workgroups of 64 quads of lanes, however many real ones carry them).  The reductions run over
+  fixed segments and the draw's chunk grid is fixed by T, so every cluster size -- chosen from the
+  number of chains -- and the single-workgroup kernel produce identical draws."""
   from causalimpact import _model
   T, p, seasons, W, S = 4800, 20, ((7, 1),), 3, 6            # 5 segments of 1024 steps
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 5)
@@ -675,14 +677,16 @@ def test_clusters_of_workgroups_give_the_same_bits_as_one_workgroup_per_chain():
     return _native.fit_gibbs(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
 
   one = fit(2, _native.FLAG_NO_CLUSTER)
-  eight = fit(2, 0)                                           # 8 x 8 workgroups <= 256 CUs
+  sixteen = fit(2, 0)                                         # 8 x 16 workgroups <= 256 CUs
+  eight = fit(20, 0)                                          # 24 x 16 > 256 >= 24 x 8
   four = fit(40, 0)                                           # 40 x 8 > 256 >= 40 x 4
   two = fit(72, 0)                                            # 72 x 4 > 256 >= 72 x 2
   # a cluster that does not assemble (one helper "never scheduled"): main notices and runs alone
   lonely = fit(2, _native.FLAG_TEST_DROP_HELPER)
   for key in one:
     np.testing.assert_array_equal(lonely[key], one[key], err_msg=key)
-    np.testing.assert_array_equal(eight[key], one[key], err_msg=key)
+    np.testing.assert_array_equal(sixteen[key], one[key], err_msg=key)
+    np.testing.assert_array_equal(eight[key][:, :2], one[key], err_msg=key)
     np.testing.assert_array_equal(four[key][:, :2], one[key], err_msg=key)
     np.testing.assert_array_equal(two[key][:, :2], one[key], err_msg=key)
   assert np.isfinite(one["posterior_trajectories"]).all()

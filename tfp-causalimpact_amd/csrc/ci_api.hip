@@ -706,7 +706,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     for (int k = 0; k < K; ++k) { s->D_full += pb->num_seasons[k]; s->dred += pb->num_seasons[k] - 1; }
     s->wide = use_wide(pb);
     if (s->wide) {
-      s->Lc = wide_steps_per_thread(T);
+      s->Lc = ci::wide_quad_steps(T);
       s->lds_bytes = ci::make_wlayout(P, s->dred).total;
       s->fn = (KernelFn)pick_wide_kernel(pb->has_slope, pb->num_seasons[0]);
     } else {
@@ -814,7 +814,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       const long long groups = ((long long)B * C + 7) / 8 * 8;
       s->cluster = 1;
       if (!(pb->flags & CI_FLAG_NO_CLUSTER) && P > 0 && (T & 3) == 0) {
-        if (groups * 8 <= num_cus) s->cluster = 8;
+        if (groups * 16 <= num_cus) s->cluster = 16;
+        else if (groups * 8 <= num_cus) s->cluster = 8;
         else if (groups * 4 <= num_cus) s->cluster = 4;
         else if (groups * 2 <= num_cus) s->cluster = 2;
       }

@@ -47,8 +47,9 @@ template <int TR, int NS> struct WDim {
 };
 
 // The Durbin-Koopman draw over the cluster's workgroups (ci_wide_quad.h): its exchange region.
-constexpr int DK_V = 4;               // virtual workgroups (64 quads of lanes each) per chain
-constexpr int DK_NWI = 16;            // wavefronts of the chain's grid: 4 per virtual workgroup
+constexpr int DK_V = 8;               // virtual workgroups (64 quads of lanes each) per chain
+constexpr int DK_CH = 64 * DK_V;      // chunks of the series: its grid, fixed by T alone
+constexpr int DK_NWI = 4 * DK_V;      // wavefronts of the chain's grid
 constexpr int DK_EF = 72;             // floats per lane of a published filtering element (d <= 8: 68)
 constexpr int DK_EA = 32;             //                         ... backward map (d <= 8: 24)
 constexpr int DK_EP = 12;             // floats of a published prior-simulation element (d <= 8: 10)
@@ -56,13 +57,18 @@ constexpr int DK_ST = 20;             // per chunk: 3 sums of squares, first sta
 constexpr int DK_VS = 80;             // floats per lane parked between phases when one workgroup runs several virtual ones
 constexpr int DK_NF = 9;              // per-step workspace: y~ -> v/F, K_t -> r_{t-1} (8 floats)
 __host__ __device__ inline size_t wide_dk_floats() {
-  return (size_t)DK_NWI * 4 * DK_EF + (size_t)DK_NWI * 4 * DK_EA + 256 + (size_t)NT * DK_ST +
+  return (size_t)DK_NWI * 4 * DK_EF + (size_t)DK_NWI * 4 * DK_EA + 512 + (size_t)DK_CH * DK_ST +
          (size_t)DK_V * NT * DK_VS;
+}
+// steps per chunk of the grid (a multiple of 4: whole 16-byte accesses)
+__host__ __device__ inline int wide_quad_steps(int T) {
+  const int lc = (T + DK_CH - 1) / DK_CH;
+  return lc < 4 ? 4 : (lc + 3) & ~3;
 }
 // floats of HBM workspace per chain
 __host__ __device__ inline size_t wide_workspace_floats(int D, int Lc) {
   (void)D;
-  const size_t TP = (size_t)NT * Lc;
+  const size_t TP = (size_t)DK_CH * Lc;
   return (6 + DK_NF) * TP + TP / 2 + wide_dk_floats();   // 6 shared T-arrays, per-step fields, mask + change bytes, exchange
 }
 
@@ -383,8 +389,8 @@ __device__ __forceinline__ void cl_wait(int* flags, int n, int value, int tid) {
   }
   __syncthreads();
 }
-constexpr int CL_INTS = 32;              // handshake counters per chain
-enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_MODE = 2, CL_V = 3, CL_DK = 4, CL_PARTIAL = 8, CL_XW = 16, CL_XCC = 24 };   // + role (< 8)
+constexpr int CL_INTS = 64;              // handshake counters per chain
+enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_MODE = 2, CL_V = 3, CL_DK = 4, CL_PARTIAL = 16, CL_XW = 32, CL_XCC = 48 };   // + role (< 16)
 // Assembling a cluster.  The handshakes below spin, so a cluster may only run when ALL its
 // workgroups are resident -- which the host sizes the launch for, but cannot guarantee (another
 // stream or process may hold CUs).  So the cluster is agreed on at the start, with time-outs:
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const KArgs& g = a.k;
   const int T = g.T, P = g.P, Lc = a.Lc;
-  const int TP = NT * Lc;
+  const int TP = DK_CH * Lc;
   // workgroup -> (chain, role): the workgroups of one chain share an XCD (ids equal mod 8)
   const int GL = a.cluster;                   // workgroups per chain in this launch
   int chain_id = blockIdx.x, role = 0;
@@ -517,9 +523,12 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const int clo = (int)((long long)(TP >> 2) * role / G), chi = (int)((long long)(TP >> 2) * (role + 1) / G);
   const int n_iter = g.W + g.S;
   // The Durbin-Koopman draw runs on the cluster's first Gd workgroups (ci_wide_quad.h); with eight
-  // workgroups the fifth one sweeps the next iteration's regression matrix meanwhile.
+  // (sixteen) workgroups the fifth (ninth) one sweeps the next iteration's regression matrix meanwhile.
+  // (measured at 32 chains x 8 workgroups: all eight in the draw and no sweep ahead -- 8 x 1 virtual
+  // workgroup -- beats four in the draw plus the sweeper, 4 x 2 virtual workgroups: the draw is the
+  // longer pole)
   const int Gd = G >= DK_V ? DK_V : G;
-  const int sweep_role = G == 8 ? 4 : -1;
+  const int sweep_role = G == 16 ? 8 : -1;
   DkSync dsy;
   dsy.cnt = csync + CL_DK; dsy.Gd = Gd; dsy.epoch = 0; dsy.cluster = Gd > 1; dsy.light = light;
   DkCtx dk;
@@ -684,11 +693,43 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     }
   };
 
+  // ---- helper workgroup: its share of phases (1), (3), (4); with eight workgroups the fifth also
+  // prepares the next iteration's regression matrix; the first Gd take part in the draw below
+  const bool sweeper = role > 0 && role == sweep_role && P > 16;
+  auto helper_iteration = [&](int it) {
+    cl_wait(csync + CL_LATENTS, 1, it + 1, tid);
+    role_segment_sums();
+    cl_publish(csync + CL_PARTIAL + role, it + 1, tid, light);
+    cl_wait(csync + CL_WEIGHTS, 1, it + 1, tid);
+    if (tid < P) R.w[tid] = cw[tid];
+    const float so = cw[P];
+    __syncthreads();
+    if (it > g.W) emit_range(it, so, clo, chi);
+    if (it < n_iter) xw_range(clo, chi);
+    cl_publish(csync + CL_XW + role, it + 1, tid, light);
+    if (sweeper && it + 1 < n_iter) {
+      // iteration it + 1 sweeps Omega s2 + X'X on the features that are in now, s2 this
+      // iteration's observation-noise variance: both are in the message just received
+      const double so_d = *reinterpret_cast<const double*>(cw + 56);
+      const bool all_in = sp.nonzero_prob >= 1.0;
+      const unsigned long long nzmask = __ballot(lane < P && (all_in || R.w[lane < P ? lane : 0] != 0.f));
+      presweep_block(R, P, so_d * so_d, nzmask, false, tid);
+      presweep_export(R, P, nzmask, cv, tid);
+      cl_publish(csync + CL_V, it + 1, tid, light);
+    }
+  };
+
+  double n_changes = 0.0;
+  double obs_scale = sp.obs_scale0, level_scale = sp.level_scale0, slope_scale = sp.slope_scale0;
+  double drift = ss.drift_scale0[0];
+  float ssl = 0.f, sss = 0.f, ssd = 0.f;
+  PriorCarry pc;
+  pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
+  Prof prof;
+  prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && tid == 0);
   if (role > 0) {
-    // ---- helper workgroup: its share of phases (1), (3), (4); the first helper also prepares the
-    // next iteration's regression matrix
-    const bool sweeper = role == sweep_role && P > 16;
-    NoProf hprof;
     if (sweeper) {
       for (int e = tid; e < P * P; e += NT) {
         R.xtx[e] = g.xtx[(size_t)series * P * P + e];
@@ -696,41 +737,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       }
       __syncthreads();
     }
-    for (int it = 0; it <= n_iter; ++it) {
-      cl_wait(csync + CL_LATENTS, 1, it + 1, tid);
-      role_segment_sums();
-      cl_publish(csync + CL_PARTIAL + role, it + 1, tid, light);
-      cl_wait(csync + CL_WEIGHTS, 1, it + 1, tid);
-      if (tid < P) R.w[tid] = cw[tid];
-      const float so = cw[P];
-      __syncthreads();
-      if (it > g.W) emit_range(it, so, clo, chi);
-      if (it < n_iter) xw_range(clo, chi);
-      cl_publish(csync + CL_XW + role, it + 1, tid, light);
-      if (sweeper && it + 1 < n_iter) {
-        // iteration it + 1 sweeps Omega s2 + X'X on the features that are in now, s2 this
-        // iteration's observation-noise variance: both are in the message just received
-        const double so_d = *reinterpret_cast<const double*>(cw + 56);
-        const bool all_in = sp.nonzero_prob >= 1.0;
-        const unsigned long long nzmask = __ballot(lane < P && (all_in || R.w[lane < P ? lane : 0] != 0.f));
-        presweep_block(R, P, so_d * so_d, nzmask, false, tid);
-        presweep_export(R, P, nzmask, cv, tid);
-        cl_publish(csync + CL_V, it + 1, tid, light);
-      }
-      if (role < Gd && it < n_iter) {
-        // a DK worker: every share of X w / the residual is in, the scales came with the weights
-        cl_wait(csync + CL_XW, G, it + 1, tid);
-        WideScal sc;
-        sc.so = cw[58]; sc.H = sc.so * sc.so;
-        sc.sl = cw[59]; sc.ql = sc.sl * sc.sl;
-        sc.ss = cw[60]; sc.qs = sc.ss * sc.ss;
-        sc.sdn = cw[61] * (1.0f / (float)NS); sc.qd = sc.sdn * sc.sdn;
-        wide_dk_quad<TR, NS>(sc, dk, rng, (uint32_t)it, role, dsy, tid, hprof);
-      }
-    }
-    return;
-  }
-
+  } else {
   float nch = 0.f;
   for (int t = tid; t < TP; t += NT) {
     const bool in = t < T;
@@ -750,21 +757,24 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     if (lane == 0) red[wave] = s;
   }
   __syncthreads();
-  const double n_changes = (double)(red[0] + red[1] + red[2] + red[3]);
+  n_changes = (double)(red[0] + red[1] + red[2] + red[3]);
   __syncthreads();
-
-  double obs_scale = sp.obs_scale0, level_scale = sp.level_scale0, slope_scale = sp.slope_scale0;
-  double drift = ss.drift_scale0[0];
-  float ssl = 0.f, sss = 0.f, ssd = 0.f;
-  PriorCarry pc;
-  pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
-  Prof prof;
-  prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && tid == 0);
   if (G > 1) cl_publish(csync + CL_LATENTS, 1, tid, light);      // masks and zeroed latents are in place
+  }
 
   for (int it = 0; it <= n_iter; ++it) {
+    WideScal sc;
+    if (role > 0) {
+      helper_iteration(it);
+      if (it == n_iter) break;
+      if (role >= Gd) continue;
+      // a DK worker: every share of X w / the residual is in, the scales came with the weights
+      cl_wait(csync + CL_XW, G, it + 1, tid);
+      sc.so = cw[58]; sc.H = sc.so * sc.so;
+      sc.sl = cw[59]; sc.ql = sc.sl * sc.sl;
+      sc.ss = cw[60]; sc.qs = sc.ss * sc.ss;
+      sc.sdn = cw[61] * (1.0f / (float)NS); sc.qd = sc.sdn * sc.sdn;
+    } else {
     // ---- (1) targets, y'y, X~'targets (time interleaved over threads: coalesced)
     if (it > 0) dk_stats<TR, NS>(dkx, cbp, T, Lc, tid, ssl, sss, ssd);
     if (vec4) {
@@ -977,17 +987,18 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       cl_publish(csync + CL_XW, it + 1, tid, light);        // this workgroup's share of the residual
       cl_wait(csync + CL_XW + 1, G - 1, it + 1, tid);
     }
-    WideScal sc;
     sc.so = scal[0]; sc.H = sc.so * sc.so;
     sc.sl = scal[2]; sc.ql = sc.sl * sc.sl;
     sc.ss = scal[3]; sc.qs = sc.ss * sc.ss;
     sc.sdn = scal[4] * (1.0f / (float)NS); sc.qd = sc.sdn * sc.sdn;
     __syncthreads();
     prof.tick(3);
-    // the Durbin-Koopman draw, with the cluster's other DK workers (ends with their barrier)
-    wide_dk_quad<TR, NS>(sc, dk, rng, (uint32_t)it, 0, dsy, tid, prof);
-    if (G > 1) cl_publish(csync + CL_LATENTS, it + 2, tid, light);
+    }
+    // the Durbin-Koopman draw, by the cluster's DK workers together (ends with their barrier)
+    wide_dk_quad<TR, NS>(sc, dk, rng, (uint32_t)it, role, dsy, tid, prof);
+    if (G > 1 && role == 0) cl_publish(csync + CL_LATENTS, it + 2, tid, light);
   }
+  if (role > 0) return;
   __syncthreads();     // the running sums were accumulated through the emission's thread mapping
   if (g.out_pred_mean) {
     const float inv = 1.0f / (float)(g.S > 0 ? g.S : 1);

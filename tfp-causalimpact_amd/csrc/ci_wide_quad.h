@@ -5,7 +5,7 @@
 // 556k cycles at cfg4, VALU-issue bound on that CU's four SIMDs (a combine of two 119-float
 // filtering elements is ~2.8k dependent FMAs on one lane; the per-step passes carry 7 x 7 matrices
 // through 40 steps per lane) while the cluster's other CUs waited.  Now:
-//   * the grid is unchanged -- 256 chunks of Lc = ceil(T / 256) steps (rounded to 4), fixed by T alone --
+//   * the grid is unchanged -- 512 chunks of Lc = ceil(T / 512) steps (rounded to 4), fixed by T alone --
 //     but a chunk belongs to the four lanes of a quad: matrices split by columns, operands from the
 //     other lanes through DPP broadcasts (ci_quad.h).  1024 lanes = four VIRTUAL workgroups of 64
 //     quads; the cluster's first Gd = 4, 2 or 1 workgroups ("DK workers") take 1, 2 or 4 of them
@@ -196,11 +196,15 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
   const int T = x.T, Lc = x.Lc;
   const int nv = DK_V / sy.Gd, v0 = role * nv;
   const bool park = nv > 1;                    // state crosses the hand-overs through L2
+  // virtual workgroups whose chunks start before the end of the series; the others are skipped and
+  // their wavefronts' totals read as the identity
+  const int nvact = (T + 64 * Lc - 1) / (64 * Lc);
+  const int nwact = 4 * nvact;
   float* xbF = x.xb;
   float* xbA = xbF + (size_t)DK_NWI * 4 * DK_EF;
   float* xbP = xbA + (size_t)DK_NWI * 4 * DK_EA;
-  float* stat = xbP + 256;
-  float* vst = stat + (size_t)NT * DK_ST;
+  float* stat = xbP + 512;
+  float* vst = stat + (size_t)DK_CH * DK_ST;
   const QScal<D> qs = make_qscal<TR, NS>(sc, q);
   auto vslot = [&](int v, int f) -> float* { return vst + ((size_t)(v * DK_VS + f) * NT + tid); };
   auto at4 = [](const float (&z)[4], int s) { return s == 0 ? z[0] : s == 1 ? z[1] : s == 2 ? z[2] : z[3]; };
@@ -255,12 +259,12 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
   float a0[D];              // predicted mean at the chunk start
   QMat<D> P0;               // predicted covariance at the chunk start
   WPElem<D> pex;            // in-wave exclusive prefix of the prior-simulation scan
-  QFElem<D> fex;            //                        ... of the filter scan
   QAElem<D> aex;            // in-wave exclusive suffix of the backward scan
 
   // =================== phase A: prior simulation, chunk elements, in-wave scan ====================
 #pragma unroll 1
   for (int v = v0; v < v0 + nv; ++v) {
+    if (v >= nvact) continue;
     const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
     WPElem<D> pe;
     {
@@ -312,6 +316,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
   // =================== phase B: x+ and y~, chunk filtering elements, in-wave scan ==================
 #pragma unroll 1
   for (int v = v0; v < v0 + nv; ++v) {
+    if (v >= nvact) continue;
     const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
     if (park) {
       pex.k = *vslot(v, 0); pex.m = (int)*vslot(v, 1);
@@ -349,14 +354,22 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
       float xp[D];
 #pragma unroll
       for (int i = 0; i < D; ++i) xp[i] = xpre[i];
+      // (one wave per SIMD: nothing hides an L2 round trip but a request made a block ahead)
+      float4 nr4 = *reinterpret_cast<const float4*>(x.resid + t0);
+      uint32_t nmk = *reinterpret_cast<const uint32_t*>(x.msk + t0);
+      uint32_t ncb = *reinterpret_cast<const uint32_t*>(x.cbv + t0);
 #pragma unroll 1
       for (int g4 = 0; g4 < Lc; g4 += 4) {
         const int t4 = t0 + g4;
+        const float4 r4 = nr4;
+        const uint32_t mk4 = nmk, cb4 = ncb;
+        if (g4 + 4 < Lc) {
+          nr4 = *reinterpret_cast<const float4*>(x.resid + t4 + 4);
+          nmk = *reinterpret_cast<const uint32_t*>(x.msk + t4 + 4);
+          ncb = *reinterpret_cast<const uint32_t*>(x.cbv + t4 + 4);
+        }
         float z[4];
         normals4(site_call(rng, iter, my_site, 0, (uint32_t)(t4 >> 2)), z);
-        const float4 r4 = *reinterpret_cast<const float4*>(x.resid + t4);
-        const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(x.msk + t4);
-        const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
 #pragma unroll 1
         for (int u = 0; u < 4; ++u) {
           const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
@@ -365,7 +378,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
           const float zl = q_bc(zm, 0), zk = q_bc(zm, 1), zo = q_bc(zm, 2), zs = q_bc(zm, 3);
           const float ru = u == 0 ? r4.x : u == 1 ? r4.y : u == 2 ? r4.z : r4.w;
           const float yt = ru - (xp[0] + xp[O] + sc.so * zo);
-          if (q == 0) x.yv[(size_t)(g4 + u) * NT + (c & 255)] = yt;
+          if (q == 0) x.yv[(size_t)(g4 + u) * DK_CH + c] = yt;
           if (obs) {
             // fold y~_t into (A, b, C, eta, J)
             QVec<D> za, cz;
@@ -418,12 +431,16 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
 #pragma unroll
       for (int i = 0; i < EF; ++i) p[i] = a.f[i];
     }
-    fex = q_shfl_up(incl, 1);
+    QFElem<D> fex = q_shfl_up(incl, 1);
     if (qi == 0) fex = qf_identity<D>(q);
-    if (park) {
+    {
+      // the in-wave prefix waits in L2 for the scan of the wave totals in every configuration: 60
+      // registers that would otherwise sit (spilled) under the 32-total scan
       const Arr<QFElem<D>> a = __builtin_bit_cast(Arr<QFElem<D>>, fex);
 #pragma unroll
       for (int i = 0; i < EF; ++i) *vslot(v, i) = a.f[i];
+    }
+    if (park) {
 #pragma unroll
       for (int i = 0; i < D; ++i) *vslot(v, EF + i) = xpre[i];
     }
@@ -433,34 +450,44 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
 
   // =================== phase C: prefixes, local filter (gains), backward chunk maps =================
   {
-    // every wavefront scans the 16 wave totals of the chain: quad j holds total j
-    QFElem<D> tot;
+    // Every wavefront scans the 32 wave totals of the chain on its own: quad j loads totals 2j and
+    // 2j + 1, combines them, and the 16 pairs go through one more Kogge-Stone (totals of skipped
+    // wavefronts are the identity).
+    QFElem<D> tot0, tot;
     {
-      const float* p = xbF + (size_t)(qi * 4 + q) * DK_EF;
-      Arr<QFElem<D>> a;
+      auto load_total = [&](int w) {
+        if (w >= nwact) return qf_identity<D>(q);
+        const float* p = xbF + (size_t)(w * 4 + q) * DK_EF;
+        Arr<QFElem<D>> a;
 #pragma unroll
-      for (int i = 0; i < EF; ++i) a.f[i] = p[i];
-      tot = __builtin_bit_cast(QFElem<D>, a);
+        for (int i = 0; i < EF; ++i) a.f[i] = p[i];
+        return __builtin_bit_cast(QFElem<D>, a);
+      };
+      tot0 = load_total(2 * qi);
+      tot = qf_combine<D>(tot0, load_total(2 * qi + 1), q);
     }
 #pragma unroll 1
     for (int off = 1; off < 16; off <<= 1) {
       const QFElem<D> o = q_shfl_up(tot, off);
       if (qi >= off) tot = qf_combine<D>(o, tot, q);
     }
-    prof.tick(23);
+    // the predicted moments at every chunk start (the totals die here: nothing of the scan stays
+    // live through the per-step passes below)
 #pragma unroll 1
     for (int v = v0; v < v0 + nv; ++v) {
-      const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
-      if (park) {
+      if (v >= nvact) continue;
+      const int c = 64 * v + (tid >> 2), wi = 4 * v + wave;
+      QFElem<D> fex;
+      {
         Arr<QFElem<D>> a;
 #pragma unroll
         for (int i = 0; i < EF; ++i) a.f[i] = *vslot(v, i);
         fex = __builtin_bit_cast(QFElem<D>, a);
-#pragma unroll
-        for (int i = 0; i < D; ++i) xpre[i] = *vslot(v, EF + i);
       }
-      QFElem<D> wp = q_shfl_from(tot, wi > 0 ? wi - 1 : 0, q);
-      if (wi == 0) wp = qf_identity<D>(q);
+      // everything before wavefront wi: the pairs before its own, and for an odd wi the even total
+      QFElem<D> wp = q_shfl_from(tot, wi >= 2 ? (wi >> 1) - 1 : 0, q);
+      if (wi < 2) wp = qf_identity<D>(q);
+      if (wi & 1) wp = qf_combine<D>(wp, q_shfl_from(tot0, wi >> 1, q), q);
       const QFElem<D> pre = qf_combine<D, true>(wp, fex, q);
       {
         QVec<D> bb = pre.b;
@@ -468,20 +495,52 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
         P0 = pre.C;
       }
       if (c == 0) prior_moments(a0, P0);        // nothing before the first chunk: the prior itself
+      if (park) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) *vslot(v, i) = a0[i];
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int i = 0; i < D; ++i) *vslot(v, 8 + h * D + i) = P0.m[h][i];
+      }
+    }
+    prof.tick(23);
+#pragma unroll 1
+    for (int v = v0; v < v0 + nv; ++v) {
+      if (v >= nvact) continue;
+      const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
+      if (park) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) { a0[i] = *vslot(v, i); xpre[i] = *vslot(v, EF + i); }
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int i = 0; i < D; ++i) P0.m[h][i] = *vslot(v, 8 + h * D + i);
+      }
       // local Kalman filter from the predicted moments at the chunk start: K_t, v_t / F_t
       {
         float am[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) am[i] = a0[i];
         QMat<D> Pc = P0;
+        float nyt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nyt[u] = x.yv[(size_t)u * DK_CH + c];
+        uint32_t nmk = *reinterpret_cast<const uint32_t*>(x.msk + t0);
+        uint32_t ncb = *reinterpret_cast<const uint32_t*>(x.cbv + t0);
 #pragma unroll 1
         for (int g4 = 0; g4 < Lc; g4 += 4) {
           const int t4 = t0 + g4;
-          const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(x.msk + t4);
-          const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
+          const uint32_t mk4 = nmk, cb4 = ncb;
           float yt4[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) yt4[u] = x.yv[(size_t)(g4 + u) * NT + (c & 255)];
+          for (int u = 0; u < 4; ++u) yt4[u] = nyt[u];
+          if (g4 + 4 < Lc) {       // the next block's rows, requested before this block's stores
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nyt[u] = x.yv[(size_t)(g4 + 4 + u) * DK_CH + c];
+            nmk = *reinterpret_cast<const uint32_t*>(x.msk + t4 + 4);
+            ncb = *reinterpret_cast<const uint32_t*>(x.cbv + t4 + 4);
+          }
 #pragma unroll 1
           for (int u = 0; u < 4; ++u) {
             const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
@@ -509,10 +568,10 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
                 for (int h = 0; h < H; ++h) Pc.m[h][i] = fmaf(-(pzr[i] * pz.v[h]), rF, Pc.m[h][i]);
               }
             }
-            float* kp = x.kr + ((size_t)(g4 + u) * NT + (c & 255)) * 8;
+            float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
             if (q == 0) *reinterpret_cast<float4*>(kp) = make_float4(kf[0], kf[1], kf[2], kf[3]);
             if (q == 1) *reinterpret_cast<float4*>(kp + 4) = make_float4(kf[4], kf[5], kf[6], kf[7]);
-            if (q == 2) x.yv[(size_t)(g4 + u) * NT + (c & 255)] = vf;
+            if (q == 2) x.yv[(size_t)(g4 + u) * DK_CH + c] = vf;
             qw_apply<TR, NS>(am, ch);
             qc_predict<TR, NS>(Pc, ch, qs, q);
           }
@@ -525,12 +584,26 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      struct KV4 { float4 a[4], b[4]; float vf[4]; uint32_t mk, cb; };
+      auto load_kv = [&](int g4, KV4& o) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
+          o.a[u] = *reinterpret_cast<const float4*>(kp);
+          o.b[u] = *reinterpret_cast<const float4*>(kp + 4);
+          o.vf[u] = x.yv[(size_t)(g4 + u) * DK_CH + c];
+        }
+        o.mk = *reinterpret_cast<const uint32_t*>(x.msk + t0 + g4);
+        o.cb = *reinterpret_cast<const uint32_t*>(x.cbv + t0 + g4);
+      };
+      KV4 nxt;
+      load_kv(Lc - 4, nxt);
 #pragma unroll 1
       for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
-        const int t4 = t0 + g4;
-        const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(x.msk + t4);
-        const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
-#pragma unroll 1
+        const KV4 cur = nxt;
+        if (g4 >= 4) load_kv(g4 - 4, nxt);
+        const uint32_t mk4 = cur.mk, cb4 = cur.cb;
+#pragma unroll
         for (int u = 3; u >= 0; --u) {
           const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
           const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
@@ -538,11 +611,9 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
           for (int h = 0; h < H; ++h) qw_apply_t<TR, NS>(ae.M.m[h], ch);
           qw_apply_t<TR, NS>(ae.c, ch);
           if (obs) {
-            const float* kp = x.kr + ((size_t)(g4 + u) * NT + (c & 255)) * 8;
-            const float4 k0 = *reinterpret_cast<const float4*>(kp);
-            const float4 k1 = *reinterpret_cast<const float4*>(kp + 4);
-            const float kf[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-            const float vf = x.yv[(size_t)(g4 + u) * NT + (c & 255)];
+            const float kf[8] = {cur.a[u].x, cur.a[u].y, cur.a[u].z, cur.a[u].w,
+                                 cur.b[u].x, cur.b[u].y, cur.b[u].z, cur.b[u].w};
+            const float vf = cur.vf[u];
             float kc = 0.f;
 #pragma unroll
             for (int i = 0; i < D; ++i) kc = fmaf(kf[i], ae.c[i], kc);
@@ -592,91 +663,112 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
 
   // =================== phase D: r through the chunk, forward reconstruction, statistics ============
   {
-    QAElem<D> tot;
+    QAElem<D> tot1, tot;
     {
-      const float* p = xbA + (size_t)(qi * 4 + q) * DK_EA;
-      Arr<QAElem<D>> a;
+      auto load_total = [&](int w) {
+        if (w >= nwact) return qa_identity<D>(q);
+        const float* p = xbA + (size_t)(w * 4 + q) * DK_EA;
+        Arr<QAElem<D>> a;
 #pragma unroll
-      for (int i = 0; i < EA; ++i) a.f[i] = p[i];
-      tot = __builtin_bit_cast(QAElem<D>, a);
+        for (int i = 0; i < EA; ++i) a.f[i] = p[i];
+        return __builtin_bit_cast(QAElem<D>, a);
+      };
+      tot1 = load_total(2 * qi + 1);
+      tot = qa_compose<D>(load_total(2 * qi), tot1, q);
     }
 #pragma unroll 1
     for (int off = 1; off < 16; off <<= 1) {
       const QAElem<D> o = q_shfl_down(tot, off);
       if (qi + off < 16) tot = qa_compose<D>(tot, o, q);
     }
-    prof.tick(26);
+    // r at every chunk's end: the maps of the wave's later chunks applied to what the later waves leave
+    float rsuf[D];
 #pragma unroll 1
     for (int v = v0; v < v0 + nv; ++v) {
-      const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
+      if (v >= nvact) continue;
+      const int wi = 4 * v + wave;
       if (park) {
         Arr<QAElem<D>> a;
 #pragma unroll
         for (int i = 0; i < EA; ++i) a.f[i] = *vslot(v, i);
         aex = __builtin_bit_cast(QAElem<D>, a);
+      }
+      // everything after wavefront wi: the pairs after its own, and for an even wi the odd total
+      QAElem<D> ws = q_shfl_from(tot, (wi >> 1) < 15 ? (wi >> 1) + 1 : 15, q);
+      if ((wi >> 1) == 15) ws = qa_identity<D>(q);
+      if (!(wi & 1)) ws = qa_compose<D>(q_shfl_from(tot1, wi >> 1, q), ws, q);
+      const QVec<D> wc = q_own<D>(ws.c, q);
 #pragma unroll
-        for (int i = 0; i < D; ++i) { xpre[i] = *vslot(v, EA + i); a0[i] = *vslot(v, EA + 8 + i); }
+      for (int i = 0; i < D; ++i) {
+        float p = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) p = fmaf(aex.M.m[h][i], wc.v[h], p);
+        rsuf[i] = aex.c[i] + q_sum(p);
+      }
+      if (park) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) *vslot(v, i) = rsuf[i];
+      }
+    }
+    prof.tick(26);
+#pragma unroll 1
+    for (int v = v0; v < v0 + nv; ++v) {
+      if (v >= nvact) continue;
+      const int c = 64 * v + (tid >> 2), t0 = c * Lc;
+      if (park) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) { rsuf[i] = *vslot(v, i); xpre[i] = *vslot(v, EA + i); a0[i] = *vslot(v, EA + 8 + i); }
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
           for (int i = 0; i < D; ++i) P0.m[h][i] = *vslot(v, EA + 16 + h * D + i);
-      }
-      // r at the chunk's end: the maps of the wave's later chunks applied to what the later waves leave
-      float rsuf[D];
-      {
-        QAElem<D> ws = q_shfl_from(tot, wi < 15 ? wi + 1 : 15, q);
-        if (wi == 15) ws = qa_identity<D>(q);
-        const QVec<D> wc = q_own<D>(ws.c, q);
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          float p = 0.f;
-#pragma unroll
-          for (int h = 0; h < H; ++h) p = fmaf(aex.M.m[h][i], wc.v[h], p);
-          rsuf[i] = aex.c[i] + q_sum(p);
-        }
       }
       // (5a) r through the chunk, backward; r_{t-1} takes the place of K_t
       {
         float r[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) r[i] = rsuf[i];
-#pragma unroll 1
-        for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
-          const int t4 = t0 + g4;
-          const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(x.msk + t4);
-          const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(x.cbv + t4);
-          // the block's four rows are requested before its stores
-          float4 ka[4], kb[4];
-          float vf4[4];
+        // The rows of a block are requested ONE BLOCK AHEAD; r_{t-1} then overwrites K_t in place.  No
+        // hazard: a row is stored after the step that consumed its loaded copy, and vmcnt returns in
+        // order -- every load of the block (issued by all four lanes in one instruction) has landed
+        // before the first of its stores is issued.
+        struct KR4 { float4 a[4], b[4]; float vf[4]; uint32_t mk, cb; };
+        auto load_kr = [&](int g4, KR4& o) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const float* kp = x.kr + ((size_t)(g4 + u) * NT + (c & 255)) * 8;
-            ka[u] = *reinterpret_cast<const float4*>(kp);
-            kb[u] = *reinterpret_cast<const float4*>(kp + 4);
-            vf4[u] = x.yv[(size_t)(g4 + u) * NT + (c & 255)];
+            const float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
+            o.a[u] = *reinterpret_cast<const float4*>(kp);
+            o.b[u] = *reinterpret_cast<const float4*>(kp + 4);
+            o.vf[u] = x.yv[(size_t)(g4 + u) * DK_CH + c];
           }
-          // every lane of the quad must have its rows before lanes 0 / 1 overwrite them
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
+          o.mk = *reinterpret_cast<const uint32_t*>(x.msk + t0 + g4);
+          o.cb = *reinterpret_cast<const uint32_t*>(x.cbv + t0 + g4);
+        };
+        KR4 nx;
+        load_kr(Lc - 4, nx);
+#pragma unroll 1
+        for (int g4 = Lc - 4; g4 >= 0; g4 -= 4) {
+          const KR4 cu = nx;
+          if (g4 >= 4) load_kr(g4 - 4, nx);
+          const uint32_t mk4 = cu.mk, cb4 = cu.cb;
 #pragma unroll
           for (int u = 3; u >= 0; --u) {
             const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
             const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
             qw_apply_t<TR, NS>(r, ch);
             if (obs) {
-              const float kf[8] = {ka[u].x, ka[u].y, ka[u].z, ka[u].w, kb[u].x, kb[u].y, kb[u].z, kb[u].w};
+              const float kf[8] = {cu.a[u].x, cu.a[u].y, cu.a[u].z, cu.a[u].w, cu.b[u].x, cu.b[u].y, cu.b[u].z, cu.b[u].w};
               float kr = 0.f;
 #pragma unroll
               for (int i = 0; i < D; ++i) kr = fmaf(kf[i], r[i], kr);
-              const float add = vf4[u] - kr;
+              const float add = cu.vf[u] - kr;
               r[0] += add;
               r[O] += add;
             }
             float r8[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) r8[i] = i < D ? r[i < D ? i : 0] : 0.f;
-            float* kp = x.kr + ((size_t)(g4 + u) * NT + (c & 255)) * 8;
+            float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
             if (q == 0) *reinterpret_cast<float4*>(kp) = make_float4(r8[0], r8[1], r8[2], r8[3]);
             if (q == 1) *reinterpret_cast<float4*>(kp + 4) = make_float4(r8[4], r8[5], r8[6], r8[7]);
           }
@@ -723,7 +815,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
           for (int u = 0; u < 4; ++u) {
             const int sidx = g4 + u + 1;          // r_t of step t = the row stored for step t + 1
             if (sidx < Lc) {
-              const float* kp = x.kr + ((size_t)sidx * NT + (c & 255)) * 8;
+              const float* kp = x.kr + ((size_t)sidx * DK_CH + c) * 8;
               ra[u] = *reinterpret_cast<const float4*>(kp);
               rb[u] = *reinterpret_cast<const float4*>(kp + 4);
             } else {
@@ -805,27 +897,32 @@ template <int TR, int NS>
 __device__ __forceinline__ void dk_stats(const float* xb, const uint8_t* cbv, int T, int Lc, int tid,
                                          float& ssl, float& sss, float& ssd) {
   constexpr int D = TR + NS - 1, O = TR;
-  const float* stat = xb + (size_t)DK_NWI * 4 * DK_EF + (size_t)DK_NWI * 4 * DK_EA + 256;
-  const float* sp = stat + (size_t)tid * DK_ST;
-  ssl = sp[0]; sss = sp[1]; ssd = sp[2];
-  const int t = tid * Lc + Lc - 1;
-  if (t + 1 < T) {
-    const float* sn = sp + DK_ST;
-    float xt[D], xn[D];
+  const float* stat = xb + (size_t)DK_NWI * 4 * DK_EF + (size_t)DK_NWI * 4 * DK_EA + 512;
+  ssl = 0.f; sss = 0.f; ssd = 0.f;
+#pragma unroll 1
+  for (int c = tid; c < DK_CH; c += NT) {
+    if (c * Lc >= T) break;                      // chunks past the end of the series were skipped
+    const float* sp = stat + (size_t)c * DK_ST;
+    ssl += sp[0]; sss += sp[1]; ssd += sp[2];
+    const int t = c * Lc + Lc - 1;
+    if (t + 1 < T) {
+      const float* sn = sp + DK_ST;
+      float xt[D], xn[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { xt[i] = sp[12 + i]; xn[i] = sn[4 + i]; }
-    float dl = xn[0] - xt[0];
-    if constexpr (TR == 2) {
-      dl -= xt[1];
-      const float ds = xn[1] - xt[1];
-      sss = fmaf(ds, ds, sss);
-    }
-    ssl = fmaf(dl, dl, ssl);
-    if (cbv[t] != 0) {
-      float w;
-      if constexpr (NS >= 3) w = (float)NS * (xt[O + 1] - xn[O]);
-      else w = -2.0f * (xn[O] + xt[O]);
-      ssd = fmaf(w, w, ssd);
+      for (int i = 0; i < D; ++i) { xt[i] = sp[12 + i]; xn[i] = sn[4 + i]; }
+      float dl = xn[0] - xt[0];
+      if constexpr (TR == 2) {
+        dl -= xt[1];
+        const float ds = xn[1] - xt[1];
+        sss = fmaf(ds, ds, sss);
+      }
+      ssl = fmaf(dl, dl, ssl);
+      if (cbv[t] != 0) {
+        float w;
+        if constexpr (NS >= 3) w = (float)NS * (xt[O + 1] - xn[O]);
+        else w = -2.0f * (xn[O] + xt[O]);
+        ssd = fmaf(w, w, ssd);
+      }
     }
   }
 }

@@ -116,6 +116,28 @@ __global__ __launch_bounds__(256) void k_quad(const float* in, float* out, float
   if (e1.b.v[0] == 1234.5f) out[0] = 1.f;
   if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = (t1 - t0) / reps; cyc[2 * blockIdx.x + 1] = ts; }
 }
+// one Kogge-Stone level inside a wavefront, as the kernel runs it: 60 ds_bpermutes + a masked combine
+template <int D>
+__global__ __launch_bounds__(256) void k_level(const float* in, float* out, long long* cyc, int reps) {
+  const int t = blockIdx.x * 256 + threadIdx.x, pair = t >> 2, q = t & 3, qi = (threadIdx.x & 63) >> 2;
+  QFElem<D> incl = load_quad<D>(in + (size_t)(2 * pair) * esz<D>(), q);
+  __syncthreads();
+  const long long t0 = clock64();
+  for (int i = 0; i < reps; ++i) {
+    const int off = 1 << (i & 3);
+    const QFElem<D> o = q_shfl_up(incl, off);
+    if (qi >= off) incl = qf_combine<D>(o, incl, q);
+  }
+  const long long t1 = clock64();
+  QFElem<D> sh = incl;
+  const long long t2 = clock64();
+  for (int i = 0; i < reps; ++i) sh = q_shfl_up(sh, 1 << (i & 3));
+  const long long t3 = clock64();
+  store_quad<D>(out + (size_t)pair * esz<D>(), incl, q);
+  if (sh.b.v[0] == 1234.5f) out[0] = 1.f;
+  if (threadIdx.x == 0) { cyc[0] = (t1 - t0) / reps; cyc[1] = (t3 - t2) / reps; }
+}
+
 // backward maps: pairs of (M, c)
 template <int D>
 __global__ __launch_bounds__(256) void k_amap(const float* in, float* out_one, float* out_quad, long long* cyc,
@@ -189,6 +211,16 @@ template <int D> void run() {
   hipDeviceSynchronize();
   long long c_quad[2];
   hipMemcpy(c_quad, cy, 16, hipMemcpyDeviceToHost);
+  {
+    hipLaunchKernelGGL(k_level<D>, dim3(1), dim3(256), 0, 0, din, oq, cy, 8);
+    hipDeviceSynchronize();
+    long long c2[2];
+    hipMemcpy(c2, cy, 16, hipMemcpyDeviceToHost);
+    printf("d=%d one scan level inside a wavefront (shuffle of the element + masked combine): %lld cycles; the shuffle alone %lld\n",
+           D, c2[0], c2[1]);
+    hipLaunchKernelGGL(k_quad<D>, dim3(NP * 4 / 256), dim3(256), 0, 0, din, oq, ot, cy, reps);
+    hipDeviceSynchronize();
+  }
   std::vector<float> a((size_t)NP * ES), b((size_t)NP * ES), tt((size_t)NP * D * D);
   hipMemcpy(a.data(), o1, a.size() * 4, hipMemcpyDeviceToHost);
   hipMemcpy(b.data(), oq, b.size() * 4, hipMemcpyDeviceToHost);

@@ -32,10 +32,11 @@ n = W + S
 names = {0: "(1) targets, X'targets, sums", 1: "(2) serial + regression block", 9: "   scale draws (wave 0)",
          10: "   regression block (workgroup)", 4: "     build A", 5: "     sweeps of the active set",
          6: "     flip proposals + sweeps", 7: "     Cholesky, solve, weights", 2: "(3) emit", 3: "(4) X w, residual",
-         20: "dk (1) prior simulation + scan", 21: "dk (2) y~, chunk filter elements",
-         22: "dk     filter scan (256 elements)", 23: "dk (3) local filter: gains",
-         24: "dk (4) backward chunk maps", 25: "dk     backward scan", 26: "dk (5a) r through the chunk",
-         27: "dk (5b) forward reconstruction"}
+         20: "dk A  prior simulation, in-wave scan", 21: "dk B  hand-over, x+ / y~, chunk elements",
+         22: "dk B  filter scan inside the wave", 23: "dk C  hand-over + scan of the 16 wave totals",
+         24: "dk C  prefix, local filter: gains", 25: "dk C  backward chunk maps",
+         26: "dk D  backward scans + hand-over", 27: "dk D  r through the chunk",
+         28: "dk D  forward reconstruction"}
 print(f"T={T} P={pb.P} chains={C}: {ms * 1e3 / n:.1f} us per iteration ({ms:.1f} ms per launch)")
 tot = 0
 for k in sorted(names):

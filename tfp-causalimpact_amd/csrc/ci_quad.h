@@ -47,57 +47,78 @@ __device__ __forceinline__ float q_sum(float x) {
 __device__ __forceinline__ float q_next(float x) { return q_dpp<0x39>(x); }   // quad_perm [1,2,3,0]
 
 // ---- column-split storage -----------------------------------------------------------------------
+// The H = ceil(d / 4) columns a lane owns are kept as ONE value per matrix row: a float for d <= 4, a
+// 2-vector for d <= 8 -- every row operation is then a packed instruction (v_pk_fma_f32 /
+// v_pk_add_f32 / v_pk_mul_f32: two columns per issue slot).
+typedef float qf2 __attribute__((ext_vector_type(2)));
+template <int H> struct QPk;
+template <> struct QPk<1> { typedef float T; };
+template <> struct QPk<2> { typedef qf2 T; };
+__device__ __forceinline__ float qp_get(float v, int) { return v; }
+__device__ __forceinline__ float qp_get(qf2 v, int h) { return h == 0 ? v.x : v.y; }
+__device__ __forceinline__ void qp_set(float& v, int, float x) { v = x; }
+__device__ __forceinline__ void qp_set(qf2& v, int h, float x) { if (h == 0) v.x = x; else v.y = x; }
+__device__ __forceinline__ float qp_hsum(float v) { return v; }
+__device__ __forceinline__ float qp_hsum(qf2 v) { return v.x + v.y; }
+template <class T> __device__ __forceinline__ T qp_splat(float x);
+template <> __device__ __forceinline__ float qp_splat<float>(float x) { return x; }
+template <> __device__ __forceinline__ qf2 qp_splat<qf2>(float x) { qf2 r = {x, x}; return r; }
+// per-lane pack: g(h) for every own slot
+template <class T, class F> __device__ __forceinline__ T qp_make(F g) {
+  T r = qp_splat<T>(0.f);
+#pragma unroll
+  for (int h = 0; h < (int)(sizeof(T) / 4); ++h) qp_set(r, h, g(h));
+  return r;
+}
+
 template <int D> struct QMat {
   static constexpr int H = (D + 3) / 4;
-  float m[H][D];          // m[h][i] = M[i][q + 4h]; columns >= D hold zeros
+  typedef typename QPk<H>::T T;
+  T r[D];                 // r[i] = (M[i][q], M[i][q + 4]); columns >= D hold zeros
 };
 template <int D> struct QVec {
   static constexpr int H = (D + 3) / 4;
-  float v[H];             // v[h] = x[q + 4h]
+  typedef typename QPk<H>::T T;
+  T v;                    // (x[q], x[q + 4])
 };
 template <int D> __device__ __forceinline__ QMat<D> qm_zero() {
-  QMat<D> r;
+  QMat<D> m;
 #pragma unroll
-  for (int h = 0; h < QMat<D>::H; ++h)
-#pragma unroll
-    for (int i = 0; i < D; ++i) r.m[h][i] = 0.f;
-  return r;
+  for (int i = 0; i < D; ++i) m.r[i] = qp_splat<typename QMat<D>::T>(0.f);
+  return m;
 }
 template <int D> __device__ __forceinline__ QMat<D> qm_eye(int q) {
-  QMat<D> r;
+  QMat<D> m;
 #pragma unroll
-  for (int h = 0; h < QMat<D>::H; ++h)
-#pragma unroll
-    for (int i = 0; i < D; ++i) r.m[h][i] = (q + 4 * h == i) ? 1.f : 0.f;
-  return r;
+  for (int i = 0; i < D; ++i)
+    m.r[i] = qp_make<typename QMat<D>::T>([&](int h) { return (q + 4 * h == i) ? 1.f : 0.f; });
+  return m;
 }
 template <int D> __device__ __forceinline__ QVec<D> qv_zero() {
-  QVec<D> r;
-#pragma unroll
-  for (int h = 0; h < QVec<D>::H; ++h) r.v[h] = 0.f;
-  return r;
+  QVec<D> x;
+  x.v = qp_splat<typename QVec<D>::T>(0.f);
+  return x;
 }
 // M[i][j] / x[k] wherever they live (i, j, k constants after unrolling)
 template <int D> __device__ __forceinline__ float q_at(const QMat<D>& M, int i, int j) {
-  return q_bc(M.m[j >> 2][i], j & 3);
+  return q_bc(qp_get(M.r[i], j >> 2), j & 3);
 }
 template <int D> __device__ __forceinline__ float q_vat(const QVec<D>& x, int k) {
-  return q_bc(x.v[k >> 2], k & 3);
+  return q_bc(qp_get(x.v, k >> 2), k & 3);
 }
 // a replicated vector -> its own entries (lane-dependent index: a select chain)
 template <int D> __device__ __forceinline__ QVec<D> q_own(const float (&rep)[D], int q) {
-  QVec<D> r;
-#pragma unroll
-  for (int h = 0; h < QVec<D>::H; ++h) {
-    float s = (4 * h < D) ? rep[4 * h] : 0.f;
+  QVec<D> x;
+  x.v = qp_make<typename QVec<D>::T>([&](int h) {
+    float s = (4 * h < D) ? rep[(4 * h < D) ? 4 * h : 0] : 0.f;
 #pragma unroll
     for (int k = 1; k < 4; ++k) {
       const float c = (4 * h + k < D) ? rep[(4 * h + k < D) ? 4 * h + k : 0] : 0.f;
       s = (q == k) ? c : s;
     }
-    r.v[h] = s;
-  }
-  return r;
+    return s;
+  });
+  return x;
 }
 template <int D> __device__ __forceinline__ void q_rep(const QVec<D>& x, float (&rep)[D]) {
 #pragma unroll
@@ -107,30 +128,22 @@ template <int D> __device__ __forceinline__ void q_rep(const QVec<D>& x, float (
 // R = X Y + R0:  X foreign (any column-split matrix), Y and R0 local
 template <int D>
 __device__ __forceinline__ QMat<D> q_mm_add(const QMat<D>& X, const QMat<D>& Y, const QMat<D>& R0) {
-  QMat<D> r = R0;
+  QMat<D> m = R0;
 #pragma unroll
   for (int k = 0; k < D; ++k)
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      const float f = q_at(X, i, k);
-#pragma unroll
-      for (int h = 0; h < QMat<D>::H; ++h) r.m[h][i] = fmaf(f, Y.m[h][k], r.m[h][i]);
-    }
-  return r;
+    for (int i = 0; i < D; ++i) m.r[i] = q_at(X, i, k) * Y.r[k] + m.r[i];
+  return m;
 }
 // R = X' Y + R0:  X foreign, read transposed
 template <int D>
 __device__ __forceinline__ QMat<D> q_mtm_add(const QMat<D>& X, const QMat<D>& Y, const QMat<D>& R0) {
-  QMat<D> r = R0;
+  QMat<D> m = R0;
 #pragma unroll
   for (int k = 0; k < D; ++k)
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      const float f = q_at(X, k, i);
-#pragma unroll
-      for (int h = 0; h < QMat<D>::H; ++h) r.m[h][i] = fmaf(f, Y.m[h][k], r.m[h][i]);
-    }
-  return r;
+    for (int i = 0; i < D; ++i) m.r[i] = q_at(X, k, i) * Y.r[k] + m.r[i];
+  return m;
 }
 
 // Transpose inside the quad: K(M) -> K(M').  4 x 4 blocks through two butterfly stages (partner
@@ -152,7 +165,7 @@ __device__ __forceinline__ void q_transpose4(float (&x)[4], int q) {
 }
 template <int D> __device__ __forceinline__ QMat<D> q_transpose(const QMat<D>& M, int q) {
   constexpr int H = QMat<D>::H;
-  QMat<D> r = qm_zero<D>();
+  QMat<D> m = qm_zero<D>();
 #pragma unroll
   for (int rb = 0; rb < H; ++rb)
 #pragma unroll
@@ -160,14 +173,14 @@ template <int D> __device__ __forceinline__ QMat<D> q_transpose(const QMat<D>& M
       // block of rows 4 rb .. 4 rb + 3, columns 4 cb .. 4 cb + 3: lane q holds its column 4 cb + q
       float x[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) x[c] = (4 * rb + c < D) ? M.m[cb][(4 * rb + c < D) ? 4 * rb + c : 0] : 0.f;
+      for (int c = 0; c < 4; ++c) x[c] = (4 * rb + c < D) ? qp_get(M.r[(4 * rb + c < D) ? 4 * rb + c : 0], cb) : 0.f;
       q_transpose4(x, q);
       // now x[c] = M[4 rb + q][4 cb + c] = M'[4 cb + c][4 rb + q]: column 4 rb + q of M', rows 4 cb + c
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (4 * cb + c < D) r.m[rb][4 * cb + c] = x[c];
+        if (4 * cb + c < D) qp_set(m.r[4 * cb + c], rb, x[c]);
     }
-  return r;
+  return m;
 }
 
 // ---- filtering element (Sarkka & Garcia-Fernandez 2021), quad-split ----------------------------
@@ -184,19 +197,15 @@ template <int D> __device__ __forceinline__ QFElem<D> qf_identity(int q) {
 // e1 covers the earlier steps, e2 the later ones (felems_combine of ci_linalg.h, same formulas):
 //   W = I + C1 J2;  G = W^-1 A1, Y = W^-1 C1, z = W^-1 (b1 + C1 eta2)   (one Gauss-Jordan, no pivoting)
 //   A = A2 G;  b = A2 z + b2;  C = A2 Y A2' + C2;  eta = G'(eta2 - J2 b1) + eta1;  J = G' J2 A1 + J1
-// STATE_ONLY: only b and C of the result (the predicted moments at a chunk start).
+// STATE_ONLY: only b and C of the result (the predicted moments at a chunk start); of e1 only b and
+// C are read then.
 template <int D, bool STATE_ONLY = false>
 __device__ __forceinline__ QFElem<D> qf_combine(const QFElem<D>& e1, const QFElem<D>& e2, int q) {
-  constexpr int H = QMat<D>::H;
   QMat<D> W = q_mm_add(e1.C, e2.J, qm_eye<D>(q));
   QMat<D> G = e1.A, Y = e1.C;
   QVec<D> u = e1.b;
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    const float f = q_vat(e2.eta, k);
-#pragma unroll
-    for (int h = 0; h < H; ++h) u.v[h] = fmaf(e1.C.m[h][k], f, u.v[h]);     // C1[own][k] = C1[k][own]
-  }
+  for (int k = 0; k < D; ++k) u.v = e1.C.r[k] * q_vat(e2.eta, k) + u.v;      // C1[own][k] = C1[k][own]
   float z[D];
   q_rep(u, z);
   QMat<D> T2;
@@ -204,73 +213,49 @@ __device__ __forceinline__ QFElem<D> qf_combine(const QFElem<D>& e1, const QFEle
   if constexpr (!STATE_ONLY) {
     T2 = q_mm_add(e2.J, e1.A, qm_zero<D>());                               // J2 A1
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const float f = q_vat(e1.b, k);
-#pragma unroll
-      for (int h = 0; h < H; ++h) w.v[h] = fmaf(-e2.J.m[h][k], f, w.v[h]);  // eta2 - J2 b1
-    }
+    for (int k = 0; k < D; ++k) w.v = e2.J.r[k] * (-q_vat(e1.b, k)) + w.v;     // eta2 - J2 b1
   }
   // Gauss-Jordan on the columns each lane owns; the multipliers W[r][c] come from the owner of
   // column c (read before that lane's own update of the same register)
 #pragma unroll
   for (int c = 0; c < D; ++c) {
     const float rp = __builtin_amdgcn_rcpf(q_at(W, c, c));
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      W.m[h][c] *= rp;
-      if constexpr (!STATE_ONLY) G.m[h][c] *= rp;
-      Y.m[h][c] *= rp;
-    }
+    W.r[c] = W.r[c] * rp;
+    if constexpr (!STATE_ONLY) G.r[c] = G.r[c] * rp;
+    Y.r[c] = Y.r[c] * rp;
     z[c] *= rp;
 #pragma unroll
     for (int r = 0; r < D; ++r) {
       if (r == c) continue;
-      const float f = q_at(W, r, c);
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        W.m[h][r] = fmaf(-f, W.m[h][c], W.m[h][r]);
-        if constexpr (!STATE_ONLY) G.m[h][r] = fmaf(-f, G.m[h][c], G.m[h][r]);
-        Y.m[h][r] = fmaf(-f, Y.m[h][c], Y.m[h][r]);
-      }
-      z[r] = fmaf(-f, z[c], z[r]);
+      const float f = -q_at(W, r, c);
+      W.r[r] = f * W.r[c] + W.r[r];
+      if constexpr (!STATE_ONLY) G.r[r] = f * G.r[c] + G.r[r];
+      Y.r[r] = f * Y.r[c] + Y.r[r];
+      z[r] = fmaf(f, z[c], z[r]);
     }
   }
-  QFElem<D> r;
+  QFElem<D> e;
   // b = A2 z + b2 (own rows of A2 = columns of A2')
-  r.b = e2.b;
+  e.b = e2.b;
 #pragma unroll
-  for (int k = 0; k < D; ++k)
-#pragma unroll
-    for (int h = 0; h < H; ++h) r.b.v[h] = fmaf(e2.AT.m[h][k], z[k], r.b.v[h]);
+  for (int k = 0; k < D; ++k) e.b.v = e2.AT.r[k] * z[k] + e.b.v;
   // C = (A2 Y) A2' + C2:  column j own needs row j of A2 = column j of A2'
   {
     const QMat<D> T1 = q_mm_add(e2.A, Y, qm_zero<D>());
-    r.C = q_mm_add(T1, e2.AT, e2.C);
+    e.C = q_mm_add(T1, e2.AT, e2.C);
   }
   if constexpr (STATE_ONLY) {
-    r.A = e2.A; r.AT = e2.AT; r.J = e2.J; r.eta = e2.eta;
-    return r;
+    e.A = e2.A; e.AT = e2.AT; e.J = e2.J; e.eta = e2.eta;
+    return e;
   }
-  r.A = q_mm_add(e2.A, G, qm_zero<D>());                // A2 G
+  e.A = q_mm_add(e2.A, G, qm_zero<D>());                // A2 G
   // K(A') : A'[i][j] = A[j][i] = sum_k A2[j][k] G[k][i], j own
-  r.AT = qm_zero<D>();
+  e.AT = q_mtm_add(G, e2.AT, qm_zero<D>());
+  e.J = q_mtm_add(G, T2, e1.J);                         // G' (J2 A1) + J1
+  e.eta = e1.eta;
 #pragma unroll
-  for (int k = 0; k < D; ++k)
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      const float f = q_at(G, k, i);
-#pragma unroll
-      for (int h = 0; h < H; ++h) r.AT.m[h][i] = fmaf(f, e2.AT.m[h][k], r.AT.m[h][i]);
-    }
-  r.J = q_mtm_add(G, T2, e1.J);                         // G' (J2 A1) + J1
-  r.eta = e1.eta;
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    const float f = q_vat(w, k);
-#pragma unroll
-    for (int h = 0; h < H; ++h) r.eta.v[h] = fmaf(G.m[h][k], f, r.eta.v[h]);   // G[k][own]
-  }
-  return r;
+  for (int k = 0; k < D; ++k) e.eta.v = G.r[k] * q_vat(w, k) + e.eta.v;   // G[k][own]
+  return e;
 }
 
 // ---- backward affine map r_in = M r_out + c, quad-split (M by columns, c on every lane) ----------
@@ -285,37 +270,37 @@ template <int D> __device__ __forceinline__ QAElem<D> qa_identity(int q) {
   for (int i = 0; i < D; ++i) e.c[i] = 0.f;
   return e;
 }
+// M x for a replicated x: every lane adds its own columns' share, the quad sums
+template <int D>
+__device__ __forceinline__ void q_mv_acc(const QMat<D>& M, const float (&xr)[D], int q, float (&acc)[D]) {
+  const QVec<D> xo = q_own<D>(xr, q);
+#pragma unroll
+  for (int i = 0; i < D; ++i) acc[i] += q_sum(qp_hsum(M.r[i] * xo.v));
+}
 // (outer o inner)(r) = outer.M (inner.M r + inner.c) + outer.c
 template <int D>
 __device__ __forceinline__ QAElem<D> qa_compose(const QAElem<D>& outer, const QAElem<D>& inner, int q) {
-  constexpr int H = QMat<D>::H;
-  QAElem<D> r;
-  r.M = q_mm_add(outer.M, inner.M, qm_zero<D>());
-  const QVec<D> ci = q_own<D>(inner.c, q);
+  QAElem<D> e;
+  e.M = q_mm_add(outer.M, inner.M, qm_zero<D>());
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    float p = 0.f;
-#pragma unroll
-    for (int h = 0; h < H; ++h) p = fmaf(outer.M.m[h][i], ci.v[h], p);   // own columns' share of row i
-    r.c[i] = outer.c[i] + q_sum(p);
-  }
-  return r;
+  for (int i = 0; i < D; ++i) e.c[i] = outer.c[i];
+  q_mv_acc(outer.M, inner.c, q, e.c);
+  return e;
 }
 
 // ---- conversions between one-lane and quad-split elements (tests, prior element) -----------------
 template <int D> __device__ __forceinline__ QMat<D> qm_from(const Mat<D>& M, int q) {
-  QMat<D> r;
+  QMat<D> m;
 #pragma unroll
-  for (int h = 0; h < QMat<D>::H; ++h)
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
+  for (int i = 0; i < D; ++i)
+    m.r[i] = qp_make<typename QMat<D>::T>([&](int h) {
       float s = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (4 * h + k < D) s = (q == k) ? M.m[i][4 * h + k] : s;
-      r.m[h][i] = s;
-    }
-  return r;
+      return s;
+    });
+  return m;
 }
 
 // Every float of a struct moved between lanes: ONE source address per lane, then the ds_bpermutes

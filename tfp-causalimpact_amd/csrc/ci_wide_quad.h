@@ -61,23 +61,23 @@ __device__ __forceinline__ void dk_barrier(DkSync& s, int tid) {
 }
 
 // ---- the transition on a d-vector held in registers (w_apply / w_apply_t of ci_wide.h on arrays) --
-template <int TR, int NS> __device__ __forceinline__ void qw_apply(float (&x)[TR + NS - 1], bool ch) {
+template <int TR, int NS, class E> __device__ __forceinline__ void qw_apply(E (&x)[TR + NS - 1], bool ch) {
   constexpr int O = TR, N1 = NS - 1;
   if constexpr (TR == 2) x[0] += x[1];
   if (ch) {
-    float s = 0.f;
+    E s = x[O];
 #pragma unroll
-    for (int i = 0; i < N1; ++i) s += x[O + i];
+    for (int i = 1; i < N1; ++i) s += x[O + i];
 #pragma unroll
     for (int i = 0; i + 1 < N1; ++i) x[O + i] = x[O + i + 1];
     x[O + N1 - 1] = -s;
   }
 }
-template <int TR, int NS> __device__ __forceinline__ void qw_apply_t(float (&x)[TR + NS - 1], bool ch) {
+template <int TR, int NS, class E> __device__ __forceinline__ void qw_apply_t(E (&x)[TR + NS - 1], bool ch) {
   constexpr int O = TR, N1 = NS - 1;
   if constexpr (TR == 2) x[1] += x[0];
   if (ch) {
-    const float last = x[O + N1 - 1];
+    const E last = x[O + N1 - 1];
 #pragma unroll
     for (int j = N1 - 1; j >= 1; --j) x[O + j] = x[O + j - 1] - last;
     x[O] = -last;
@@ -87,8 +87,8 @@ template <int TR, int NS> __device__ __forceinline__ void qw_apply_t(float (&x)[
 // per-lane constants of the covariance prediction
 template <int D> struct QScal {
   static constexpr int H = (D + 3) / 4;
-  float ql0, qs1;          // ql on the lane that owns column 0 (else 0), qs on the owner of column 1
-  float qd_own[H];         // qd where the own column is a seasonal one
+  typename QPk<H>::T qd_own;   // qd where the own column is a seasonal one
+  typename QPk<H>::T ql_own, qs_own;   // ql at (row 0, column 0), qs at (row 1, column 1): on their owners' first slot
   bool keep0;              // slot 0 holds a trend column (does not move in the seasonal shift)
   bool inject;             // this lane's last slot is "column D": receives minus the row sums before the shift
   bool last_own;           // (d % 4 == 0) this lane's last slot is column D - 1
@@ -97,10 +97,10 @@ template <int TR, int NS>
 __device__ __forceinline__ QScal<TR + NS - 1> make_qscal(const WideScal& sc, int q) {
   constexpr int D = TR + NS - 1, O = TR, H = (D + 3) / 4;
   QScal<D> s;
-  s.ql0 = q == 0 ? sc.ql : 0.f;
-  s.qs1 = (TR == 2 && q == 1) ? sc.qs : 0.f;
-#pragma unroll
-  for (int h = 0; h < H; ++h) s.qd_own[h] = (q + 4 * h >= O && q + 4 * h < D) ? sc.qd : 0.f;
+  typedef typename QPk<H>::T PT;
+  s.ql_own = qp_make<PT>([&](int h) { return (h == 0 && q == 0) ? sc.ql : 0.f; });
+  s.qs_own = qp_make<PT>([&](int h) { return (TR == 2 && h == 0 && q == 1) ? sc.qs : 0.f; });
+  s.qd_own = qp_make<PT>([&](int h) { return (q + 4 * h >= O && q + 4 * h < D) ? sc.qd : 0.f; });
   s.keep0 = q < O;
   s.inject = (D % 4 != 0) && q == (D & 3);
   s.last_own = (D % 4 == 0) && q == 3;
@@ -116,26 +116,22 @@ template <int TR, int NS>
 __device__ __forceinline__ void qc_predict(QMat<TR + NS - 1>& C, bool ch, const QScal<TR + NS - 1>& qs,
                                            int q) {
   constexpr int D = TR + NS - 1, O = TR, H = (D + 3) / 4;
+  typedef typename QPk<H>::T PT;
   float rs[D];
   if (ch) {
     QVec<D> cs;
+    cs.v = C.r[O];
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      float s = 0.f;
-#pragma unroll
-      for (int r = O; r < D; ++r) s += C.m[h][r];
-      cs.v[h] = s;
-    }
+    for (int r = O + 1; r < D; ++r) cs.v += C.r[r];
     q_rep(cs, rs);
     qw_apply<TR, NS>(rs, true);
   }
-#pragma unroll
-  for (int h = 0; h < H; ++h) qw_apply<TR, NS>(C.m[h], ch);
+  qw_apply<TR, NS>(C.r, ch);
   if constexpr (TR == 2) {
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      const float t = q_bc(C.m[0][i], 1);
-      C.m[0][i] += (q == 0) ? t : 0.f;
+      const float t = q_bc(qp_get(C.r[i], 0), 1);
+      qp_set(C.r[i], 0, qp_get(C.r[i], 0) + ((q == 0) ? t : 0.f));
     }
   }
   if (ch) {
@@ -143,7 +139,7 @@ __device__ __forceinline__ void qc_predict(QMat<TR + NS - 1>& C, bool ch, const 
     for (int i = 0; i < D; ++i) {
       float v[H + 1], n[H + 1];
 #pragma unroll
-      for (int h = 0; h < H; ++h) v[h] = C.m[h][i];
+      for (int h = 0; h < H; ++h) v[h] = qp_get(C.r[i], h);
       if constexpr (D % 4 != 0) v[H - 1] = qs.inject ? -rs[i] : v[H - 1];
 #pragma unroll
       for (int h = 0; h < H; ++h) n[h] = q_next(v[h]);
@@ -153,16 +149,14 @@ __device__ __forceinline__ void qc_predict(QMat<TR + NS - 1>& C, bool ch, const 
         float take = (q == 3) ? n[h + 1] : n[h];
         if constexpr (D % 4 == 0)
           if (h == H - 1) take = qs.last_own ? -rs[i] : take;
-        C.m[h][i] = (h == 0 && qs.keep0) ? C.m[h][i] : take;
+        qp_set(C.r[i], h, (h == 0 && qs.keep0) ? qp_get(C.r[i], h) : take);
       }
     }
 #pragma unroll
-    for (int h = 0; h < H; ++h)
-#pragma unroll
-      for (int i = O; i < D; ++i) C.m[h][i] += qs.qd_own[h];
+    for (int i = O; i < D; ++i) C.r[i] += qs.qd_own;
   }
-  C.m[0][0] += qs.ql0;
-  if constexpr (TR == 2) C.m[0][1] += qs.qs1;
+  C.r[0] += qs.ql_own;
+  if constexpr (TR == 2) C.r[1] += qs.qs_own;
 }
 
 // ---- everything one chain's draw needs ------------------------------------------------------------
@@ -241,17 +235,15 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
       m1[i] = s;
     }
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const int j = q + 4 * h;
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
+    for (int i = 0; i < D; ++i)
+      P1.r[i] = qp_make<typename QMat<D>::T>([&](int h) {
+        const int j = q + 4 * h;
         float p = 0.f;
         if (i == 0 && j == 0) p = x.p1l;
         if (TR == 2 && i == 1 && j == 1) p = x.p1s;
         if (i >= O && j >= O && j < D) p = x.p1e * ((i == j ? 1.f : 0.f) - 1.f / (float)NS);
-        P1.m[h][i] = p;
-      }
-    }
+        return p;
+      });
   };
 
   // per-virtual-workgroup state that lives in registers when nv == 1
@@ -382,8 +374,8 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
           if (obs) {
             // fold y~_t into (A, b, C, eta, J)
             QVec<D> za, cz;
-#pragma unroll
-            for (int h = 0; h < H; ++h) { za.v[h] = A.m[h][0] + A.m[h][O]; cz.v[h] = C.m[h][0] + C.m[h][O]; }
+            za.v = A.r[0] + A.r[O];
+            cz.v = C.r[0] + C.r[O];
             float zar[D], czr[D];
             q_rep(za, zar);
             q_rep(cz, czr);
@@ -395,18 +387,14 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
             for (int i = 0; i < D; ++i) {
               eta[i] = fmaf(zar[i], e, eta[i]);
               b[i] = fmaf(czr[i], e, b[i]);
-              const float ki = czr[i] * rS, zi = zar[i] * rS;
-#pragma unroll
-              for (int h = 0; h < H; ++h) {
-                A.m[h][i] = fmaf(-ki, za.v[h], A.m[h][i]);
-                J.m[h][i] = fmaf(zi, za.v[h], J.m[h][i]);
-                C.m[h][i] = fmaf(-ki, cz.v[h], C.m[h][i]);
-              }
+              const float ki = -(czr[i] * rS), zi = zar[i] * rS;
+              A.r[i] = ki * za.v + A.r[i];
+              J.r[i] = zi * za.v + J.r[i];
+              C.r[i] = ki * cz.v + C.r[i];
             }
           }
           // time update t -> t + 1
-#pragma unroll
-          for (int h = 0; h < H; ++h) qw_apply<TR, NS>(A.m[h], ch);
+          qw_apply<TR, NS>(A.r, ch);
           qw_apply<TR, NS>(b, ch);
           qc_predict<TR, NS>(C, ch, qs, q);
           xplus_step(xp, ch, zl, zs, zk);
@@ -501,7 +489,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
-          for (int i = 0; i < D; ++i) *vslot(v, 8 + h * D + i) = P0.m[h][i];
+          for (int i = 0; i < D; ++i) *vslot(v, 8 + h * D + i) = qp_get(P0.r[i], h);
       }
     }
     prof.tick(23);
@@ -515,7 +503,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
-          for (int i = 0; i < D; ++i) P0.m[h][i] = *vslot(v, 8 + h * D + i);
+          for (int i = 0; i < D; ++i) qp_set(P0.r[i], h, *vslot(v, 8 + h * D + i));
       }
       // local Kalman filter from the predicted moments at the chunk start: K_t, v_t / F_t
       {
@@ -552,8 +540,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
             for (int i = 0; i < 8; ++i) kf[i] = 0.f;
             if (obs) {
               QVec<D> pz;
-#pragma unroll
-              for (int h = 0; h < H; ++h) pz.v[h] = Pc.m[h][0] + Pc.m[h][O];
+              pz.v = Pc.r[0] + Pc.r[O];
               float pzr[D];
               q_rep(pz, pzr);
               const float Fv = pzr[0] + pzr[O] + sc.H;
@@ -564,8 +551,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
               for (int i = 0; i < D; ++i) {
                 kf[i] = pzr[i] * rF;
                 am[i] = fmaf(kf[i], vv, am[i]);
-#pragma unroll
-                for (int h = 0; h < H; ++h) Pc.m[h][i] = fmaf(-(pzr[i] * pz.v[h]), rF, Pc.m[h][i]);
+                Pc.r[i] = (pz.v * (-pzr[i])) * rF + Pc.r[i];
               }
             }
             float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
@@ -607,8 +593,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
         for (int u = 3; u >= 0; --u) {
           const bool obs = ((mk4 >> (8 * u)) & 0xFFu) == 0u;
           const bool ch = ((cb4 >> (8 * u)) & 0xFFu) != 0u;
-#pragma unroll
-          for (int h = 0; h < H; ++h) qw_apply_t<TR, NS>(ae.M.m[h], ch);
+          qw_apply_t<TR, NS>(ae.M.r, ch);
           qw_apply_t<TR, NS>(ae.c, ch);
           if (obs) {
             const float kf[8] = {cur.a[u].x, cur.a[u].y, cur.a[u].z, cur.a[u].w,
@@ -620,13 +605,12 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
             const float add = vf - kc;
             ae.c[0] += add;
             ae.c[O] += add;
+            {
+              typename QMat<D>::T kr = ae.M.r[0] * kf[0];
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-              float kr = 0.f;
-#pragma unroll
-              for (int i = 0; i < D; ++i) kr = fmaf(kf[i], ae.M.m[h][i], kr);
-              ae.M.m[h][0] -= kr;
-              ae.M.m[h][O] -= kr;
+              for (int i = 1; i < D; ++i) kr = ae.M.r[i] * kf[i] + kr;
+              ae.M.r[0] -= kr;
+              ae.M.r[O] -= kr;
             }
           }
         }
@@ -655,7 +639,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
-          for (int i = 0; i < D; ++i) *vslot(v, EA + 16 + h * D + i) = P0.m[h][i];
+          for (int i = 0; i < D; ++i) *vslot(v, EA + 16 + h * D + i) = qp_get(P0.r[i], h);
       }
     }
   }
@@ -697,14 +681,9 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
       QAElem<D> ws = q_shfl_from(tot, (wi >> 1) < 15 ? (wi >> 1) + 1 : 15, q);
       if ((wi >> 1) == 15) ws = qa_identity<D>(q);
       if (!(wi & 1)) ws = qa_compose<D>(q_shfl_from(tot1, wi >> 1, q), ws, q);
-      const QVec<D> wc = q_own<D>(ws.c, q);
 #pragma unroll
-      for (int i = 0; i < D; ++i) {
-        float p = 0.f;
-#pragma unroll
-        for (int h = 0; h < H; ++h) p = fmaf(aex.M.m[h][i], wc.v[h], p);
-        rsuf[i] = aex.c[i] + q_sum(p);
-      }
+      for (int i = 0; i < D; ++i) rsuf[i] = aex.c[i];
+      q_mv_acc(aex.M, ws.c, q, rsuf);
       if (park) {
 #pragma unroll
         for (int i = 0; i < D; ++i) *vslot(v, i) = rsuf[i];
@@ -721,7 +700,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
-          for (int i = 0; i < D; ++i) P0.m[h][i] = *vslot(v, EA + 16 + h * D + i);
+          for (int i = 0; i < D; ++i) qp_set(P0.r[i], h, *vslot(v, EA + 16 + h * D + i));
       }
       // (5a) r through the chunk, backward; r_{t-1} takes the place of K_t
       {
@@ -774,14 +753,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
           }
         }
         // x^ at the chunk start: a + P r_{t0 - 1}
-        const QVec<D> ro = q_own<D>(r, q);
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          float p = 0.f;
-#pragma unroll
-          for (int h = 0; h < H; ++h) p = fmaf(P0.m[h][i], ro.v[h], p);
-          a0[i] += q_sum(p);
-        }
+        q_mv_acc(P0, r, q, a0);
       }
       prof.tick(27);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

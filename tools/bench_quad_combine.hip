@@ -48,13 +48,13 @@ template <int D> __device__ QFElem<D> load_quad(const float* p, int q) {
   for (int h = 0; h < H; ++h) {
     const int j = q + 4 * h;
     for (int i = 0; i < D; ++i) {
-      e.A.m[h][i] = j < D ? p[i * D + j] : 0.f;
-      e.AT.m[h][i] = j < D ? p[j * D + i] : 0.f;
-      e.C.m[h][i] = j < D ? p[D * D + D + i * D + j] : 0.f;
-      e.J.m[h][i] = j < D ? p[2 * D * D + 2 * D + i * D + j] : 0.f;
+      qp_set(e.A.r[i], h, j < D ? p[i * D + j] : 0.f);
+      qp_set(e.AT.r[i], h, j < D ? p[j * D + i] : 0.f);
+      qp_set(e.C.r[i], h, j < D ? p[D * D + D + i * D + j] : 0.f);
+      qp_set(e.J.r[i], h, j < D ? p[2 * D * D + 2 * D + i * D + j] : 0.f);
     }
-    e.b.v[h] = j < D ? p[D * D + j] : 0.f;
-    e.eta.v[h] = j < D ? p[2 * D * D + D + j] : 0.f;
+    qp_set(e.b.v, h, j < D ? p[D * D + j] : 0.f);
+    qp_set(e.eta.v, h, j < D ? p[2 * D * D + D + j] : 0.f);
   }
   return e;
 }
@@ -64,12 +64,12 @@ template <int D> __device__ void store_quad(float* p, const QFElem<D>& e, int q)
     const int j = q + 4 * h;
     if (j >= D) continue;
     for (int i = 0; i < D; ++i) {
-      p[i * D + j] = e.A.m[h][i];
-      p[D * D + D + i * D + j] = e.C.m[h][i];
-      p[2 * D * D + 2 * D + i * D + j] = e.J.m[h][i];
+      p[i * D + j] = qp_get(e.A.r[i], h);
+      p[D * D + D + i * D + j] = qp_get(e.C.r[i], h);
+      p[2 * D * D + 2 * D + i * D + j] = qp_get(e.J.r[i], h);
     }
-    p[D * D + j] = e.b.v[h];
-    p[2 * D * D + D + j] = e.eta.v[h];
+    p[D * D + j] = qp_get(e.b.v, h);
+    p[2 * D * D + D + j] = qp_get(e.eta.v, h);
   }
 }
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_quad(const float* in, float* out, float
     const QMat<D> tr = q_transpose(r.A, q);
     for (int h = 0; h < QMat<D>::H; ++h)
       for (int i = 0; i < D; ++i)
-        if (q + 4 * h < D) out_t[(size_t)pair * D * D + (q + 4 * h) * D + i] = tr.m[h][i] - r.AT.m[h][i];
+        if (q + 4 * h < D) out_t[(size_t)pair * D * D + (q + 4 * h) * D + i] = qp_get(tr.r[i], h) - qp_get(r.AT.r[i], h);
   }
   __syncthreads();
   const long long t0 = clock64();
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_quad(const float* in, float* out, float
     for (int i = 0; i < reps; ++i) e1 = qf_combine<D, true>(e1, e2, q);
     ts = (clock64() - a) / reps;
   }
-  if (e1.b.v[0] == 1234.5f) out[0] = 1.f;
+  if (qp_get(e1.b.v, 0) == 1234.5f) out[0] = 1.f;
   if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = (t1 - t0) / reps; cyc[2 * blockIdx.x + 1] = ts; }
 }
 // one Kogge-Stone level inside a wavefront, as the kernel runs it: 60 ds_bpermutes + a masked combine
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_level(const float* in, float* out, long
   for (int i = 0; i < reps; ++i) sh = q_shfl_up(sh, 1 << (i & 3));
   const long long t3 = clock64();
   store_quad<D>(out + (size_t)pair * esz<D>(), incl, q);
-  if (sh.b.v[0] == 1234.5f) out[0] = 1.f;
+  if (qp_get(sh.b.v, 0) == 1234.5f) out[0] = 1.f;
   if (threadIdx.x == 0) { cyc[0] = (t1 - t0) / reps; cyc[1] = (t3 - t2) / reps; }
 }
 
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_amap(const float* in, float* out_one, f
     }
   for (int h = 0; h < QMat<D>::H; ++h)
     for (int i = 0; i < D; ++i)
-      if (q + 4 * h < D) out_quad[(size_t)pair * AS + i * D + q + 4 * h] = rq.M.m[h][i];
+      if (q + 4 * h < D) out_quad[(size_t)pair * AS + i * D + q + 4 * h] = qp_get(rq.M.r[i], h);
   __syncthreads();
   const long long t0 = clock64();
   for (int i = 0; i < reps; ++i) rq = qa_compose(rq, q2, q);

@@ -389,8 +389,11 @@ __device__ __forceinline__ void cl_wait(int* flags, int n, int value, int tid) {
   }
   __syncthreads();
 }
-constexpr int CL_INTS = 64;              // handshake counters per chain
-enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_MODE = 2, CL_V = 3, CL_DK = 4, CL_PARTIAL = 16, CL_XW = 32, CL_XCC = 48 };   // + role (< 16)
+constexpr int CL_INTS = 160;             // handshake ints per chain, in 128-byte lines by who polls what
+// line 0: flags (written once per iteration, polled by many); line 1: per-role flags; line 2: check-in
+// slots (start only); line 3: arrival counters (atomic adds, never polled); line 4: the DK barrier's flag
+enum ClusterFlag { CL_LATENTS = 0, CL_WEIGHTS = 1, CL_MODE = 2, CL_V = 3, CL_SCALES = 5, CL_PARTIAL = 32, CL_XW = 48,
+                   CL_XCC = 64, CL_DK = 96, CL_LATCNT = 97, CL_DKFLAG = 128 };   // PARTIAL / XW / XCC + role (< 16)
 // Assembling a cluster.  The handshakes below spin, so a cluster may only run when ALL its
 // workgroups are resident -- which the host sizes the launch for, but cannot guarantee (another
 // stream or process may hold CUs).  So the cluster is agreed on at the start, with time-outs:
@@ -528,9 +531,15 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   // workgroup -- beats four in the draw plus the sweeper, 4 x 2 virtual workgroups: the draw is the
   // longer pole)
   const int Gd = G >= DK_V ? DK_V : G;
-  const int sweep_role = G == 16 ? 8 : -1;
+  const int sweep_role = G == 16 ? 9 : -1;
+  // with sixteen workgroups main is NOT a DK worker (roles 1..8 are): the draw's first phase needs the
+  // disturbance scales only and runs on them while main is still in the regression block
+  const int dw0 = G == 16 ? 1 : 0;
+  const bool dk_worker = role >= dw0 && role < dw0 + Gd;
+  const bool early_a = G == 16;
   DkSync dsy;
-  dsy.cnt = csync + CL_DK; dsy.Gd = Gd; dsy.epoch = 0; dsy.cluster = Gd > 1; dsy.light = light;
+  dsy.cnt = csync + CL_DK; dsy.flag = csync + CL_DKFLAG; dsy.latcnt = csync + CL_LATCNT; dsy.latflag = csync + CL_LATENTS;
+  dsy.Gd = Gd; dsy.epoch = 0; dsy.cluster = G > 1; dsy.light = light;
   DkCtx dk;
   dk.T = T; dk.Lc = Lc; dk.resid = residw; dk.msk = mskp; dk.cbv = cbp;
   dk.yv = wsp; dk.kr = wsp + TP; dk.levw = levw; dk.slpw = slpw; dk.seaw = seaw; dk.xb = dkx;
@@ -696,10 +705,23 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   // ---- helper workgroup: its share of phases (1), (3), (4); with eight workgroups the fifth also
   // prepares the next iteration's regression matrix; the first Gd take part in the draw below
   const bool sweeper = role > 0 && role == sweep_role && P > 16;
+  Prof prof;
+  // phase budget: main's phases from chain 0's main workgroup, the draw's from its first DK worker
+  prof.start(g.prof, g.prof != nullptr && tid == 0 && chain_id == 0 && (role == 0 || role == dw0));
   auto helper_iteration = [&](int it) {
     cl_wait(csync + CL_LATENTS, 1, it + 1, tid);
     role_segment_sums();
     cl_publish(csync + CL_PARTIAL + role, it + 1, tid, light);
+    if (early_a && dk_worker && it < n_iter) {
+      // the prior simulation of this iteration's draw, as soon as main has drawn the scales
+      cl_wait(csync + CL_SCALES, 1, it + 1, tid);
+      WideScal se;
+      se.so = 0.f; se.H = 0.f;
+      se.sl = cw[59]; se.ql = se.sl * se.sl;
+      se.ss = cw[60]; se.qs = se.ss * se.ss;
+      se.sdn = cw[61] * (1.0f / (float)NS); se.qd = se.sdn * se.sdn;
+      wide_dk_quad<TR, NS>(se, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, true, false);
+    }
     cl_wait(csync + CL_WEIGHTS, 1, it + 1, tid);
     if (tid < P) R.w[tid] = cw[tid];
     const float so = cw[P];
@@ -727,8 +749,6 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   pc.valid = 0; pc.S = 0ull; pc.pdiag = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) pc.p[r] = 0.0;
-  Prof prof;
-  prof.start(g.prof, g.prof != nullptr && blockIdx.x == 0 && tid == 0);
   if (role > 0) {
     if (sweeper) {
       for (int e = tid; e < P * P; e += NT) {
@@ -767,7 +787,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     if (role > 0) {
       helper_iteration(it);
       if (it == n_iter) break;
-      if (role >= Gd) continue;
+      if (!dk_worker) continue;
       // a DK worker: every share of X w / the residual is in, the scales came with the weights
       cl_wait(csync + CL_XW, G, it + 1, tid);
       sc.so = cw[58]; sc.H = sc.so * sc.so;
@@ -898,6 +918,16 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
             for (int j = lane; j < P; j += 64) g.out_weights[o * P + j] = R.w[j];
         }
       }
+      if (early_a && it < n_iter && lane == 0) {
+        // the DK workers start the draw's prior simulation on these while the regression is drawn
+        cw[59] = (float)level_scale; cw[60] = (float)slope_scale; cw[61] = (float)drift;
+        if (light) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(csync + CL_SCALES, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          __hip_atomic_store(csync + CL_SCALES, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       if (P > 0 && it < n_iter) {
         const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
         if (P <= 16) {
@@ -994,9 +1024,10 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     __syncthreads();
     prof.tick(3);
     }
-    // the Durbin-Koopman draw, by the cluster's DK workers together (ends with their barrier)
-    wide_dk_quad<TR, NS>(sc, dk, rng, (uint32_t)it, role, dsy, tid, prof);
-    if (G > 1 && role == 0) cl_publish(csync + CL_LATENTS, it + 2, tid, light);
+    // the Durbin-Koopman draw, by the cluster's DK workers together; its last worker raises the
+    // latents flag to it + 2
+    if (dk_worker) wide_dk_quad<TR, NS>(sc, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, !early_a, true);
+    if (role == 0 && G > 1) cl_wait(csync + CL_LATENTS, 1, it + 2, tid);
   }
   if (role > 0) return;
   __syncthreads();     // the running sums were accumulated through the emission's thread mapping

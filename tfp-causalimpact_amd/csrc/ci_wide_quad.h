@@ -29,11 +29,27 @@
 namespace ci {
 
 struct DkSync {
-  int* cnt;            // arrival counter of the DK workers (monotone)
+  int* cnt;            // arrival counter of the DK workers (monotone; nobody polls it)
+  int* flag;           // epoch of the last completed barrier, written by its last arriver (own cache line)
+  int* latcnt;         // arrivals at the END of a draw
+  int* latflag;        // the cluster's "latents of iteration it are in place" flag (CL_LATENTS)
   int Gd, epoch;
   bool cluster, light;
 };
-// Barrier of the chain's DK workers with release / acquire of everything written before it.
+// everything this workgroup wrote is in L2 (one XCD) / written back (several) before tid 0 arrives
+__device__ __forceinline__ void dk_release(const DkSync& s) {
+  if (s.light) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    __threadfence();
+  }
+  __syncthreads();
+}
+// Barrier of the chain's DK workers with release / acquire of everything written before it.  An
+// arrival is one atomic add whose RESULT tells the last arriver, and only that workgroup writes the
+// flag the others poll -- on its own cache line: polling the arrival counter itself made the adds
+// queue behind the polls (measured: 5.7k cycles for 8 workgroups, 10.1k for 16, empty barrier).
 __device__ __forceinline__ void dk_barrier(DkSync& s, int tid) {
   if (!s.cluster) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -42,22 +58,43 @@ __device__ __forceinline__ void dk_barrier(DkSync& s, int tid) {
     return;
   }
   ++s.epoch;
-  if (s.light) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores in the shared L2 before the arrival
-  } else {
-    __threadfence();
-  }
-  __syncthreads();
+  dk_release(s);
   if (tid == 0) {
-    if (s.light) (void)__hip_atomic_fetch_add(s.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else (void)__hip_atomic_fetch_add(s.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const int want = s.epoch * s.Gd;
-    while (__hip_atomic_load(s.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
-      __builtin_amdgcn_s_sleep(1);
+    const int old = s.light ? __hip_atomic_fetch_add(s.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            : __hip_atomic_fetch_add(s.cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == s.epoch * s.Gd) {
+      if (s.light) __hip_atomic_store(s.flag, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(s.flag, s.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(s.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s.epoch)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    // Acquire: the CU's vector L1 drops its stale lines.  ONE wave's invalidate serves the whole
+    // workgroup (the L1 belongs to the CU); the fence on every wave cost 1.5k cycles more per barrier
+    // at 8 workgroups, 3k at 16 (tools/bench_cluster_barrier2.hip, with a stale-read check).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("" ::: "memory");
+}
+// End of a draw: arrive, and the last worker raises the cluster's latents flag to `value`.  Nobody
+// waits here -- every workgroup of the cluster waits for that flag where it next needs the latents.
+__device__ __forceinline__ void dk_finish(DkSync& s, int value, int done_draws, int tid) {
+  if (!s.cluster) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return;
+  }
+  dk_release(s);
+  if (tid == 0) {
+    const int old = s.light ? __hip_atomic_fetch_add(s.latcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            : __hip_atomic_fetch_add(s.latcnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == done_draws * s.Gd) {
+      if (s.light) __hip_atomic_store(s.latflag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(s.latflag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---- the transition on a d-vector held in registers (w_apply / w_apply_t of ci_wide.h on arrays) --
@@ -177,11 +214,15 @@ struct DkCtx {
 };
 
 // One Durbin-Koopman draw.  Called by the chain's DK workers (role 0 .. Gd-1) with the same
-// arguments; contains 4 dk_barrier()s.  Leaves the latents in levw / slpw / seaw and, per chunk, the
+// arguments (`role` = index among them); contains 3 dk_barrier()s and ends with dk_finish().
+// do_a / do_rest: phase A (prior simulation: needs the disturbance scales only, so a cluster whose
+// main workgroup is not a DK worker runs it while the regression is still being drawn) and phases
+// B-D; the hand-over between them is in L2 either way.  Leaves the latents in levw / slpw / seaw and, per chunk, the
 // sums of squared increments + first / last state in the exchange region (dk_stats reads them).
 template <int TR, int NS, class P>
 __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x, const Rng& rng,
-                                             uint32_t iter, int role, DkSync& sy, int tid, P& prof) {
+                                             uint32_t iter, int role, DkSync& sy, int tid, P& prof,
+                                             bool do_a, bool do_rest) {
   using W = WDim<TR, NS>;
   constexpr int D = W::D, O = W::O, N1 = W::N1, H = (D + 3) / 4;
   constexpr int EF = (int)(sizeof(QFElem<D>) / 4), EA = (int)(sizeof(QAElem<D>) / 4);
@@ -250,10 +291,11 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
   float xpre[D];            // x+ at the chunk start
   float a0[D];              // predicted mean at the chunk start
   QMat<D> P0;               // predicted covariance at the chunk start
-  WPElem<D> pex;            // in-wave exclusive prefix of the prior-simulation scan
   QAElem<D> aex;            // in-wave exclusive suffix of the backward scan
 
+  prof.tick(19);     // (whatever this workgroup did since its last stamp is not the draw's)
   // =================== phase A: prior simulation, chunk elements, in-wave scan ====================
+  if (do_a) {
 #pragma unroll 1
   for (int v = v0; v < v0 + nv; ++v) {
     if (v >= nvact) continue;
@@ -294,9 +336,9 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
 #pragma unroll
       for (int i = 0; i < D; ++i) p[2 + i] = incl.s.v[i];
     }
-    pex = q_shfl_up(incl, 1);
+    WPElem<D> pex = q_shfl_up(incl, 1);
     if (qi == 0) { pex.k = 0.f; pex.m = 0; pex.s = vzero<D>(); }
-    if (park) {
+    {
       *vslot(v, 0) = pex.k; *vslot(v, 1) = (float)pex.m;
 #pragma unroll
       for (int i = 0; i < D; ++i) *vslot(v, 2 + i) = pex.s.v[i];
@@ -304,30 +346,44 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
   }
   prof.tick(20);
   dk_barrier(sy, tid);
+  prof.tick(16);
+  }
+  if (!do_rest) return;
 
   // =================== phase B: x+ and y~, chunk filtering elements, in-wave scan ==================
 #pragma unroll 1
   for (int v = v0; v < v0 + nv; ++v) {
     if (v >= nvact) continue;
     const int c = 64 * v + (tid >> 2), t0 = c * Lc, wi = 4 * v + wave;
-    if (park) {
+    WPElem<D> pex;
+    {
       pex.k = *vslot(v, 0); pex.m = (int)*vslot(v, 1);
 #pragma unroll
       for (int i = 0; i < D; ++i) pex.s.v[i] = *vslot(v, 2 + i);
     }
     {
-      // the earlier wavefronts' totals, in order, then the in-wave prefix
-      WPElem<D> acc;
-      acc.k = 0.f; acc.m = 0; acc.s = vzero<D>();
-#pragma unroll 1
-      for (int w = 0; w < wi; ++w) {
-        const float* p = xbP + w * DK_EP;
-        WPElem<D> e;
-        e.k = p[0]; e.m = (int)p[1];
+      // Everything before this wavefront: lane l of each half-wave loads the total of wavefront l
+      // (skipped ones: the identity), a Kogge-Stone over the 32 lanes, and the prefix is read off lane
+      // wi - 1.  (A serial walk over the earlier totals -- up to 31 dependent L2 round trips -- made
+      // the last DK worker enter its element pass 18k cycles after the first.)
+      WPElem<D> e;
+      {
+        const int w = lane & 31;
+        e.k = 0.f; e.m = 0; e.s = vzero<D>();
+        if (w < nwact) {
+          const float* p = xbP + w * DK_EP;
+          e.k = p[0]; e.m = (int)p[1];
 #pragma unroll
-        for (int i = 0; i < D; ++i) e.s.v[i] = p[2 + i];
-        acc = wpelem_combine<TR, NS>(acc, e);
+          for (int i = 0; i < D; ++i) e.s.v[i] = p[2 + i];
+        }
       }
+#pragma unroll 1
+      for (int off = 1; off < 32; off <<= 1) {
+        const WPElem<D> o = q_perm(e, (lane & 31) >= off ? lane - off : lane);
+        if ((lane & 31) >= off) e = wpelem_combine<TR, NS>(o, e);
+      }
+      WPElem<D> acc = q_perm(e, wi > 0 ? wi - 1 : 0);
+      if (wi == 0) { acc.k = 0.f; acc.m = 0; acc.s = vzero<D>(); }
       acc = wpelem_combine<TR, NS>(acc, pex);
 #pragma unroll
       for (int i = 0; i < D; ++i) xpre[i] = acc.s.v[i];
@@ -435,6 +491,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
     prof.tick(22);
   }
   dk_barrier(sy, tid);
+  prof.tick(17);
 
   // =================== phase C: prefixes, local filter (gains), backward chunk maps =================
   {
@@ -644,6 +701,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
     }
   }
   dk_barrier(sy, tid);
+  prof.tick(18);
 
   // =================== phase D: r through the chunk, forward reconstruction, statistics ============
   {
@@ -860,7 +918,8 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
       prof.tick(28);
     }
   }
-  dk_barrier(sy, tid);
+  dk_finish(sy, (int)iter + 2, (int)iter + 1, tid);
+  prof.tick(29);
 }
 
 // The statistics of the draw for the scale updates: thread i adds chunk i's sums and the increment

@@ -36,12 +36,14 @@ names = {0: "(1) targets, X'targets, sums", 1: "(2) serial + regression block", 
          22: "dk B  filter scan inside the wave", 23: "dk C  hand-over + scan of the 16 wave totals",
          24: "dk C  prefix, local filter: gains", 25: "dk C  backward chunk maps",
          26: "dk D  backward scans + hand-over", 27: "dk D  r through the chunk",
-         28: "dk D  forward reconstruction"}
+         28: "dk D  forward reconstruction", 29: "dk    end of the draw: arrival", 16: "dk    barrier after A", 17: "dk    barrier after B", 18: "dk    barrier after C",
+         19: "(DK worker: its share of main's phases, waits)"}
 print(f"T={T} P={pb.P} chains={C}: {ms * 1e3 / n:.1f} us per iteration ({ms:.1f} ms per launch)")
 tot = 0
 for k in sorted(names):
   print(f"  [{k:2d}] {names[k]:36s} {cyc[k] / n:10.0f} cycles / iteration")
   tot += cyc[k]
+print(f"  (main's phases [0-10] and the draw's [20-29] are stamped by different workgroups when the cluster has 16: they overlap)")
 print(f"  sum {tot / n:.0f} cycles / iteration")
 w = sess.fetch(["weights"])["weights"]
 print("  active features per draw:", float((w != 0).sum(axis=-1).mean()))

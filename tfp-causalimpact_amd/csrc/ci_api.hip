@@ -456,6 +456,7 @@ struct ci_session {
   int Lc = 0;
   DevBuf<float> ws;
   int cluster = 1;            // time-parallel seasonal kernel: workgroups per chain
+  int dk_lds = 0;             //   its DK workers keep the draw's per-step rows in LDS (clusters of 16)
   bool tp = false;            // general seasonal models / trend + P > MAXP on ci_seasonal_tp.h
   size_t tp_ws_bytes = 0;     //   its per-chain HBM workspace
   DevBuf<int> csync;
@@ -819,6 +820,18 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
         else if (groups * 4 <= num_cus) s->cluster = 4;
         else if (groups * 2 <= num_cus) s->cluster = 2;
       }
+      if (s->cluster == 16 && getenv("CI_WIDE_DK_GLOBAL") == nullptr) {
+        // sixteen workgroups: the draw's workers are helpers whose LDS holds no regression matrices
+        const size_t need = ci::make_wlayout(P, s->dred).big0 + ci::wide_dk_lds_bytes(s->Lc);
+        if (need <= 160 * 1024 - 256) {
+          s->dk_lds = 1;
+          if (need > s->lds_bytes) {
+            s->lds_bytes = need;
+            HIP_TRY(hipFuncSetAttribute((const void*)s->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)s->lds_bytes));
+          }
+        }
+      }
       const size_t nseg = ((size_t)(T >> 2) + ci::NT - 1) / ci::NT;
       const size_t RS = (size_t)(P > 16 ? P : 16) + 4;
       HIP_TRY(s->csync.alloc((size_t)B * C * ci::CL_INTS));
@@ -933,6 +946,7 @@ static int session_launch(ci_session* s) {
     sa.ws_stride = s->tp ? s->tp_ws_bytes : (s->wide ? 0 : s->seasonal_ws_bytes);
     sa.cluster = (s->wide || s->tp) ? s->cluster : 1;
     sa.cluster_drop = (pb.flags & CI_FLAG_TEST_DROP_HELPER) ? sa.cluster - 1 : 0;
+    sa.dk_lds = s->wide ? s->dk_lds : 0;
     sa.csync = s->csync.p; sa.cpart = s->cpart.p; sa.cw = s->cw.p; sa.cv = s->cv.p;
     int grid = pb.num_series * pb.num_chains;
     if ((s->wide || s->tp) && s->cluster > 1) {

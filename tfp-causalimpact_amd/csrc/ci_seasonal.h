@@ -50,6 +50,7 @@ struct SArgs {
   // time-parallel kernel, several workgroups per chain (ci_wide.h "clusters"):
   int cluster;                       //   workgroups per chain (1, 2, 4 or 8)
   int cluster_drop;                  //   test knob: this role exits before checking in (0 = none)
+  int dk_lds;                        //   clusters of 16: the DK workers keep the draw's per-step rows in LDS
   int* csync;                        //   [B*C][32] handshake counters, zeroed before the launch
   float* cpart;                      //   [B*C][segments][4][RS] partial sums of X~'targets, y'y
   float* cw;                         //   [B*C][64] weights + emission scale of the iteration

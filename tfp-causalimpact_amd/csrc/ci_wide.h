@@ -29,6 +29,12 @@
 
 namespace ci {
 
+#ifndef CI_LDS
+#define CI_LDS __attribute__((address_space(3)))
+#define CI_GLB __attribute__((address_space(1)))
+#endif
+typedef float ci_f4v __attribute__((ext_vector_type(4)));
+
 constexpr int WIDE_MAX_LC = 256;      // T <= 65536
 constexpr int XR = 16;              // design rows per pass of the X'targets / X w loops
 
@@ -310,21 +316,17 @@ __device__ __forceinline__ E block_scan_excl_bwd_rolled(const E& tot, Op op, con
 
 struct WLayout {
   size_t xtx, omega, aug0, aug1, pri0, pri1, chol, bvec, zv, uperm, nz, perm, idx, w, scal, red,
-      st, gsum, total;
+      st, gsum, big0, total;
 };
+// The small arrays first, the regression block's matrices from `big0` on: a DK worker that is
+// neither the main workgroup nor the sweeper never touches the matrices, and keeps the per-step
+// workspace of its share of the Durbin-Koopman draw there (wide_dk_lds_bytes, ci_wide_quad.h).
 __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   WLayout l;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
   const int Pp = P > 0 ? P : 1;
   const bool big = P > 16;    // the LDS-resident regression block is only used for P > 16
-  l.xtx = take(sizeof(double) * Pp * Pp);
-  l.omega = take(sizeof(double) * Pp * Pp);
-  l.aug0 = take(big ? sizeof(double) * block_matrix_doubles(Pp + 1) : 16);
-  l.aug1 = take(16);
-  l.pri0 = take(big ? sizeof(double) * block_matrix_doubles(Pp) : 16);
-  l.pri1 = take(16);
-  l.chol = take(big ? sizeof(double) * block_chol_doubles(Pp) : 16);   // recorded pivot rows / Cholesky + staging
   l.bvec = take(sizeof(double) * (Pp + 4));
   l.zv = take(sizeof(double) * Pp);
   l.uperm = take(sizeof(double) * Pp);
@@ -337,8 +339,22 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   (void)D;
   l.st = take(sizeof(double) * 4);      // serial wave -> block: previous sigma_obs, gamma variate
   l.gsum = take(sizeof(double) * NW * 64);   // quarter sums of the segment partials
+  o = (o + 127) & ~(size_t)127;
+  l.big0 = o;
+  l.xtx = take(sizeof(double) * Pp * Pp);
+  l.omega = take(sizeof(double) * Pp * Pp);
+  l.aug0 = take(big ? sizeof(double) * block_matrix_doubles(Pp + 1) : 16);
+  l.aug1 = take(16);
+  l.pri0 = take(big ? sizeof(double) * block_matrix_doubles(Pp) : 16);
+  l.pri1 = take(16);
+  l.chol = take(big ? sizeof(double) * block_chol_doubles(Pp) : 16);   // recorded pivot rows / Cholesky + staging
   l.total = o;
   return l;
+}
+// LDS a DK worker needs to keep its share of the draw's per-step rows (K_t / r_{t-1}: 8 floats, y~ /
+// v/F: 1 float, for 64 chunks of Lc steps) and the 72 floats per lane parked between the phases
+__host__ __device__ inline size_t wide_dk_lds_bytes(int Lc) {
+  return sizeof(float) * ((size_t)DK_EF * NT + (size_t)Lc * 64 * 9);
 }
 
 }  // namespace ci
@@ -540,7 +556,13 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   DkSync dsy;
   dsy.cnt = csync + CL_DK; dsy.flag = csync + CL_DKFLAG; dsy.latcnt = csync + CL_LATCNT; dsy.latflag = csync + CL_LATENTS;
   dsy.Gd = Gd; dsy.epoch = 0; dsy.cluster = G > 1; dsy.light = light;
+  // (the draw's per-step rows in LDS: only where the DK workers are helpers that never touch the
+  // regression block's matrices -- sixteen workgroups -- and the host found room)
+  const bool dk_lds = a.dk_lds != 0 && G == 16;
   DkCtx dk;
+  dk.lv = (CI_LDS float*)(smem + lay.big0);
+  dk.lkr = dk.lv + DK_EF * NT;
+  dk.lyv = dk.lkr + Lc * 64 * 8;
   dk.T = T; dk.Lc = Lc; dk.resid = residw; dk.msk = mskp; dk.cbv = cbp;
   dk.yv = wsp; dk.kr = wsp + TP; dk.levw = levw; dk.slpw = slpw; dk.seaw = seaw; dk.xb = dkx;
   dk.chol1 = chol1; dk.a1_loc = (float)sp.init_level_loc;
@@ -720,7 +742,8 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       se.sl = cw[59]; se.ql = se.sl * se.sl;
       se.ss = cw[60]; se.qs = se.ss * se.ss;
       se.sdn = cw[61] * (1.0f / (float)NS); se.qd = se.sdn * se.sdn;
-      wide_dk_quad<TR, NS>(se, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, true, false);
+      if (dk_lds) wide_dk_quad<TR, NS, true>(se, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, true, false);
+      else wide_dk_quad<TR, NS, false>(se, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, true, false);
     }
     cl_wait(csync + CL_WEIGHTS, 1, it + 1, tid);
     if (tid < P) R.w[tid] = cw[tid];
@@ -1026,7 +1049,10 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     }
     // the Durbin-Koopman draw, by the cluster's DK workers together; its last worker raises the
     // latents flag to it + 2
-    if (dk_worker) wide_dk_quad<TR, NS>(sc, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, !early_a, true);
+    if (dk_worker) {
+      if (dk_lds) wide_dk_quad<TR, NS, true>(sc, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, false, true);
+      else wide_dk_quad<TR, NS, false>(sc, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, !early_a, true);
+    }
     if (role == 0 && G > 1) cl_wait(csync + CL_LATENTS, 1, it + 2, tid);
   }
   if (role > 0) return;

@@ -208,6 +208,9 @@ struct DkCtx {
   float* slpw;
   float* seaw;
   float* xb;           // exchange region (wide_dk_floats())
+  CI_LDS float* lv;    // LW builds: what a lane parks between the phases [DK_EF][256 lanes],
+  CI_LDS float* lkr;   //   K_t, then r_{t-1} in place [Lc][64 chunks of this workgroup][8],
+  CI_LDS float* lyv;   //   y~_t, then v_t / F_t in place [Lc][64]
   const float* chol1;  // lower Cholesky factor of the prior covariance of x_0 (d x d)
   float a1_loc;        // prior mean of the level
   float p1l, p1s, p1e; // prior variances: level, slope, seasonal effects
@@ -219,7 +222,10 @@ struct DkCtx {
 // main workgroup is not a DK worker runs it while the regression is still being drawn) and phases
 // B-D; the hand-over between them is in L2 either way.  Leaves the latents in levw / slpw / seaw and, per chunk, the
 // sums of squared increments + first / last state in the exchange region (dk_stats reads them).
-template <int TR, int NS, class P>
+// LW: the per-step rows and the parked state in this workgroup's LDS (one virtual workgroup per
+// worker: every lane only reads back what its own quad wrote) instead of the chain's workspace in
+// L2 / HBM -- same arithmetic, same bits.
+template <int TR, int NS, bool LW, class P>
 __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x, const Rng& rng,
                                              uint32_t iter, int role, DkSync& sy, int tid, P& prof,
                                              bool do_a, bool do_rest) {
@@ -241,7 +247,23 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
   float* stat = xbP + 512;
   float* vst = stat + (size_t)DK_CH * DK_ST;
   const QScal<D> qs = make_qscal<TR, NS>(sc, q);
-  auto vslot = [&](int v, int f) -> float* { return vst + ((size_t)(v * DK_VS + f) * NT + tid); };
+  typedef typename std::conditional<LW, CI_LDS float*, float*>::type FP;
+  typedef typename std::conditional<LW, CI_LDS ci_f4v*, ci_f4v*>::type F4P;
+  const int cl = tid >> 2;                     // LW: the chunk's index inside this workgroup
+  auto vslot = [&](int v, int f) -> FP {
+    if constexpr (LW) { (void)v; return x.lv + (f * NT + tid); }
+    else return vst + ((size_t)(v * DK_VS + f) * NT + tid);
+  };
+  auto krow = [&](int step, int c) -> FP {     // the 8 floats of step `step` of chunk c
+    if constexpr (LW) { (void)c; return x.lkr + (step * 64 + cl) * 8; }
+    else return x.kr + ((size_t)step * DK_CH + c) * 8;
+  };
+  auto yvp = [&](int step, int c) -> FP {
+    if constexpr (LW) { (void)c; return x.lyv + (step * 64 + cl); }
+    else return x.yv + ((size_t)step * DK_CH + c);
+  };
+  auto ld4 = [](FP p) -> float4 { const ci_f4v t = *(F4P)p; return make_float4(t.x, t.y, t.z, t.w); };
+  auto st4 = [](FP p, float a, float b, float c, float d) { *(F4P)p = ci_f4v{a, b, c, d}; };
   auto at4 = [](const float (&z)[4], int s) { return s == 0 ? z[0] : s == 1 ? z[1] : s == 2 ? z[2] : z[3]; };
   // the four random-number sites of a 4-step block, one per lane of the quad
   const uint32_t my_site = q == 0 ? (uint32_t)SITE_PRIOR_LEVEL : q == 1 ? (uint32_t)SITE_PRIOR_SEAS
@@ -426,7 +448,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
           const float zl = q_bc(zm, 0), zk = q_bc(zm, 1), zo = q_bc(zm, 2), zs = q_bc(zm, 3);
           const float ru = u == 0 ? r4.x : u == 1 ? r4.y : u == 2 ? r4.z : r4.w;
           const float yt = ru - (xp[0] + xp[O] + sc.so * zo);
-          if (q == 0) x.yv[(size_t)(g4 + u) * DK_CH + c] = yt;
+          if (q == 0) *yvp(g4 + u, c) = yt;
           if (obs) {
             // fold y~_t into (A, b, C, eta, J)
             QVec<D> za, cz;
@@ -570,7 +592,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
         QMat<D> Pc = P0;
         float nyt[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) nyt[u] = x.yv[(size_t)u * DK_CH + c];
+        for (int u = 0; u < 4; ++u) nyt[u] = *yvp(u, c);
         uint32_t nmk = *reinterpret_cast<const uint32_t*>(x.msk + t0);
         uint32_t ncb = *reinterpret_cast<const uint32_t*>(x.cbv + t0);
 #pragma unroll 1
@@ -582,7 +604,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
           for (int u = 0; u < 4; ++u) yt4[u] = nyt[u];
           if (g4 + 4 < Lc) {       // the next block's rows, requested before this block's stores
 #pragma unroll
-            for (int u = 0; u < 4; ++u) nyt[u] = x.yv[(size_t)(g4 + 4 + u) * DK_CH + c];
+            for (int u = 0; u < 4; ++u) nyt[u] = *yvp(g4 + 4 + u, c);
             nmk = *reinterpret_cast<const uint32_t*>(x.msk + t4 + 4);
             ncb = *reinterpret_cast<const uint32_t*>(x.cbv + t4 + 4);
           }
@@ -611,10 +633,10 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
                 Pc.r[i] = (pz.v * (-pzr[i])) * rF + Pc.r[i];
               }
             }
-            float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
-            if (q == 0) *reinterpret_cast<float4*>(kp) = make_float4(kf[0], kf[1], kf[2], kf[3]);
-            if (q == 1) *reinterpret_cast<float4*>(kp + 4) = make_float4(kf[4], kf[5], kf[6], kf[7]);
-            if (q == 2) x.yv[(size_t)(g4 + u) * DK_CH + c] = vf;
+            const FP kp = krow(g4 + u, c);
+            if (q == 0) st4(kp, kf[0], kf[1], kf[2], kf[3]);
+            if (q == 1) st4(kp + 4, kf[4], kf[5], kf[6], kf[7]);
+            if (q == 2) *yvp(g4 + u, c) = vf;
             qw_apply<TR, NS>(am, ch);
             qc_predict<TR, NS>(Pc, ch, qs, q);
           }
@@ -631,10 +653,10 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
       auto load_kv = [&](int g4, KV4& o) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
-          o.a[u] = *reinterpret_cast<const float4*>(kp);
-          o.b[u] = *reinterpret_cast<const float4*>(kp + 4);
-          o.vf[u] = x.yv[(size_t)(g4 + u) * DK_CH + c];
+          const FP kp = krow(g4 + u, c);
+          o.a[u] = ld4(kp);
+          o.b[u] = ld4(kp + 4);
+          o.vf[u] = *yvp(g4 + u, c);
         }
         o.mk = *reinterpret_cast<const uint32_t*>(x.msk + t0 + g4);
         o.cb = *reinterpret_cast<const uint32_t*>(x.cbv + t0 + g4);
@@ -773,10 +795,10 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
         auto load_kr = [&](int g4, KR4& o) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
-            o.a[u] = *reinterpret_cast<const float4*>(kp);
-            o.b[u] = *reinterpret_cast<const float4*>(kp + 4);
-            o.vf[u] = x.yv[(size_t)(g4 + u) * DK_CH + c];
+            const FP kp = krow(g4 + u, c);
+            o.a[u] = ld4(kp);
+            o.b[u] = ld4(kp + 4);
+            o.vf[u] = *yvp(g4 + u, c);
           }
           o.mk = *reinterpret_cast<const uint32_t*>(x.msk + t0 + g4);
           o.cb = *reinterpret_cast<const uint32_t*>(x.cbv + t0 + g4);
@@ -805,9 +827,9 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
             float r8[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) r8[i] = i < D ? r[i < D ? i : 0] : 0.f;
-            float* kp = x.kr + ((size_t)(g4 + u) * DK_CH + c) * 8;
-            if (q == 0) *reinterpret_cast<float4*>(kp) = make_float4(r8[0], r8[1], r8[2], r8[3]);
-            if (q == 1) *reinterpret_cast<float4*>(kp + 4) = make_float4(r8[4], r8[5], r8[6], r8[7]);
+            const FP kp = krow(g4 + u, c);
+            if (q == 0) st4(kp, r8[0], r8[1], r8[2], r8[3]);
+            if (q == 1) st4(kp + 4, r8[4], r8[5], r8[6], r8[7]);
           }
         }
         // x^ at the chunk start: a + P r_{t0 - 1}
@@ -845,9 +867,9 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
           for (int u = 0; u < 4; ++u) {
             const int sidx = g4 + u + 1;          // r_t of step t = the row stored for step t + 1
             if (sidx < Lc) {
-              const float* kp = x.kr + ((size_t)sidx * DK_CH + c) * 8;
-              ra[u] = *reinterpret_cast<const float4*>(kp);
-              rb[u] = *reinterpret_cast<const float4*>(kp + 4);
+              const FP kp = krow(sidx, c);
+              ra[u] = ld4(kp);
+              rb[u] = ld4(kp + 4);
             } else {
               float r8[8];
 #pragma unroll

@@ -354,7 +354,7 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
 // LDS a DK worker needs to keep its share of the draw's per-step rows (K_t / r_{t-1}: 8 floats, y~ /
 // v/F: 1 float, for 64 chunks of Lc steps) and the 72 floats per lane parked between the phases
 __host__ __device__ inline size_t wide_dk_lds_bytes(int Lc) {
-  return sizeof(float) * ((size_t)DK_EF * NT + (size_t)Lc * 64 * 9);
+  return sizeof(float) * ((size_t)DK_VS * NT + (size_t)Lc * 64 * 9);
 }
 
 }  // namespace ci
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const bool dk_lds = a.dk_lds != 0 && G == 16;
   DkCtx dk;
   dk.lv = (CI_LDS float*)(smem + lay.big0);
-  dk.lkr = dk.lv + DK_EF * NT;
+  dk.lkr = dk.lv + DK_VS * NT;
   dk.lyv = dk.lkr + Lc * 64 * 8;
   dk.T = T; dk.Lc = Lc; dk.resid = residw; dk.msk = mskp; dk.cbv = cbp;
   dk.yv = wsp; dk.kr = wsp + TP; dk.levw = levw; dk.slpw = slpw; dk.seaw = seaw; dk.xb = dkx;

@@ -236,7 +236,7 @@ __device__ __forceinline__ void wide_dk_quad(const WideScal& sc, const DkCtx& x,
   const int lane = tid & 63, wave = tid >> 6, q = tid & 3, qi = lane >> 2;
   const int T = x.T, Lc = x.Lc;
   const int nv = DK_V / sy.Gd, v0 = role * nv;
-  const bool park = nv > 1;                    // state crosses the hand-overs through L2
+  const bool park = true;                      // state crosses the hand-overs through L2 (LW: LDS), never in registers
   // virtual workgroups whose chunks start before the end of the series; the others are skipped and
   // their wavefronts' totals read as the identity
   const int nvact = (T + 64 * Lc - 1) / (64 * Lc);

@@ -322,6 +322,42 @@ def test_batch_of_series_equals_single_series_runs():
   np.testing.assert_array_equal(tw["level"][1], plain["level"][0])
 
 
+@pytest.mark.gpu
+def test_seasonal_batch_larger_than_the_device_equals_single_series_runs():
+  """The route of a seasonal model is a function of (T, D, P) alone: a batch with MORE chains than
+  the device has CUs (66 series x 4 chains = 264 workgroups) runs every series on the kernel a
+  single-series launch picks, so series b of the batch reproduces the single launch with
+  series_offset = b bit for bit (round-5 advisor: the route used to flip to the sequential kernel
+  at B*C > CU count, and the two agree only up to float summation order)."""
+  from causalimpact import _model
+  T, p, B, C, seasons = 130, 2, 66, 4, ((5, 1), (3, 5))
+  counts, flg = _model.expand_seasons(seasons, T)
+  ys, masks, Xs, specs = [], [], [], []
+  for b in range(B):
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 300 + b)
+    y = y + 0.5 * np.sin(2 * np.pi * np.arange(T) / 5.0)
+    ys.append(y); masks.append(mask); Xs.append(X)
+    specs.append(orc.default_spec(y, mask, X, has_slope=True, seasons=seasons))
+  P = specs[0]["P"]
+  kw = dict(T=T, P=P, has_slope=1, num_seasons=counts, num_warmup=2, num_results=4, num_chains=C, seed=(5, 9))
+  sess = _native.Session(_native.make_problem(num_series=B, **kw), np.stack(ys), np.stack(masks), np.stack(Xs),
+                         flg, _native.make_params(specs))
+  name = sess.kernel_name()
+  assert "gibbs_seasonal_tp_kernel" in name
+  sess.run()
+  batch = sess.fetch()
+  sess.close()
+  for b in (0, 37, B - 1):
+    one_s = _native.Session(_native.make_problem(num_series=1, series_offset=b, **kw), ys[b][None], masks[b][None],
+                            Xs[b][None], flg, _native.make_params([specs[b]]))
+    assert one_s.kernel_name().split(" ")[0] == name.split(" ")[0]
+    one_s.run()
+    one = one_s.fetch()
+    one_s.close()
+    for k in ("level", "weights", "observation_noise_scale", "seasonal_levels", "posterior_trajectories"):
+      np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
+
+
 def test_baseline_cfg5_full_size_batch_equals_single_series_runs_and_oracle():
   """BASELINE 'batch of 512 independent series, T=500, 5 covariates' at full size (fewer
   iterations): one launch of 512 workgroups; spot-checked series equal their own single-series

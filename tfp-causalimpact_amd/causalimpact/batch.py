@@ -295,14 +295,11 @@ def fit_causalimpact_batch(data: Union[Sequence[pd.DataFrame], np.ndarray],
   a batch equals `fit_causalimpact` on that series alone with the same seed.
   `shared_streams=True` keys the streams by chain only: EVERY series then reproduces its
   single-series fit draw for draw, at the price of perfectly correlated Monte-Carlo errors.
-  "Equals" is bit for bit for trend models with at most 52 covariates and for trend + one block of
-  2-7 seasons (every launch size runs the same arithmetic, tests/test_gpu_gibbs.py).  Models on
-  the general seasonal routes (several `Seasons` blocks, more than 7 seasons, more than 52
-  covariates) run time-parallel while `series x chains <= CUs of the device` (256) and on the
-  sequential one-wavefront kernel beyond that: the same random numbers through the same model, but
-  a different float32 summation order -- such a series of a LARGE batch agrees with its own
-  single-series fit to float32 round-off accumulated over the fit (draws within ~1e-3 of the
-  outcome's scale; identical inclusion patterns are not guaranteed), not bit for bit.
+  "Equals" is bit for bit on every route: the kernel a series runs on is a function of its model
+  and length alone (trend models, trend + one block of 2-7 seasons, and the general seasonal /
+  more-than-52-covariate routes alike), never of the batch size or the device's CU count; the
+  launch size only decides how many workgroups share one chain's work, which does not change the
+  arithmetic (tests/test_gpu_gibbs.py, including a seasonal batch with more chains than CUs).
 
   `DataOptions.dtype=float64` and `standardize_data=False` batches are NOT one launch: they are
   fitted series by series on the single-series routes (float64 kernels / exact internal

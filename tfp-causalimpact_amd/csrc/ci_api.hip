@@ -722,9 +722,11 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     }
     // Any other block list -- and trend models with more than MAXP design columns -- with a state
     // of at most 32 components: the TIME-PARALLEL kernel of ci_seasonal_tp.h, a cluster of up to 32
-    // workgroups of 4 wavefronts per chain (one chunk of the series per wavefront), as long as every
-    // chain of the launch gets at least one CU to itself (bigger batches are throughput-bound: one
-    // wavefront per chain on the sequential kernel does less work per step).
+    // workgroups of 4 wavefronts per chain (one chunk of the series per wavefront).  The ROUTE is a
+    // function of the model and the series alone (T, D, P) -- never of the launch size or the device's
+    // CU count: the two seasonal kernels agree only up to float summation order, and a series of a
+    // batch must reproduce fit_causalimpact on that series alone bit for bit, on any device.  The
+    // launch size only decides how many real workgroups share a chain's chunks (same bits).
     // (measured, round 5: below ~110 steps the one-wavefront kernel is as fast or faster -- 158 us
     // against 171 us at T = 96 on the 4+7+6 model, 202 us against 174 us at T = 128)
     const int tp_min_t = P > ci::MAXP ? 64 : 112;
@@ -734,7 +736,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, pb->device);
       const long long groups = ((long long)B * C + 7) / 8 * 8;
       const ci::TpLds tl = ci::make_tplds(P, s->D_full);
-      if ((long long)B * C <= num_cus && tl.total <= 160 * 1024) {
+      if (tl.total <= 160 * 1024) {
         // the chunk grid (G virtual workgroups of TP_NWV chunks) depends on the series alone; the
         // launch size only decides how many real workgroups (Gc) share them: same bits either way
         int G = 1;

@@ -4,7 +4,7 @@
 # rocprofv3 runs from /tmp with TMPDIR=/tmp; PMC counters are collected in their own passes
 # (never together with trace domains).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -29,6 +29,9 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg_tr
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cfg_pmc_fetch" -o cfg -- python tools/run_configs.py cfg4 > "$OUT/cfg_pmc_fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cfg_pmc_write" -o cfg -- python tools/run_configs.py cfg4 > "$OUT/cfg_pmc_write.log" 2>&1
 timeout 300 rocprofv3 --pmc $SQ --output-format csv -d "$OUT/cfg_pmc_sq" -o cfg -- python tools/run_configs.py cfg4 > "$OUT/cfg_pmc_sq.log" 2>&1
+# cfg4 at BASELINE's own size (S = 1000) under the counters: traffic against the 978 MB of algorithmic bytes
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cfg4full_pmc_fetch" -o cfg -- python tools/run_configs.py cfg4_full > "$OUT/cfg4full_pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cfg4full_pmc_write" -o cfg -- python tools/run_configs.py cfg4_full > "$OUT/cfg4full_pmc_write.log" 2>&1
 # ---- end-to-end fit_causalimpact, phase budgets, RCCL single-rank run
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_e2e" -o e2e -- python tools/time_end_to_end.py > "$OUT/e2e.log" 2>&1
 timeout 200 python tools/profile_phases.py > "$OUT/phase_cycles.txt" 2>&1
@@ -53,5 +56,11 @@ if [ -x tools/build/bench_tp_combine ]; then timeout 120 tools/build/bench_tp_co
 # ---- round 5: phase cycles of an HMC leapfrog step (cfg3), host profile of fit_causalimpact
 timeout 200 python tools/exp_hmc_phases.py > "$OUT/hmc_phase_cycles.txt" 2>&1
 timeout 200 python tools/profile_e2e.py 10 2>&1 | head -70 | cut -c1-160 > "$OUT/e2e_host_profile.txt"
+# ---- round 6: cfg4 routes (1 / 8 / 32 / 64 chains, LDS vs L2 workspace of the draw), large seasonal batches on both routes
+timeout 300 python tools/exp_cfg4_routes.py > "$OUT/cfg4_routes.txt" 2>&1
+CI_WIDE_DK_GLOBAL=1 timeout 300 python tools/exp_cfg4_routes.py 2>&1 | head -3 > "$OUT/cfg4_routes_dk_rows_in_l2.txt"
+timeout 300 python tools/exp_seasonal_batch_routes.py > "$OUT/seasonal_batch_routes.txt" 2>&1
+timeout 300 python tools/time_general_seasonal.py > "$OUT/general_seasonal_times.txt" 2>&1
+python tools/kernel_resources.py > "$OUT/kernel_resources.txt" 2>&1
 find "$OUT" -name "*.csv" | wc -l
 tail -1 "$OUT/bench.json" | cut -c1-400

@@ -2,7 +2,7 @@
 # Copies the summaries the judge reads from gpurun_out/<tag>/ (tools/collect_profiles.sh) into
 # profiles/ under the round's names:   tools/publish_profiles.sh r03
 set -eu
-TAG=${1:-r05}
+TAG=${1:-r06}
 SRC=gpurun_out/$TAG
 P=profiles
 R=$TAG
@@ -32,13 +32,17 @@ rows $SRC/cfg_pmc_write/cfg_counter_collection.csv gibbs_wide > $P/${R}_cfg4_pmc
 python tools/pmc_summary.py hbm $SRC/cfg_pmc_fetch/cfg_counter_collection.csv $SRC/cfg_pmc_write/cfg_counter_collection.csv \
   --kernel gibbs_wide --last 3 --algorithmic-bytes 209065600 --out $P/${R}_cfg4_pmc.json > /dev/null
 python tools/pmc_summary.py sq $SRC/cfg_pmc_sq/cfg_counter_collection.csv --kernel gibbs_wide --last 3 --out $P/${R}_cfg4_sq_counters.json > /dev/null
+if [ -d $SRC/cfg4full_pmc_fetch ]; then
+  python tools/pmc_summary.py hbm $SRC/cfg4full_pmc_fetch/cfg_counter_collection.csv $SRC/cfg4full_pmc_write/cfg_counter_collection.csv \
+    --kernel gibbs_wide --algorithmic-bytes 978448000 --out $P/${R}_cfg4_pmc_s1000.json > /dev/null
+fi
 cp $SRC/cfg4_phase_cycles.txt $P/${R}_cfg4_phase_cycles.txt
 # end to end, the multi-rank code path
 cp $SRC/trace_e2e/e2e_kernel_stats.csv $P/${R}_fit_causalimpact_kernel_stats.csv
 grep '^{"metric"' $SRC/bench_force_dist.json | tail -1 > $P/${R}_bench_force_dist_rccl_1rank.json
 (grep -v '^{"metric"' $SRC/bench_force_dist.json; cat $SRC/bench_force_dist.err) > $P/${R}_bench_force_dist_rccl_1rank.log || true
 cp $SRC/comm_tests.txt $P/${R}_two_ranks_on_gpu0_host_transport.txt
-for f in p_scale t_scale phase_cycles_p52 f64_phase_cycles hmc_phase_cycles e2e_host_profile; do
+for f in p_scale t_scale phase_cycles_p52 f64_phase_cycles hmc_phase_cycles e2e_host_profile cfg4_routes cfg4_routes_dk_rows_in_l2 seasonal_batch_routes general_seasonal_times kernel_resources; do
   if [ -f $SRC/$f.txt ]; then cp $SRC/$f.txt $P/${R}_$f.txt; fi
 done
 # round 5: the time-parallel general seasonal kernel

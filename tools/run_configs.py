@@ -127,12 +127,8 @@ def cfg4(chains, S=1000, with_cpu=False, with_traffic=False):
          "algorithmic_GBps": nbytes / ms / 1e6}
   traffic, note = (None, None)
   if with_traffic:
-    # the counter passes run the S = 200 fit of `run_configs.py cfg4`: scale to this launch's draws
-    t200, note = measured_traffic("cfg4", "gibbs_wide")
-    if t200 is not None:
-      per_iter = t200 / (8 * (200 + 23))                  # bytes per chain-iteration of the 8-chain pass
-      traffic = per_iter * chains * (S + W)
-      note += "; per chain-iteration figure of the 8-chain S=200 pass scaled to this launch"
+    # counter passes over THIS launch (same chains, same S) in child runs of `run_configs.py cfg4_c<chains>_s<S>`
+    traffic, note = measured_traffic(f"cfg4_c{chains}_s{S}", "gibbs_wide")
   row["roofline"] = roofline(nbytes, ms, traffic, note)
   if with_cpu:
     y, mask, X, seasons = data
@@ -280,8 +276,15 @@ if __name__ == "__main__":
     sys.exit(0)
   if which == "cfg4":        # counter passes: one short cfg4 fit per chain count
     runs = (lambda: cfg4(1, S=200), lambda: cfg4(8, S=200))
+  elif which.startswith("cfg4_c"):   # counter passes of one launch shape: cfg4_c<chains>_s<S>
+    cc, ss = which[len("cfg4_c"):].split("_s")
+    runs = (lambda: cfg4(int(cc), S=int(ss)),)
+  elif which == "cfg4_full":   # counter passes at BASELINE's own size: 8 chains x (112 + 1000) iterations
+    runs = (lambda: cfg4(8),)
   else:
-    runs = (lambda: cfg4(1), lambda: cfg4(8, with_cpu=True, with_traffic=True), lambda: cfg5(64), lambda: cfg5(512, with_cpu=True))
+    runs = (lambda: cfg4(1, with_traffic=True), lambda: cfg4(8, with_cpu=True, with_traffic=True),
+            lambda: cfg4(32, with_traffic=True),      # 32 chains x 8 CUs: the whole chip
+            lambda: cfg5(64, with_cpu=True), lambda: cfg5(512, with_cpu=True))
   for run in runs:
     print(json.dumps(run()), flush=True)
   if which == "all":

@@ -752,6 +752,62 @@ def test_concurrent_cluster_launches_on_one_gpu_neither_hang_nor_change_the_draw
                                     getattr(one.posterior_samples, f), err_msg=f)
 
 
+def test_cluster_handshakes_under_contention_give_the_bits_of_one_workgroup_per_chain():
+  """Round-5 advisor (high): on one XCD the cluster handshakes publish data with a relaxed flag, so
+  every wave must have drained its stores to the shared L2 before the arrival -- a missing drain
+  shows only under load, as silently different draws.  Both cluster kernels (trend + weekly block:
+  ci_wide.h, sixteen workgroups per chain with the draw's rows in LDS; a two-block model:
+  ci_seasonal_tp.h) run ten times each WHILE another thread keeps a batch of 160 series running on
+  its own stream (L2 / HBM / CU contention; when the cluster cannot assemble the fall-back runs --
+  same bits either way), and every run must equal the one-workgroup-per-chain launch bit for bit."""
+  import threading
+  from causalimpact import _model
+  stop = threading.Event()
+
+  def contention():
+    T, p, B = 500, 5, 160
+    ys, ms, Xs, specs = [], [], [], []
+    for b in range(B):
+      y, mask, X, _ = syn.make_sampler_inputs(T, p, 900 + b)
+      ys.append(y); ms.append(mask); Xs.append(X)
+      specs.append(orc.default_spec(y, mask, X))
+    pb = _native.make_problem(T=T, P=specs[0]["P"], has_slope=0, num_warmup=10, num_results=200,
+                              num_chains=1, num_series=B, seed=(1, 1))
+    sess = _native.Session(pb, np.stack(ys), np.stack(ms), np.stack(Xs), None, _native.make_params(specs))
+    while not stop.is_set():
+      sess.run()
+    sess.close()
+
+  th = threading.Thread(target=contention)
+  th.start()
+  try:
+    for T, p, seasons in ((4800, 20, ((7, 1),)), (1300, 6, ((4, 1), (7, 4)))):
+      y, mask, X, _ = syn.make_sampler_inputs(T, p, 5)
+      y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+      spec = orc.default_spec(y, mask, X, has_slope=False, seasons=seasons)
+      counts, flg = _model.expand_seasons(seasons, T)
+
+      def session(flags):
+        pb = _native.make_problem(T=T, P=spec["P"], has_slope=0, num_seasons=counts, num_warmup=3,
+                                  num_results=12, num_chains=2, seed=(4, 2), flags=flags)
+        return _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+
+      ref_s = session(_native.FLAG_NO_CLUSTER)
+      ref_s.run()
+      ref = ref_s.fetch()
+      ref_s.close()
+      sess = session(0)
+      for rep in range(10):
+        sess.run()
+        got = sess.fetch()
+        for key in ref:
+          np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{sess.kernel_name()} {key} run {rep}")
+      sess.close()
+  finally:
+    stop.set()
+    th.join()
+
+
 def test_fit_causalimpact_with_more_than_52_covariates():
   """The reference has no cap on the number of covariates (causalimpact_lib.py:445-453).  80
   control series, 3 of them carrying the signal: the drop-in call runs (sequential kernel,

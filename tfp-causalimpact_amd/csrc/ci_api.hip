@@ -822,8 +822,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
         else if (groups * 4 <= num_cus) s->cluster = 4;
         else if (groups * 2 <= num_cus) s->cluster = 2;
       }
-      if (s->cluster == 16 && getenv("CI_WIDE_DK_GLOBAL") == nullptr) {
-        // sixteen workgroups: the draw's workers are helpers whose LDS holds no regression matrices
+      if ((s->cluster == 16 || s->cluster == 8) && getenv("CI_WIDE_DK_GLOBAL") == nullptr) {
+        // the draw's workers other than main are helpers whose LDS holds no regression matrices
         const size_t need = ci::make_wlayout(P, s->dred).big0 + ci::wide_dk_lds_bytes(s->Lc);
         if (need <= 160 * 1024 - 256) {
           s->dk_lds = 1;

@@ -2226,9 +2226,32 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
     }
   } else {
     if (presweep) {     // the swept matrix, then the pivot rows of its sweeps (presweep_export)
-      for (int e = tid; e < n * n; e += NTH) R.aug[0][e] = presweep[e];
       const int nrec = __popcll(nzmask) * REC_LD;
-      for (int e = tid; e < nrec; e += NTH) rec[e] = presweep[n * n + e];
+      if (((n * n) & 1) == 0 && (REC_LD & 1) == 0) {
+        // 16 bytes per lane, four loads in flight (the copy is 36 KB from L2 at P = 51: element by
+        // element it was a chain of ~18 dependent round trips)
+        const double2* s2 = reinterpret_cast<const double2*>(presweep);
+        double2* a2 = reinterpret_cast<double2*>(R.aug[0]);
+        double2* r2 = reinterpret_cast<double2*>(rec);
+        const int na2 = (n * n) >> 1, nt2 = na2 + (nrec >> 1);
+        for (int e0 = tid; e0 < nt2; e0 += 4 * NTH) {
+          double2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * NTH;
+            v[u] = s2[e < nt2 ? e : 0];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * NTH;
+            if (e < na2) a2[e] = v[u];
+            else if (e < nt2) r2[e - na2] = v[u];
+          }
+        }
+      } else {
+        for (int e = tid; e < n * n; e += NTH) R.aug[0][e] = presweep[e];
+        for (int e = tid; e < nrec; e += NTH) rec[e] = presweep[n * n + e];
+      }
       __syncthreads();
     } else {
       presweep_block(R, P, prev_var, nzmask, first, tid);
@@ -2398,12 +2421,15 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
 }
 
 // gibbs_sampler._resample_scale: sqrt(IG(conc + n/2, scale + ss/2)) clipped at the bound.
+// (the gamma variate needs the prior and the number of terms only: callers with idle time draw it ahead)
+__device__ __forceinline__ double scale_from_gamma(double scale, double ub, double ss, double g) {
+  const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
+  return s < ub ? s : ub;
+}
 __device__ __forceinline__ double scale_draw(double conc, double scale, double ub, double n,
                                              double ss, const Rng& rng, uint32_t iter,
                                              uint32_t site, int lane) {
-  const double g = gamma_wave(conc + 0.5 * n, rng, iter, site, 0, lane);
-  const double s = (double)__fsqrt_rn((float)((scale + 0.5 * ss) * fast_rcp(g)));
-  return s < ub ? s : ub;
+  return scale_from_gamma(scale, ub, ss, gamma_wave(conc + 0.5 * n, rng, iter, site, 0, lane));
 }
 
 // ------------------------------------------------------------------------------------

@@ -106,7 +106,7 @@ struct TpLds {
   size_t wave0, wave_stride, cm, am, scr, pzv, vb, reg, shared, total;
   size_t big_a, big_p;   // P > MAXP: the swept matrices of the regression block in LDS (0: HBM workspace)
   // regression block (offsets from `reg`)
-  size_t xtx, omega, bvec, aug0, pri0, chol, zv, uperm, nz, perm, idx, w;
+  size_t xtx, omega, bvec, aug0, pri0, chol, zv, uperm, nz, perm, idx, w, trow;
 };
 __host__ __device__ inline TpLds make_tplds(int P, int D) {
   TpLds l;
@@ -130,10 +130,13 @@ __host__ __device__ inline TpLds make_tplds(int P, int D) {
   l.aug0 = take(big ? sizeof(double) * sweep_padded((size_t)(Pp + 1) * (Pp + 1)) : 16);
   l.chol = take(big ? sizeof(double) * Pp * Pp : 16);
   l.zv = take(big ? sizeof(double) * Pp : 16);
-  l.uperm = take(big ? sizeof(double) * Pp : 16);
-  l.nz = take(big ? sizeof(int) * Pp : 16);
-  l.perm = take(big ? sizeof(int) * Pp : 16);
-  l.idx = take(big ? sizeof(int) * Pp : 16);
+  // (P > MAXP: the draw's small state in LDS too -- the matrices may live in the HBM workspace, what
+  // every row of every sweep reads may not: tp_spike_slab_draw_big_wg)
+  l.uperm = take(big || bigp ? sizeof(double) * Pp : 16);
+  l.nz = take(big || bigp ? sizeof(int) * Pp : 16);
+  l.perm = take(big || bigp ? sizeof(int) * Pp : 16);
+  l.idx = take(big || bigp ? sizeof(int) * Pp : 16);
+  l.trow = take(bigp ? sizeof(double) * 4 * (Pp + 1) : 16);   // two saved pivot rows, the weights' solve, the posterior means
   // P > MAXP (spike_slab_draw_big's workspace block): one CU pulls ~20 B/clk out of L2, i.e. a sweep
   // of a 100 x 100 float64 matrix costs 8k cycles there; in LDS it is bandwidth for free.  The
   // augmented matrix A ((P+1)^2 doubles, rebuilt every iteration: overlay) goes to LDS when it
@@ -1285,7 +1288,8 @@ static __device__ __noinline__ void tp_recon_pass(const TpCtx& cref, int s, int 
 // Every thread returns the same new observation-noise scale.
 // ------------------------------------------------------------------------------------
 template <int NTH, class PA, class PP>
-__device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, PP Pm, float* w, int P,
+__device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, PP Pm, CI_LDS double* trow,
+                                                         float* w, int P,
                                                          const DevSeriesParams& sp, double prev_obs_scale,
                                                          double g_obs, const Rng& rng, uint32_t iter,
                                                          int tid, bool first) {
@@ -1295,34 +1299,74 @@ __device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, 
   const double prev_var = prev_obs_scale * prev_obs_scale;
   const double a_post = sp.obs_conc + 0.5 * sp.n_obs;
   const bool all_in = sp.nonzero_prob >= 1.0;
-  double* ta = R.chol + (size_t)P * P;      // saved pivot row of A   [n]
-  double* tp = ta + n;                      // saved pivot row of Pm  [n]
-  // (every loop over a matrix walks rows by wavefront and columns by lane: no integer division)
-  for (int i = wv; i < n; i += NWV_)
+  // (round 6) Everything the draw reads many times per sweep lives in LDS: the saved pivot rows, the
+  // active-set flags, the visiting order, the right-hand side of the weights' solve.  They used to
+  // sit in the chain's HBM workspace with the matrices (bigp_point): every row of every sweep then
+  // waited for an L2 round trip on its pivot-row entry -- 18k cycles per sweep at P = 101, 546k per
+  // iteration.
+  CI_LDS double* ta = trow;                // saved pivot row of A   [n]
+  CI_LDS double* tp = trow + n;            // saved pivot row of Pm  [n]
+  CI_LDS double* zv = trow + 2 * n;        // normals -> solution of the weights' solve; posterior means behind it
+  CI_LDS double* mean = trow + 3 * n;
+  CI_LDS double* uperm = tp_lds<double>(R.uperm);
+  CI_LDS int* nz = tp_lds<int>(R.nz);
+  CI_LDS int* perm = tp_lds<int>(R.perm);
+  CI_LDS int* idx = tp_lds<int>(R.idx);
+  CI_GLB const double* omega = (CI_GLB const double*)R.omega;
+  CI_GLB const double* xtx = (CI_GLB const double*)R.xtx;
+  CI_LDS const double* bvec = tp_lds<double>(R.bvec);
+  // Walks of a matrix: rows by wavefront, FOUR rows of a wavefront in flight (their loads are all
+  // issued before the first store: one memory round trip per batch, not per row), columns by lane.
+  for (int i0 = wv; i0 < n; i0 += 4 * NWV_)
     for (int j = lane; j < n; j += 64) {
-      double v;
-      if (i < P && j < P) v = R.omega[i * P + j] * prev_var + R.xtx[i * P + j];
-      else v = R.bvec[(i == P && j == P) ? P : (i < j ? i : j)];
-      A[i * n + j] = v;
+      double om[4], xx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NWV_;
+        const int ic = i < P ? i : P - 1, jc = j < P ? j : P - 1;
+        om[u] = omega[ic * P + jc]; xx[u] = xtx[ic * P + jc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NWV_;
+        if (i < n) {
+          double v;
+          if (i < P && j < P) v = om[u] * prev_var + xx[u];
+          else v = bvec[(i == P && j == P) ? P : (i < j ? i : j)];
+          A[i * n + j] = v;
+        }
+      }
     }
   if (first)
     for (int i = wv; i < P; i += NWV_)
-      for (int j = lane; j < P; j += 64) Pm[i * P + j] = R.omega[i * P + j];
+      for (int j = lane; j < P; j += 64) Pm[i * P + j] = omega[i * P + j];
   for (int j = tid; j < P; j += NTH) {
-    R.nz[j] = all_in ? 1 : (w[j] != 0.f ? 1 : 0);
-    if (!all_in) R.uperm[j] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j);
+    nz[j] = all_in ? 1 : (w[j] != 0.f ? 1 : 0);
+    if (!all_in) uperm[j] = uniform_d(rng, iter, SITE_PERM, 0, (uint32_t)j);
   }
   tp_wg_barrier();
-  auto sweep_one_wg = [&](auto M, int m, const double* t, int k, double sgn) {
+  auto sweep_one_wg = [&](auto M, int m, CI_LDS const double* t, int k, double sgn) {
     const double rd = 1.0 / t[k];
-    for (int i = wv; i < m; i += NWV_) {
-      const double ti = t[i];
+    for (int i0 = wv; i0 < m; i0 += 4 * NWV_) {
+      double ti[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * NWV_; ti[u] = t[i < m ? i : m - 1]; }
       for (int j = lane; j < m; j += 64) {
-        double v;
-        if (i == k) v = (j == k) ? -rd : sgn * t[j] * rd;
-        else if (j == k) v = sgn * ti * rd;
-        else v = M[i * m + j] - (ti * rd) * t[j];
-        M[i * m + j] = v;
+        const double tj = t[j];
+        double mv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * NWV_; mv[u] = M[(i < m ? i : m - 1) * m + j]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NWV_;
+          if (i < m) {
+            double v;
+            if (i == k) v = (j == k) ? -rd : sgn * tj * rd;
+            else if (j == k) v = sgn * ti[u] * rd;
+            else v = mv[u] - (ti[u] * rd) * tj;
+            M[i * m + j] = v;
+          }
+        }
       }
     }
   };
@@ -1337,16 +1381,16 @@ __device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, 
     tp_wg_barrier();
   };
   for (int k = 0; k < P; ++k)
-    if (R.nz[k]) sweep_both(k, false, first);
+    if (nz[k]) sweep_both(k, false, first);
   if (!all_in) {
     for (int j = tid; j < P; j += NTH) {
-      const double uj = R.uperm[j];
+      const double uj = uperm[j];
       int rank = 0;
       for (int k = 0; k < P; ++k) {
-        const double uk = R.uperm[k];
+        const double uk = uperm[k];
         rank += (uk < uj || (uk == uj && k < j)) ? 1 : 0;
       }
-      R.perm[rank] = j;
+      perm[rank] = j;
     }
     tp_wg_barrier();
     const double logit_pi = log(sp.nonzero_prob) - log1p(-sp.nonzero_prob);
@@ -1356,8 +1400,8 @@ __device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, 
       const int pos = base + lane;
       bool flip = false;
       if (pos < P && pos >= s_cur) {
-        const int j = R.perm[pos];
-        const bool in = R.nz[j] != 0;
+        const int j = perm[pos];
+        const bool in = nz[j] != 0;
         const double ajj = A[j * n + j], ajb = A[j * n + P], corner = A[P * n + P];
         const double pju = Pm[j * P + j];
         const double beta_old = sp.obs_scale + 0.5 * corner;
@@ -1378,11 +1422,11 @@ __device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, 
       const unsigned long long bal = __ballot(flip);
       if (bal == 0ull) { s_cur = base + 64; continue; }
       const int s_star = base + __ffsll((long long)bal) - 1;
-      const int j = R.perm[s_star];
-      const bool in = R.nz[j] != 0;
+      const int j = perm[s_star];
+      const bool in = nz[j] != 0;
       tp_wg_barrier();                       // every wavefront has read the state it decided on
       sweep_both(j, in, true);
-      if (tid == 0) R.nz[j] = in ? 0 : 1;
+      if (tid == 0) nz[j] = in ? 0 : 1;
       tp_wg_barrier();
       s_cur = s_star + 1;
     }
@@ -1395,42 +1439,79 @@ __device__ __noinline__ double tp_spike_slab_draw_big_wg(const RegLds& R, PA A, 
   int na = 0;
   for (int j0 = 0; j0 < P; j0 += 64) {
     const int j = j0 + lane;
-    const int mynz = j < P ? R.nz[j] : 0;
+    const int mynz = j < P ? nz[j] : 0;
     const unsigned long long bal = __ballot(mynz != 0);
-    if (mynz && tid < 64) R.idx[na + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+    if (mynz && tid < 64) idx[na + __popcll(bal & ((1ull << lane) - 1ull))] = j;
     na += __popcll(bal);
   }
   for (int j = tid; j < P; j += NTH) w[j] = 0.f;
   tp_wg_barrier();
-  for (int i = wv; i < na; i += NWV_)
-    for (int j = lane; j < na; j += 64) {
-      const int fi = R.idx[i], fj = R.idx[j];
-      R.chol[i * na + j] = R.omega[fi * P + fj] * prev_var + R.xtx[fi * P + fj];
-    }
-  for (int i = tid; i < na; i += NTH) R.zv[i] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)R.idx[i]);
-  tp_wg_barrier();
-  for (int k = 0; k < na; ++k) {
-    const double dkk = sqrt(R.chol[k * na + k]);
-    tp_wg_barrier();
-    for (int i = k + tid; i < na; i += NTH) R.chol[i * na + k] = (i == k) ? dkk : R.chol[i * na + k] / dkk;
-    tp_wg_barrier();
-    for (int i = k + 1 + wv; i < na; i += NWV_) {
-      const double lik = R.chol[i * na + k];
-      for (int j = k + 1 + lane; j <= i; j += 64) R.chol[i * na + j] -= lik * R.chol[j * na + k];
-    }
-    tp_wg_barrier();
-  }
-  for (int i = na - 1; i >= 0; --i) {
-    const double ui = R.zv[i] / R.chol[i * na + i];
-    tp_wg_barrier();
-    if (tid == 0) R.zv[i] = ui;
-    for (int k = tid; k < i; k += NTH) R.zv[k] -= R.chol[i * na + k] * ui;
-    tp_wg_barrier();
-  }
+  // The posterior means (border column of the swept matrix) are saved, and the included block's
+  // Cholesky factor is built IN PLACE OF A (na <= P rows of na: always fits): in LDS whenever A is.
   for (int i = tid; i < na; i += NTH) {
-    const int f = R.idx[i];
-    w[f] = (float)(A[f * n + P] + new_scale * R.zv[i]);
+    mean[i] = A[idx[i] * n + P];
+    zv[i] = normal_d(rng, iter, SITE_WEIGHTS, 0, (uint32_t)idx[i]);
   }
+  tp_wg_barrier();
+  PA Lm = A;
+  for (int i0 = wv; i0 < na; i0 += 4 * NWV_)
+    for (int j = lane; j < na; j += 64) {
+      double om[4], xx[4];
+      const int fj = idx[j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NWV_;
+        const int fi = idx[i < na ? i : na - 1];
+        om[u] = omega[fi * P + fj]; xx[u] = xtx[fi * P + fj];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NWV_;
+        if (i < na) Lm[i * na + j] = om[u] * prev_var + xx[u];
+      }
+    }
+  tp_wg_barrier();
+  // right-looking, one barrier per column: every thread scales its own operands by 1 / L_kk (the
+  // same quotients whoever computes them), column k of L goes to the UPPER triangle (row k) and the
+  // diagonal to `tp`, so nothing a concurrent thread still reads is overwritten
+  CI_LDS double* ldiag = tp;
+  for (int k = 0; k < na; ++k) {
+    const double dkk = sqrt(Lm[k * na + k]);
+    for (int i = k + 1 + wv; i < na; i += NWV_) {
+      const double lik = Lm[i * na + k] / dkk;
+      for (int j = k + 1 + lane; j <= i; j += 64) Lm[i * na + j] -= lik * (Lm[j * na + k] / dkk);
+      if (lane == 0) Lm[k * na + i] = lik;
+    }
+    if (tid == 0) ldiag[k] = dkk;
+    tp_wg_barrier();
+  }
+  // L' u = z by column-oriented back substitution: L_ik sits at row k, column i of the upper triangle
+  if (na <= 64) {
+    // one wavefront, z_l in lane l's registers, u_i broadcast by v_readlane: no barriers (the same
+    // quotients and multiply-subtracts as the loop below)
+    if (wv == 0) {
+      double z = lane < na ? zv[lane] : 0.0;
+      double lnext = (na > 0 && lane < na - 1) ? Lm[lane * na + (na - 1)] : 0.0;
+      for (int i = na - 1; i >= 0; --i) {
+        const double li = lnext;
+        if (i > 0) lnext = lane < i - 1 ? Lm[lane * na + (i - 1)] : 0.0;
+        const double ui = readlane_d(z, i) / ldiag[i];
+        if (lane == i) z = ui;
+        if (lane < i) z -= li * ui;
+      }
+      if (lane < na) zv[lane] = z;
+    }
+    tp_wg_barrier();
+  } else {
+    for (int i = na - 1; i >= 0; --i) {
+      const double ui = zv[i] / ldiag[i];
+      tp_wg_barrier();
+      if (tid == 0) zv[i] = ui;
+      for (int k = tid; k < i; k += NTH) zv[k] -= Lm[k * na + i] * ui;
+      tp_wg_barrier();
+    }
+  }
+  for (int i = tid; i < na; i += NTH) w[idx[i]] = (float)(mean[i] + new_scale * zv[i]);
   tp_wg_barrier();
   return new_scale;
 }
@@ -1528,7 +1609,13 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
   R.nz = tp_opaque((int*)(smem + LL.reg + LL.nz)); R.perm = tp_opaque((int*)(smem + LL.reg + LL.perm));
   R.idx = tp_opaque((int*)(smem + LL.reg + LL.idx));
   const bool bigp = P > MAXP;
-  if (bigp) bigp_point(R, wsc + L.big, P);
+  if (bigp) {
+    // the matrices (and X'X, Omega) in the chain's HBM workspace -- or in LDS where the host found
+    // room (big_a / big_p) --, the draw's small state in LDS
+    int* nz_l = R.nz; int* perm_l = R.perm; int* idx_l = R.idx; double* uperm_l = R.uperm;
+    bigp_point(R, wsc + L.big, P);
+    R.nz = nz_l; R.perm = perm_l; R.idx = idx_l; R.uperm = uperm_l;
+  }
   const DevSeriesParams sp = g.sp[series];
   const DevSeasonalParams ss = a.ssp[series];
   const Rng rng{stream_key0(g.seed0, g.series_stream_base, series), stream_key1(g.seed1, g.series_stream_base, series),
@@ -1760,13 +1847,13 @@ __global__ __launch_bounds__(TP_NT) void gibbs_seasonal_tp_kernel(SArgs a) {
       typedef CI_GLB double* GD;
       double ns;
       if (LL.big_a && LL.big_p)
-        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, tp_lds<double>(smem + LL.reg + LL.big_a), tp_lds<double>(smem + LL.big_p), R.w, P, sp,
+        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, tp_lds<double>(smem + LL.reg + LL.big_a), tp_lds<double>(smem + LL.big_p), tp_lds<double>(smem + LL.reg + LL.trow), R.w, P, sp,
                                               shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
       else if (LL.big_a)
-        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, tp_lds<double>(smem + LL.reg + LL.big_a), (GD)R.pri[0], R.w, P, sp,
+        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, tp_lds<double>(smem + LL.reg + LL.big_a), (GD)R.pri[0], tp_lds<double>(smem + LL.reg + LL.trow), R.w, P, sp,
                                               shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
       else
-        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, (GD)R.aug[0], (GD)R.pri[0], R.w, P, sp,
+        ns = tp_spike_slab_draw_big_wg<TP_NT>(R, (GD)R.aug[0], (GD)R.pri[0], tp_lds<double>(smem + LL.reg + LL.trow), R.w, P, sp,
                                               shd[0], shd[1], rng, (uint32_t)it, tid, it == 0);
       if (wave == 0) obs_scale = ns;
     }

@@ -316,7 +316,7 @@ __device__ __forceinline__ E block_scan_excl_bwd_rolled(const E& tot, Op op, con
 
 struct WLayout {
   size_t xtx, omega, aug0, aug1, pri0, pri1, chol, bvec, zv, uperm, nz, perm, idx, w, scal, red,
-      st, gsum, big0, total;
+      st, bpre, gsum, big0, total;
 };
 // The small arrays first, the regression block's matrices from `big0` on: a DK worker that is
 // neither the main workgroup nor the sweeper never touches the matrices, and keeps the per-step
@@ -337,7 +337,8 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   l.scal = take(sizeof(float) * 16);
   l.red = take(sizeof(float) * NW * ((Pp > 16 ? Pp : 16) + 4));
   (void)D;
-  l.st = take(sizeof(double) * 4);      // serial wave -> block: previous sigma_obs, gamma variate
+  l.st = take(sizeof(double) * 8);      // serial wave -> block: previous sigma_obs, gamma variate; [2..5] gamma variates drawn ahead
+  l.bpre = take(sizeof(double) * BLOCK_PRE_DOUBLES);   // the regression block's randomness (block_randoms) drawn ahead
   l.gsum = take(sizeof(double) * NW * 64);   // quarter sums of the segment partials
   o = (o + 127) & ~(size_t)127;
   l.big0 = o;
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   float* red = (float*)(smem + lay.red);
   double* st = (double*)(smem + lay.st);
   double* gsum = (double*)(smem + lay.gsum);
+  double* bpre = (double*)(smem + lay.bpre);
   const int RS = (P > 16 ? P : 16) + 4;
 
   // per-chain HBM workspace
@@ -556,9 +558,10 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   DkSync dsy;
   dsy.cnt = csync + CL_DK; dsy.flag = csync + CL_DKFLAG; dsy.latcnt = csync + CL_LATCNT; dsy.latflag = csync + CL_LATENTS;
   dsy.Gd = Gd; dsy.epoch = 0; dsy.cluster = G > 1; dsy.light = light;
-  // (the draw's per-step rows in LDS: only where the DK workers are helpers that never touch the
-  // regression block's matrices -- sixteen workgroups -- and the host found room)
-  const bool dk_lds = a.dk_lds != 0 && G == 16;
+  // (the draw's per-step rows in LDS: on the DK workers that are helpers -- they never touch the
+  // regression block's matrices -- when every worker runs ONE virtual workgroup (clusters of sixteen
+  // or eight) and the host found room)
+  const bool dk_lds = a.dk_lds != 0 && (G == 16 || (G == 8 && role > 0));   // (eight: main is a DK worker and keeps its matrices)
   DkCtx dk;
   dk.lv = (CI_LDS float*)(smem + lay.big0);
   dk.lkr = dk.lv + DK_VS * NT;
@@ -655,14 +658,20 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         const float4 loc = make_float4(lv.x + sv.x + xv.x, lv.y + sv.y + xv.y, lv.z + sv.z + xv.z,
                                        lv.w + sv.w + xv.w);
         const size_t at = row + 4 * (size_t)c;
-        if (g.out_level) *reinterpret_cast<float4*>(g.out_level + at) = lv;
-        if (g.out_slope && TR == 2)
-          *reinterpret_cast<float4*>(g.out_slope + at) = *reinterpret_cast<const float4*>(slpw + 4 * c);
-        if (a.out_seasonal) *reinterpret_cast<float4*>(a.out_seasonal + at) = sv;
+        // (the draws are written once and never read by the kernel: streamed past the L2's
+        // retention, which the chain's design matrix and workspace need)
+        auto put = [](float* p, float x, float y, float z, float w_) {
+          __builtin_nontemporal_store(ci_f4v{x, y, z, w_}, reinterpret_cast<ci_f4v*>(p));
+        };
+        if (g.out_level) put(g.out_level + at, lv.x, lv.y, lv.z, lv.w);
+        if (g.out_slope && TR == 2) {
+          const float4 sl4 = *reinterpret_cast<const float4*>(slpw + 4 * c);
+          put(g.out_slope + at, sl4.x, sl4.y, sl4.z, sl4.w);
+        }
+        if (a.out_seasonal) put(a.out_seasonal + at, sv.x, sv.y, sv.z, sv.w);
         if (g.out_traj)
-          *reinterpret_cast<float4*>(g.out_traj + at) =
-              make_float4(fmaf(so, zp[0], loc.x), fmaf(so, zp[1], loc.y), fmaf(so, zp[2], loc.z),
-                          fmaf(so, zp[3], loc.w));
+          put(g.out_traj + at, fmaf(so, zp[0], loc.x), fmaf(so, zp[1], loc.y), fmaf(so, zp[2], loc.z),
+              fmaf(so, zp[3], loc.w));
         if (g.out_pred_mean) {
           float4* pm = reinterpret_cast<float4*>(g.out_pred_mean + chain_lin * T + 4 * c);
           float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -914,13 +923,12 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       double emit_obs = obs_scale;
       if (it > 0) {
         const uint32_t pit = (uint32_t)(it - 1);
-        level_scale = scale_draw(sp.level_conc, sp.level_scale, sp.level_ub, (double)(T - 1),
-                                 R.bvec[P + 1], rng, pit, SITE_LEVEL_SCALE, lane);
+        // (the gamma variates of these draws were drawn at the end of the previous pass: draw_ahead)
+        level_scale = scale_from_gamma(sp.level_scale, sp.level_ub, R.bvec[P + 1], st[2]);
         if constexpr (TR == 2)
-          slope_scale = scale_draw(sp.slope_conc, sp.slope_scale, sp.slope_ub, (double)(T - 1),
-                                   R.bvec[P + 2], rng, pit, SITE_SLOPE_SCALE, lane);
+          slope_scale = scale_from_gamma(sp.slope_scale, sp.slope_ub, R.bvec[P + 2], st[3]);
         {
-          const double gk = gamma_wave(ss.drift_conc + 0.5 * n_changes, rng, pit, SITE_DRIFT_SCALE, 0, lane);
+          const double gk = st[4];
           const double sd = (double)__fsqrt_rn((float)((ss.drift_scale + 0.5 * R.bvec[P + 3]) * fast_rcp(gk)));
           drift = sd < ss.drift_ub ? sd : ss.drift_ub;
         }
@@ -952,7 +960,8 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         }
       }
       if (P > 0 && it < n_iter) {
-        const double g_obs = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
+        const double g_obs = it > 0 ? st[5]
+                                    : gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, (uint32_t)it, SITE_OBSVAR, 0, lane);
         if (P <= 16) {
           obs_scale = spike_slab_draw_regs(R, P, sp, obs_scale, g_obs, rng, (uint32_t)it, lane, prof, pc);
         } else if (lane == 0) {       // drawn by the whole workgroup below
@@ -975,7 +984,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       const bool prepared = sweep_role > 0 && it > 0;      // a helper of the cluster swept the matrix
       if (prepared) cl_wait(csync + CL_V, 1, it, tid);
       obs_scale = spike_slab_draw_block(R, P, sp, st[0], st[1], rng, (uint32_t)it, tid, it == 0, &prof,
-                                        true, prepared ? cv : nullptr);
+                                        true, prepared ? cv : nullptr, 4, it > 0 ? bpre : nullptr);
       if (tid == 0) scal[0] = (float)obs_scale;
       __syncthreads();
       prof.tick(10);
@@ -1050,8 +1059,26 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     // the Durbin-Koopman draw, by the cluster's DK workers together; its last worker raises the
     // latents flag to it + 2
     if (dk_worker) {
-      if (dk_lds) wide_dk_quad<TR, NS, true>(sc, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, false, true);
+      if (dk_lds) wide_dk_quad<TR, NS, true>(sc, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, !early_a, true);
       else wide_dk_quad<TR, NS, false>(sc, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, !early_a, true);
+    }
+    // Main, before it waits for the latents (with sixteen workgroups it is idle through the whole
+    // draw): everything of the next serial section that needs no data -- the gamma variates of this
+    // iteration's scale draws and of the next sigma^2_obs, the regression block's visiting order,
+    // flip uniforms and weight normals.  Same sites, same counters: the same numbers as drawn in place.
+    if (role == 0) {
+      if (wave == 0) {
+        const uint32_t pit = (uint32_t)it;
+        const double g_lev = gamma_wave(sp.level_conc + 0.5 * (double)(T - 1), rng, pit, SITE_LEVEL_SCALE, 0, lane);
+        double g_slp = 1.0;
+        if constexpr (TR == 2)
+          g_slp = gamma_wave(sp.slope_conc + 0.5 * (double)(T - 1), rng, pit, SITE_SLOPE_SCALE, 0, lane);
+        const double g_drf = gamma_wave(ss.drift_conc + 0.5 * n_changes, rng, pit, SITE_DRIFT_SCALE, 0, lane);
+        const double g_obn = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, pit + 1u, SITE_OBSVAR, 0, lane);
+        if (lane == 0) { st[2] = g_lev; st[3] = g_slp; st[4] = g_drf; st[5] = g_obn; }
+      } else if (wave == 1 && P > 16) {
+        block_randoms_store(block_randoms(rng, (uint32_t)it + 1u, P, lane), bpre, lane);
+      }
     }
     if (role == 0 && G > 1) cl_wait(csync + CL_LATENTS, 1, it + 2, tid);
   }

@@ -920,19 +920,68 @@ def test_time_parallel_and_sequential_general_seasonal_kernels_sample_the_same_p
                              atol=0.04)
 
 
-def test_trend_models_with_more_than_52_covariates_keep_their_sequential_route_too():
-  """Trend + P > 52 runs on the time-parallel kernel by default (test_first_iterations_...: 61,
-  131, 71, 512 columns); the sequential one-wavefront route stays reachable and equal per draw."""
+def test_trend_models_with_more_than_52_covariates_agree_on_their_three_routes():
+  """Trend + 53..~150 columns runs on the BIGP build of the trend + one-block kernel by default
+  (round 6: ci_wide.h with the regression draw of ci_bigp.h; test_first_iterations_...: 61 and 131
+  columns against the oracle); the general time-parallel kernel (CI_FLAG_CLUSTER_SEASONAL; the route
+  of wider designs: 512 columns in that test) and the sequential one-wavefront kernel stay
+  reachable and equal per draw."""
   T, p = 400, 60
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 0)
   spec = orc.default_spec(y, mask, X, has_slope=False)
   out = {}
-  for flags in (0, SEQ):
+  for flags in (0, _native.FLAG_CLUSTER_SEASONAL, SEQ):
     pb = _native.make_problem(T=T, P=spec["P"], has_slope=0, num_warmup=0, num_results=4, seed=(5, 9), flags=flags)
     sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
     out[flags] = (sess.kernel_name(), sess.run(), sess.fetch())
     sess.close()
-  assert "tp_kernel" in out[0][0] and "gibbs_seasonal_kernel" in out[SEQ][0]
-  np.testing.assert_array_equal(out[0][2]["weights"] != 0, out[SEQ][2]["weights"] != 0)
-  np.testing.assert_allclose(out[0][2]["level"], out[SEQ][2]["level"], atol=2e-3)
-  np.testing.assert_allclose(out[0][2]["weights"], out[SEQ][2]["weights"], atol=2e-3)
+  assert "gibbs_wide_kernel" in out[0][0] and "bigp" in out[0][0]
+  assert "tp_kernel" in out[_native.FLAG_CLUSTER_SEASONAL][0] and "gibbs_seasonal_kernel" in out[SEQ][0]
+  for other in (_native.FLAG_CLUSTER_SEASONAL, SEQ):
+    np.testing.assert_array_equal(out[0][2]["weights"] != 0, out[other][2]["weights"] != 0)
+    np.testing.assert_allclose(out[0][2]["level"], out[other][2]["level"], atol=2e-3)
+    np.testing.assert_allclose(out[0][2]["weights"], out[other][2]["weights"], atol=2e-3)
+
+
+@pytest.mark.parametrize("T,p,has_slope,seasons", [
+    (1000, 100, 0, ()),            # the P = 101 case of the round-5 review, trend only
+    (600, 70, 1, ((7, 1),)),       # local linear trend + weekly block, 71 columns
+    (2048, 139, 0, ()),            # close to the widest design whose matrix and index table fit in LDS
+])
+def test_wide_kernel_with_more_than_52_columns_matches_the_oracle_and_any_cluster_size(T, p, has_slope, seasons):
+  """The BIGP builds of ci_wide.h: per draw against the float64 oracle, and the same bits from one
+  workgroup per chain (CI_FLAG_NO_CLUSTER), the default cluster and a launch of 40 chains (smaller
+  clusters)."""
+  from causalimpact import _model
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 11)
+  if seasons:
+    y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  spec = orc.default_spec(y, mask, X, has_slope=bool(has_slope), seasons=seasons)
+  counts, flg = (_model.expand_seasons(seasons, T) if seasons else ((), None))
+  S = 3
+
+  def fit(C, flags):
+    pb = _native.make_problem(T=T, P=spec["P"], has_slope=has_slope, num_seasons=counts, num_warmup=0,
+                              num_results=S, num_chains=C, seed=(2, 6), flags=flags)
+    sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+    name = sess.kernel_name()
+    sess.run()
+    got = sess.fetch()
+    sess.close()
+    return name, got
+
+  name, one = fit(1, _native.FLAG_NO_CLUSTER)
+  assert "gibbs_wide_kernel" in name and "bigp" in name
+  _, many = fit(1, 0)
+  _, crowd = fit(40, 0)
+  for k, v in one.items():
+    np.testing.assert_array_equal(many[k], v, err_msg=k)
+    np.testing.assert_array_equal(crowd[k][:, :1], v, err_msg=k)
+  w = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=0, seed=(2, 6))
+  np.testing.assert_array_equal(one["weights"][0, 0] != 0, w["weights"] != 0)
+  np.testing.assert_allclose(one["level"][0, 0], w["level"], atol=5e-3)
+  np.testing.assert_allclose(one["weights"][0, 0], w["weights"], atol=5e-3)
+  np.testing.assert_allclose(one["observation_noise_scale"][0, 0], w["obs_scale"], rtol=5e-3)
+  np.testing.assert_allclose(one["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
+  if seasons:
+    np.testing.assert_allclose(one["seasonal_levels"][0, 0], w["seasonal"], atol=5e-3)

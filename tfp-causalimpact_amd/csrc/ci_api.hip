@@ -37,6 +37,10 @@ extern "C" void* ci_gibbs_seasonal_tp_fn_nq8(void);
 extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs*, int, hipStream_t);
 extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs*, int, hipStream_t);
 extern "C" void ci_launch_gibbs64(const ci::G64Args*, int, size_t, int, hipStream_t);
+extern "C" void* ci_gibbs_wide_bigp_fn_tr1_ns2(void);
+extern "C" void* ci_gibbs_wide_bigp_fn_tr2_ns2(void);
+extern "C" void* ci_gibbs_wide_bigp_fn_tr1_ns7(void);
+extern "C" void* ci_gibbs_wide_bigp_fn_tr2_ns7(void);
 #define CI_WIDE_DECL(NS)                                  \
   extern "C" void* ci_gibbs_wide_fn_tr1_ns##NS(void);     \
   extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);     \
@@ -357,7 +361,24 @@ void* pick_wide_kernel(int has_slope, int num_seasons) {
 #undef CI_WIDE_CASE
   return nullptr;
 }
+// ... and its BIGP builds (53+ design columns): trend-only models (through the inert 2-season block)
+// and trend + a weekly block, while the packed regression matrix and its index table fit in LDS
+// (P <= ~150); wider designs, other block lists and very short series keep the general routes.
+void* pick_wide_bigp_kernel(int has_slope, int num_seasons) {
+  if (num_seasons == 2) return has_slope ? ci_gibbs_wide_bigp_fn_tr2_ns2() : ci_gibbs_wide_bigp_fn_tr1_ns2();
+  if (num_seasons == 7) return has_slope ? ci_gibbs_wide_bigp_fn_tr2_ns7() : ci_gibbs_wide_bigp_fn_tr1_ns7();
+  return nullptr;
+}
+bool wide_bigp_ok(const ci_problem* pb) {
+  if (pb->P <= ci::MAXP || pb->T < 64) return false;
+  if (pb->flags & (CI_FLAG_SEQUENTIAL_SEASONAL | CI_FLAG_CLUSTER_SEASONAL | CI_FLAG_SEASONAL_WORKSPACE)) return false;
+  if (!(pb->num_blocks == 0 || (pb->num_blocks == 1 && (pb->num_seasons[0] == 2 || pb->num_seasons[0] == 7))))
+    return false;
+  const int d = (pb->has_slope ? 2 : 1) + (pb->num_blocks == 1 ? pb->num_seasons[0] - 1 : 1);
+  return ci::make_wlayout(pb->P, d).total <= 160 * 1024 - 512;
+}
 bool use_wide(const ci_problem* pb) {
+  if (pb->num_blocks == 1 && pb->P > ci::MAXP) return wide_bigp_ok(pb);
   return pb->num_blocks == 1 && pb->P <= ci::MAXP && !(pb->flags & CI_FLAG_SEQUENTIAL_SEASONAL) &&
          !(pb->flags & CI_FLAG_CLUSTER_SEASONAL) &&
          pick_wide_kernel(pb->has_slope, pb->num_seasons[0]) != nullptr;
@@ -626,7 +647,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
   // More than MAXP design columns: every model runs on the sequential one-wavefront kernel, whose
   // regression block then keeps its O(P^2) arrays in a per-chain HBM workspace (any T as well).
   const bool bigp = pb->P > ci::MAXP;
-  const bool long_trend = pb->num_blocks == 0 && steps_per_thread(pb->T) == 0 && !bigp;
+  // (53+ columns, trend only: the BIGP build of that kernel, at any length -- wide_bigp_ok)
+  const bool long_trend = pb->num_blocks == 0 && ((steps_per_thread(pb->T) == 0 && !bigp) || wide_bigp_ok(pb));
   std::vector<uint8_t> no_changes;
   if (long_trend) {
     s->kpb.num_blocks = 1;
@@ -709,7 +731,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     if (s->wide) {
       s->Lc = ci::wide_quad_steps(T);
       s->lds_bytes = ci::make_wlayout(P, s->dred).total;
-      s->fn = (KernelFn)pick_wide_kernel(pb->has_slope, pb->num_seasons[0]);
+      s->fn = (KernelFn)(bigp ? pick_wide_bigp_kernel(pb->has_slope, pb->num_seasons[0])
+                              : pick_wide_kernel(pb->has_slope, pb->num_seasons[0]));
     } else {
       // arrays over time in LDS when the whole layout fits (fastest), else in a per-chain HBM
       // workspace: no bound on the series length, and room in LDS for the P > 16 regression block
@@ -766,7 +789,7 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
     char nm[96];
     if (s->tp) snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_tp_kernel<%d> %d chunks x%d", ci::tp_nr(s->D_full) / 4,
                         s->Lc * ci::TP_NWV, s->cluster);
-    else if (s->wide) snprintf(nm, sizeof(nm), "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
+    else if (s->wide) snprintf(nm, sizeof(nm), bigp ? "ci::gibbs_wide_kernel<%d,%d,bigp>" : "ci::gibbs_wide_kernel<%d,%d>", D, pb->num_seasons[0]);
     else snprintf(nm, sizeof(nm), "ci::gibbs_seasonal_kernel<%s,%s>", s->seasonal_gws ? "true" : "false",
                   bigp ? "true" : "false");
     s->kernel_name = nm;
@@ -838,8 +861,8 @@ int ci_session_create(const ci_problem* pb, const float* y, const uint8_t* mask,
       const size_t RS = (size_t)(P > 16 ? P : 16) + 4;
       HIP_TRY(s->csync.alloc((size_t)B * C * ci::CL_INTS));
       HIP_TRY(s->cpart.alloc((size_t)B * C * (nseg > 0 ? nseg : 1) * ci::NW * RS));
-      HIP_TRY(s->cw.alloc((size_t)B * C * 64));
-      HIP_TRY(s->cv.alloc((size_t)B * C * ci::presweep_doubles(P)));
+      HIP_TRY(s->cw.alloc((size_t)B * C * ci::wide_cw_floats(P)));
+      HIP_TRY(s->cv.alloc((size_t)B * C * ci::wide_cv_doubles(P)));
     }
     else if (s->tp) {
       HIP_TRY(s->ws.alloc((size_t)B * C * (s->tp_ws_bytes / sizeof(float))));

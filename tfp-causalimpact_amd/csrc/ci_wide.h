@@ -26,6 +26,7 @@
 #pragma once
 #include "ci_kernels.h"
 #include "ci_seasonal.h"   // SArgs, DevSeasonalParams (declarations only in this TU)
+#include "ci_bigp.h"       // the regression draw of the BIGP builds (53+ design columns)
 
 namespace ci {
 
@@ -314,15 +315,17 @@ __device__ __forceinline__ E block_scan_excl_bwd_rolled(const E& tot, Op op, con
   return acc;
 }
 
-struct WLayout {
+// (the layout of the <= 52-column builds, kept apart from the BIGP one below: the kernel's code
+// generation is sensitive to what the layout struct carries)
+struct WLayoutS {
   size_t xtx, omega, aug0, aug1, pri0, pri1, chol, bvec, zv, uperm, nz, perm, idx, w, scal, red,
       st, bpre, gsum, big0, total;
 };
 // The small arrays first, the regression block's matrices from `big0` on: a DK worker that is
 // neither the main workgroup nor the sweeper never touches the matrices, and keeps the per-step
 // workspace of its share of the Durbin-Koopman draw there (wide_dk_lds_bytes, ci_wide_quad.h).
-__host__ __device__ inline WLayout make_wlayout(int P, int D) {
-  WLayout l;
+__host__ __device__ inline WLayoutS make_wlayout_small(int P, int D) {
+  WLayoutS l;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
   const int Pp = P > 0 ? P : 1;
@@ -351,6 +354,77 @@ __host__ __device__ inline WLayout make_wlayout(int P, int D) {
   l.chol = take(big ? sizeof(double) * block_chol_doubles(Pp) : 16);   // recorded pivot rows / Cholesky + staging
   l.total = o;
   return l;
+}
+struct WLayout {
+  size_t xtx, omega, aug0, aug1, pri0, pri1, chol, bvec, zv, uperm, nz, perm, idx, w, scal, red,
+      st, bpre, gsum, big0, total;
+  // BIGP builds (P > MAXP; spike_slab_draw_big_wg): aug0 = the packed swept matrix, pri0 = the packed
+  // swept prior block when it fits (pm_lds; else the chain's workspace), the sweeps' (i, j) table,
+  // the draw's row buffers; gs = doubles per wave of `gsum`
+  size_t ijtab, trow;
+  int pm_lds, gs;
+};
+// The small arrays first, the regression block's matrices from `big0` on: a DK worker that is
+// neither the main workgroup nor the sweeper never touches the matrices, and keeps the per-step
+// workspace of its share of the Durbin-Koopman draw there (wide_dk_lds_bytes, ci_wide_quad.h).
+__host__ __device__ inline WLayout make_wlayout(int P, int D) {
+  WLayout l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
+  const int Pp = P > 0 ? P : 1;
+  const bool bigp = P > MAXP;
+  const bool big = P > 16 && !bigp;    // the LDS-resident regression block of 17..MAXP columns
+  l.gs = bigp ? ((Pp + 1 + 63) & ~63) : 64;
+  l.bvec = take(sizeof(double) * (Pp + 4));
+  l.zv = take(sizeof(double) * Pp);
+  l.uperm = take(sizeof(double) * Pp);
+  l.nz = take(sizeof(int) * Pp);
+  l.perm = take(sizeof(int) * Pp);
+  l.idx = take(sizeof(int) * Pp);
+  l.w = take(sizeof(float) * (Pp > 16 ? Pp : 16));
+  l.scal = take(sizeof(float) * 16);
+  l.red = take(sizeof(float) * NW * ((Pp > 16 ? Pp : 16) + 4));
+  (void)D;
+  l.st = take(sizeof(double) * 8);      // serial wave -> block: previous sigma_obs, gamma variate; [2..5] gamma variates drawn ahead
+  l.bpre = take(sizeof(double) * BLOCK_PRE_DOUBLES);   // the regression block's randomness (block_randoms) drawn ahead
+  l.gsum = take(sizeof(double) * NW * l.gs);   // quarter sums of the segment partials
+  l.trow = 0;
+  if (bigp) l.trow = take(sizeof(double) * bigp_trow_doubles(Pp));
+  o = (o + 127) & ~(size_t)127;
+  l.big0 = o;
+  l.ijtab = 0; l.pm_lds = 0;
+  if (bigp) {
+    // X'X and Omega stay where the setup kernel left them (global memory)
+    l.xtx = take(16); l.omega = take(16);
+    l.aug0 = take(sizeof(double) * bigp_packed(Pp + 1));
+    l.aug1 = take(16);
+    l.ijtab = take(sizeof(unsigned) * bigp_packed(Pp + 1));
+    const size_t p_bytes = sizeof(double) * bigp_packed(Pp);
+    l.pm_lds = o + p_bytes + 64 <= 160 * 1024 - 512 ? 1 : 0;
+    l.pri0 = take(l.pm_lds ? p_bytes : 16);
+    l.pri1 = take(16);
+    l.chol = take(16);
+    l.total = o;
+    return l;
+  }
+  l.xtx = take(sizeof(double) * Pp * Pp);
+  l.omega = take(sizeof(double) * Pp * Pp);
+  l.aug0 = take(big ? sizeof(double) * block_matrix_doubles(Pp + 1) : 16);
+  l.aug1 = take(16);
+  l.pri0 = take(big ? sizeof(double) * block_matrix_doubles(Pp) : 16);
+  l.pri1 = take(16);
+  l.chol = take(big ? sizeof(double) * block_chol_doubles(Pp) : 16);   // recorded pivot rows / Cholesky + staging
+  l.total = o;
+  return l;
+}
+// floats of the per-chain cluster message `cw`: weights [P], emission scale, then (from cw0) sigma_obs
+// as a double and the four scales of the draw
+__host__ __device__ inline int wide_cw0(int P) { return P > MAXP ? ((P + 4) & ~3) : 56; }
+__host__ __device__ inline int wide_cw_floats(int P) { return P > MAXP ? wide_cw0(P) + 8 : 64; }
+// doubles of the per-chain buffer `cv`: the matrix swept ahead (17..MAXP columns), or the BIGP builds'
+// workspace -- the swept prior block when it has no room in LDS, then the included block's factor
+__host__ __device__ inline size_t wide_cv_doubles(int P) {
+  return P > MAXP ? 2 * (size_t)P * P + 16 : presweep_doubles(P);
 }
 // LDS a DK worker needs to keep its share of the draw's per-step rows (K_t / r_{t-1}: 8 floats, y~ /
 // v/F: 1 float, for 64 chunks of Lc steps) and the 72 floats per lane parked between the phases
@@ -471,7 +545,10 @@ __device__ __forceinline__ int cl_assemble(int* csync, int role, int G, int tid)
 // the persistent Gibbs kernel (same iteration structure as gibbs_kernel / the oracle's
 // ci_oracle_fit_gibbs; gibbs_sampler.fit_with_gibbs_sampling called at causalimpact_lib.py:365)
 // ------------------------------------------------------------------------------------
-template <int TR, int NS>
+// BIGP: the build for 53+ design columns (its own instantiation: the kernels for <= 52 columns are
+// what they were) -- X'X / Omega in global memory, the regression draw of ci_bigp.h by the main
+// workgroup, no sweeper, wider cluster message and partial-sum rows.
+template <int TR, int NS, bool BIGP = false>
 __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   using W = WDim<TR, NS>;
   constexpr int D = W::D, O = W::O, N1 = W::N1;
@@ -492,7 +569,9 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   }
   const int series = chain_id / g.C, chain = chain_id % g.C;
   const size_t chain_lin = (size_t)series * g.C + chain;
-  const WLayout lay = make_wlayout(P, D);
+  typedef typename std::conditional<BIGP, WLayout, WLayoutS>::type Lay;
+  Lay lay;
+  if constexpr (BIGP) lay = make_wlayout(P, D); else lay = make_wlayout_small(P, D);
   RegLds R;
   R.xtx = (double*)(smem + lay.xtx); R.omega = (double*)(smem + lay.omega);
   R.aug[0] = (double*)(smem + lay.aug0); R.aug[1] = (double*)(smem + lay.aug1);
@@ -501,6 +580,13 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   R.zv = (double*)(smem + lay.zv); R.uperm = (double*)(smem + lay.uperm);
   R.nz = (int*)(smem + lay.nz); R.perm = (int*)(smem + lay.perm); R.idx = (int*)(smem + lay.idx);
   R.w = (float*)(smem + lay.w);
+  if constexpr (BIGP) {      // X'X and Omega where the setup kernel left them
+    R.bvec = bp_opaque(R.bvec); R.zv = bp_opaque(R.zv); R.uperm = bp_opaque(R.uperm);
+    R.nz = bp_opaque(R.nz); R.perm = bp_opaque(R.perm); R.idx = bp_opaque(R.idx);
+    R.aug[0] = bp_opaque(R.aug[0]); R.aug[1] = R.aug[0]; R.pri[0] = bp_opaque(R.pri[0]); R.pri[1] = R.pri[0];
+    R.xtx = const_cast<double*>(g.xtx + (size_t)series * P * P);
+    R.omega = const_cast<double*>(g.omega + (size_t)series * P * P);
+  }
   float* scal = (float*)(smem + lay.scal);
   float* red = (float*)(smem + lay.red);
   double* st = (double*)(smem + lay.st);
@@ -539,8 +625,12 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   const int G = cmode == 3 ? 1 : GL;          // workgroups actually sharing this chain
   const bool light = cmode == 2;
   float* cpart = a.cpart + chain_lin * (size_t)nseg * NW * RS;
-  float* cw = a.cw + chain_lin * 64;
-  double* cv = a.cv + chain_lin * presweep_doubles(P);
+  int GS = 64;                          // (constants in the <= 52-column builds)
+  if constexpr (BIGP) GS = lay.gs;
+  const int CW0 = BIGP ? wide_cw0(P) : 56;
+  float* cw = a.cw + chain_lin * (BIGP ? wide_cw_floats(P) : 64);
+  double* cv = a.cv + chain_lin * (BIGP ? wide_cv_doubles(P) : presweep_doubles(P));
+  if constexpr (BIGP) R.chol = cv + (size_t)P * P;      // (the included block's factor when it has no room in LDS)
   const int clo = (int)((long long)(TP >> 2) * role / G), chi = (int)((long long)(TP >> 2) * (role + 1) / G);
   const int n_iter = g.W + g.S;
   // The Durbin-Koopman draw runs on the cluster's first Gd workgroups (ci_wide_quad.h); with eight
@@ -701,7 +791,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
 
   // (4) X w and the residual of chunks [lo, hi) (T % 4 == 0): only the INCLUDED features' rows are
   // streamed (a zero weight contributes an exact zero)
-  auto xw_range = [&](int lo, int hi) {
+  auto xw_range_small = [&](int lo, int hi) {
     const unsigned long long included = __ballot(lane < P && R.w[lane < P ? lane : 0] != 0.f);
     for (int c4 = lo + tid; c4 < hi; c4 += NT) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f), yv = s;
@@ -733,9 +823,65 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     }
   };
 
+  // ... BIGP builds: the included features in blocks of 64 columns
+  auto xw_range_big = [&](int lo, int hi) {
+    // (the included features in blocks of 64 columns: BIGP builds; one mask otherwise)
+    constexpr int NBLK = BIGP ? 8 : 1;
+    unsigned long long included[NBLK];
+    if constexpr (BIGP) {
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        const int j = 64 * b + lane;
+        included[b] = __ballot(j < P && R.w[j < P ? j : 0] != 0.f);
+      }
+    } else {
+      included[0] = __ballot(lane < P && R.w[lane < P ? lane : 0] != 0.f);
+    }
+    for (int c4 = lo + tid; c4 < hi; c4 += NT) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f), yv = s;
+      if (4 * c4 < T) {
+        auto block = [&](unsigned long long mask, int base) __attribute__((always_inline)) {
+          for (unsigned long long todo = mask; todo != 0ull;) {
+            float4 xv[XR];
+            float wj[XR];
+#pragma unroll
+            for (int q = 0; q < XR; ++q) {
+              const bool have = todo != 0ull;
+              const int j = have ? base + __ffsll((long long)todo) - 1 : 0;
+              todo &= todo - 1ull;
+              wj[q] = have ? R.w[j] : 0.f;
+              xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * c4);
+            }
+#pragma unroll
+            for (int q = 0; q < XR; ++q) {
+              s.x = fmaf(xv[q].x, wj[q], s.x); s.y = fmaf(xv[q].y, wj[q], s.y);
+              s.z = fmaf(xv[q].z, wj[q], s.z); s.w = fmaf(xv[q].w, wj[q], s.w);
+            }
+          }
+        };
+        if constexpr (BIGP) {
+          for (int b = 0; b < NBLK; ++b) block(included[b], 64 * b);
+        } else {
+          block(included[0], 0);
+        }
+        const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * c4);
+        const uint32_t mk = *reinterpret_cast<const uint32_t*>(mskp + 4 * c4);
+        yv.x = (mk & 0xFFu) ? 0.f : y4.x; yv.y = (mk & 0xFF00u) ? 0.f : y4.y;
+        yv.z = (mk & 0xFF0000u) ? 0.f : y4.z; yv.w = (mk & 0xFF000000u) ? 0.f : y4.w;
+      }
+      *reinterpret_cast<float4*>(xww + 4 * c4) = s;
+      *reinterpret_cast<float4*>(residw + 4 * c4) = make_float4(yv.x - s.x, yv.y - s.y, yv.z - s.z, yv.w - s.w);
+    }
+  };
+
+  auto xw_range = [&](int lo, int hi) {
+    if constexpr (BIGP) xw_range_big(lo, hi);
+    else xw_range_small(lo, hi);
+  };
+
   // ---- helper workgroup: its share of phases (1), (3), (4); with eight workgroups the fifth also
   // prepares the next iteration's regression matrix; the first Gd take part in the draw below
-  const bool sweeper = role > 0 && role == sweep_role && P > 16;
+  const bool sweeper = !BIGP && role > 0 && role == sweep_role && P > 16;
   Prof prof;
   // phase budget: main's phases from chain 0's main workgroup, the draw's from its first DK worker
   prof.start(g.prof, g.prof != nullptr && tid == 0 && chain_id == 0 && (role == 0 || role == dw0));
@@ -748,9 +894,9 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       cl_wait(csync + CL_SCALES, 1, it + 1, tid);
       WideScal se;
       se.so = 0.f; se.H = 0.f;
-      se.sl = cw[59]; se.ql = se.sl * se.sl;
-      se.ss = cw[60]; se.qs = se.ss * se.ss;
-      se.sdn = cw[61] * (1.0f / (float)NS); se.qd = se.sdn * se.sdn;
+      se.sl = cw[CW0 + 3]; se.ql = se.sl * se.sl;
+      se.ss = cw[CW0 + 4]; se.qs = se.ss * se.ss;
+      se.sdn = cw[CW0 + 5] * (1.0f / (float)NS); se.qd = se.sdn * se.sdn;
       if (dk_lds) wide_dk_quad<TR, NS, true>(se, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, true, false);
       else wide_dk_quad<TR, NS, false>(se, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, true, false);
     }
@@ -764,7 +910,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     if (sweeper && it + 1 < n_iter) {
       // iteration it + 1 sweeps Omega s2 + X'X on the features that are in now, s2 this
       // iteration's observation-noise variance: both are in the message just received
-      const double so_d = *reinterpret_cast<const double*>(cw + 56);
+      const double so_d = *reinterpret_cast<const double*>(cw + CW0);
       const bool all_in = sp.nonzero_prob >= 1.0;
       const unsigned long long nzmask = __ballot(lane < P && (all_in || R.w[lane < P ? lane : 0] != 0.f));
       presweep_block(R, P, so_d * so_d, nzmask, false, tid);
@@ -799,10 +945,11 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     if (t + 1 < T && c) nch += 1.f;
     levw[t] = 0.f; slpw[t] = 0.f; seaw[t] = 0.f; xww[t] = 0.f; residw[t] = 0.f; tgw[t] = 0.f;
   }
-  for (int e = tid; e < P * P; e += NT) {
-    R.xtx[e] = g.xtx[(size_t)series * P * P + e];
-    R.omega[e] = g.omega[(size_t)series * P * P + e];
-  }
+  if constexpr (!BIGP)
+    for (int e = tid; e < P * P; e += NT) {
+      R.xtx[e] = g.xtx[(size_t)series * P * P + e];
+      R.omega[e] = g.omega[(size_t)series * P * P + e];
+    }
   if (tid < 16 || tid < P) R.w[tid] = 0.f;
   {
     const float s = wave_sum_dpp(nch);
@@ -822,10 +969,10 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       if (!dk_worker) continue;
       // a DK worker: every share of X w / the residual is in, the scales came with the weights
       cl_wait(csync + CL_XW, G, it + 1, tid);
-      sc.so = cw[58]; sc.H = sc.so * sc.so;
-      sc.sl = cw[59]; sc.ql = sc.sl * sc.sl;
-      sc.ss = cw[60]; sc.qs = sc.ss * sc.ss;
-      sc.sdn = cw[61] * (1.0f / (float)NS); sc.qd = sc.sdn * sc.sdn;
+      sc.so = cw[CW0 + 2]; sc.H = sc.so * sc.so;
+      sc.sl = cw[CW0 + 3]; sc.ql = sc.sl * sc.sl;
+      sc.ss = cw[CW0 + 4]; sc.qs = sc.ss * sc.ss;
+      sc.sdn = cw[CW0 + 5] * (1.0f / (float)NS); sc.qd = sc.sdn * sc.sdn;
     } else {
     // ---- (1) targets, y'y, X~'targets (time interleaved over threads: coalesced)
     if (it > 0) dk_stats<TR, NS>(dkx, cbp, T, Lc, tid, ssl, sss, ssd);
@@ -895,7 +1042,14 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       // X~'targets and y'y: wave w adds its quarter of the (segment, wave) partials in order; the
       // serial section adds the four quarters -- a fixed tree, whatever the cluster size
       const int ne = nseg * NW, e0 = ne * wave / NW, e1 = ne * (wave + 1) / NW;
-      if (lane <= P) {
+      if constexpr (BIGP) {
+        for (int j = lane; j <= P; j += 64) {
+          const int src = j < P ? j : RS - 4;
+          double sq = 0.0;
+          for (int e = e0; e < e1; ++e) sq += (double)cpart[(size_t)e * RS + src];
+          gsum[wave * GS + j] = sq;
+        }
+      } else if (lane <= P) {
         const int src = lane < P ? lane : RS - 4;
         double sq = 0.0;
         for (int e = e0; e < e1; ++e) sq += (double)cpart[(size_t)e * RS + src];
@@ -912,7 +1066,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         double s = 0.0;
         if (vec4 && j <= P) {
 #pragma unroll
-          for (int w = 0; w < NW; ++w) s += gsum[w * 64 + j];
+          for (int w = 0; w < NW; ++w) s += gsum[w * GS + j];
         } else {
 #pragma unroll
           for (int w = 0; w < NW; ++w) s += (double)red[w * RS + src];
@@ -951,7 +1105,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       }
       if (early_a && it < n_iter && lane == 0) {
         // the DK workers start the draw's prior simulation on these while the regression is drawn
-        cw[59] = (float)level_scale; cw[60] = (float)slope_scale; cw[61] = (float)drift;
+        cw[CW0 + 3] = (float)level_scale; cw[CW0 + 4] = (float)slope_scale; cw[CW0 + 5] = (float)drift;
         if (light) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __hip_atomic_store(csync + CL_SCALES, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -978,7 +1132,24 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       }
     }
     __syncthreads();
-    if (P > 16 && it < n_iter) {
+    if constexpr (BIGP) {
+      if (it < n_iter) {
+        // 53+ columns: spike_slab_draw_big_wg (ci_bigp.h) by this workgroup -- the packed swept matrix,
+        // its (i, j) table and the row buffers in LDS, the swept prior block too when it fits
+        typedef CI_GLB double* GD;
+        CI_LDS double* Al = (CI_LDS double*)(smem + lay.aug0);
+        CI_LDS unsigned* ijt = (CI_LDS unsigned*)(smem + lay.ijtab);
+        CI_LDS double* trow = (CI_LDS double*)(smem + lay.trow);
+        if (lay.pm_lds)
+          obs_scale = spike_slab_draw_big_wg<NT>(R, Al, (CI_LDS double*)(smem + lay.pri0), trow, ijt, R.w, P, sp, st[0],
+                                                 st[1], rng, (uint32_t)it, tid, it == 0, prof, 9, 11);
+        else
+          obs_scale = spike_slab_draw_big_wg<NT>(R, Al, (GD)cv, trow, ijt, R.w, P, sp, st[0], st[1], rng,
+                                                 (uint32_t)it, tid, it == 0, prof, 9, 11);
+        if (tid == 0) scal[0] = (float)obs_scale;
+        __syncthreads();
+      }
+    } else if (P > 16 && it < n_iter) {
       // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
       prof.tick(9);
       const bool prepared = sweep_role > 0 && it > 0;      // a helper of the cluster swept the matrix
@@ -996,8 +1167,8 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       if (tid < P) cw[tid] = R.w[tid];
       if (tid == 0) {
         cw[P] = scal[1];
-        *reinterpret_cast<double*>(cw + 56) = obs_scale;
-        cw[58] = scal[0]; cw[59] = scal[2]; cw[60] = scal[3]; cw[61] = scal[4];    // the DK workers' scales
+        *reinterpret_cast<double*>(cw + CW0) = obs_scale;
+        cw[CW0 + 2] = scal[0]; cw[CW0 + 3] = scal[2]; cw[CW0 + 4] = scal[3]; cw[CW0 + 5] = scal[4];    // the DK workers' scales
       }
       cl_publish(csync + CL_WEIGHTS, it + 1, tid, light);
     }
@@ -1076,7 +1247,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         const double g_drf = gamma_wave(ss.drift_conc + 0.5 * n_changes, rng, pit, SITE_DRIFT_SCALE, 0, lane);
         const double g_obn = gamma_wave(sp.obs_conc + 0.5 * sp.n_obs, rng, pit + 1u, SITE_OBSVAR, 0, lane);
         if (lane == 0) { st[2] = g_lev; st[3] = g_slp; st[4] = g_drf; st[5] = g_obn; }
-      } else if (wave == 1 && P > 16) {
+      } else if (!BIGP && wave == 1 && P > 16) {
         block_randoms_store(block_randoms(rng, (uint32_t)it + 1u, P, lane), bpre, lane);
       }
     }

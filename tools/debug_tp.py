@@ -42,8 +42,8 @@ def run(T, p, slope, seasons, flags, S=3, W=0, C=1, oracle=True, label="", prof=
              "fwd intra", "fwd barrier", "fwd cluster"]
     line += "\n      cycles/iter: " + "  ".join(f"{n}: {cyc[20 + i] / (W + S):.0f}" for i, n in enumerate(names))
     if spec["P"] > 52:
-      reg = ["build", "sweep-in", "order + proposals + flips", "active set + block", "Cholesky", "solve + weights"]
-      line += "\n      regression draw of the whole workgroup: " + "  ".join(f"{n}: {cyc[8 + i] / (W + S):.0f}" for i, n in enumerate(reg))
+      reg = ["build + sweep-in", "order + proposals + flips", "active set + block", "Cholesky", "solve + weights"]
+      line += "\n      regression draw of the whole workgroup: " + "  ".join(f"{n}: {cyc[9 + i] / (W + S):.0f}" for i, n in enumerate(reg))
   sess.close()
   if oracle:
     w = orc.fit_gibbs(y, mask, X, spec, num_results=S, num_warmup=W, seed=(2, 6))

@@ -260,15 +260,27 @@ __device__ __forceinline__ void tp_cluster_barrier(TpSync& s, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else __threadfence();
   __syncthreads();
+  // (round 6, as dk_barrier of ci_wide_quad.h; tools/bench_cluster_barrier*.hip) The arrival's RESULT
+  // tells the last arriver, and only that workgroup writes the flag the others poll -- on another
+  // cache line (the check-in slots' line, idle once the cluster is assembled): polling the arrival
+  // counter itself made the adds queue behind the polls.  The acquire is ONE wave's L1 invalidate
+  // per workgroup (the vector L1 belongs to the CU): a fence on every wave cost 1.5k cycles more per
+  // barrier at 8 workgroups, 3k at 16.
   if (tid == 0) {
-    if (s.light) (void)__hip_atomic_fetch_add(s.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else (void)__hip_atomic_fetch_add(s.flags, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const int want = s.epoch * s.G;
-    while (__hip_atomic_load(s.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
-      __builtin_amdgcn_s_sleep(1);
+    int* flag = s.flags + TPC_XCC;
+    const int old = s.light ? __hip_atomic_fetch_add(s.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            : __hip_atomic_fetch_add(s.flags, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == s.epoch * s.G) {
+      if (s.light) __hip_atomic_store(flag, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(flag, s.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s.epoch)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("" ::: "memory");
 }
 // Assembling the cluster (ci_wide.h cl_assemble, for up to TP_MAXG workgroups): helpers check in
 // with their XCD id, workgroup 0 claims them and publishes the mode -- 2: all here, one XCD; 1: all

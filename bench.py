@@ -368,9 +368,46 @@ def _other_configs(device):
       sess.close()
     return out
 
+  def capability_routes():
+    """Two routes outside BASELINE's five configs that rounds 5-6 built kernels for: 100 covariates
+    (the BIGP build of the trend + one-block kernel) and the reference's own multi-block test model
+    (causalimpact_lib_test.py:738-752: Seasons 4 / 7 / 6) at cfg4's size."""
+    out = []
+    T, p, W, S, C = 1000, 100, 50, 200, 8
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
+    pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_warmup=W, num_results=S, num_chains=C,
+                              seed=(0, 1), device=device)
+    sess = _native.Session(pb, y[None], mask[None], X[None], None,
+                           _native.make_params([_model.series_params(y, mask, X)]))
+    sess.run()
+    ms = sess.run()
+    out.append({"config": "T=1000, 100 covariates (P=101), LocalLevel + spike-and-slab regression, Gibbs",
+                "kernel": sess.kernel_name(), "chains": C, "kernel_ms": ms,
+                "us_per_gibbs_iteration": ms / (W + S) * 1e3, "samples_per_s": C * S / ms * 1e3,
+                "roofline": _roof(sess.algorithmic_bytes(), ms)})
+    sess.close()
+    seasons = (ci.Seasons(num_seasons=4, num_steps_per_season=(2, 1, 1, 1)), ci.Seasons(num_seasons=7),
+               ci.Seasons(num_seasons=6, num_steps_per_season=((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))
+    T, p, W, S, C = 10000, 50, 12, 100, 8
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 0)
+    y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+    counts, flg = _model.expand_seasons(seasons, T)
+    pb = _native.make_problem(T=T, P=X.shape[1], has_slope=0, num_seasons=counts, num_warmup=W, num_results=S,
+                              num_chains=C, seed=(0, 1), device=device)
+    sess = _native.Session(pb, y[None], mask[None], X[None], flg,
+                           _native.make_params([_model.series_params(y, mask, X, num_seasonal_blocks=3)]))
+    sess.run()
+    ms = sess.run()
+    out.append({"config": "T=10000, 50 covariates + Seasons 4/7/6 (state of 18), Gibbs", "kernel": sess.kernel_name(),
+                "chains": C, "kernel_ms": ms, "us_per_gibbs_iteration": ms / (W + S) * 1e3,
+                "samples_per_s": C * S / ms * 1e3, "roofline": _roof(sess.algorithmic_bytes(), ms)})
+    sess.close()
+    return out
+
   guarded("cfg3", cfg3)
   guarded("cfg4", cfg4)
   guarded("cfg5", cfg5)
+  guarded("capability routes", capability_routes)
   return rows
 
 

@@ -607,8 +607,8 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   uint8_t* cbp = mskp + TP;                               // season-change flags, padded with 0
   float* dkx = (float*)(cbp + TP);                        // exchange region of the draw (wide_dk_floats())
 
-  const DevSeriesParams sp = g.sp[series];
-  const DevSeasonalParams ss = a.ssp[series];
+  const DevSeriesParams& sp = g.sp[series];       // (by reference: a copy holds ~50 scalar registers through the whole kernel)
+  const DevSeasonalParams& ss = a.ssp[series];
   Rng rng{stream_key0(g.seed0, g.series_stream_base, series), stream_key1(g.seed1, g.series_stream_base, series), (uint32_t)(g.chain_offset + chain)};
   const float* yg = g.y + (size_t)series * T;
   const float* Xg = g.Xt + (size_t)series * P * T;

@@ -947,6 +947,7 @@ def test_trend_models_with_more_than_52_covariates_agree_on_their_three_routes()
     (1000, 100, 0, ()),            # the P = 101 case of the round-5 review, trend only
     (600, 70, 1, ((7, 1),)),       # local linear trend + weekly block, 71 columns
     (2048, 139, 0, ()),            # close to the widest design whose matrix and index table fit in LDS
+    (500, 60, 0, ((4, 1),)),       # a four-season block (every block size 2..7 has a BIGP build)
 ])
 def test_wide_kernel_with_more_than_52_columns_matches_the_oracle_and_any_cluster_size(T, p, has_slope, seasons):
   """The BIGP builds of ci_wide.h: per draw against the float64 oracle, and the same bits from one

@@ -37,10 +37,11 @@ extern "C" void* ci_gibbs_seasonal_tp_fn_nq8(void);
 extern "C" void ci_launch_seq_score(const ci::SeqScoreArgs*, int, hipStream_t);
 extern "C" void ci_launch_hmc_seq(const ci::HmcSeqArgs*, int, hipStream_t);
 extern "C" void ci_launch_gibbs64(const ci::G64Args*, int, size_t, int, hipStream_t);
-extern "C" void* ci_gibbs_wide_bigp_fn_tr1_ns2(void);
-extern "C" void* ci_gibbs_wide_bigp_fn_tr2_ns2(void);
-extern "C" void* ci_gibbs_wide_bigp_fn_tr1_ns7(void);
-extern "C" void* ci_gibbs_wide_bigp_fn_tr2_ns7(void);
+#define CI_WIDEBIG_DECL(NS)                                    \
+  extern "C" void* ci_gibbs_wide_bigp_fn_tr1_ns##NS(void);     \
+  extern "C" void* ci_gibbs_wide_bigp_fn_tr2_ns##NS(void);
+CI_WIDEBIG_DECL(2) CI_WIDEBIG_DECL(3) CI_WIDEBIG_DECL(4) CI_WIDEBIG_DECL(5) CI_WIDEBIG_DECL(6) CI_WIDEBIG_DECL(7)
+#undef CI_WIDEBIG_DECL
 #define CI_WIDE_DECL(NS)                                  \
   extern "C" void* ci_gibbs_wide_fn_tr1_ns##NS(void);     \
   extern "C" void* ci_gibbs_wide_fn_tr2_ns##NS(void);     \
@@ -362,17 +363,19 @@ void* pick_wide_kernel(int has_slope, int num_seasons) {
   return nullptr;
 }
 // ... and its BIGP builds (53+ design columns): trend-only models (through the inert 2-season block)
-// and trend + a weekly block, while the packed regression matrix and its index table fit in LDS
+// and trend + one block of 2-7 seasons, while the packed regression matrix and its index table fit in LDS
 // (P <= ~150); wider designs, other block lists and very short series keep the general routes.
 void* pick_wide_bigp_kernel(int has_slope, int num_seasons) {
-  if (num_seasons == 2) return has_slope ? ci_gibbs_wide_bigp_fn_tr2_ns2() : ci_gibbs_wide_bigp_fn_tr1_ns2();
-  if (num_seasons == 7) return has_slope ? ci_gibbs_wide_bigp_fn_tr2_ns7() : ci_gibbs_wide_bigp_fn_tr1_ns7();
+#define CI_WIDEBIG_CASE(NS) \
+  if (num_seasons == NS) return has_slope ? ci_gibbs_wide_bigp_fn_tr2_ns##NS() : ci_gibbs_wide_bigp_fn_tr1_ns##NS();
+  CI_WIDEBIG_CASE(2) CI_WIDEBIG_CASE(3) CI_WIDEBIG_CASE(4) CI_WIDEBIG_CASE(5) CI_WIDEBIG_CASE(6) CI_WIDEBIG_CASE(7)
+#undef CI_WIDEBIG_CASE
   return nullptr;
 }
 bool wide_bigp_ok(const ci_problem* pb) {
   if (pb->P <= ci::MAXP || pb->T < 64) return false;
   if (pb->flags & (CI_FLAG_SEQUENTIAL_SEASONAL | CI_FLAG_CLUSTER_SEASONAL | CI_FLAG_SEASONAL_WORKSPACE)) return false;
-  if (!(pb->num_blocks == 0 || (pb->num_blocks == 1 && (pb->num_seasons[0] == 2 || pb->num_seasons[0] == 7))))
+  if (!(pb->num_blocks == 0 || (pb->num_blocks == 1 && pb->num_seasons[0] >= 2 && pb->num_seasons[0] <= 7)))
     return false;
   const int d = (pb->has_slope ? 2 : 1) + (pb->num_blocks == 1 ? pb->num_seasons[0] - 1 : 1);
   return ci::make_wlayout(pb->P, d).total <= 160 * 1024 - 512;

@@ -107,23 +107,24 @@ __device__ __noinline__ double spike_slab_draw_big_wg(const RegLds& R, PA A, PP 
   // every walk below: four entries per thread in flight; body(e, i, j) after the loads of `pre`
   // (the table-or-not choice is made OUTSIDE the loop: inside it every table read was followed by its
   // own wait and a branch)
+  constexpr int FE_U = 8;      // entries per thread in flight (4: 6.3k cycles per sweep at P = 101)
   auto for_entries_t = [&](auto tab, int E, auto pre, auto body) {
-    for (int e0 = tid; e0 < E; e0 += 4 * NTH) {
-      int ii[4], jj[4];
+    for (int e0 = tid; e0 < E; e0 += FE_U * NTH) {
+      int ii[FE_U], jj[FE_U];
       if constexpr (decltype(tab)::value) {
-        unsigned v[4];
+        unsigned v[FE_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ijtab[e0 + u * NTH < E ? e0 + u * NTH : E - 1];
+        for (int u = 0; u < FE_U; ++u) v[u] = ijtab[e0 + u * NTH < E ? e0 + u * NTH : E - 1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { ii[u] = (int)(v[u] & 0xFFFFu); jj[u] = (int)(v[u] >> 16); }
+        for (int u = 0; u < FE_U; ++u) { ii[u] = (int)(v[u] & 0xFFFFu); jj[u] = (int)(v[u] >> 16); }
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ij_of(e0 + u * NTH < E ? e0 + u * NTH : E - 1, ii[u], jj[u]);
+        for (int u = 0; u < FE_U; ++u) ij_of(e0 + u * NTH < E ? e0 + u * NTH : E - 1, ii[u], jj[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) pre(u, e0 + u * NTH < E ? e0 + u * NTH : E - 1, ii[u], jj[u]);
+      for (int u = 0; u < FE_U; ++u) pre(u, e0 + u * NTH < E ? e0 + u * NTH : E - 1, ii[u], jj[u]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < FE_U; ++u)
         if (e0 + u * NTH < E) body(u, e0 + u * NTH, ii[u], jj[u]);
     }
   };
@@ -133,7 +134,7 @@ __device__ __noinline__ double spike_slab_draw_big_wg(const RegLds& R, PA A, PP 
   };
   if (ijtab) bp_barrier();
   {
-    double om[4], xx[4];
+    double om[FE_U], xx[FE_U];
     for_entries(EA,
                 [&](int u, int, int i, int j) {
                   const int ic = i < P ? i : P - 1, jc = j < P ? j : P - 1;
@@ -155,7 +156,7 @@ __device__ __noinline__ double spike_slab_draw_big_wg(const RegLds& R, PA A, PP 
   // the pivot row / column (m entries, disjoint from what the flat loop writes) by thread j.
   auto sweep_one_wg = [&](auto M, int m, int E, CI_LDS const double* t, CI_LDS const double* tr, int k, double sgn) {
     const double rd = 1.0 / t[k];
-    double mv[4], ti[4], tj[4];
+    double mv[FE_U], ti[FE_U], tj[FE_U];
     for_entries(E,
                 [&](int u, int e, int i, int j) { mv[u] = M[e]; ti[u] = tr[i]; tj[u] = t[j]; },
                 [&](int u, int e, int i, int j) {

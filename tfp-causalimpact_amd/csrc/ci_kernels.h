@@ -2598,8 +2598,10 @@ static __device__ __forceinline__ void serial_section(SerialCtx* cx, const RegLd
       if (P > 16 && P + 1 <= 32) {
         // 17-31 columns: the tiles of the sweep-in fit this wavefront, which draws alone while the
         // other waves emit and generate normals
+        Prof* pp = nullptr;                      // (instrumented build: the draw's four phases, slots 9-12)
+        if constexpr (std::is_same<PF, Prof>::value) pp = &prof;
         obs_scale = spike_slab_draw_block<true>(R, P, cx->sp, obs_scale, g_obs, cx->rng, (uint32_t)it, lane,
-                                                it == 0, nullptr, false, nullptr, 4,
+                                                it == 0, pp, false, nullptr, 9,
                                                 block_st + 4 + BLOCK_PRE_DOUBLES * (it & 1));
       } else if (P > 16) {     // drawn by the whole workgroup right after this section
         if (lane == 0) { block_st[0] = obs_scale; block_st[1] = g_obs; }

@@ -1,6 +1,6 @@
 // ci_wide_bigp.hip -- the BIGP build (53+ design columns) of the time-parallel trend + one-block Gibbs
-// kernel, one (TR, NS) instantiation per object file.  Compile with -DCI_TR=<1|2> -DCI_NS=<2|7>
-// (NS = 2: trend-only models through the inert block; NS = 7: a weekly block).
+// kernel, one (TR, NS) instantiation per object file.  Compile with -DCI_TR=<1|2> -DCI_NS=<2..7>
+// (NS = 2 also carries trend-only models, through the inert block).
 #include <hip/hip_runtime.h>
 
 #define CI_SEASONAL_DECL_ONLY

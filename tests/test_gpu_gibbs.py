@@ -986,3 +986,43 @@ def test_wide_kernel_with_more_than_52_columns_matches_the_oracle_and_any_cluste
   np.testing.assert_allclose(one["posterior_trajectories"][0, 0], w["trajectories"], atol=1e-2)
   if seasons:
     np.testing.assert_allclose(one["seasonal_levels"][0, 0], w["seasonal"], atol=5e-3)
+
+
+def test_wide_kernel_with_more_than_52_columns_on_a_ragged_batch():
+  """BIGP builds off the beaten path: a length that is no multiple of 4 (no clusters, scalar reads),
+  53 columns (the first width beyond the LDS block), the first observation missing, and a batch of
+  three series x two chains whose series reproduce their single-series launches bit for bit; per
+  draw against the oracle."""
+  T, p, B, C, S = 1001, 52, 3, 2, 3
+  ys, masks, Xs, specs = [], [], [], []
+  for b in range(B):
+    y, mask, X, _ = syn.make_sampler_inputs(T, p, 40 + b)
+    mask = mask.copy()
+    mask[0] = True
+    mask[[17, 500]] = True
+    ys.append(y); masks.append(mask); Xs.append(X)
+    specs.append(orc.default_spec(y, mask, X, has_slope=True))
+  P = specs[0]["P"]
+  assert P == 53
+  kw = dict(T=T, P=P, has_slope=1, num_warmup=0, num_results=S, num_chains=C, seed=(3, 1))
+  sess = _native.Session(_native.make_problem(num_series=B, **kw), np.stack(ys), np.stack(masks), np.stack(Xs), None,
+                         _native.make_params(specs))
+  assert "bigp" in sess.kernel_name()
+  sess.run()
+  batch = sess.fetch()
+  sess.close()
+  for b in range(B):
+    one_s = _native.Session(_native.make_problem(num_series=1, series_offset=b, **kw), ys[b][None], masks[b][None],
+                            Xs[b][None], None, _native.make_params([specs[b]]))
+    one_s.run()
+    one = one_s.fetch()
+    one_s.close()
+    for k in ("level", "slope", "weights", "observation_noise_scale", "posterior_trajectories"):
+      np.testing.assert_array_equal(batch[k][b], one[k][0], err_msg=f"{k} series {b}")
+  # (series 0 of a batch draws from the plain single-series streams: the oracle's)
+  w = orc.fit_gibbs(ys[0], masks[0], Xs[0], specs[0], num_results=S, num_warmup=0, seed=(3, 1), chain=1)
+  np.testing.assert_array_equal(batch["weights"][0, 1] != 0, w["weights"] != 0)
+  np.testing.assert_allclose(batch["level"][0, 1], w["level"], atol=5e-3)
+  np.testing.assert_allclose(batch["slope"][0, 1], w["slope"], atol=5e-3)
+  np.testing.assert_allclose(batch["weights"][0, 1], w["weights"], atol=5e-3)
+  np.testing.assert_allclose(batch["posterior_trajectories"][0, 1], w["trajectories"], atol=1e-2)

@@ -81,8 +81,11 @@ typedef struct ci_problem {
   int32_t reserved;             /* 0 */
 } ci_problem;
 
-/* Seasonal models: use the one-wavefront-per-chain sequential kernel even where the
- * time-parallel kernel (one seasonal block, state dim <= 8) applies.  Test/diagnostic knob. */
+/* Seasonal models (and any model with more than 52 design columns): use the one-wavefront-per-chain
+ * sequential kernel even where a time-parallel kernel applies.  The route of a fit is otherwise a
+ * function of the model and the series alone -- never of the launch size or the device -- so this
+ * flag must be given to a batch and to the single-series fit it is compared with alike.  Higher
+ * throughput for batches of hundreds of short multi-block series; test / diagnostic knob. */
 #define CI_FLAG_SEQUENTIAL_SEASONAL 1
 /* Batches: every series consumes the random streams of series 0 (series b of the batch then
  * reproduces a single-series fit of series b draw for draw; Monte-Carlo errors are perfectly
@@ -97,8 +100,9 @@ typedef struct ci_problem {
  * they would fit in LDS (the library does so by itself for long series / many covariates).
  * Test / diagnostic knob. */
 #define CI_FLAG_SEASONAL_WORKSPACE 8
-/* Time-parallel seasonal kernel: one workgroup per chain even where the library would spread a
- * chain's time-independent phases over a cluster of 2, 4 or 8 CUs (few chains of a long series).
+/* Time-parallel kernels: one workgroup per chain even where the library would spread a chain over a
+ * cluster of 2, 4, 8 or 16 CUs (csrc/ci_wide.h: the Durbin-Koopman draw on up to eight of them, the
+ * streaming phases on all; csrc/ci_seasonal_tp.h: up to 32) because the launch leaves CUs idle.
  * Every cluster size gives the same bits; test / diagnostic knob. */
 #define CI_FLAG_NO_CLUSTER 16
 /* Test knob: the last workgroup of every cluster exits at once, as if it had never been
@@ -107,9 +111,9 @@ typedef struct ci_problem {
 #define CI_FLAG_TEST_DROP_HELPER 32
 /* Seasonal models: take the wave-cooperative time-parallel kernel (csrc/ci_seasonal_tp.h: chunks of
  * the series on the wavefronts of a cluster of up to 32 workgroups of 4 wavefronts, any block list with a state of at
- * most 32 components) even for "trend + one block of 2-7 seasons", which by default runs on the
- * thread-per-chunk kernel of csrc/ci_wide.h.  Few chains of a long series leave most of the GPU
- * idle: there the cluster kernel is the faster one (profiles/). */
+ * most 32 components) even for "trend + one block of 2-7 seasons" and for trend models with 53+
+ * design columns, which by default run on the quad-split kernel of csrc/ci_wide.h (the faster one
+ * since round 6: profiles/).  Test / diagnostic knob. */
 #define CI_FLAG_CLUSTER_SEASONAL 64
 
 /* Caller-allocated result buffers (float32, chain-major so per-device shards

@@ -663,6 +663,10 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   dk.p1s = (float)(sp.init_slope_scale * sp.init_slope_scale);
   dk.p1e = (float)(ss.init_seasonal_scale * ss.init_seasonal_scale);
 
+  const bool sweeper = !BIGP && role > 0 && role == sweep_role && P > 16;
+  Prof prof;
+  // phase budget: main's phases from chain 0's main workgroup, the draw's from its first DK worker
+  prof.start(g.prof, g.prof != nullptr && tid == 0 && chain_id == 0 && (role == 0 || role == dw0));
   // (1) targets y - level - seasonal of segments `sa` and `sb` (NT chunks of 4 steps each; sb may be
   // >= nseg: nothing), their squares and X~'targets: four wave partials per column and segment, to
   // cpart[seg][wave][.].  Two segments per pass keep 2 x XR 16-byte loads in flight per thread (one
@@ -725,9 +729,61 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       if (two) outb[wave * RS + RS - 4] = wb;
     }
   };
+  // One segment alone (a role's odd one out -- with sixteen workgroups and ten segments EVERY role's):
+  // the same sums as above (same expressions, same reduction tree: same bits) without the idle second
+  // lane of work -- its sixteen wave reductions per pass were half of this phase's instructions
+  // (28k cycles per iteration on the draw's workers) -- and with the next pass's rows requested
+  // before this pass's are reduced.
+  auto segment_single_sums = [&](int sa) {
+    const int c4 = sa * NT + tid;
+    const bool ha = c4 < n4;
+    const int ca = ha ? c4 : 0;
+    float4 tg;
+    {
+      const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * ca);
+      const float4 l4 = *reinterpret_cast<const float4*>(levw + 4 * ca);
+      const float4 s4 = *reinterpret_cast<const float4*>(seaw + 4 * ca);
+      const uint32_t mk = ha ? *reinterpret_cast<const uint32_t*>(mskp + 4 * ca) : 0xFFFFFFFFu;
+      tg.x = (mk & 0xFFu) ? 0.f : y4.x - l4.x - s4.x;
+      tg.y = (mk & 0xFF00u) ? 0.f : y4.y - l4.y - s4.y;
+      tg.z = (mk & 0xFF0000u) ? 0.f : y4.z - l4.z - s4.z;
+      tg.w = (mk & 0xFF000000u) ? 0.f : y4.w - l4.w - s4.w;
+    }
+    float ya = 0.f;
+    ya = fmaf(tg.x, tg.x, ya); ya = fmaf(tg.y, tg.y, ya);
+    ya = fmaf(tg.z, tg.z, ya); ya = fmaf(tg.w, tg.w, ya);
+    float* outa = cpart + (size_t)sa * NW * RS;
+    constexpr int XS = 8;           // rows per pass (two passes' rows are live at once)
+    float4 xn[XS];
+#pragma unroll
+    for (int q = 0; q < XS; ++q) xn[q] = *reinterpret_cast<const float4*>(Xg + (size_t)(q < P ? q : P - 1) * T + 4 * ca);
+    for (int j0 = 0; j0 < P; j0 += XS) {
+      float4 xv[XS];
+#pragma unroll
+      for (int q = 0; q < XS; ++q) xv[q] = xn[q];
+      if (j0 + XS < P) {
+#pragma unroll
+        for (int q = 0; q < XS; ++q) {
+          const int j = j0 + XS + q < P ? j0 + XS + q : P - 1;
+          xn[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * ca);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < XS; ++q) {
+        const float pa = xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
+        const float wa = wave_sum_dpp(pa);
+        if (lane == 0 && j0 + q < P) outa[wave * RS + j0 + q] = wa;
+      }
+    }
+    const float wa = wave_sum_dpp(ya);
+    if (lane == 0) outa[wave * RS + RS - 4] = wa;
+  };
   // the segments of one role: role, role + G, ... taken two at a time
   auto role_segment_sums = [&]() {
-    for (int sa = role; sa < nseg; sa += 2 * G) segment_pair_sums(sa, sa + G);
+    for (int sa = role; sa < nseg; sa += 2 * G) {
+      if (sa + G < nseg) segment_pair_sums(sa, sa + G);
+      else segment_single_sums(sa);
+    }
   };
 
   // (3) latents and posterior-predictive trajectory of iteration it - 1, chunks [lo, hi)
@@ -881,14 +937,12 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
 
   // ---- helper workgroup: its share of phases (1), (3), (4); with eight workgroups the fifth also
   // prepares the next iteration's regression matrix; the first Gd take part in the draw below
-  const bool sweeper = !BIGP && role > 0 && role == sweep_role && P > 16;
-  Prof prof;
-  // phase budget: main's phases from chain 0's main workgroup, the draw's from its first DK worker
-  prof.start(g.prof, g.prof != nullptr && tid == 0 && chain_id == 0 && (role == 0 || role == dw0));
   auto helper_iteration = [&](int it) {
     cl_wait(csync + CL_LATENTS, 1, it + 1, tid);
+    prof.tick(19);
     role_segment_sums();
     cl_publish(csync + CL_PARTIAL + role, it + 1, tid, light);
+    prof.tick(8);       // (DK worker's budget) its segments of X'targets
     if (early_a && dk_worker && it < n_iter) {
       // the prior simulation of this iteration's draw, as soon as main has drawn the scales
       cl_wait(csync + CL_SCALES, 1, it + 1, tid);
@@ -901,12 +955,15 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       else wide_dk_quad<TR, NS, false>(se, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, true, false);
     }
     cl_wait(csync + CL_WEIGHTS, 1, it + 1, tid);
+    prof.tick(14);      // ... waiting for main's serial section (scales, regression draw)
     if (tid < P) R.w[tid] = cw[tid];
     const float so = cw[P];
     __syncthreads();
     if (it > g.W) emit_range(it, so, clo, chi);
+    prof.tick(15);      // ... its share of the emission
     if (it < n_iter) xw_range(clo, chi);
     cl_publish(csync + CL_XW + role, it + 1, tid, light);
+    prof.tick(13);      // ... its share of X w
     if (sweeper && it + 1 < n_iter) {
       // iteration it + 1 sweeps Omega s2 + X'X on the features that are in now, s2 this
       // iteration's observation-noise variance: both are in the message just received

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     prof.tick(19);
     role_segment_sums();
     cl_publish(csync + CL_PARTIAL + role, it + 1, tid, light);
-    prof.tick(8);       // (DK worker's budget) its segments of X'targets
+    if constexpr (!BIGP) prof.tick(8);       // (DK worker's budget) its segments of X'targets
     if (early_a && dk_worker && it < n_iter) {
       // the prior simulation of this iteration's draw, as soon as main has drawn the scales
       cl_wait(csync + CL_SCALES, 1, it + 1, tid);
@@ -955,15 +955,15 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       else wide_dk_quad<TR, NS, false>(se, dk, rng, (uint32_t)it, role - dw0, dsy, tid, prof, true, false);
     }
     cl_wait(csync + CL_WEIGHTS, 1, it + 1, tid);
-    prof.tick(14);      // ... waiting for main's serial section (scales, regression draw)
+    if constexpr (!BIGP) prof.tick(14);      // ... waiting for main's serial section (scales, regression draw; BIGP builds: slots 11-15 are the draw's)
     if (tid < P) R.w[tid] = cw[tid];
     const float so = cw[P];
     __syncthreads();
     if (it > g.W) emit_range(it, so, clo, chi);
-    prof.tick(15);      // ... its share of the emission
+    if constexpr (!BIGP) prof.tick(15);      // ... its share of the emission
     if (it < n_iter) xw_range(clo, chi);
     cl_publish(csync + CL_XW + role, it + 1, tid, light);
-    prof.tick(13);      // ... its share of X w
+    if constexpr (!BIGP) prof.tick(13);      // ... its share of X w
     if (sweeper && it + 1 < n_iter) {
       // iteration it + 1 sweeps Omega s2 + X'X on the features that are in now, s2 this
       // iteration's observation-noise variance: both are in the message just received

@@ -39,7 +39,7 @@ names = {0: "(1) targets, X'targets, sums", 1: "(2) serial + regression block", 
          28: "dk D  forward reconstruction", 29: "dk    end of the draw: arrival", 16: "dk    barrier after A", 17: "dk    barrier after B", 18: "dk    barrier after C",
          19: "(DK worker) waits for the latents flag / other stamps", 8: "(DK worker) its segments of X'targets",
          14: "(DK worker) waits for main's serial section", 15: "(DK worker) its share of the emission",
-         13: "(DK worker) its share of X w", 11: "(DK worker)   X'targets: targets", 12: "(DK worker)   X'targets: rows + sums"}
+         13: "(DK worker) its share of X w"}
 print(f"T={T} P={pb.P} chains={C}: {ms * 1e3 / n:.1f} us per iteration ({ms:.1f} ms per launch)")
 tot = 0
 for k in sorted(names):

@@ -2100,6 +2100,41 @@ __device__ __forceinline__ void presweep_export(const RegLds& R, int P, unsigned
   for (int e = tid; e < nrec; e += NT) dst[n * n + e] = R.chol[e];
 }
 
+// The matrix another workgroup swept ahead (presweep_export: (P + 1)^2 doubles, then the pivot rows of
+// its sweeps) into this workgroup's LDS.  No barrier.
+template <int NTH>
+__device__ __forceinline__ void presweep_import(const RegLds& R, int P, unsigned long long nzmask,
+                                                const double* presweep, int tid) {
+  const int n = P + 1;
+  double* rec = R.chol;
+  const int nrec = __popcll(nzmask) * REC_LD;
+  if (((n * n) & 1) == 0 && (REC_LD & 1) == 0) {
+    // 16 bytes per lane, four loads in flight (the copy is 36 KB from L2 at P = 51: element by
+    // element it was a chain of ~18 dependent round trips)
+    const double2* s2 = reinterpret_cast<const double2*>(presweep);
+    double2* a2 = reinterpret_cast<double2*>(R.aug[0]);
+    double2* r2 = reinterpret_cast<double2*>(rec);
+    const int na2 = (n * n) >> 1, nt2 = na2 + (nrec >> 1);
+    for (int e0 = tid; e0 < nt2; e0 += 4 * NTH) {
+      double2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NTH;
+        v[u] = s2[e < nt2 ? e : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NTH;
+        if (e < na2) a2[e] = v[u];
+        else if (e < nt2) r2[e - na2] = v[u];
+      }
+    }
+  } else {
+    for (int e = tid; e < n * n; e += NTH) R.aug[0][e] = presweep[e];
+    for (int e = tid; e < nrec; e += NTH) rec[e] = presweep[n * n + e];
+  }
+}
+
 // split: the matrix comes from presweep_block -- computed here, or copied from `presweep`
 // ((P + 1)^2 doubles in global memory) when another workgroup prepared it -- and the border is
 // filled by a matrix-vector product instead of being carried through the sweeps (the same
@@ -2163,8 +2198,10 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
                                                         bool first, Prof* prof = nullptr,
                                                         bool split = false,
                                                         const double* presweep = nullptr,
-                                                        int slot0 = 4, const double* pre = nullptr) {
+                                                        int slot0 = 4, const double* pre = nullptr,
+                                                        bool imported = false) {
   // pre (LDS, may be null): this iteration's block_randoms, drawn ahead by another wave
+  // imported: the caller has already copied `presweep` into LDS (presweep_import)
   constexpr int NTH = WAVE ? 64 : NT;          // threads taking part
   auto sync = [] { if constexpr (WAVE) wave_sync(); else __syncthreads(); };
   // a sweep of A and the prior block on pivot k (iteration 0 and accepted flips)
@@ -2226,32 +2263,7 @@ __device__ __forceinline__ double spike_slab_draw_block(const RegLds& R, int P,
     }
   } else {
     if (presweep) {     // the swept matrix, then the pivot rows of its sweeps (presweep_export)
-      const int nrec = __popcll(nzmask) * REC_LD;
-      if (((n * n) & 1) == 0 && (REC_LD & 1) == 0) {
-        // 16 bytes per lane, four loads in flight (the copy is 36 KB from L2 at P = 51: element by
-        // element it was a chain of ~18 dependent round trips)
-        const double2* s2 = reinterpret_cast<const double2*>(presweep);
-        double2* a2 = reinterpret_cast<double2*>(R.aug[0]);
-        double2* r2 = reinterpret_cast<double2*>(rec);
-        const int na2 = (n * n) >> 1, nt2 = na2 + (nrec >> 1);
-        for (int e0 = tid; e0 < nt2; e0 += 4 * NTH) {
-          double2 v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * NTH;
-            v[u] = s2[e < nt2 ? e : 0];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * NTH;
-            if (e < na2) a2[e] = v[u];
-            else if (e < nt2) r2[e - na2] = v[u];
-          }
-        }
-      } else {
-        for (int e = tid; e < n * n; e += NTH) R.aug[0][e] = presweep[e];
-        for (int e = tid; e < nrec; e += NTH) rec[e] = presweep[n * n + e];
-      }
+      if (!imported) presweep_import<NTH>(R, P, nzmask, presweep, tid);
       __syncthreads();
     } else {
       presweep_block(R, P, prev_var, nzmask, first, tid);

@@ -1209,10 +1209,11 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     } else if (P > 16 && it < n_iter) {
       // P > 16: the regression draw with its (P+1)^2 sweeps spread over all four waves
       prof.tick(9);
-      const bool prepared = sweep_role > 0 && it > 0;      // a helper of the cluster swept the matrix
-      if (prepared) cl_wait(csync + CL_V, 1, it, tid);
+      // a helper of the cluster swept the matrix, and main copied it into LDS while it waited for
+      // the previous draw (end of the loop body)
+      const bool prepared = sweep_role > 0 && it > 0;
       obs_scale = spike_slab_draw_block(R, P, sp, st[0], st[1], rng, (uint32_t)it, tid, it == 0, &prof,
-                                        true, prepared ? cv : nullptr, 4, it > 0 ? bpre : nullptr);
+                                        true, prepared ? cv : nullptr, 4, it > 0 ? bpre : nullptr, prepared);
       if (tid == 0) scal[0] = (float)obs_scale;
       __syncthreads();
       prof.tick(10);
@@ -1306,6 +1307,16 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
         if (lane == 0) { st[2] = g_lev; st[3] = g_slp; st[4] = g_drf; st[5] = g_obn; }
       } else if (!BIGP && wave == 1 && P > 16) {
         block_randoms_store(block_randoms(rng, (uint32_t)it + 1u, P, lane), bpre, lane);
+      }
+    }
+    if constexpr (!BIGP) {
+      if (role == 0 && sweep_role > 0 && P > 16 && it + 1 < n_iter) {
+        // ... and the matrix the sweeper prepared for the next regression draw (36 KB through L2 at
+        // P = 51: 7k cycles of the serial section when copied there)
+        cl_wait(csync + CL_V, 1, it + 1, tid);
+        const bool all_in = sp.nonzero_prob >= 1.0;
+        const unsigned long long nzmask = __ballot(lane < P && (all_in || R.w[lane < P ? lane : 0] != 0.f));
+        presweep_import<NT>(R, P, nzmask, cv, tid);
       }
     }
     if (role == 0 && G > 1) cl_wait(csync + CL_LATENTS, 1, it + 2, tid);

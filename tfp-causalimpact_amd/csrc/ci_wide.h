@@ -667,74 +667,13 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   Prof prof;
   // phase budget: main's phases from chain 0's main workgroup, the draw's from its first DK worker
   prof.start(g.prof, g.prof != nullptr && tid == 0 && chain_id == 0 && (role == 0 || role == dw0));
-  // (1) targets y - level - seasonal of segments `sa` and `sb` (NT chunks of 4 steps each; sb may be
-  // >= nseg: nothing), their squares and X~'targets: four wave partials per column and segment, to
-  // cpart[seg][wave][.].  Two segments per pass keep 2 x XR 16-byte loads in flight per thread (one
-  // wave per SIMD here: memory latency is hidden by bytes in flight, not by occupancy).
-  auto segment_pair_sums = [&](int sa, int sb) {
-    const int c4 = sa * NT + tid, c4b = sb * NT + tid;
-    const bool two = sb < nseg;                                    // uniform
-    const bool ha = c4 < n4, hb = two && c4b < n4;
-    const int ca = ha ? c4 : 0, cb = hb ? c4b : 0;
-    float4 tg, tgb;
-    {
-      const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * ca);
-      const float4 l4 = *reinterpret_cast<const float4*>(levw + 4 * ca);
-      const float4 s4 = *reinterpret_cast<const float4*>(seaw + 4 * ca);
-      const uint32_t mk = ha ? *reinterpret_cast<const uint32_t*>(mskp + 4 * ca) : 0xFFFFFFFFu;
-      tg.x = (mk & 0xFFu) ? 0.f : y4.x - l4.x - s4.x;
-      tg.y = (mk & 0xFF00u) ? 0.f : y4.y - l4.y - s4.y;
-      tg.z = (mk & 0xFF0000u) ? 0.f : y4.z - l4.z - s4.z;
-      tg.w = (mk & 0xFF000000u) ? 0.f : y4.w - l4.w - s4.w;
-    }
-    {
-      const float4 y4 = *reinterpret_cast<const float4*>(yg + 4 * cb);
-      const float4 l4 = *reinterpret_cast<const float4*>(levw + 4 * cb);
-      const float4 s4 = *reinterpret_cast<const float4*>(seaw + 4 * cb);
-      const uint32_t mk = hb ? *reinterpret_cast<const uint32_t*>(mskp + 4 * cb) : 0xFFFFFFFFu;
-      tgb.x = (mk & 0xFFu) ? 0.f : y4.x - l4.x - s4.x;
-      tgb.y = (mk & 0xFF00u) ? 0.f : y4.y - l4.y - s4.y;
-      tgb.z = (mk & 0xFF0000u) ? 0.f : y4.z - l4.z - s4.z;
-      tgb.w = (mk & 0xFF000000u) ? 0.f : y4.w - l4.w - s4.w;
-    }
-    float ya = 0.f, yb = 0.f;
-    ya = fmaf(tg.x, tg.x, ya); ya = fmaf(tg.y, tg.y, ya);
-    ya = fmaf(tg.z, tg.z, ya); ya = fmaf(tg.w, tg.w, ya);
-    yb = fmaf(tgb.x, tgb.x, yb); yb = fmaf(tgb.y, tgb.y, yb);
-    yb = fmaf(tgb.z, tgb.z, yb); yb = fmaf(tgb.w, tgb.w, yb);
-    float* outa = cpart + (size_t)sa * NW * RS;
-    float* outb = cpart + (size_t)(two ? sb : sa) * NW * RS;
-    for (int j0 = 0; j0 < P; j0 += XR) {
-      float4 xv[XR], xb[XR];
-#pragma unroll
-      for (int q = 0; q < XR; ++q) {
-        const int j = j0 + q < P ? j0 + q : P - 1;
-        xv[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * ca);
-        xb[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * cb);
-      }
-#pragma unroll
-      for (int q = 0; q < XR; ++q) {
-        const float pa = xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
-        const float pb = xb[q].x * tgb.x + xb[q].y * tgb.y + xb[q].z * tgb.z + xb[q].w * tgb.w;
-        const float wa = wave_sum_dpp(pa), wb = wave_sum_dpp(pb);
-        if (lane == 0 && j0 + q < P) {
-          outa[wave * RS + j0 + q] = wa;
-          if (two) outb[wave * RS + j0 + q] = wb;
-        }
-      }
-    }
-    const float wa = wave_sum_dpp(ya), wb = wave_sum_dpp(yb);
-    if (lane == 0) {
-      outa[wave * RS + RS - 4] = wa;
-      if (two) outb[wave * RS + RS - 4] = wb;
-    }
-  };
-  // One segment alone (a role's odd one out -- with sixteen workgroups and ten segments EVERY role's):
-  // the same sums as above (same expressions, same reduction tree: same bits) without the idle second
-  // lane of work -- its sixteen wave reductions per pass were half of this phase's instructions
-  // (28k cycles per iteration on the draw's workers) -- and with the next pass's rows requested
-  // before this pass's are reduced.
-  auto segment_single_sums = [&](int sa) {
+  // (1) targets y - level - seasonal of segment `sa` (NT chunks of 4 steps each), their squares (`yy`)
+  // and X~'targets for the columns [jlo, jhi): four wave partials per column and segment, to
+  // cpart[seg][wave][.].  One wave per SIMD here: memory latency is hidden by bytes in flight, not by
+  // occupancy -- the next pass's rows are requested before this pass's are reduced.  (Round 6: the
+  // two-segments-per-pass form this replaces gave a role with ONE segment -- every role of a cluster of
+  // sixteen at cfg4 -- an idle second lane of work whose wave reductions were half of the phase.)
+  auto segment_part_sums = [&](int sa, int jlo, int jhi, bool yy) {
     const int c4 = sa * NT + tid;
     const bool ha = c4 < n4;
     const int ca = ha ? c4 : 0;
@@ -749,22 +688,22 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       tg.z = (mk & 0xFF0000u) ? 0.f : y4.z - l4.z - s4.z;
       tg.w = (mk & 0xFF000000u) ? 0.f : y4.w - l4.w - s4.w;
     }
-    float ya = 0.f;
-    ya = fmaf(tg.x, tg.x, ya); ya = fmaf(tg.y, tg.y, ya);
-    ya = fmaf(tg.z, tg.z, ya); ya = fmaf(tg.w, tg.w, ya);
     float* outa = cpart + (size_t)sa * NW * RS;
     constexpr int XS = 8;           // rows per pass (two passes' rows are live at once)
     float4 xn[XS];
+    if (jlo < jhi) {
 #pragma unroll
-    for (int q = 0; q < XS; ++q) xn[q] = *reinterpret_cast<const float4*>(Xg + (size_t)(q < P ? q : P - 1) * T + 4 * ca);
-    for (int j0 = 0; j0 < P; j0 += XS) {
+      for (int q = 0; q < XS; ++q)
+        xn[q] = *reinterpret_cast<const float4*>(Xg + (size_t)(jlo + q < jhi ? jlo + q : jhi - 1) * T + 4 * ca);
+    }
+    for (int j0 = jlo; j0 < jhi; j0 += XS) {
       float4 xv[XS];
 #pragma unroll
       for (int q = 0; q < XS; ++q) xv[q] = xn[q];
-      if (j0 + XS < P) {
+      if (j0 + XS < jhi) {
 #pragma unroll
         for (int q = 0; q < XS; ++q) {
-          const int j = j0 + XS + q < P ? j0 + XS + q : P - 1;
+          const int j = j0 + XS + q < jhi ? j0 + XS + q : jhi - 1;
           xn[q] = *reinterpret_cast<const float4*>(Xg + (size_t)j * T + 4 * ca);
         }
       }
@@ -772,17 +711,35 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
       for (int q = 0; q < XS; ++q) {
         const float pa = xv[q].x * tg.x + xv[q].y * tg.y + xv[q].z * tg.z + xv[q].w * tg.w;
         const float wa = wave_sum_dpp(pa);
-        if (lane == 0 && j0 + q < P) outa[wave * RS + j0 + q] = wa;
+        if (lane == 0 && j0 + q < jhi) outa[wave * RS + j0 + q] = wa;
       }
     }
-    const float wa = wave_sum_dpp(ya);
-    if (lane == 0) outa[wave * RS + RS - 4] = wa;
+    if (yy) {
+      float ya = 0.f;
+      ya = fmaf(tg.x, tg.x, ya); ya = fmaf(tg.y, tg.y, ya);
+      ya = fmaf(tg.z, tg.z, ya); ya = fmaf(tg.w, tg.w, ya);
+      const float wa = wave_sum_dpp(ya);
+      if (lane == 0) outa[wave * RS + RS - 4] = wa;
+    }
   };
-  // the segments of one role: role, role + G, ... taken two at a time
+  // The work items of one role.  A segment's columns are cut into `ns` parts when that shortens the
+  // longest role (ten segments on sixteen workgroups: three parts, two items of 17 columns per role
+  // instead of one of 51); who sums a (segment, column) pair never changes its value.
   auto role_segment_sums = [&]() {
-    for (int sa = role; sa < nseg; sa += 2 * G) {
-      if (sa + G < nseg) segment_pair_sums(sa, sa + G);
-      else segment_single_sums(sa);
+    int ns = 1;
+    {
+      int best = 0x7fffffff;
+      for (int c = 1; c <= 4; ++c) {
+        const int per_role = (nseg * c + G - 1) / G;
+        const int cost = per_role * ((P + c - 1) / c + 4);       // rows + what loading the targets costs
+        if (cost < best) { best = cost; ns = c; }
+      }
+    }
+    const int fs = (P + ns - 1) / ns;
+    for (int w = role; w < nseg * ns; w += G) {
+      const int sa = w / ns, part = w - sa * ns;
+      const int jlo = part * fs, jhi = (part + 1) * fs < P ? (part + 1) * fs : P;
+      segment_part_sums(sa, jlo < P ? jlo : P, jhi, part == 0);
     }
   };
 

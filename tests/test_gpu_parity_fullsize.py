@@ -250,3 +250,35 @@ def test_general_seasonal_long_run_posterior_matches_oracle_within_one_percent_o
   _compare_paths("general_seasonal", g["posterior_means"][0, CO:],
                  np.stack([c["_pred_mean_path"] for c in ora]),
                  pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))
+
+
+def test_hundred_covariates_long_run_posterior_matches_oracle_within_one_percent_or_mc_error():
+  """T=1000, 100 covariates (P=101) on the BIGP build of the trend + one-block kernel (round 6:
+  csrc/ci_wide.h + ci_bigp.h -- packed triangular sweeps, flat entry loops): W=50, S=350.  256 device
+  chains in one launch against 128 oracle chains (0.55 ms per iteration each; 128 a side are what
+  brings 4 s.e. of sigma_obs below 1 %): device chains 128..255 are independent replicates, device
+  chains 0..127 the oracle's own random streams (float32 latents and float64 regression draw
+  against the float64 oracle over 400 iterations)."""
+  T, p, W, S, C, CO = 1000, 100, 50, 350, 256, 128
+  seed = (5, 2)
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
+  spec = orc.default_spec(y, mask, X)
+  post = slice(int(0.7 * T), T)
+  pb = _native.make_problem(T=T, P=p + 1, has_slope=0, num_warmup=W, num_results=S, num_chains=C, seed=seed)
+  sess = _native.Session(pb, y[None], mask[None], X[None], None, _native.make_params([spec]))
+  assert "bigp" in sess.kernel_name()
+  sess.run()
+  g = sess.fetch(["observation_noise_scale", "level_scale", "slope_scale", "weights",
+                  "posterior_trajectories", "posterior_means"])
+  sess.close()
+  dev = [_chain_summaries(g["observation_noise_scale"][0, c], g["level_scale"][0, c],
+                          g["slope_scale"][0, c], g["weights"][0, c],
+                          g["posterior_trajectories"][0, c][:, post].mean(axis=1),
+                          g["posterior_means"][0, c][post].mean()) for c in range(C)]
+  with concurrent.futures.ProcessPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex:
+    ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
+  _compare("p101", dev[CO:], ora, must_reach_1pct=("sigma_obs.mean",))      # independent replicates
+  same = _compare("p101_same_chains", dev[:CO], ora)                        # drift of the same streams
+  assert abs(same["sigma_obs.mean"]["rel"]) < 2e-3
+  _compare_paths("p101", g["posterior_means"][0, CO:], np.stack([c["_pred_mean_path"] for c in ora]),
+                 pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))

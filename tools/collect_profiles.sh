@@ -61,6 +61,7 @@ timeout 300 python tools/exp_cfg4_routes.py > "$OUT/cfg4_routes.txt" 2>&1
 CI_WIDE_DK_GLOBAL=1 timeout 300 python tools/exp_cfg4_routes.py 2>&1 | head -3 > "$OUT/cfg4_routes_dk_rows_in_l2.txt"
 timeout 300 python tools/exp_seasonal_batch_routes.py > "$OUT/seasonal_batch_routes.txt" 2>&1
 timeout 300 python tools/time_general_seasonal.py > "$OUT/general_seasonal_times.txt" 2>&1
+timeout 300 python tools/time_bigp.py > "$OUT/bigp_phase_cycles.txt" 2>&1
 python tools/kernel_resources.py > "$OUT/kernel_resources.txt" 2>&1
 find "$OUT" -name "*.csv" | wc -l
 tail -1 "$OUT/bench.json" | cut -c1-400

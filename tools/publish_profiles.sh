@@ -42,7 +42,7 @@ cp $SRC/trace_e2e/e2e_kernel_stats.csv $P/${R}_fit_causalimpact_kernel_stats.csv
 grep '^{"metric"' $SRC/bench_force_dist.json | tail -1 > $P/${R}_bench_force_dist_rccl_1rank.json
 (grep -v '^{"metric"' $SRC/bench_force_dist.json; cat $SRC/bench_force_dist.err) > $P/${R}_bench_force_dist_rccl_1rank.log || true
 cp $SRC/comm_tests.txt $P/${R}_two_ranks_on_gpu0_host_transport.txt
-for f in p_scale t_scale phase_cycles_p52 f64_phase_cycles hmc_phase_cycles e2e_host_profile cfg4_routes cfg4_routes_dk_rows_in_l2 seasonal_batch_routes general_seasonal_times kernel_resources; do
+for f in p_scale t_scale phase_cycles_p52 f64_phase_cycles hmc_phase_cycles e2e_host_profile cfg4_routes cfg4_routes_dk_rows_in_l2 seasonal_batch_routes general_seasonal_times kernel_resources bigp_phase_cycles; do
   if [ -f $SRC/$f.txt ]; then cp $SRC/$f.txt $P/${R}_$f.txt; fi
 done
 # round 5: the time-parallel general seasonal kernel

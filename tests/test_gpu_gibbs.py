@@ -1026,3 +1026,28 @@ def test_wide_kernel_with_more_than_52_columns_on_a_ragged_batch():
   np.testing.assert_allclose(batch["slope"][0, 1], w["slope"], atol=5e-3)
   np.testing.assert_allclose(batch["weights"][0, 1], w["weights"], atol=5e-3)
   np.testing.assert_allclose(batch["posterior_trajectories"][0, 1], w["trajectories"], atol=1e-2)
+
+
+def test_cfg4_clusters_equal_one_workgroup_per_chain_over_a_long_run():
+  """BASELINE cfg4's shape (T=10000, 50 covariates, weekly block), 150 iterations, 8 chains: the
+  cluster of sixteen (the draw on eight workgroups with its rows in LDS, the matrix swept ahead and
+  imported during the draw, randomness drawn ahead) against one workgroup per chain, bit for bit in
+  every output -- a hand-off that is wrong once in a thousand iterations shows here."""
+  from causalimpact import _model
+  T, p, seasons, W, S, C = 10000, 50, ((7, 1),), 30, 120, 8
+  y, mask, X, _ = syn.make_sampler_inputs(T, p, 0)
+  y = y + 0.8 * np.sin(2 * np.pi * np.arange(T) / 7.0)
+  spec = orc.default_spec(y, mask, X, has_slope=False, seasons=seasons)
+  counts, flg = _model.expand_seasons(seasons, T)
+  want = ("observation_noise_scale", "level_scale", "seasonal_drift_scales", "weights", "posterior_means")
+  out = {}
+  for flags in (_native.FLAG_NO_CLUSTER, 0):
+    pb = _native.make_problem(T=T, P=spec["P"], has_slope=0, num_seasons=counts, num_warmup=W, num_results=S,
+                              num_chains=C, seed=(9, 9), flags=flags)
+    sess = _native.Session(pb, y[None], mask[None], X[None], flg, _native.make_params([spec]))
+    sess.run()
+    out[flags] = sess.fetch(want)
+    sess.close()
+  for k in want:
+    np.testing.assert_array_equal(out[0][k], out[_native.FLAG_NO_CLUSTER][k], err_msg=k)
+  assert np.isfinite(out[0]["posterior_means"]).all()

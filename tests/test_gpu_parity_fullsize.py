@@ -179,13 +179,15 @@ def test_cfg2_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
 def test_cfg4_long_run_posterior_matches_oracle_within_one_percent_or_mc_error():
   """BASELINE cfg4: T=10000, 50 covariates (P=51) + Seasonal(num_seasons=7), time-parallel
   kernel over its HBM workspace; W=112, S=400 -- NOT the configuration's 1000 draws: the oracle
-  costs ~8 ms per iteration, ~4 s per chain, run in parallel on the host.  32 device chains in one
-  launch against 16 oracle chains (ids 0..15): device chains 16..31 are INDEPENDENT replicates of
-  the oracle's, device chains 0..15 the same random streams (float32-vs-float64 drift of one
-  stream).  sigma_obs must meet 1 % of its value outright; sigma_level (0.004) and sigma_drift
-  (0.001) mix slowly -- their bands are 4 s.e. and are written, as per cent of the value, into
-  the table's `_summary.mc_limited`."""
-  T, p, W, S, C, CO = 10000, 50, 112, 400, 32, 16
+  costs ~4 ms per iteration, ~2 s per chain, run in parallel on the host's cores.  256 device chains
+  in one launch against 128 oracle chains (ids 0..127): device chains 128..255 are INDEPENDENT
+  replicates of the oracle's, device chains 0..127 the same random streams (float32-vs-float64 drift
+  of one stream).  128 chains a side are what brings 4 s.e. of sigma_level (0.004, slowly mixing)
+  below 1 % of its value: sigma_obs AND sigma_level must meet the 1 % figure outright; sigma_drift
+  (0.001) is held to 4 s.e., listed with that band in `_summary.mc_limited`.  (The predictive draws
+  are not downloaded at this chain count -- 4 GB --: the prediction is compared path-wise through
+  `posterior_means`, which is what pins it.)"""
+  T, p, W, S, C, CO = 10000, 50, 112, 400, 256, 128
   seed = (3, 1)
   y, mask, X, _ = syn.make_sampler_inputs(T, p, 7)
   t = np.arange(T)
@@ -198,15 +200,14 @@ def test_cfg4_long_run_posterior_matches_oracle_within_one_percent_or_mc_error()
   sc = np.stack(spec["season_change"])
   g = _native.fit_gibbs(pb, y[None], mask[None], X[None], sc, _native.make_params([spec]),
                         want=("observation_noise_scale", "level_scale", "slope_scale", "weights",
-                              "posterior_trajectories", "posterior_means", "seasonal_drift_scales"))
+                              "posterior_means", "seasonal_drift_scales"))
   dev = [_chain_summaries(g["observation_noise_scale"][0, c], g["level_scale"][0, c],
-                          g["slope_scale"][0, c], g["weights"][0, c],
-                          g["posterior_trajectories"][0, c][:, post].mean(axis=1),
+                          g["slope_scale"][0, c], g["weights"][0, c], np.zeros(S),
                           g["posterior_means"][0, c][post].mean(),
                           g["seasonal_drift_scales"][0, c]) for c in range(C)]
   with concurrent.futures.ProcessPoolExecutor(max_workers=min(CO, os.cpu_count() or 1)) as ex:
     ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
-  _compare("cfg4", dev[CO:], ora, must_reach_1pct=("sigma_obs.mean",))     # independent replicates
+  _compare("cfg4", dev[CO:], ora, must_reach_1pct=("sigma_obs.mean", "sigma_level.mean"))   # independent replicates
   _compare("cfg4_same_chains", dev[:CO], ora)                              # drift of the same streams
   _compare_paths("cfg4", g["posterior_means"][0, CO:], np.stack([c["_pred_mean_path"] for c in ora]),
                  pre_end=int(0.7 * T), outcome_sd=float(np.nanstd(np.where(mask, np.nan, y))))
@@ -216,10 +217,12 @@ def test_general_seasonal_long_run_posterior_matches_oracle_within_one_percent_o
   """The reference's 4+7+6-season model (causalimpact_lib_test.py:738-752) at cfg4's size -- T=10000,
   50 covariates -- on the time-parallel cluster kernel of round 5 (csrc/ci_seasonal_tp.h: 128 chunks
   of 80 steps, wave-cooperative float32 scan elements): W=100, S=300 (the oracle costs ~10 ms per
-  iteration: ~4 s per chain, in parallel on the host).  16 device chains in one launch against 8
-  oracle chains: device chains 8..15 are independent replicates, device chains 0..7 the oracle's
-  own random streams (the float32-vs-float64 drift of one stream over 400 iterations)."""
-  T, p, W, S, C, CO = 10000, 50, 100, 300, 16, 8
+  iteration: ~4 s per chain, in parallel on the host).  192 device chains in one launch (one workgroup
+  per chain at that count) against 96 oracle chains: device chains 96..191 are independent replicates,
+  device chains 0..95 the oracle's own random streams (the float32-vs-float64 drift of one stream over
+  400 iterations).  The predictive draws are not downloaded at this chain count; the prediction is
+  compared path-wise through `posterior_means`."""
+  T, p, W, S, C, CO = 10000, 50, 100, 300, 192, 96
   seed = (3, 1)
   seasons = ((4, (2, 1, 1, 1)), (7, 1), (6, ((2, 2, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1))))
   from causalimpact import _model
@@ -236,16 +239,15 @@ def test_general_seasonal_long_run_posterior_matches_oracle_within_one_percent_o
   assert "gibbs_seasonal_tp_kernel" in sess.kernel_name()
   sess.run()
   g = sess.fetch(["observation_noise_scale", "level_scale", "slope_scale", "weights",
-                  "posterior_trajectories", "posterior_means", "seasonal_drift_scales"])
+                  "posterior_means", "seasonal_drift_scales"])
   sess.close()
   dev = [_chain_summaries(g["observation_noise_scale"][0, c], g["level_scale"][0, c],
-                          g["slope_scale"][0, c], g["weights"][0, c],
-                          g["posterior_trajectories"][0, c][:, post].mean(axis=1),
+                          g["slope_scale"][0, c], g["weights"][0, c], np.zeros(S),
                           g["posterior_means"][0, c][post].mean(),
                           g["seasonal_drift_scales"][0, c]) for c in range(C)]
   with concurrent.futures.ProcessPoolExecutor(max_workers=min(CO, os.cpu_count() or 1)) as ex:
     ora = list(ex.map(_oracle_chain, [(y, mask, X, spec, S, W, seed, c, post) for c in range(CO)]))
-  _compare("general_seasonal", dev[CO:], ora, must_reach_1pct=("sigma_obs.mean",))   # independent replicates
+  _compare("general_seasonal", dev[CO:], ora, must_reach_1pct=("sigma_obs.mean", "sigma_level.mean"))   # independent replicates
   _compare("general_seasonal_same_chains", dev[:CO], ora)                            # drift of the same streams
   _compare_paths("general_seasonal", g["posterior_means"][0, CO:],
                  np.stack([c["_pred_mean_path"] for c in ora]),

@@ -48,7 +48,7 @@ struct SArgs {
   float* ws;                         // time-parallel kernel (ci_wide.h): per-chain HBM workspace
   int Lc;                            //   and steps per thread
   // time-parallel kernel, several workgroups per chain (ci_wide.h "clusters"):
-  int cluster;                       //   workgroups per chain (1, 2, 4 or 8)
+  int cluster;                       //   workgroups per chain (ci_wide.h: 1, 2, 4, 8 or 16; ci_seasonal_tp.h: 1 .. 32)
   int cluster_drop;                  //   test knob: this role exits before checking in (0 = none)
   int dk_lds;                        //   clusters of 16: the DK workers keep the draw's per-step rows in LDS
   int* csync;                        //   [B*C][32] handshake counters, zeroed before the launch

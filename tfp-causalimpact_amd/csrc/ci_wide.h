@@ -633,11 +633,11 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
   if constexpr (BIGP) R.chol = cv + (size_t)P * P;      // (the included block's factor when it has no room in LDS)
   const int clo = (int)((long long)(TP >> 2) * role / G), chi = (int)((long long)(TP >> 2) * (role + 1) / G);
   const int n_iter = g.W + g.S;
-  // The Durbin-Koopman draw runs on the cluster's first Gd workgroups (ci_wide_quad.h); with eight
-  // (sixteen) workgroups the fifth (ninth) one sweeps the next iteration's regression matrix meanwhile.
-  // (measured at 32 chains x 8 workgroups: all eight in the draw and no sweep ahead -- 8 x 1 virtual
-  // workgroup -- beats four in the draw plus the sweeper, 4 x 2 virtual workgroups: the draw is the
-  // longer pole)
+  // The Durbin-Koopman draw runs on Gd workgroups of the cluster (ci_wide_quad.h); with sixteen
+  // workgroups the tenth (role 9) sweeps the next iteration's regression matrix meanwhile, and main
+  // imports it while it waits for the draw.  (Eight workgroups: all eight in the draw and no sweep
+  // ahead -- 8 x 1 virtual workgroup -- measured at 32 chains against four in the draw plus a
+  // sweeper, 4 x 2 virtual workgroups: the draw is the longer pole.)
   const int Gd = G >= DK_V ? DK_V : G;
   const int sweep_role = G == 16 ? 9 : -1;
   // with sixteen workgroups main is NOT a DK worker (roles 1..8 are): the draw's first phase needs the
@@ -892,8 +892,8 @@ __global__ __launch_bounds__(NT) void gibbs_wide_kernel(SArgs a) {
     else xw_range_small(lo, hi);
   };
 
-  // ---- helper workgroup: its share of phases (1), (3), (4); with eight workgroups the fifth also
-  // prepares the next iteration's regression matrix; the first Gd take part in the draw below
+  // ---- helper workgroup: its share of phases (1), (3), (4); the sweeper (sixteen workgroups: role 9)
+  // also prepares the next iteration's regression matrix; the DK workers take part in the draw below
   auto helper_iteration = [&](int it) {
     cl_wait(csync + CL_LATENTS, 1, it + 1, tid);
     prof.tick(19);
